@@ -1,0 +1,100 @@
+/* saugns_amd.h -- C ABI of the MI355X generator backend (libsaugns_amd.so).
+ *
+ * Part 1 is the drop-in boundary: exactly the symbols sau/generator.o exports
+ * in the reference, with the same argument meaning and
+ * error behaviour.  Linking this library ahead of -lsau makes the unchanged
+ * reference host (parser, player) render on the GPU; see INTEGRATION.md.
+ *
+ * Part 2 are extensions around the same hot path: many programs rendered in
+ * lock step (BASELINE config 4), device-resident PCM, wave-table injection,
+ * and a pointer-free program image so that programs can be stored and
+ * rebuilt without the reference parser.
+ *
+ * Plain pointers and sizes only; no C++ or torch types cross this boundary.
+ */
+#ifndef SAUGNS_AMD_H
+#define SAUGNS_AMD_H
+
+#include "sau_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAU_AMD_API __attribute__((visibility("default")))
+
+/* ---- Part 1: drop-in boundary ------------------------------------------- */
+
+typedef struct sauGenerator sauGenerator;
+
+/* replaces sau/generator.h:20-21 (generator.c:200-217).
+ * NULL on failure (no usable GPU, out of memory, graph too large). */
+SAU_AMD_API sauGenerator *sau_create_Generator(const sauProgram *prg, uint32_t srate);
+
+/* replaces sau/generator.h:22 (generator.c:222-228). NULL-safe. */
+SAU_AMD_API void sau_destroy_Generator(sauGenerator *o);
+
+/* replaces sau/generator.h:24-26 (generator.c:905-973): fill buf with
+ * buf_len frames (interleaved L,R when stereo, else (L+R)/2); returns false
+ * once the signal has ended, with *out_len = frames generated this call. */
+SAU_AMD_API bool sauGenerator_run(sauGenerator *o, int16_t *buf, size_t buf_len,
+		bool stereo, size_t *out_len);
+
+/* replaces the definition in sau/generator/noise.h:18-21, which the
+ * reference's parser.o and help.o import. */
+SAU_AMD_API extern const char *const sauNoise_names[SAU_NOISE_NAMED + 1];
+
+/* ---- Part 2: extensions --------------------------------------------------- */
+
+typedef struct sauAmdBatch sauAmdBatch;
+
+/* n independent programs rendered together; stream i renders prgs[i].
+ * Programs are borrowed and must outlive the batch. NULL on failure. */
+SAU_AMD_API sauAmdBatch *sauAmd_create_Batch(const sauProgram *const *prgs, size_t n,
+		uint32_t srate);
+SAU_AMD_API void sauAmd_destroy_Batch(sauAmdBatch *b);
+
+/* Advance every stream by buf_len frames. bufs may be NULL, or hold one host
+ * pointer per stream (entries may be NULL): PCM is copied there; otherwise it
+ * stays on the device. more[i]/out_len[i] (either may be NULL) as
+ * sauGenerator_run for stream i. Returns false on a backend error. */
+SAU_AMD_API bool sauAmd_Batch_run(sauAmdBatch *b, int16_t *const *bufs, size_t buf_len,
+		bool stereo, bool *more, size_t *out_len);
+
+/* Device address of stream i's PCM row of the last run (hipMalloc memory). */
+SAU_AMD_API const int16_t *sauAmd_Batch_device_pcm(sauAmdBatch *b, size_t stream);
+
+/* Wait for all queued device work of the batch. */
+SAU_AMD_API bool sauAmd_Batch_sync(sauAmdBatch *b);
+
+/* Accumulated HIP-event timings of the render / mix kernels since the last
+ * call with reset != 0 (any pointer may be NULL). Enables timing on first use. */
+SAU_AMD_API void sauAmd_Batch_timing(sauAmdBatch *b, double *render_ms, double *mix_ms,
+		uint64_t *render_launches, int reset);
+
+/* The stream the batch launches its kernels on, as a hipStream_t. */
+SAU_AMD_API void *sauAmd_Batch_stream(sauAmdBatch *b);
+
+/* Use these twelve 2048-entry tables (wave-id order) instead of the built-in
+ * ones for generators created afterwards. */
+SAU_AMD_API void sauAmd_set_piluts(const float *tables);
+/* The tables a new generator would use. */
+SAU_AMD_API const float *sauAmd_get_piluts(void);
+
+/* Text of the last error on this thread ("" if none). */
+SAU_AMD_API const char *sauAmd_last_error(void);
+
+/* Number of visible HIP devices; <= 0 when none or HIP is unusable. */
+SAU_AMD_API int sauAmd_device_count(void);
+
+/* Program image: every struct of a sauProgram in one relocatable block.
+ * serialize returns the size needed; nothing is written if cap is smaller. */
+SAU_AMD_API size_t sauAmd_program_serialize(const sauProgram *prg, void *buf, size_t cap);
+/* Rebuild a sauProgram from an image (one allocation; free with _free). */
+SAU_AMD_API sauProgram *sauAmd_program_load(const void *image, size_t len);
+SAU_AMD_API void sauAmd_program_free(sauProgram *prg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAUGNS_AMD_H */

@@ -1,0 +1,7 @@
+"""saugns_amd -- MI355X-native backend for the saugns audio generator hot path.
+
+The product is ``libsaugns_amd.so`` (HIP kernels + C++ host control plane behind
+the reference's C API); this package builds it in-tree and binds it with ctypes.
+"""
+from .api import Batch, Generator, Program, get_piluts, last_error, lib, set_piluts  # noqa: F401
+from .build import build  # noqa: F401

@@ -1,0 +1,44 @@
+"""Build libsaugns_amd.so (host control plane + gfx950 kernels) in-tree."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libsaugns_amd.so")
+SOURCES = ["capi.cpp", "engine.cpp", "plan.cpp", "tables.cpp", "program_io.cpp",
+           "hip_backend.hip"]
+HEADERS = ["engine.h", "hip_backend.h", "sau_dev_math.h", "sau_dev_ops.h",
+           "sau_dev_types.h", "../../include/sau_abi.h", "../../include/saugns_amd.h"]
+# -ffp-contract=off: the arithmetic contract forbids FMA contraction
+FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17",
+         "-Wall", "-fvisibility=hidden", "-fvisibility-inlines-hidden"]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [__file__]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(CSRC, src.rsplit(".", 1)[0] + ".o")
+        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

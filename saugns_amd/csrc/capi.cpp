@@ -1,0 +1,146 @@
+/* capi.cpp -- extern "C" surface of libsaugns_amd.so (include/saugns_amd.h). */
+#include "../../include/saugns_amd.h"
+#include "engine.h"
+#include "hip_backend.h"
+#include <stdio.h>
+#include <string.h>
+#include <string>
+
+using sauengine::Backend;
+using sauengine::Engine;
+
+namespace {
+thread_local std::string g_last_error;
+
+void report(const char *where, const std::string &err) {
+	g_last_error = err;
+	/* same channel as sau_warning/sau_error in the reference (sau/error.c) */
+	fprintf(stderr, "error [%s]: %s\n", where, err.c_str());
+}
+} /* namespace */
+
+struct sauAmdBatch {
+	Engine *engine;
+	sauhip::HipBackend *hip; /* NULL when a test backend was injected */
+};
+
+struct sauGenerator {
+	sauAmdBatch batch;
+};
+
+/* sau/generator/noise.h:18-21 */
+extern "C" const char *const sauNoise_names[SAU_NOISE_NAMED + 1] = {
+	"wh", "gw", "bw", "tw", "re", "vi", "bv", nullptr
+};
+
+static bool make_batch(sauAmdBatch &b, const sauProgram *const *prgs, size_t n,
+		uint32_t srate, Backend *injected) {
+	std::string err;
+	b.engine = nullptr;
+	b.hip = nullptr;
+	Backend *be = injected;
+	if (!be) {
+		b.hip = sauhip::create_hip_backend(err);
+		if (!b.hip) { report("generator", err); return false; }
+		be = b.hip;
+	}
+	b.engine = Engine::create(prgs, n, srate, be, err);
+	if (!b.engine) { b.hip = nullptr; report("generator", err); return false; }
+	return true;
+}
+
+extern "C" sauGenerator *sau_create_Generator(const sauProgram *prg, uint32_t srate) {
+	if (!prg) return nullptr;
+	sauGenerator *g = new sauGenerator();
+	if (!make_batch(g->batch, &prg, 1, srate, nullptr)) { delete g; return nullptr; }
+	return g;
+}
+
+extern "C" void sau_destroy_Generator(sauGenerator *o) {
+	if (!o) return;
+	delete o->batch.engine;
+	delete o;
+}
+
+extern "C" bool sauGenerator_run(sauGenerator *o, int16_t *buf, size_t buf_len,
+		bool stereo, size_t *out_len) {
+	bool more = false;
+	size_t len = 0;
+	std::string err;
+	int16_t *bufs[1] = {buf};
+	if (!o->batch.engine->run(bufs, buf_len, stereo, &more, &len, err)) {
+		/* the reference cannot fail here: report, give silence, end */
+		report("generator", err);
+		memset(buf, 0, sizeof(int16_t) * buf_len * (stereo ? 2 : 1));
+		if (out_len) *out_len = 0;
+		return false;
+	}
+	if (out_len) *out_len = len;
+	return more;
+}
+
+extern "C" sauAmdBatch *sauAmd_create_Batch(const sauProgram *const *prgs, size_t n,
+		uint32_t srate) {
+	if (!prgs || !n) return nullptr;
+	sauAmdBatch *b = new sauAmdBatch();
+	if (!make_batch(*b, prgs, n, srate, nullptr)) { delete b; return nullptr; }
+	return b;
+}
+
+/* Test hook (not in the public header): run the host control plane on a
+ * caller-supplied sauengine::Backend. Used by tests/ to exercise event
+ * handling and plan compilation without a GPU. */
+extern "C" SAU_AMD_API sauAmdBatch *sauAmd_create_Batch_with_backend(const sauProgram *const *prgs,
+		size_t n, uint32_t srate, void *backend) {
+	if (!prgs || !n || !backend) return nullptr;
+	sauAmdBatch *b = new sauAmdBatch();
+	if (!make_batch(*b, prgs, n, srate, (Backend *)backend)) { delete b; return nullptr; }
+	return b;
+}
+
+extern "C" void sauAmd_destroy_Batch(sauAmdBatch *b) {
+	if (!b) return;
+	delete b->engine;
+	delete b;
+}
+
+extern "C" bool sauAmd_Batch_run(sauAmdBatch *b, int16_t *const *bufs, size_t buf_len,
+		bool stereo, bool *more, size_t *out_len) {
+	std::string err;
+	if (!b->engine->run(bufs, buf_len, stereo, more, out_len, err)) {
+		report("batch", err);
+		return false;
+	}
+	return true;
+}
+
+extern "C" const int16_t *sauAmd_Batch_device_pcm(sauAmdBatch *b, size_t stream) {
+	return b->engine->backend()->device_pcm((uint32_t)stream);
+}
+
+extern "C" bool sauAmd_Batch_sync(sauAmdBatch *b) {
+	std::string err;
+	if (!b->engine->backend()->sync(err)) { report("batch", err); return false; }
+	return true;
+}
+
+extern "C" void sauAmd_Batch_timing(sauAmdBatch *b, double *render_ms, double *mix_ms,
+		uint64_t *render_launches, int reset) {
+	if (render_ms) *render_ms = 0;
+	if (mix_ms) *mix_ms = 0;
+	if (render_launches) *render_launches = 0;
+	if (b->hip) b->hip->timing(render_ms, mix_ms, render_launches, reset != 0);
+}
+
+extern "C" void *sauAmd_Batch_stream(sauAmdBatch *b) {
+	return b->hip ? b->hip->stream_handle() : nullptr;
+}
+
+extern "C" void sauAmd_set_piluts(const float *tables) {
+	if (tables) sauengine::override_piluts(tables);
+}
+extern "C" const float *sauAmd_get_piluts(void) { return sauengine::builtin_piluts(); }
+
+extern "C" const char *sauAmd_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int sauAmd_device_count(void) { return sauhip::device_count(); }

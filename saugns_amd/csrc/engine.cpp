@@ -1,0 +1,359 @@
+/* engine.cpp -- host control plane (see engine.h). */
+#include "engine.h"
+#include <algorithm>
+#include <string.h>
+
+namespace sauengine {
+
+static const sauProgramIDArr g_no_ids = {0};
+
+/* sau/math.h:35-46 */
+static uint64_t ms_to_samples(uint64_t ms, uint64_t srate, int *carry) {
+	uint64_t t = ms * srate;
+	if (carry) {
+		t += *carry;
+		*carry = (int)(t % 1000);
+	}
+	return t / 1000;
+}
+
+Engine::~Engine() { delete backend_; }
+
+/* generator.c:135-217 */
+Engine *Engine::create(const sauProgram *const *prgs, size_t n_prgs, uint32_t srate,
+		Backend *backend, std::string &err) {
+	Engine *e = new Engine();
+	e->backend_ = backend;
+	e->srate_ = srate;
+	e->streams_.resize(n_prgs);
+	uint32_t op_base = 0, vo_base = 0;
+	for (size_t s = 0; s < n_prgs; ++s) {
+		const sauProgram *prg = prgs[s];
+		Stream &st = e->streams_[s];
+		st.prg = prg;
+		st.op_base = op_base;
+		st.vo_base = vo_base;
+		st.ops.resize(prg->op_count);
+		st.voices.resize(prg->vo_count);
+		st.amp_scale = 0.5f * prg->ampmult;
+		if (prg->mode & SAU_PMODE_AMP_DIV_VOICES)
+			st.amp_scale /= prg->vo_count;
+		int carry = 0;
+		st.events.resize(prg->ev_count);
+		for (size_t i = 0; i < prg->ev_count; ++i) {
+			st.events[i].wait = (uint32_t)ms_to_samples(prg->events[i].wait_ms, srate, &carry);
+			st.events[i].pe = &prg->events[i];
+		}
+		op_base += prg->op_count;
+		vo_base += prg->vo_count;
+	}
+	e->total_ops_ = op_base;
+	e->total_voices_ = vo_base;
+	e->plan_refs_.resize(vo_base);
+	BackendConfig cfg;
+	cfg.srate = srate;
+	cfg.op_count = op_base;
+	cfg.voice_count = vo_base;
+	cfg.n_streams = (uint32_t)n_prgs;
+	cfg.max_frames = 0;
+	cfg.piluts = builtin_piluts();
+	cfg.wconst = wave_consts();
+	if (!backend->init(cfg, err)) {
+		delete e;
+		return nullptr;
+	}
+	return e;
+}
+
+static LineUpdate make_line_update(const sauLine *src, uint32_t srate) {
+	LineUpdate u;
+	memset(&u, 0, sizeof u);
+	if (!src) return u;
+	u.v0 = src->v0; u.vt = src->vt;
+	u.end_samples = (uint32_t)ms_to_samples(src->time_ms, srate, nullptr);
+	u.type = src->type;
+	u.flags = src->flags;
+	return u;
+}
+
+bool Engine::flush_updates(std::vector<OpUpdate> &batch, std::vector<uint8_t> &touched,
+		std::string &err) {
+	if (batch.empty()) return true;
+	bool ok = backend_->apply_updates(batch.data(), batch.size(), err);
+	for (const OpUpdate &u : batch) touched[u.op] = 0;
+	batch.clear();
+	return ok;
+}
+
+/* generator.c:348-377 (handle_event) with 245-343 mirrored for what the host
+ * needs: operator times, modulator lists, pan line, wave ids. */
+bool Engine::handle_event(Stream &st, const EventNode &e, std::vector<OpUpdate> &batch,
+		std::vector<uint8_t> &touched, std::string &err) {
+	const sauProgramEvent *pe = e.pe;
+	for (size_t i = 0; i < pe->op_data_count; ++i) {
+		const sauProgramOpData *od = &pe->op_data[i];
+		if (od->id >= st.ops.size()) { err = "event refers to an operator id out of range"; return false; }
+		OpMirror &m = st.ops[od->id];
+		uint32_t gid = st.op_base + od->id;
+		if (touched[gid] && !flush_updates(batch, touched, err)) return false;
+		OpUpdate u;
+		memset(&u, 0, sizeof u);
+		u.op = gid;
+		u.params = od->params;
+		u.type = od->type;
+		u.first = !m.inited;
+		u.coeff = (float)(0x1p32 / (double)srate_);
+		if (!m.inited) {
+			m = OpMirror();
+			m.inited = true;
+			m.type = od->type;
+			for (int k = 0; k < SAU_POP_NAMED; ++k) m.mods[k] = &g_no_ids;
+			m.wave = SAU_WAVE_N_sin;
+		}
+		const bool is_osc = (od->type == SAU_POPT_N_wave || od->type == SAU_POPT_N_raseg);
+		u.mode_main = od->mode.main;
+		if (od->type == SAU_POPT_N_raseg) {
+			u.ras_line = od->mode.ras.line;
+			u.ras_flags = od->mode.ras.flags;
+			u.ras_func = od->mode.ras.func;
+			u.ras_level = od->mode.ras.level;
+			u.ras_alpha = od->mode.ras.alpha;
+		}
+		if (od->type == SAU_POPT_N_wave && (od->params & SAU_POPP_MODE))
+			m.wave = od->mode.main < SAU_WAVE_NAMED ? od->mode.main : 0;
+		u.phase = od->phase;
+		u.seed = od->seed;
+		const sauLine *src[L_COUNT] = {od->pan, od->amp, od->amp2, nullptr, nullptr, nullptr};
+		if (is_osc) {
+			src[L_FREQ] = od->freq; src[L_FREQ2] = od->freq2; src[L_PMA] = od->pm_a;
+			if (od->fmods) m.mods[SAU_POP_N_fmod] = od->fmods;
+			if (od->rfmods) m.mods[SAU_POP_N_rfmod] = od->rfmods;
+			if (od->pmods) m.mods[SAU_POP_N_pmod] = od->pmods;
+			if (od->apmods) m.mods[SAU_POP_N_apmod] = od->apmods;
+			if (od->fpmods) m.mods[SAU_POP_N_fpmod] = od->fpmods;
+		}
+		for (uint32_t l = 0; l < L_COUNT; ++l) {
+			u.line[l] = make_line_update(src[l], srate_);
+			if (src[l]) m.line_set |= (uint8_t)(1u << l);
+		}
+		line_copy(m.pan, u.line[L_PAN]);
+		if (od->params & SAU_POPP_TIME) {
+			if (od->time.flags & SAU_TIMEP_IMPLICIT) {
+				m.time = 0; m.time_inf = true;
+				u.time = 0; u.time_inf = 1;
+			} else {
+				m.time = (uint32_t)ms_to_samples(od->time.v_ms, srate_, nullptr);
+				m.time_inf = false;
+				u.time = m.time; u.time_inf = 0;
+			}
+		}
+		if (od->camods) m.mods[SAU_POP_N_camod] = od->camods;
+		if (od->amods) m.mods[SAU_POP_N_amod] = od->amods;
+		if (od->ramods) m.mods[SAU_POP_N_ramod] = od->ramods;
+		batch.push_back(u);
+		touched[gid] = 1;
+	}
+	if (pe->vo_id != SAU_PVO_NO_ID) {
+		if (pe->vo_id >= st.voices.size()) { err = "event refers to a voice id out of range"; return false; }
+		VoiceHost &vn = st.voices[pe->vo_id];
+		vn.carr_op = pe->carr_op_id;
+		vn.init = true;
+		if (st.voice > pe->vo_id)
+			st.voice = pe->vo_id;
+		/* generator.c:233-240 */
+		vn.duration = (vn.carr_op < st.ops.size()) ? st.ops[vn.carr_op].time : 0;
+		vn.plan_valid = false;
+		plans_dirty_ = true;
+	} else if (pe->op_data_count > 0) {
+		/* operators changed without a voice: graphs may have changed */
+		for (VoiceHost &vn : st.voices) vn.plan_valid = false;
+		plans_dirty_ = true;
+	}
+	return true;
+}
+
+bool Engine::rebuild_plans(std::string &err) {
+	all_steps_.clear();
+	all_op_ids_.clear();
+	for (Stream &st : streams_) {
+		for (size_t v = 0; v < st.voices.size(); ++v) {
+			VoiceHost &vn = st.voices[v];
+			PlanRef &ref = plan_refs_[st.vo_base + v];
+			ref = PlanRef{0, 0, 0, 0};
+			if (!vn.init) continue;
+			if (!vn.plan_valid) {
+				if (!compile_voice_plan(st.ops, vn.carr_op, vn.plan, err)) {
+					/* a voice whose carrier never got data stays silent */
+					vn.plan.steps.clear();
+					vn.plan.op_ids.clear();
+					if (err != "voice carrier operator was never initialised")
+						return false;
+					err.clear();
+				}
+				vn.plan_valid = true;
+			}
+			ref.plan_ofs = (uint32_t)all_steps_.size();
+			ref.plan_len = (uint32_t)vn.plan.steps.size();
+			ref.ops_ofs = (uint32_t)all_op_ids_.size();
+			ref.nops = (uint32_t)vn.plan.op_ids.size();
+			all_steps_.insert(all_steps_.end(), vn.plan.steps.begin(), vn.plan.steps.end());
+			for (uint32_t id : vn.plan.op_ids)
+				all_op_ids_.push_back(st.op_base + id);
+		}
+	}
+	/* An operator reachable from two voices would be advanced concurrently by
+	 * two workgroups; the reference advances it twice in voice order. */
+	{
+		std::vector<uint8_t> seen(total_ops_, 0);
+		for (Stream &st : streams_)
+			for (VoiceHost &vn : st.voices) {
+				if (!vn.init || vn.duration == 0) continue;
+				for (uint32_t id : vn.plan.op_ids) {
+					if (seen[st.op_base + id]) {
+						err = "an operator is shared between two live voices (unsupported)";
+						return false;
+					}
+					seen[st.op_base + id] = 1;
+				}
+			}
+	}
+	plans_dirty_ = false;
+	return backend_->upload_plans(all_steps_.data(), all_steps_.size(),
+			all_op_ids_.data(), all_op_ids_.size(), err);
+}
+
+/* generator.c:854-878 (run_for_time) + 833-846 (run_voice), one segment. */
+bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::string &err) {
+	std::vector<VoiceDesc> descs;
+	std::vector<SegmentDesc::Stream> sdescs(streams_.size());
+	uint32_t n_slots = 1, max_ops = 1, n_pan = 0;
+	uint64_t wave_mask = 0;
+	for (size_t s = 0; s < streams_.size(); ++s) {
+		Stream &st = streams_[s];
+		SegmentDesc::Stream &sd = sdescs[s];
+		sd.first_voice = (uint32_t)descs.size();
+		sd.amp_scale = st.amp_scale;
+		sd.write_len = 0;
+		for (uint32_t v = st.voice; v < st.voices.size(); ++v) {
+			VoiceHost &vn = st.voices[v];
+			if (vn.duration == 0) continue;
+			uint32_t run_len = std::min(vn.duration, len);
+			vn.duration -= run_len;
+			if (vn.carr_op >= st.ops.size()) continue;
+			OpMirror &carr = st.ops[vn.carr_op];
+			uint32_t out_len = 0;
+			if (carr.time > 0) /* generator.c:839; implicit-time carriers have time 0 */
+				out_len = carr.time_inf ? run_len : std::min(run_len, carr.time);
+			if (out_len == 0 || vn.plan.steps.empty()) continue;
+			if (!carr.time_inf) carr.time -= out_len;
+			const PlanRef &ref = plan_refs_[st.vo_base + v];
+			VoiceDesc d;
+			d.plan_ofs = ref.plan_ofs; d.plan_len = ref.plan_len;
+			d.ops_ofs = ref.ops_ofs; d.nops = ref.nops;
+			d.carr_local = vn.plan.carr_local;
+			d.run_len = run_len;
+			d.out_row = (uint32_t)descs.size();
+			/* generator.c:756-762: dynamic pan needs per-sample values */
+			bool dyn = (carr.pan.flags & LP_GOAL) || vn.plan.has_camods;
+			d.pan_dynamic_row = dyn ? n_pan++ : ~0u;
+			if (dyn) line_begin(carr.pan, out_len, false, 0.f);
+			else line_skip(carr.pan, out_len);
+			descs.push_back(d);
+			if (out_len > sd.write_len) sd.write_len = out_len;
+			n_slots = std::max(n_slots, vn.plan.n_slots);
+			max_ops = std::max(max_ops, (uint32_t)vn.plan.op_ids.size());
+			wave_mask |= vn.plan.wave_mask;
+		}
+		sd.n_voices = (uint32_t)descs.size() - sd.first_voice;
+		if (sd.write_len > 0) {
+			size_t end = (size_t)(offset - (uint32_t)st.part_start) + sd.write_len;
+			if (end > st.part_gen) st.part_gen = end;
+		}
+	}
+	if (descs.empty()) return true;
+	out_dirty_ = true;
+	SegmentDesc seg;
+	seg.len = len; seg.pcm_offset = offset; seg.stereo = stereo;
+	seg.voices = descs.data(); seg.n_voices = (uint32_t)descs.size();
+	seg.streams = sdescs.data(); seg.n_streams = (uint32_t)sdescs.size();
+	seg.n_slots = n_slots; seg.max_ops = max_ops; seg.n_pan_rows = n_pan;
+	seg.wave_mask = wave_mask;
+	return backend_->render(seg, err);
+}
+
+/* generator.c:905-973, for all streams in lock step. */
+bool Engine::run(int16_t *const *host_bufs, size_t buf_len, bool stereo,
+		bool *more, size_t *out_len, std::string &err) {
+	if (buf_len > UINT32_MAX) { err = "buffer too long"; return false; }
+	const uint32_t total = (uint32_t)buf_len;
+	if (total > reserved_frames_ || (stereo && !reserved_stereo_)) {
+		uint32_t want = std::max(total, reserved_frames_);
+		if (!backend_->reserve_frames(want, stereo || reserved_stereo_, err)) return false;
+		reserved_frames_ = want;
+		reserved_stereo_ = stereo || reserved_stereo_;
+	}
+	if (out_dirty_) { /* generator.c:911-914 */
+		if (!backend_->clear_pcm(reserved_frames_, reserved_stereo_, err)) return false;
+		out_dirty_ = false;
+	}
+	for (Stream &st : streams_) { st.call_gen = 0; st.part_start = 0; st.part_gen = 0; }
+	std::vector<OpUpdate> batch;
+	std::vector<uint8_t> touched(total_ops_, 0);
+	uint32_t pos = 0, remaining = total;
+	while (remaining > 0) {
+		for (Stream &st : streams_) {
+			bool split = false;
+			while (st.event < st.events.size()) {
+				const EventNode &e = st.events[st.event];
+				if (st.event_pos < e.wait) break;
+				if (!split && pos > (uint32_t)st.part_start) {
+					/* this stream's own split point: generator.c:939-946 */
+					st.call_gen += pos - st.part_start;
+					st.part_start = pos; st.part_gen = 0;
+				}
+				split = true;
+				if (!handle_event(st, e, batch, touched, err)) return false;
+				++st.event;
+				st.event_pos = 0;
+			}
+		}
+		if (!flush_updates(batch, touched, err)) return false;
+		if (plans_dirty_ && !rebuild_plans(err)) return false;
+		uint32_t seg = remaining;
+		for (Stream &st : streams_) {
+			if (st.event < st.events.size()) {
+				uint32_t wt = st.events[st.event].wait - st.event_pos;
+				if (wt < seg) seg = wt;
+			}
+		}
+		for (Stream &st : streams_)
+			if (st.event < st.events.size()) st.event_pos += seg;
+		if (!render_segment(seg, pos, stereo, err)) return false;
+		pos += seg;
+		remaining -= seg;
+	}
+	frames_done_ += total;
+	for (size_t s = 0; s < streams_.size(); ++s) {
+		Stream &st = streams_[s];
+		st.call_gen += st.part_gen;
+		bool ended = false;
+		for (;;) { /* generator.c:953-967 */
+			if (st.voice == st.voices.size()) {
+				if (st.event != st.events.size()) break;
+				ended = true;
+				break;
+			}
+			if (st.voices[st.voice].duration != 0) break;
+			++st.voice;
+		}
+		if (more) more[s] = !ended;
+		if (out_len) out_len[s] = ended ? st.call_gen : buf_len;
+		if (host_bufs && host_bufs[s]) {
+			if (!backend_->fetch_pcm((uint32_t)s, host_bufs[s], total, stereo, err))
+				return false;
+		}
+	}
+	return true;
+}
+
+} /* namespace sauengine */

@@ -1,0 +1,180 @@
+/* engine.h -- host control plane of the MI355X generator backend.
+ *
+ * Mirrors the control flow of sau/generator.c (event timeline, voice
+ * durations, end-of-signal detection: generator.c:172-195,348-377,833-973)
+ * on the host, flattens every voice's operator graph into a plan
+ * (plan.cpp), and drives a Backend that owns the operator state and does the
+ * per-sample work.  The product backend is the HIP one (hip_backend.hip);
+ * the interface exists so that the host logic can be exercised without a GPU
+ * by tests/ (which inject their own sequential executor) -- the library
+ * itself never falls back to a CPU path.
+ */
+#ifndef SAU_ENGINE_H
+#define SAU_ENGINE_H
+
+#include "../../include/sau_abi.h"
+#include "sau_dev_types.h"
+#include <stddef.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+namespace sauengine {
+
+using namespace saudev;
+
+/* Everything the backend needs to render one segment (no events inside). */
+struct SegmentDesc {
+	uint32_t len;             /* frames */
+	uint32_t pcm_offset;      /* frame offset into each stream's PCM row */
+	bool stereo;
+	/* active voices of all streams, ascending (stream, voice id) */
+	const VoiceDesc *voices;
+	uint32_t n_voices;
+	/* per stream: range of `voices`, amp_scale, frames to write (last_len) */
+	struct Stream {
+		uint32_t first_voice, n_voices;
+		float amp_scale;
+		uint32_t write_len;
+	};
+	const Stream *streams;
+	uint32_t n_streams;
+	uint32_t n_slots;         /* max slots any active plan uses */
+	uint32_t max_ops;         /* max operators in any active voice */
+	uint32_t n_pan_rows;
+	uint64_t wave_mask;       /* wave ids in use (bit per id) */
+};
+
+struct BackendConfig {
+	uint32_t srate;
+	uint32_t op_count;        /* all streams */
+	uint32_t voice_count;     /* all streams */
+	uint32_t n_streams;
+	uint32_t max_frames;      /* PCM row capacity, frames */
+	const float *piluts;      /* 12 x 2048 */
+	const WaveConst *wconst;  /* 12 */
+};
+
+class Backend {
+public:
+	virtual ~Backend() {}
+	virtual bool init(const BackendConfig &cfg, std::string &err) = 0;
+	/* grow PCM / voice matrices when a caller passes a longer buffer */
+	virtual bool reserve_frames(uint32_t max_frames, bool stereo, std::string &err) = 0;
+	/* plans changed: full step array + op id lists */
+	virtual bool upload_plans(const Step *steps, size_t n_steps,
+			const uint32_t *op_ids, size_t n_ids, std::string &err) = 0;
+	/* apply operator updates in order; ops are distinct within one call */
+	virtual bool apply_updates(const OpUpdate *recs, size_t n, std::string &err) = 0;
+	/* zero the PCM rows [0, frames) of every stream */
+	virtual bool clear_pcm(uint32_t frames, bool stereo, std::string &err) = 0;
+	virtual bool render(const SegmentDesc &seg, std::string &err) = 0;
+	/* copy stream `s` PCM [0, frames) to host memory (blocks until done) */
+	virtual bool fetch_pcm(uint32_t stream, int16_t *dst, uint32_t frames,
+			bool stereo, std::string &err) = 0;
+	/* device address of stream s PCM row, or NULL (test backends) */
+	virtual const int16_t *device_pcm(uint32_t stream) = 0;
+	virtual bool sync(std::string &err) = 0;
+};
+
+/* ---- plan compiler (plan.cpp) -------------------------------------------- */
+
+struct OpMirror { /* host-side knowledge about one operator */
+	bool inited = false;
+	uint8_t type = 0;
+	uint32_t time = 0;
+	bool time_inf = false;
+	uint8_t line_set = 0;             /* bit per L_*: line ever given */
+	LineState pan;                    /* mirrored exactly (never ratio-scaled) */
+	const sauProgramIDArr *mods[SAU_POP_NAMED] = {}; /* by use type; [0] unused */
+	uint8_t wave = 0;
+	OpMirror() { pan = LineState{0, 0, 0, 0, 0, 0}; }
+};
+
+struct VoicePlan {
+	std::vector<Step> steps;
+	std::vector<uint32_t> op_ids;  /* voice-local index -> stream-local op id */
+	uint32_t carr_local = 0;
+	uint32_t n_slots = 0;
+	uint64_t wave_mask = 0;
+	bool has_camods = false;
+};
+
+/* Flatten the graph under `carrier` into steps. Returns false (with err) when
+ * the graph exceeds what a workgroup can hold. */
+bool compile_voice_plan(const std::vector<OpMirror> &ops, uint32_t carrier,
+		VoicePlan &out, std::string &err);
+
+/* ---- engine ---------------------------------------------------------------- */
+
+class Engine {
+public:
+	/* programs are borrowed and must outlive the engine (generator.c:191) */
+	static Engine *create(const sauProgram *const *prgs, size_t n_prgs,
+			uint32_t srate, Backend *backend /* owned */, std::string &err);
+	~Engine();
+
+	/* Advance every stream by buf_len frames. host_bufs[s] may be NULL (PCM
+	 * stays on the device). more[s]/out_len[s] as sauGenerator_run. */
+	bool run(int16_t *const *host_bufs, size_t buf_len, bool stereo,
+			bool *more, size_t *out_len, std::string &err);
+
+	size_t n_streams() const { return streams_.size(); }
+	Backend *backend() { return backend_; }
+	uint64_t frames_done() const { return frames_done_; }
+
+private:
+	struct EventNode { uint32_t wait; const sauProgramEvent *pe; };
+	struct VoiceHost {
+		uint32_t duration = 0;
+		bool init = false;
+		uint32_t carr_op = 0;
+		VoicePlan plan;
+		bool plan_valid = false;
+	};
+	struct Stream {
+		const sauProgram *prg = nullptr;
+		std::vector<EventNode> events;
+		size_t event = 0;
+		uint32_t event_pos = 0;
+		std::vector<VoiceHost> voices;
+		uint32_t voice = 0;
+		float amp_scale = 0.f;
+		uint32_t op_base = 0;   /* offset into the global op array */
+		uint32_t vo_base = 0;
+		std::vector<OpMirror> ops;
+		/* per-call output length accounting (generator.c:938-949) */
+		size_t call_gen = 0, part_start = 0, part_gen = 0;
+	};
+
+	Engine() {}
+	bool handle_event(Stream &st, const EventNode &e, std::vector<OpUpdate> &batch,
+			std::vector<uint8_t> &touched, std::string &err);
+	bool flush_updates(std::vector<OpUpdate> &batch, std::vector<uint8_t> &touched,
+			std::string &err);
+	bool rebuild_plans(std::string &err);
+	bool render_segment(uint32_t len, uint32_t offset, bool stereo, std::string &err);
+
+	Backend *backend_ = nullptr;
+	uint32_t srate_ = 0;
+	std::vector<Stream> streams_;
+	uint32_t total_ops_ = 0, total_voices_ = 0;
+	uint32_t reserved_frames_ = 0;
+	bool reserved_stereo_ = false;
+	bool plans_dirty_ = true;
+	/* concatenated plans as uploaded; per (stream,voice) offsets */
+	std::vector<Step> all_steps_;
+	std::vector<uint32_t> all_op_ids_;
+	struct PlanRef { uint32_t plan_ofs, plan_len, ops_ofs, nops; };
+	std::vector<PlanRef> plan_refs_; /* indexed by global voice index */
+	bool out_dirty_ = false;         /* PCM written since last clear */
+	uint64_t frames_done_ = 0;
+};
+
+/* tables.cpp */
+const float *builtin_piluts();            /* 12 x 2048, built on first use */
+const WaveConst *wave_consts();           /* 12 */
+void override_piluts(const float *tables);/* replace (e.g. host's own tables) */
+
+} /* namespace sauengine */
+#endif

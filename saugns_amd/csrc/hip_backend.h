@@ -1,0 +1,21 @@
+/* hip_backend.h -- the product backend: operator state in HBM, hand-written
+ * gfx950 kernels (hip_backend.hip). */
+#ifndef SAU_HIP_BACKEND_H
+#define SAU_HIP_BACKEND_H
+
+#include "engine.h"
+
+namespace sauhip {
+
+class HipBackend : public sauengine::Backend {
+public:
+	virtual void timing(double *render_ms, double *mix_ms, uint64_t *launches, bool reset) = 0;
+	virtual void *stream_handle() = 0;
+};
+
+/* NULL (with err) when no HIP device is usable: there is no CPU fallback. */
+HipBackend *create_hip_backend(std::string &err);
+int device_count();
+
+} /* namespace sauhip */
+#endif

@@ -1,0 +1,1073 @@
+/* hip_backend.hip -- gfx950 kernels and the HIP backend of the generator.
+ *
+ * Work decomposition (DESIGN.md "Kernels"):
+ *   render_kernel<W,T>  one workgroup (W waves) per live voice.  The voice's
+ *       operator states (256 B each) and all block buffers live in LDS for
+ *       the whole segment; Hermite coefficient tables of the wave types in
+ *       use are staged into LDS once per workgroup.  Time runs in blocks of
+ *       W*(64T-1) samples; inside a block every lane owns T consecutive
+ *       samples, so the differentiator's "previous sample" is in-lane except
+ *       at lane boundaries (one cross-lane shuffle) and wave boundaries (one
+ *       overlapping halo sample per wave instead of an exchange).  Phase
+ *       accumulation is an exact integer prefix scan (wave shuffles + one LDS
+ *       exchange).  The only serial code is the feedback recurrence of
+ *       self-modulating operators and the rare dphase==0 fill-forward.
+ *       Each voice's carrier block goes to HBM once (f32 [voice][frame]).
+ *   mix_kernel  one thread per output frame sums the voices of its stream in
+ *       ascending voice order (the reference's f32 accumulation order,
+ *       generator.c:749-788) and writes int16 PCM (795-825).
+ *   event_kernel  applies operator updates to the state in HBM.
+ *
+ * Arithmetic: sau_dev_math.h, compiled with -ffp-contract=off.
+ */
+#include <hip/hip_runtime.h>
+#include "hip_backend.h"
+#include "sau_dev_ops.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+namespace sauhip {
+
+using namespace saudev;
+using sauengine::BackendConfig;
+using sauengine::SegmentDesc;
+
+/* ------------------------------------------------------------------------ */
+/* device side                                                              */
+/* ------------------------------------------------------------------------ */
+
+struct RenderParams {
+	const VoiceDesc *voices;
+	const Step *steps;
+	const uint32_t *op_ids;
+	DevOp *ops;
+	float *vout;           /* [row][row_stride] carrier blocks */
+	float *pan;            /* [pan row][row_stride] */
+	VoiceOut *vinfo;       /* [row] */
+	const HerpC23 *g_c23;  /* [12][2048] */
+	const HerpC01 *g_c01;
+	uint32_t row_stride;
+	uint32_t seg_len;
+	uint32_t n_slots;
+	uint32_t max_ops;
+	uint32_t n_tabs;       /* wave types staged in LDS */
+	int8_t tab_of_wave[12];/* LDS table index per wave id, or -1 */
+	uint8_t wave_of_tab[12];
+	WaveConst wc[12];
+};
+
+struct Misc {
+	uint32_t len_stack[MAX_NEST + 1];
+	uint32_t tot32[16];
+	unsigned long long tot64[16];
+	uint32_t flag;
+	uint32_t pad;
+};
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		uint32_t t = __shfl_up(v, d);
+		if (lane >= d) v += t;
+	}
+	return v;
+}
+__device__ __forceinline__ unsigned long long wave_incl_scan64(unsigned long long v, int lane) {
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		unsigned long long t = __shfl_up(v, d);
+		if (lane >= d) v += t;
+	}
+	return v;
+}
+
+/* Where the coefficient tables of one wave type are read from. */
+struct TabRef {
+	const HerpC23 *c23;
+	const HerpC01 *c01;
+	bool in_lds;
+};
+
+__device__ __forceinline__ double herp_lookup(const TabRef &t, uint32_t phase) {
+	uint32_t ind = phase >> SLEN_BITS;
+	HerpC23 hi;
+	HerpC01 lo;
+	if (t.in_lds) {
+		const HerpC23 *p23 = (const HerpC23 *)__builtin_assume_aligned(t.c23, 16);
+		hi = p23[ind];
+		lo = t.c01[ind];
+	} else {
+		hi = t.c23[ind];
+		lo = t.c01[ind];
+	}
+	return herp_poly(hi, lo, phase);
+}
+
+template <int W, int T>
+struct Geo {
+	static constexpr int NP = 64 * T;        /* slot entries per wave */
+	static constexpr int NB = W * (NP - 1);  /* new samples per block */
+	static constexpr int SLOT = W * NP;      /* floats per slot */
+};
+
+/* entry index of sample j (>= 0) */
+template <int W, int T>
+__device__ __forceinline__ uint32_t entry_of(uint32_t j) {
+	constexpr uint32_t S = Geo<W, T>::NP - 1;
+	uint32_t w = j / S;
+	return w * Geo<W, T>::NP + (j - w * S) + 1;
+}
+
+/* store one owned sample, keeping the next wave's halo copy in step */
+template <int W, int T>
+__device__ __forceinline__ void slot_put(float *slot, int w, int p, float v) {
+	slot[w * Geo<W, T>::NP + p] = v;
+	if (p == Geo<W, T>::NP - 1 && w + 1 < W)
+		slot[(w + 1) * Geo<W, T>::NP] = v;
+}
+
+template <int W, int T>
+__global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
+	using G = Geo<W, T>;
+	extern __shared__ __align__(16) unsigned char lds[];
+	const int tid = threadIdx.x;
+	const int w = tid >> 6;
+	const int l = tid & 63;
+
+	HerpC23 *t23 = (HerpC23 *)lds;
+	HerpC01 *t01 = (HerpC01 *)(lds + (size_t)P.n_tabs * WAVE_LEN * sizeof(HerpC23));
+	float *slots = (float *)(lds + (size_t)P.n_tabs * WAVE_LEN * (sizeof(HerpC23) + sizeof(HerpC01)));
+	DevOp *ops = (DevOp *)(slots + (size_t)P.n_slots * G::SLOT);
+	Misc *misc = (Misc *)(ops + P.max_ops);
+
+	/* stage coefficient tables (16-byte copies) */
+	for (uint32_t t = 0; t < P.n_tabs; ++t) {
+		const uint32_t wave = P.wave_of_tab[t];
+		const uint4 *s23 = (const uint4 *)(P.g_c23 + (size_t)wave * WAVE_LEN);
+		uint4 *d23 = (uint4 *)(t23 + (size_t)t * WAVE_LEN);
+		for (uint32_t i = tid; i < WAVE_LEN; i += 64 * W) d23[i] = s23[i];
+		const uint2 *s01 = (const uint2 *)(P.g_c01 + (size_t)wave * WAVE_LEN);
+		uint2 *d01 = (uint2 *)(t01 + (size_t)t * WAVE_LEN);
+		for (uint32_t i = tid; i < WAVE_LEN; i += 64 * W) d01[i] = s01[i];
+	}
+
+	const VoiceDesc vd = P.voices[blockIdx.x];
+	const uint32_t *my_ids = P.op_ids + vd.ops_ofs;
+	for (uint32_t i = tid; i < vd.nops * 64; i += 64 * W)
+		((uint32_t *)ops)[i] = ((const uint32_t *)&P.ops[my_ids[i >> 6]])[i & 63];
+	__syncthreads();
+
+	float *vrow = P.vout + (size_t)vd.out_row * P.row_stride;
+	float *prow = (vd.pan_dynamic_row != ~0u) ? P.pan + (size_t)vd.pan_dynamic_row * P.row_stride : nullptr;
+	const Step *plan = P.steps + vd.plan_ofs;
+	uint32_t done = 0, produced = 0;
+
+	/* per-thread sample geometry: p = l*T + k, block sample j = w*(NP-1) + p - 1 */
+	const int p0 = l * T;
+	const int jbase = w * (G::NP - 1) + p0 - 1;
+
+	while (done < vd.run_len) {
+		if (ops[vd.carr_local].time == 0) break; /* generator.c:839 */
+		const uint32_t blen = min((uint32_t)G::NB, vd.run_len - done);
+		uint32_t depth = 0;
+		uint32_t cur_len = blen;
+		bool block_ended = false;
+
+		for (uint32_t si = 0; si < vd.plan_len && !block_ended; ++si) {
+			const Step st = plan[si];
+			uint32_t parent_len = cur_len;
+			DevOp *op = &ops[st.op];
+			if (st.flags & SF_BEGIN) { /* generator.c:694-698 */
+				if (tid == 0) misc->len_stack[depth] = cur_len;
+				++depth;
+				if (!(op->flags & OPF_TIME_INF) && op->time < cur_len) cur_len = op->time;
+			}
+			const uint32_t len = cur_len;
+
+			switch (st.kind) {
+			case ST_ZERO: {
+				float *out = slots + (size_t)st.out * G::SLOT;
+#pragma unroll
+				for (int k = 0; k < T; ++k) {
+					int j = jbase + k;
+					if (p0 + k >= 1 && j < (int)len) slot_put<W, T>(out, w, p0 + k, 0.f);
+				}
+				break;
+			}
+			case ST_LINE: {
+				float *out = slots + (size_t)st.out * G::SLOT;
+				const float *mul = st.fmul != NO_SLOT ? slots + (size_t)st.fmul * G::SLOT : nullptr;
+				LineState ls = op->line[st.which];
+				LineBlock lb = line_begin(ls, len, mul != nullptr, mul ? mul[1] : 0.f);
+#pragma unroll
+				for (int k = 0; k < T; ++k) {
+					int j = jbase + k;
+					if (p0 + k >= 1 && j < (int)len) {
+						float m = mul ? mul[w * G::NP + p0 + k] : 1.f;
+						slot_put<W, T>(out, w, p0 + k, line_value(lb, (uint32_t)j, m));
+					}
+				}
+				__syncthreads(); /* every thread has read the old line state */
+				if (tid == 0) {
+					op->line[st.which] = ls;
+					if (st.flags & SF_SKIP2) {
+						LineState l2 = op->line[st.tmp];
+						line_skip(l2, len);
+						op->line[st.tmp] = l2;
+					}
+				}
+				break;
+			}
+			case ST_SMLINE: { /* generator.c:485-490 */
+				float *out = slots + (size_t)st.out * G::SLOT;
+				LineState ls = op->line[L_PMA];
+				const bool active = (ls.v0 != 0.f) || (ls.flags & LP_GOAL);
+				LineBlock lb;
+				if (active) lb = line_begin(ls, len, false, 0.f);
+				else line_skip(ls, len);
+#pragma unroll
+				for (int k = 0; k < T; ++k) {
+					int j = jbase + k;
+					if (p0 + k >= 1 && j < (int)len)
+						slot_put<W, T>(out, w, p0 + k, active ? line_value(lb, (uint32_t)j, 1.f) : 0.f);
+				}
+				__syncthreads();
+				if (tid == 0) op->line[L_PMA] = ls;
+				break;
+			}
+			case ST_LERP: { /* generator.c:466-467 */
+				float *par = slots + (size_t)st.out * G::SLOT;
+				const float *rpar = slots + (size_t)st.freq * G::SLOT;
+				const float *mod = slots + (size_t)st.pm * G::SLOT;
+#pragma unroll
+				for (int k = 0; k < T; ++k) {
+					int j = jbase + k;
+					if (p0 + k >= 1 && j < (int)len) {
+						int e = w * G::NP + p0 + k;
+						float pv = par[e];
+						pv += (rpar[e] - pv) * mod[e];
+						slot_put<W, T>(par, w, p0 + k, pv);
+					}
+				}
+				break;
+			}
+			case ST_OSC: {
+				float *out = slots + (size_t)st.out * G::SLOT;
+				float *scratch = slots; /* SCRATCH_SLOT */
+				uint32_t *scratch_u = (uint32_t *)slots;
+				unsigned long long wb_grand64 = 0; /* R: counter advance */
+				uint32_t wb_noise_prev = 0;
+				bool wb_noise_prev_set = false;
+				const float *fslot = st.freq != NO_SLOT ? slots + (size_t)st.freq * G::SLOT : nullptr;
+				const float *fmul = st.fmul != NO_SLOT ? slots + (size_t)st.fmul * G::SLOT : nullptr;
+				const float *pmS = st.pm != NO_SLOT ? slots + (size_t)st.pm * G::SLOT : nullptr;
+				const float *fpmS = st.fpm != NO_SLOT ? slots + (size_t)st.fpm * G::SLOT : nullptr;
+				const float *ampS = st.amp != NO_SLOT ? slots + (size_t)st.amp * G::SLOT : nullptr;
+				const float *smS = st.sm != NO_SLOT ? slots + (size_t)st.sm * G::SLOT : nullptr;
+				const uint32_t type = op->type;
+				const bool is_osc = (type == OT_WAVE || type == OT_RASEG);
+				if (tid == 0) misc->flag = 0;
+
+				/* --- uniform line setup ------------------------------------ */
+				LineState fls, als, pls;
+				LineBlock flb, alb, plb;
+				bool f_inline = is_osc && !fslot;
+				if (f_inline) {
+					fls = op->line[L_FREQ];
+					flb = line_begin(fls, len, fmul != nullptr, fmul ? fmul[1] : 0.f);
+				}
+				const bool a_inline = !ampS;
+				if (a_inline) {
+					als = op->line[L_AMP];
+					alb = line_begin(als, len, false, 0.f);
+				}
+				bool sm_inline_active = false;
+				if (is_osc && (st.flags & SF_SM_INLINE)) {
+					pls = op->line[L_PMA];
+					sm_inline_active = (pls.v0 != 0.f) || (pls.flags & LP_GOAL);
+					if (sm_inline_active) plb = line_begin(pls, len, false, 0.f);
+					else line_skip(pls, len);
+				}
+				const bool selfmod = is_osc && (smS != nullptr || sm_inline_active);
+
+				float s[T];
+				bool owned[T];
+#pragma unroll
+				for (int k = 0; k < T; ++k) {
+					owned[k] = (p0 + k >= 1) && (jbase + k < (int)len);
+					s[k] = 0.f;
+				}
+
+				if (type == OT_WAVE) {
+					/* ---- phase accumulation: wosc.h:135-169 ------------- */
+					const WaveConst wc = P.wc[op->wave];
+					TabRef tab;
+					{
+						int ti = P.tab_of_wave[op->wave];
+						tab.in_lds = ti >= 0;
+						tab.c23 = ti >= 0 ? t23 + (size_t)ti * WAVE_LEN : P.g_c23 + (size_t)op->wave * WAVE_LEN;
+						tab.c01 = ti >= 0 ? t01 + (size_t)ti * WAVE_LEN : P.g_c01 + (size_t)op->wave * WAVE_LEN;
+					}
+					const float coeff = op->coeff;
+					uint32_t inc[T], ofs[T];
+					uint32_t lane_sum = 0;
+					/* halo sample of this wave (lane 0, k 0) needs its PM offset too */
+					const bool halo = (p0 == 0);
+					const bool halo_live = halo && w > 0 && (jbase < (int)len);
+#pragma unroll
+					for (int k = 0; k < T; ++k) {
+						inc[k] = 0; ofs[k] = 0;
+						const bool need = owned[k] || (k == 0 && halo_live);
+						if (need) {
+							const int e = w * G::NP + p0 + k;
+							const int j = jbase + k;
+							float f = fslot ? fslot[e]
+							                : line_value(flb, (uint32_t)j, fmul ? fmul[e] : 1.f);
+							if (owned[k]) inc[k] = rint32w(coeff * f);
+							ofs[k] = (uint32_t)pm_offset(pmS != nullptr, fpmS != nullptr,
+									pmS ? pmS[e] : 0.f, fpmS ? fpmS[e] : 0.f, f, 0x1p31f);
+						}
+						lane_sum += inc[k];
+					}
+					const uint32_t incl = wave_incl_scan(lane_sum, l);
+					if (l == 63) misc->tot32[w] = incl;
+					__syncthreads();
+					uint32_t base = op->phase, grand = 0;
+#pragma unroll
+					for (int ww = 0; ww < W; ++ww) {
+						uint32_t t = misc->tot32[ww];
+						if (ww < w) base += t;
+						grand += t;
+					}
+					const bool reset = (op->flags & OPF_OSC_RESET) && len > 0;
+					uint32_t ph[T];
+					uint32_t run = base + (incl - lane_sum);
+#pragma unroll
+					for (int k = 0; k < T; ++k) {
+						run += inc[k];
+						ph[k] = run + ofs[k];
+					}
+					if (!selfmod) {
+						/* ---- lookup + differentiate: wosc.h:238-266 ------- */
+						double Is[T];
+						if (halo && w == 0) {
+							/* sample before the block: carried state, or the
+							 * one-table-step restart of wosc.h:215-231 */
+							ph[0] = reset ? ph[1] - SLEN : op->prev_phase;
+						}
+#pragma unroll
+						for (int k = 0; k < T; ++k) {
+							const bool need = owned[k] || (k == 0 && (halo_live || (halo && w == 0)));
+							Is[k] = need ? herp_lookup(tab, ph[k]) : 0.0;
+						}
+						if (halo && w == 0 && !reset) Is[0] = op->prev_Is;
+						uint32_t pph = __shfl_up(ph[T - 1], 1);
+						double pIs = __shfl_up(Is[T - 1], 1);
+						bool anyzero = false;
+#pragma unroll
+						for (int k = 0; k < T; ++k) {
+							if (k > 0) { pph = ph[k - 1]; pIs = Is[k - 1]; }
+							if (owned[k]) {
+								int32_t d = (int32_t)(ph[k] - pph);
+								if (d == 0) anyzero = true;
+								else s[k] = wosc_diff(Is[k], pIs, d, wc.diff_scale, wc.diff_offset);
+							}
+						}
+						if (__any(anyzero) && l == 0) misc->flag = 1;
+						__syncthreads();
+						if (misc->flag == 0) {
+							/* carried state: owner of the last sample */
+#pragma unroll
+							for (int k = 0; k < T; ++k) {
+								if (owned[k] && jbase + k == (int)len - 1) {
+									uint32_t r = base + (incl - lane_sum);
+									for (int q = 0; q <= k; ++q) r += inc[q];
+									op->phase = r;
+									op->prev_phase = ph[k];
+									op->prev_Is = Is[k];
+									op->prev_s = s[k];
+									op->flags &= ~OPF_OSC_RESET;
+								}
+							}
+						}
+					}
+					if (selfmod || misc->flag != 0) {
+						/* ---- serial path: feedback recurrence (wosc.h:273-310)
+						 * or fill-forward over dphase == 0 (wosc.h:251-252) ---- */
+						if (!selfmod) __syncthreads(); /* all flag reads done before scratch reuse */
+#pragma unroll
+						for (int k = 0; k < T; ++k)
+							if (owned[k]) scratch_u[w * G::NP + p0 + k] = ph[k];
+						__syncthreads();
+						if (tid == 0 && len > 0) {
+							uint32_t prev_phase = op->prev_phase;
+							double prev_Is = op->prev_Is;
+							float prev_s = op->prev_s, fb_s = op->fb_s;
+							if (op->flags & OPF_OSC_RESET) {
+								uint32_t phase0 = scratch_u[entry_of<W, T>(0)];
+								prev_Is = herp_lookup(tab, phase0 - SLEN);
+								double Is0 = herp_lookup(tab, phase0);
+								prev_s = wosc_diff(Is0, prev_Is, (int32_t)SLEN, wc.diff_scale, wc.diff_offset);
+								prev_Is = Is0;
+								prev_phase = phase0;
+							}
+							for (uint32_t j = 0; j < len; ++j) {
+								const uint32_t e = entry_of<W, T>(j);
+								uint32_t phase = scratch_u[e];
+								if (selfmod) {
+									float pma = smS ? smS[e] : line_value(plb, j, 1.f);
+									phase += rint32w(fb_s * pma * 0x1p31f);
+								}
+								int32_t d = (int32_t)(phase - prev_phase);
+								float sv;
+								if (d == 0) {
+									sv = prev_s;
+								} else {
+									double Isv = herp_lookup(tab, phase);
+									sv = wosc_diff(Isv, prev_Is, d, wc.diff_scale, wc.diff_offset);
+									prev_Is = Isv; prev_s = sv; prev_phase = phase;
+								}
+								scratch[e] = sv;
+								if (selfmod) fb_s = (fb_s + sv) * 0.5f;
+							}
+							op->phase += grand;
+							op->prev_phase = prev_phase;
+							op->prev_Is = prev_Is;
+							op->prev_s = prev_s;
+							op->fb_s = fb_s;
+							op->flags &= ~OPF_OSC_RESET;
+						}
+						__syncthreads();
+#pragma unroll
+						for (int k = 0; k < T; ++k)
+							if (owned[k]) s[k] = scratch[w * G::NP + p0 + k];
+					}
+				} else if (type == OT_RASEG) {
+					/* ---- rasg.h:165-222 cycle|phase counter (post-increment) */
+					const bool rate2x = (op->flags & OPF_RATE2X) != 0;
+					const float coeff = rate2x ? op->coeff * 2 : op->coeff;
+					const float phase_scale = rate2x ? 0x1p31f * 2 : 0x1p31f;
+					const RasParams rp = ras_params(op->ras_func, op->ras_flags, op->ras_level,
+							op->ras_alpha, op->wave);
+					unsigned long long inc[T], ofs[T], lane_sum = 0;
+#pragma unroll
+					for (int k = 0; k < T; ++k) {
+						inc[k] = 0; ofs[k] = 0;
+						if (owned[k]) {
+							const int e = w * G::NP + p0 + k;
+							const int j = jbase + k;
+							float f = fslot ? fslot[e]
+							                : line_value(flb, (uint32_t)j, fmul ? fmul[e] : 1.f);
+							inc[k] = (unsigned long long)rint64(coeff * f);
+							ofs[k] = (unsigned long long)pm_offset(pmS != nullptr, fpmS != nullptr,
+									pmS ? pmS[e] : 0.f, fpmS ? fpmS[e] : 0.f, f, phase_scale);
+						}
+						lane_sum += inc[k];
+					}
+					const unsigned long long incl = wave_incl_scan64(lane_sum, l);
+					if (l == 63) misc->tot64[w] = incl;
+					__syncthreads();
+					unsigned long long base = op->cycle_phase, grand = 0;
+#pragma unroll
+					for (int ww = 0; ww < W; ++ww) {
+						unsigned long long t = misc->tot64[ww];
+						if (ww < w) base += t;
+						grand += t;
+					}
+					unsigned long long run = base + (incl - lane_sum);
+					uint32_t cyc[T];
+					float phf[T];
+#pragma unroll
+					for (int k = 0; k < T; ++k) {
+						unsigned long long cp = ofs[k] + run;
+						run += inc[k];
+						ras_split(cp, cyc[k], phf[k]);
+					}
+					if (!selfmod) {
+#pragma unroll
+						for (int k = 0; k < T; ++k)
+							if (owned[k]) s[k] = ras_sample(rp, cyc[k], phf[k]); /* rasg.h:692-743 */
+						wb_grand64 = grand;
+					} else {
+						/* rasg.h:242-280 per-sample form with feedback */
+						uint32_t *tmp = (uint32_t *)(slots + (size_t)st.tmp * G::SLOT);
+#pragma unroll
+						for (int k = 0; k < T; ++k) {
+							if (owned[k]) {
+								scratch[w * G::NP + p0 + k] = phf[k];
+								tmp[w * G::NP + p0 + k] = cyc[k];
+							}
+						}
+						__syncthreads();
+						if (tid == 0 && len > 0) {
+							float fb_s = op->fb_s, prev_s = op->prev_s;
+							for (uint32_t j = 0; j < len; ++j) {
+								const uint32_t e = entry_of<W, T>(j);
+								float pma_v = smS ? smS[e] : line_value(plb, j, 1.f);
+								float pm_a = fb_s * pma_v * 0.5f;
+								float phase = scratch[e] + pm_a;
+								int32_t cycle_adj = (int32_t)floorf(phase);
+								uint32_t cycle = tmp[e] + (uint32_t)cycle_adj;
+								phase -= (float)cycle_adj;
+								float sv = ras_sample(rp, cycle, phase);
+								scratch[e] = sv;
+								fb_s = (fb_s + sv + prev_s) * 0.5f;
+								prev_s = sv;
+							}
+							op->fb_s = fb_s;
+							op->prev_s = prev_s;
+						}
+						wb_grand64 = grand;
+						__syncthreads();
+#pragma unroll
+						for (int k = 0; k < T; ++k)
+							if (owned[k]) s[k] = scratch[w * G::NP + p0 + k];
+					}
+				} else if (type == OT_NOISE) {
+					/* ---- noise.h:41-185 ---------------------------------- */
+					const uint32_t nz = op->wave;
+					const uint32_t n0 = op->noise_n;
+					if (nz == NZ_re) {
+						uint32_t term[T], lane_sum = 0;
+#pragma unroll
+						for (int k = 0; k < T; ++k) {
+							term[k] = owned[k] ? (uint32_t)(((int32_t)ranfast32(n0 + (uint32_t)(jbase + k))) >> 6) : 0u;
+							lane_sum += term[k];
+						}
+						const uint32_t incl = wave_incl_scan(lane_sum, l);
+						if (l == 63) misc->tot32[w] = incl;
+						__syncthreads();
+						uint32_t base = op->noise_prev, grand = 0;
+#pragma unroll
+						for (int ww = 0; ww < W; ++ww) {
+							uint32_t t = misc->tot32[ww];
+							if (ww < w) base += t;
+							grand += t;
+						}
+						uint32_t run = base + (incl - lane_sum);
+#pragma unroll
+						for (int k = 0; k < T; ++k) {
+							run += term[k];
+							if (owned[k]) s[k] = fscalei((uint32_t)foldhd32((int32_t)run), 0x1p-31f);
+						}
+						wb_noise_prev = op->noise_prev + grand; wb_noise_prev_set = true;
+					} else if (nz == NZ_vi) {
+#pragma unroll
+						for (int k = 0; k < T; ++k) {
+							if (owned[k]) {
+								uint32_t j = (uint32_t)(jbase + k);
+								uint32_t s1 = ranfast32(n0 + j);
+								uint32_t s0 = j == 0 ? op->noise_prev : ranfast32(n0 + j - 1);
+								s[k] = fscalei((s1 / 2) - (s0 / 2), 0x1p-31f);
+							}
+						}
+						if (len > 0) { wb_noise_prev = ranfast32(n0 + len - 1); wb_noise_prev_set = true; }
+					} else if (nz == NZ_bv) {
+#pragma unroll
+						for (int k = 0; k < T; ++k) {
+							if (owned[k]) {
+								uint32_t j = (uint32_t)(jbase + k);
+								int32_t s1 = noise_bv_term(n0 + j);
+								int32_t s0 = j == 0 ? (int32_t)op->noise_prev : noise_bv_term(n0 + j - 1);
+								s[k] = (float)(s1 - s0);
+							}
+						}
+						if (len > 0) { wb_noise_prev = (uint32_t)noise_bv_term(n0 + len - 1); wb_noise_prev_set = true; }
+					} else {
+#pragma unroll
+						for (int k = 0; k < T; ++k)
+							if (owned[k]) s[k] = noise_stateless(nz, n0 + (uint32_t)(jbase + k));
+					}
+					(void)0;
+				} else { /* OT_AMP: generator.c:517-518 */
+#pragma unroll
+					for (int k = 0; k < T; ++k) s[k] = 1.f;
+				}
+
+				/* ---- amplitude + combine: generator.c:384-440 ------------ */
+				const bool wave_env = (st.flags & SF_WAVE_ENV) != 0;
+				const bool layer = (st.flags & SF_LAYER) != 0;
+#pragma unroll
+				for (int k = 0; k < T; ++k) {
+					if (owned[k]) {
+						const int e = w * G::NP + p0 + k;
+						float a = ampS ? ampS[e] : line_value(alb, (uint32_t)(jbase + k), 1.f);
+						float d = layer ? out[e] : 0.f;
+						slot_put<W, T>(out, w, p0 + k, mix_combine(d, s[k], a, wave_env, layer));
+					}
+				}
+				__syncthreads(); /* all reads of the operator state are done */
+				if (tid == 0) {
+					if (type == OT_RASEG) op->cycle_phase += wb_grand64;
+					if (type == OT_NOISE) {
+						op->noise_n += len;
+						if (wb_noise_prev_set) op->noise_prev = wb_noise_prev;
+					}
+					if (f_inline) {
+						op->line[L_FREQ] = fls;
+						LineState l2 = op->line[L_FREQ2];
+						line_skip(l2, len);
+						op->line[L_FREQ2] = l2;
+					}
+					if (a_inline) {
+						op->line[L_AMP] = als;
+						LineState l2 = op->line[L_AMP2];
+						line_skip(l2, len);
+						op->line[L_AMP2] = l2;
+					}
+					if (is_osc && (st.flags & SF_SM_INLINE)) op->line[L_PMA] = pls;
+				}
+				break;
+			}
+			case ST_VOICE: { /* generator.c:749-788, mixing itself is mix_kernel */
+				const float *src = slots + (size_t)st.out * G::SLOT;
+				const float *panS = st.pm != NO_SLOT ? slots + (size_t)st.pm * G::SLOT : nullptr;
+				LineState pl = op->line[L_PAN];
+				LineBlock plb2;
+				const bool pan_goal = !panS && (pl.flags & LP_GOAL);
+				if (!panS) {
+					if (pan_goal) plb2 = line_begin(pl, len, false, 0.f);
+					else line_skip(pl, len);
+				}
+#pragma unroll
+				for (int k = 0; k < T; ++k) {
+					int j = jbase + k;
+					if (p0 + k >= 1 && j < (int)len) {
+						const int e = w * G::NP + p0 + k;
+						vrow[done + j] = src[e];
+						if (prow)
+							prow[done + j] = panS ? panS[e]
+								: (pan_goal ? line_value(plb2, (uint32_t)j, 1.f) : pl.v0);
+					}
+				}
+				__syncthreads();
+				if (tid == 0 && !panS) op->line[L_PAN] = pl;
+				produced += len;
+				break;
+			}
+			default: break;
+			}
+
+			if (st.flags & SF_END) { /* generator.c:719-728 */
+				if (!(op->flags & OPF_TIME_INF)) {
+					uint32_t outer;
+					if (st.flags & SF_BEGIN) outer = parent_len;
+					else outer = misc->len_stack[depth - 1];
+					if (!(st.flags & SF_LAYER) && st.kind == ST_OSC) {
+						float *out = slots + (size_t)st.out * G::SLOT;
+#pragma unroll
+						for (int k = 0; k < T; ++k) {
+							int j = jbase + k;
+							if (p0 + k >= 1 && j >= (int)len && j < (int)outer)
+								slot_put<W, T>(out, w, p0 + k, 0.f);
+						}
+					}
+				}
+				--depth;
+				uint32_t restored = (st.flags & SF_BEGIN) ? parent_len : misc->len_stack[depth];
+				__syncthreads(); /* time/len reads above precede the update */
+				if (tid == 0 && !(op->flags & OPF_TIME_INF)) op->time -= len;
+				if (depth == 0) {
+					/* carrier finished: the voice-level steps run for its length */
+					cur_len = len;
+					if (len == 0) block_ended = true; /* generator.c:842 */
+				} else {
+					cur_len = restored;
+				}
+			}
+			__syncthreads();
+		}
+		done += blen;
+	}
+
+	/* rows are read up to the stream's write_len: silence after this voice ends */
+	for (uint32_t i = produced + tid; i < P.seg_len; i += 64 * W) {
+		vrow[i] = 0.f;
+		if (prow) prow[i] = 0.f;
+	}
+	if (tid == 0) {
+		VoiceOut vo;
+		vo.pan_const = ops[vd.carr_local].line[L_PAN].v0;
+		vo.has_pan = prow ? 1u : 0u;
+		P.vinfo[vd.out_row] = vo;
+	}
+	__syncthreads();
+	for (uint32_t i = tid; i < vd.nops * 64; i += 64 * W)
+		((uint32_t *)&P.ops[my_ids[i >> 6]])[i & 63] = ((const uint32_t *)ops)[i];
+}
+
+struct MixStream {
+	uint32_t first_row, n_rows;
+	float amp_scale;
+	uint32_t write_len;
+	int16_t *pcm; /* stream's PCM row */
+};
+
+struct MixParams {
+	const MixStream *streams;
+	const float *vout;
+	const float *pan;
+	const VoiceOut *vinfo;
+	const VoiceDesc *voices;
+	uint32_t row_stride;
+	uint32_t pcm_offset;
+	uint32_t stereo;
+};
+
+/* generator.c:749-825: ordered voice sum (ref-build association) and PCM. */
+__global__ void __launch_bounds__(256) mix_kernel(MixParams P) {
+	const MixStream ms = P.streams[blockIdx.y];
+	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= ms.write_len) return;
+	float L = 0.f, R = 0.f;
+	for (uint32_t r = 0; r < ms.n_rows; ++r) {
+		const uint32_t row = ms.first_row + r;
+		const VoiceOut vo = P.vinfo[row];
+		float sv = P.vout[(size_t)row * P.row_stride + i] * ms.amp_scale;
+		float pan = vo.pan_const;
+		if (vo.has_pan) pan = P.pan[(size_t)P.voices[row].pan_dynamic_row * P.row_stride + i];
+		float s_r = sv * pan;
+		L = (L + sv) - s_r;
+		R = (R + sv) + s_r;
+	}
+	if (P.stereo) {
+		int16_t *d = ms.pcm + 2 * (size_t)(P.pcm_offset + i);
+		d[0] = pcm16(L);
+		d[1] = pcm16(R);
+	} else {
+		ms.pcm[P.pcm_offset + i] = pcm16((L + R) * 0.5f);
+	}
+}
+
+__global__ void event_kernel(DevOp *ops, const OpUpdate *recs, uint32_t n, const WaveConst *wc) {
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	OpUpdate u = recs[i];
+	DevOp o = ops[u.op];
+	apply_update(o, u, wc);
+	ops[u.op] = o;
+}
+
+/* ------------------------------------------------------------------------ */
+/* host side                                                                */
+/* ------------------------------------------------------------------------ */
+
+#define HIP_OK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+	err = std::string(#call) + ": " + hipGetErrorString(e_); return false; } } while (0)
+
+template <typename T> struct DevBuf {
+	T *p = nullptr;
+	size_t cap = 0;
+	bool ensure(size_t n, std::string &err, bool keep = false) {
+		if (n <= cap) return true;
+		size_t want = n + n / 4 + 16;
+		T *q = nullptr;
+		HIP_OK(hipMalloc((void **)&q, want * sizeof(T)));
+		if (keep && p && cap) {
+			hipError_t e = hipMemcpy(q, p, cap * sizeof(T), hipMemcpyDeviceToDevice);
+			if (e != hipSuccess) { err = hipGetErrorString(e); return false; }
+		}
+		if (p) (void)hipFree(p);
+		p = q; cap = want;
+		return true;
+	}
+	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+template <typename T> struct PinBuf { /* page-locked staging for async H2D */
+	T *p = nullptr;
+	size_t cap = 0;
+	bool ensure(size_t n, std::string &err) {
+		if (n <= cap) return true;
+		size_t want = n + n / 4 + 16;
+		if (p) (void)hipHostFree(p);
+		p = nullptr; cap = 0;
+		HIP_OK(hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault));
+		cap = want;
+		return true;
+	}
+	void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+int device_count() {
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+class HipBackendImpl : public HipBackend {
+public:
+	~HipBackendImpl() override {
+		ops_.release(); steps_.release(); op_ids_.release(); voices_.release();
+		vout_.release(); pan_.release(); vinfo_.release(); pcm_.release();
+		recs_.release(); mstreams_.release(); c23_.release(); c01_.release(); wc_.release();
+		h_voices_.release(); h_ms_.release();
+		if (copy_done_) (void)hipEventDestroy(copy_done_);
+		for (auto &e : events_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+		if (stream_) (void)hipStreamDestroy(stream_);
+	}
+
+	bool init(const BackendConfig &cfg, std::string &err) override {
+		cfg_ = cfg;
+		int dev = 0;
+		const char *env = getenv("SAU_AMD_DEVICE");
+		if (env) dev = atoi(env);
+		HIP_OK(hipSetDevice(dev));
+		HIP_OK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+		HIP_OK(hipEventCreateWithFlags(&copy_done_, hipEventDisableTiming));
+		hipDeviceProp_t prop;
+		HIP_OK(hipGetDeviceProperties(&prop, dev));
+		lds_limit_ = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor
+		                                                    : prop.sharedMemPerBlock;
+		if (lds_limit_ > 160 * 1024) lds_limit_ = 160 * 1024;
+		if (const char *ll = getenv("SAU_AMD_LDS_LIMIT")) lds_limit_ = (size_t)atol(ll);
+		const char *wt = getenv("SAU_AMD_GEOMETRY"); /* "8x2" (default) or "4x4" */
+		geo_ = (wt && !strcmp(wt, "4x4")) ? 1 : 0;
+		if (!ops_.ensure(cfg.op_count ? cfg.op_count : 1, err)) return false;
+		HIP_OK(hipMemsetAsync(ops_.p, 0, ops_.cap * sizeof(DevOp), stream_));
+		/* Hermite coefficient tables from the PILUTs (sau/wave.h:127-141) */
+		std::vector<HerpC23> h23((size_t)12 * WAVE_LEN);
+		std::vector<HerpC01> h01((size_t)12 * WAVE_LEN);
+		for (uint32_t wv = 0; wv < 12; ++wv)
+			for (uint32_t i = 0; i < WAVE_LEN; ++i)
+				herp_coeffs(cfg.piluts + (size_t)wv * WAVE_LEN, i,
+						h23[(size_t)wv * WAVE_LEN + i], h01[(size_t)wv * WAVE_LEN + i]);
+		if (!c23_.ensure(h23.size(), err) || !c01_.ensure(h01.size(), err) || !wc_.ensure(12, err))
+			return false;
+		HIP_OK(hipMemcpy(c23_.p, h23.data(), h23.size() * sizeof(HerpC23), hipMemcpyHostToDevice));
+		HIP_OK(hipMemcpy(c01_.p, h01.data(), h01.size() * sizeof(HerpC01), hipMemcpyHostToDevice));
+		HIP_OK(hipMemcpy(wc_.p, cfg.wconst, 12 * sizeof(WaveConst), hipMemcpyHostToDevice));
+		memcpy(wconst_, cfg.wconst, sizeof wconst_);
+		return true;
+	}
+
+	bool reserve_frames(uint32_t max_frames, bool stereo, std::string &err) override {
+		HIP_OK(hipStreamSynchronize(stream_));
+		row_stride_ = (max_frames + 63) & ~63u;
+		pcm_row_ = (size_t)row_stride_ * 2; /* room for stereo */
+		(void)stereo;
+		if (!pcm_.ensure(pcm_row_ * cfg_.n_streams, err)) return false;
+		HIP_OK(hipMemset(pcm_.p, 0, pcm_.cap * sizeof(int16_t)));
+		vout_rows_ = 0; /* re-sized on the next render */
+		return true;
+	}
+
+	bool upload_plans(const Step *steps, size_t n_steps, const uint32_t *op_ids, size_t n_ids,
+			std::string &err) override {
+		HIP_OK(hipStreamSynchronize(stream_));
+		if (!steps_.ensure(n_steps ? n_steps : 1, err) || !op_ids_.ensure(n_ids ? n_ids : 1, err))
+			return false;
+		if (n_steps) HIP_OK(hipMemcpy(steps_.p, steps, n_steps * sizeof(Step), hipMemcpyHostToDevice));
+		if (n_ids) HIP_OK(hipMemcpy(op_ids_.p, op_ids, n_ids * sizeof(uint32_t), hipMemcpyHostToDevice));
+		return true;
+	}
+
+	bool apply_updates(const OpUpdate *recs, size_t n, std::string &err) override {
+		if (!n) return true;
+		HIP_OK(hipStreamSynchronize(stream_));
+		if (!recs_.ensure(n, err)) return false;
+		HIP_OK(hipMemcpy(recs_.p, recs, n * sizeof(OpUpdate), hipMemcpyHostToDevice));
+		hipLaunchKernelGGL(event_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream_,
+				ops_.p, recs_.p, (uint32_t)n, wc_.p);
+		HIP_OK(hipGetLastError());
+		return true;
+	}
+
+	bool clear_pcm(uint32_t frames, bool stereo, std::string &err) override {
+		(void)frames; (void)stereo;
+		if (pcm_.p) HIP_OK(hipMemsetAsync(pcm_.p, 0, pcm_row_ * cfg_.n_streams * sizeof(int16_t), stream_));
+		return true;
+	}
+
+	template <int W, int T>
+	bool launch_render(const RenderParams &rp, uint32_t n_voices, size_t lds, std::string &err) {
+		static size_t configured = 0;
+		if (lds > configured) {
+			HIP_OK(hipFuncSetAttribute((const void *)render_kernel<W, T>,
+					hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+			configured = lds;
+		}
+		hipLaunchKernelGGL((render_kernel<W, T>), dim3(n_voices), dim3(64 * W), lds, stream_, rp);
+		HIP_OK(hipGetLastError());
+		return true;
+	}
+
+	bool render(const SegmentDesc &seg, std::string &err) override {
+		if (!seg.n_voices) return true;
+		const uint32_t W = geo_ ? 4 : 8, T = geo_ ? 4 : 2;
+		const size_t slot_bytes = (size_t)W * 64 * T * sizeof(float);
+		/* LDS budget: slots + operator cache + misc, rest for tables */
+		size_t fixed = slot_bytes * seg.n_slots + (size_t)seg.max_ops * sizeof(DevOp) + sizeof(Misc) + 64;
+		if (fixed > lds_limit_) {
+			err = "voice too large for one workgroup's LDS (block buffers + operator states)";
+			return false;
+		}
+		RenderParams rp;
+		memset(&rp, 0, sizeof rp);
+		uint32_t n_tabs = 0;
+		const size_t tab_bytes = (size_t)WAVE_LEN * (sizeof(HerpC23) + sizeof(HerpC01));
+		/* keep two workgroups per CU when possible: cap at half the LDS */
+		size_t budget = lds_limit_ / 2 > fixed ? lds_limit_ / 2 - fixed : 0;
+		if (budget < tab_bytes && lds_limit_ - fixed >= tab_bytes) budget = tab_bytes;
+		for (int wv = 0; wv < 12; ++wv) {
+			rp.tab_of_wave[wv] = -1;
+			if ((seg.wave_mask >> wv) & 1) {
+				if ((n_tabs + 1) * tab_bytes <= budget) {
+					rp.tab_of_wave[wv] = (int8_t)n_tabs;
+					rp.wave_of_tab[n_tabs] = (uint8_t)wv;
+					++n_tabs;
+				}
+			}
+		}
+		const size_t lds = n_tabs * tab_bytes + fixed;
+		/* device buffers */
+		if (!voices_.ensure(seg.n_voices, err) || !vinfo_.ensure(seg.n_voices, err)) return false;
+		if (seg.n_voices > vout_rows_ || !vout_.p) {
+			HIP_OK(hipStreamSynchronize(stream_));
+			if (!vout_.ensure((size_t)seg.n_voices * row_stride_, err)) return false;
+			vout_rows_ = seg.n_voices;
+		}
+		if (seg.n_pan_rows && !pan_.ensure((size_t)seg.n_pan_rows * row_stride_, err)) return false;
+		if (!mstreams_.ensure(seg.n_streams, err)) return false;
+		/* descriptors go through page-locked staging that is reused once the
+		 * previous segment's copies have left it */
+		if (copy_pending_) { HIP_OK(hipEventSynchronize(copy_done_)); copy_pending_ = false; }
+		if (!h_voices_.ensure(seg.n_voices, err) || !h_ms_.ensure(seg.n_streams, err)) return false;
+		memcpy(h_voices_.p, seg.voices, seg.n_voices * sizeof(VoiceDesc));
+		HIP_OK(hipMemcpyAsync(voices_.p, h_voices_.p, seg.n_voices * sizeof(VoiceDesc),
+				hipMemcpyHostToDevice, stream_));
+		MixStream *ms = h_ms_.p;
+		uint32_t max_write = 0;
+		for (uint32_t s = 0; s < seg.n_streams; ++s) {
+			ms[s].first_row = seg.streams[s].first_voice;
+			ms[s].n_rows = seg.streams[s].n_voices;
+			ms[s].amp_scale = seg.streams[s].amp_scale;
+			ms[s].write_len = seg.streams[s].write_len;
+			ms[s].pcm = pcm_.p + pcm_row_ * s;
+			if (ms[s].write_len > max_write) max_write = ms[s].write_len;
+		}
+		HIP_OK(hipMemcpyAsync(mstreams_.p, ms, seg.n_streams * sizeof(MixStream),
+				hipMemcpyHostToDevice, stream_));
+		HIP_OK(hipEventRecord(copy_done_, stream_));
+		copy_pending_ = true;
+		rp.voices = voices_.p; rp.steps = steps_.p; rp.op_ids = op_ids_.p; rp.ops = ops_.p;
+		rp.vout = vout_.p; rp.pan = pan_.p; rp.vinfo = vinfo_.p;
+		rp.g_c23 = c23_.p; rp.g_c01 = c01_.p;
+		rp.row_stride = row_stride_; rp.seg_len = seg.len;
+		rp.n_slots = seg.n_slots; rp.max_ops = seg.max_ops; rp.n_tabs = n_tabs;
+		memcpy(rp.wc, wconst_, sizeof wconst_);
+		TimedPair *tp = timing_on_ ? new_pair() : nullptr;
+		if (tp) (void)hipEventRecord(tp->a, stream_);
+		bool ok = geo_ ? launch_render<4, 4>(rp, seg.n_voices, lds, err)
+		               : launch_render<8, 2>(rp, seg.n_voices, lds, err);
+		if (!ok) return false;
+		if (tp) (void)hipEventRecord(tp->b, stream_);
+		if (max_write) {
+			MixParams mp;
+			mp.streams = mstreams_.p; mp.vout = vout_.p; mp.pan = pan_.p; mp.vinfo = vinfo_.p;
+			mp.voices = voices_.p; mp.row_stride = row_stride_; mp.pcm_offset = seg.pcm_offset;
+			mp.stereo = seg.stereo ? 1 : 0;
+			TimedPair *tm = timing_on_ ? new_pair() : nullptr;
+			if (tm) { tm->is_mix = true; (void)hipEventRecord(tm->a, stream_); }
+			hipLaunchKernelGGL(mix_kernel, dim3((max_write + 255) / 256, seg.n_streams), dim3(256), 0,
+					stream_, mp);
+			HIP_OK(hipGetLastError());
+			if (tm) (void)hipEventRecord(tm->b, stream_);
+		}
+		return true;
+	}
+
+	bool fetch_pcm(uint32_t stream, int16_t *dst, uint32_t frames, bool stereo, std::string &err) override {
+		HIP_OK(hipMemcpyAsync(dst, pcm_.p + pcm_row_ * stream,
+				(size_t)frames * (stereo ? 2 : 1) * sizeof(int16_t), hipMemcpyDeviceToHost, stream_));
+		HIP_OK(hipStreamSynchronize(stream_));
+		return true;
+	}
+
+	const int16_t *device_pcm(uint32_t stream) override { return pcm_.p ? pcm_.p + pcm_row_ * stream : nullptr; }
+
+	bool sync(std::string &err) override {
+		HIP_OK(hipStreamSynchronize(stream_));
+		return true;
+	}
+
+	void timing(double *render_ms, double *mix_ms, uint64_t *launches, bool reset) override {
+		if (!timing_on_) { timing_on_ = true; }
+		(void)hipStreamSynchronize(stream_);
+		drain_pairs();
+		if (render_ms) *render_ms = acc_render_ms_;
+		if (mix_ms) *mix_ms = acc_mix_ms_;
+		if (launches) *launches = acc_launches_;
+		if (reset) { acc_render_ms_ = acc_mix_ms_ = 0; acc_launches_ = 0; }
+	}
+
+	void *stream_handle() override { return (void *)stream_; }
+
+private:
+	struct TimedPair { hipEvent_t a, b; bool is_mix; bool used; };
+	TimedPair *new_pair() {
+		if (n_used_ == events_.size()) {
+			if (events_.size() >= 4096) { (void)hipStreamSynchronize(stream_); drain_pairs(); }
+			else {
+				TimedPair p; p.is_mix = false; p.used = false;
+				if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return nullptr;
+				events_.push_back(p);
+			}
+		}
+		TimedPair *p = &events_[n_used_++];
+		p->is_mix = false; p->used = true;
+		return p;
+	}
+	void drain_pairs() {
+		for (size_t i = 0; i < n_used_; ++i) {
+			float ms = 0;
+			if (hipEventElapsedTime(&ms, events_[i].a, events_[i].b) == hipSuccess) {
+				if (events_[i].is_mix) acc_mix_ms_ += ms;
+				else { acc_render_ms_ += ms; ++acc_launches_; }
+			}
+		}
+		n_used_ = 0;
+	}
+
+	BackendConfig cfg_;
+	hipStream_t stream_ = nullptr;
+	size_t lds_limit_ = 64 * 1024;
+	int geo_ = 0;
+	uint32_t row_stride_ = 0;
+	size_t pcm_row_ = 0;
+	uint32_t vout_rows_ = 0;
+	WaveConst wconst_[12];
+	DevBuf<DevOp> ops_;
+	DevBuf<Step> steps_;
+	DevBuf<uint32_t> op_ids_;
+	DevBuf<VoiceDesc> voices_;
+	DevBuf<float> vout_, pan_;
+	DevBuf<VoiceOut> vinfo_;
+	DevBuf<int16_t> pcm_;
+	DevBuf<OpUpdate> recs_;
+	DevBuf<MixStream> mstreams_;
+	DevBuf<HerpC23> c23_;
+	DevBuf<HerpC01> c01_;
+	DevBuf<WaveConst> wc_;
+	PinBuf<VoiceDesc> h_voices_;
+	PinBuf<MixStream> h_ms_;
+	hipEvent_t copy_done_ = nullptr;
+	bool copy_pending_ = false;
+	std::vector<TimedPair> events_;
+	size_t n_used_ = 0;
+	bool timing_on_ = false;
+	double acc_render_ms_ = 0, acc_mix_ms_ = 0;
+	uint64_t acc_launches_ = 0;
+};
+
+HipBackend *create_hip_backend(std::string &err) {
+	if (device_count() <= 0) {
+		err = "no HIP device available (this backend has no CPU fallback)";
+		return nullptr;
+	}
+	return new HipBackendImpl();
+}
+
+} /* namespace sauhip */

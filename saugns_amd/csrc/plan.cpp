@@ -1,0 +1,216 @@
+/* plan.cpp -- flatten one voice's operator graph into a step list.
+ *
+ * The reference evaluates a voice by recursion (generator.c:675-729 run_block,
+ * 548-664 run_block_wosc/rasg, 505-541 amp/noise, 448-498 parameter helpers,
+ * 749-788 mix_add).  Here the same post-order walk is done once per graph
+ * change on the host and recorded as steps over numbered block buffers
+ * ("slots"); the device then replays the steps for every block.  Buffer
+ * numbers are allocated by liveness instead of the reference's fixed
+ * 7-per-nesting-level layout, and the phase buffer is never materialised
+ * (phase accumulation, lookup and mixing are fused into ST_OSC).
+ */
+#include "engine.h"
+#include <unordered_map>
+
+namespace sauengine {
+
+namespace {
+
+struct Compiler {
+	const std::vector<OpMirror> &ops;
+	VoicePlan &out;
+	std::string &err;
+	std::vector<uint32_t> path;     /* operators being evaluated (cycle guard) */
+	std::unordered_map<uint32_t, uint32_t> local;
+	bool used[256] = {};
+	uint32_t high = 0;
+	bool failed = false;
+
+	Compiler(const std::vector<OpMirror> &o, VoicePlan &p, std::string &e)
+		: ops(o), out(p), err(e) { used[SCRATCH_SLOT] = true; }
+
+	uint8_t alloc() {
+		for (uint32_t s = 1; s < 250; ++s) {
+			if (!used[s]) {
+				used[s] = true;
+				if (s > high) high = s;
+				return (uint8_t)s;
+			}
+		}
+		if (!failed) { failed = true; err = "operator graph needs more than 249 block buffers"; }
+		return 1;
+	}
+	void release(uint8_t s) { if (s != NO_SLOT) used[s] = false; }
+
+	uint32_t local_of(uint32_t op) {
+		auto it = local.find(op);
+		if (it != local.end()) return it->second;
+		uint32_t idx = (uint32_t)out.op_ids.size();
+		out.op_ids.push_back(op);
+		local[op] = idx;
+		return idx;
+	}
+
+	Step &emit(uint8_t kind, uint32_t op_local) {
+		Step s;
+		s.kind = kind; s.flags = 0;
+		s.out = s.freq = s.fmul = s.pm = s.fpm = s.amp = s.sm = NO_SLOT;
+		s.which = 0; s.tmp = NO_SLOT; s.pad = 0;
+		s.op = op_local;
+		out.steps.push_back(s);
+		return out.steps.back();
+	}
+
+	static uint32_t count(const sauProgramIDArr *a) { return a ? a->count : 0; }
+
+	void children(const sauProgramIDArr *ids, uint8_t dst, uint8_t freq,
+			bool wave_env, bool layer_all) {
+		for (uint32_t i = 0; i < count(ids); ++i)
+			eval(ids->ids[i], dst, freq, wave_env, layer_all ? true : (i > 0), false);
+	}
+
+	/* parameter with optional range modulation + additive modulators into a
+	 * slot: generator.c:448-477. Returns with `dst` holding the values. */
+	void param_to_slot(uint32_t lop, uint32_t line, uint32_t line2, uint8_t dst,
+			uint8_t mul, uint8_t child_freq, const sauProgramIDArr *mods,
+			const sauProgramIDArr *r_mods, bool &first) {
+		Step &s = emit(ST_LINE, lop);
+		s.which = (uint8_t)line; s.out = dst; s.fmul = mul;
+		s.tmp = (uint8_t)line2;
+		if (first) { s.flags |= SF_BEGIN; first = false; }
+		if (count(r_mods) == 0) {
+			s.flags |= SF_SKIP2;
+		} else {
+			uint8_t r = alloc();
+			Step &s2 = emit(ST_LINE, lop);
+			s2.which = (uint8_t)line2; s2.out = r; s2.fmul = mul; s2.tmp = (uint8_t)line2;
+			uint8_t m = alloc();
+			children(r_mods, m, child_freq, true, false);
+			Step &l = emit(ST_LERP, lop);
+			l.out = dst; l.freq = r; l.pm = m;
+			release(m); release(r);
+		}
+		if (count(mods) > 0)
+			children(mods, dst, child_freq, false, true);
+	}
+
+	/* One operator, combined into slot `dst`. Returns the slot that holds its
+	 * frequency block when keep_freq (caller releases it), else NO_SLOT. */
+	uint8_t eval(uint32_t op, uint8_t dst, uint8_t parent_freq, bool wave_env,
+			bool layer, bool keep_freq) {
+		if (failed) return NO_SLOT;
+		for (uint32_t p : path) {
+			if (p == op) { /* generator.c:685-689 */
+				Step &z = emit(ST_ZERO, local_of(op));
+				z.out = dst;
+				return NO_SLOT;
+			}
+		}
+		if (op >= ops.size() || !ops[op].inited) {
+			if (!layer) { Step &z = emit(ST_ZERO, 0); z.out = dst; }
+			return NO_SLOT;
+		}
+		if (path.size() >= MAX_NEST) {
+			failed = true; err = "operator nesting deeper than 64";
+			return NO_SLOT;
+		}
+		const OpMirror &m = ops[op];
+		const uint32_t lop = local_of(op);
+		path.push_back(op);
+		bool first = true;
+		const bool is_osc = (m.type == SAU_POPT_N_wave || m.type == SAU_POPT_N_raseg);
+		const sauProgramIDArr *amods = m.mods[SAU_POP_N_amod];
+		const sauProgramIDArr *ramods = m.mods[SAU_POP_N_ramod];
+		uint8_t F = NO_SLOT, P = NO_SLOT, Q = NO_SLOT, A = NO_SLOT, S = NO_SLOT, T = NO_SLOT;
+		uint8_t osc_flags = 0;
+		if (is_osc) {
+			const sauProgramIDArr *fmods = m.mods[SAU_POP_N_fmod];
+			const sauProgramIDArr *rfmods = m.mods[SAU_POP_N_rfmod];
+			const sauProgramIDArr *pmods = m.mods[SAU_POP_N_pmod];
+			const sauProgramIDArr *fpmods = m.mods[SAU_POP_N_fpmod];
+			const sauProgramIDArr *apmods = m.mods[SAU_POP_N_apmod];
+			bool any_child = count(fmods) || count(rfmods) || count(pmods) ||
+				count(fpmods) || count(amods) || count(ramods) || count(apmods);
+			if (any_child || keep_freq) {
+				F = alloc();
+				param_to_slot(lop, L_FREQ, L_FREQ2, F, parent_freq, F, fmods, rfmods, first);
+			} else {
+				osc_flags |= SF_SKIP_FREQ2;
+			}
+			if (count(pmods)) { P = alloc(); children(pmods, P, F, false, false); }
+			if (count(fpmods)) { Q = alloc(); children(fpmods, Q, F, false, false); }
+			if (count(amods) || count(ramods)) {
+				A = alloc();
+				param_to_slot(lop, L_AMP, L_AMP2, A, NO_SLOT, F, amods, ramods, first);
+			} else {
+				osc_flags |= SF_SKIP_AMP2;
+			}
+			if (count(apmods)) { /* generator.c:479-498 */
+				S = alloc();
+				Step &sm = emit(ST_SMLINE, lop);
+				sm.out = S;
+				if (first) { sm.flags |= SF_BEGIN; first = false; }
+				children(apmods, S, F, false, true);
+			} else if (m.line_set & (1u << L_PMA)) {
+				osc_flags |= SF_SM_INLINE;
+			}
+			if (m.type == SAU_POPT_N_raseg && (S != NO_SLOT || (osc_flags & SF_SM_INLINE)))
+				T = alloc();
+			if (m.type == SAU_POPT_N_wave)
+				out.wave_mask |= 1ull << (m.wave & 63);
+		} else {
+			if (count(amods) || count(ramods)) {
+				A = alloc();
+				param_to_slot(lop, L_AMP, L_AMP2, A, NO_SLOT, NO_SLOT, amods, ramods, first);
+			} else {
+				osc_flags |= SF_SKIP_AMP2;
+			}
+		}
+		Step &o = emit(ST_OSC, lop);
+		o.out = dst; o.freq = F; o.fmul = parent_freq; o.pm = P; o.fpm = Q;
+		o.amp = A; o.sm = S; o.tmp = T;
+		o.flags = osc_flags | SF_END;
+		if (first) o.flags |= SF_BEGIN;
+		if (wave_env) o.flags |= SF_WAVE_ENV;
+		if (layer) o.flags |= SF_LAYER;
+		release(T); release(S); release(A); release(Q); release(P);
+		if (!keep_freq) { release(F); F = NO_SLOT; }
+		path.pop_back();
+		return F;
+	}
+};
+
+} /* namespace */
+
+bool compile_voice_plan(const std::vector<OpMirror> &ops, uint32_t carrier,
+		VoicePlan &out, std::string &err) {
+	out.steps.clear();
+	out.op_ids.clear();
+	out.wave_mask = 0;
+	Compiler c(ops, out, err);
+	if (carrier >= ops.size() || !ops[carrier].inited) {
+		err = "voice carrier operator was never initialised";
+		return false;
+	}
+	const OpMirror &cm = ops[carrier];
+	const sauProgramIDArr *camods = cm.mods[SAU_POP_N_camod];
+	out.has_camods = camods && camods->count > 0;
+	out.carr_local = c.local_of(carrier);
+	uint8_t V = c.alloc();
+	/* generator.c:833-846 run_voice -> run_block(carrier, NULL, false, false) */
+	uint8_t F = c.eval(carrier, V, NO_SLOT, false, false, out.has_camods);
+	uint8_t Pn = NO_SLOT;
+	if (out.has_camods) { /* generator.c:756-771 */
+		Pn = c.alloc();
+		Step &pl = c.emit(ST_LINE, out.carr_local);
+		pl.which = L_PAN; pl.out = Pn; pl.tmp = L_PAN;
+		c.children(camods, Pn, F, false, true);
+	}
+	Step &v = c.emit(ST_VOICE, out.carr_local);
+	v.out = V; v.pm = Pn;
+	c.release(Pn); c.release(F); c.release(V);
+	out.n_slots = c.high + 1;
+	return !c.failed;
+}
+
+} /* namespace sauengine */

@@ -1,0 +1,651 @@
+/* sau_dev_math.h -- per-sample arithmetic of the generator hot path, written
+ * once for both sides of the PCIe bus: the HIP kernels (kernels.hip) include
+ * it as device code, host code (event application mirror, table builder) and
+ * the test-side sequential plan executor include it as plain C++.
+ *
+ * Every function states the reference expression it reproduces (saugns
+ * v0.4.7 file:line).  Evaluation order is exactly the order written here:
+ * build with -ffp-contract=off and without fast-math.  Where the reference's
+ * own build (gcc -O3 -ffast-math on sau/line.c and sau/generator.c)
+ * evaluates in a different association than its C source, the association of
+ * that build's main loops is used (marked "ref-build form"); see DESIGN.md
+ * "Arithmetic contract".
+ */
+#ifndef SAU_DEV_MATH_H
+#define SAU_DEV_MATH_H
+
+#include <stdint.h>
+#include <math.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define SAU_HD __host__ __device__ __forceinline__
+#else
+#define SAU_HD static inline
+#endif
+
+namespace saudev {
+
+/* ---- constants of the data contract (include/sau_abi.h) ----------------- */
+enum : uint32_t {
+	LP_STATE = 1, LP_STATE_RATIO = 2, LP_GOAL = 4, LP_GOAL_RATIO = 8,
+	LP_TYPE = 16, LP_TIME = 32, LP_TIME_IF_NEW = 64,
+};
+enum : uint32_t {
+	LN_cos = 0, LN_lin, LN_sah, LN_exp, LN_log, LN_xpe, LN_lge, LN_sqe,
+	LN_cub, LN_smo, LN_ncl, LN_nhl, LN_uwh, LN_COUNT
+};
+enum : uint32_t { OT_AMP = 0, OT_NOISE, OT_WAVE, OT_RASEG };
+enum : uint32_t { NZ_wh = 0, NZ_gw, NZ_bw, NZ_tw, NZ_re, NZ_vi, NZ_bv };
+enum : uint32_t {
+	RF_URAND = 0, RF_GAUSS, RF_BIN, RF_TERN, RF_FIXED, RF_ADDREC
+};
+enum : uint32_t {
+	RO_PERLIN = 1, RO_HALFSHAPE = 2, RO_ZIGZAG = 4, RO_SQUARE = 8, RO_VIOLET = 16,
+	RO_LINE_SET = 1 << 6, RO_FUNC_SET = 1 << 7, RO_LEVEL_SET = 1 << 8,
+	RO_ASUBVAL_SET = 1 << 9,
+};
+
+constexpr uint32_t WAVE_LEN = 2048;
+constexpr uint32_t WAVE_MASK = WAVE_LEN - 1;
+constexpr uint32_t SLEN_BITS = 21;           /* sau/wave.h:27 */
+constexpr uint32_t SLEN = 1u << SLEN_BITS;
+
+/* ---- integer helpers ----------------------------------------------------- */
+
+/* sau/math.h:63-64 + generator.c:17: llrintf, kept as int64 */
+SAU_HD int64_t rint64(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	return __float2ll_rn(x);
+#else
+	return llrintf(x);
+#endif
+}
+/* ... and wrapped into a 32-bit phase */
+SAU_HD uint32_t rint32w(float x) { return (uint32_t)rint64(x); }
+
+/* sau/math.h:297-303 */
+SAU_HD uint32_t ranfast32(uint32_t n) {
+	uint32_t s = n * 0x9e3779b9u;
+	s ^= s >> 14;
+	s = (s | 1u) * s;
+	s ^= s >> 13;
+	return s;
+}
+/* sau/math.h:283-285 */
+SAU_HD uint32_t mcg32(uint32_t seed) { return seed * 0xe47135u; }
+/* sau/math.h:94-96 */
+SAU_HD int32_t sar32(int32_t x, int s) { return x < 0 ? ~(~x >> s) : x >> s; }
+/* sau/math.h:112-118 */
+SAU_HD int32_t foldhd32(int32_t x) {
+	uint32_t s = (uint32_t)x;
+	if (s + (1u << 29) > (1u << 31))
+		s = (1u << 31) + (1u << 30) - s;
+	s = (s - (1u << 29)) * 2u;
+	return (int32_t)s;
+}
+SAU_HD int odd_sign(uint32_t n) { return 1 - (int)((n & 1u) * 2u); } /* math.h:89 */
+SAU_HD float fscalei(uint32_t i, float sc) { return (float)(int32_t)i * sc; } /* generator.c:19 */
+SAU_HD int32_t divi(uint32_t i, int32_t d) { return ((int32_t)i) / d; }       /* generator.c:20 */
+SAU_HD float bits_f(uint32_t u) { union { uint32_t u; float f; } c; c.u = u; return c.f; }
+SAU_HD uint32_t f_bits(float f) { union { uint32_t u; float f; } c; c.f = f; return c.u; }
+
+/* sau/math.h:366-379 */
+SAU_HD float sinpi_d5f(float x) {
+	const float k0 = +3.14042741234069229463f;
+	const float k1 = -5.13655757476162831091f;
+	const float k2 = +2.29939170159543653372f;
+	float x2 = x * x;
+	return x * (k0 + x2 * (k1 + x2 * k2));
+}
+
+/* ---- ramp shapes --------------------------------------------------------- */
+
+/* sau/line.h:174-183 */
+SAU_HD float sinramp(float x) {
+	const float k0 = +1.5702137061703461473139223358864f;
+	const float k1 = -2.568278787380814155456160152724f;
+	const float k2 = +1.1496958507977182668618673644367f;
+	float x2 = x * x;
+	return x * (k0 + x2 * (k1 + x2 * k2));
+}
+/* sau/line.h:195-200, ref-build form: x3 + ((x*c1 + x2*c2)*(x3 - 1))*x2 */
+SAU_HD float expramp6(float x) {
+	float x2 = x * x;
+	float x3 = x2 * x;
+	return x3 + ((x * (629.f / 1792.f) + x2 * (1163.f / 1792.f)) * (x3 + -1.f)) * x2;
+}
+
+/* Scalar shape value, sau/line.h:153-266 (ref-build forms for cub smo ncl nhl
+ * and, through expramp6, exp log xpe lge). */
+SAU_HD float shape_val(uint32_t type, float x, float a, float b) {
+	switch (type) {
+	default:
+	case LN_sah: return a;
+	case LN_lin: return a + (b - a) * x;
+	case LN_cos: return a + (b - a) * (sinramp(x - 0.5f) + 0.5f);
+	case LN_exp:
+		return (a > b) ? b + (a - b) * expramp6(1.f - x) : a + (b - a) * expramp6(x);
+	case LN_log:
+		return (a < b) ? b + (a - b) * expramp6(1.f - x) : a + (b - a) * expramp6(x);
+	case LN_xpe: return b + (a - b) * expramp6(1.f - x);
+	case LN_lge: return a + (b - a) * expramp6(x);
+	case LN_sqe: { float y = 1.f - x; return b + (a - b) * (y * y); }
+	case LN_cub: {
+		float y = (0.5f - x) * 2;
+		return b + (y * y * y + 1.f) * ((a - b) * 0.5f);
+	}
+	case LN_smo:
+		return a + (((b - a) * x) * (x * x)) * ((x * 6.f + -15.f) * x + 10.f);
+	case LN_uwh: {
+		int32_t s = (int32_t)ranfast32(f_bits(x));
+		return a + (b - a) * (0.5f + (0.5f * 0x1p-31f) * (float)s);
+	}
+	case LN_ncl: {
+		int32_t s = (int32_t)ranfast32(f_bits(x));
+		float t = ((x + x) + -3.f) * x + 1.f;
+		return a + (b - a) * ((t * (float)s) * (x * (0.5f * 0x1p-31f)) + x);
+	}
+	case LN_nhl: {
+		int32_t s = (int32_t)ranfast32(f_bits(x));
+		return a + (b - a) * (((float)s * (1.f - x)) * (x * 0x1p-31f) + x);
+	}
+	}
+}
+
+/* Parameters of one timed sweep, hoisted out of the per-sample evaluation
+ * exactly as the reference's fill functions hoist them (sau/line.c:65-281). */
+struct Sweep {
+	uint32_t type;   /* LN_* with exp/log already resolved to xpe/lge */
+	float v0, vt;
+	uint32_t pos;    /* index of sample 0 of this block inside the sweep */
+	int32_t adj_pos; /* pos - time/2 */
+	float inv_time;  /* 1.f / time */
+	float k;         /* shape-specific hoisted factor */
+	float vm, vd;
+};
+
+SAU_HD Sweep sweep_setup(uint32_t type, float v0, float vt, uint32_t pos, uint32_t time) {
+	Sweep s;
+	if (type == LN_exp) type = (v0 > vt) ? LN_xpe : LN_lge; /* sau/line.c:125-131 */
+	else if (type == LN_log) type = (v0 < vt) ? LN_xpe : LN_lge; /* 142-148 */
+	s.type = type; s.v0 = v0; s.vt = vt; s.pos = pos;
+	s.adj_pos = (int32_t)(pos - (time / 2));
+	s.inv_time = 1.f / (float)time;
+	s.vm = (v0 + vt) * 0.5f;
+	s.vd = (vt - v0);
+	s.k = 0.f;
+	switch (type) {
+	case LN_lin: s.k = s.vd * s.inv_time; break;          /* ref-build hoist */
+	case LN_cub: s.k = -2 * s.inv_time; break;            /* sau/line.c:206 */
+	case LN_uwh: s.vd = (vt - v0) * (0.5f / (float)INT32_MAX); break; /* :230 */
+	default: break;
+	}
+	return s;
+}
+
+/* Value of sample i of the block (i + pos inside the sweep), before any
+ * ratio multiplication. sau/line.c:27-37,65-281 in ref-build forms. */
+SAU_HD float sweep_value(const Sweep &s, uint32_t i) {
+	switch (s.type) {
+	default:
+	case LN_sah: return s.v0;
+	case LN_lin: return s.vm + s.k * (float)((int32_t)i + s.adj_pos);
+	case LN_cos: {
+		float x = (float)((int32_t)i + s.adj_pos) * s.inv_time;
+		float x2 = x * x;
+		return s.vm + (s.vd * x) * ((x2 * +1.1496958507977182668618673644367f
+			+ -2.568278787380814155456160152724f) * x2
+			+ +1.5702137061703461473139223358864f);
+	}
+	case LN_xpe: case LN_lge: case LN_smo: {
+		float x = (float)(i + s.pos) * s.inv_time;
+		return shape_val(s.type, x, s.v0, s.vt);
+	}
+	case LN_sqe: {
+		float x = 0.5f - (float)((int32_t)i + s.adj_pos) * s.inv_time;
+		return s.vt + (s.v0 - s.vt) * (x * x);
+	}
+	case LN_cub: {
+		float x = (float)((int32_t)i + s.adj_pos) * s.k;
+		return s.vt + (x * x * x + 1.f) * ((s.v0 - s.vt) * 0.5f);
+	}
+	case LN_uwh: {
+		int32_t r = (int32_t)ranfast32(s.pos + i);
+		return s.vm + s.vd * (float)r;
+	}
+	case LN_ncl: {
+		float x = (float)((int32_t)i + s.adj_pos) * s.inv_time;
+		int32_t r = (int32_t)ranfast32(s.pos + i);
+		float xb0 = x + 0.5f;
+		float t = ((xb0 + xb0) + -3.f) * xb0 + 1.f;
+		return s.vm + s.vd * (((float)r * t) * (xb0 * (0.5f / (float)INT32_MAX)) + x);
+	}
+	case LN_nhl: {
+		float x = (float)((int32_t)i + s.adj_pos) * s.inv_time;
+		int32_t r = (int32_t)ranfast32(s.pos + i);
+		float xb0 = x + 0.5f;
+		return s.vm + s.vd * (((float)r * (1.f - xb0)) * (xb0 * (2 * 0.5f / (float)INT32_MAX)) + x);
+	}
+	}
+}
+
+/* ---- ramp state machine -------------------------------------------------- */
+
+struct LineState { /* device copy of sauLine minus time_ms */
+	float v0, vt;
+	uint32_t pos, end;
+	uint32_t type;  /* LN_* */
+	uint32_t flags; /* LP_* */
+};
+
+/* What one block of `len` samples of a line looks like: samples [0,goal_len)
+ * follow the sweep, the rest hold a constant; each part optionally multiplied
+ * by the ratio buffer. Produced by line_begin(), which also advances the state
+ * exactly as sauLine_run does (sau/line.c:417-445 incl. sauLine_get 349-378). */
+struct LineBlock {
+	Sweep sw;
+	uint32_t goal_len;
+	bool mul_goal, mul_hold;
+	float hold;
+};
+
+/* have_mul: a ratio buffer exists; mul0: its first value (only read when the
+ * state/goal ratio flags disagree, sau/line.c:358-370). */
+SAU_HD LineBlock line_begin(LineState &o, uint32_t len, bool have_mul, float mul0) {
+	LineBlock b;
+	b.goal_len = 0; b.mul_goal = false; b.mul_hold = false; b.hold = 0.f;
+	b.sw = sweep_setup(LN_sah, 0.f, 0.f, 0, 1);
+	bool hold;
+	if (!(o.flags & LP_GOAL)) {
+		/* advance_len, sau/line.c:385-398 */
+		if (o.pos < o.end) {
+			uint32_t l = o.end - o.pos;
+			if (l > len) l = len;
+			o.pos += l;
+		}
+		if (o.pos >= o.end) {
+			o.pos = 0;
+			o.flags &= ~LP_TIME;
+		}
+		hold = true;
+	} else {
+		bool mul = have_mul;
+		if (o.flags & LP_GOAL_RATIO) {
+			if (!(o.flags & LP_STATE_RATIO)) {
+				if (have_mul) o.v0 /= mul0;
+				o.flags |= LP_STATE_RATIO;
+			}
+		} else {
+			if (o.flags & LP_STATE_RATIO) {
+				if (have_mul) o.v0 *= mul0;
+				o.flags &= ~LP_STATE_RATIO;
+			}
+			mul = false;
+		}
+		uint32_t glen = 0;
+		if (o.pos < o.end) {
+			glen = o.end - o.pos;
+			if (glen > len) glen = len;
+			b.sw = sweep_setup(o.type, o.v0, o.vt, o.pos, o.end);
+			b.mul_goal = mul;
+		}
+		b.goal_len = glen;
+		o.pos += glen;
+		hold = (o.pos >= o.end);
+		if (hold) {
+			o.v0 = o.vt;
+			o.pos = 0;
+			o.flags &= ~(LP_GOAL | LP_GOAL_RATIO | LP_TIME);
+		}
+	}
+	if (hold) {
+		b.mul_hold = have_mul && (o.flags & LP_STATE_RATIO);
+		b.hold = o.v0;
+	}
+	return b;
+}
+
+SAU_HD float line_value(const LineBlock &b, uint32_t i, float mul_i) {
+	if (i < b.goal_len) {
+		float v = sweep_value(b.sw, i);
+		return b.mul_goal ? v * mul_i : v;
+	}
+	return b.mul_hold ? b.hold * mul_i : b.hold;
+}
+
+/* sau/line.c:456-473 */
+SAU_HD void line_skip(LineState &o, uint32_t len) {
+	if (o.pos < o.end) {
+		uint32_t l = o.end - o.pos;
+		if (l > len) l = len;
+		o.pos += l;
+	}
+	if (o.pos >= o.end) {
+		o.pos = 0;
+		o.flags &= ~LP_TIME;
+		if (!(o.flags & LP_GOAL))
+			return;
+		o.v0 = o.vt;
+		if (o.flags & LP_GOAL_RATIO) o.flags |= LP_STATE_RATIO;
+		else o.flags &= ~LP_STATE_RATIO;
+		o.flags &= ~(LP_GOAL | LP_GOAL_RATIO);
+	}
+}
+
+/* An update as carried by an event (sauLine by value). sau/line.c:287-332.
+ * end_samples = time_ms converted with the generator's sample rate. */
+struct LineUpdate {
+	float v0, vt;
+	uint32_t end_samples;
+	uint32_t type;
+	uint32_t flags; /* LP_*; 0 = no update */
+};
+
+SAU_HD void line_copy(LineState &o, const LineUpdate &src) {
+	if (!src.flags)
+		return;
+	uint32_t mask = 0;
+	if (src.flags & LP_STATE) {
+		o.v0 = src.v0;
+		mask |= LP_STATE | LP_STATE_RATIO;
+	} else if (o.flags & LP_GOAL) {
+		if (src.flags & LP_GOAL) {
+			/* sauLine_get(o, &f, 1, NULL): value at the current position */
+			LineState t = o;
+			LineBlock b = line_begin(t, 1, false, 0.f);
+			/* line_begin advanced a copy; only the ratio-flag side effect
+			 * of sauLine_get persists in the reference (v0 is untouched
+			 * without a ratio buffer). */
+			if (o.flags & LP_GOAL_RATIO) o.flags |= LP_STATE_RATIO;
+			else o.flags &= ~LP_STATE_RATIO;
+			if (b.goal_len > 0)
+				o.v0 = sweep_value(b.sw, 0);
+			/* else: sauLine_get wrote nothing; reference then reads an
+			 * uninitialised float -- unreachable in practice because a set
+			 * goal always has pos < end between blocks. */
+		}
+	}
+	if (src.flags & LP_GOAL) {
+		o.vt = src.vt;
+		if (src.flags & LP_TIME_IF_NEW)
+			o.end -= o.pos;
+		o.pos = 0;
+		mask |= LP_GOAL | LP_GOAL_RATIO;
+	}
+	if (src.flags & LP_TYPE) {
+		o.type = src.type;
+		mask |= LP_TYPE;
+	}
+	if (!(o.flags & LP_TIME) || !(src.flags & LP_TIME_IF_NEW)) {
+		if (src.flags & LP_TIME) {
+			o.end = src.end_samples;
+			mask |= LP_TIME;
+		}
+	}
+	o.flags &= ~mask;
+	o.flags |= (src.flags & mask);
+}
+
+/* ---- wave oscillator ------------------------------------------------------ */
+
+/* Hermite coefficients of one table index, precomputed from the four taps in
+ * the exact expression order of sauWave_get_herp (sau/wave.h:127-141). c0 and
+ * c1 are exactly representable as f32; c2 and c3 need f64. */
+struct HerpC23 { double c3, c2; };
+struct HerpC01 { float c1, c0; };
+
+SAU_HD void herp_coeffs(const float *lut, uint32_t ind, HerpC23 &hi, HerpC01 &lo) {
+	float s0 = lut[(ind - 1) & WAVE_MASK];
+	float s1 = lut[ind & WAVE_MASK];
+	float s2 = lut[(ind + 1) & WAVE_MASK];
+	float s3 = lut[(ind + 2) & WAVE_MASK];
+	lo.c0 = s1;
+	lo.c1 = (float)(1 / 2.0 * (double)(s2 - s0)); /* halving is exact */
+	hi.c2 = (double)s0 - 5 / 2.0 * (double)s1 + (double)(2 * s2) - 1 / 2.0 * (double)s3;
+	hi.c3 = 1 / 2.0 * (double)(s3 - s0) + 3 / 2.0 * (double)(s1 - s2);
+}
+
+SAU_HD double herp_poly(const HerpC23 &hi, const HerpC01 &lo, uint32_t phase) {
+	double x = (double)((float)(phase & (SLEN - 1)) * (1.f / (float)SLEN));
+	return ((hi.c3 * x + hi.c2) * x + (double)lo.c1) * x + (double)lo.c0;
+}
+
+/* wosc.h:250-256: one differentiated output sample */
+SAU_HD float wosc_diff(double Is, double prev_Is, int32_t phase_diff,
+		float diff_scale, float diff_offset) {
+	double x = (double)(diff_scale / (float)phase_diff);
+	return (float)((Is - prev_Is) * x + (double)diff_offset);
+}
+
+/* Phase offset from the PM inputs, wosc.h:135-169 / rasg.h:165-222 in
+ * ref-build forms. phase_scale is 2^31 (W, R half-shape) or 2^32 (R rate2x). */
+constexpr float FPM_SCALE = (float)(1.0 / 632.45553203367586639978);
+SAU_HD int64_t pm_offset(bool has_pm, bool has_fpm, float pm, float fpm, float f,
+		float phase_scale) {
+	if (has_pm && has_fpm) {
+		float p = pm + ((fpm * f) * FPM_SCALE);
+		return rint64(p * phase_scale);
+	} else if (has_pm) {
+		return rint64(pm * phase_scale);
+	} else if (has_fpm) {
+		return rint64((fpm * f) * (FPM_SCALE * phase_scale));
+	}
+	return 0;
+}
+
+/* ---- noise ---------------------------------------------------------------- */
+
+/* noise.h:61-70 */
+SAU_HD float soft_sqrtm2logp1(float x) {
+	const float k0 = -0.80270565422983103084f;
+	const float k1 = +5.52274428214641442648f;
+	const float k2 = -138.87126103150588693697f;
+	float x2 = x * x;
+	float x4 = x2 * x2;
+	return 0.5f + x * (k0 + x4 * (k1 + x4 * k2));
+}
+/* noise.h:77-81 */
+SAU_HD float ssgauss_dist4(float x) {
+	float x2 = x * x;
+	float gx = (x + x2) * 0.5f;
+	return x * (1 - gx * (1 - x2));
+}
+/* noise.h:90-98 */
+SAU_HD float franssgauss32(uint32_t n) {
+	int32_t s0 = (int32_t)ranfast32(n);
+	int32_t s1 = (int32_t)mcg32((uint32_t)s0);
+	float a = (float)((double)s0 * 0x1p-32);
+	float b = (float)((double)s1 * 0x1p-32);
+	float c = ssgauss_dist4(soft_sqrtm2logp1(a));
+	b = c * sinpi_d5f(b);
+	return b;
+}
+
+/* Sample with counter value n of the counter-hash noises (noise.h:41-128).
+ * `re` `vi` `bv` carry state and are handled by the callers:
+ *   re: running u32 sum of (int32)hash >> 6, folded       (noise.h:136-147)
+ *   vi: hash(n)/2 - hash(n-1)/2                             (noise.h:149-159)
+ *   bv: tw-like value minus its predecessor                  (noise.h:161-172) */
+SAU_HD float noise_stateless(uint32_t type, uint32_t n) {
+	switch (type) {
+	default:
+	case NZ_wh: return fscalei(ranfast32(n), 0x1p-31f);
+	case NZ_gw: return franssgauss32(n);
+	case NZ_bw: return (float)(sar32((int32_t)ranfast32(n), 31) * 2 + 1);
+	case NZ_tw: {
+		int32_t s = sar32((int32_t)ranfast32(n), 31) * 2 + 1;
+		return (n & 1u) ? (float)s : 0.f;
+	}
+	}
+}
+SAU_HD int32_t noise_bv_term(uint32_t n) {
+	int32_t s1 = sar32((int32_t)ranfast32(n), 31);
+	return (n & 1u) ? (s1 * 2 + 1) : 0;
+}
+
+/* ---- random-segments oscillator -------------------------------------------- */
+
+struct RasParams {
+	uint32_t func, flags, level, alpha, line;
+	float vbin_scale; /* rasg.h:398-402 */
+	float perlin_amp; /* rasg.h:244-247,702-705 */
+};
+
+SAU_HD uint32_t ras_level9() { return (9 - 4) * (9 - 4) + 2; } /* program.h:146-148 */
+
+SAU_HD float perlin_amp_of(uint32_t line) { /* sau/line.h:18-32 */
+	switch (line) {
+	case LN_sah: case LN_uwh: return 1.f;
+	case LN_exp: case LN_log: case LN_xpe: case LN_lge: return 1.55845810035f;
+	case LN_sqe: case LN_nhl: return 1.89339094650f;
+	default: return 2.f;
+	}
+}
+
+SAU_HD RasParams ras_params(uint32_t func, uint32_t flags, uint32_t level,
+		uint32_t alpha, uint32_t line) {
+	RasParams p;
+	p.func = func; p.flags = flags; p.level = level; p.alpha = alpha; p.line = line;
+	const float scale_diff = 1.f - ((float)sar32(INT32_MAX, (int)level) / 0x1p31f);
+	p.vbin_scale = (1.f + scale_diff * scale_diff) / 0x1p31f;
+	p.perlin_amp = (flags & (RO_HALFSHAPE | RO_ZIGZAG)) ? 1.f : perlin_amp_of(line);
+	return p;
+}
+
+/* Segment end values for a cycle index; rasg.h:299-671. */
+SAU_HD void ras_ends(const RasParams &c, uint32_t cycle, float &a, float &b) {
+	const int sr = (int)c.level;
+	const bool violet = (c.flags & RO_VIOLET) != 0;
+	switch (c.func) {
+	default:
+	case RF_URAND:
+		if (violet) {
+			uint32_t s0 = ranfast32(cycle - 1) / 2;
+			uint32_t s1 = ranfast32(cycle) / 2;
+			uint32_t s2 = ranfast32(cycle + 1) / 2;
+			a = fscalei(s1 - s0, 0x1p-31f);
+			b = fscalei(s2 - s1, 0x1p-31f);
+		} else {
+			a = fscalei(ranfast32(cycle), 0x1p-31f);
+			b = fscalei(ranfast32(cycle + 1), 0x1p-31f);
+		}
+		break;
+	case RF_GAUSS:
+		a = franssgauss32(cycle);
+		b = franssgauss32(cycle + 1);
+		break;
+	case RF_BIN:
+		if (violet) {
+			uint32_t sb = (cycle & 1u) << 31;
+			uint32_t sb_flip = (1u << 31) - sb;
+			uint32_t s0 = (uint32_t)divi((uint32_t)sar32((int32_t)ranfast32(cycle - 1), sr) + sb, 2);
+			uint32_t s1 = (uint32_t)divi((uint32_t)sar32((int32_t)ranfast32(cycle), sr) + sb_flip, 2);
+			uint32_t s2 = (uint32_t)divi((uint32_t)sar32((int32_t)ranfast32(cycle + 1), sr) + sb, 2);
+			a = fscalei(s1 - s0, c.vbin_scale);
+			b = fscalei(s2 - s1, c.vbin_scale);
+		} else {
+			uint32_t offs = (uint32_t)INT32_MAX + (cycle & 1u) * 2u;
+			uint32_t s1 = (uint32_t)sar32((int32_t)ranfast32(cycle), sr) + offs;
+			uint32_t s2 = (uint32_t)sar32((int32_t)ranfast32(cycle + 1), sr) - offs;
+			a = fscalei(s1, 0x1p-31f);
+			b = fscalei(s2, 0x1p-31f);
+		}
+		break;
+	case RF_TERN: {
+		uint32_t sb = (cycle & 1u) << 31;
+		uint32_t sb_flip = (1u << 31) - sb;
+		uint32_t s1 = (uint32_t)sar32((int32_t)ranfast32(cycle), sr) + sb_flip;
+		uint32_t s2 = (uint32_t)sar32((int32_t)ranfast32(cycle + 1), sr) + sb;
+		a = fscalei(s1, 0x1p-31f);
+		b = fscalei(s2, 0x1p-31f);
+		break;
+	}
+	case RF_FIXED:
+		if (c.level >= ras_level9()) {
+			a = (float)odd_sign(cycle);
+			b = -a;
+		} else if (violet) {
+			uint32_t sign = (uint32_t)odd_sign(cycle);
+			uint32_t s0 = (uint32_t)divi(sign * ((ranfast32(cycle - 1) >> sr) - (uint32_t)INT32_MAX), 2);
+			uint32_t s1 = (uint32_t)divi((0u - sign) * ((ranfast32(cycle) >> sr) - (uint32_t)INT32_MAX), 2);
+			uint32_t s2 = (uint32_t)divi(sign * ((ranfast32(cycle + 1) >> sr) - (uint32_t)INT32_MAX), 2);
+			a = fscalei(s1 - s0, 0x1p-31f);
+			b = fscalei(s2 - s1, 0x1p-31f);
+		} else {
+			uint32_t sign = (uint32_t)odd_sign(cycle);
+			a = fscalei((0u - sign) * ((ranfast32(cycle) >> sr) - (uint32_t)INT32_MAX), 0x1p-31f);
+			b = fscalei(sign * ((ranfast32(cycle + 1) >> sr) - (uint32_t)INT32_MAX), 0x1p-31f);
+		}
+		break;
+	case RF_ADDREC: {
+		uint32_t s0 = cycle * c.alpha;
+		uint32_t s1 = (cycle + 1) * c.alpha;
+		a = fscalei(s0, 0x1p-31f);
+		b = fscalei(s1, 0x1p-31f);
+		break;
+	}
+	}
+}
+
+/* One output value from cycle index and in-cycle phase in [0,1):
+ * rasg.h:692-743 (block form) == rasg.h:254-275 (per-sample form). */
+SAU_HD float ras_sample(const RasParams &c, uint32_t cycle, float phase) {
+	float a, b;
+	ras_ends(c, cycle, a, b);
+	if (c.flags & RO_PERLIN) {
+		a *= c.perlin_amp * phase;
+		b *= c.perlin_amp * (phase - 1.f);
+	}
+	if (c.flags & RO_HALFSHAPE) {
+		float mx = a < b ? b : a;
+		float mn = a > b ? b : a;
+		a = mx; b = mn;
+	}
+	if (c.flags & RO_ZIGZAG) {
+		float t = a; a = b; b = t;
+	}
+	if (c.flags & RO_SQUARE) {
+		a *= fabsf(a);
+		b *= fabsf(b);
+	}
+	return shape_val(c.line, phase, a, b);
+}
+
+/* Split the 64-bit cycle|phase counter: rasg.h:184-186 */
+SAU_HD void ras_split(uint64_t cp, uint32_t &cycle, float &phase) {
+	cycle = (uint32_t)(cp >> 32);
+	uint32_t ph = ((uint32_t)cp) >> 1;
+	phase = (float)(int32_t)ph * 0x1p-31f;
+}
+
+/* ---- mixing ----------------------------------------------------------------- */
+
+/* generator.c:384-426 */
+SAU_HD float mix_combine(float dst, float in, float amp, bool wave_env, bool layer) {
+	if (wave_env) {
+		float s_amp = amp * 0.5f;
+		float s = (in * s_amp) + fabsf(s_amp);
+		return layer ? dst * s : s;
+	}
+	return layer ? dst + in * amp : in * amp;
+}
+
+SAU_HD float clampf(float x, float lo, float hi) { /* sau/math.h:133-137 */
+	x = x < lo ? lo : x;
+	x = x > hi ? hi : x;
+	return x;
+}
+
+/* generator.c:803,822-823 */
+SAU_HD int16_t pcm16(float s) {
+	s = clampf(s, -1.f, 1.f);
+#if defined(__HIP_DEVICE_COMPILE__)
+	return (int16_t)__float2int_rn(s * (float)INT16_MAX);
+#else
+	return (int16_t)lrintf(s * (float)INT16_MAX);
+#endif
+}
+
+} /* namespace saudev */
+#endif /* SAU_DEV_MATH_H */

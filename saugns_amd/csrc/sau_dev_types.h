@@ -1,0 +1,132 @@
+/* sau_dev_types.h -- data shared between the host control plane, the HIP
+ * kernels and the test-side sequential executor: device operator state, event
+ * update records, and the flattened per-voice plan ("batched operator graph").
+ */
+#ifndef SAU_DEV_TYPES_H
+#define SAU_DEV_TYPES_H
+
+#include "sau_dev_math.h"
+
+namespace saudev {
+
+/* Line slots inside an operator, same order as the sweep ids of the program
+ * format (sau/program.h:53-60). */
+enum : uint32_t { L_PAN = 0, L_AMP, L_AMP2, L_FREQ, L_FREQ2, L_PMA, L_COUNT };
+
+enum : uint32_t { /* DevOp.flags */
+	OPF_TIME_INF = 1u << 0,  /* generator.c:42 ON_TIME_INF */
+	OPF_OSC_RESET = 1u << 1, /* wosc.h:37-38 */
+	OPF_RATE2X = 1u << 2,    /* rasg.h:32 */
+};
+
+/* Persistent state of one operator (generator.c:45-88 OperatorNode, flattened).
+ * Lives in HBM between launches; a voice's operators are cached in LDS while
+ * its workgroup renders a segment. 64 dwords. */
+struct DevOp {
+	uint32_t time;           /* remaining samples (unless OPF_TIME_INF) */
+	uint32_t flags;          /* OPF_* */
+	uint32_t type;           /* OT_* */
+	uint32_t wave;           /* W: wave id; N: noise id; R: line shape */
+	LineState line[L_COUNT]; /* 36 dwords */
+	float coeff;             /* 2^32 / srate as f32 (wosc.h:30, rasg.h:27) */
+	uint32_t phase;          /* W: accumulator (includes the wave's phase_adj) */
+	uint32_t prev_phase;     /* W */
+	uint32_t ras_flags;      /* R */
+	double prev_Is;          /* W */
+	uint64_t cycle_phase;    /* R */
+	float prev_s, fb_s;      /* W and R feedback */
+	uint32_t ras_func, ras_level, ras_alpha;
+	uint32_t noise_n, noise_prev; /* N */
+	uint32_t pad[9];
+};
+static_assert(sizeof(DevOp) == 256, "DevOp is 64 dwords");
+
+/* One operator update of an event (sauProgramOpData by value), applied on the
+ * device by the event kernel: generator.c:245-343 prepare_op + update_op. */
+struct OpUpdate {
+	uint32_t op;
+	uint32_t params;       /* SAU_POPP_* */
+	uint32_t type;         /* OT_* */
+	uint32_t first;        /* operator not yet initialised: run prepare_op */
+	uint32_t time;         /* samples, when params & TIME */
+	uint32_t time_inf;
+	uint32_t mode_main;    /* wave / noise id */
+	uint32_t ras_line, ras_flags, ras_func, ras_level, ras_alpha;
+	uint32_t phase, seed;
+	float coeff;
+	uint32_t pad;
+	LineUpdate line[L_COUNT];
+};
+
+enum : uint32_t { POPP_TIME = 1, POPP_MODE = 2, POPP_PHASE = 4, POPP_SEED = 8 };
+
+/* Per-wave constants, sau/wave.h:33-69,144-149 */
+struct WaveConst {
+	float diff_scale;  /* amp_scale * 0.125f * (float)UINT32_MAX */
+	float diff_offset; /* amp_dc */
+	int32_t phase_adj;
+	uint32_t pad;
+};
+
+/* ---- plan ------------------------------------------------------------------ */
+
+constexpr uint8_t NO_SLOT = 0xFF;
+constexpr uint8_t SCRATCH_SLOT = 0; /* used inside a step only */
+
+enum : uint8_t {
+	ST_LINE = 1, /* out <- line `which` of op (x fmul)               */
+	ST_LERP,     /* out += (freq - out) * pm   (generator.c:466-467)  */
+	ST_OSC,      /* evaluate operator, combine into out               */
+	ST_ZERO,     /* out <- 0 (circular reference guard, gen.c:685-689)*/
+	ST_SMLINE,   /* out <- pm_a line or zeros; latch self-mod state   */
+	ST_VOICE,    /* hand carrier block (+pan) to the mixer            */
+};
+
+enum : uint8_t {
+	SF_BEGIN = 1 << 0,     /* first step of op: clip len to op time, push  */
+	SF_END = 1 << 1,       /* last step of op: zero tail, time -= len, pop  */
+	SF_WAVE_ENV = 1 << 2,  /* block_mix_mul_waveenv instead of _add          */
+	SF_LAYER = 1 << 3,     /* combine with existing out instead of replacing */
+	SF_SKIP2 = 1 << 4,     /* ST_LINE: also skip the range partner line      */
+	SF_SKIP_FREQ2 = 1 << 4,/* ST_OSC with inline freq: skip freq2            */
+	SF_SKIP_AMP2 = 1 << 5, /* ST_OSC with inline amp: skip amp2              */
+	SF_SM_INLINE = 1 << 6, /* ST_OSC: test/run pm_a line inline (no apmods)  */
+	SF_SM_SKIP = 1 << 7,   /* ST_OSC: pm_a line was set once: skip it        */
+};
+
+struct Step {
+	uint8_t kind, flags;
+	uint8_t out;   /* destination slot */
+	uint8_t freq;  /* ST_OSC: freq slot or NO_SLOT (inline); ST_LERP: range end */
+	uint8_t fmul;  /* parent frequency slot for ratio lines, or NO_SLOT */
+	uint8_t pm;    /* ST_OSC: PM sum; ST_LERP: modulator; ST_VOICE: pan slot */
+	uint8_t fpm;
+	uint8_t amp;   /* ST_OSC: amp slot or NO_SLOT (inline) */
+	uint8_t sm;    /* ST_OSC: self-modulation amount slot */
+	uint8_t which; /* ST_LINE: L_* */
+	uint8_t tmp;   /* extra scratch slot (R self-mod) */
+	uint8_t pad;
+	uint32_t op;   /* voice-local operator index */
+};
+static_assert(sizeof(Step) == 16, "Step is 4 dwords");
+
+/* One voice of one render stream, for one segment launch. */
+struct VoiceDesc {
+	uint32_t plan_ofs, plan_len; /* into the step array */
+	uint32_t ops_ofs, nops;      /* into the op-id array (global op indices) */
+	uint32_t carr_local;         /* carrier's voice-local op index */
+	uint32_t run_len;            /* min(duration, segment length) */
+	uint32_t out_row;            /* row in the voice output matrix */
+	uint32_t pan_dynamic_row;    /* row of the pan matrix, or ~0u */
+};
+
+/* Per-voice result of a segment, read by the mixer. */
+struct VoiceOut {
+	float pan_const;   /* pan.v0 when no pan row is written */
+	uint32_t has_pan;  /* 1: pan matrix row holds per-sample values */
+};
+
+constexpr uint32_t MAX_NEST = 64; /* deepest operator nesting a plan may have */
+
+} /* namespace saudev */
+#endif

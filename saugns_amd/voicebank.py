@@ -1,0 +1,230 @@
+"""Build ``sauProgram`` structures directly (no parser) for synthetic voice banks.
+
+The structures are laid out exactly as the reference parser lays them out for
+the equivalent script (one event per voice, operator data in post-order,
+carrier last; line/time flag conventions of sau/parser.c) -- tests check the
+builder against parser-made images of BASELINE configs 2, 3 and 5
+(SURVEY.md section 8d gives the script text of each config).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import api
+from .api import (LINES, LP_GOAL, LP_STATE, LP_STATE_RATIO, LP_TIME, LP_TIME_IF_NEW, LP_TYPE,
+                  POP_AMOD, POP_APMOD, POP_CAMOD, POP_CARR, POP_FMOD, POP_FPMOD, POP_PMOD,
+                  POP_RAMOD, POP_RFMOD, POPT_WAVE, SauEvent, SauLine, SauOpData, SauProgram,
+                  TIMEP_DEFAULT, TIMEP_IMPLICIT, TIMEP_SET, WAVES)
+
+_LIST_FIELDS = {POP_CAMOD: "camods", POP_AMOD: "amods", POP_RAMOD: "ramods",
+                POP_FMOD: "fmods", POP_RFMOD: "rfmods", POP_PMOD: "pmods",
+                POP_APMOD: "apmods", POP_FPMOD: "fpmods"}
+
+
+def cyclepos(x):
+    """sau_cyclepos_dtoui32 (sau/math.h:70-72): cycle fraction -> u32 phase."""
+    v = math.remainder(x, 1.0) * 2.0 ** 32
+    r = np.rint(v)  # round-half-even like lrint in the default mode
+    return int(r) & 0xFFFFFFFF
+
+
+class Line:
+    def __init__(self, v0, goal=None, shape="lin", ratio=False, state=True):
+        self.v0, self.goal, self.shape, self.ratio, self.state = v0, goal, shape, ratio, state
+
+
+class Op:
+    """One operator of a voice tree (only what configs 1-5 style banks need)."""
+
+    def __init__(self, wave="sin", freq=None, amp=1.0, time_ms=None, phase=0.0,
+                 amp2=None, freq2=None, pm_a=None, mods=None, op_type=POPT_WAVE):
+        self.wave = wave
+        self.freq = freq if isinstance(freq, Line) or freq is None else Line(freq)
+        self.amp = amp if isinstance(amp, Line) else Line(amp)
+        self.amp2 = amp2 if isinstance(amp2, Line) or amp2 is None else Line(amp2)
+        self.freq2 = freq2 if isinstance(freq2, Line) or freq2 is None else Line(freq2)
+        self.pm_a = pm_a if isinstance(pm_a, Line) or pm_a is None else Line(pm_a)
+        self.time_ms = time_ms
+        self.phase = phase
+        self.mods = mods or {}  # use type -> [Op]
+        self.op_type = op_type
+
+
+class BuiltProgram(api.Program):
+    """A Program whose memory is owned by Python objects kept in ``_keep``."""
+
+    def __init__(self, prg, keep):
+        super().__init__(C.addressof(prg))
+        self._keep = keep
+        self._prg = prg
+
+
+def _mk_line(keep, ln, time_ms, is_r_par=False):
+    if ln is None:
+        return None
+    s = SauLine()
+    s.v0 = ln.v0
+    s.vt = ln.goal if ln.goal is not None else 0.0
+    s.pos = 0
+    s.end = 0
+    s.time_ms = time_ms
+    s.type = LINES.index(ln.shape)
+    fl = LP_TIME | LP_TIME_IF_NEW
+    if ln.state:
+        fl |= LP_STATE
+    if not is_r_par:
+        fl |= LP_TYPE
+    if ln.ratio:
+        fl |= LP_STATE_RATIO
+    if ln.goal is not None:
+        fl |= LP_GOAL
+    s.flags = fl
+    keep.append(s)
+    return C.pointer(s)
+
+
+def build_program(voices, ampmult=1.0, default_mod_ms=1000):
+    """voices: list of carrier Ops (each with .time_ms) -> BuiltProgram."""
+    keep = []
+    events = (SauEvent * len(voices))()
+    next_id = [0]
+    depth_max = [0]
+    dur = 0
+
+    def assign_ids(op):
+        op._id = next_id[0]
+        next_id[0] += 1
+        for use in sorted(op.mods):
+            for m in op.mods[use]:
+                assign_ids(m)
+
+    def emit(op, use, depth, out):
+        depth_max[0] = max(depth_max[0], depth)
+        for u in sorted(op.mods):
+            for m in op.mods[u]:
+                emit(m, u, depth + 1, out)
+        od = SauOpData()
+        od.id = op._id
+        od.params = 0xF
+        carrier = use == POP_CARR
+        t_ms = op.time_ms if op.time_ms is not None else default_mod_ms
+        od.time.v_ms = t_ms
+        od.time.flags = TIMEP_SET if op.time_ms is not None else \
+            (TIMEP_SET | TIMEP_DEFAULT | TIMEP_IMPLICIT)
+        p = _mk_line(keep, Line(0.0) if carrier else None, t_ms)
+        if p: od.pan = p
+        for name, ln, rp in (("amp", op.amp, False), ("amp2", op.amp2, True),
+                             ("freq", op.freq, False), ("freq2", op.freq2, True),
+                             ("pm_a", op.pm_a, False)):
+            p = _mk_line(keep, ln, t_ms, rp)
+            if p: setattr(od, name, p)
+        od.phase = cyclepos(op.phase)
+        od.seed = 0
+        od.use_type = use
+        od.type = op.op_type
+        od.mode.ras.word = 0
+        od.mode.ras.alpha = 0
+        od.mode.main = WAVES.index(op.wave)
+        for u, lst in op.mods.items():
+            arr = (C.c_uint32 * (1 + len(lst)))(len(lst), *[m._id for m in lst])
+            keep.append(arr)
+            setattr(od, _LIST_FIELDS[u], C.addressof(arr))
+        out.append(od)
+
+    for v, carr in enumerate(voices):
+        assign_ids(carr)
+    for v, carr in enumerate(voices):
+        ods = []
+        emit(carr, POP_CARR, 0, ods)
+        arr = (SauOpData * len(ods))(*ods)
+        keep.append(arr)
+        ev = events[v]
+        ev.wait_ms = 0
+        ev.vo_id = v
+        ev.carr_op_id = carr._id
+        ev.op_count = 0
+        ev.op_data_count = len(ods)
+        ev.op_list = None
+        ev.op_data = arr
+        dur = max(dur, carr.time_ms)
+    prg = SauProgram()
+    prg.events = events
+    prg.ev_count = len(voices)
+    prg.mode = api.PMODE_AMP_DIV_VOICES
+    prg.vo_count = len(voices)
+    prg.op_count = next_id[0]
+    prg.op_nest_depth = depth_max[0]
+    prg.duration_ms = dur
+    prg.ampmult = ampmult
+    prg.name = b"voicebank"
+    keep.append(events)
+    return BuiltProgram(prg, keep)
+
+
+def _f32(x):
+    return float(np.float32(x))
+
+
+def _num(fmt, x):
+    """The value a script would carry: formatted, parsed back, stored as f32."""
+    return _f32(float(format(x, fmt)))
+
+
+# ---- BASELINE configs (script text in SURVEY.md section 8d) ---------------------
+
+def config1():
+    """`Wsin`: 1 voice, 440 Hz default, 1 s."""
+    return build_program([Op("sin", freq=440.0, amp=1.0, time_ms=1000)])
+
+
+def config2(n=256, seconds=10):
+    """n x `Wsin f.. p.. t10`: flat batch, no modulation."""
+    voices = []
+    for i in range(n):
+        f = _num(".4f", 55.0 * (1 + i % 64) + (i // 64) * 0.37)
+        ph = float(format((i * 0.6180339887) % 1, ".6f"))
+        voices.append(Op("sin", freq=f, time_ms=seconds * 1000, phase=ph))
+    return build_program(voices)
+
+
+def config3(n=1024, seconds=10):
+    """n voices, each carrier + 3-deep PM chain (the headline workload)."""
+    voices = []
+    for i in range(n):
+        m3 = Op("sin", freq=Line(float(3 + i % 4), ratio=True), amp=_f32(0.4))
+        m2 = Op("sin", freq=Line(float(2 + i % 3), ratio=True), amp=_f32(0.7),
+                mods={POP_PMOD: [m3]})
+        m1 = Op("sin", freq=Line(float(1 + i % 5), ratio=True),
+                amp=_num(".2f", 0.5 + (i % 7) * 0.1), mods={POP_PMOD: [m2]})
+        voices.append(Op("sin", freq=_num(".4f", 110.0 + i * 0.731), time_ms=seconds * 1000,
+                         mods={POP_PMOD: [m1]}))
+    return build_program(voices)
+
+
+def config5(n=4096, seconds=10):
+    """n voices: self-feedback FM carrier with ramps + range-AM modulator."""
+    voices = []
+    for i in range(n):
+        lfo = Op("sin", freq=float(3 + i % 9), amp=1.0)
+        carr = Op("sin",
+                  freq=Line(_num(".4f", 80.0 + i * 0.211), goal=_num(".3f", 160.0 + i * 0.1),
+                            shape="exp"),
+                  pm_a=Line(_num(".2f", 0.3 + (i % 8) * 0.1), goal=_f32(0.1), shape="lin"),
+                  amp=Line(1.0, goal=_f32(0.2), shape="xpe"),
+                  amp2=Line(_f32(0.2)),
+                  time_ms=seconds * 1000, mods={POP_RAMOD: [lfo]})
+        voices.append(carr)
+    return build_program(voices)
+
+
+def config_scripts():
+    """Script text of configs 2, 3, 5 (for the reference parser; fixtures only)."""
+    c2 = "\n".join(f"Wsin f{55.0*(1+i%64)+(i//64)*0.37:.4f} p{(i*0.6180339887)%1:.6f} t10"
+                   for i in range(256))
+    c3 = "\n".join(f"Wsin f{110.0+i*0.731:.4f} t10 p[Wsin r{1+i%5} a{0.5+(i%7)*0.1:.2f} "
+                   f"p[Wsin r{2+i%3} a0.7 p[Wsin r{3+i%4} a0.4]]]" for i in range(1024))
+    c5 = "\n".join(f"Wsin f{80.0+i*0.211:.4f}[g{160.0+i*0.1:.3f} lexp] "
+                   f"p.a{0.3+(i%8)*0.1:.2f}[g0.1 llin] a1[g0.2 lxpe].r0.2[Wsin f{3+i%9}] t10"
+                   for i in range(4096))
+    return {"config2": c2, "config3": c3, "config5": c5}

@@ -1,0 +1,70 @@
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def tables():
+    return np.fromfile(os.path.join(GOLDEN, "piluts_ref.f32"), dtype="<f4").reshape(12, 2048)
+
+
+@pytest.fixture(scope="session")
+def index():
+    return json.load(open(os.path.join(GOLDEN, "index.json")))
+
+
+@pytest.fixture(scope="session")
+def heads():
+    return np.load(os.path.join(GOLDEN, "pcm_heads.npz"))
+
+
+@pytest.fixture(scope="session")
+def oracle(tables):
+    """The CPU restatement, using the reference's wave tables."""
+    from oracle import pyoracle as po
+    po.build(ref=False)
+    po.oracle_use_tables(tables)
+    return po
+
+
+@pytest.fixture(scope="session")
+def sa(tables):
+    import saugns_amd
+    saugns_amd.lib()
+    saugns_amd.set_piluts(tables)
+    return saugns_amd
+
+
+@pytest.fixture(scope="session")
+def seqexec():
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "seqexec")])
+    lib = C.CDLL(os.path.join(ROOT, "tests", "seqexec", "libseqexec.so"))
+    lib.seq_backend_create.restype = C.c_void_p
+    lib.seq_backend_create.argtypes = [C.c_uint32]
+    return lib
+
+
+def load_program(sa, key):
+    blob = open(os.path.join(GOLDEN, "programs", key + ".saup"), "rb").read()
+    return sa.Program.from_image(blob)
+
+
+def max_diff(a, b):
+    assert len(a) == len(b), (len(a), len(b))
+    if len(a) == 0:
+        return 0
+    return int(np.abs(a.astype(np.int32) - b.astype(np.int32)).max())

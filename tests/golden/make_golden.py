@@ -1,0 +1,136 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/ from the compiled reference (run in the build container).
+
+Needs oracle/_ref/libsau_ref.so (oracle/Makefile `ref`, built from
+/root/reference) and the script corpus under /root/reference.  Only DATA is
+written here: program images (this repo's SAUPIMG1 format), PCM produced by the
+reference generator, the reference's wave tables, and ramp known-answer vectors.
+
+    python tests/golden/make_golden.py
+"""
+import ctypes as C
+import glob
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import pyoracle as po  # noqa: E402
+import saugns_amd as sa  # noqa: E402
+from saugns_amd import voicebank  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+# these crash the reference's own parser when run in-process
+SKIP = ("alarm-25m", "testbindmultiple", "label_without_operator")
+CORPUS_RATE = 12000
+HEAD = 12000  # frames of PCM kept per corpus script
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def main():
+    os.makedirs(os.path.join(OUT, "programs"), exist_ok=True)
+    tables = po.ref_piluts()
+    tables.astype("<f4").tofile(os.path.join(OUT, "piluts_ref.f32"))
+    index = {"corpus_rate": CORPUS_RATE, "head_frames": HEAD, "corpus": {}, "configs": {}}
+    pcm_store = {}
+
+    # ---- script corpus -------------------------------------------------------
+    files = sorted(glob.glob(REF + "/examples/*.sau") + glob.glob(REF + "/examples/*/*.sau") +
+                   glob.glob(REF + "/examples/*/*/*.sau") + glob.glob(REF + "/devtests/*.sau") +
+                   glob.glob(REF + "/devtests/*/*.sau"))
+    for f in files:
+        if any(s in f for s in SKIP):
+            continue
+        p = po.ref_build_program(f, is_path=True)
+        if not p:
+            continue
+        key = os.path.relpath(f, REF).replace("/", "__").replace(".sau", "")
+        img = sa.Program.borrow(p).image()
+        open(os.path.join(OUT, "programs", key + ".saup"), "wb").write(img)
+        pcm = po.ref_render(p, CORPUS_RATE, True)
+        index["corpus"][key] = {"frames": int(len(pcm) // 2), "sha256": sha(pcm)}
+        pcm_store[key] = pcm[: HEAD * 2]
+
+    # ---- BASELINE configs 1-5 (44.1 kHz mono) ----------------------------------
+    scripts = voicebank.config_scripts()
+    scripts["config1"] = "Wsin"
+    heads = {"config1": 44100, "config2": 11025, "config3": 11025, "config5": 11025}
+    for name in ("config1", "config2", "config3", "config5"):
+        p = po.ref_build_program(scripts[name])
+        img = sa.Program.borrow(p).image()
+        if name in ("config1",):
+            open(os.path.join(OUT, "programs", name + ".saup"), "wb").write(img)
+        full = name in ("config1", "config2", "config3")  # config5 full = 86 s of CPU
+        pcm = po.ref_render(p, 44100, False, max_frames=0 if full else heads[name])
+        index["configs"][name] = {
+            "frames": int(len(pcm)) if full else None,
+            "sha256": sha(pcm) if full else None,
+            "head_frames": heads[name], "head_sha256": sha(pcm[: heads[name]]),
+            "script_md5": hashlib.md5((scripts[name] + "\n").encode()).hexdigest()
+            if name != "config1" else None,
+        }
+        pcm_store[name] = pcm[: heads[name]]
+    # config 4: rainy_thunder with seed=k
+    for k in range(4):
+        p = po.ref_build_program(REF + "/examples/rainy_thunder.sau", is_path=True,
+                                 predefs={"seed": k})
+        img = sa.Program.borrow(p).image()
+        open(os.path.join(OUT, "programs", f"config4_seed{k}.saup"), "wb").write(img)
+        pcm = po.ref_render(p, 44100, False)
+        index["configs"][f"config4_seed{k}"] = {
+            "frames": int(len(pcm)), "sha256": sha(pcm), "head_frames": 88200,
+            "head_sha256": sha(pcm[:88200])}
+        pcm_store[f"config4_seed{k}"] = pcm[:88200]
+
+    # ---- ramp known-answer vectors (sauLine_fill_* / sauLine_map_*) --------------
+    ref = po.ref()
+    FILL = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_uint32,
+                       C.c_uint32, C.c_void_p)
+    MAP = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p)
+    fills = (C.c_void_p * 13).in_dll(ref, "sauLine_fill_funcs")
+    maps = (C.c_void_p * 13).in_dll(ref, "sauLine_map_funcs")
+    rng = np.random.default_rng(20241016)
+    kat = {}
+    cases = []
+    for c in range(6):
+        time = int(rng.integers(64, 40000))
+        pos = int(rng.integers(0, time - 40))
+        n = 40  # multiple of 4: only the reference build's main-loop forms
+        v0 = float(np.float32(rng.uniform(-500, 500)))
+        vt = float(np.float32(rng.uniform(-500, 500)))
+        cases.append((time, pos, n, v0, vt))
+    kat["cases"] = np.array(cases, dtype=np.float64)
+    mul = rng.uniform(50, 5000, 40).astype(np.float32)
+    x = rng.uniform(0, 1, 40).astype(np.float32)
+    e0 = rng.uniform(-1, 1, 40).astype(np.float32)
+    e1 = rng.uniform(-1, 1, 40).astype(np.float32)
+    kat["mul"], kat["x"], kat["e0"], kat["e1"] = mul, x, e0, e1
+    for t in range(13):
+        f, m = FILL(fills[t]), MAP(maps[t])
+        rows = []
+        for (time, pos, n, v0, vt) in cases:
+            for mb in (None, mul):
+                a = np.zeros(n, np.float32)
+                f(a.ctypes.data, n, v0, vt, pos, time, mb.ctypes.data if mb is not None else None)
+                rows.append(a)
+        kat[f"fill_{t}"] = np.stack(rows)
+        xa = x.copy()
+        m(xa.ctypes.data, 40, e0.ctypes.data, e1.ctypes.data)
+        kat[f"map_{t}"] = xa
+    np.savez_compressed(os.path.join(OUT, "ramp_kat.npz"), **kat)
+
+    np.savez_compressed(os.path.join(OUT, "pcm_heads.npz"), **pcm_store)
+    json.dump(index, open(os.path.join(OUT, "index.json"), "w"), indent=1, sort_keys=True)
+    print("programs:", len(index["corpus"]), "configs:", list(index["configs"]))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,105 @@
+"""GPU parity: HIP path (through the C ABI) against the oracle and the reference goldens."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_program, max_diff
+
+pytestmark = pytest.mark.gpu
+
+# scripts that exercise each part of the path; the full corpus runs in test_gpu_corpus
+SMALL = ["devtests__voice-reuse", "examples__dull_seq-fm_pm", "examples__tests__panning",
+         "examples__tests__wavetypes", "examples__rainy_thunder"]
+
+
+def _corpus_keys(index):
+    return sorted(index["corpus"].keys())
+
+
+@pytest.fixture(scope="module")
+def gpu(sa):
+    if sa.lib().sauAmd_device_count() <= 0:
+        pytest.fail("no HIP device: the GPU tests need the real hardware")
+    return sa
+
+
+def test_config1_plumbing(gpu, oracle, index, heads):
+    """`-e "Wsin"`: 44100 frames, identical to the reference's own output."""
+    from saugns_amd import voicebank
+    pcm = gpu.Generator(voicebank.config1(), 44100).render()
+    assert len(pcm) == 44100
+    assert list(pcm[:8]) == [1001, 1538, 2557, 3565, 4560, 5537, 6492, 7421]
+    assert hashlib.sha256(pcm.tobytes()).hexdigest() == index["configs"]["config1"]["sha256"]
+
+
+@pytest.mark.parametrize("key", SMALL)
+def test_scripts_bit_exact_vs_oracle(gpu, oracle, index, key):
+    oracle.oracle().ora_set_fastmath_forms(1)
+    prg = load_program(gpu, key)
+    rate = index["corpus_rate"]
+    want = oracle.oracle_render(prg.ptr, rate, True)
+    got = gpu.Generator(prg, rate).render(stereo=True)
+    assert max_diff(got, want) == 0
+
+
+def test_gpu_corpus(gpu, oracle, index, heads):
+    """Every corpus script: bit-exact vs the oracle, <= 1 LSB vs the reference."""
+    oracle.oracle().ora_set_fastmath_forms(1)
+    rate, head = index["corpus_rate"], index["head_frames"]
+    worst_ref = 0
+    bad = []
+    for key in _corpus_keys(index):
+        prg = load_program(gpu, key)
+        want = oracle.oracle_render(prg.ptr, rate, True)
+        got = gpu.Generator(prg, rate).render(stereo=True)
+        if len(got) != len(want) or max_diff(got, want) != 0:
+            bad.append(key)
+            continue
+        assert len(got) // 2 == index["corpus"][key]["frames"]
+        g = heads[key]
+        d = max_diff(got[: len(g)], g)
+        worst_ref = max(worst_ref, d)
+    assert not bad, f"GPU != oracle for {bad}"
+    assert worst_ref <= 1  # tolerance of the north star: +-1 LSB int16
+
+
+@pytest.mark.parametrize("name,n", [("config2", 11025), ("config3", 11025)])
+def test_voicebank_heads(gpu, heads, index, name, n):
+    """Configs 2/3 at full voice count, first 0.25 s, against the reference's PCM."""
+    from saugns_amd import voicebank
+    prg = getattr(voicebank, name)()
+    pcm = gpu.Generator(prg, 44100).render(max_frames=n, chunk=n)
+    assert hashlib.sha256(pcm[:n].tobytes()).hexdigest() == index["configs"][name]["head_sha256"]
+
+
+def test_config3_full_checksum(gpu, index):
+    """1024 voices x depth-3 PM, full 10 s: SHA-256 of the PCM equals the reference's."""
+    from saugns_amd import voicebank
+    pcm = gpu.Generator(voicebank.config3(), 44100).render(chunk=44100)
+    assert len(pcm) == index["configs"]["config3"]["frames"]
+    assert hashlib.sha256(pcm.tobytes()).hexdigest() == index["configs"]["config3"]["sha256"]
+
+
+def test_config5_head(gpu, heads):
+    """4096 voices with feedback FM + range AM + ramps: first 0.25 s, <= 1 LSB."""
+    from saugns_amd import voicebank
+    pcm = gpu.Generator(voicebank.config5(), 44100).render(max_frames=11025, chunk=11025)
+    assert max_diff(pcm[:11025], heads["config5"][:11025]) <= 1
+
+
+def test_config4_batch(gpu, heads, index):
+    """rainy_thunder x 4 seeds rendered as one batch == the reference, stream by stream."""
+    prgs = [load_program(gpu, f"config4_seed{k}") for k in range(4)]
+    outs = gpu.Batch(prgs, 44100).render(chunk=44100, max_frames=88200)
+    for k, pcm in enumerate(outs):
+        assert max_diff(pcm[:88200], heads[f"config4_seed{k}"]) <= 1
+
+
+def test_chunk_size_invariance(gpu, oracle):
+    """Caller buffer length must not change the result (SURVEY D-2)."""
+    prg = load_program(gpu, "examples__dull_seq-fm_pm")
+    a = gpu.Generator(prg, 12000).render(stereo=True, chunk=3072)
+    b = gpu.Generator(prg, 12000).render(stereo=True, chunk=997)
+    assert max_diff(a, b) == 0
