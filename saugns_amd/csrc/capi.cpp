@@ -144,3 +144,22 @@ extern "C" const float *sauAmd_get_piluts(void) { return sauengine::builtin_pilu
 extern "C" const char *sauAmd_last_error(void) { return g_last_error.c_str(); }
 
 extern "C" int sauAmd_device_count(void) { return sauhip::device_count(); }
+
+/* Test probes (not in the public header): the shared line arithmetic as
+ * compiled for the device and for the host. state = {v0, vt, pos, end, type,
+ * flags} as 6 dwords, updated in place. */
+extern "C" SAU_AMD_API int sauAmd_kat_line_device(uint32_t *state, uint32_t len, const float *mul, float *out) {
+	saudev::LineState st, st2;
+	memcpy(&st, state, sizeof st);
+	if (!sauhip::kat_line(st, len, mul, out, &st2)) return 0;
+	memcpy(state, &st2, sizeof st2);
+	return 1;
+}
+extern "C" SAU_AMD_API int sauAmd_kat_line_host(uint32_t *state, uint32_t len, const float *mul, float *out) {
+	saudev::LineState st;
+	memcpy(&st, state, sizeof st);
+	saudev::LineBlock lb = saudev::line_begin(st, len, mul != nullptr, mul ? mul[0] : 0.f);
+	for (uint32_t j = 0; j < len; ++j) out[j] = saudev::line_value(lb, j, mul ? mul[j] : 1.f);
+	memcpy(state, &st, sizeof st);
+	return 1;
+}

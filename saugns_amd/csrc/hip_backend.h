@@ -16,6 +16,9 @@ public:
 /* NULL (with err) when no HIP device is usable: there is no CPU fallback. */
 HipBackend *create_hip_backend(std::string &err);
 int device_count();
+/* test probe: evaluate one line block on the device (kat_line_kernel) */
+bool kat_line(const saudev::LineState &st, uint32_t len, const float *mul, float *out,
+		saudev::LineState *st_out);
 
 } /* namespace sauhip */
 #endif

@@ -270,9 +270,18 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 				const bool is_osc = (type == OT_WAVE || type == OT_RASEG);
 				if (tid == 0) misc->flag = 0;
 
-				/* --- uniform line setup ------------------------------------ */
+				float s[T], av[T];
+				bool owned[T];
+#pragma unroll
+				for (int k = 0; k < T; ++k) {
+					owned[k] = (p0 + k >= 1) && (jbase + k < (int)len);
+					s[k] = 0.f;
+				}
+
+				/* --- uniform line setup; per-sample values are taken right
+				 * away so that only T floats stay live, not the line blocks */
 				LineState fls, als, pls;
-				LineBlock flb, alb, plb;
+				LineBlock flb;
 				bool f_inline = is_osc && !fslot;
 				if (f_inline) {
 					fls = op->line[L_FREQ];
@@ -281,24 +290,21 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 				const bool a_inline = !ampS;
 				if (a_inline) {
 					als = op->line[L_AMP];
-					alb = line_begin(als, len, false, 0.f);
+					const LineBlock alb = line_begin(als, len, false, 0.f);
+#pragma unroll
+					for (int k = 0; k < T; ++k)
+						av[k] = owned[k] ? line_value(alb, (uint32_t)(jbase + k), 1.f) : 0.f;
 				}
 				bool sm_inline_active = false;
+				LineState pls0; /* pm_a line before this block (serial path re-derives its values) */
 				if (is_osc && (st.flags & SF_SM_INLINE)) {
 					pls = op->line[L_PMA];
+					pls0 = pls;
 					sm_inline_active = (pls.v0 != 0.f) || (pls.flags & LP_GOAL);
-					if (sm_inline_active) plb = line_begin(pls, len, false, 0.f);
+					if (sm_inline_active) (void)line_begin(pls, len, false, 0.f);
 					else line_skip(pls, len);
 				}
 				const bool selfmod = is_osc && (smS != nullptr || sm_inline_active);
-
-				float s[T];
-				bool owned[T];
-#pragma unroll
-				for (int k = 0; k < T; ++k) {
-					owned[k] = (p0 + k >= 1) && (jbase + k < (int)len);
-					s[k] = 0.f;
-				}
 
 				if (type == OT_WAVE) {
 					/* ---- phase accumulation: wosc.h:135-169 ------------- */
@@ -402,6 +408,8 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 							if (owned[k]) scratch_u[w * G::NP + p0 + k] = ph[k];
 						__syncthreads();
 						if (tid == 0 && len > 0) {
+							LineBlock plb;
+							if (sm_inline_active) { LineState t = pls0; plb = line_begin(t, len, false, 0.f); }
 							uint32_t prev_phase = op->prev_phase;
 							double prev_Is = op->prev_Is;
 							float prev_s = op->prev_s, fb_s = op->fb_s;
@@ -502,6 +510,8 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 						}
 						__syncthreads();
 						if (tid == 0 && len > 0) {
+							LineBlock plb;
+							if (sm_inline_active) { LineState t = pls0; plb = line_begin(t, len, false, 0.f); }
 							float fb_s = op->fb_s, prev_s = op->prev_s;
 							for (uint32_t j = 0; j < len; ++j) {
 								const uint32_t e = entry_of<W, T>(j);
@@ -593,7 +603,7 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 				for (int k = 0; k < T; ++k) {
 					if (owned[k]) {
 						const int e = w * G::NP + p0 + k;
-						float a = ampS ? ampS[e] : line_value(alb, (uint32_t)(jbase + k), 1.f);
+						float a = ampS ? ampS[e] : av[k];
 						float d = layer ? out[e] : 0.f;
 						slot_put<W, T>(out, w, p0 + k, mix_combine(d, s[k], a, wave_env, layer));
 					}
@@ -750,6 +760,17 @@ __global__ void event_kernel(DevOp *ops, const OpUpdate *recs, uint32_t n, const
 	ops[u.op] = o;
 }
 
+/* Known-answer probe of the shared arithmetic as compiled for the device:
+ * one block evaluates a line for `len` samples exactly as ST_LINE does. */
+__global__ void kat_line_kernel(LineState st, uint32_t len, const float *mul, float *out,
+		LineState *st_out) {
+	LineState ls = st;
+	LineBlock lb = line_begin(ls, len, mul != nullptr, mul ? mul[0] : 0.f);
+	for (uint32_t j = threadIdx.x; j < len; j += blockDim.x)
+		out[j] = line_value(lb, j, mul ? mul[j] : 1.f);
+	if (threadIdx.x == 0) *st_out = ls;
+}
+
 /* ------------------------------------------------------------------------ */
 /* host side                                                                */
 /* ------------------------------------------------------------------------ */
@@ -825,6 +846,7 @@ public:
 		if (const char *ll = getenv("SAU_AMD_LDS_LIMIT")) lds_limit_ = (size_t)atol(ll);
 		const char *wt = getenv("SAU_AMD_GEOMETRY"); /* "8x2" (default) or "4x4" */
 		geo_ = (wt && !strcmp(wt, "4x4")) ? 1 : 0;
+		debug_ = getenv("SAU_AMD_DEBUG") != nullptr;
 		if (!ops_.ensure(cfg.op_count ? cfg.op_count : 1, err)) return false;
 		HIP_OK(hipMemsetAsync(ops_.p, 0, ops_.cap * sizeof(DevOp), stream_));
 		/* Hermite coefficient tables from the PILUTs (sau/wave.h:127-141) */
@@ -964,6 +986,7 @@ public:
 		               : launch_render<8, 2>(rp, seg.n_voices, lds, err);
 		if (!ok) return false;
 		if (tp) (void)hipEventRecord(tp->b, stream_);
+		if (debug_) debug_dump("after render", seg);
 		if (max_write) {
 			MixParams mp;
 			mp.streams = mstreams_.p; mp.vout = vout_.p; mp.pan = pan_.p; mp.vinfo = vinfo_.p;
@@ -1005,6 +1028,28 @@ public:
 
 	void *stream_handle() override { return (void *)stream_; }
 
+	void debug_dump(const char *what, const SegmentDesc &seg) {
+		(void)hipStreamSynchronize(stream_);
+		uint32_t n = cfg_.op_count < 8 ? cfg_.op_count : 8;
+		std::vector<DevOp> h(n);
+		(void)hipMemcpy(h.data(), ops_.p, n * sizeof(DevOp), hipMemcpyDeviceToHost);
+		fprintf(stderr, "[sau-amd] %s: seg len %u off %u voices %u slots %u\n", what, seg.len,
+				seg.pcm_offset, seg.n_voices, seg.n_slots);
+		for (uint32_t v = 0; v < seg.n_voices && v < 4; ++v)
+			fprintf(stderr, "  voice %u: run_len %u plan %u+%u ops %u+%u\n", v, seg.voices[v].run_len,
+					seg.voices[v].plan_ofs, seg.voices[v].plan_len, seg.voices[v].ops_ofs, seg.voices[v].nops);
+		for (uint32_t i = 0; i < n; ++i) {
+			const DevOp &o = h[i];
+			fprintf(stderr, "  op %u: time %u flags %#x type %u wave %u phase %u prev_s %g fb %g\n", i, o.time,
+					o.flags, o.type, o.wave, o.phase, o.prev_s, o.fb_s);
+			for (int l = 0; l < 6; ++l)
+				if (o.line[l].flags || o.line[l].v0 != 0.f)
+					fprintf(stderr, "     line %d: v0 %g vt %g pos %u end %u type %u flags %#x\n", l,
+							o.line[l].v0, o.line[l].vt, o.line[l].pos, o.line[l].end, o.line[l].type,
+							o.line[l].flags);
+		}
+	}
+
 private:
 	struct TimedPair { hipEvent_t a, b; bool is_mix; bool used; };
 	TimedPair *new_pair() {
@@ -1035,6 +1080,7 @@ private:
 	hipStream_t stream_ = nullptr;
 	size_t lds_limit_ = 64 * 1024;
 	int geo_ = 0;
+	bool debug_ = false;
 	uint32_t row_stride_ = 0;
 	size_t pcm_row_ = 0;
 	uint32_t vout_rows_ = 0;
@@ -1061,6 +1107,27 @@ private:
 	double acc_render_ms_ = 0, acc_mix_ms_ = 0;
 	uint64_t acc_launches_ = 0;
 };
+
+bool kat_line(const LineState &st, uint32_t len, const float *mul, float *out, LineState *st_out) {
+	float *d_mul = nullptr, *d_out = nullptr;
+	LineState *d_st = nullptr;
+	bool ok = hipMalloc((void **)&d_out, (len + 1) * sizeof(float)) == hipSuccess &&
+		hipMalloc((void **)&d_st, sizeof(LineState)) == hipSuccess;
+	if (ok && mul) {
+		ok = hipMalloc((void **)&d_mul, (len + 1) * sizeof(float)) == hipSuccess &&
+			hipMemcpy(d_mul, mul, len * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+	}
+	if (ok) {
+		hipLaunchKernelGGL(kat_line_kernel, dim3(1), dim3(256), 0, 0, st, len, d_mul, d_out, d_st);
+		ok = hipDeviceSynchronize() == hipSuccess &&
+			hipMemcpy(out, d_out, len * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess &&
+			hipMemcpy(st_out, d_st, sizeof(LineState), hipMemcpyDeviceToHost) == hipSuccess;
+	}
+	if (d_mul) (void)hipFree(d_mul);
+	if (d_out) (void)hipFree(d_out);
+	if (d_st) (void)hipFree(d_st);
+	return ok;
+}
 
 HipBackend *create_hip_backend(std::string &err) {
 	if (device_count() <= 0) {
