@@ -1,0 +1,61 @@
+"""Multi-GPU path on CPU: sharding of independent renders over ranks (gloo, world size 2).
+
+BASELINE config 4 shards whole renders; there is no data-path collective
+ -- only the metadata all-reduce of {frames, checksum} that the
+scaling report uses."""
+import os
+import subprocess
+import sys
+import textwrap
+
+from conftest import ROOT
+
+
+def test_shard_ranges_cover_everything():
+    from saugns_amd.shard import shard_range
+    for total in (1, 7, 512, 513):
+        for world in (1, 2, 3, 8):
+            got = []
+            for r in range(world):
+                a, b = shard_range(total, r, world)
+                got += list(range(a, b))
+            assert got == list(range(total))
+
+
+def test_two_rank_gloo_batch(tmp_path):
+    script = textwrap.dedent("""
+        import os, sys, ctypes as C
+        sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+        import numpy as np, torch, torch.distributed as dist
+        dist.init_process_group("gloo")
+        rank, world = dist.get_rank(), dist.get_world_size()
+        import saugns_amd as sa
+        from saugns_amd.shard import shard_range, reduce_report
+        from conftest import load_program, GOLDEN
+        tabs = np.fromfile(os.path.join(GOLDEN, "piluts_ref.f32"), dtype="<f4").reshape(12, 2048)
+        sa.set_piluts(tabs)
+        seq = C.CDLL(os.path.join(%r, "tests", "seqexec", "libseqexec.so"))
+        seq.seq_backend_create.restype = C.c_void_p; seq.seq_backend_create.argtypes = [C.c_uint32]
+        keys = ["config4_seed%%d" %% k for k in range(4)]
+        a, b = shard_range(len(keys), rank, world)
+        prgs = [load_program(sa, k) for k in keys[a:b]]
+        outs = sa.Batch(prgs, 44100, backend=seq.seq_backend_create(1016)).render(chunk=11025, max_frames=11025)
+        heads = np.load(os.path.join(GOLDEN, "pcm_heads.npz"))
+        for k, pcm in zip(keys[a:b], outs):
+            assert int(np.abs(pcm.astype(int) - heads[k][:11025].astype(int)).max()) <= 1, k
+        frames, checksum = reduce_report(sum(len(o) for o in outs), sum(int(o.astype(np.int64).sum()) for o in outs))
+        if rank == 0:
+            want = sum(int(heads[k][:11025].astype(np.int64).sum()) for k in keys)
+            assert frames == 4 * 11025, frames
+            assert abs(checksum - want) <= 4 * 11025, (checksum, want)
+            print("OK", frames)
+        dist.destroy_process_group()
+    """ % (ROOT, ROOT, ROOT))
+    f = tmp_path / "rank.py"
+    f.write_text(script)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                          "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port",
+                          "29533", str(f)], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "OK 44100" in out.stdout

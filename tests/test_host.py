@@ -1,0 +1,117 @@
+"""Host logic without a GPU: C ABI surface, program images, control plane + plan
+compiler (through the sequential test executor), and the loud failure without HIP."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, load_program, max_diff
+
+
+def test_library_exports_every_declared_symbol(sa):
+    hdr = open(os.path.join(ROOT, "include", "saugns_amd.h")).read()
+    names = re.findall(r"SAU_AMD_API[^;(]*?\b(sau\w+)\s*[\[(]", hdr)
+    assert {"sau_create_Generator", "sau_destroy_Generator", "sauGenerator_run",
+            "sauNoise_names"} <= set(names)
+    L = sa.lib()
+    for n in names:
+        assert hasattr(L, n) or C.c_void_p.in_dll(L, n) is not None, n
+    noise = (C.c_char_p * 8).in_dll(L, "sauNoise_names")
+    assert [x.decode() for x in noise[:7]] == ["wh", "gw", "bw", "tw", "re", "vi", "bv"]
+    assert noise[7] is None
+
+
+def test_no_gpu_means_loud_failure(sa):
+    """Without a HIP device the product refuses to run: no CPU fallback."""
+    if sa.lib().sauAmd_device_count() > 0:
+        pytest.skip("a GPU is present")
+    from saugns_amd import voicebank
+    with pytest.raises(RuntimeError, match="NULL"):
+        sa.Generator(voicebank.config1(), 44100)
+    assert "no HIP device" in sa.last_error()
+
+
+def test_program_image_round_trip(sa):
+    for key in ("examples__rainy_thunder", "devtests__voice-reuse", "examples__misc3-2pm_R"):
+        blob = open(os.path.join(GOLDEN, "programs", key + ".saup"), "rb").read()
+        prg = sa.Program.from_image(blob)
+        assert prg.image() == blob
+    with pytest.raises(ValueError):
+        sa.Program.from_image(b"not an image at all.............................")
+
+
+def test_abi_struct_sizes():
+    from saugns_amd import api
+    assert C.sizeof(api.SauLine) == 24 and C.sizeof(api.SauOpData) == 152
+    assert C.sizeof(api.SauEvent) == 40 and C.sizeof(api.SauProgram) == 64
+    assert api.SauOpData.pan.offset == 16 and api.SauOpData.camods.offset == 88
+    assert api.SauOpData.mode.offset == 76 and api.SauProgram.ampmult.offset == 32
+
+
+HOST_KEYS = ["devtests__voice-reuse", "devtests__pm-addremaddrem", "examples__dull_seq-fm_pm",
+             "examples__rainy_thunder", "examples__tests__panning", "examples__tests__wavetypes",
+             "examples__sounds__unnamed2", "examples__tests__scales", "examples__misc3-2pm_R",
+             "examples__tests__sin_ramp_f-exp_log", "examples__random-blip_thump",
+             "examples__tests__line_noisy", "devtests__compnest", "examples__sounds__stereo_static"]
+
+
+@pytest.mark.parametrize("key", HOST_KEYS)
+def test_control_plane_and_plans_vs_oracle(sa, oracle, seqexec, key):
+    """Engine (events, voices, end detection) + plan compiler + shared arithmetic,
+    executed sequentially, against the oracle: bit-exact, any block length."""
+    oracle.oracle().ora_set_fastmath_forms(1)
+    prg = load_program(sa, key)
+    want = oracle.oracle_render(prg.ptr, 12000, True)
+    for block, chunk in ((1016, 11289), (64, 1000)):
+        got = sa.Batch([prg], 12000, backend=seqexec.seq_backend_create(block)).render(
+            stereo=True, chunk=chunk)[0]
+        assert max_diff(got, want) == 0, (key, block)
+
+
+def test_run_return_values_match_reference_semantics(sa, oracle, seqexec):
+    """(more, out_len) per call, like sauGenerator_run (generator.c:953-972)."""
+    prg = load_program(sa, "devtests__voice-reuse")
+    lib = oracle.oracle()
+    g = lib.ora_create(prg.ptr, 12000)
+    b = sa.Batch([prg], 12000, backend=seqexec.seq_backend_create(1016))
+    buf = np.zeros(3001, np.int16)
+    n = C.c_size_t()
+    for _ in range(100):
+        more_o = lib.ora_run(g, buf.ctypes.data, 3001, False, C.byref(n))
+        pcm, more, lens = b.run(3001)
+        assert (bool(more_o), n.value) == (more[0], lens[0])
+        assert (pcm[0] == buf).all()
+        if not more_o:
+            break
+    else:
+        pytest.fail("never ended")
+    lib.ora_destroy(g)
+
+
+def test_batch_streams_are_independent(sa, oracle, seqexec):
+    """Programs with different event timelines in one batch == each alone."""
+    oracle.oracle().ora_set_fastmath_forms(1)
+    keys = ["devtests__voice-reuse", "examples__tests__scales", "examples__dull_seq-fm_pm"]
+    prgs = [load_program(sa, k) for k in keys]
+    outs = sa.Batch(prgs, 12000, backend=seqexec.seq_backend_create(1016)).render(stereo=False, chunk=5000)
+    for k, prg, got in zip(keys, prgs, outs):
+        want = oracle.oracle_render(prg.ptr, 12000, False)
+        assert max_diff(got, want) == 0, k
+
+
+def test_voicebank_builder_equals_parser_images(sa):
+    """The parser-free builder lays out config 1 exactly like the reference parser."""
+    from saugns_amd import voicebank
+    want = sa.Program.from_image(open(os.path.join(GOLDEN, "programs", "config1.saup"), "rb").read())
+    got = voicebank.config1()
+    a, b = want.struct, got.struct
+    assert (a.ev_count, a.vo_count, a.op_count, a.mode, a.duration_ms) == \
+           (b.ev_count, b.vo_count, b.op_count, b.mode, b.duration_ms)
+    oa, ob = a.events[0].op_data[0], b.events[0].op_data[0]
+    for f in ("id", "params", "phase", "seed", "use_type", "type"):
+        assert getattr(oa, f) == getattr(ob, f), f
+    for ln in ("pan", "amp", "freq"):
+        la, lb = getattr(oa, ln).contents, getattr(ob, ln).contents
+        assert (la.v0, la.vt, la.time_ms, la.type, la.flags) == (lb.v0, lb.vt, lb.time_ms, lb.type, lb.flags)

@@ -1,0 +1,114 @@
+"""The oracle (oracle/sau_oracle.c) pinned against the reference's own outputs.
+
+Goldens under tests/golden/ were produced by the compiled reference
+(tests/golden/make_golden.py); when oracle/_ref/libsau_ref.so is present the
+oracle is additionally compared with the live reference."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_program, max_diff
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_tables_fixture_is_what_the_oracle_loads(oracle, tables):
+    got = np.ctypeslib.as_array(oracle.oracle().ora_get_piluts(), shape=(12 * 2048,)).reshape(12, 2048)
+    assert (got.view(np.uint32) == tables.view(np.uint32)).all()
+
+
+def test_ramp_known_answers(oracle):
+    """All 13 shapes, fill and map forms, bit-exact against the reference build."""
+    kat = np.load(os.path.join(GOLDEN, "ramp_kat.npz"))
+    ora = oracle.oracle()
+    ora.ora_set_fastmath_forms(2)
+    mul, e0, e1 = kat["mul"], kat["e0"], kat["e1"]  # keep alive: NpzFile makes temporaries
+    for t in range(13):
+        rows = kat[f"fill_{t}"]
+        r = 0
+        for (time, pos, n, v0, vt) in kat["cases"]:
+            for mb in (None, mul):
+                out = np.zeros(int(n), np.float32)
+                ora.ora_ramp_fill(t, out.ctypes.data, int(n), float(v0), float(vt), int(pos), int(time),
+                                  mb.ctypes.data if mb is not None else None)
+                assert (out.view(np.uint32) == rows[r].view(np.uint32)).all(), (t, r)
+                r += 1
+        x = kat["x"].copy()
+        ora.ora_ramp_map(t, x.ctypes.data, len(x), e0.ctypes.data, e1.ctypes.data)
+        assert (x.view(np.uint32) == kat[f"map_{t}"].view(np.uint32)).all(), t
+
+
+def test_config1_matches_reference(oracle, index):
+    from saugns_amd import voicebank
+    oracle.oracle().ora_set_fastmath_forms(2)
+    prg = voicebank.config1()  # keep the Python-owned structs alive during the render
+    pcm = oracle.oracle_render(prg.ptr, 44100, False)
+    assert len(pcm) == 44100
+    assert list(pcm[:8]) == [1001, 1538, 2557, 3565, 4560, 5537, 6492, 7421]
+    assert _sha(pcm) == index["configs"]["config1"]["sha256"]
+
+
+@pytest.mark.parametrize("name,n", [("config2", 11025), ("config3", 11025), ("config5", 2000)])
+def test_voicebank_heads_match_reference(oracle, heads, name, n):
+    """Configs 2/3/5 built without the parser render exactly what the reference renders."""
+    from saugns_amd import voicebank
+    oracle.oracle().ora_set_fastmath_forms(2)
+    prg = getattr(voicebank, name)()
+    pcm = oracle.oracle_render(prg.ptr, 44100, False, max_frames=n, chunk=11289)
+    assert max_diff(pcm[:n], heads[name][:n]) == 0
+
+
+def test_corpus_heads_bit_exact(oracle, sa, index, heads):
+    """Every corpus script (95): oracle == reference on the committed PCM and full-length hash."""
+    oracle.oracle().ora_set_fastmath_forms(2)
+    rate = index["corpus_rate"]
+    keys = sorted(index["corpus"])
+    assert len(keys) >= 90
+    for key in keys:
+        info = index["corpus"][key]
+        if info["frames"] > 400000:  # keep the CPU suite short; long ones run in the ref test
+            continue
+        prg = load_program(sa, key)
+        pcm = oracle.oracle_render(prg.ptr, rate, True)
+        assert len(pcm) // 2 == info["frames"], key
+        assert _sha(pcm) == info["sha256"], key
+        g = heads[key]
+        assert max_diff(pcm[: len(g)], g) == 0, key
+
+
+def test_config4_seeds(oracle, sa, index, heads):
+    oracle.oracle().ora_set_fastmath_forms(2)
+    prg = load_program(sa, "config4_seed1")
+    pcm = oracle.oracle_render(prg.ptr, 44100, False, max_frames=88200)
+    assert max_diff(pcm[:88200], heads["config4_seed1"]) == 0
+
+
+@pytest.mark.parametrize("block", [1016, 256, 37])
+def test_block_length_invariance(oracle, sa, block):
+    """SURVEY D-2: the result must not depend on the internal block length."""
+    oracle.oracle().ora_set_fastmath_forms(1)
+    for key in ("examples__dull_seq-fm_pm", "examples__rainy_thunder", "devtests__voice-reuse"):
+        prg = load_program(sa, key)
+        a = oracle.oracle_render(prg.ptr, 12000, True, max_frames=60000)
+        b = oracle.oracle_render(prg.ptr, 12000, True, max_frames=60000, block_len=block)
+        assert max_diff(a, b) == 0, key
+
+
+def test_against_live_reference_when_present(oracle, sa, index):
+    """With oracle/_ref built: a few scripts straight against libsau_ref.so."""
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref/libsau_ref.so not built")
+    oracle.oracle().ora_set_fastmath_forms(2)
+    tabs = oracle.ref_piluts()
+    fixture = np.fromfile(os.path.join(GOLDEN, "piluts_ref.f32"), dtype="<f4").reshape(12, 2048)
+    assert (tabs.view(np.uint32) == fixture.view(np.uint32)).all()
+    for key in ("examples__tests__long__sin_pm_1m", "examples__halfrect_ringmod",
+                "examples__tests__through-zero-morph", "examples__sounds__bg-drum-01b"):
+        prg = load_program(sa, key)
+        a = oracle.ref_render(prg.ptr, 12000, True)
+        b = oracle.oracle_render(prg.ptr, 12000, True)
+        assert max_diff(a, b) == 0, key
