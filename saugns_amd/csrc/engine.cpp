@@ -226,7 +226,7 @@ bool Engine::rebuild_plans(std::string &err) {
 bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::string &err) {
 	std::vector<VoiceDesc> descs;
 	std::vector<SegmentDesc::Stream> sdescs(streams_.size());
-	uint32_t n_slots = 1, max_ops = 1, n_pan = 0;
+	uint32_t n_slots = 1, max_ops = 1, n_pan = 0, max_steps = 1;
 	uint64_t wave_mask = 0;
 	for (size_t s = 0; s < streams_.size(); ++s) {
 		Stream &st = streams_[s];
@@ -262,6 +262,7 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 			if (out_len > sd.write_len) sd.write_len = out_len;
 			n_slots = std::max(n_slots, vn.plan.n_slots);
 			max_ops = std::max(max_ops, (uint32_t)vn.plan.op_ids.size());
+			max_steps = std::max(max_steps, (uint32_t)vn.plan.steps.size());
 			wave_mask |= vn.plan.wave_mask;
 		}
 		sd.n_voices = (uint32_t)descs.size() - sd.first_voice;
@@ -277,6 +278,7 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 	seg.voices = descs.data(); seg.n_voices = (uint32_t)descs.size();
 	seg.streams = sdescs.data(); seg.n_streams = (uint32_t)sdescs.size();
 	seg.n_slots = n_slots; seg.max_ops = max_ops; seg.n_pan_rows = n_pan;
+	seg.max_steps = max_steps;
 	seg.wave_mask = wave_mask;
 	return backend_->render(seg, err);
 }

@@ -41,6 +41,7 @@ struct SegmentDesc {
 	uint32_t n_streams;
 	uint32_t n_slots;         /* max slots any active plan uses */
 	uint32_t max_ops;         /* max operators in any active voice */
+	uint32_t max_steps;       /* longest active plan */
 	uint32_t n_pan_rows;
 	uint64_t wave_mask;       /* wave ids in use (bit per id) */
 };

@@ -38,6 +38,8 @@ using sauengine::SegmentDesc;
 /* device side                                                              */
 /* ------------------------------------------------------------------------ */
 
+typedef uint32_t __attribute__((may_alias)) u32_alias; /* raw copies of typed structs */
+
 struct RenderParams {
 	const VoiceDesc *voices;
 	const Step *steps;
@@ -52,6 +54,7 @@ struct RenderParams {
 	uint32_t seg_len;
 	uint32_t n_slots;
 	uint32_t max_ops;
+	uint32_t max_steps;    /* longest plan of the launch (LDS copy) */
 	uint32_t n_tabs;       /* wave types staged in LDS */
 	int8_t tab_of_wave[12];/* LDS table index per wave id, or -1 */
 	uint8_t wave_of_tab[12];
@@ -59,6 +62,8 @@ struct RenderParams {
 };
 
 struct Misc {
+	WaveConst wc[12];      /* per-wave constants, copied from the launch parameters */
+	int32_t tab_of_wave[12];
 	uint32_t len_stack[MAX_NEST + 1];
 	uint32_t tot32[16];
 	unsigned long long tot64[16];
@@ -81,6 +86,31 @@ __device__ __forceinline__ unsigned long long wave_incl_scan64(unsigned long lon
 		if (lane >= d) v += t;
 	}
 	return v;
+}
+
+/* Values that are the same in every lane of the workgroup (plan steps,
+ * operator state, block lengths) are loaded from LDS into vector registers;
+ * moving them to scalar registers lets the compiler use scalar branches and
+ * scalar arithmetic for all the per-step bookkeeping. */
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float uni(float v) { return bits_f(uni(f_bits(v))); }
+__device__ __forceinline__ bool uni(bool v) { return uni((uint32_t)v) != 0; }
+__device__ __forceinline__ double uni(double v) {
+	union { double d; uint32_t u[2]; } c; c.d = v;
+	c.u[0] = uni(c.u[0]); c.u[1] = uni(c.u[1]);
+	return c.d;
+}
+__device__ __forceinline__ LineState uni(const LineState &l) {
+	LineState r;
+	r.v0 = uni(l.v0); r.vt = uni(l.vt); r.pos = uni(l.pos); r.end = uni(l.end);
+	r.type = uni(l.type); r.flags = uni(l.flags);
+	return r;
+}
+__device__ __forceinline__ Step uni(const Step &st) {
+	union { Step s; uint32_t u[4]; } c; c.s = st;
+	c.u[0] = uni(c.u[0]); c.u[1] = uni(c.u[1]); c.u[2] = uni(c.u[2]); c.u[3] = uni(c.u[3]);
+	return c.s;
 }
 
 /* Where the coefficient tables of one wave type are read from. */
@@ -128,6 +158,21 @@ __device__ __forceinline__ void slot_put(float *slot, int w, int p, float v) {
 		slot[(w + 1) * Geo<W, T>::NP] = v;
 }
 
+/* Frequency of one operator for a block when it is a single value:
+ * a held line (no sweep pending) that is absolute, or a ratio of a parent
+ * frequency that is itself a single value. */
+__device__ __forceinline__ bool const_freq(const LineState &ls, bool has_mul, bool parent_const,
+		float parent_f, float &fc) {
+	if (ls.flags & LP_GOAL) return false;
+	if (has_mul && (ls.flags & LP_STATE_RATIO)) {
+		if (!parent_const) return false;
+		fc = ls.v0 * parent_f; /* sau/line.c:72 v0 * mulbuf[i] */
+		return true;
+	}
+	fc = ls.v0;
+	return true;
+}
+
 template <int W, int T>
 __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 	using G = Geo<W, T>;
@@ -141,6 +186,7 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 	float *slots = (float *)(lds + (size_t)P.n_tabs * WAVE_LEN * (sizeof(HerpC23) + sizeof(HerpC01)));
 	DevOp *ops = (DevOp *)(slots + (size_t)P.n_slots * G::SLOT);
 	Misc *misc = (Misc *)(ops + P.max_ops);
+	Step *plan = (Step *)(misc + 1); /* this voice's steps, read every block */
 
 	/* stage coefficient tables (16-byte copies) */
 	for (uint32_t t = 0; t < P.n_tabs; ++t) {
@@ -156,12 +202,20 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 	const VoiceDesc vd = P.voices[blockIdx.x];
 	const uint32_t *my_ids = P.op_ids + vd.ops_ofs;
 	for (uint32_t i = tid; i < vd.nops * 64; i += 64 * W)
-		((uint32_t *)ops)[i] = ((const uint32_t *)&P.ops[my_ids[i >> 6]])[i & 63];
+		((u32_alias *)ops)[i] = ((const u32_alias *)&P.ops[my_ids[i >> 6]])[i & 63];
+	{
+		const u32_alias *src = (const u32_alias *)(P.steps + vd.plan_ofs);
+		for (uint32_t i = tid; i < vd.plan_len * 4; i += 64 * W) ((u32_alias *)plan)[i] = src[i];
+	}
+	if (tid < 12) {
+		misc->wc[tid] = P.wc[tid];
+		misc->tab_of_wave[tid] = P.tab_of_wave[tid];
+	}
+	if (tid == 0) misc->flag = 0;
 	__syncthreads();
 
 	float *vrow = P.vout + (size_t)vd.out_row * P.row_stride;
 	float *prow = (vd.pan_dynamic_row != ~0u) ? P.pan + (size_t)vd.pan_dynamic_row * P.row_stride : nullptr;
-	const Step *plan = P.steps + vd.plan_ofs;
 	uint32_t done = 0, produced = 0;
 
 	/* per-thread sample geometry: p = l*T + k, block sample j = w*(NP-1) + p - 1 */
@@ -169,49 +223,74 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 	const int jbase = w * (G::NP - 1) + p0 - 1;
 
 	while (done < vd.run_len) {
-		if (ops[vd.carr_local].time == 0) break; /* generator.c:839 */
+		if (uni(ops[vd.carr_local].time) == 0) break; /* generator.c:839 */
 		const uint32_t blen = min((uint32_t)G::NB, vd.run_len - done);
 		uint32_t depth = 0;
 		uint32_t cur_len = blen;
 		bool block_ended = false;
 
 		for (uint32_t si = 0; si < vd.plan_len && !block_ended; ++si) {
-			const Step st = plan[si];
-			uint32_t parent_len = cur_len;
+			const Step st = uni(plan[si]);
+			const uint32_t parent_len = cur_len;
 			DevOp *op = &ops[st.op];
+			const uint32_t op_flags = uni(op->flags);
 			if (st.flags & SF_BEGIN) { /* generator.c:694-698 */
 				if (tid == 0) misc->len_stack[depth] = cur_len;
 				++depth;
-				if (!(op->flags & OPF_TIME_INF) && op->time < cur_len) cur_len = op->time;
+				const uint32_t op_time = uni(op->time);
+				if (!(op_flags & OPF_TIME_INF) && op_time < cur_len) cur_len = op_time;
 			}
 			const uint32_t len = cur_len;
+			bool owned[T];
+#pragma unroll
+			for (int k = 0; k < T; ++k) owned[k] = (p0 + k >= 1) && (jbase + k < (int)len);
 
+			/* Every step: reads of operator state and of input slots come first,
+			 * then barrier A, then slot stores and state write-backs, then
+			 * barrier B (steps that exchange data add barriers in between). */
 			switch (st.kind) {
 			case ST_ZERO: {
 				float *out = slots + (size_t)st.out * G::SLOT;
+				__syncthreads();
 #pragma unroll
-				for (int k = 0; k < T; ++k) {
-					int j = jbase + k;
-					if (p0 + k >= 1 && j < (int)len) slot_put<W, T>(out, w, p0 + k, 0.f);
-				}
+				for (int k = 0; k < T; ++k)
+					if (owned[k]) slot_put<W, T>(out, w, p0 + k, 0.f);
 				break;
 			}
 			case ST_LINE: {
 				float *out = slots + (size_t)st.out * G::SLOT;
 				const float *mul = st.fmul != NO_SLOT ? slots + (size_t)st.fmul * G::SLOT : nullptr;
-				LineState ls = op->line[st.which];
-				LineBlock lb = line_begin(ls, len, mul != nullptr, mul ? mul[1] : 0.f);
+				LineState ls = uni(op->line[st.which]);
+				/* a held frequency is passed on as one value instead of a block */
+				bool pconst = false; float pf = 0.f;
+				if (mul && st.prov != NO_SLOT) { pconst = uni(ops[st.prov].rt_fconst_valid) != 0; pf = uni(ops[st.prov].rt_fconst); }
+				float fc = 0.f;
+				const bool lazy = st.which == L_FREQ && !(st.flags & SF_FORCE) && st.op < 255 &&
+					const_freq(ls, mul != nullptr, pconst, pf, fc);
+				float v[T];
+				if (!lazy) {
+					/* the provider's block may be a single value (never stored) */
+					const bool mconst = mul && pconst;
+					LineBlock lb = line_begin(ls, len, mul != nullptr, mul ? (mconst ? pf : mul[1]) : 0.f);
 #pragma unroll
-				for (int k = 0; k < T; ++k) {
-					int j = jbase + k;
-					if (p0 + k >= 1 && j < (int)len) {
-						float m = mul ? mul[w * G::NP + p0 + k] : 1.f;
-						slot_put<W, T>(out, w, p0 + k, line_value(lb, (uint32_t)j, m));
+					for (int k = 0; k < T; ++k) {
+						if (owned[k]) {
+							float m = mul ? (mconst ? pf : mul[w * G::NP + p0 + k]) : 1.f;
+							v[k] = line_value(lb, (uint32_t)(jbase + k), m);
+						}
 					}
+				} else {
+					line_advance_hold(ls, len);
 				}
-				__syncthreads(); /* every thread has read the old line state */
+				__syncthreads();
+				if (!lazy) {
+#pragma unroll
+					for (int k = 0; k < T; ++k)
+						if (owned[k]) slot_put<W, T>(out, w, p0 + k, v[k]);
+				}
 				if (tid == 0) {
 					op->line[st.which] = ls;
+					if (st.which == L_FREQ) { op->rt_fconst_valid = lazy ? 1u : 0u; op->rt_fconst = fc; }
 					if (st.flags & SF_SKIP2) {
 						LineState l2 = op->line[st.tmp];
 						line_skip(l2, len);
@@ -222,18 +301,23 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 			}
 			case ST_SMLINE: { /* generator.c:485-490 */
 				float *out = slots + (size_t)st.out * G::SLOT;
-				LineState ls = op->line[L_PMA];
+				LineState ls = uni(op->line[L_PMA]);
 				const bool active = (ls.v0 != 0.f) || (ls.flags & LP_GOAL);
-				LineBlock lb;
-				if (active) lb = line_begin(ls, len, false, 0.f);
-				else line_skip(ls, len);
+				float v[T];
+				if (active) {
+					LineBlock lb = line_begin(ls, len, false, 0.f);
 #pragma unroll
-				for (int k = 0; k < T; ++k) {
-					int j = jbase + k;
-					if (p0 + k >= 1 && j < (int)len)
-						slot_put<W, T>(out, w, p0 + k, active ? line_value(lb, (uint32_t)j, 1.f) : 0.f);
+					for (int k = 0; k < T; ++k)
+						v[k] = owned[k] ? line_value(lb, (uint32_t)(jbase + k), 1.f) : 0.f;
+				} else {
+					line_skip(ls, len);
+#pragma unroll
+					for (int k = 0; k < T; ++k) v[k] = 0.f;
 				}
 				__syncthreads();
+#pragma unroll
+				for (int k = 0; k < T; ++k)
+					if (owned[k]) slot_put<W, T>(out, w, p0 + k, v[k]);
 				if (tid == 0) op->line[L_PMA] = ls;
 				break;
 			}
@@ -241,64 +325,91 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 				float *par = slots + (size_t)st.out * G::SLOT;
 				const float *rpar = slots + (size_t)st.freq * G::SLOT;
 				const float *mod = slots + (size_t)st.pm * G::SLOT;
+				float v[T];
 #pragma unroll
 				for (int k = 0; k < T; ++k) {
-					int j = jbase + k;
-					if (p0 + k >= 1 && j < (int)len) {
+					if (owned[k]) {
 						int e = w * G::NP + p0 + k;
 						float pv = par[e];
 						pv += (rpar[e] - pv) * mod[e];
-						slot_put<W, T>(par, w, p0 + k, pv);
+						v[k] = pv;
 					}
 				}
+				__syncthreads();
+#pragma unroll
+				for (int k = 0; k < T; ++k)
+					if (owned[k]) slot_put<W, T>(par, w, p0 + k, v[k]);
 				break;
 			}
 			case ST_OSC: {
 				float *out = slots + (size_t)st.out * G::SLOT;
 				float *scratch = slots; /* SCRATCH_SLOT */
-				uint32_t *scratch_u = (uint32_t *)slots;
-				unsigned long long wb_grand64 = 0; /* R: counter advance */
-				uint32_t wb_noise_prev = 0;
-				bool wb_noise_prev_set = false;
+				u32_alias *scratch_u = (u32_alias *)slots;
 				const float *fslot = st.freq != NO_SLOT ? slots + (size_t)st.freq * G::SLOT : nullptr;
 				const float *fmul = st.fmul != NO_SLOT ? slots + (size_t)st.fmul * G::SLOT : nullptr;
 				const float *pmS = st.pm != NO_SLOT ? slots + (size_t)st.pm * G::SLOT : nullptr;
 				const float *fpmS = st.fpm != NO_SLOT ? slots + (size_t)st.fpm * G::SLOT : nullptr;
 				const float *ampS = st.amp != NO_SLOT ? slots + (size_t)st.amp * G::SLOT : nullptr;
 				const float *smS = st.sm != NO_SLOT ? slots + (size_t)st.sm * G::SLOT : nullptr;
-				const uint32_t type = op->type;
+				const uint32_t type = uni(op->type);
 				const bool is_osc = (type == OT_WAVE || type == OT_RASEG);
-				if (tid == 0) misc->flag = 0;
+				const bool wave_env = (st.flags & SF_WAVE_ENV) != 0;
+				const bool layer = (st.flags & SF_LAYER) != 0;
 
-				float s[T], av[T];
-				bool owned[T];
+				float s[T], av[T], dv[T];
 #pragma unroll
-				for (int k = 0; k < T; ++k) {
-					owned[k] = (p0 + k >= 1) && (jbase + k < (int)len);
-					s[k] = 0.f;
-				}
+				for (int k = 0; k < T; ++k) { s[k] = 0.f; av[k] = 0.f; dv[k] = 0.f; }
 
-				/* --- uniform line setup; per-sample values are taken right
-				 * away so that only T floats stay live, not the line blocks */
+				/* ---- frequency: one value for the block, a slot, or a line ---- */
+				bool pconst = false; float pf = 0.f;
+				if (st.prov != NO_SLOT) { pconst = uni(ops[st.prov].rt_fconst_valid) != 0; pf = uni(ops[st.prov].rt_fconst); }
 				LineState fls, als, pls;
 				LineBlock flb;
-				bool f_inline = is_osc && !fslot;
-				if (f_inline) {
-					fls = op->line[L_FREQ];
-					flb = line_begin(fls, len, fmul != nullptr, fmul ? fmul[1] : 0.f);
+				const bool f_inline = is_osc && !fslot;
+				bool fconst = false; float fc = 0.f;
+				bool mconst = false; /* the ratio multiplier is a single value */
+				if (is_osc) {
+					if (f_inline) {
+						fls = uni(op->line[L_FREQ]);
+						fconst = const_freq(fls, fmul != nullptr, pconst, pf, fc);
+						mconst = fmul && pconst;
+						if (!fconst)
+							flb = line_begin(fls, len, fmul != nullptr, fmul ? (mconst ? pf : fmul[1]) : 0.f);
+						else
+							line_advance_hold(fls, len);
+					} else if (pconst) { /* own frequency block was never stored */
+						fconst = true; fc = pf;
+					}
 				}
+				/* ---- amplitude values, existing output for layering ---------- */
 				const bool a_inline = !ampS;
 				if (a_inline) {
-					als = op->line[L_AMP];
-					const LineBlock alb = line_begin(als, len, false, 0.f);
+					als = uni(op->line[L_AMP]);
+					if (!(als.flags & LP_GOAL)) {
+						const float ac = als.v0; /* held: sau/line.c:435-442 */
+						line_advance_hold(als, len);
+#pragma unroll
+						for (int k = 0; k < T; ++k) av[k] = ac;
+					} else {
+						const LineBlock alb = line_begin(als, len, false, 0.f);
+#pragma unroll
+						for (int k = 0; k < T; ++k)
+							av[k] = owned[k] ? line_value(alb, (uint32_t)(jbase + k), 1.f) : 0.f;
+					}
+				} else {
 #pragma unroll
 					for (int k = 0; k < T; ++k)
-						av[k] = owned[k] ? line_value(alb, (uint32_t)(jbase + k), 1.f) : 0.f;
+						if (owned[k]) av[k] = ampS[w * G::NP + p0 + k];
+				}
+				if (layer) {
+#pragma unroll
+					for (int k = 0; k < T; ++k)
+						if (owned[k]) dv[k] = out[w * G::NP + p0 + k];
 				}
 				bool sm_inline_active = false;
-				LineState pls0; /* pm_a line before this block (serial path re-derives its values) */
+				LineState pls0; /* pm_a line before this block (the serial path re-derives values) */
 				if (is_osc && (st.flags & SF_SM_INLINE)) {
-					pls = op->line[L_PMA];
+					pls = uni(op->line[L_PMA]);
 					pls0 = pls;
 					sm_inline_active = (pls.v0 != 0.f) || (pls.flags & LP_GOAL);
 					if (sm_inline_active) (void)line_begin(pls, len, false, 0.f);
@@ -306,57 +417,93 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 				}
 				const bool selfmod = is_osc && (smS != nullptr || sm_inline_active);
 
+				/* state updates decided before barrier A, applied after it */
+				uint32_t wb_phase = 0, wb_prev_phase = 0; double wb_prev_Is = 0; float wb_prev_s = 0;
+				bool wb_owner = false;            /* this lane holds the block's last sample */
+				bool wb_serial_done = false;      /* serial path already updated the osc state */
+				unsigned long long wb_grand64 = 0;
+				uint32_t wb_grand32 = 0;
+				uint32_t wb_noise_prev = 0; bool wb_noise_prev_set = false;
+				bool w_parallel = false;
+				TabRef tab; tab.c23 = nullptr; tab.c01 = nullptr; tab.in_lds = false;
+				WaveConst wc; wc.diff_scale = 0; wc.diff_offset = 0; wc.phase_adj = 0; wc.pad = 0;
+				uint32_t ph[T];
+#pragma unroll
+				for (int k = 0; k < T; ++k) ph[k] = 0;
+
 				if (type == OT_WAVE) {
-					/* ---- phase accumulation: wosc.h:135-169 ------------- */
-					const WaveConst wc = P.wc[op->wave];
-					TabRef tab;
+					const uint32_t wave = uni(op->wave);
+					wc.diff_scale = uni(misc->wc[wave].diff_scale);
+					wc.diff_offset = uni(misc->wc[wave].diff_offset);
 					{
-						int ti = P.tab_of_wave[op->wave];
+						int ti = uni(misc->tab_of_wave[wave]);
 						tab.in_lds = ti >= 0;
-						tab.c23 = ti >= 0 ? t23 + (size_t)ti * WAVE_LEN : P.g_c23 + (size_t)op->wave * WAVE_LEN;
-						tab.c01 = ti >= 0 ? t01 + (size_t)ti * WAVE_LEN : P.g_c01 + (size_t)op->wave * WAVE_LEN;
+						tab.c23 = ti >= 0 ? t23 + (size_t)ti * WAVE_LEN : P.g_c23 + (size_t)wave * WAVE_LEN;
+						tab.c01 = ti >= 0 ? t01 + (size_t)ti * WAVE_LEN : P.g_c01 + (size_t)wave * WAVE_LEN;
 					}
-					const float coeff = op->coeff;
-					uint32_t inc[T], ofs[T];
-					uint32_t lane_sum = 0;
-					/* halo sample of this wave (lane 0, k 0) needs its PM offset too */
+					const float coeff = uni(op->coeff);
 					const bool halo = (p0 == 0);
 					const bool halo_live = halo && w > 0 && (jbase < (int)len);
+					const uint32_t phase0 = uni(op->phase);
+					uint32_t acc_last = 0; /* accumulator after this lane's last owned sample */
+					if (fconst) {
+						/* ---- wosc.h:135-169 with a constant increment: the wrapping
+						 * sum of j+1 equal increments is one multiplication ---------- */
+						const uint32_t inc = rint32w(coeff * fc);
 #pragma unroll
-					for (int k = 0; k < T; ++k) {
-						inc[k] = 0; ofs[k] = 0;
-						const bool need = owned[k] || (k == 0 && halo_live);
-						if (need) {
-							const int e = w * G::NP + p0 + k;
-							const int j = jbase + k;
-							float f = fslot ? fslot[e]
-							                : line_value(flb, (uint32_t)j, fmul ? fmul[e] : 1.f);
-							if (owned[k]) inc[k] = rint32w(coeff * f);
-							ofs[k] = (uint32_t)pm_offset(pmS != nullptr, fpmS != nullptr,
-									pmS ? pmS[e] : 0.f, fpmS ? fpmS[e] : 0.f, f, 0x1p31f);
+						for (int k = 0; k < T; ++k) {
+							const bool need = owned[k] || (k == 0 && halo_live);
+							if (need) {
+								const int e = w * G::NP + p0 + k;
+								const uint32_t acc = phase0 + inc * (uint32_t)(jbase + k + 1);
+								uint32_t ofs = (uint32_t)pm_offset(pmS != nullptr, fpmS != nullptr,
+										pmS ? pmS[e] : 0.f, fpmS ? fpmS[e] : 0.f, fc, 0x1p31f);
+								ph[k] = acc + ofs;
+								if (owned[k]) acc_last = acc;
+							}
 						}
-						lane_sum += inc[k];
-					}
-					const uint32_t incl = wave_incl_scan(lane_sum, l);
-					if (l == 63) misc->tot32[w] = incl;
-					__syncthreads();
-					uint32_t base = op->phase, grand = 0;
+						wb_grand32 = inc * len;
+					} else {
+						/* ---- wosc.h:135-169: exact integer prefix scan -------------- */
+						uint32_t inc[T], ofs[T];
+						uint32_t lane_sum = 0;
 #pragma unroll
-					for (int ww = 0; ww < W; ++ww) {
-						uint32_t t = misc->tot32[ww];
-						if (ww < w) base += t;
-						grand += t;
-					}
-					const bool reset = (op->flags & OPF_OSC_RESET) && len > 0;
-					uint32_t ph[T];
-					uint32_t run = base + (incl - lane_sum);
+						for (int k = 0; k < T; ++k) {
+							inc[k] = 0; ofs[k] = 0;
+							const bool need = owned[k] || (k == 0 && halo_live);
+							if (need) {
+								const int e = w * G::NP + p0 + k;
+								const int j = jbase + k;
+								float f = fslot ? fslot[e]
+								                : line_value(flb, (uint32_t)j, fmul ? (mconst ? pf : fmul[e]) : 1.f);
+								if (owned[k]) inc[k] = rint32w(coeff * f);
+								ofs[k] = (uint32_t)pm_offset(pmS != nullptr, fpmS != nullptr,
+										pmS ? pmS[e] : 0.f, fpmS ? fpmS[e] : 0.f, f, 0x1p31f);
+							}
+							lane_sum += inc[k];
+						}
+						const uint32_t incl = wave_incl_scan(lane_sum, l);
+						if (l == 63) misc->tot32[w] = incl;
+						__syncthreads();
+						uint32_t base = phase0;
 #pragma unroll
-					for (int k = 0; k < T; ++k) {
-						run += inc[k];
-						ph[k] = run + ofs[k];
+						for (int ww = 0; ww < W; ++ww) {
+							uint32_t t = misc->tot32[ww];
+							if (ww < w) base += t;
+							wb_grand32 += t;
+						}
+						uint32_t run = base + (incl - lane_sum);
+#pragma unroll
+						for (int k = 0; k < T; ++k) {
+							run += inc[k];
+							ph[k] = run + ofs[k];
+							if (owned[k]) acc_last = run;
+						}
 					}
 					if (!selfmod) {
 						/* ---- lookup + differentiate: wosc.h:238-266 ------- */
+						w_parallel = true;
+						const bool reset = (op_flags & OPF_OSC_RESET) && len > 0;
 						double Is[T];
 						if (halo && w == 0) {
 							/* sample before the block: carried state, or the
@@ -365,7 +512,7 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 						}
 #pragma unroll
 						for (int k = 0; k < T; ++k) {
-							const bool need = owned[k] || (k == 0 && (halo_live || (halo && w == 0)));
+							const bool need = owned[k] || (k == 0 && (halo_live || (halo && w == 0 && reset)));
 							Is[k] = need ? herp_lookup(tab, ph[k]) : 0.0;
 						}
 						if (halo && w == 0 && !reset) Is[0] = op->prev_Is;
@@ -379,30 +526,17 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 								int32_t d = (int32_t)(ph[k] - pph);
 								if (d == 0) anyzero = true;
 								else s[k] = wosc_diff(Is[k], pIs, d, wc.diff_scale, wc.diff_offset);
-							}
-						}
-						if (__any(anyzero) && l == 0) misc->flag = 1;
-						__syncthreads();
-						if (misc->flag == 0) {
-							/* carried state: owner of the last sample */
-#pragma unroll
-							for (int k = 0; k < T; ++k) {
-								if (owned[k] && jbase + k == (int)len - 1) {
-									uint32_t r = base + (incl - lane_sum);
-									for (int q = 0; q <= k; ++q) r += inc[q];
-									op->phase = r;
-									op->prev_phase = ph[k];
-									op->prev_Is = Is[k];
-									op->prev_s = s[k];
-									op->flags &= ~OPF_OSC_RESET;
+								if (jbase + k == (int)len - 1) {
+									wb_owner = true;
+									wb_phase = acc_last; wb_prev_phase = ph[k];
+									wb_prev_Is = Is[k]; wb_prev_s = s[k];
 								}
 							}
 						}
-					}
-					if (selfmod || misc->flag != 0) {
-						/* ---- serial path: feedback recurrence (wosc.h:273-310)
-						 * or fill-forward over dphase == 0 (wosc.h:251-252) ---- */
-						if (!selfmod) __syncthreads(); /* all flag reads done before scratch reuse */
+						if (__any(anyzero) && l == 0) misc->flag = 1;
+					} else {
+						/* ---- serial: feedback recurrence, wosc.h:273-310 ---------- */
+						__syncthreads(); /* scratch may still be read as a slot by a lagging wave */
 #pragma unroll
 						for (int k = 0; k < T; ++k)
 							if (owned[k]) scratch_u[w * G::NP + p0 + k] = ph[k];
@@ -414,20 +548,17 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 							double prev_Is = op->prev_Is;
 							float prev_s = op->prev_s, fb_s = op->fb_s;
 							if (op->flags & OPF_OSC_RESET) {
-								uint32_t phase0 = scratch_u[entry_of<W, T>(0)];
-								prev_Is = herp_lookup(tab, phase0 - SLEN);
-								double Is0 = herp_lookup(tab, phase0);
+								uint32_t phase00 = scratch_u[entry_of<W, T>(0)];
+								prev_Is = herp_lookup(tab, phase00 - SLEN);
+								double Is0 = herp_lookup(tab, phase00);
 								prev_s = wosc_diff(Is0, prev_Is, (int32_t)SLEN, wc.diff_scale, wc.diff_offset);
 								prev_Is = Is0;
-								prev_phase = phase0;
+								prev_phase = phase00;
 							}
 							for (uint32_t j = 0; j < len; ++j) {
 								const uint32_t e = entry_of<W, T>(j);
-								uint32_t phase = scratch_u[e];
-								if (selfmod) {
-									float pma = smS ? smS[e] : line_value(plb, j, 1.f);
-									phase += rint32w(fb_s * pma * 0x1p31f);
-								}
+								float pma = smS ? smS[e] : line_value(plb, j, 1.f);
+								uint32_t phase = scratch_u[e] + rint32w(fb_s * pma * 0x1p31f);
 								int32_t d = (int32_t)(phase - prev_phase);
 								float sv;
 								if (d == 0) {
@@ -438,19 +569,18 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 									prev_Is = Isv; prev_s = sv; prev_phase = phase;
 								}
 								scratch[e] = sv;
-								if (selfmod) fb_s = (fb_s + sv) * 0.5f;
+								fb_s = (fb_s + sv) * 0.5f;
 							}
-							op->phase += grand;
 							op->prev_phase = prev_phase;
 							op->prev_Is = prev_Is;
 							op->prev_s = prev_s;
 							op->fb_s = fb_s;
-							op->flags &= ~OPF_OSC_RESET;
 						}
 						__syncthreads();
 #pragma unroll
 						for (int k = 0; k < T; ++k)
 							if (owned[k]) s[k] = scratch[w * G::NP + p0 + k];
+						wb_serial_done = true;
 					}
 				} else if (type == OT_RASEG) {
 					/* ---- rasg.h:165-222 cycle|phase counter (post-increment) */
@@ -466,8 +596,8 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 						if (owned[k]) {
 							const int e = w * G::NP + p0 + k;
 							const int j = jbase + k;
-							float f = fslot ? fslot[e]
-							                : line_value(flb, (uint32_t)j, fmul ? fmul[e] : 1.f);
+							float f = fconst ? fc : (fslot ? fslot[e]
+							                : line_value(flb, (uint32_t)j, fmul ? (mconst ? pf : fmul[e]) : 1.f));
 							inc[k] = (unsigned long long)rint64(coeff * f);
 							ofs[k] = (unsigned long long)pm_offset(pmS != nullptr, fpmS != nullptr,
 									pmS ? pmS[e] : 0.f, fpmS ? fpmS[e] : 0.f, f, phase_scale);
@@ -477,12 +607,12 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 					const unsigned long long incl = wave_incl_scan64(lane_sum, l);
 					if (l == 63) misc->tot64[w] = incl;
 					__syncthreads();
-					unsigned long long base = op->cycle_phase, grand = 0;
+					unsigned long long base = op->cycle_phase;
 #pragma unroll
 					for (int ww = 0; ww < W; ++ww) {
 						unsigned long long t = misc->tot64[ww];
 						if (ww < w) base += t;
-						grand += t;
+						wb_grand64 += t;
 					}
 					unsigned long long run = base + (incl - lane_sum);
 					uint32_t cyc[T];
@@ -497,10 +627,9 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 #pragma unroll
 						for (int k = 0; k < T; ++k)
 							if (owned[k]) s[k] = ras_sample(rp, cyc[k], phf[k]); /* rasg.h:692-743 */
-						wb_grand64 = grand;
 					} else {
 						/* rasg.h:242-280 per-sample form with feedback */
-						uint32_t *tmp = (uint32_t *)(slots + (size_t)st.tmp * G::SLOT);
+						u32_alias *tmp = (u32_alias *)(slots + (size_t)st.tmp * G::SLOT);
 #pragma unroll
 						for (int k = 0; k < T; ++k) {
 							if (owned[k]) {
@@ -529,7 +658,6 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 							op->fb_s = fb_s;
 							op->prev_s = prev_s;
 						}
-						wb_grand64 = grand;
 						__syncthreads();
 #pragma unroll
 						for (int k = 0; k < T; ++k)
@@ -590,26 +718,94 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 						for (int k = 0; k < T; ++k)
 							if (owned[k]) s[k] = noise_stateless(nz, n0 + (uint32_t)(jbase + k));
 					}
-					(void)0;
 				} else { /* OT_AMP: generator.c:517-518 */
 #pragma unroll
 					for (int k = 0; k < T; ++k) s[k] = 1.f;
 				}
 
-				/* ---- amplitude + combine: generator.c:384-440 ------------ */
-				const bool wave_env = (st.flags & SF_WAVE_ENV) != 0;
-				const bool layer = (st.flags & SF_LAYER) != 0;
+				/* ---- barrier A: every read of operator state and input slots is done */
+				__syncthreads();
+				if (w_parallel && uni(misc->flag) != 0) {
+					/* rare: dphase == 0 somewhere -> hold the previous output
+					 * (wosc.h:251-252), resolved serially over the block */
+					__syncthreads(); /* all flag reads done before it is cleared below */
+#pragma unroll
+					for (int k = 0; k < T; ++k)
+						if (owned[k]) scratch_u[w * G::NP + p0 + k] = ph[k];
+					__syncthreads();
+					if (tid == 0 && len > 0) {
+						uint32_t prev_phase = op->prev_phase;
+						double prev_Is = op->prev_Is;
+						float prev_s = op->prev_s;
+						if (op->flags & OPF_OSC_RESET) {
+							uint32_t phase00 = scratch_u[entry_of<W, T>(0)];
+							prev_Is = herp_lookup(tab, phase00 - SLEN);
+							double Is0 = herp_lookup(tab, phase00);
+							prev_s = wosc_diff(Is0, prev_Is, (int32_t)SLEN, wc.diff_scale, wc.diff_offset);
+							prev_Is = Is0;
+							prev_phase = phase00;
+						}
+						for (uint32_t j = 0; j < len; ++j) {
+							const uint32_t e = entry_of<W, T>(j);
+							uint32_t phase = scratch_u[e];
+							int32_t d = (int32_t)(phase - prev_phase);
+							float sv;
+							if (d == 0) {
+								sv = prev_s;
+							} else {
+								double Isv = herp_lookup(tab, phase);
+								sv = wosc_diff(Isv, prev_Is, d, wc.diff_scale, wc.diff_offset);
+								prev_Is = Isv; prev_s = sv; prev_phase = phase;
+							}
+							scratch[e] = sv;
+						}
+						op->prev_phase = prev_phase;
+						op->prev_Is = prev_Is;
+						op->prev_s = prev_s;
+						misc->flag = 0;
+					}
+					__syncthreads();
+#pragma unroll
+					for (int k = 0; k < T; ++k)
+						if (owned[k]) s[k] = scratch[w * G::NP + p0 + k];
+					wb_serial_done = true;
+					wb_owner = false;
+				}
+
+				/* ---- combine (generator.c:384-440), hand-over, write-backs ------ */
+				const bool to_voice = (st.which & OX_VOICE) != 0;
+				LineState pl;
+				LineBlock plb2;
+				bool pan_goal = false;
+				if (to_voice) { /* generator.c:749-788; the sum over voices is mix_kernel */
+					pl = uni(op->line[L_PAN]);
+					pan_goal = (pl.flags & LP_GOAL) != 0;
+					if (pan_goal) plb2 = line_begin(pl, len, false, 0.f);
+					else line_skip(pl, len);
+				}
 #pragma unroll
 				for (int k = 0; k < T; ++k) {
 					if (owned[k]) {
-						const int e = w * G::NP + p0 + k;
-						float a = ampS ? ampS[e] : av[k];
-						float d = layer ? out[e] : 0.f;
-						slot_put<W, T>(out, w, p0 + k, mix_combine(d, s[k], a, wave_env, layer));
+						const float r = mix_combine(dv[k], s[k], av[k], wave_env, layer);
+						if (to_voice) {
+							const int j = jbase + k;
+							vrow[done + j] = r;
+							if (prow) prow[done + j] = pan_goal ? line_value(plb2, (uint32_t)j, 1.f) : pl.v0;
+						} else {
+							slot_put<W, T>(out, w, p0 + k, r);
+						}
 					}
 				}
-				__syncthreads(); /* all reads of the operator state are done */
+				if (wb_owner) { /* the lane that holds the block's last sample */
+					op->prev_phase = wb_prev_phase;
+					op->prev_Is = wb_prev_Is;
+					op->prev_s = wb_prev_s;
+				}
 				if (tid == 0) {
+					if (type == OT_WAVE) {
+						op->phase += wb_grand32;
+						if (len > 0) op->flags &= ~OPF_OSC_RESET;
+					}
 					if (type == OT_RASEG) op->cycle_phase += wb_grand64;
 					if (type == OT_NOISE) {
 						op->noise_n += len;
@@ -620,6 +816,8 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 						LineState l2 = op->line[L_FREQ2];
 						line_skip(l2, len);
 						op->line[L_FREQ2] = l2;
+						op->rt_fconst_valid = fconst ? 1u : 0u;
+						op->rt_fconst = fc;
 					}
 					if (a_inline) {
 						op->line[L_AMP] = als;
@@ -628,10 +826,13 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 						op->line[L_AMP2] = l2;
 					}
 					if (is_osc && (st.flags & SF_SM_INLINE)) op->line[L_PMA] = pls;
+					if (to_voice) op->line[L_PAN] = pl;
 				}
+				if (to_voice) produced += len;
+				(void)wb_phase; (void)wb_serial_done;
 				break;
 			}
-			case ST_VOICE: { /* generator.c:749-788, mixing itself is mix_kernel */
+			case ST_VOICE: { /* generator.c:749-788 with pan modulators */
 				const float *src = slots + (size_t)st.out * G::SLOT;
 				const float *panS = st.pm != NO_SLOT ? slots + (size_t)st.pm * G::SLOT : nullptr;
 				LineState pl = op->line[L_PAN];
@@ -643,8 +844,8 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 				}
 #pragma unroll
 				for (int k = 0; k < T; ++k) {
-					int j = jbase + k;
-					if (p0 + k >= 1 && j < (int)len) {
+					if (owned[k]) {
+						const int j = jbase + k;
 						const int e = w * G::NP + p0 + k;
 						vrow[done + j] = src[e];
 						if (prow)
@@ -657,36 +858,34 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 				produced += len;
 				break;
 			}
-			default: break;
+			default:
+				__syncthreads();
+				break;
 			}
 
-			if (st.flags & SF_END) { /* generator.c:719-728 */
-				if (!(op->flags & OPF_TIME_INF)) {
-					uint32_t outer;
-					if (st.flags & SF_BEGIN) outer = parent_len;
-					else outer = misc->len_stack[depth - 1];
-					if (!(st.flags & SF_LAYER) && st.kind == ST_OSC) {
-						float *out = slots + (size_t)st.out * G::SLOT;
+			if (st.flags & SF_END) { /* generator.c:719-728; runs after barrier A of ST_OSC */
+				const bool inf = (op_flags & OPF_TIME_INF) != 0;
+				--depth;
+				const uint32_t outer = (st.flags & SF_BEGIN) ? parent_len : uni(misc->len_stack[depth]);
+				if (!inf && !(st.flags & SF_LAYER) && !(st.which & OX_VOICE)) {
+					float *out = slots + (size_t)st.out * G::SLOT;
 #pragma unroll
-						for (int k = 0; k < T; ++k) {
-							int j = jbase + k;
-							if (p0 + k >= 1 && j >= (int)len && j < (int)outer)
-								slot_put<W, T>(out, w, p0 + k, 0.f);
-						}
+					for (int k = 0; k < T; ++k) {
+						int j = jbase + k;
+						if (p0 + k >= 1 && j >= (int)len && j < (int)outer)
+							slot_put<W, T>(out, w, p0 + k, 0.f);
 					}
 				}
-				--depth;
-				uint32_t restored = (st.flags & SF_BEGIN) ? parent_len : misc->len_stack[depth];
-				__syncthreads(); /* time/len reads above precede the update */
-				if (tid == 0 && !(op->flags & OPF_TIME_INF)) op->time -= len;
 				if (depth == 0) {
-					/* carrier finished: the voice-level steps run for its length */
+					/* carrier finished: voice-level steps run for its length */
 					cur_len = len;
 					if (len == 0) block_ended = true; /* generator.c:842 */
 				} else {
-					cur_len = restored;
+					cur_len = outer;
 				}
+				if (tid == 0 && !inf) op->time -= len;
 			}
+			/* ---- barrier B: stores and write-backs visible to the next step ---- */
 			__syncthreads();
 		}
 		done += blen;
@@ -705,7 +904,7 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 	}
 	__syncthreads();
 	for (uint32_t i = tid; i < vd.nops * 64; i += 64 * W)
-		((uint32_t *)&P.ops[my_ids[i >> 6]])[i & 63] = ((const uint32_t *)ops)[i];
+		((u32_alias *)&P.ops[my_ids[i >> 6]])[i & 63] = ((const u32_alias *)ops)[i];
 }
 
 struct MixStream {
@@ -845,7 +1044,7 @@ public:
 		if (lds_limit_ > 160 * 1024) lds_limit_ = 160 * 1024;
 		if (const char *ll = getenv("SAU_AMD_LDS_LIMIT")) lds_limit_ = (size_t)atol(ll);
 		const char *wt = getenv("SAU_AMD_GEOMETRY"); /* "8x2" (default) or "4x4" */
-		geo_ = (wt && !strcmp(wt, "4x4")) ? 1 : 0;
+		geo_ = (wt && !strcmp(wt, "8x2")) ? 0 : 1; /* default 4 waves x 4 samples per lane */
 		debug_ = getenv("SAU_AMD_DEBUG") != nullptr;
 		if (!ops_.ensure(cfg.op_count ? cfg.op_count : 1, err)) return false;
 		HIP_OK(hipMemsetAsync(ops_.p, 0, ops_.cap * sizeof(DevOp), stream_));
@@ -921,7 +1120,8 @@ public:
 		const uint32_t W = geo_ ? 4 : 8, T = geo_ ? 4 : 2;
 		const size_t slot_bytes = (size_t)W * 64 * T * sizeof(float);
 		/* LDS budget: slots + operator cache + misc, rest for tables */
-		size_t fixed = slot_bytes * seg.n_slots + (size_t)seg.max_ops * sizeof(DevOp) + sizeof(Misc) + 64;
+		size_t fixed = slot_bytes * seg.n_slots + (size_t)seg.max_ops * sizeof(DevOp) + sizeof(Misc) +
+			(size_t)seg.max_steps * sizeof(Step) + 64;
 		if (fixed > lds_limit_) {
 			err = "voice too large for one workgroup's LDS (block buffers + operator states)";
 			return false;
@@ -979,6 +1179,7 @@ public:
 		rp.g_c23 = c23_.p; rp.g_c01 = c01_.p;
 		rp.row_stride = row_stride_; rp.seg_len = seg.len;
 		rp.n_slots = seg.n_slots; rp.max_ops = seg.max_ops; rp.n_tabs = n_tabs;
+		rp.max_steps = seg.max_steps;
 		memcpy(rp.wc, wconst_, sizeof wconst_);
 		TimedPair *tp = timing_on_ ? new_pair() : nullptr;
 		if (tp) (void)hipEventRecord(tp->a, stream_);

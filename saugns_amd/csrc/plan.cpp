@@ -55,7 +55,7 @@ struct Compiler {
 		Step s;
 		s.kind = kind; s.flags = 0;
 		s.out = s.freq = s.fmul = s.pm = s.fpm = s.amp = s.sm = NO_SLOT;
-		s.which = 0; s.tmp = NO_SLOT; s.pad = 0;
+		s.which = 0; s.tmp = NO_SLOT; s.prov = NO_SLOT;
 		s.op = op_local;
 		out.steps.push_back(s);
 		return out.steps.back();
@@ -63,41 +63,44 @@ struct Compiler {
 
 	static uint32_t count(const sauProgramIDArr *a) { return a ? a->count : 0; }
 
-	void children(const sauProgramIDArr *ids, uint8_t dst, uint8_t freq,
+	void children(const sauProgramIDArr *ids, uint8_t dst, uint8_t freq, uint8_t prov,
 			bool wave_env, bool layer_all) {
 		for (uint32_t i = 0; i < count(ids); ++i)
-			eval(ids->ids[i], dst, freq, wave_env, layer_all ? true : (i > 0), false);
+			eval(ids->ids[i], dst, freq, prov, wave_env, layer_all ? true : (i > 0), false);
 	}
 
 	/* parameter with optional range modulation + additive modulators into a
 	 * slot: generator.c:448-477. Returns with `dst` holding the values. */
 	void param_to_slot(uint32_t lop, uint32_t line, uint32_t line2, uint8_t dst,
-			uint8_t mul, uint8_t child_freq, const sauProgramIDArr *mods,
-			const sauProgramIDArr *r_mods, bool &first) {
+			uint8_t mul, uint8_t mul_prov, uint8_t child_freq, uint8_t child_prov,
+			const sauProgramIDArr *mods, const sauProgramIDArr *r_mods, bool &first) {
 		Step &s = emit(ST_LINE, lop);
-		s.which = (uint8_t)line; s.out = dst; s.fmul = mul;
+		s.which = (uint8_t)line; s.out = dst; s.fmul = mul; s.prov = mul_prov;
 		s.tmp = (uint8_t)line2;
 		if (first) { s.flags |= SF_BEGIN; first = false; }
+		/* a frequency block that nothing adds into may stay a single value */
+		if (line != L_FREQ || count(mods) || count(r_mods)) s.flags |= SF_FORCE;
 		if (count(r_mods) == 0) {
 			s.flags |= SF_SKIP2;
 		} else {
 			uint8_t r = alloc();
 			Step &s2 = emit(ST_LINE, lop);
-			s2.which = (uint8_t)line2; s2.out = r; s2.fmul = mul; s2.tmp = (uint8_t)line2;
+			s2.which = (uint8_t)line2; s2.out = r; s2.fmul = mul; s2.prov = mul_prov;
+			s2.tmp = (uint8_t)line2; s2.flags |= SF_FORCE;
 			uint8_t m = alloc();
-			children(r_mods, m, child_freq, true, false);
+			children(r_mods, m, child_freq, child_prov, true, false);
 			Step &l = emit(ST_LERP, lop);
 			l.out = dst; l.freq = r; l.pm = m;
 			release(m); release(r);
 		}
 		if (count(mods) > 0)
-			children(mods, dst, child_freq, false, true);
+			children(mods, dst, child_freq, child_prov, false, true);
 	}
 
 	/* One operator, combined into slot `dst`. Returns the slot that holds its
 	 * frequency block when keep_freq (caller releases it), else NO_SLOT. */
-	uint8_t eval(uint32_t op, uint8_t dst, uint8_t parent_freq, bool wave_env,
-			bool layer, bool keep_freq) {
+	uint8_t eval(uint32_t op, uint8_t dst, uint8_t parent_freq, uint8_t parent_prov,
+			bool wave_env, bool layer, bool keep_freq) {
 		if (failed) return NO_SLOT;
 		for (uint32_t p : path) {
 			if (p == op) { /* generator.c:685-689 */
@@ -116,6 +119,7 @@ struct Compiler {
 		}
 		const OpMirror &m = ops[op];
 		const uint32_t lop = local_of(op);
+		const uint8_t me = lop < 255 ? (uint8_t)lop : NO_SLOT;
 		path.push_back(op);
 		bool first = true;
 		const bool is_osc = (m.type == SAU_POPT_N_wave || m.type == SAU_POPT_N_raseg);
@@ -133,15 +137,15 @@ struct Compiler {
 				count(fpmods) || count(amods) || count(ramods) || count(apmods);
 			if (any_child || keep_freq) {
 				F = alloc();
-				param_to_slot(lop, L_FREQ, L_FREQ2, F, parent_freq, F, fmods, rfmods, first);
+				param_to_slot(lop, L_FREQ, L_FREQ2, F, parent_freq, parent_prov, F, me, fmods, rfmods, first);
 			} else {
 				osc_flags |= SF_SKIP_FREQ2;
 			}
-			if (count(pmods)) { P = alloc(); children(pmods, P, F, false, false); }
-			if (count(fpmods)) { Q = alloc(); children(fpmods, Q, F, false, false); }
+			if (count(pmods)) { P = alloc(); children(pmods, P, F, me, false, false); }
+			if (count(fpmods)) { Q = alloc(); children(fpmods, Q, F, me, false, false); }
 			if (count(amods) || count(ramods)) {
 				A = alloc();
-				param_to_slot(lop, L_AMP, L_AMP2, A, NO_SLOT, F, amods, ramods, first);
+				param_to_slot(lop, L_AMP, L_AMP2, A, NO_SLOT, NO_SLOT, F, me, amods, ramods, first);
 			} else {
 				osc_flags |= SF_SKIP_AMP2;
 			}
@@ -150,7 +154,7 @@ struct Compiler {
 				Step &sm = emit(ST_SMLINE, lop);
 				sm.out = S;
 				if (first) { sm.flags |= SF_BEGIN; first = false; }
-				children(apmods, S, F, false, true);
+				children(apmods, S, F, me, false, true);
 			} else if (m.line_set & (1u << L_PMA)) {
 				osc_flags |= SF_SM_INLINE;
 			}
@@ -161,13 +165,14 @@ struct Compiler {
 		} else {
 			if (count(amods) || count(ramods)) {
 				A = alloc();
-				param_to_slot(lop, L_AMP, L_AMP2, A, NO_SLOT, NO_SLOT, amods, ramods, first);
+				param_to_slot(lop, L_AMP, L_AMP2, A, NO_SLOT, NO_SLOT, NO_SLOT, NO_SLOT, amods, ramods, first);
 			} else {
 				osc_flags |= SF_SKIP_AMP2;
 			}
 		}
 		Step &o = emit(ST_OSC, lop);
 		o.out = dst; o.freq = F; o.fmul = parent_freq; o.pm = P; o.fpm = Q;
+		o.prov = (F != NO_SLOT) ? me : parent_prov;
 		o.amp = A; o.sm = S; o.tmp = T;
 		o.flags = osc_flags | SF_END;
 		if (first) o.flags |= SF_BEGIN;
@@ -198,16 +203,20 @@ bool compile_voice_plan(const std::vector<OpMirror> &ops, uint32_t carrier,
 	out.carr_local = c.local_of(carrier);
 	uint8_t V = c.alloc();
 	/* generator.c:833-846 run_voice -> run_block(carrier, NULL, false, false) */
-	uint8_t F = c.eval(carrier, V, NO_SLOT, false, false, out.has_camods);
+	uint8_t F = c.eval(carrier, V, NO_SLOT, NO_SLOT, false, false, out.has_camods);
+	const uint8_t cprov = out.carr_local < 255 ? (uint8_t)out.carr_local : NO_SLOT;
 	uint8_t Pn = NO_SLOT;
 	if (out.has_camods) { /* generator.c:756-771 */
 		Pn = c.alloc();
 		Step &pl = c.emit(ST_LINE, out.carr_local);
-		pl.which = L_PAN; pl.out = Pn; pl.tmp = L_PAN;
-		c.children(camods, Pn, F, false, true);
+		pl.which = L_PAN; pl.out = Pn; pl.tmp = L_PAN; pl.flags |= SF_FORCE;
+		c.children(camods, Pn, F, F != NO_SLOT ? cprov : NO_SLOT, false, true);
+		Step &v = c.emit(ST_VOICE, out.carr_local);
+		v.out = V; v.pm = Pn;
+	} else {
+		/* no pan modulators: the carrier's own step writes the mixer row */
+		out.steps.back().which |= OX_VOICE;
 	}
-	Step &v = c.emit(ST_VOICE, out.carr_local);
-	v.out = V; v.pm = Pn;
 	c.release(Pn); c.release(F); c.release(V);
 	out.n_slots = c.high + 1;
 	return !c.failed;

@@ -20,8 +20,12 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define SAU_HD __host__ __device__ __forceinline__
+/* larger helpers: real functions on the device (smaller kernels, and the line
+ * code is then compiled once instead of once per call site) */
+#define SAU_HD_CALL __host__ __device__ inline __attribute__((noinline))
 #else
 #define SAU_HD static inline
+#define SAU_HD_CALL static inline
 #endif
 
 namespace saudev {
@@ -62,7 +66,20 @@ SAU_HD int64_t rint64(float x) {
 #endif
 }
 /* ... and wrapped into a 32-bit phase */
-SAU_HD uint32_t rint32w(float x) { return (uint32_t)rint64(x); }
+SAU_HD uint32_t rint32w(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	/* gfx950 has no f32->i64 conversion; only the low 32 bits are needed.
+	 * Small magnitudes convert directly; larger ones are reduced mod 2^32 in
+	 * f64, where every step is exact (integer-valued operands < 2^128). */
+	float r = rintf(x);
+	if (fabsf(r) < 0x1p31f) return (uint32_t)(int32_t)r;
+	double d = (double)r;
+	double q = floor(d * 0x1p-32);
+	return (uint32_t)(d - q * 0x1p32);
+#else
+	return (uint32_t)rint64(x);
+#endif
+}
 
 /* sau/math.h:297-303 */
 SAU_HD uint32_t ranfast32(uint32_t n) {
@@ -118,7 +135,7 @@ SAU_HD float expramp6(float x) {
 
 /* Scalar shape value, sau/line.h:153-266 (ref-build forms for cub smo ncl nhl
  * and, through expramp6, exp log xpe lge). */
-SAU_HD float shape_val(uint32_t type, float x, float a, float b) {
+SAU_HD_CALL float shape_val(uint32_t type, float x, float a, float b) {
 	switch (type) {
 	default:
 	case LN_sah: return a;
@@ -165,7 +182,7 @@ struct Sweep {
 	float vm, vd;
 };
 
-SAU_HD Sweep sweep_setup(uint32_t type, float v0, float vt, uint32_t pos, uint32_t time) {
+SAU_HD_CALL Sweep sweep_setup(uint32_t type, float v0, float vt, uint32_t pos, uint32_t time) {
 	Sweep s;
 	if (type == LN_exp) type = (v0 > vt) ? LN_xpe : LN_lge; /* sau/line.c:125-131 */
 	else if (type == LN_log) type = (v0 < vt) ? LN_xpe : LN_lge; /* 142-148 */
@@ -186,7 +203,7 @@ SAU_HD Sweep sweep_setup(uint32_t type, float v0, float vt, uint32_t pos, uint32
 
 /* Value of sample i of the block (i + pos inside the sweep), before any
  * ratio multiplication. sau/line.c:27-37,65-281 in ref-build forms. */
-SAU_HD float sweep_value(const Sweep &s, uint32_t i) {
+SAU_HD_CALL float sweep_value(const Sweep &s, uint32_t i) {
 	switch (s.type) {
 	default:
 	case LN_sah: return s.v0;
@@ -250,9 +267,23 @@ struct LineBlock {
 	float hold;
 };
 
+/* The no-sweep part of sauLine_run: advance_len (sau/line.c:385-398). After it
+ * the block holds v0 (times the ratio buffer when LP_STATE_RATIO). */
+SAU_HD void line_advance_hold(LineState &o, uint32_t len) {
+	if (o.pos < o.end) {
+		uint32_t l = o.end - o.pos;
+		if (l > len) l = len;
+		o.pos += l;
+	}
+	if (o.pos >= o.end) {
+		o.pos = 0;
+		o.flags &= ~LP_TIME;
+	}
+}
+
 /* have_mul: a ratio buffer exists; mul0: its first value (only read when the
  * state/goal ratio flags disagree, sau/line.c:358-370). */
-SAU_HD LineBlock line_begin(LineState &o, uint32_t len, bool have_mul, float mul0) {
+SAU_HD_CALL LineBlock line_begin(LineState &o, uint32_t len, bool have_mul, float mul0) {
 	LineBlock b;
 	b.goal_len = 0; b.mul_goal = false; b.mul_hold = false; b.hold = 0.f;
 	b.sw = sweep_setup(LN_sah, 0.f, 0.f, 0, 1);
@@ -306,7 +337,7 @@ SAU_HD LineBlock line_begin(LineState &o, uint32_t len, bool have_mul, float mul
 	return b;
 }
 
-SAU_HD float line_value(const LineBlock &b, uint32_t i, float mul_i) {
+SAU_HD_CALL float line_value(const LineBlock &b, uint32_t i, float mul_i) {
 	if (i < b.goal_len) {
 		float v = sweep_value(b.sw, i);
 		return b.mul_goal ? v * mul_i : v;

@@ -50,8 +50,7 @@ SAU_HD void ras_set_opt(DevOp &n, const OpUpdate &u) {
 SAU_HD void apply_update(DevOp &n, const OpUpdate &u, const WaveConst *wc) {
 	if (u.first) {
 		/* prepare_op: zeroed node, type-specific initial state */
-		uint32_t *w = (uint32_t *)&n;
-		for (uint32_t i = 0; i < sizeof(DevOp) / 4; ++i) w[i] = 0;
+		n = DevOp();
 		n.type = u.type;
 		n.coeff = u.coeff;
 		if (u.type == OT_WAVE) {

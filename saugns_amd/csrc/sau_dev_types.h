@@ -23,21 +23,25 @@ enum : uint32_t { /* DevOp.flags */
  * Lives in HBM between launches; a voice's operators are cached in LDS while
  * its workgroup renders a segment. 64 dwords. */
 struct DevOp {
-	uint32_t time;           /* remaining samples (unless OPF_TIME_INF) */
-	uint32_t flags;          /* OPF_* */
-	uint32_t type;           /* OT_* */
-	uint32_t wave;           /* W: wave id; N: noise id; R: line shape */
-	LineState line[L_COUNT]; /* 36 dwords */
-	float coeff;             /* 2^32 / srate as f32 (wosc.h:30, rasg.h:27) */
-	uint32_t phase;          /* W: accumulator (includes the wave's phase_adj) */
-	uint32_t prev_phase;     /* W */
-	uint32_t ras_flags;      /* R */
-	double prev_Is;          /* W */
-	uint64_t cycle_phase;    /* R */
-	float prev_s, fb_s;      /* W and R feedback */
-	uint32_t ras_func, ras_level, ras_alpha;
-	uint32_t noise_n, noise_prev; /* N */
-	uint32_t pad[9];
+	uint32_t time = 0;       /* remaining samples (unless OPF_TIME_INF) */
+	uint32_t flags = 0;      /* OPF_* */
+	uint32_t type = 0;       /* OT_* */
+	uint32_t wave = 0;       /* W: wave id; N: noise id; R: line shape */
+	LineState line[L_COUNT] = {}; /* 36 dwords */
+	float coeff = 0;         /* 2^32 / srate as f32 (wosc.h:30, rasg.h:27) */
+	uint32_t phase = 0;      /* W: accumulator (includes the wave's phase_adj) */
+	uint32_t prev_phase = 0; /* W */
+	uint32_t ras_flags = 0;  /* R */
+	double prev_Is = 0;      /* W */
+	uint64_t cycle_phase = 0;/* R */
+	float prev_s = 0, fb_s = 0; /* W and R feedback */
+	uint32_t ras_func = 0, ras_level = 0, ras_alpha = 0;
+	uint32_t noise_n = 0, noise_prev = 0; /* N */
+	/* per-block scratch of the renderer (not part of the persistent state):
+	 * set while this operator's frequency is one value for the whole block */
+	float rt_fconst = 0;
+	uint32_t rt_fconst_valid = 0;
+	uint32_t pad[7] = {};
 };
 static_assert(sizeof(DevOp) == 256, "DevOp is 64 dwords");
 
@@ -88,10 +92,15 @@ enum : uint8_t {
 	SF_WAVE_ENV = 1 << 2,  /* block_mix_mul_waveenv instead of _add          */
 	SF_LAYER = 1 << 3,     /* combine with existing out instead of replacing */
 	SF_SKIP2 = 1 << 4,     /* ST_LINE: also skip the range partner line      */
+	SF_FORCE = 1 << 3,     /* ST_LINE: always write the slot (it is added to) */
 	SF_SKIP_FREQ2 = 1 << 4,/* ST_OSC with inline freq: skip freq2            */
 	SF_SKIP_AMP2 = 1 << 5, /* ST_OSC with inline amp: skip amp2              */
 	SF_SM_INLINE = 1 << 6, /* ST_OSC: test/run pm_a line inline (no apmods)  */
 	SF_SM_SKIP = 1 << 7,   /* ST_OSC: pm_a line was set once: skip it        */
+};
+
+enum : uint8_t { /* Step.which for ST_OSC */
+	OX_VOICE = 1 << 0,     /* carrier: hand the block to the mixer in this step */
 };
 
 struct Step {
@@ -105,7 +114,7 @@ struct Step {
 	uint8_t sm;    /* ST_OSC: self-modulation amount slot */
 	uint8_t which; /* ST_LINE: L_* */
 	uint8_t tmp;   /* extra scratch slot (R self-mod) */
-	uint8_t pad;
+	uint8_t prov;  /* voice-local op whose frequency block `fmul` is, or NO_SLOT */
 	uint32_t op;   /* voice-local operator index */
 };
 static_assert(sizeof(Step) == 16, "Step is 4 dwords");

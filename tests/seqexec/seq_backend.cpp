@@ -236,6 +236,17 @@ struct SeqBackend : public Backend {
 					const bool wave_env = st.flags & SF_WAVE_ENV, layer = st.flags & SF_LAYER;
 					for (uint32_t j = 0; j < len; ++j)
 						slot[st.out][j] = mix_combine(layer ? slot[st.out][j] : 0.f, s[j], av[j], wave_env, layer);
+					if (st.which & OX_VOICE) { /* carrier hands its block to the mixer in this step */
+						LineState &pl = op.line[L_PAN];
+						LineBlock lb;
+						bool goal = (pl.flags & LP_GOAL) != 0;
+						if (goal) lb = line_begin(pl, len, false, 0.f); else line_skip(pl, len);
+						for (uint32_t j = 0; j < len; ++j) {
+							vrow[done + j] = slot[st.out][j];
+							if (!prow.empty()) prow[done + j] = goal ? line_value(lb, j, 1.f) : pl.v0;
+						}
+						produced += len;
+					}
 					break;
 				}
 				case ST_VOICE: {
