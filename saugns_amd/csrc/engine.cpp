@@ -256,6 +256,7 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 			/* generator.c:756-762: dynamic pan needs per-sample values */
 			bool dyn = (carr.pan.flags & LP_GOAL) || vn.plan.has_camods;
 			d.pan_dynamic_row = dyn ? n_pan++ : ~0u;
+			d.flags = vn.plan.no_fast ? VD_NO_FAST : 0;
 			if (dyn) line_begin(carr.pan, out_len, false, 0.f);
 			else line_skip(carr.pan, out_len);
 			descs.push_back(d);

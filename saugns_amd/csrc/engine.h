@@ -99,6 +99,7 @@ struct VoicePlan {
 	uint32_t n_slots = 0;
 	uint64_t wave_mask = 0;
 	bool has_camods = false;
+	bool no_fast = false;          /* an operator is evaluated twice per block */
 };
 
 /* Flatten the graph under `carrier` into steps. Returns false (with err) when

@@ -68,6 +68,8 @@ struct Misc {
 	uint32_t tot32[16];
 	unsigned long long tot64[16];
 	uint32_t flag;
+	/* time-parallel regime */
+	uint32_t fast_bad, min_time, bail, fast_depth;
 	uint32_t pad;
 };
 
@@ -221,6 +223,266 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 	/* per-thread sample geometry: p = l*T + k, block sample j = w*(NP-1) + p - 1 */
 	const int p0 = l * T;
 	const int jbase = w * (G::NP - 1) + p0 - 1;
+
+	/* ================= time-parallel regime =================================
+	 * While every line of the voice is held (no sweep pending), every
+	 * oscillator frequency is one value, nothing feeds back and no operator
+	 * runs out of time, sample t of the segment depends on the segment-start
+	 * state only through closed forms: phase(t) = phase0 + inc*(t+1) (the
+	 * wrapping sum of equal increments), noise counter n0 + t.  Waves then take
+	 * chunks of the time axis independently -- no barriers, no carried state;
+	 * each chunk recomputes H = nesting-depth samples of lead-in so that the
+	 * differentiators (wosc.h:250-256) have their previous sample.  Anything
+	 * else (sweeps, FM, feedback, expiring operators) runs in the block loop
+	 * below, which is exact for every graph. */
+	{
+		if (tid == 0) {
+			misc->fast_bad = (vd.flags & VD_NO_FAST) ? 1u : 0u;
+			misc->min_time = 0xFFFFFFFFu;
+			misc->bail = 0;
+			misc->fast_depth = 0;
+		}
+		__syncthreads();
+		for (uint32_t i = tid; i < vd.nops; i += 64 * W) {
+			DevOp &o = ops[i];
+			bool bad = false;
+			for (uint32_t ln = 0; ln < L_COUNT; ++ln)
+				if (o.line[ln].flags & LP_GOAL) bad = true;
+			if (o.type == OT_RASEG) bad = true;
+			if (o.type == OT_NOISE && o.wave == NZ_re) bad = true;
+			if (o.line[L_PMA].v0 != 0.f) bad = true; /* self-modulation is a recurrence */
+			o.rt_fconst_valid = 0;
+			if (bad) atomicOr(&misc->fast_bad, 1u);
+			if (!(o.flags & OPF_TIME_INF)) atomicMin(&misc->min_time, o.time);
+		}
+		__syncthreads();
+		if (tid == 0 && misc->fast_bad == 0) {
+			uint32_t depth = 0, maxd = 0;
+			bool bad = false;
+			for (uint32_t si = 0; si < vd.plan_len && !bad; ++si) {
+				const Step st = plan[si];
+				DevOp &o = ops[st.op];
+				if (st.flags & SF_BEGIN) { ++depth; if (depth > maxd) maxd = depth; }
+				const bool freq_here = (st.kind == ST_LINE && st.which == L_FREQ) ||
+					(st.kind == ST_OSC && st.freq == NO_SLOT && (o.type == OT_WAVE));
+				if (st.kind == ST_SMLINE || st.kind == ST_ZERO) bad = true;
+				if (st.kind == ST_LINE && st.which == L_FREQ && (st.flags & SF_FORCE)) bad = true; /* FM */
+				if (st.kind == ST_OSC && st.sm != NO_SLOT) bad = true;
+				if (freq_here && !bad) {
+					const LineState &fl = o.line[L_FREQ];
+					float fc = fl.v0;
+					if (st.fmul != NO_SLOT && (fl.flags & LP_STATE_RATIO)) {
+						if (st.prov == NO_SLOT || !ops[st.prov].rt_fconst_valid) bad = true;
+						else fc = fl.v0 * ops[st.prov].rt_fconst;
+					}
+					o.rt_fconst = fc;
+					o.rt_fconst_valid = 1;
+				}
+				if (st.kind == ST_OSC && o.type == OT_WAVE && st.freq != NO_SLOT && !o.rt_fconst_valid) bad = true;
+				if (st.flags & SF_END) --depth;
+			}
+			if (bad) misc->fast_bad = 1;
+			misc->fast_depth = maxd;
+		}
+		__syncthreads();
+		const uint32_t H = uni(misc->fast_depth);
+		uint32_t fast_total = 0;
+		if (uni(misc->fast_bad) == 0 && H >= 1 && H <= (uint32_t)G::NP / 2)
+			fast_total = min(uni(misc->min_time), vd.run_len);
+		if (fast_total > 0) {
+			const uint32_t C = (uint32_t)G::NP - H;
+			const uint32_t nch = (fast_total + C - 1) / C;
+			for (uint32_t c = (uint32_t)w; c < nch; c += W) {
+				const int t_base = (int)(c * C) - (int)H; /* segment sample at p = 0 */
+				const bool first_chunk = (c == 0);
+				for (uint32_t si = 0; si < vd.plan_len; ++si) {
+					const Step st = uni(plan[si]);
+					DevOp *op = &ops[st.op];
+					switch (st.kind) {
+					case ST_LINE: {
+						if (st.which == L_FREQ && !(st.flags & SF_FORCE)) break; /* single value, kept in rt_fconst */
+						float *out = slots + (size_t)st.out * G::SLOT;
+						const float *mul = st.fmul != NO_SLOT ? slots + (size_t)st.fmul * G::SLOT : nullptr;
+						const LineState ls = uni(op->line[st.which]);
+						const bool ratio = mul && (ls.flags & LP_STATE_RATIO);
+						bool pconst = false; float pf = 0.f;
+						if (ratio && st.prov != NO_SLOT) { pconst = uni(ops[st.prov].rt_fconst_valid) != 0; pf = uni(ops[st.prov].rt_fconst); }
+#pragma unroll
+						for (int k = 0; k < T; ++k) {
+							const int e = w * G::NP + p0 + k;
+							out[e] = ratio ? ls.v0 * (pconst ? pf : mul[e]) : ls.v0;
+						}
+						break;
+					}
+					case ST_LERP: {
+						float *par = slots + (size_t)st.out * G::SLOT;
+						const float *rpar = slots + (size_t)st.freq * G::SLOT;
+						const float *mod = slots + (size_t)st.pm * G::SLOT;
+#pragma unroll
+						for (int k = 0; k < T; ++k) {
+							const int e = w * G::NP + p0 + k;
+							float pv = par[e];
+							pv += (rpar[e] - pv) * mod[e];
+							par[e] = pv;
+						}
+						break;
+					}
+					case ST_OSC: {
+						float *out = slots + (size_t)st.out * G::SLOT;
+						const float *pmS = st.pm != NO_SLOT ? slots + (size_t)st.pm * G::SLOT : nullptr;
+						const float *fpmS = st.fpm != NO_SLOT ? slots + (size_t)st.fpm * G::SLOT : nullptr;
+						const float *ampS = st.amp != NO_SLOT ? slots + (size_t)st.amp * G::SLOT : nullptr;
+						const uint32_t type = uni(op->type);
+						const bool wave_env = (st.flags & SF_WAVE_ENV) != 0;
+						const bool layer = (st.flags & SF_LAYER) != 0;
+						const float ac = ampS ? 0.f : uni(op->line[L_AMP].v0);
+						float s[T];
+						if (type == OT_WAVE) {
+							const uint32_t wave = uni(op->wave);
+							const float diff_scale = uni(misc->wc[wave].diff_scale);
+							const float diff_offset = uni(misc->wc[wave].diff_offset);
+							TabRef tab;
+							{
+								const int ti = uni(misc->tab_of_wave[wave]);
+								tab.in_lds = ti >= 0;
+								tab.c23 = ti >= 0 ? t23 + (size_t)ti * WAVE_LEN : P.g_c23 + (size_t)wave * WAVE_LEN;
+								tab.c01 = ti >= 0 ? t01 + (size_t)ti * WAVE_LEN : P.g_c01 + (size_t)wave * WAVE_LEN;
+							}
+							const float fc = uni(op->rt_fconst);
+							const uint32_t inc = rint32w(uni(op->coeff) * fc);
+							const uint32_t phase0 = uni(op->phase);
+							const bool reset = (uni(op->flags) & OPF_OSC_RESET) != 0;
+							uint32_t ph[T];
+							double Is[T];
+#pragma unroll
+							for (int k = 0; k < T; ++k) {
+								const int e = w * G::NP + p0 + k;
+								const int t = t_base + p0 + k;
+								const uint32_t ofs = (uint32_t)pm_offset(pmS != nullptr, fpmS != nullptr,
+										pmS ? pmS[e] : 0.f, fpmS ? fpmS[e] : 0.f, fc, 0x1p31f);
+								ph[k] = phase0 + inc * (uint32_t)(t + 1) + ofs;
+							}
+							if (first_chunk) {
+								/* t = -1: the sample before the segment (wosc.h:215-231 on restart) */
+								const uint32_t next0 = __shfl_down(ph[0], 1);
+#pragma unroll
+								for (int k = 0; k < T; ++k) {
+									if (p0 + k == (int)H - 1) {
+										const uint32_t nxt = (k < T - 1) ? ph[k < T - 1 ? k + 1 : k] : next0;
+										ph[k] = reset ? nxt - SLEN : uni(op->prev_phase);
+									}
+								}
+							}
+#pragma unroll
+							for (int k = 0; k < T; ++k) Is[k] = herp_lookup(tab, ph[k]);
+							if (first_chunk && !reset) {
+#pragma unroll
+								for (int k = 0; k < T; ++k)
+									if (p0 + k == (int)H - 1) Is[k] = uni(op->prev_Is);
+							}
+							uint32_t pph = __shfl_up(ph[T - 1], 1);
+							double pIs = __shfl_up(Is[T - 1], 1);
+							bool zero = false;
+#pragma unroll
+							for (int k = 0; k < T; ++k) {
+								if (k > 0) { pph = ph[k - 1]; pIs = Is[k - 1]; }
+								const int t = t_base + p0 + k;
+								const int32_t d = (int32_t)(ph[k] - pph);
+								const bool live = (p0 + k >= 1) && t >= 0 && t < (int)fast_total;
+								if (live && d == 0) zero = true;
+								s[k] = wosc_diff(Is[k], pIs, d, diff_scale, diff_offset);
+								if (t == (int)fast_total - 1 && p0 + k >= (int)H) {
+									op->st_prev_phase = ph[k];
+									op->st_prev_Is = Is[k];
+									op->st_prev_s = s[k];
+								}
+							}
+							if (__any(zero) && l == 0) misc->bail = 1; /* hold-previous run: block loop handles it */
+						} else if (type == OT_NOISE) {
+							const uint32_t nz = uni(op->wave);
+							const uint32_t n0 = uni(op->noise_n);
+							const uint32_t nprev = uni(op->noise_prev);
+#pragma unroll
+							for (int k = 0; k < T; ++k) {
+								const int t = t_base + p0 + k;
+								const uint32_t n = n0 + (uint32_t)t;
+								if (nz == NZ_vi) {
+									uint32_t s1 = ranfast32(n);
+									uint32_t s0 = t == 0 ? nprev : ranfast32(n - 1);
+									s[k] = fscalei((s1 / 2) - (s0 / 2), 0x1p-31f);
+								} else if (nz == NZ_bv) {
+									int32_t s1 = noise_bv_term(n);
+									int32_t s0 = t == 0 ? (int32_t)nprev : noise_bv_term(n - 1);
+									s[k] = (float)(s1 - s0);
+								} else {
+									s[k] = noise_stateless(nz, n);
+								}
+							}
+						} else {
+#pragma unroll
+							for (int k = 0; k < T; ++k) s[k] = 1.f;
+						}
+						const bool to_voice = (st.which & OX_VOICE) != 0;
+#pragma unroll
+						for (int k = 0; k < T; ++k) {
+							const int e = w * G::NP + p0 + k;
+							const int t = t_base + p0 + k;
+							const float a = ampS ? ampS[e] : ac;
+							const float r = mix_combine(layer ? out[e] : 0.f, s[k], a, wave_env, layer);
+							if (to_voice) {
+								if (p0 + k >= (int)H && t < (int)fast_total) vrow[t] = r;
+							} else {
+								out[e] = r;
+							}
+						}
+						break;
+					}
+					case ST_VOICE: {
+						const float *src = slots + (size_t)st.out * G::SLOT;
+						const float *panS = st.pm != NO_SLOT ? slots + (size_t)st.pm * G::SLOT : nullptr;
+						const float pv = uni(op->line[L_PAN].v0);
+#pragma unroll
+						for (int k = 0; k < T; ++k) {
+							const int e = w * G::NP + p0 + k;
+							const int t = t_base + p0 + k;
+							if (p0 + k >= (int)H && t < (int)fast_total) {
+								vrow[t] = src[e];
+								if (prow) prow[t] = panS ? panS[e] : pv;
+							}
+						}
+						break;
+					}
+					default: break;
+					}
+				}
+			}
+			__syncthreads();
+			if (uni(misc->bail) != 0) {
+				fast_total = 0; /* redo the whole segment in the block loop */
+			} else {
+				for (uint32_t i = tid; i < vd.nops; i += 64 * W) {
+					DevOp &o = ops[i];
+					if (!(o.flags & OPF_TIME_INF)) o.time -= fast_total;
+					for (uint32_t ln = 0; ln < L_COUNT; ++ln) line_advance_hold(o.line[ln], fast_total);
+					if (o.type == OT_WAVE) {
+						const uint32_t inc = rint32w(o.coeff * o.rt_fconst);
+						o.phase += inc * fast_total;
+						o.prev_phase = o.st_prev_phase;
+						o.prev_Is = o.st_prev_Is;
+						o.prev_s = o.st_prev_s;
+						o.flags &= ~OPF_OSC_RESET;
+					} else if (o.type == OT_NOISE) {
+						const uint32_t n0 = o.noise_n;
+						if (o.wave == NZ_vi) o.noise_prev = ranfast32(n0 + fast_total - 1);
+						else if (o.wave == NZ_bv) o.noise_prev = (uint32_t)noise_bv_term(n0 + fast_total - 1);
+						o.noise_n = n0 + fast_total;
+					}
+				}
+			}
+			__syncthreads();
+			done = produced = fast_total;
+		}
+	}
 
 	while (done < vd.run_len) {
 		if (uni(ops[vd.carr_local].time) == 0) break; /* generator.c:839 */

@@ -219,6 +219,18 @@ bool compile_voice_plan(const std::vector<OpMirror> &ops, uint32_t carrier,
 	}
 	c.release(Pn); c.release(F); c.release(V);
 	out.n_slots = c.high + 1;
+	/* closed-form (time-parallel) evaluation assumes one visit per operator */
+	out.no_fast = false;
+	{
+		std::vector<uint8_t> seen(out.op_ids.size(), 0);
+		for (const Step &st : out.steps) {
+			if (st.kind == ST_ZERO) out.no_fast = true;
+			if (st.kind == ST_OSC) {
+				if (seen[st.op]) out.no_fast = true;
+				seen[st.op] = 1;
+			}
+		}
+	}
 	return !c.failed;
 }
 

@@ -41,7 +41,11 @@ struct DevOp {
 	 * set while this operator's frequency is one value for the whole block */
 	float rt_fconst = 0;
 	uint32_t rt_fconst_valid = 0;
-	uint32_t pad[7] = {};
+	/* end-of-segment oscillator state staged by the time-parallel path */
+	uint32_t st_prev_phase = 0;
+	double st_prev_Is = 0;
+	float st_prev_s = 0;
+	uint32_t pad[3] = {};
 };
 static_assert(sizeof(DevOp) == 256, "DevOp is 64 dwords");
 
@@ -127,6 +131,11 @@ struct VoiceDesc {
 	uint32_t run_len;            /* min(duration, segment length) */
 	uint32_t out_row;            /* row in the voice output matrix */
 	uint32_t pan_dynamic_row;    /* row of the pan matrix, or ~0u */
+	uint32_t flags;              /* VD_* */
+};
+
+enum : uint32_t {
+	VD_NO_FAST = 1u << 0, /* graph visits an operator twice or has a cycle guard */
 };
 
 /* Per-voice result of a segment, read by the mixer. */
