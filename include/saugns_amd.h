@@ -72,6 +72,12 @@ SAU_AMD_API bool sauAmd_Batch_sync(sauAmdBatch *b);
 SAU_AMD_API void sauAmd_Batch_timing(sauAmdBatch *b, double *render_ms, double *mix_ms,
 		uint64_t *render_launches, int reset);
 
+/* Per-kernel split of the same timings: out4[0] time-parallel kernel
+ * (fast_kernel), [1] block-loop kernel (render_kernel), [2] mixer, [3] analyze
+ * + finalize, all in ms; *segments = number of rendered segments. */
+SAU_AMD_API void sauAmd_Batch_timing_ex(sauAmdBatch *b, double *out4, uint64_t *segments,
+		int reset);
+
 /* The stream the batch launches its kernels on, as a hipStream_t. */
 SAU_AMD_API void *sauAmd_Batch_stream(sauAmdBatch *b);
 

@@ -106,6 +106,7 @@ def lib():
     L.sauAmd_Batch_sync.argtypes = [C.c_void_p]
     L.sauAmd_Batch_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                       C.POINTER(C.c_uint64), C.c_int]
+    L.sauAmd_Batch_timing_ex.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
     L.sauAmd_Batch_stream.restype = C.c_void_p
     L.sauAmd_Batch_stream.argtypes = [C.c_void_p]
     L.sauAmd_set_piluts.argtypes = [C.c_void_p]
@@ -264,6 +265,14 @@ class Batch:
         r, m, n = C.c_double(), C.c_double(), C.c_uint64()
         lib().sauAmd_Batch_timing(self._b, C.byref(r), C.byref(m), C.byref(n), int(reset))
         return r.value, m.value, n.value
+
+    def timing_ex(self, reset=False):
+        """-> dict of accumulated kernel times (ms) and the number of segments."""
+        out = (C.c_double * 4)()
+        n = C.c_uint64()
+        lib().sauAmd_Batch_timing_ex(self._b, out, C.byref(n), int(reset))
+        return {"fast_ms": out[0], "block_ms": out[1], "mix_ms": out[2], "aux_ms": out[3],
+                "segments": n.value}
 
     def device_pcm(self, stream):
         return lib().sauAmd_Batch_device_pcm(self._b, stream)

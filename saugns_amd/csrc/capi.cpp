@@ -132,6 +132,12 @@ extern "C" void sauAmd_Batch_timing(sauAmdBatch *b, double *render_ms, double *m
 	if (b->hip) b->hip->timing(render_ms, mix_ms, render_launches, reset != 0);
 }
 
+extern "C" void sauAmd_Batch_timing_ex(sauAmdBatch *b, double *out4, uint64_t *segments, int reset) {
+	out4[0] = out4[1] = out4[2] = out4[3] = 0;
+	if (segments) *segments = 0;
+	if (b->hip) b->hip->timing_ex(out4, segments, reset != 0);
+}
+
 extern "C" void *sauAmd_Batch_stream(sauAmdBatch *b) {
 	return b->hip ? b->hip->stream_handle() : nullptr;
 }

@@ -121,6 +121,8 @@ bool Engine::handle_event(Stream &st, const EventNode &e, std::vector<OpUpdate> 
 		}
 		if (od->type == SAU_POPT_N_wave && (od->params & SAU_POPP_MODE))
 			m.wave = od->mode.main < SAU_WAVE_NAMED ? od->mode.main : 0;
+		if (od->type == SAU_POPT_N_noise && (od->params & SAU_POPP_MODE))
+			m.wave = od->mode.main;
 		u.phase = od->phase;
 		u.seed = od->seed;
 		const sauLine *src[L_COUNT] = {od->pan, od->amp, od->amp2, nullptr, nullptr, nullptr};
@@ -135,6 +137,7 @@ bool Engine::handle_event(Stream &st, const EventNode &e, std::vector<OpUpdate> 
 		for (uint32_t l = 0; l < L_COUNT; ++l) {
 			u.line[l] = make_line_update(src[l], srate_);
 			if (src[l]) m.line_set |= (uint8_t)(1u << l);
+			if (src[l] && (src[l]->flags & SAU_LINEP_GOAL)) m.goal_seen = true;
 		}
 		line_copy(m.pan, u.line[L_PAN]);
 		if (od->params & SAU_POPP_TIME) {
@@ -226,8 +229,9 @@ bool Engine::rebuild_plans(std::string &err) {
 bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::string &err) {
 	std::vector<VoiceDesc> descs;
 	std::vector<SegmentDesc::Stream> sdescs(streams_.size());
-	uint32_t n_slots = 1, max_ops = 1, n_pan = 0, max_steps = 1;
+	uint32_t n_main = 1, n_fpool = 0, max_ops = 1, n_pan = 0, max_steps = 1;
 	uint64_t wave_mask = 0;
+	bool maybe_block = false;
 	for (size_t s = 0; s < streams_.size(); ++s) {
 		Stream &st = streams_[s];
 		SegmentDesc::Stream &sd = sdescs[s];
@@ -261,10 +265,23 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 			else line_skip(carr.pan, out_len);
 			descs.push_back(d);
 			if (out_len > sd.write_len) sd.write_len = out_len;
-			n_slots = std::max(n_slots, vn.plan.n_slots);
+			n_main = std::max(n_main, vn.plan.n_main);
+			n_fpool = std::max(n_fpool, vn.plan.n_slots - vn.plan.n_main);
 			max_ops = std::max(max_ops, (uint32_t)vn.plan.op_ids.size());
 			max_steps = std::max(max_steps, (uint32_t)vn.plan.steps.size());
 			wave_mask |= vn.plan.wave_mask;
+			/* will the time-parallel path surely cover this voice's whole run? */
+			if (vn.plan.static_block || vn.plan.no_fast) maybe_block = true;
+			for (uint32_t id : vn.plan.op_ids) {
+				OpMirror &m = st.ops[id];
+				if (m.goal_seen || (m.line_set & (1u << L_PMA))) maybe_block = true;
+				if (id != vn.carr_op && !m.time_inf) {
+					/* conservative mirror: non-carriers tick whenever the voice runs */
+					if (m.time < run_len) maybe_block = true;
+					m.time -= std::min(m.time, out_len);
+				}
+			}
+			if (out_len < run_len) maybe_block = true;
 		}
 		sd.n_voices = (uint32_t)descs.size() - sd.first_voice;
 		if (sd.write_len > 0) {
@@ -278,9 +295,10 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 	seg.len = len; seg.pcm_offset = offset; seg.stereo = stereo;
 	seg.voices = descs.data(); seg.n_voices = (uint32_t)descs.size();
 	seg.streams = sdescs.data(); seg.n_streams = (uint32_t)sdescs.size();
-	seg.n_slots = n_slots; seg.max_ops = max_ops; seg.n_pan_rows = n_pan;
+	seg.n_slots = n_main + n_fpool; seg.n_main = n_main; seg.max_ops = max_ops; seg.n_pan_rows = n_pan;
 	seg.max_steps = max_steps;
 	seg.wave_mask = wave_mask;
+	seg.maybe_block = maybe_block;
 	return backend_->render(seg, err);
 }
 

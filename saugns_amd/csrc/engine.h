@@ -39,11 +39,13 @@ struct SegmentDesc {
 	};
 	const Stream *streams;
 	uint32_t n_streams;
-	uint32_t n_slots;         /* max slots any active plan uses */
+	uint32_t n_slots;         /* max over active plans of main + frequency slots */
+	uint32_t n_main;          /* max main-pool slots (slot_index() base) */
 	uint32_t max_ops;         /* max operators in any active voice */
 	uint32_t max_steps;       /* longest active plan */
 	uint32_t n_pan_rows;
 	uint64_t wave_mask;       /* wave ids in use (bit per id) */
+	bool maybe_block;         /* some voice may need the block loop (sweeps, FM, ...) */
 };
 
 struct BackendConfig {
@@ -89,6 +91,7 @@ struct OpMirror { /* host-side knowledge about one operator */
 	LineState pan;                    /* mirrored exactly (never ratio-scaled) */
 	const sauProgramIDArr *mods[SAU_POP_NAMED] = {}; /* by use type; [0] unused */
 	uint8_t wave = 0;
+	bool goal_seen = false;           /* some event gave one of its lines a sweep */
 	OpMirror() { pan = LineState{0, 0, 0, 0, 0, 0}; }
 };
 
@@ -96,10 +99,12 @@ struct VoicePlan {
 	std::vector<Step> steps;
 	std::vector<uint32_t> op_ids;  /* voice-local index -> stream-local op id */
 	uint32_t carr_local = 0;
-	uint32_t n_slots = 0;
+	uint32_t n_slots = 0;          /* memory slots: main pool + frequency pool */
+	uint32_t n_main = 0;           /* main-pool slots (ids below FSLOT_BASE) */
 	uint64_t wave_mask = 0;
 	bool has_camods = false;
 	bool no_fast = false;          /* an operator is evaluated twice per block */
+	bool static_block = false;     /* graph has FM / feedback / R / filtered noise: block loop */
 };
 
 /* Flatten the graph under `carrier` into steps. Returns false (with err) when

@@ -11,6 +11,7 @@ class HipBackend : public sauengine::Backend {
 public:
 	virtual void timing(double *render_ms, double *mix_ms, uint64_t *launches, bool reset) = 0;
 	virtual void *stream_handle() = 0;
+	virtual void timing_ex(double *out4, uint64_t *segments, bool reset) = 0;
 };
 
 /* NULL (with err) when no HIP device is usable: there is no CPU fallback. */

@@ -53,8 +53,12 @@ struct RenderParams {
 	uint32_t row_stride;
 	uint32_t seg_len;
 	uint32_t n_slots;
+	uint32_t n_main;       /* main-pool slots (slot_index() base) */
 	uint32_t max_ops;
 	uint32_t max_steps;    /* longest plan of the launch (LDS copy) */
+	const uint32_t *fast_done; /* [voice row] frames already rendered by fast_kernel */
+	const uint32_t *worklist;  /* voice rows that still need the block loop */
+	const uint32_t *work_count;
 	uint32_t n_tabs;       /* wave types staged in LDS */
 	int8_t tab_of_wave[12];/* LDS table index per wave id, or -1 */
 	uint8_t wave_of_tab[12];
@@ -190,6 +194,9 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 	Misc *misc = (Misc *)(ops + P.max_ops);
 	Step *plan = (Step *)(misc + 1); /* this voice's steps, read every block */
 
+	const uint32_t n_work = *P.work_count;
+	if (blockIdx.x >= n_work) return;
+
 	/* stage coefficient tables (16-byte copies) */
 	for (uint32_t t = 0; t < P.n_tabs; ++t) {
 		const uint32_t wave = P.wave_of_tab[t];
@@ -201,8 +208,17 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 		for (uint32_t i = tid; i < WAVE_LEN; i += 64 * W) d01[i] = s01[i];
 	}
 
-	const VoiceDesc vd = P.voices[blockIdx.x];
+	/* persistent over the work list: voices the time-parallel path finished
+	 * never get here */
+	for (uint32_t item = blockIdx.x; item < n_work; item += gridDim.x) {
+	const uint32_t vrow_id = P.worklist[item];
+	const VoiceDesc vd = P.voices[vrow_id];
 	const uint32_t *my_ids = P.op_ids + vd.ops_ofs;
+	float *vrow = P.vout + (size_t)vd.out_row * P.row_stride;
+	float *prow = (vd.pan_dynamic_row != ~0u) ? P.pan + (size_t)vd.pan_dynamic_row * P.row_stride : nullptr;
+	uint32_t done = P.fast_done[vrow_id]; /* frames rendered by fast_kernel */
+	uint32_t produced = done;
+	__syncthreads(); /* previous voice's LDS contents are no longer needed */
 	for (uint32_t i = tid; i < vd.nops * 64; i += 64 * W)
 		((u32_alias *)ops)[i] = ((const u32_alias *)&P.ops[my_ids[i >> 6]])[i & 63];
 	{
@@ -216,273 +232,9 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 	if (tid == 0) misc->flag = 0;
 	__syncthreads();
 
-	float *vrow = P.vout + (size_t)vd.out_row * P.row_stride;
-	float *prow = (vd.pan_dynamic_row != ~0u) ? P.pan + (size_t)vd.pan_dynamic_row * P.row_stride : nullptr;
-	uint32_t done = 0, produced = 0;
-
 	/* per-thread sample geometry: p = l*T + k, block sample j = w*(NP-1) + p - 1 */
 	const int p0 = l * T;
 	const int jbase = w * (G::NP - 1) + p0 - 1;
-
-	/* ================= time-parallel regime =================================
-	 * While every line of the voice is held (no sweep pending), every
-	 * oscillator frequency is one value, nothing feeds back and no operator
-	 * runs out of time, sample t of the segment depends on the segment-start
-	 * state only through closed forms: phase(t) = phase0 + inc*(t+1) (the
-	 * wrapping sum of equal increments), noise counter n0 + t.  Waves then take
-	 * chunks of the time axis independently -- no barriers, no carried state;
-	 * each chunk recomputes H = nesting-depth samples of lead-in so that the
-	 * differentiators (wosc.h:250-256) have their previous sample.  Anything
-	 * else (sweeps, FM, feedback, expiring operators) runs in the block loop
-	 * below, which is exact for every graph. */
-	{
-		if (tid == 0) {
-			misc->fast_bad = (vd.flags & VD_NO_FAST) ? 1u : 0u;
-			misc->min_time = 0xFFFFFFFFu;
-			misc->bail = 0;
-			misc->fast_depth = 0;
-		}
-		__syncthreads();
-		for (uint32_t i = tid; i < vd.nops; i += 64 * W) {
-			DevOp &o = ops[i];
-			bool bad = false;
-			for (uint32_t ln = 0; ln < L_COUNT; ++ln)
-				if (o.line[ln].flags & LP_GOAL) bad = true;
-			if (o.type == OT_RASEG) bad = true;
-			if (o.type == OT_NOISE && o.wave == NZ_re) bad = true;
-			if (o.line[L_PMA].v0 != 0.f) bad = true; /* self-modulation is a recurrence */
-			o.rt_fconst_valid = 0;
-			if (bad) atomicOr(&misc->fast_bad, 1u);
-			if (!(o.flags & OPF_TIME_INF)) atomicMin(&misc->min_time, o.time);
-		}
-		__syncthreads();
-		if (tid == 0 && misc->fast_bad == 0) {
-			uint32_t depth = 0, maxd = 0;
-			bool bad = false;
-			for (uint32_t si = 0; si < vd.plan_len && !bad; ++si) {
-				const Step st = plan[si];
-				DevOp &o = ops[st.op];
-				if (st.flags & SF_BEGIN) { ++depth; if (depth > maxd) maxd = depth; }
-				const bool freq_here = (st.kind == ST_LINE && st.which == L_FREQ) ||
-					(st.kind == ST_OSC && st.freq == NO_SLOT && (o.type == OT_WAVE));
-				if (st.kind == ST_SMLINE || st.kind == ST_ZERO) bad = true;
-				if (st.kind == ST_LINE && st.which == L_FREQ && (st.flags & SF_FORCE)) bad = true; /* FM */
-				if (st.kind == ST_OSC && st.sm != NO_SLOT) bad = true;
-				if (freq_here && !bad) {
-					const LineState &fl = o.line[L_FREQ];
-					float fc = fl.v0;
-					if (st.fmul != NO_SLOT && (fl.flags & LP_STATE_RATIO)) {
-						if (st.prov == NO_SLOT || !ops[st.prov].rt_fconst_valid) bad = true;
-						else fc = fl.v0 * ops[st.prov].rt_fconst;
-					}
-					o.rt_fconst = fc;
-					o.rt_fconst_valid = 1;
-				}
-				if (st.kind == ST_OSC && o.type == OT_WAVE && st.freq != NO_SLOT && !o.rt_fconst_valid) bad = true;
-				if (st.flags & SF_END) --depth;
-			}
-			if (bad) misc->fast_bad = 1;
-			misc->fast_depth = maxd;
-		}
-		__syncthreads();
-		const uint32_t H = uni(misc->fast_depth);
-		uint32_t fast_total = 0;
-		if (uni(misc->fast_bad) == 0 && H >= 1 && H <= (uint32_t)G::NP / 2)
-			fast_total = min(uni(misc->min_time), vd.run_len);
-		if (fast_total > 0) {
-			const uint32_t C = (uint32_t)G::NP - H;
-			const uint32_t nch = (fast_total + C - 1) / C;
-			for (uint32_t c = (uint32_t)w; c < nch; c += W) {
-				const int t_base = (int)(c * C) - (int)H; /* segment sample at p = 0 */
-				const bool first_chunk = (c == 0);
-				for (uint32_t si = 0; si < vd.plan_len; ++si) {
-					const Step st = uni(plan[si]);
-					DevOp *op = &ops[st.op];
-					switch (st.kind) {
-					case ST_LINE: {
-						if (st.which == L_FREQ && !(st.flags & SF_FORCE)) break; /* single value, kept in rt_fconst */
-						float *out = slots + (size_t)st.out * G::SLOT;
-						const float *mul = st.fmul != NO_SLOT ? slots + (size_t)st.fmul * G::SLOT : nullptr;
-						const LineState ls = uni(op->line[st.which]);
-						const bool ratio = mul && (ls.flags & LP_STATE_RATIO);
-						bool pconst = false; float pf = 0.f;
-						if (ratio && st.prov != NO_SLOT) { pconst = uni(ops[st.prov].rt_fconst_valid) != 0; pf = uni(ops[st.prov].rt_fconst); }
-#pragma unroll
-						for (int k = 0; k < T; ++k) {
-							const int e = w * G::NP + p0 + k;
-							out[e] = ratio ? ls.v0 * (pconst ? pf : mul[e]) : ls.v0;
-						}
-						break;
-					}
-					case ST_LERP: {
-						float *par = slots + (size_t)st.out * G::SLOT;
-						const float *rpar = slots + (size_t)st.freq * G::SLOT;
-						const float *mod = slots + (size_t)st.pm * G::SLOT;
-#pragma unroll
-						for (int k = 0; k < T; ++k) {
-							const int e = w * G::NP + p0 + k;
-							float pv = par[e];
-							pv += (rpar[e] - pv) * mod[e];
-							par[e] = pv;
-						}
-						break;
-					}
-					case ST_OSC: {
-						float *out = slots + (size_t)st.out * G::SLOT;
-						const float *pmS = st.pm != NO_SLOT ? slots + (size_t)st.pm * G::SLOT : nullptr;
-						const float *fpmS = st.fpm != NO_SLOT ? slots + (size_t)st.fpm * G::SLOT : nullptr;
-						const float *ampS = st.amp != NO_SLOT ? slots + (size_t)st.amp * G::SLOT : nullptr;
-						const uint32_t type = uni(op->type);
-						const bool wave_env = (st.flags & SF_WAVE_ENV) != 0;
-						const bool layer = (st.flags & SF_LAYER) != 0;
-						const float ac = ampS ? 0.f : uni(op->line[L_AMP].v0);
-						float s[T];
-						if (type == OT_WAVE) {
-							const uint32_t wave = uni(op->wave);
-							const float diff_scale = uni(misc->wc[wave].diff_scale);
-							const float diff_offset = uni(misc->wc[wave].diff_offset);
-							TabRef tab;
-							{
-								const int ti = uni(misc->tab_of_wave[wave]);
-								tab.in_lds = ti >= 0;
-								tab.c23 = ti >= 0 ? t23 + (size_t)ti * WAVE_LEN : P.g_c23 + (size_t)wave * WAVE_LEN;
-								tab.c01 = ti >= 0 ? t01 + (size_t)ti * WAVE_LEN : P.g_c01 + (size_t)wave * WAVE_LEN;
-							}
-							const float fc = uni(op->rt_fconst);
-							const uint32_t inc = rint32w(uni(op->coeff) * fc);
-							const uint32_t phase0 = uni(op->phase);
-							const bool reset = (uni(op->flags) & OPF_OSC_RESET) != 0;
-							uint32_t ph[T];
-							double Is[T];
-#pragma unroll
-							for (int k = 0; k < T; ++k) {
-								const int e = w * G::NP + p0 + k;
-								const int t = t_base + p0 + k;
-								const uint32_t ofs = (uint32_t)pm_offset(pmS != nullptr, fpmS != nullptr,
-										pmS ? pmS[e] : 0.f, fpmS ? fpmS[e] : 0.f, fc, 0x1p31f);
-								ph[k] = phase0 + inc * (uint32_t)(t + 1) + ofs;
-							}
-							if (first_chunk) {
-								/* t = -1: the sample before the segment (wosc.h:215-231 on restart) */
-								const uint32_t next0 = __shfl_down(ph[0], 1);
-#pragma unroll
-								for (int k = 0; k < T; ++k) {
-									if (p0 + k == (int)H - 1) {
-										const uint32_t nxt = (k < T - 1) ? ph[k < T - 1 ? k + 1 : k] : next0;
-										ph[k] = reset ? nxt - SLEN : uni(op->prev_phase);
-									}
-								}
-							}
-#pragma unroll
-							for (int k = 0; k < T; ++k) Is[k] = herp_lookup(tab, ph[k]);
-							if (first_chunk && !reset) {
-#pragma unroll
-								for (int k = 0; k < T; ++k)
-									if (p0 + k == (int)H - 1) Is[k] = uni(op->prev_Is);
-							}
-							uint32_t pph = __shfl_up(ph[T - 1], 1);
-							double pIs = __shfl_up(Is[T - 1], 1);
-							bool zero = false;
-#pragma unroll
-							for (int k = 0; k < T; ++k) {
-								if (k > 0) { pph = ph[k - 1]; pIs = Is[k - 1]; }
-								const int t = t_base + p0 + k;
-								const int32_t d = (int32_t)(ph[k] - pph);
-								const bool live = (p0 + k >= 1) && t >= 0 && t < (int)fast_total;
-								if (live && d == 0) zero = true;
-								s[k] = wosc_diff(Is[k], pIs, d, diff_scale, diff_offset);
-								if (t == (int)fast_total - 1 && p0 + k >= (int)H) {
-									op->st_prev_phase = ph[k];
-									op->st_prev_Is = Is[k];
-									op->st_prev_s = s[k];
-								}
-							}
-							if (__any(zero) && l == 0) misc->bail = 1; /* hold-previous run: block loop handles it */
-						} else if (type == OT_NOISE) {
-							const uint32_t nz = uni(op->wave);
-							const uint32_t n0 = uni(op->noise_n);
-							const uint32_t nprev = uni(op->noise_prev);
-#pragma unroll
-							for (int k = 0; k < T; ++k) {
-								const int t = t_base + p0 + k;
-								const uint32_t n = n0 + (uint32_t)t;
-								if (nz == NZ_vi) {
-									uint32_t s1 = ranfast32(n);
-									uint32_t s0 = t == 0 ? nprev : ranfast32(n - 1);
-									s[k] = fscalei((s1 / 2) - (s0 / 2), 0x1p-31f);
-								} else if (nz == NZ_bv) {
-									int32_t s1 = noise_bv_term(n);
-									int32_t s0 = t == 0 ? (int32_t)nprev : noise_bv_term(n - 1);
-									s[k] = (float)(s1 - s0);
-								} else {
-									s[k] = noise_stateless(nz, n);
-								}
-							}
-						} else {
-#pragma unroll
-							for (int k = 0; k < T; ++k) s[k] = 1.f;
-						}
-						const bool to_voice = (st.which & OX_VOICE) != 0;
-#pragma unroll
-						for (int k = 0; k < T; ++k) {
-							const int e = w * G::NP + p0 + k;
-							const int t = t_base + p0 + k;
-							const float a = ampS ? ampS[e] : ac;
-							const float r = mix_combine(layer ? out[e] : 0.f, s[k], a, wave_env, layer);
-							if (to_voice) {
-								if (p0 + k >= (int)H && t < (int)fast_total) vrow[t] = r;
-							} else {
-								out[e] = r;
-							}
-						}
-						break;
-					}
-					case ST_VOICE: {
-						const float *src = slots + (size_t)st.out * G::SLOT;
-						const float *panS = st.pm != NO_SLOT ? slots + (size_t)st.pm * G::SLOT : nullptr;
-						const float pv = uni(op->line[L_PAN].v0);
-#pragma unroll
-						for (int k = 0; k < T; ++k) {
-							const int e = w * G::NP + p0 + k;
-							const int t = t_base + p0 + k;
-							if (p0 + k >= (int)H && t < (int)fast_total) {
-								vrow[t] = src[e];
-								if (prow) prow[t] = panS ? panS[e] : pv;
-							}
-						}
-						break;
-					}
-					default: break;
-					}
-				}
-			}
-			__syncthreads();
-			if (uni(misc->bail) != 0) {
-				fast_total = 0; /* redo the whole segment in the block loop */
-			} else {
-				for (uint32_t i = tid; i < vd.nops; i += 64 * W) {
-					DevOp &o = ops[i];
-					if (!(o.flags & OPF_TIME_INF)) o.time -= fast_total;
-					for (uint32_t ln = 0; ln < L_COUNT; ++ln) line_advance_hold(o.line[ln], fast_total);
-					if (o.type == OT_WAVE) {
-						const uint32_t inc = rint32w(o.coeff * o.rt_fconst);
-						o.phase += inc * fast_total;
-						o.prev_phase = o.st_prev_phase;
-						o.prev_Is = o.st_prev_Is;
-						o.prev_s = o.st_prev_s;
-						o.flags &= ~OPF_OSC_RESET;
-					} else if (o.type == OT_NOISE) {
-						const uint32_t n0 = o.noise_n;
-						if (o.wave == NZ_vi) o.noise_prev = ranfast32(n0 + fast_total - 1);
-						else if (o.wave == NZ_bv) o.noise_prev = (uint32_t)noise_bv_term(n0 + fast_total - 1);
-						o.noise_n = n0 + fast_total;
-					}
-				}
-			}
-			__syncthreads();
-			done = produced = fast_total;
-		}
-	}
 
 	while (done < vd.run_len) {
 		if (uni(ops[vd.carr_local].time) == 0) break; /* generator.c:839 */
@@ -492,7 +244,18 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 		bool block_ended = false;
 
 		for (uint32_t si = 0; si < vd.plan_len && !block_ended; ++si) {
-			const Step st = uni(plan[si]);
+			Step st = uni(plan[si]);
+			{ /* slot ids -> memory indices (two pools, sau_dev_types.h) */
+				const uint32_t nm = P.n_main;
+				if (st.out != NO_SLOT) st.out = (uint8_t)slot_index(st.out, nm);
+				if (st.freq != NO_SLOT) st.freq = (uint8_t)slot_index(st.freq, nm);
+				if (st.fmul != NO_SLOT) st.fmul = (uint8_t)slot_index(st.fmul, nm);
+				if (st.pm != NO_SLOT) st.pm = (uint8_t)slot_index(st.pm, nm);
+				if (st.fpm != NO_SLOT) st.fpm = (uint8_t)slot_index(st.fpm, nm);
+				if (st.amp != NO_SLOT) st.amp = (uint8_t)slot_index(st.amp, nm);
+				if (st.sm != NO_SLOT) st.sm = (uint8_t)slot_index(st.sm, nm);
+				if (st.kind == ST_OSC && st.tmp != NO_SLOT) st.tmp = (uint8_t)slot_index(st.tmp, nm);
+			}
 			const uint32_t parent_len = cur_len;
 			DevOp *op = &ops[st.op];
 			const uint32_t op_flags = uni(op->flags);
@@ -1153,20 +916,409 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 		done += blen;
 	}
 
-	/* rows are read up to the stream's write_len: silence after this voice ends */
-	for (uint32_t i = produced + tid; i < P.seg_len; i += 64 * W) {
-		vrow[i] = 0.f;
-		if (prow) prow[i] = 0.f;
-	}
-	if (tid == 0) {
+	if (tid == 0) { /* what the mixer needs to know about this row */
 		VoiceOut vo;
 		vo.pan_const = ops[vd.carr_local].line[L_PAN].v0;
 		vo.has_pan = prow ? 1u : 0u;
+		vo.valid_len = produced;
+		vo.pan_row = vd.pan_dynamic_row;
 		P.vinfo[vd.out_row] = vo;
 	}
 	__syncthreads();
 	for (uint32_t i = tid; i < vd.nops * 64; i += 64 * W)
 		((u32_alias *)&P.ops[my_ids[i >> 6]])[i & 63] = ((const u32_alias *)ops)[i];
+	} /* work list */
+}
+
+
+/* ======================================================================== */
+/* time-parallel path: analyze -> fast -> finalize                          */
+/* ======================================================================== */
+/* While every line of a voice is held (no sweep pending), every oscillator
+ * frequency is one value, nothing feeds back and no operator runs out of
+ * time, sample t of the segment depends on the segment-start state only
+ * through closed forms: phase(t) = phase0 + inc*(t+1) (the wrapping sum of
+ * equal increments, wosc.h:129,145), noise counter n0 + t (noise.h:45).  Waves
+ * then take chunks of the time axis independently: no barriers, no carried
+ * state, block buffers private to the wave.  Each chunk recomputes H =
+ * nesting-depth samples of lead-in so that the differentiators
+ * (wosc.h:250-256) have their previous sample.  Everything else (sweeps, FM,
+ * feedback, operators that expire) is left to render_kernel's block loop,
+ * which continues where this path stops (fast_done). */
+
+struct FastInfo {
+	uint32_t total; /* frames this path renders (0: not eligible) */
+	uint32_t H;     /* lead-in samples per chunk */
+	uint32_t bail;  /* set when a chunk met dphase == 0 (hold-previous run) */
+	uint32_t pad;
+};
+
+struct FastOp { /* per-wave LDS copy of what a chunk needs from one operator */
+	uint32_t type, wave, reset, inc;
+	float fc, ac, pan, diff_scale;
+	float diff_offset; int32_t tab; uint32_t phase0, prev_phase;
+	double prev_Is;
+	uint32_t noise_n, noise_prev;
+};
+static_assert(sizeof(FastOp) == 64, "FastOp is 16 dwords");
+
+struct FastParams {
+	const VoiceDesc *voices;
+	const Step *steps;
+	const uint32_t *op_ids;
+	DevOp *ops;
+	float *vout;
+	float *pan;
+	FastInfo *info;
+	uint32_t *fast_done;
+	uint32_t *worklist;   /* out: voices the block loop still has to run */
+	uint32_t *work_count;
+	VoiceOut *vinfo;
+	const HerpC23 *g_c23;
+	const HerpC01 *g_c01;
+	uint32_t row_stride, n_voices, n_main, max_ops, max_steps, n_tabs, np;
+	uint32_t enable;      /* 0: leave every voice to the block loop */
+	int8_t tab_of_wave[12];
+	uint8_t wave_of_tab[12];
+	WaveConst wc[12];
+};
+
+__global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
+	const uint32_t v = blockIdx.x * 64 + threadIdx.x;
+	if (v >= P.n_voices) return;
+	const VoiceDesc vd = P.voices[v];
+	const uint32_t *ids = P.op_ids + vd.ops_ofs;
+	bool bad = (vd.flags & VD_NO_FAST) != 0 || !P.enable;
+	uint32_t min_time = 0xFFFFFFFFu;
+	for (uint32_t i = 0; i < vd.nops; ++i) {
+		DevOp &o = P.ops[ids[i]];
+		for (uint32_t ln = 0; ln < L_COUNT; ++ln)
+			if (o.line[ln].flags & LP_GOAL) bad = true;
+		if (o.type == OT_RASEG) bad = true;
+		if (o.type == OT_NOISE && o.wave == NZ_re) bad = true;
+		if (o.line[L_PMA].v0 != 0.f) bad = true; /* self-modulation is a recurrence */
+		o.rt_fconst_valid = 0;
+		if (!(o.flags & OPF_TIME_INF) && o.time < min_time) min_time = o.time;
+	}
+	uint32_t depth = 0, maxd = 0;
+	const Step *plan = P.steps + vd.plan_ofs;
+	for (uint32_t si = 0; si < vd.plan_len && !bad; ++si) {
+		const Step st = plan[si];
+		DevOp &o = P.ops[ids[st.op]];
+		if (st.flags & SF_BEGIN) { ++depth; if (depth > maxd) maxd = depth; }
+		const bool freq_here = (st.kind == ST_LINE && st.which == L_FREQ) ||
+			(st.kind == ST_OSC && st.freq == NO_SLOT && o.type == OT_WAVE);
+		if (st.kind == ST_SMLINE || st.kind == ST_ZERO) bad = true;
+		if (st.kind == ST_LINE && st.which == L_FREQ && (st.flags & SF_FORCE)) bad = true; /* FM */
+		if (st.kind == ST_OSC && st.sm != NO_SLOT) bad = true;
+		if (freq_here && !bad) {
+			const LineState &fl = o.line[L_FREQ];
+			float fc = fl.v0;
+			if (st.fmul != NO_SLOT && (fl.flags & LP_STATE_RATIO)) {
+				const uint32_t pg = st.prov != NO_SLOT ? ids[st.prov] : 0;
+				if (st.prov == NO_SLOT || !P.ops[pg].rt_fconst_valid) bad = true;
+				else fc = fl.v0 * P.ops[pg].rt_fconst; /* sau/line.c:72 */
+			}
+			o.rt_fconst = fc;
+			o.rt_fconst_valid = 1;
+		}
+		if (st.kind == ST_OSC && o.type == OT_WAVE && st.freq != NO_SLOT && !o.rt_fconst_valid) bad = true;
+		if (st.flags & SF_END) --depth;
+	}
+	FastInfo fi;
+	fi.H = maxd; fi.bail = 0; fi.pad = 0;
+	fi.total = 0;
+	if (!bad && vd.nops <= P.max_ops && vd.plan_len <= P.max_steps && maxd >= 1 && maxd <= P.np / 2)
+		fi.total = min(min_time, vd.run_len);
+	P.info[v] = fi;
+	P.fast_done[v] = 0;
+}
+
+template <int T>
+__global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
+	constexpr int NP = 64 * T;
+	constexpr int W = 16;
+	extern __shared__ __align__(16) unsigned char lds[];
+	const int tid = threadIdx.x;
+	const int w = tid >> 6;
+	const int l = tid & 63;
+	const int p0 = l * T;
+
+	HerpC23 *t23 = (HerpC23 *)lds;
+	HerpC01 *t01 = (HerpC01 *)(lds + (size_t)P.n_tabs * WAVE_LEN * sizeof(HerpC23));
+	unsigned char *areas = lds + (size_t)P.n_tabs * WAVE_LEN * (sizeof(HerpC23) + sizeof(HerpC01));
+	const size_t area_bytes = (size_t)P.max_ops * sizeof(FastOp) + (size_t)P.max_steps * sizeof(Step) +
+		(size_t)P.n_main * NP * sizeof(float);
+	FastOp *fops = (FastOp *)(areas + (size_t)w * area_bytes);
+	Step *plan = (Step *)(fops + P.max_ops);
+	float *slots = (float *)(plan + P.max_steps);
+
+	for (uint32_t t = 0; t < P.n_tabs; ++t) {
+		const uint32_t wave = P.wave_of_tab[t];
+		const uint4 *s23 = (const uint4 *)(P.g_c23 + (size_t)wave * WAVE_LEN);
+		uint4 *d23 = (uint4 *)(t23 + (size_t)t * WAVE_LEN);
+		for (uint32_t i = tid; i < WAVE_LEN; i += 64 * W) d23[i] = s23[i];
+		const uint2 *s01 = (const uint2 *)(P.g_c01 + (size_t)wave * WAVE_LEN);
+		uint2 *d01 = (uint2 *)(t01 + (size_t)t * WAVE_LEN);
+		for (uint32_t i = tid; i < WAVE_LEN; i += 64 * W) d01[i] = s01[i];
+	}
+	__syncthreads(); /* the only barrier: tables are shared, all else is per wave */
+
+	const uint32_t g = blockIdx.x * W + (uint32_t)w;
+	const uint32_t total_waves = gridDim.x * W;
+	const uint32_t NV = P.n_voices;
+	uint32_t wpv = total_waves >= NV ? total_waves / NV : 1; /* waves per voice */
+	uint32_t v = total_waves >= NV ? g / wpv : g;
+	const uint32_t vstride = total_waves >= NV ? NV /* one voice per wave */ : total_waves;
+	const uint32_t cstart = total_waves >= NV ? g % wpv : 0;
+
+	for (; v < NV; v += vstride) {
+		const FastInfo fi = P.info[v];
+		const uint32_t fast_total = uni(fi.total);
+		if (fast_total == 0) continue;
+		const VoiceDesc vd = P.voices[v];
+		const uint32_t *ids = P.op_ids + vd.ops_ofs;
+		const uint32_t H = uni(fi.H);
+		/* per-wave copies: operator constants and the plan */
+		if ((uint32_t)l < vd.nops) {
+			const DevOp &o = P.ops[ids[l]];
+			FastOp f;
+			f.type = o.type; f.wave = o.wave; f.reset = (o.flags & OPF_OSC_RESET) ? 1u : 0u;
+			f.fc = o.rt_fconst;
+			f.inc = rint32w(o.coeff * o.rt_fconst);
+			f.ac = o.line[L_AMP].v0;
+			f.pan = o.line[L_PAN].v0;
+			const uint32_t wv = o.type == OT_WAVE ? (o.wave < 12 ? o.wave : 0) : 0;
+			f.diff_scale = P.wc[wv].diff_scale;
+			f.diff_offset = P.wc[wv].diff_offset;
+			f.tab = P.tab_of_wave[wv];
+			f.phase0 = o.phase; f.prev_phase = o.prev_phase; f.prev_Is = o.prev_Is;
+			f.noise_n = o.noise_n; f.noise_prev = o.noise_prev;
+			fops[l] = f;
+		}
+		{
+			const u32_alias *src = (const u32_alias *)(P.steps + vd.plan_ofs);
+			for (uint32_t i = l; i < vd.plan_len * 4; i += 64) ((u32_alias *)plan)[i] = src[i];
+		}
+		float *vrow = P.vout + (size_t)vd.out_row * P.row_stride;
+		float *prow = (vd.pan_dynamic_row != ~0u) ? P.pan + (size_t)vd.pan_dynamic_row * P.row_stride : nullptr;
+		const uint32_t C = (uint32_t)NP - H;
+		const uint32_t nch = (fast_total + C - 1) / C;
+		bool zero_seen = false;
+
+		for (uint32_t c = cstart; c < nch; c += wpv) {
+			const int t_base = (int)(c * C) - (int)H; /* segment sample at p = 0 */
+			const bool first_chunk = (c == 0);
+			for (uint32_t si = 0; si < vd.plan_len; ++si) {
+				const Step st = uni(plan[si]);
+				const FastOp *op = &fops[st.op];
+				switch (st.kind) {
+				case ST_LINE: {
+					if (st.which == L_FREQ) break; /* single value: FastOp.fc */
+					/* held line: v0 (sau/line.c:435-442); ratio lines only exist for freq */
+					float *out = slots + (size_t)st.out * NP;
+					const DevOp &o = P.ops[ids[st.op]];
+					const float v0 = uni(o.line[st.which].v0);
+#pragma unroll
+					for (int k = 0; k < T; ++k) out[p0 + k] = v0;
+					break;
+				}
+				case ST_LERP: { /* generator.c:466-467 */
+					float *par = slots + (size_t)st.out * NP;
+					const float *rpar = slots + (size_t)st.freq * NP;
+					const float *mod = slots + (size_t)st.pm * NP;
+#pragma unroll
+					for (int k = 0; k < T; ++k) {
+						const int e = p0 + k;
+						float pv = par[e];
+						pv += (rpar[e] - pv) * mod[e];
+						par[e] = pv;
+					}
+					break;
+				}
+				case ST_OSC: {
+					float *out = slots + (size_t)st.out * NP;
+					const float *pmS = st.pm != NO_SLOT ? slots + (size_t)st.pm * NP : nullptr;
+					const float *fpmS = st.fpm != NO_SLOT ? slots + (size_t)st.fpm * NP : nullptr;
+					const float *ampS = st.amp != NO_SLOT ? slots + (size_t)st.amp * NP : nullptr;
+					const uint32_t type = uni(op->type);
+					const bool wave_env = (st.flags & SF_WAVE_ENV) != 0;
+					const bool layer = (st.flags & SF_LAYER) != 0;
+					const float ac = uni(op->ac);
+					float s[T];
+					if (type == OT_WAVE) {
+						const float diff_scale = uni(op->diff_scale);
+						const float diff_offset = uni(op->diff_offset);
+						const uint32_t wave = uni(op->wave);
+						TabRef tab;
+						{
+							const int ti = uni(op->tab);
+							tab.in_lds = ti >= 0;
+							tab.c23 = ti >= 0 ? t23 + (size_t)ti * WAVE_LEN : P.g_c23 + (size_t)wave * WAVE_LEN;
+							tab.c01 = ti >= 0 ? t01 + (size_t)ti * WAVE_LEN : P.g_c01 + (size_t)wave * WAVE_LEN;
+						}
+						const float fc = uni(op->fc);
+						const uint32_t inc = uni(op->inc);
+						const uint32_t phase0 = uni(op->phase0);
+						const bool reset = uni(op->reset) != 0;
+						uint32_t ph[T];
+						double Is[T];
+#pragma unroll
+						for (int k = 0; k < T; ++k) {
+							const int e = p0 + k;
+							const int t = t_base + e;
+							const uint32_t ofs = pm_offset32(pmS != nullptr, fpmS != nullptr,
+									pmS ? pmS[e] : 0.f, fpmS ? fpmS[e] : 0.f, fc);
+							ph[k] = phase0 + inc * (uint32_t)(t + 1) + ofs;
+						}
+						if (first_chunk) {
+							/* t = -1: the sample before the segment (wosc.h:215-231 on restart) */
+							const uint32_t next0 = __shfl_down(ph[0], 1);
+							const uint32_t pprev = uni(op->prev_phase);
+#pragma unroll
+							for (int k = 0; k < T; ++k) {
+								if (p0 + k == (int)H - 1) {
+									const uint32_t nxt = (k < T - 1) ? ph[(k + 1) % T] : next0;
+									ph[k] = reset ? nxt - SLEN : pprev;
+								}
+							}
+						}
+#pragma unroll
+						for (int k = 0; k < T; ++k) Is[k] = herp_lookup(tab, ph[k]);
+						if (first_chunk && !reset) {
+							const double pIs0 = uni(op->prev_Is);
+#pragma unroll
+							for (int k = 0; k < T; ++k)
+								if (p0 + k == (int)H - 1) Is[k] = pIs0;
+						}
+						uint32_t pph = __shfl_up(ph[T - 1], 1);
+						double pIs = __shfl_up(Is[T - 1], 1);
+						bool zero = false;
+#pragma unroll
+						for (int k = 0; k < T; ++k) {
+							if (k > 0) { pph = ph[k - 1]; pIs = Is[k - 1]; }
+							const int t = t_base + p0 + k;
+							const int32_t d = (int32_t)(ph[k] - pph);
+							const bool live = (p0 + k >= 1) && t >= 0 && t < (int)fast_total;
+							if (live && d == 0) zero = true;
+							s[k] = wosc_diff(Is[k], pIs, d, diff_scale, diff_offset);
+							if (t == (int)fast_total - 1 && p0 + k >= (int)H) {
+								DevOp &o = P.ops[ids[st.op]];
+								o.st_prev_phase = ph[k];
+								o.st_prev_Is = Is[k];
+								o.st_prev_s = s[k];
+							}
+						}
+						if (zero) zero_seen = true;
+					} else if (type == OT_NOISE) {
+						const uint32_t nz = uni(op->wave);
+						const uint32_t n0 = uni(op->noise_n);
+						const uint32_t nprev = uni(op->noise_prev);
+#pragma unroll
+						for (int k = 0; k < T; ++k) {
+							const int t = t_base + p0 + k;
+							const uint32_t n = n0 + (uint32_t)t;
+							if (nz == NZ_vi) {
+								uint32_t s1 = ranfast32(n);
+								uint32_t s0 = t == 0 ? nprev : ranfast32(n - 1);
+								s[k] = fscalei((s1 / 2) - (s0 / 2), 0x1p-31f);
+							} else if (nz == NZ_bv) {
+								int32_t s1 = noise_bv_term(n);
+								int32_t s0 = t == 0 ? (int32_t)nprev : noise_bv_term(n - 1);
+								s[k] = (float)(s1 - s0);
+							} else {
+								s[k] = noise_stateless(nz, n);
+							}
+						}
+					} else { /* OT_AMP: generator.c:517-518 */
+#pragma unroll
+						for (int k = 0; k < T; ++k) s[k] = 1.f;
+					}
+					const bool to_voice = (st.which & OX_VOICE) != 0;
+#pragma unroll
+					for (int k = 0; k < T; ++k) {
+						const int e = p0 + k;
+						const int t = t_base + e;
+						const float a = ampS ? ampS[e] : ac;
+						const float r = mix_combine(layer ? out[e] : 0.f, s[k], a, wave_env, layer);
+						if (to_voice) {
+							if (e >= (int)H && t < (int)fast_total) vrow[t] = r;
+						} else {
+							out[e] = r;
+						}
+					}
+					break;
+				}
+				case ST_VOICE: { /* generator.c:749-788 with pan modulators; summed by mix_kernel */
+					const float *src = slots + (size_t)st.out * NP;
+					const float *panS = st.pm != NO_SLOT ? slots + (size_t)st.pm * NP : nullptr;
+					const float pv = uni(op->pan);
+#pragma unroll
+					for (int k = 0; k < T; ++k) {
+						const int e = p0 + k;
+						const int t = t_base + e;
+						if (e >= (int)H && t < (int)fast_total) {
+							vrow[t] = src[e];
+							if (prow) prow[t] = panS ? panS[e] : pv;
+						}
+					}
+					break;
+				}
+				default: break;
+				}
+			}
+		}
+		if (__any(zero_seen) && l == 0) atomicOr(&P.info[v].bail, 1u);
+	}
+}
+
+/* Apply the closed forms to the operator state, or hand the whole segment
+ * to the block loop when a chunk had to bail out. */
+__global__ void __launch_bounds__(64) finalize_kernel(FastParams P) {
+	const uint32_t v = blockIdx.x * 64 + threadIdx.x;
+	if (v >= P.n_voices) return;
+	const FastInfo fi = P.info[v];
+	const VoiceDesc vd = P.voices[v];
+	if (fi.total == 0 || fi.bail) {
+		P.fast_done[v] = 0;
+		P.worklist[atomicAdd(P.work_count, 1u)] = v;
+		return;
+	}
+	const uint32_t *ids = P.op_ids + vd.ops_ofs;
+	const uint32_t total = fi.total;
+	for (uint32_t i = 0; i < vd.nops; ++i) {
+		DevOp &o = P.ops[ids[i]];
+		if (!(o.flags & OPF_TIME_INF)) o.time -= total;
+		for (uint32_t ln = 0; ln < L_COUNT; ++ln) {
+			LineState ls = o.line[ln];
+			line_advance_hold(ls, total);
+			o.line[ln] = ls;
+		}
+		if (o.type == OT_WAVE) {
+			const uint32_t inc = rint32w(o.coeff * o.rt_fconst);
+			o.phase += inc * total;
+			o.prev_phase = o.st_prev_phase;
+			o.prev_Is = o.st_prev_Is;
+			o.prev_s = o.st_prev_s;
+			o.flags &= ~OPF_OSC_RESET;
+		} else if (o.type == OT_NOISE) {
+			const uint32_t n0 = o.noise_n;
+			if (o.wave == NZ_vi) o.noise_prev = ranfast32(n0 + total - 1);
+			else if (o.wave == NZ_bv) o.noise_prev = (uint32_t)noise_bv_term(n0 + total - 1);
+			o.noise_n = n0 + total;
+		}
+	}
+	P.fast_done[v] = total;
+	if (total < vd.run_len) {
+		P.worklist[atomicAdd(P.work_count, 1u)] = v;
+	} else { /* whole segment done here: tell the mixer */
+		VoiceOut vo;
+		vo.pan_const = P.ops[ids[vd.carr_local]].line[L_PAN].v0;
+		vo.has_pan = vd.pan_dynamic_row != ~0u ? 1u : 0u;
+		vo.valid_len = total;
+		vo.pan_row = vd.pan_dynamic_row;
+		P.vinfo[vd.out_row] = vo;
+	}
 }
 
 struct MixStream {
@@ -1181,28 +1333,63 @@ struct MixParams {
 	const float *vout;
 	const float *pan;
 	const VoiceOut *vinfo;
-	const VoiceDesc *voices;
 	uint32_t row_stride;
 	uint32_t pcm_offset;
 	uint32_t stereo;
 };
 
-/* generator.c:749-825: ordered voice sum (ref-build association) and PCM. */
+/* generator.c:749-825: ordered voice sum (ref-build association) and PCM.
+ * One thread per output frame walks the stream's voices in ascending id --
+ * the reference's f32 accumulation order -- so the sum is bit-identical to
+ * the CPU's and independent of scheduling.  Loads are issued eight voices
+ * ahead of the (serially dependent) adds. */
+constexpr int MIX_TILE = 256; /* voices whose constants are staged at a time */
 __global__ void __launch_bounds__(256) mix_kernel(MixParams P) {
+	__shared__ float s_pan[MIX_TILE];
+	__shared__ uint32_t s_valid[MIX_TILE];
+	__shared__ uint32_t s_prow[MIX_TILE]; /* pan row, or ~0u */
 	const MixStream ms = P.streams[blockIdx.y];
 	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-	if (i >= ms.write_len) return;
+	if (blockIdx.x * 256 >= ms.write_len) return;
+	const bool act = i < ms.write_len;
 	float L = 0.f, R = 0.f;
-	for (uint32_t r = 0; r < ms.n_rows; ++r) {
-		const uint32_t row = ms.first_row + r;
-		const VoiceOut vo = P.vinfo[row];
-		float sv = P.vout[(size_t)row * P.row_stride + i] * ms.amp_scale;
-		float pan = vo.pan_const;
-		if (vo.has_pan) pan = P.pan[(size_t)P.voices[row].pan_dynamic_row * P.row_stride + i];
-		float s_r = sv * pan;
-		L = (L + sv) - s_r;
-		R = (R + sv) + s_r;
+	for (uint32_t r0 = 0; r0 < ms.n_rows; r0 += MIX_TILE) {
+		const uint32_t nt = min((uint32_t)MIX_TILE, ms.n_rows - r0);
+		__syncthreads();
+		if (threadIdx.x < nt) {
+			const VoiceOut vo = P.vinfo[ms.first_row + r0 + threadIdx.x];
+			s_pan[threadIdx.x] = vo.pan_const;
+			s_valid[threadIdx.x] = vo.valid_len;
+			s_prow[threadIdx.x] = vo.has_pan ? vo.pan_row : ~0u;
+		}
+		__syncthreads();
+		if (!act) continue;
+		const float *base = P.vout + (size_t)(ms.first_row + r0) * P.row_stride + i;
+		for (uint32_t r = 0; r < nt; r += 8) {
+			float sv[8], pn[8];
+			bool okv[8];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) {
+				const uint32_t rr = r + u;
+				const bool ok = rr < nt && i < s_valid[rr < nt ? rr : 0];
+				okv[u] = ok;
+				sv[u] = ok ? base[(size_t)rr * P.row_stride] : 0.f;
+				const uint32_t pr = rr < nt ? s_prow[rr] : ~0u;
+				pn[u] = rr < nt ? s_pan[rr] : 0.f;
+				if (ok && pr != ~0u) pn[u] = P.pan[(size_t)pr * P.row_stride + i];
+			}
+#pragma unroll
+			for (int u = 0; u < 8; ++u) {
+				if (okv[u]) { /* generator.c:842-843: a voice adds only the frames it produced */
+					const float v = sv[u] * ms.amp_scale;
+					const float s_r = v * pn[u];
+					L = (L + v) - s_r;
+					R = (R + v) + s_r;
+				}
+			}
+		}
 	}
+	if (!act) return;
 	if (P.stereo) {
 		int16_t *d = ms.pcm + 2 * (size_t)(P.pcm_offset + i);
 		d[0] = pcm16(L);
@@ -1285,6 +1472,7 @@ public:
 		ops_.release(); steps_.release(); op_ids_.release(); voices_.release();
 		vout_.release(); pan_.release(); vinfo_.release(); pcm_.release();
 		recs_.release(); mstreams_.release(); c23_.release(); c01_.release(); wc_.release();
+		finfo_.release(); fdone_.release(); worklist_.release(); work_count_.release();
 		h_voices_.release(); h_ms_.release();
 		if (copy_done_) (void)hipEventDestroy(copy_done_);
 		for (auto &e : events_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -1308,6 +1496,7 @@ public:
 		const char *wt = getenv("SAU_AMD_GEOMETRY"); /* "8x2" (default) or "4x4" */
 		geo_ = (wt && !strcmp(wt, "8x2")) ? 0 : 1; /* default 4 waves x 4 samples per lane */
 		debug_ = getenv("SAU_AMD_DEBUG") != nullptr;
+		fast_enabled_ = getenv("SAU_AMD_NO_FAST") == nullptr;
 		if (!ops_.ensure(cfg.op_count ? cfg.op_count : 1, err)) return false;
 		HIP_OK(hipMemsetAsync(ops_.p, 0, ops_.cap * sizeof(DevOp), stream_));
 		/* Hermite coefficient tables from the PILUTs (sau/wave.h:127-141) */
@@ -1441,22 +1630,86 @@ public:
 		rp.g_c23 = c23_.p; rp.g_c01 = c01_.p;
 		rp.row_stride = row_stride_; rp.seg_len = seg.len;
 		rp.n_slots = seg.n_slots; rp.max_ops = seg.max_ops; rp.n_tabs = n_tabs;
-		rp.max_steps = seg.max_steps;
+		rp.max_steps = seg.max_steps; rp.n_main = seg.n_main;
+		rp.fast_done = nullptr;
 		memcpy(rp.wc, wconst_, sizeof wconst_);
-		TimedPair *tp = timing_on_ ? new_pair() : nullptr;
+		/* ---- time-parallel path first; the block loop continues after it ---- */
+		{
+			constexpr uint32_t FT = 4, FNP = 64 * FT;
+			const uint32_t fmax_ops = seg.max_ops < 64 ? seg.max_ops : 64;
+			const size_t area = (size_t)fmax_ops * sizeof(FastOp) + (size_t)seg.max_steps * sizeof(Step) +
+				(size_t)seg.n_main * FNP * sizeof(float);
+			const bool use_fast = fast_enabled_ && (16 * area + 1024 <= lds_limit_);
+			if (!finfo_.ensure(seg.n_voices, err) || !fdone_.ensure(seg.n_voices, err) ||
+			    !worklist_.ensure(seg.n_voices, err) || !work_count_.ensure(4, err)) return false;
+			HIP_OK(hipMemsetAsync(work_count_.p, 0, sizeof(uint32_t), stream_));
+			FastParams fp;
+			memset(&fp, 0, sizeof fp);
+			fp.voices = voices_.p; fp.steps = steps_.p; fp.op_ids = op_ids_.p; fp.ops = ops_.p;
+			fp.vout = vout_.p; fp.pan = pan_.p; fp.info = finfo_.p; fp.fast_done = fdone_.p;
+			fp.worklist = worklist_.p; fp.work_count = work_count_.p; fp.vinfo = vinfo_.p;
+			fp.g_c23 = c23_.p; fp.g_c01 = c01_.p;
+			fp.row_stride = row_stride_; fp.n_voices = seg.n_voices; fp.n_main = seg.n_main;
+			fp.max_ops = fmax_ops; fp.max_steps = seg.max_steps; fp.np = FNP;
+			fp.enable = use_fast ? 1u : 0u;
+			memcpy(fp.wc, wconst_, sizeof wconst_);
+			uint32_t ft = 0;
+			for (int wv = 0; wv < 12; ++wv) {
+				fp.tab_of_wave[wv] = -1;
+				if (use_fast && ((seg.wave_mask >> wv) & 1) &&
+				    16 * area + (ft + 1) * tab_bytes + 1024 <= lds_limit_) {
+					fp.tab_of_wave[wv] = (int8_t)ft;
+					fp.wave_of_tab[ft] = (uint8_t)wv;
+					++ft;
+				}
+			}
+			fp.n_tabs = ft;
+			TimedPair *ta = timing_on_ ? new_pair(3) : nullptr;
+			if (ta) (void)hipEventRecord(ta->a, stream_);
+			hipLaunchKernelGGL(analyze_kernel, dim3((seg.n_voices + 63) / 64), dim3(64), 0, stream_, fp);
+			if (ta) (void)hipEventRecord(ta->b, stream_);
+			if (use_fast) {
+				const size_t flds = ft * tab_bytes + 16 * area;
+				static size_t fconfigured = 0;
+				if (flds > fconfigured) {
+					HIP_OK(hipFuncSetAttribute((const void *)fast_kernel<FT>,
+							hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+					fconfigured = flds;
+				}
+				/* four waves per voice when there are few voices, one CU-filling grid at most */
+				uint32_t fgrid = (seg.n_voices * 4 + 15) / 16;
+				if (fgrid > 256) fgrid = 256;
+				if (fgrid < 1) fgrid = 1;
+				TimedPair *tf = timing_on_ ? new_pair(2) : nullptr;
+				if (tf) (void)hipEventRecord(tf->a, stream_);
+				hipLaunchKernelGGL((fast_kernel<FT>), dim3(fgrid), dim3(1024), flds, stream_, fp);
+				if (tf) (void)hipEventRecord(tf->b, stream_);
+			}
+			TimedPair *tz = timing_on_ ? new_pair(3) : nullptr;
+			if (tz) (void)hipEventRecord(tz->a, stream_);
+			hipLaunchKernelGGL(finalize_kernel, dim3((seg.n_voices + 63) / 64), dim3(64), 0, stream_, fp);
+			if (tz) (void)hipEventRecord(tz->b, stream_);
+			HIP_OK(hipGetLastError());
+			rp.fast_done = fdone_.p; rp.worklist = worklist_.p; rp.work_count = work_count_.p;
+			/* Block-loop grid: persistent over the device-built work list. When the
+			 * host knows of nothing that needs it (no sweeps, FM, feedback or expiring
+			 * operators), a token grid still serves the rare dphase == 0 bail-out. */
+			block_grid_ = (seg.maybe_block || !use_fast) ? (seg.n_voices < 1024 ? seg.n_voices : 1024) : 16;
+		}
+		TimedPair *tp = timing_on_ ? new_pair(0) : nullptr;
 		if (tp) (void)hipEventRecord(tp->a, stream_);
-		bool ok = geo_ ? launch_render<4, 4>(rp, seg.n_voices, lds, err)
-		               : launch_render<8, 2>(rp, seg.n_voices, lds, err);
+		bool ok = geo_ ? launch_render<4, 4>(rp, block_grid_, lds, err)
+		               : launch_render<8, 2>(rp, block_grid_, lds, err);
 		if (!ok) return false;
 		if (tp) (void)hipEventRecord(tp->b, stream_);
 		if (debug_) debug_dump("after render", seg);
 		if (max_write) {
 			MixParams mp;
 			mp.streams = mstreams_.p; mp.vout = vout_.p; mp.pan = pan_.p; mp.vinfo = vinfo_.p;
-			mp.voices = voices_.p; mp.row_stride = row_stride_; mp.pcm_offset = seg.pcm_offset;
+			mp.row_stride = row_stride_; mp.pcm_offset = seg.pcm_offset;
 			mp.stereo = seg.stereo ? 1 : 0;
-			TimedPair *tm = timing_on_ ? new_pair() : nullptr;
-			if (tm) { tm->is_mix = true; (void)hipEventRecord(tm->a, stream_); }
+			TimedPair *tm = timing_on_ ? new_pair(1) : nullptr;
+			if (tm) (void)hipEventRecord(tm->a, stream_);
 			hipLaunchKernelGGL(mix_kernel, dim3((max_write + 255) / 256, seg.n_streams), dim3(256), 0,
 					stream_, mp);
 			HIP_OK(hipGetLastError());
@@ -1483,13 +1736,23 @@ public:
 		if (!timing_on_) { timing_on_ = true; }
 		(void)hipStreamSynchronize(stream_);
 		drain_pairs();
-		if (render_ms) *render_ms = acc_render_ms_;
-		if (mix_ms) *mix_ms = acc_mix_ms_;
+		if (render_ms) *render_ms = acc_ms_[0] + acc_ms_[2];
+		if (mix_ms) *mix_ms = acc_ms_[1];
 		if (launches) *launches = acc_launches_;
-		if (reset) { acc_render_ms_ = acc_mix_ms_ = 0; acc_launches_ = 0; }
+		if (reset) { acc_ms_[0] = acc_ms_[1] = acc_ms_[2] = acc_ms_[3] = 0; acc_launches_ = 0; }
 	}
 
 	void *stream_handle() override { return (void *)stream_; }
+
+	void timing_ex(double *out4, uint64_t *segments, bool reset) override {
+		if (!timing_on_) timing_on_ = true;
+		(void)hipStreamSynchronize(stream_);
+		drain_pairs();
+		/* out: time-parallel kernel, block-loop kernel, mixer, analyze+finalize (ms) */
+		out4[0] = acc_ms_[2]; out4[1] = acc_ms_[0]; out4[2] = acc_ms_[1]; out4[3] = acc_ms_[3];
+		if (segments) *segments = acc_launches_;
+		if (reset) { acc_ms_[0] = acc_ms_[1] = acc_ms_[2] = acc_ms_[3] = 0; acc_launches_ = 0; }
+	}
 
 	void debug_dump(const char *what, const SegmentDesc &seg) {
 		(void)hipStreamSynchronize(stream_);
@@ -1501,6 +1764,24 @@ public:
 		for (uint32_t v = 0; v < seg.n_voices && v < 4; ++v)
 			fprintf(stderr, "  voice %u: run_len %u plan %u+%u ops %u+%u\n", v, seg.voices[v].run_len,
 					seg.voices[v].plan_ofs, seg.voices[v].plan_len, seg.voices[v].ops_ofs, seg.voices[v].nops);
+		{
+			uint32_t wc = 0;
+			(void)hipMemcpy(&wc, work_count_.p, 4, hipMemcpyDeviceToHost);
+			std::vector<VoiceOut> vi(seg.n_voices < 4 ? seg.n_voices : 4);
+			std::vector<uint32_t> fd(vi.size());
+			std::vector<FastInfo> fi(vi.size());
+			(void)hipMemcpy(vi.data(), vinfo_.p, vi.size() * sizeof(VoiceOut), hipMemcpyDeviceToHost);
+			(void)hipMemcpy(fd.data(), fdone_.p, fd.size() * 4, hipMemcpyDeviceToHost);
+			(void)hipMemcpy(fi.data(), finfo_.p, fi.size() * sizeof(FastInfo), hipMemcpyDeviceToHost);
+			float v8[8] = {0};
+			(void)hipMemcpy(v8, vout_.p, sizeof v8, hipMemcpyDeviceToHost);
+			fprintf(stderr, "  work_count %u block_grid %u; row0: %g %g %g %g %g %g\n", wc, block_grid_, v8[0], v8[1],
+					v8[2], v8[3], v8[4], v8[5]);
+			for (size_t v = 0; v < vi.size(); ++v)
+				fprintf(stderr, "  vinfo %zu: pan %g has_pan %u valid %u prow %u | fast total %u H %u bail %u done %u\n", v,
+						vi[v].pan_const, vi[v].has_pan, vi[v].valid_len, vi[v].pan_row, fi[v].total, fi[v].H,
+						fi[v].bail, fd[v]);
+		}
 		for (uint32_t i = 0; i < n; ++i) {
 			const DevOp &o = h[i];
 			fprintf(stderr, "  op %u: time %u flags %#x type %u wave %u phase %u prev_s %g fb %g\n", i, o.time,
@@ -1514,26 +1795,27 @@ public:
 	}
 
 private:
-	struct TimedPair { hipEvent_t a, b; bool is_mix; bool used; };
-	TimedPair *new_pair() {
+	/* kind: 0 block-loop kernel, 1 mixer, 2 time-parallel kernel, 3 analyze/finalize */
+	struct TimedPair { hipEvent_t a, b; int kind; bool used; };
+	TimedPair *new_pair(int kind) {
 		if (n_used_ == events_.size()) {
 			if (events_.size() >= 4096) { (void)hipStreamSynchronize(stream_); drain_pairs(); }
 			else {
-				TimedPair p; p.is_mix = false; p.used = false;
+				TimedPair p; p.kind = 0; p.used = false;
 				if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return nullptr;
 				events_.push_back(p);
 			}
 		}
 		TimedPair *p = &events_[n_used_++];
-		p->is_mix = false; p->used = true;
+		p->kind = kind; p->used = true;
 		return p;
 	}
 	void drain_pairs() {
 		for (size_t i = 0; i < n_used_; ++i) {
 			float ms = 0;
 			if (hipEventElapsedTime(&ms, events_[i].a, events_[i].b) == hipSuccess) {
-				if (events_[i].is_mix) acc_mix_ms_ += ms;
-				else { acc_render_ms_ += ms; ++acc_launches_; }
+				acc_ms_[events_[i].kind & 3] += ms;
+				if (events_[i].kind == 0) ++acc_launches_;
 			}
 		}
 		n_used_ = 0;
@@ -1567,8 +1849,12 @@ private:
 	std::vector<TimedPair> events_;
 	size_t n_used_ = 0;
 	bool timing_on_ = false;
-	double acc_render_ms_ = 0, acc_mix_ms_ = 0;
+	double acc_ms_[4] = {0, 0, 0, 0};
 	uint64_t acc_launches_ = 0;
+	bool fast_enabled_ = true;
+	DevBuf<FastInfo> finfo_;
+	DevBuf<uint32_t> fdone_, worklist_, work_count_;
+	uint32_t block_grid_ = 1;
 };
 
 bool kat_line(const LineState &st, uint32_t len, const float *mul, float *out, LineState *st_out) {

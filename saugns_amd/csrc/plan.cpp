@@ -23,22 +23,37 @@ struct Compiler {
 	std::vector<uint32_t> path;     /* operators being evaluated (cycle guard) */
 	std::unordered_map<uint32_t, uint32_t> local;
 	bool used[256] = {};
-	uint32_t high = 0;
+	uint32_t high = 0;       /* highest main-pool slot */
+	uint32_t high_f = 0;     /* number of frequency-pool slots */
 	bool failed = false;
 
 	Compiler(const std::vector<OpMirror> &o, VoicePlan &p, std::string &e)
 		: ops(o), out(p), err(e) { used[SCRATCH_SLOT] = true; }
 
 	uint8_t alloc() {
-		for (uint32_t s = 1; s < 250; ++s) {
+		for (uint32_t s = 1; s < FSLOT_BASE; ++s) {
 			if (!used[s]) {
 				used[s] = true;
 				if (s > high) high = s;
 				return (uint8_t)s;
 			}
 		}
-		if (!failed) { failed = true; err = "operator graph needs more than 249 block buffers"; }
+		if (!failed) { failed = true; err = "operator graph needs more than 127 block buffers"; }
 		return 1;
+	}
+	/* Frequency blocks get numbers from a second pool (FSLOT_BASE up): while
+	 * an operator's frequency is one value they are never materialised, so a
+	 * launch that only runs such voices needs no memory for them. */
+	uint8_t alloc_f() {
+		for (uint32_t s = FSLOT_BASE; s < 250; ++s) {
+			if (!used[s]) {
+				used[s] = true;
+				if (s - FSLOT_BASE + 1 > high_f) high_f = s - FSLOT_BASE + 1;
+				return (uint8_t)s;
+			}
+		}
+		if (!failed) { failed = true; err = "operator graph needs more than 122 frequency buffers"; }
+		return FSLOT_BASE;
 	}
 	void release(uint8_t s) { if (s != NO_SLOT) used[s] = false; }
 
@@ -136,7 +151,7 @@ struct Compiler {
 			bool any_child = count(fmods) || count(rfmods) || count(pmods) ||
 				count(fpmods) || count(amods) || count(ramods) || count(apmods);
 			if (any_child || keep_freq) {
-				F = alloc();
+				F = alloc_f();
 				param_to_slot(lop, L_FREQ, L_FREQ2, F, parent_freq, parent_prov, F, me, fmods, rfmods, first);
 			} else {
 				osc_flags |= SF_SKIP_FREQ2;
@@ -218,9 +233,20 @@ bool compile_voice_plan(const std::vector<OpMirror> &ops, uint32_t carrier,
 		out.steps.back().which |= OX_VOICE;
 	}
 	c.release(Pn); c.release(F); c.release(V);
-	out.n_slots = c.high + 1;
+	out.n_main = c.high + 1;
+	out.n_slots = out.n_main + c.high_f;
 	/* closed-form (time-parallel) evaluation assumes one visit per operator */
 	out.no_fast = false;
+	out.static_block = false;
+	for (uint32_t id : out.op_ids) {
+		const OpMirror &m = ops[id];
+		if (m.type == SAU_POPT_N_raseg) out.static_block = true;
+		if (m.type == SAU_POPT_N_noise && m.wave == SAU_NOISE_N_re) out.static_block = true;
+	}
+	for (const Step &st : out.steps) {
+		if (st.kind == ST_SMLINE) out.static_block = true;
+		if (st.kind == ST_LINE && st.which == L_FREQ && (st.flags & SF_FORCE)) out.static_block = true;
+	}
 	{
 		std::vector<uint8_t> seen(out.op_ids.size(), 0);
 		for (const Step &st : out.steps) {

@@ -81,6 +81,22 @@ SAU_HD uint32_t rint32w(float x) {
 #endif
 }
 
+/* rint(p * 2^31) wrapped to 32 bits (the PM offset of wosc.h:152-166).
+ * Device form without a 64-bit conversion and without branches: with
+ * r = rint(p/2), m = p - 2r is exact and |m| <= 1, and
+ * p*2^31 = m*2^31 + r*2^32, so the wrapped results agree. */
+SAU_HD uint32_t rint32w_p31(float p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	float r = rintf(p * 0.5f);
+	float m = p - (r + r);
+	float y = rintf(m * 0x1p31f);          /* in [-2^31, 2^31] */
+	if (y >= 0x1p31f) y -= 0x1p32f;        /* wrap +2^31 to -2^31: now in int32 range */
+	return (uint32_t)(int32_t)y;
+#else
+	return (uint32_t)rint64(p * 0x1p31f);
+#endif
+}
+
 /* sau/math.h:297-303 */
 SAU_HD uint32_t ranfast32(uint32_t n) {
 	uint32_t s = n * 0x9e3779b9u;
@@ -461,6 +477,20 @@ SAU_HD int64_t pm_offset(bool has_pm, bool has_fpm, float pm, float fpm, float f
 		return rint64(pm * phase_scale);
 	} else if (has_fpm) {
 		return rint64((fpm * f) * (FPM_SCALE * phase_scale));
+	}
+	return 0;
+}
+
+/* The same for the W oscillator, where only the low 32 bits matter
+ * (phase_scale = 2^31). */
+SAU_HD uint32_t pm_offset32(bool has_pm, bool has_fpm, float pm, float fpm, float f) {
+	if (has_pm && has_fpm) {
+		float p = pm + ((fpm * f) * FPM_SCALE);
+		return rint32w_p31(p);
+	} else if (has_pm) {
+		return rint32w_p31(pm);
+	} else if (has_fpm) {
+		return rint32w((fpm * f) * (FPM_SCALE * 0x1p31f));
 	}
 	return 0;
 }

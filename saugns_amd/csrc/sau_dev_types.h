@@ -80,6 +80,12 @@ struct WaveConst {
 
 constexpr uint8_t NO_SLOT = 0xFF;
 constexpr uint8_t SCRATCH_SLOT = 0; /* used inside a step only */
+constexpr uint8_t FSLOT_BASE = 128; /* slot ids from here: frequency blocks */
+
+/* slot id -> index of its memory, for a launch with n_main main-pool slots */
+SAU_HD uint32_t slot_index(uint32_t id, uint32_t n_main) {
+	return id < FSLOT_BASE ? id : n_main + (id - FSLOT_BASE);
+}
 
 enum : uint8_t {
 	ST_LINE = 1, /* out <- line `which` of op (x fmul)               */
@@ -140,8 +146,10 @@ enum : uint32_t {
 
 /* Per-voice result of a segment, read by the mixer. */
 struct VoiceOut {
-	float pan_const;   /* pan.v0 when no pan row is written */
-	uint32_t has_pan;  /* 1: pan matrix row holds per-sample values */
+	float pan_const;    /* pan.v0 when no pan row is written */
+	uint32_t has_pan;   /* 1: pan matrix row holds per-sample values */
+	uint32_t valid_len; /* frames of the row that were written (rest is silence) */
+	uint32_t pan_row;   /* row of the pan matrix when has_pan */
 };
 
 constexpr uint32_t MAX_NEST = 64; /* deepest operator nesting a plan may have */

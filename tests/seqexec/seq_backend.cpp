@@ -65,7 +65,7 @@ struct SeqBackend : public Backend {
 
 	/* one voice, one segment */
 	void run_voice(const VoiceDesc &vd, uint32_t seg_len, std::vector<float> &vrow,
-			std::vector<float> &prow, float &pan_const, uint32_t n_slots) {
+			std::vector<float> &prow, float &pan_const, uint32_t n_slots, uint32_t n_main) {
 		std::vector<DevOp> lo(vd.nops);
 		for (uint32_t i = 0; i < vd.nops; ++i) lo[i] = ops[op_ids[vd.ops_ofs + i]];
 		std::vector<std::vector<float>> slot(n_slots, std::vector<float>(block, 0.f));
@@ -79,7 +79,12 @@ struct SeqBackend : public Backend {
 			uint32_t depth = 0, cur_len = blen;
 			bool ended = false;
 			for (uint32_t si = 0; si < vd.plan_len && !ended; ++si) {
-				const Step st = steps[vd.plan_ofs + si];
+				Step st = steps[vd.plan_ofs + si];
+				{ /* slot ids -> memory indices */
+					uint8_t *f[] = {&st.out, &st.freq, &st.fmul, &st.pm, &st.fpm, &st.amp, &st.sm};
+					for (uint8_t *x : f) if (*x != NO_SLOT) *x = (uint8_t)slot_index(*x, n_main);
+					if (st.kind == ST_OSC && st.tmp != NO_SLOT) st.tmp = (uint8_t)slot_index(st.tmp, n_main);
+				}
 				DevOp &op = lo[st.op];
 				uint32_t parent_len = cur_len;
 				if (st.flags & SF_BEGIN) {
@@ -288,7 +293,7 @@ struct SeqBackend : public Backend {
 		std::vector<float> pan_const(seg.n_voices, 0.f);
 		for (uint32_t v = 0; v < seg.n_voices; ++v) {
 			if (seg.voices[v].pan_dynamic_row != ~0u) pan[v].assign(seg.len, 0.f);
-			run_voice(seg.voices[v], seg.len, vout[v], pan[v], pan_const[v], seg.n_slots);
+			run_voice(seg.voices[v], seg.len, vout[v], pan[v], pan_const[v], seg.n_slots, seg.n_main);
 		}
 		for (uint32_t s = 0; s < seg.n_streams; ++s) {
 			const SegmentDesc::Stream &sd = seg.streams[s];

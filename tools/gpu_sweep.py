@@ -14,8 +14,9 @@ def run(name, prg, frames=44100, steps=8):
     t0 = time.perf_counter()
     for _ in range(steps): b.run(frames, fetch=False)
     b.sync(); dt = time.perf_counter() - t0
-    r, m, n = b.timing()
-    print(f"{name:28s} wall {dt/steps*1e3:7.3f} ms/step  render {r/n:7.3f} ms  mix {m/steps:6.3f} ms  -> {frames*steps/dt:10.3e} frames/s")
+    t = b.timing_ex()
+    n = max(1, t["segments"])
+    print(f"{name:28s} wall {dt/steps*1e3:7.3f} ms/step  fast {t['fast_ms']/n:6.3f}  block {t['block_ms']/n:6.3f}  mix {t['mix_ms']/n:6.3f}  aux {t['aux_ms']/n:6.3f} ms -> {frames*steps/dt:10.3e} frames/s")
 which = sys.argv[1:] or ["c2", "c3", "c3x4"]
 if "c2" in which: run("1024 x 1 op (flat)", vb.config2(n=1024, seconds=30))
 if "c2b" in which: run("4096 x 1 op (flat)", vb.config2(n=4096, seconds=30))
