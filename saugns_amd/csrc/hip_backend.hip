@@ -1109,9 +1109,11 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 		for (uint32_t c = cstart; c < nch; c += wpv) {
 			const int t_base = (int)(c * C) - (int)H; /* segment sample at p = 0 */
 			const bool first_chunk = (c == 0);
+			uint32_t depth = 0;
 			for (uint32_t si = 0; si < vd.plan_len; ++si) {
 				const Step st = uni(plan[si]);
 				const FastOp *op = &fops[st.op];
+				if (st.flags & SF_BEGIN) ++depth;
 				switch (st.kind) {
 				case ST_LINE: {
 					if (st.which == L_FREQ) break; /* single value: FastOp.fc */
@@ -1150,26 +1152,27 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 						const float diff_scale = uni(op->diff_scale);
 						const float diff_offset = uni(op->diff_offset);
 						const uint32_t wave = uni(op->wave);
-						TabRef tab;
-						{
-							const int ti = uni(op->tab);
-							tab.in_lds = ti >= 0;
-							tab.c23 = ti >= 0 ? t23 + (size_t)ti * WAVE_LEN : P.g_c23 + (size_t)wave * WAVE_LEN;
-							tab.c01 = ti >= 0 ? t01 + (size_t)ti * WAVE_LEN : P.g_c01 + (size_t)wave * WAVE_LEN;
-						}
+						const int ti = uni(op->tab);
+						/* keep the two address spaces apart: ds_read for staged tables */
+						const HerpC23 *l23 = t23 + (size_t)(ti >= 0 ? ti : 0) * WAVE_LEN;
+						const HerpC01 *l01 = t01 + (size_t)(ti >= 0 ? ti : 0) * WAVE_LEN;
+						const HerpC23 *g23 = P.g_c23 + (size_t)wave * WAVE_LEN;
+						const HerpC01 *g01 = P.g_c01 + (size_t)wave * WAVE_LEN;
 						const float fc = uni(op->fc);
 						const uint32_t inc = uni(op->inc);
 						const uint32_t phase0 = uni(op->phase0);
 						const bool reset = uni(op->reset) != 0;
 						uint32_t ph[T];
 						double Is[T];
+						/* phase0 + inc*(t+1): one multiply per lane, then adds */
+						uint32_t acc = phase0 + inc * (uint32_t)(t_base + p0);
 #pragma unroll
 						for (int k = 0; k < T; ++k) {
 							const int e = p0 + k;
-							const int t = t_base + e;
 							const uint32_t ofs = pm_offset32(pmS != nullptr, fpmS != nullptr,
 									pmS ? pmS[e] : 0.f, fpmS ? fpmS[e] : 0.f, fc);
-							ph[k] = phase0 + inc * (uint32_t)(t + 1) + ofs;
+							acc += inc;
+							ph[k] = acc + ofs;
 						}
 						if (first_chunk) {
 							/* t = -1: the sample before the segment (wosc.h:215-231 on restart) */
@@ -1183,8 +1186,19 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 								}
 							}
 						}
+						if (ti >= 0) {
 #pragma unroll
-						for (int k = 0; k < T; ++k) Is[k] = herp_lookup(tab, ph[k]);
+							for (int k = 0; k < T; ++k) {
+								const uint32_t ind = ph[k] >> SLEN_BITS;
+								Is[k] = herp_poly(l23[ind], l01[ind], ph[k]);
+							}
+						} else {
+#pragma unroll
+							for (int k = 0; k < T; ++k) {
+								const uint32_t ind = ph[k] >> SLEN_BITS;
+								Is[k] = herp_poly(g23[ind], g01[ind], ph[k]);
+							}
+						}
 						if (first_chunk && !reset) {
 							const double pIs0 = uni(op->prev_Is);
 #pragma unroll
@@ -1193,23 +1207,58 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 						}
 						uint32_t pph = __shfl_up(ph[T - 1], 1);
 						double pIs = __shfl_up(Is[T - 1], 1);
+						/* this operator's values are defined from position p_min on
+						 * (one more lead-in sample per nesting level below it) */
+						const int p_min = (int)H - (int)depth + 1;
 						bool zero = false;
 #pragma unroll
 						for (int k = 0; k < T; ++k) {
 							if (k > 0) { pph = ph[k - 1]; pIs = Is[k - 1]; }
-							const int t = t_base + p0 + k;
 							const int32_t d = (int32_t)(ph[k] - pph);
-							const bool live = (p0 + k >= 1) && t >= 0 && t < (int)fast_total;
-							if (live && d == 0) zero = true;
+							if (d == 0 && p0 + k >= p_min) zero = true;
 							s[k] = wosc_diff(Is[k], pIs, d, diff_scale, diff_offset);
-							if (t == (int)fast_total - 1 && p0 + k >= (int)H) {
-								DevOp &o = P.ops[ids[st.op]];
-								o.st_prev_phase = ph[k];
-								o.st_prev_Is = Is[k];
-								o.st_prev_s = s[k];
+						}
+						if (__any(zero)) {
+							/* dphase == 0: the differentiator holds its previous output
+							 * (wosc.h:251-252). Isolated cases resolve inside the wave; a
+							 * run that reaches back past the lead-in goes to the block loop. */
+							bool held[T], src[T]; /* src: holds a defined output to copy from */
+							bool unresolved = false;
+#pragma unroll
+							for (int k = 0; k < T; ++k) {
+								const uint32_t q = k > 0 ? ph[k - 1] : __shfl_up(ph[T - 1], 1);
+								const int t = t_base + p0 + k;
+								const bool defined = p0 + k >= p_min && t >= 0;
+								held[k] = (ph[k] == q) && defined && t < (int)fast_total;
+								src[k] = defined && !held[k];
+							}
+							for (int it = 0; it < 64; ++it) {
+								const float sp = __shfl_up(s[T - 1], 1);
+								const bool okp = __shfl_up(src[T - 1], 1);
+								bool changed = false;
+								if (held[0] && okp && l > 0) { s[0] = sp; held[0] = false; src[0] = true; changed = true; }
+#pragma unroll
+								for (int k = 1; k < T; ++k)
+									if (held[k] && src[k - 1]) { s[k] = s[k - 1]; held[k] = false; src[k] = true; changed = true; }
+								if (!__any(changed)) break;
+							}
+#pragma unroll
+							for (int k = 0; k < T; ++k) if (held[k]) unresolved = true;
+							if (unresolved) zero_seen = true;
+						}
+						if (t_base + (int)NP > (int)fast_total - 1 && t_base <= (int)fast_total - 1) {
+							/* the chunk that holds the segment's last sample stages the state */
+#pragma unroll
+							for (int k = 0; k < T; ++k) {
+								const int t = t_base + p0 + k;
+								if (t == (int)fast_total - 1 && p0 + k >= (int)H) {
+									DevOp &o = P.ops[ids[st.op]];
+									o.st_prev_phase = ph[k];
+									o.st_prev_Is = Is[k];
+									o.st_prev_s = s[k];
+								}
 							}
 						}
-						if (zero) zero_seen = true;
 					} else if (type == OT_NOISE) {
 						const uint32_t nz = uni(op->wave);
 						const uint32_t n0 = uni(op->noise_n);
@@ -1266,6 +1315,7 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 				}
 				default: break;
 				}
+				if (st.flags & SF_END) --depth;
 			}
 		}
 		if (__any(zero_seen) && l == 0) atomicOr(&P.info[v].bail, 1u);
