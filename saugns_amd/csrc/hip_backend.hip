@@ -1394,10 +1394,12 @@ struct MixParams {
  * the CPU's and independent of scheduling.  Loads are issued eight voices
  * ahead of the (serially dependent) adds. */
 constexpr int MIX_TILE = 256; /* voices whose constants are staged at a time */
+constexpr int MIX_AHEAD = 16; /* loads in flight per thread */
 __global__ void __launch_bounds__(256) mix_kernel(MixParams P) {
 	__shared__ float s_pan[MIX_TILE];
 	__shared__ uint32_t s_valid[MIX_TILE];
 	__shared__ uint32_t s_prow[MIX_TILE]; /* pan row, or ~0u */
+	__shared__ uint32_t s_special;        /* tile has a short row or a pan row */
 	const MixStream ms = P.streams[blockIdx.y];
 	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
 	if (blockIdx.x * 256 >= ms.write_len) return;
@@ -1406,15 +1408,41 @@ __global__ void __launch_bounds__(256) mix_kernel(MixParams P) {
 	for (uint32_t r0 = 0; r0 < ms.n_rows; r0 += MIX_TILE) {
 		const uint32_t nt = min((uint32_t)MIX_TILE, ms.n_rows - r0);
 		__syncthreads();
+		if (threadIdx.x == 0) s_special = 0;
+		__syncthreads();
 		if (threadIdx.x < nt) {
 			const VoiceOut vo = P.vinfo[ms.first_row + r0 + threadIdx.x];
 			s_pan[threadIdx.x] = vo.pan_const;
 			s_valid[threadIdx.x] = vo.valid_len;
 			s_prow[threadIdx.x] = vo.has_pan ? vo.pan_row : ~0u;
+			if (vo.has_pan || vo.valid_len < ms.write_len) s_special = 1;
 		}
 		__syncthreads();
 		if (!act) continue;
 		const float *base = P.vout + (size_t)(ms.first_row + r0) * P.row_stride + i;
+		if (s_special == 0) {
+			/* every row of the tile covers the whole segment with a constant pan */
+			uint32_t r = 0;
+			for (; r + MIX_AHEAD <= nt; r += MIX_AHEAD) {
+				float sv[MIX_AHEAD];
+#pragma unroll
+				for (int u = 0; u < MIX_AHEAD; ++u) sv[u] = base[(size_t)(r + u) * P.row_stride];
+#pragma unroll
+				for (int u = 0; u < MIX_AHEAD; ++u) {
+					const float v = sv[u] * ms.amp_scale;
+					const float s_r = v * s_pan[r + u];
+					L = (L + v) - s_r;
+					R = (R + v) + s_r;
+				}
+			}
+			for (; r < nt; ++r) {
+				const float v = base[(size_t)r * P.row_stride] * ms.amp_scale;
+				const float s_r = v * s_pan[r];
+				L = (L + v) - s_r;
+				R = (R + v) + s_r;
+			}
+			continue;
+		}
 		for (uint32_t r = 0; r < nt; r += 8) {
 			float sv[8], pn[8];
 			bool okv[8];
