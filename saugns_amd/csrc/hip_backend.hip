@@ -978,6 +978,7 @@ struct FastParams {
 	const HerpC01 *g_c01;
 	uint32_t row_stride, n_voices, n_main, max_ops, max_steps, n_tabs, np;
 	uint32_t enable;      /* 0: leave every voice to the block loop */
+	uint32_t ablate;      /* timing experiments only (SAU_AMD_ABLATE): skip parts of the math */
 	int8_t tab_of_wave[12];
 	uint8_t wave_of_tab[12];
 	WaveConst wc[12];
@@ -1034,6 +1035,30 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 	P.fast_done[v] = 0;
 }
 
+/* One step of a voice's plan, decoded once per voice per wave into immediate
+ * form (LDS offsets, constants) so that a chunk touches no operator records:
+ * lazily-constant frequency lines vanish, everything a step needs is 20 dwords. */
+struct FastStep {
+	uint32_t kind;      /* ST_* | flags << 8 | which << 16 | depth << 24 */
+	uint32_t out_off, pm_off, fpm_off, amp_off, aux_off; /* float offsets in the wave's slot area, ~0u = none */
+	uint32_t type;      /* OT_* | wave/noise id << 8 | reset << 16 */
+	uint32_t inc, phase0, prev_phase; /* N: noise_n in phase0, noise_prev in prev_phase */
+	float fc, ac, diff_scale, diff_offset;
+	int32_t tab;        /* index of the staged table, or -1 */
+	uint32_t gop;       /* global operator index (state staging) */
+	double prev_Is;
+	float pan;
+	uint32_t pad;
+};
+static_assert(sizeof(FastStep) == 80, "FastStep is 20 dwords");
+
+__device__ __forceinline__ FastStep uni(const FastStep &f) {
+	union { FastStep s; uint32_t u[20]; } c; c.s = f;
+#pragma unroll
+	for (int i = 0; i < 20; ++i) c.u[i] = uni(c.u[i]);
+	return c.s;
+}
+
 template <int T>
 __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 	constexpr int NP = 64 * T;
@@ -1047,11 +1072,9 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 	HerpC23 *t23 = (HerpC23 *)lds;
 	HerpC01 *t01 = (HerpC01 *)(lds + (size_t)P.n_tabs * WAVE_LEN * sizeof(HerpC23));
 	unsigned char *areas = lds + (size_t)P.n_tabs * WAVE_LEN * (sizeof(HerpC23) + sizeof(HerpC01));
-	const size_t area_bytes = (size_t)P.max_ops * sizeof(FastOp) + (size_t)P.max_steps * sizeof(Step) +
-		(size_t)P.n_main * NP * sizeof(float);
-	FastOp *fops = (FastOp *)(areas + (size_t)w * area_bytes);
-	Step *plan = (Step *)(fops + P.max_ops);
-	float *slots = (float *)(plan + P.max_steps);
+	const size_t area_bytes = (size_t)P.max_steps * sizeof(FastStep) + (size_t)P.n_main * NP * sizeof(float);
+	FastStep *fsteps = (FastStep *)(areas + (size_t)w * area_bytes);
+	float *slots = (float *)(fsteps + P.max_steps);
 
 	for (uint32_t t = 0; t < P.n_tabs; ++t) {
 		const uint32_t wave = P.wave_of_tab[t];
@@ -1067,9 +1090,9 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 	const uint32_t g = blockIdx.x * W + (uint32_t)w;
 	const uint32_t total_waves = gridDim.x * W;
 	const uint32_t NV = P.n_voices;
-	uint32_t wpv = total_waves >= NV ? total_waves / NV : 1; /* waves per voice */
+	const uint32_t wpv = total_waves >= NV ? total_waves / NV : 1; /* waves per voice */
 	uint32_t v = total_waves >= NV ? g / wpv : g;
-	const uint32_t vstride = total_waves >= NV ? NV /* one voice per wave */ : total_waves;
+	const uint32_t vstride = total_waves >= NV ? NV : total_waves;
 	const uint32_t cstart = total_waves >= NV ? g % wpv : 0;
 
 	for (; v < NV; v += vstride) {
@@ -1079,120 +1102,116 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 		const VoiceDesc vd = P.voices[v];
 		const uint32_t *ids = P.op_ids + vd.ops_ofs;
 		const uint32_t H = uni(fi.H);
-		/* per-wave copies: operator constants and the plan */
-		if ((uint32_t)l < vd.nops) {
-			const DevOp &o = P.ops[ids[l]];
-			FastOp f;
-			f.type = o.type; f.wave = o.wave; f.reset = (o.flags & OPF_OSC_RESET) ? 1u : 0u;
-			f.fc = o.rt_fconst;
-			f.inc = rint32w(o.coeff * o.rt_fconst);
-			f.ac = o.line[L_AMP].v0;
-			f.pan = o.line[L_PAN].v0;
-			const uint32_t wv = o.type == OT_WAVE ? (o.wave < 12 ? o.wave : 0) : 0;
-			f.diff_scale = P.wc[wv].diff_scale;
-			f.diff_offset = P.wc[wv].diff_offset;
-			f.tab = P.tab_of_wave[wv];
-			f.phase0 = o.phase; f.prev_phase = o.prev_phase; f.prev_Is = o.prev_Is;
-			f.noise_n = o.noise_n; f.noise_prev = o.noise_prev;
-			fops[l] = f;
-		}
+
+		/* ---- decode the plan: lane si handles step si (plan_len <= 64) ---- */
+		uint32_t n_fsteps;
 		{
-			const u32_alias *src = (const u32_alias *)(P.steps + vd.plan_ofs);
-			for (uint32_t i = l; i < vd.plan_len * 4; i += 64) ((u32_alias *)plan)[i] = src[i];
+			bool keep = false;
+			FastStep f;
+			uint32_t dep = 0;
+			if ((uint32_t)l < vd.plan_len) {
+				const Step *plan = P.steps + vd.plan_ofs;
+				/* nesting depth of this step = BEGINs up to and including it minus ENDs before it */
+				for (uint32_t q = 0; q <= (uint32_t)l; ++q) {
+					const Step sq = plan[q];
+					if (sq.flags & SF_BEGIN) ++dep;
+					if (q < (uint32_t)l && (sq.flags & SF_END)) --dep;
+				}
+				const Step st = plan[l];
+				const DevOp &o = P.ops[ids[st.op]];
+				keep = !(st.kind == ST_LINE && st.which == L_FREQ);
+				f.kind = (uint32_t)st.kind | ((uint32_t)st.flags << 8) | ((uint32_t)st.which << 16) | (dep << 24);
+				f.out_off = st.out != NO_SLOT ? (uint32_t)st.out * NP : ~0u;
+				f.pm_off = st.pm != NO_SLOT ? (uint32_t)st.pm * NP : ~0u;
+				f.fpm_off = st.fpm != NO_SLOT ? (uint32_t)st.fpm * NP : ~0u;
+				f.amp_off = st.amp != NO_SLOT ? (uint32_t)st.amp * NP : ~0u;
+				f.aux_off = (st.kind == ST_LERP && st.freq != NO_SLOT) ? (uint32_t)st.freq * NP : ~0u;
+				const uint32_t wv = o.type == OT_WAVE ? (o.wave < 12 ? o.wave : 0) : o.wave;
+				f.type = o.type | (wv << 8) | ((o.flags & OPF_OSC_RESET) ? 1u << 16 : 0u);
+				f.fc = o.rt_fconst;
+				f.inc = rint32w(o.coeff * o.rt_fconst);
+				f.phase0 = o.type == OT_NOISE ? o.noise_n : o.phase;
+				f.prev_phase = o.type == OT_NOISE ? o.noise_prev : o.prev_phase;
+				f.ac = (st.kind == ST_LINE) ? o.line[st.which].v0 : o.line[L_AMP].v0;
+				f.diff_scale = o.type == OT_WAVE ? P.wc[wv].diff_scale : 0.f;
+				f.diff_offset = o.type == OT_WAVE ? P.wc[wv].diff_offset : 0.f;
+				f.tab = o.type == OT_WAVE ? P.tab_of_wave[wv] : -1;
+				f.gop = ids[st.op];
+				f.prev_Is = o.prev_Is;
+				f.pan = o.line[L_PAN].v0;
+				f.pad = 0;
+			}
+			const unsigned long long m = __ballot(keep);
+			if (keep) fsteps[__popcll(m & ((1ull << l) - 1ull))] = f;
+			n_fsteps = (uint32_t)__popcll(m);
 		}
 		float *vrow = P.vout + (size_t)vd.out_row * P.row_stride;
 		float *prow = (vd.pan_dynamic_row != ~0u) ? P.pan + (size_t)vd.pan_dynamic_row * P.row_stride : nullptr;
 		const uint32_t C = (uint32_t)NP - H;
 		const uint32_t nch = (fast_total + C - 1) / C;
-		bool zero_seen = false;
+		uint32_t zero_acc = 0; /* nonzero: some hold-previous run could not be resolved here */
 
 		for (uint32_t c = cstart; c < nch; c += wpv) {
 			const int t_base = (int)(c * C) - (int)H; /* segment sample at p = 0 */
 			const bool first_chunk = (c == 0);
-			uint32_t depth = 0;
-			for (uint32_t si = 0; si < vd.plan_len; ++si) {
-				const Step st = uni(plan[si]);
-				const FastOp *op = &fops[st.op];
-				if (st.flags & SF_BEGIN) ++depth;
-				switch (st.kind) {
-				case ST_LINE: {
-					if (st.which == L_FREQ) break; /* single value: FastOp.fc */
-					/* held line: v0 (sau/line.c:435-442); ratio lines only exist for freq */
-					float *out = slots + (size_t)st.out * NP;
-					const DevOp &o = P.ops[ids[st.op]];
-					const float v0 = uni(o.line[st.which].v0);
-#pragma unroll
-					for (int k = 0; k < T; ++k) out[p0 + k] = v0;
-					break;
-				}
-				case ST_LERP: { /* generator.c:466-467 */
-					float *par = slots + (size_t)st.out * NP;
-					const float *rpar = slots + (size_t)st.freq * NP;
-					const float *mod = slots + (size_t)st.pm * NP;
-#pragma unroll
-					for (int k = 0; k < T; ++k) {
-						const int e = p0 + k;
-						float pv = par[e];
-						pv += (rpar[e] - pv) * mod[e];
-						par[e] = pv;
-					}
-					break;
-				}
-				case ST_OSC: {
-					float *out = slots + (size_t)st.out * NP;
-					const float *pmS = st.pm != NO_SLOT ? slots + (size_t)st.pm * NP : nullptr;
-					const float *fpmS = st.fpm != NO_SLOT ? slots + (size_t)st.fpm * NP : nullptr;
-					const float *ampS = st.amp != NO_SLOT ? slots + (size_t)st.amp * NP : nullptr;
-					const uint32_t type = uni(op->type);
-					const bool wave_env = (st.flags & SF_WAVE_ENV) != 0;
-					const bool layer = (st.flags & SF_LAYER) != 0;
-					const float ac = uni(op->ac);
+			const bool last_chunk = t_base + (int)NP > (int)fast_total - 1 && t_base <= (int)fast_total - 1;
+			for (uint32_t si = 0; si < n_fsteps; ++si) {
+				const FastStep f = uni(fsteps[si]);
+				const uint32_t kind = f.kind & 0xff;
+				const uint32_t flags = (f.kind >> 8) & 0xff;
+				if (kind == ST_OSC) {
+					const uint32_t type = f.type & 0xff;
+					const bool wave_env = (flags & SF_WAVE_ENV) != 0;
+					const bool layer = (flags & SF_LAYER) != 0;
+					const bool to_voice = ((f.kind >> 16) & OX_VOICE) != 0;
 					float s[T];
 					if (type == OT_WAVE) {
-						const float diff_scale = uni(op->diff_scale);
-						const float diff_offset = uni(op->diff_offset);
-						const uint32_t wave = uni(op->wave);
-						const int ti = uni(op->tab);
-						/* keep the two address spaces apart: ds_read for staged tables */
-						const HerpC23 *l23 = t23 + (size_t)(ti >= 0 ? ti : 0) * WAVE_LEN;
-						const HerpC01 *l01 = t01 + (size_t)(ti >= 0 ? ti : 0) * WAVE_LEN;
-						const HerpC23 *g23 = P.g_c23 + (size_t)wave * WAVE_LEN;
-						const HerpC01 *g01 = P.g_c01 + (size_t)wave * WAVE_LEN;
-						const float fc = uni(op->fc);
-						const uint32_t inc = uni(op->inc);
-						const uint32_t phase0 = uni(op->phase0);
-						const bool reset = uni(op->reset) != 0;
+						const bool has_pm = f.pm_off != ~0u, has_fpm = f.fpm_off != ~0u;
 						uint32_t ph[T];
 						double Is[T];
 						/* phase0 + inc*(t+1): one multiply per lane, then adds */
-						uint32_t acc = phase0 + inc * (uint32_t)(t_base + p0);
+						uint32_t acc = f.phase0 + f.inc * (uint32_t)(t_base + p0);
+						if (has_pm && !has_fpm) {
 #pragma unroll
-						for (int k = 0; k < T; ++k) {
-							const int e = p0 + k;
-							const uint32_t ofs = pm_offset32(pmS != nullptr, fpmS != nullptr,
-									pmS ? pmS[e] : 0.f, fpmS ? fpmS[e] : 0.f, fc);
-							acc += inc;
-							ph[k] = acc + ofs;
+							for (int k = 0; k < T; ++k) {
+								acc += f.inc;
+								ph[k] = acc + rint32w_p31(slots[f.pm_off + p0 + k]);
+							}
+						} else if (!has_pm && !has_fpm) {
+#pragma unroll
+							for (int k = 0; k < T; ++k) { acc += f.inc; ph[k] = acc; }
+						} else {
+#pragma unroll
+							for (int k = 0; k < T; ++k) {
+								acc += f.inc;
+								ph[k] = acc + pm_offset32(has_pm, has_fpm, has_pm ? slots[f.pm_off + p0 + k] : 0.f,
+										has_fpm ? slots[f.fpm_off + p0 + k] : 0.f, f.fc);
+							}
 						}
+						const bool reset = (f.type >> 16) & 1;
 						if (first_chunk) {
 							/* t = -1: the sample before the segment (wosc.h:215-231 on restart) */
 							const uint32_t next0 = __shfl_down(ph[0], 1);
-							const uint32_t pprev = uni(op->prev_phase);
 #pragma unroll
 							for (int k = 0; k < T; ++k) {
 								if (p0 + k == (int)H - 1) {
 									const uint32_t nxt = (k < T - 1) ? ph[(k + 1) % T] : next0;
-									ph[k] = reset ? nxt - SLEN : pprev;
+									ph[k] = reset ? nxt - SLEN : f.prev_phase;
 								}
 							}
 						}
-						if (ti >= 0) {
+						if (f.tab >= 0) {
+							const HerpC23 *l23 = t23 + (size_t)f.tab * WAVE_LEN;
+							const HerpC01 *l01 = t01 + (size_t)f.tab * WAVE_LEN;
 #pragma unroll
 							for (int k = 0; k < T; ++k) {
 								const uint32_t ind = ph[k] >> SLEN_BITS;
 								Is[k] = herp_poly(l23[ind], l01[ind], ph[k]);
 							}
 						} else {
+							const uint32_t wave = (f.type >> 8) & 0xff;
+							const HerpC23 *g23 = P.g_c23 + (size_t)wave * WAVE_LEN;
+							const HerpC01 *g01 = P.g_c01 + (size_t)wave * WAVE_LEN;
 #pragma unroll
 							for (int k = 0; k < T; ++k) {
 								const uint32_t ind = ph[k] >> SLEN_BITS;
@@ -1200,30 +1219,28 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 							}
 						}
 						if (first_chunk && !reset) {
-							const double pIs0 = uni(op->prev_Is);
 #pragma unroll
 							for (int k = 0; k < T; ++k)
-								if (p0 + k == (int)H - 1) Is[k] = pIs0;
+								if (p0 + k == (int)H - 1) Is[k] = f.prev_Is;
 						}
 						uint32_t pph = __shfl_up(ph[T - 1], 1);
 						double pIs = __shfl_up(Is[T - 1], 1);
 						/* this operator's values are defined from position p_min on
 						 * (one more lead-in sample per nesting level below it) */
-						const int p_min = (int)H - (int)depth + 1;
-						bool zero = false;
+						const int p_min = (int)H - (int)(f.kind >> 24) + 1;
+						uint32_t zero = 0;
 #pragma unroll
 						for (int k = 0; k < T; ++k) {
 							if (k > 0) { pph = ph[k - 1]; pIs = Is[k - 1]; }
 							const int32_t d = (int32_t)(ph[k] - pph);
-							if (d == 0 && p0 + k >= p_min) zero = true;
-							s[k] = wosc_diff(Is[k], pIs, d, diff_scale, diff_offset);
+							zero |= (uint32_t)(d == 0 && p0 + k >= p_min);
+							s[k] = wosc_diff(Is[k], pIs, d, f.diff_scale, f.diff_offset);
 						}
 						if (__any(zero)) {
 							/* dphase == 0: the differentiator holds its previous output
 							 * (wosc.h:251-252). Isolated cases resolve inside the wave; a
 							 * run that reaches back past the lead-in goes to the block loop. */
 							bool held[T], src[T]; /* src: holds a defined output to copy from */
-							bool unresolved = false;
 #pragma unroll
 							for (int k = 0; k < T; ++k) {
 								const uint32_t q = k > 0 ? ph[k - 1] : __shfl_up(ph[T - 1], 1);
@@ -1243,16 +1260,15 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 								if (!__any(changed)) break;
 							}
 #pragma unroll
-							for (int k = 0; k < T; ++k) if (held[k]) unresolved = true;
-							if (unresolved) zero_seen = true;
+							for (int k = 0; k < T; ++k) zero_acc |= (uint32_t)held[k];
 						}
-						if (t_base + (int)NP > (int)fast_total - 1 && t_base <= (int)fast_total - 1) {
+						if (last_chunk) {
 							/* the chunk that holds the segment's last sample stages the state */
 #pragma unroll
 							for (int k = 0; k < T; ++k) {
 								const int t = t_base + p0 + k;
 								if (t == (int)fast_total - 1 && p0 + k >= (int)H) {
-									DevOp &o = P.ops[ids[st.op]];
+									DevOp &o = P.ops[f.gop];
 									o.st_prev_phase = ph[k];
 									o.st_prev_Is = Is[k];
 									o.st_prev_s = s[k];
@@ -1260,9 +1276,8 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 							}
 						}
 					} else if (type == OT_NOISE) {
-						const uint32_t nz = uni(op->wave);
-						const uint32_t n0 = uni(op->noise_n);
-						const uint32_t nprev = uni(op->noise_prev);
+						const uint32_t nz = (f.type >> 8) & 0xff;
+						const uint32_t n0 = f.phase0, nprev = f.prev_phase;
 #pragma unroll
 						for (int k = 0; k < T; ++k) {
 							const int t = t_base + p0 + k;
@@ -1283,42 +1298,60 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 #pragma unroll
 						for (int k = 0; k < T; ++k) s[k] = 1.f;
 					}
-					const bool to_voice = (st.which & OX_VOICE) != 0;
+					/* amplitude and combine: generator.c:384-440 */
+					float a[T];
+					if (f.amp_off != ~0u) {
+#pragma unroll
+						for (int k = 0; k < T; ++k) a[k] = slots[f.amp_off + p0 + k];
+					} else {
+#pragma unroll
+						for (int k = 0; k < T; ++k) a[k] = f.ac;
+					}
+					float r[T];
+					if (layer || wave_env) {
+#pragma unroll
+						for (int k = 0; k < T; ++k)
+							r[k] = mix_combine(layer ? slots[f.out_off + p0 + k] : 0.f, s[k], a[k], wave_env, layer);
+					} else {
+#pragma unroll
+						for (int k = 0; k < T; ++k) r[k] = s[k] * a[k];
+					}
+					if (to_voice) {
+#pragma unroll
+						for (int k = 0; k < T; ++k) {
+							const int t = t_base + p0 + k;
+							if (p0 + k >= (int)H && t < (int)fast_total) vrow[t] = r[k];
+						}
+					} else {
+#pragma unroll
+						for (int k = 0; k < T; ++k) slots[f.out_off + p0 + k] = r[k];
+					}
+				} else if (kind == ST_LINE) {
+					/* held line: v0 (sau/line.c:435-442); ratio lines only exist for freq */
+#pragma unroll
+					for (int k = 0; k < T; ++k) slots[f.out_off + p0 + k] = f.ac;
+				} else if (kind == ST_LERP) { /* generator.c:466-467 */
 #pragma unroll
 					for (int k = 0; k < T; ++k) {
 						const int e = p0 + k;
-						const int t = t_base + e;
-						const float a = ampS ? ampS[e] : ac;
-						const float r = mix_combine(layer ? out[e] : 0.f, s[k], a, wave_env, layer);
-						if (to_voice) {
-							if (e >= (int)H && t < (int)fast_total) vrow[t] = r;
-						} else {
-							out[e] = r;
-						}
+						float pv = slots[f.out_off + e];
+						pv += (slots[f.aux_off + e] - pv) * slots[f.pm_off + e];
+						slots[f.out_off + e] = pv;
 					}
-					break;
-				}
-				case ST_VOICE: { /* generator.c:749-788 with pan modulators; summed by mix_kernel */
-					const float *src = slots + (size_t)st.out * NP;
-					const float *panS = st.pm != NO_SLOT ? slots + (size_t)st.pm * NP : nullptr;
-					const float pv = uni(op->pan);
+				} else if (kind == ST_VOICE) { /* generator.c:749-788 with pan modulators */
 #pragma unroll
 					for (int k = 0; k < T; ++k) {
 						const int e = p0 + k;
 						const int t = t_base + e;
 						if (e >= (int)H && t < (int)fast_total) {
-							vrow[t] = src[e];
-							if (prow) prow[t] = panS ? panS[e] : pv;
+							vrow[t] = slots[f.out_off + e];
+							if (prow) prow[t] = f.pm_off != ~0u ? slots[f.pm_off + e] : f.pan;
 						}
 					}
-					break;
 				}
-				default: break;
-				}
-				if (st.flags & SF_END) --depth;
 			}
 		}
-		if (__any(zero_seen) && l == 0) atomicOr(&P.info[v].bail, 1u);
+		if (__any(zero_acc) && l == 0) atomicOr(&P.info[v].bail, 1u);
 	}
 }
 
@@ -1715,8 +1748,8 @@ public:
 		{
 			constexpr uint32_t FT = 4, FNP = 64 * FT;
 			const uint32_t fmax_ops = seg.max_ops < 64 ? seg.max_ops : 64;
-			const size_t area = (size_t)fmax_ops * sizeof(FastOp) + (size_t)seg.max_steps * sizeof(Step) +
-				(size_t)seg.n_main * FNP * sizeof(float);
+			const uint32_t fmax_steps = seg.max_steps < 64 ? seg.max_steps : 64;
+			const size_t area = (size_t)fmax_steps * sizeof(FastStep) + (size_t)seg.n_main * FNP * sizeof(float);
 			const bool use_fast = fast_enabled_ && (16 * area + 1024 <= lds_limit_);
 			if (!finfo_.ensure(seg.n_voices, err) || !fdone_.ensure(seg.n_voices, err) ||
 			    !worklist_.ensure(seg.n_voices, err) || !work_count_.ensure(4, err)) return false;
@@ -1728,8 +1761,9 @@ public:
 			fp.worklist = worklist_.p; fp.work_count = work_count_.p; fp.vinfo = vinfo_.p;
 			fp.g_c23 = c23_.p; fp.g_c01 = c01_.p;
 			fp.row_stride = row_stride_; fp.n_voices = seg.n_voices; fp.n_main = seg.n_main;
-			fp.max_ops = fmax_ops; fp.max_steps = seg.max_steps; fp.np = FNP;
+			fp.max_ops = fmax_ops; fp.max_steps = fmax_steps; fp.np = FNP;
 			fp.enable = use_fast ? 1u : 0u;
+			fp.ablate = getenv("SAU_AMD_ABLATE") ? (uint32_t)atoi(getenv("SAU_AMD_ABLATE")) : 0u;
 			memcpy(fp.wc, wconst_, sizeof wconst_);
 			uint32_t ft = 0;
 			for (int wv = 0; wv < 12; ++wv) {

@@ -458,10 +458,29 @@ SAU_HD double herp_poly(const HerpC23 &hi, const HerpC01 &lo, uint32_t phase) {
 	return ((hi.c3 * x + hi.c2) * x + (double)lo.c1) * x + (double)lo.c0;
 }
 
+/* Correctly rounded a/b for operands well inside the normal range (here
+ * a ~ 1e8..1e9 and 1 <= |b| <= 2^31): the reciprocal-refinement sequence the
+ * compiler itself emits for IEEE division, without the range scaling and the
+ * special-case fix-up that these operands never need. */
+SAU_HD float div_f32_normal(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	float r = __builtin_amdgcn_rcpf(b);
+	float e = fmaf(-b, r, 1.0f);
+	r = fmaf(e, r, r);
+	float q = a * r;
+	float rem = fmaf(-b, q, a);
+	q = fmaf(rem, r, q);
+	rem = fmaf(-b, q, a);
+	return fmaf(rem, r, q);
+#else
+	return a / b;
+#endif
+}
+
 /* wosc.h:250-256: one differentiated output sample */
 SAU_HD float wosc_diff(double Is, double prev_Is, int32_t phase_diff,
 		float diff_scale, float diff_offset) {
-	double x = (double)(diff_scale / (float)phase_diff);
+	double x = (double)div_f32_normal(diff_scale, (float)phase_diff);
 	return (float)((Is - prev_Is) * x + (double)diff_offset);
 }
 
