@@ -78,6 +78,10 @@ SAU_AMD_API void sauAmd_Batch_timing(sauAmdBatch *b, double *render_ms, double *
 SAU_AMD_API void sauAmd_Batch_timing_ex(sauAmdBatch *b, double *out4, uint64_t *segments,
 		int reset);
 
+/* HIP-event timing: 0 off, 1 only the dominant (time-parallel) kernel,
+ * 2 every kernel. The query functions above switch level 2 on when still off. */
+SAU_AMD_API void sauAmd_Batch_set_timing(sauAmdBatch *b, int level);
+
 /* The stream the batch launches its kernels on, as a hipStream_t. */
 SAU_AMD_API void *sauAmd_Batch_stream(sauAmdBatch *b);
 

@@ -107,6 +107,7 @@ def lib():
     L.sauAmd_Batch_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                       C.POINTER(C.c_uint64), C.c_int]
     L.sauAmd_Batch_timing_ex.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
+    L.sauAmd_Batch_set_timing.argtypes = [C.c_void_p, C.c_int]
     L.sauAmd_Batch_stream.restype = C.c_void_p
     L.sauAmd_Batch_stream.argtypes = [C.c_void_p]
     L.sauAmd_set_piluts.argtypes = [C.c_void_p]
@@ -265,6 +266,9 @@ class Batch:
         r, m, n = C.c_double(), C.c_double(), C.c_uint64()
         lib().sauAmd_Batch_timing(self._b, C.byref(r), C.byref(m), C.byref(n), int(reset))
         return r.value, m.value, n.value
+
+    def set_timing(self, level):
+        lib().sauAmd_Batch_set_timing(self._b, int(level))
 
     def timing_ex(self, reset=False):
         """-> dict of accumulated kernel times (ms) and the number of segments."""

@@ -138,6 +138,10 @@ extern "C" void sauAmd_Batch_timing_ex(sauAmdBatch *b, double *out4, uint64_t *s
 	if (b->hip) b->hip->timing_ex(out4, segments, reset != 0);
 }
 
+extern "C" void sauAmd_Batch_set_timing(sauAmdBatch *b, int level) {
+	if (b->hip) b->hip->set_timing(level);
+}
+
 extern "C" void *sauAmd_Batch_stream(sauAmdBatch *b) {
 	return b->hip ? b->hip->stream_handle() : nullptr;
 }

@@ -11,6 +11,8 @@ class HipBackend : public sauengine::Backend {
 public:
 	virtual void timing(double *render_ms, double *mix_ms, uint64_t *launches, bool reset) = 0;
 	virtual void *stream_handle() = 0;
+	/* 0 off, 1 time-parallel kernel only, 2 every kernel */
+	virtual void set_timing(int level) = 0;
 	virtual void timing_ex(double *out4, uint64_t *segments, bool reset) = 0;
 };
 

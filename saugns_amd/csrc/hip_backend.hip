@@ -1679,6 +1679,7 @@ public:
 
 	bool render(const SegmentDesc &seg, std::string &err) override {
 		if (!seg.n_voices) return true;
+		++acc_launches_; /* segments rendered */
 		const uint32_t W = geo_ ? 4 : 8, T = geo_ ? 4 : 2;
 		const size_t slot_bytes = (size_t)W * 64 * T * sizeof(float);
 		/* LDS budget: slots + operator cache + misc, rest for tables */
@@ -1855,6 +1856,7 @@ public:
 	}
 
 	void *stream_handle() override { return (void *)stream_; }
+	void set_timing(int level) override { timing_on_ = level > 0; timing_level_ = level; }
 
 	void timing_ex(double *out4, uint64_t *segments, bool reset) override {
 		if (!timing_on_) timing_on_ = true;
@@ -1910,6 +1912,7 @@ private:
 	/* kind: 0 block-loop kernel, 1 mixer, 2 time-parallel kernel, 3 analyze/finalize */
 	struct TimedPair { hipEvent_t a, b; int kind; bool used; };
 	TimedPair *new_pair(int kind) {
+		if (timing_level_ == 1 && kind != 2) return nullptr; /* level 1: dominant kernel only */
 		if (n_used_ == events_.size()) {
 			if (events_.size() >= 4096) { (void)hipStreamSynchronize(stream_); drain_pairs(); }
 			else {
@@ -1927,7 +1930,6 @@ private:
 			float ms = 0;
 			if (hipEventElapsedTime(&ms, events_[i].a, events_[i].b) == hipSuccess) {
 				acc_ms_[events_[i].kind & 3] += ms;
-				if (events_[i].kind == 0) ++acc_launches_;
 			}
 		}
 		n_used_ = 0;
@@ -1964,6 +1966,7 @@ private:
 	double acc_ms_[4] = {0, 0, 0, 0};
 	uint64_t acc_launches_ = 0;
 	bool fast_enabled_ = true;
+	int timing_level_ = 2;
 	DevBuf<FastInfo> finfo_;
 	DevBuf<uint32_t> fdone_, worklist_, work_count_;
 	uint32_t block_grid_ = 1;

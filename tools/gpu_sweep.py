@@ -11,6 +11,7 @@ def run(name, prg, frames=44100, steps=8):
     b = sa.Batch([prg], 44100)
     for _ in range(2): b.run(frames, fetch=False)
     b.sync(); b.timing(reset=True)
+    lvl = int(os.environ.get("TLEVEL", "2")); b.set_timing(lvl)
     t0 = time.perf_counter()
     for _ in range(steps): b.run(frames, fetch=False)
     b.sync(); dt = time.perf_counter() - t0
