@@ -107,6 +107,17 @@ def main():
         alg_bytes = (n_ops * 8 + 2) * args.frames
         launch_s = (tm["fast_ms"] / 1e3) / max(1, tm["segments"])
         achieved = alg_bytes / launch_s / 1e9 if launch_s > 0 else 0.0
+        # HBM bytes per launch of the same kernel on the same workload, from the committed
+        # PMC passes (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); counters
+        # cannot be collected from inside this process, so null when the workload differs
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_b_pmc_summary.json")))
+            wl = pmc["workload"]
+            if wl["voices"] == args.voices and wl["frames_per_step"] == args.frames:
+                traffic = pmc["kernels"]["sauhip::fast_kernel<4>"]["hbm_bytes_per_launch_corrected"]
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "mono samples/sec/GPU @ N voices (depth-3 FM)",
             "value": value, "unit": "mixed mono int16 frames/s",
@@ -122,7 +133,7 @@ def main():
                        "voice_samples_per_s": value * args.voices,
                        "operator_samples_per_s": value * n_ops},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None,
+                         "frac": achieved / 8000.0, "traffic": traffic,
                          "kernel": "fast_kernel<4>", "avg_launch_ms": launch_s * 1e3,
                          "launches": tm["segments"],
                          "algorithmic_bytes_per_launch": alg_bytes},
