@@ -950,18 +950,10 @@ struct FastInfo {
 	uint32_t total; /* frames this path renders (0: not eligible) */
 	uint32_t H;     /* lead-in samples per chunk */
 	uint32_t bail;  /* set when a chunk met dphase == 0 (hold-previous run) */
-	uint32_t pad;
+	uint32_t n_fsteps; /* decoded steps of the voice (decode_kernel) */
 };
 
-struct FastOp { /* per-wave LDS copy of what a chunk needs from one operator */
-	uint32_t type, wave, reset, inc;
-	float fc, ac, pan, diff_scale;
-	float diff_offset; int32_t tab; uint32_t phase0, prev_phase;
-	double prev_Is;
-	uint32_t noise_n, noise_prev;
-};
-static_assert(sizeof(FastOp) == 64, "FastOp is 16 dwords");
-
+struct FastStep;
 struct FastParams {
 	const VoiceDesc *voices;
 	const Step *steps;
@@ -976,9 +968,9 @@ struct FastParams {
 	VoiceOut *vinfo;
 	const HerpC23 *g_c23;
 	const HerpC01 *g_c01;
+	FastStep *fsteps;     /* [n_voices][max_steps], written by decode_kernel */
 	uint32_t row_stride, n_voices, n_main, max_ops, max_steps, n_tabs, np;
 	uint32_t enable;      /* 0: leave every voice to the block loop */
-	uint32_t ablate;      /* timing experiments only (SAU_AMD_ABLATE): skip parts of the math */
 	int8_t tab_of_wave[12];
 	uint8_t wave_of_tab[12];
 	WaveConst wc[12];
@@ -1027,7 +1019,7 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 		if (st.flags & SF_END) --depth;
 	}
 	FastInfo fi;
-	fi.H = maxd; fi.bail = 0; fi.pad = 0;
+	fi.H = maxd; fi.bail = 0; fi.n_fsteps = 0;
 	fi.total = 0;
 	if (!bad && vd.nops <= P.max_ops && vd.plan_len <= P.max_steps && maxd >= 1 && maxd <= P.np / 2)
 		fi.total = min(min_time, vd.run_len);
@@ -1059,22 +1051,101 @@ __device__ __forceinline__ FastStep uni(const FastStep &f) {
 	return c.s;
 }
 
+/* One step of a voice's plan in immediate form (LDS offsets, constants), so
+ * that a row touches no operator records: lazily-constant frequency lines
+ * vanish, everything a step needs is 20 dwords in scalar registers. */
+__global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
+	constexpr int NP = 64 * 4; /* fast_kernel<4> slot size */
+	const uint32_t v = blockIdx.x;
+	const int l = threadIdx.x;
+	if (P.info[v].total == 0) return;
+	const VoiceDesc vd = P.voices[v];
+	const uint32_t *ids = P.op_ids + vd.ops_ofs;
+	FastStep *fsteps = P.fsteps + (size_t)v * P.max_steps;
+	/* lane si handles step si (plan_len <= 64) */
+	bool keep = false;
+	FastStep f;
+	uint32_t dep = 0;
+	if ((uint32_t)l < vd.plan_len) {
+		const Step *plan = P.steps + vd.plan_ofs;
+		/* nesting depth of this step = BEGINs up to and including it minus ENDs before it */
+		for (uint32_t q = 0; q <= (uint32_t)l; ++q) {
+			const Step sq = plan[q];
+			if (sq.flags & SF_BEGIN) ++dep;
+			if (q < (uint32_t)l && (sq.flags & SF_END)) --dep;
+		}
+		const Step st = plan[l];
+		const DevOp &o = P.ops[ids[st.op]];
+		keep = !(st.kind == ST_LINE && st.which == L_FREQ);
+		f.kind = (uint32_t)st.kind | ((uint32_t)st.flags << 8) | ((uint32_t)st.which << 16) | (dep << 24);
+		f.out_off = st.out != NO_SLOT ? (uint32_t)st.out * NP : ~0u;
+		f.pm_off = st.pm != NO_SLOT ? (uint32_t)st.pm * NP : ~0u;
+		f.fpm_off = st.fpm != NO_SLOT ? (uint32_t)st.fpm * NP : ~0u;
+		f.amp_off = st.amp != NO_SLOT ? (uint32_t)st.amp * NP : ~0u;
+		f.aux_off = (st.kind == ST_LERP && st.freq != NO_SLOT) ? (uint32_t)st.freq * NP : ~0u;
+		const uint32_t wv = o.type == OT_WAVE ? (o.wave < 12 ? o.wave : 0) : o.wave;
+		f.type = o.type | (wv << 8) | ((o.flags & OPF_OSC_RESET) ? 1u << 16 : 0u);
+		f.fc = o.rt_fconst;
+		f.inc = rint32w(o.coeff * o.rt_fconst);
+		f.phase0 = o.type == OT_NOISE ? o.noise_n : o.phase;
+		f.prev_phase = o.type == OT_NOISE ? o.noise_prev : o.prev_phase;
+		f.ac = (st.kind == ST_LINE) ? o.line[st.which].v0 : o.line[L_AMP].v0;
+		f.diff_scale = o.type == OT_WAVE ? P.wc[wv].diff_scale : 0.f;
+		f.diff_offset = o.type == OT_WAVE ? P.wc[wv].diff_offset : 0.f;
+		f.tab = o.type == OT_WAVE ? P.tab_of_wave[wv] : -1;
+		f.gop = ids[st.op];
+		f.prev_Is = o.prev_Is;
+		f.pan = o.line[L_PAN].v0;
+		f.pad = 0;
+	}
+	const unsigned long long m = __ballot(keep);
+	if (keep) fsteps[__popcll(m & ((1ull << l) - 1ull))] = f;
+	if (l == 0) P.info[v].n_fsteps = (uint32_t)__popcll(m);
+}
+
+/* lane l receives lane l-1's value (lane 0: zero; it is lead-in) */
+__device__ __forceinline__ uint32_t lane_prev(uint32_t x) {
+	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+}
+__device__ __forceinline__ double lane_prev(double x) {
+	const uint32_t lo = lane_prev((uint32_t)__double2loint(x));
+	const uint32_t hi = lane_prev((uint32_t)__double2hiint(x));
+	return __hiloint2double((int)hi, (int)lo);
+}
+
+/* rint(p * 2^31) wrapped to 32 bits for |p| < 2^20: in f64, p + 1.5 * 2^21
+ * has an ulp of 2^-31, so the addition rounds p to a multiple of 2^-31
+ * (nearest-even, as llrintf does in the default mode) and leaves that
+ * multiple, mod 2^32, in the low word of the significand. */
+__device__ __forceinline__ uint32_t rint32w_p31_small(float p) {
+	return (uint32_t)__double2loint((double)p + 0x1.8p21);
+}
+
+/* Uniform (scalar-cache) load of one decoded step: the address is the same
+ * for the whole wave and the memory was written by an earlier kernel. */
+typedef const uint32_t __attribute__((address_space(4))) *const_u32_ptr;
+__device__ __forceinline__ FastStep load_step_uniform(const FastStep *p) {
+	const_u32_ptr q = (const_u32_ptr)(uintptr_t)p;
+	union { FastStep s; uint32_t u[20]; } c;
+#pragma unroll
+	for (int i = 0; i < 20; ++i) c.u[i] = q[i];
+	return c.s;
+}
+
 template <int T>
 __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 	constexpr int NP = 64 * T;
 	constexpr int W = 16;
 	extern __shared__ __align__(16) unsigned char lds[];
 	const int tid = threadIdx.x;
-	const int w = tid >> 6;
+	const int w = (int)uni((uint32_t)tid >> 6);
 	const int l = tid & 63;
-	const int p0 = l * T;
 
 	HerpC23 *t23 = (HerpC23 *)lds;
 	HerpC01 *t01 = (HerpC01 *)(lds + (size_t)P.n_tabs * WAVE_LEN * sizeof(HerpC23));
 	unsigned char *areas = lds + (size_t)P.n_tabs * WAVE_LEN * (sizeof(HerpC23) + sizeof(HerpC01));
-	const size_t area_bytes = (size_t)P.max_steps * sizeof(FastStep) + (size_t)P.n_main * NP * sizeof(float);
-	FastStep *fsteps = (FastStep *)(areas + (size_t)w * area_bytes);
-	float *slots = (float *)(fsteps + P.max_steps);
+	const size_t area_bytes = (size_t)P.n_main * NP * sizeof(float);
+	float *slots = (float *)(areas + (size_t)w * area_bytes) + l; /* lane's column of every row */
 
 	for (uint32_t t = 0; t < P.n_tabs; ++t) {
 		const uint32_t wave = P.wave_of_tab[t];
@@ -1103,60 +1174,24 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 		const uint32_t *ids = P.op_ids + vd.ops_ofs;
 		const uint32_t H = uni(fi.H);
 
-		/* ---- decode the plan: lane si handles step si (plan_len <= 64) ---- */
-		uint32_t n_fsteps;
-		{
-			bool keep = false;
-			FastStep f;
-			uint32_t dep = 0;
-			if ((uint32_t)l < vd.plan_len) {
-				const Step *plan = P.steps + vd.plan_ofs;
-				/* nesting depth of this step = BEGINs up to and including it minus ENDs before it */
-				for (uint32_t q = 0; q <= (uint32_t)l; ++q) {
-					const Step sq = plan[q];
-					if (sq.flags & SF_BEGIN) ++dep;
-					if (q < (uint32_t)l && (sq.flags & SF_END)) --dep;
-				}
-				const Step st = plan[l];
-				const DevOp &o = P.ops[ids[st.op]];
-				keep = !(st.kind == ST_LINE && st.which == L_FREQ);
-				f.kind = (uint32_t)st.kind | ((uint32_t)st.flags << 8) | ((uint32_t)st.which << 16) | (dep << 24);
-				f.out_off = st.out != NO_SLOT ? (uint32_t)st.out * NP : ~0u;
-				f.pm_off = st.pm != NO_SLOT ? (uint32_t)st.pm * NP : ~0u;
-				f.fpm_off = st.fpm != NO_SLOT ? (uint32_t)st.fpm * NP : ~0u;
-				f.amp_off = st.amp != NO_SLOT ? (uint32_t)st.amp * NP : ~0u;
-				f.aux_off = (st.kind == ST_LERP && st.freq != NO_SLOT) ? (uint32_t)st.freq * NP : ~0u;
-				const uint32_t wv = o.type == OT_WAVE ? (o.wave < 12 ? o.wave : 0) : o.wave;
-				f.type = o.type | (wv << 8) | ((o.flags & OPF_OSC_RESET) ? 1u << 16 : 0u);
-				f.fc = o.rt_fconst;
-				f.inc = rint32w(o.coeff * o.rt_fconst);
-				f.phase0 = o.type == OT_NOISE ? o.noise_n : o.phase;
-				f.prev_phase = o.type == OT_NOISE ? o.noise_prev : o.prev_phase;
-				f.ac = (st.kind == ST_LINE) ? o.line[st.which].v0 : o.line[L_AMP].v0;
-				f.diff_scale = o.type == OT_WAVE ? P.wc[wv].diff_scale : 0.f;
-				f.diff_offset = o.type == OT_WAVE ? P.wc[wv].diff_offset : 0.f;
-				f.tab = o.type == OT_WAVE ? P.tab_of_wave[wv] : -1;
-				f.gop = ids[st.op];
-				f.prev_Is = o.prev_Is;
-				f.pan = o.line[L_PAN].v0;
-				f.pad = 0;
-			}
-			const unsigned long long m = __ballot(keep);
-			if (keep) fsteps[__popcll(m & ((1ull << l) - 1ull))] = f;
-			n_fsteps = (uint32_t)__popcll(m);
-		}
+		const uint32_t n_fsteps = uni(fi.n_fsteps);
+		const FastStep *fsteps = P.fsteps + (size_t)v * P.max_steps;
 		float *vrow = P.vout + (size_t)vd.out_row * P.row_stride;
 		float *prow = (vd.pan_dynamic_row != ~0u) ? P.pan + (size_t)vd.pan_dynamic_row * P.row_stride : nullptr;
-		const uint32_t C = (uint32_t)NP - H;
-		const uint32_t nch = (fast_total + C - 1) / C;
+		/* A wave renders T rows at a time; a row is 64 consecutive frames, one per
+		 * lane, of which the first H are lead-in (recomputed, not stored). */
+		const uint32_t C = 64u - H;                       /* new frames per row */
+		const uint32_t nrows = (fast_total + C - 1) / C;
+		const uint32_t ngroups = (nrows + T - 1) / T;
+		const uint32_t last_group = ((fast_total - 1) / C) / T; /* holds the segment's last frame */
 		uint32_t zero_acc = 0; /* nonzero: some hold-previous run could not be resolved here */
 
-		for (uint32_t c = cstart; c < nch; c += wpv) {
-			const int t_base = (int)(c * C) - (int)H; /* segment sample at p = 0 */
-			const bool first_chunk = (c == 0);
-			const bool last_chunk = t_base + (int)NP > (int)fast_total - 1 && t_base <= (int)fast_total - 1;
+		for (uint32_t cg = cstart; cg < ngroups; cg += wpv) {
+			const int t0 = (int)(cg * T * C) - (int)H + l; /* this lane's frame in row 0 */
+			const bool first_group = (cg == 0);
+			const bool is_last_group = (cg == last_group);
 			for (uint32_t si = 0; si < n_fsteps; ++si) {
-				const FastStep f = uni(fsteps[si]);
+				const FastStep f = load_step_uniform(fsteps + si);
 				const uint32_t kind = f.kind & 0xff;
 				const uint32_t flags = (f.kind >> 8) & 0xff;
 				if (kind == ST_OSC) {
@@ -1170,35 +1205,52 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 						uint32_t ph[T];
 						double Is[T];
 						/* phase0 + inc*(t+1): one multiply per lane, then adds */
-						uint32_t acc = f.phase0 + f.inc * (uint32_t)(t_base + p0);
+						{
+							uint32_t acc = f.phase0 + f.inc * (uint32_t)(t0 + 1);
+							const uint32_t row_inc = f.inc * C;
+#pragma unroll
+							for (int k = 0; k < T; ++k) { ph[k] = acc; acc += row_inc; }
+						}
 						if (has_pm && !has_fpm) {
+							float pm[T];
+							bool big = false;
 #pragma unroll
 							for (int k = 0; k < T; ++k) {
-								acc += f.inc;
-								ph[k] = acc + rint32w_p31(slots[f.pm_off + p0 + k]);
+								pm[k] = slots[f.pm_off + k * 64];
+								big |= !(fabsf(pm[k]) < 0x1p20f);
 							}
-						} else if (!has_pm && !has_fpm) {
+							if (!__any(big)) {
 #pragma unroll
-							for (int k = 0; k < T; ++k) { acc += f.inc; ph[k] = acc; }
-						} else {
+								for (int k = 0; k < T; ++k) ph[k] += rint32w_p31_small(pm[k]);
+							} else {
 #pragma unroll
-							for (int k = 0; k < T; ++k) {
-								acc += f.inc;
-								ph[k] = acc + pm_offset32(has_pm, has_fpm, has_pm ? slots[f.pm_off + p0 + k] : 0.f,
-										has_fpm ? slots[f.fpm_off + p0 + k] : 0.f, f.fc);
+								for (int k = 0; k < T; ++k) ph[k] += rint32w_p31(pm[k]);
+							}
+						} else if (has_pm || has_fpm) {
+							float pm[T], fpm[T];
+#pragma unroll
+							for (int k = 0; k < T; ++k) { pm[k] = 0.f; fpm[k] = 0.f; }
+							if (has_pm) {
+#pragma unroll
+								for (int k = 0; k < T; ++k) pm[k] = slots[f.pm_off + k * 64];
+							}
+							if (has_fpm) {
+#pragma unroll
+								for (int k = 0; k < T; ++k) fpm[k] = slots[f.fpm_off + k * 64];
+							}
+							if (has_pm) {
+#pragma unroll
+								for (int k = 0; k < T; ++k) ph[k] += pm_offset32(true, true, pm[k], fpm[k], f.fc);
+							} else {
+#pragma unroll
+								for (int k = 0; k < T; ++k) ph[k] += pm_offset32(false, true, 0.f, fpm[k], f.fc);
 							}
 						}
 						const bool reset = (f.type >> 16) & 1;
-						if (first_chunk) {
+						if (first_group) {
 							/* t = -1: the sample before the segment (wosc.h:215-231 on restart) */
-							const uint32_t next0 = __shfl_down(ph[0], 1);
-#pragma unroll
-							for (int k = 0; k < T; ++k) {
-								if (p0 + k == (int)H - 1) {
-									const uint32_t nxt = (k < T - 1) ? ph[(k + 1) % T] : next0;
-									ph[k] = reset ? nxt - SLEN : f.prev_phase;
-								}
-							}
+							const uint32_t nxt = __shfl_down(ph[0], 1);
+							if (l == (int)H - 1) ph[0] = reset ? nxt - SLEN : f.prev_phase;
 						}
 						if (f.tab >= 0) {
 							const HerpC23 *l23 = t23 + (size_t)f.tab * WAVE_LEN;
@@ -1218,56 +1270,53 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 								Is[k] = herp_poly(g23[ind], g01[ind], ph[k]);
 							}
 						}
-						if (first_chunk && !reset) {
-#pragma unroll
-							for (int k = 0; k < T; ++k)
-								if (p0 + k == (int)H - 1) Is[k] = f.prev_Is;
+						if (first_group && !reset) {
+							if (l == (int)H - 1) Is[0] = f.prev_Is;
 						}
-						uint32_t pph = __shfl_up(ph[T - 1], 1);
-						double pIs = __shfl_up(Is[T - 1], 1);
-						/* this operator's values are defined from position p_min on
+						/* this operator's values are defined from lane p_min on
 						 * (one more lead-in sample per nesting level below it) */
 						const int p_min = (int)H - (int)(f.kind >> 24) + 1;
-						uint32_t zero = 0;
+						uint32_t pph[T];
+						bool zero = false;
 #pragma unroll
 						for (int k = 0; k < T; ++k) {
-							if (k > 0) { pph = ph[k - 1]; pIs = Is[k - 1]; }
-							const int32_t d = (int32_t)(ph[k] - pph);
-							zero |= (uint32_t)(d == 0 && p0 + k >= p_min);
+							pph[k] = lane_prev(ph[k]);
+							const double pIs = lane_prev(Is[k]);
+							const int32_t d = (int32_t)(ph[k] - pph[k]);
+							zero |= (d == 0);
 							s[k] = wosc_diff(Is[k], pIs, d, f.diff_scale, f.diff_offset);
 						}
-						if (__any(zero)) {
+						if (__any(zero && l >= p_min)) {
 							/* dphase == 0: the differentiator holds its previous output
-							 * (wosc.h:251-252). Isolated cases resolve inside the wave; a
+							 * (wosc.h:251-252). Isolated cases resolve inside the row; a
 							 * run that reaches back past the lead-in goes to the block loop. */
 							bool held[T], src[T]; /* src: holds a defined output to copy from */
 #pragma unroll
 							for (int k = 0; k < T; ++k) {
-								const uint32_t q = k > 0 ? ph[k - 1] : __shfl_up(ph[T - 1], 1);
-								const int t = t_base + p0 + k;
-								const bool defined = p0 + k >= p_min && t >= 0;
-								held[k] = (ph[k] == q) && defined && t < (int)fast_total;
+								const int t = t0 + k * (int)C;
+								const bool defined = l >= p_min && t >= 0;
+								held[k] = (ph[k] == pph[k]) && defined && t < (int)fast_total;
 								src[k] = defined && !held[k];
 							}
 							for (int it = 0; it < 64; ++it) {
-								const float sp = __shfl_up(s[T - 1], 1);
-								const bool okp = __shfl_up(src[T - 1], 1);
 								bool changed = false;
-								if (held[0] && okp && l > 0) { s[0] = sp; held[0] = false; src[0] = true; changed = true; }
 #pragma unroll
-								for (int k = 1; k < T; ++k)
-									if (held[k] && src[k - 1]) { s[k] = s[k - 1]; held[k] = false; src[k] = true; changed = true; }
+								for (int k = 0; k < T; ++k) {
+									const float sp = __shfl_up(s[k], 1);
+									const bool okp = __shfl_up(src[k], 1);
+									if (held[k] && okp && l > 0) { s[k] = sp; held[k] = false; src[k] = true; changed = true; }
+								}
 								if (!__any(changed)) break;
 							}
 #pragma unroll
 							for (int k = 0; k < T; ++k) zero_acc |= (uint32_t)held[k];
 						}
-						if (last_chunk) {
-							/* the chunk that holds the segment's last sample stages the state */
+						if (is_last_group) {
+							/* the row that holds the segment's last frame stages the state */
 #pragma unroll
 							for (int k = 0; k < T; ++k) {
-								const int t = t_base + p0 + k;
-								if (t == (int)fast_total - 1 && p0 + k >= (int)H) {
+								const int t = t0 + k * (int)C;
+								if (t == (int)fast_total - 1 && l >= (int)H) {
 									DevOp &o = P.ops[f.gop];
 									o.st_prev_phase = ph[k];
 									o.st_prev_Is = Is[k];
@@ -1280,7 +1329,7 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 						const uint32_t n0 = f.phase0, nprev = f.prev_phase;
 #pragma unroll
 						for (int k = 0; k < T; ++k) {
-							const int t = t_base + p0 + k;
+							const int t = t0 + k * (int)C;
 							const uint32_t n = n0 + (uint32_t)t;
 							if (nz == NZ_vi) {
 								uint32_t s1 = ranfast32(n);
@@ -1299,53 +1348,53 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 						for (int k = 0; k < T; ++k) s[k] = 1.f;
 					}
 					/* amplitude and combine: generator.c:384-440 */
-					float a[T];
+					float r[T];
 					if (f.amp_off != ~0u) {
 #pragma unroll
-						for (int k = 0; k < T; ++k) a[k] = slots[f.amp_off + p0 + k];
+						for (int k = 0; k < T; ++k) r[k] = slots[f.amp_off + k * 64];
 					} else {
 #pragma unroll
-						for (int k = 0; k < T; ++k) a[k] = f.ac;
+						for (int k = 0; k < T; ++k) r[k] = f.ac;
 					}
-					float r[T];
-					if (layer || wave_env) {
+					if (layer) {
 #pragma unroll
 						for (int k = 0; k < T; ++k)
-							r[k] = mix_combine(layer ? slots[f.out_off + p0 + k] : 0.f, s[k], a[k], wave_env, layer);
+							r[k] = mix_combine(slots[f.out_off + k * 64], s[k], r[k], wave_env, true);
+					} else if (wave_env) {
+#pragma unroll
+						for (int k = 0; k < T; ++k) r[k] = mix_combine(0.f, s[k], r[k], true, false);
 					} else {
 #pragma unroll
-						for (int k = 0; k < T; ++k) r[k] = s[k] * a[k];
+						for (int k = 0; k < T; ++k) r[k] = s[k] * r[k];
 					}
 					if (to_voice) {
 #pragma unroll
 						for (int k = 0; k < T; ++k) {
-							const int t = t_base + p0 + k;
-							if (p0 + k >= (int)H && t < (int)fast_total) vrow[t] = r[k];
+							const int t = t0 + k * (int)C;
+							if (l >= (int)H && t < (int)fast_total) vrow[t] = r[k];
 						}
 					} else {
 #pragma unroll
-						for (int k = 0; k < T; ++k) slots[f.out_off + p0 + k] = r[k];
+						for (int k = 0; k < T; ++k) slots[f.out_off + k * 64] = r[k];
 					}
 				} else if (kind == ST_LINE) {
 					/* held line: v0 (sau/line.c:435-442); ratio lines only exist for freq */
 #pragma unroll
-					for (int k = 0; k < T; ++k) slots[f.out_off + p0 + k] = f.ac;
+					for (int k = 0; k < T; ++k) slots[f.out_off + k * 64] = f.ac;
 				} else if (kind == ST_LERP) { /* generator.c:466-467 */
 #pragma unroll
 					for (int k = 0; k < T; ++k) {
-						const int e = p0 + k;
-						float pv = slots[f.out_off + e];
-						pv += (slots[f.aux_off + e] - pv) * slots[f.pm_off + e];
-						slots[f.out_off + e] = pv;
+						float pv = slots[f.out_off + k * 64];
+						pv += (slots[f.aux_off + k * 64] - pv) * slots[f.pm_off + k * 64];
+						slots[f.out_off + k * 64] = pv;
 					}
 				} else if (kind == ST_VOICE) { /* generator.c:749-788 with pan modulators */
 #pragma unroll
 					for (int k = 0; k < T; ++k) {
-						const int e = p0 + k;
-						const int t = t_base + e;
-						if (e >= (int)H && t < (int)fast_total) {
-							vrow[t] = slots[f.out_off + e];
-							if (prow) prow[t] = f.pm_off != ~0u ? slots[f.pm_off + e] : f.pan;
+						const int t = t0 + k * (int)C;
+						if (l >= (int)H && t < (int)fast_total) {
+							vrow[t] = slots[f.out_off + k * 64];
+							if (prow) prow[t] = f.pm_off != ~0u ? slots[f.pm_off + k * 64] : f.pan;
 						}
 					}
 				}
@@ -1614,9 +1663,14 @@ public:
 		std::vector<HerpC23> h23((size_t)12 * WAVE_LEN);
 		std::vector<HerpC01> h01((size_t)12 * WAVE_LEN);
 		for (uint32_t wv = 0; wv < 12; ++wv)
-			for (uint32_t i = 0; i < WAVE_LEN; ++i)
+			for (uint32_t i = 0; i < WAVE_LEN; ++i) {
+				if (!herp_c1_scalable(cfg.piluts + (size_t)wv * WAVE_LEN, i)) {
+					err = "wave table has slopes below 2^-100: unsupported";
+					return false;
+				}
 				herp_coeffs(cfg.piluts + (size_t)wv * WAVE_LEN, i,
 						h23[(size_t)wv * WAVE_LEN + i], h01[(size_t)wv * WAVE_LEN + i]);
+			}
 		if (!c23_.ensure(h23.size(), err) || !c01_.ensure(h01.size(), err) || !wc_.ensure(12, err))
 			return false;
 		HIP_OK(hipMemcpy(c23_.p, h23.data(), h23.size() * sizeof(HerpC23), hipMemcpyHostToDevice));
@@ -1748,23 +1802,22 @@ public:
 		/* ---- time-parallel path first; the block loop continues after it ---- */
 		{
 			constexpr uint32_t FT = 4, FNP = 64 * FT;
-			const uint32_t fmax_ops = seg.max_ops < 64 ? seg.max_ops : 64;
 			const uint32_t fmax_steps = seg.max_steps < 64 ? seg.max_steps : 64;
-			const size_t area = (size_t)fmax_steps * sizeof(FastStep) + (size_t)seg.n_main * FNP * sizeof(float);
+			const size_t area = (size_t)seg.n_main * FNP * sizeof(float);
 			const bool use_fast = fast_enabled_ && (16 * area + 1024 <= lds_limit_);
 			if (!finfo_.ensure(seg.n_voices, err) || !fdone_.ensure(seg.n_voices, err) ||
-			    !worklist_.ensure(seg.n_voices, err) || !work_count_.ensure(4, err)) return false;
+			    !worklist_.ensure(seg.n_voices, err) || !work_count_.ensure(4, err) ||
+			    !fsteps_.ensure((size_t)seg.n_voices * fmax_steps * sizeof(FastStep), err)) return false;
 			HIP_OK(hipMemsetAsync(work_count_.p, 0, sizeof(uint32_t), stream_));
 			FastParams fp;
 			memset(&fp, 0, sizeof fp);
 			fp.voices = voices_.p; fp.steps = steps_.p; fp.op_ids = op_ids_.p; fp.ops = ops_.p;
 			fp.vout = vout_.p; fp.pan = pan_.p; fp.info = finfo_.p; fp.fast_done = fdone_.p;
 			fp.worklist = worklist_.p; fp.work_count = work_count_.p; fp.vinfo = vinfo_.p;
-			fp.g_c23 = c23_.p; fp.g_c01 = c01_.p;
+			fp.g_c23 = c23_.p; fp.g_c01 = c01_.p; fp.fsteps = (FastStep *)fsteps_.p;
 			fp.row_stride = row_stride_; fp.n_voices = seg.n_voices; fp.n_main = seg.n_main;
-			fp.max_ops = fmax_ops; fp.max_steps = fmax_steps; fp.np = FNP;
+			fp.max_ops = seg.max_ops; fp.max_steps = fmax_steps; fp.np = 64;
 			fp.enable = use_fast ? 1u : 0u;
-			fp.ablate = getenv("SAU_AMD_ABLATE") ? (uint32_t)atoi(getenv("SAU_AMD_ABLATE")) : 0u;
 			memcpy(fp.wc, wconst_, sizeof wconst_);
 			uint32_t ft = 0;
 			for (int wv = 0; wv < 12; ++wv) {
@@ -1782,6 +1835,7 @@ public:
 			hipLaunchKernelGGL(analyze_kernel, dim3((seg.n_voices + 63) / 64), dim3(64), 0, stream_, fp);
 			if (ta) (void)hipEventRecord(ta->b, stream_);
 			if (use_fast) {
+				hipLaunchKernelGGL(decode_kernel, dim3(seg.n_voices), dim3(64), 0, stream_, fp);
 				const size_t flds = ft * tab_bytes + 16 * area;
 				static size_t fconfigured = 0;
 				if (flds > fconfigured) {
@@ -1969,6 +2023,7 @@ private:
 	int timing_level_ = 2;
 	DevBuf<FastInfo> finfo_;
 	DevBuf<uint32_t> fdone_, worklist_, work_count_;
+	DevBuf<unsigned char> fsteps_;
 	uint32_t block_grid_ = 1;
 };
 

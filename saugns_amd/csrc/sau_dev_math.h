@@ -438,7 +438,13 @@ SAU_HD void line_copy(LineState &o, const LineUpdate &src) {
 
 /* Hermite coefficients of one table index, precomputed from the four taps in
  * the exact expression order of sauWave_get_herp (sau/wave.h:127-141). c0 and
- * c1 are exactly representable as f32; c2 and c3 need f64. */
+ * c1 are exactly representable as f32; c2 and c3 need f64.
+ *
+ * The reference evaluates ((c3*x + c2)*x + c1)*x + c0 with x = frac * 2^-21
+ * (frac: the low 21 phase bits).  Stored here are c3 * 2^-63, c2 * 2^-42 and
+ * c1 * 2^-21, and the polynomial runs on X = (double)frac: every intermediate
+ * is the reference's times a power of two, so each rounding is the same and
+ * the final sum (scale 2^0) is bit-identical, with two conversions fewer. */
 struct HerpC23 { double c3, c2; };
 struct HerpC01 { float c1, c0; };
 
@@ -448,13 +454,20 @@ SAU_HD void herp_coeffs(const float *lut, uint32_t ind, HerpC23 &hi, HerpC01 &lo
 	float s2 = lut[(ind + 1) & WAVE_MASK];
 	float s3 = lut[(ind + 2) & WAVE_MASK];
 	lo.c0 = s1;
-	lo.c1 = (float)(1 / 2.0 * (double)(s2 - s0)); /* halving is exact */
-	hi.c2 = (double)s0 - 5 / 2.0 * (double)s1 + (double)(2 * s2) - 1 / 2.0 * (double)s3;
-	hi.c3 = 1 / 2.0 * (double)(s3 - s0) + 3 / 2.0 * (double)(s1 - s2);
+	lo.c1 = (float)(1 / 2.0 * (double)(s2 - s0)) * 0x1p-21f; /* halving and scaling are exact */
+	hi.c2 = ((double)s0 - 5 / 2.0 * (double)s1 + (double)(2 * s2) - 1 / 2.0 * (double)s3) * 0x1p-42;
+	hi.c3 = (1 / 2.0 * (double)(s3 - s0) + 3 / 2.0 * (double)(s1 - s2)) * 0x1p-63;
+}
+/* false if scaling c1 would leave the normal f32 range (inexact): such a
+ * table cannot use the prescaled form */
+SAU_HD bool herp_c1_scalable(const float *lut, uint32_t ind) {
+	float d = lut[(ind + 1) & WAVE_MASK] - lut[(ind - 1) & WAVE_MASK];
+	float a = d < 0 ? -d : d;
+	return a == 0.f || a >= 0x1p-100f;
 }
 
 SAU_HD double herp_poly(const HerpC23 &hi, const HerpC01 &lo, uint32_t phase) {
-	double x = (double)((float)(phase & (SLEN - 1)) * (1.f / (float)SLEN));
+	double x = (double)(phase & (SLEN - 1));
 	return ((hi.c3 * x + hi.c2) * x + (double)lo.c1) * x + (double)lo.c0;
 }
 
