@@ -83,7 +83,8 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.build()
+    # SAU_AMD_LIB: load another build of the same library (A/B timing of kernel variants)
+    path = os.environ.get("SAU_AMD_LIB") or _build.build()
     L = C.CDLL(path)
     L.sau_create_Generator.restype = C.c_void_p
     L.sau_create_Generator.argtypes = [C.c_void_p, C.c_uint32]

@@ -23,6 +23,22 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_variant(name, defines):
+    """Kernel-tuning aid: build saugns_amd/variants/lib_<name>.so with extra -D flags
+    (only hip_backend.hip is recompiled; the other objects come from the main build)."""
+    build()
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    vdir = os.path.join(HERE, "variants")
+    os.makedirs(vdir, exist_ok=True)
+    obj = os.path.join(vdir, "hip_backend_%s.o" % name)
+    subprocess.check_call([hipcc] + FLAGS + ["-D" + d for d in defines] +
+                          ["-c", os.path.join(CSRC, "hip_backend.hip"), "-o", obj])
+    objs = [os.path.join(CSRC, s.rsplit(".", 1)[0] + ".o") for s in SOURCES if s != "hip_backend.hip"]
+    out = os.path.join(vdir, "lib_%s.so" % name)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + [obj, "-ldl"])
+    return out
+
+
 def build(force=False, verbose=False):
     if not force and not _stale():
         return LIB
@@ -41,4 +57,7 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":  # --variant NAME DEF1 DEF2 ...
+        print(build_variant(sys.argv[2], sys.argv[3:]))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

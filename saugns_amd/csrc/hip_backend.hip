@@ -1132,6 +1132,17 @@ __device__ __forceinline__ FastStep load_step_uniform(const FastStep *p) {
 	return c.s;
 }
 
+/* (A 24-byte interleaved LDS entry read with ds_read2_b64 + ds_read_b64 was
+ * measured 60 % worse in bank conflicts than this split 16 + 8 byte layout.) */
+#ifndef FK_COMMON
+#define FK_COMMON 1
+#endif
+#ifndef FK_CONSTD
+#define FK_CONSTD 1
+#endif
+#ifndef FK_PREFETCH
+#define FK_PREFETCH 0 /* loading the next step early measured 6 % slower (SGPR pressure) */
+#endif
 template <int T>
 __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 	constexpr int NP = 64 * T;
@@ -1190,8 +1201,16 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 			const int t0 = (int)(cg * T * C) - (int)H + l; /* this lane's frame in row 0 */
 			const bool first_group = (cg == 0);
 			const bool is_last_group = (cg == last_group);
+#if FK_PREFETCH
+			FastStep fnext = load_step_uniform(fsteps);
+#endif
 			for (uint32_t si = 0; si < n_fsteps; ++si) {
+#if FK_PREFETCH
+				const FastStep f = fnext;
+				fnext = load_step_uniform(fsteps + (si + 1 < n_fsteps ? si + 1 : si)); /* in flight during this step */
+#else
 				const FastStep f = load_step_uniform(fsteps + si);
+#endif
 				const uint32_t kind = f.kind & 0xff;
 				const uint32_t flags = (f.kind >> 8) & 0xff;
 				if (kind == ST_OSC) {
@@ -1202,125 +1221,190 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 					float s[T];
 					if (type == OT_WAVE) {
 						const bool has_pm = f.pm_off != ~0u, has_fpm = f.fpm_off != ~0u;
-						uint32_t ph[T];
-						double Is[T];
-						/* phase0 + inc*(t+1): one multiply per lane, then adds */
-						{
-							uint32_t acc = f.phase0 + f.inc * (uint32_t)(t0 + 1);
-							const uint32_t row_inc = f.inc * C;
-#pragma unroll
-							for (int k = 0; k < T; ++k) { ph[k] = acc; acc += row_inc; }
-						}
-						if (has_pm && !has_fpm) {
-							float pm[T];
-							bool big = false;
-#pragma unroll
-							for (int k = 0; k < T; ++k) {
-								pm[k] = slots[f.pm_off + k * 64];
-								big |= !(fabsf(pm[k]) < 0x1p20f);
-							}
-							if (!__any(big)) {
-#pragma unroll
-								for (int k = 0; k < T; ++k) ph[k] += rint32w_p31_small(pm[k]);
-							} else {
-#pragma unroll
-								for (int k = 0; k < T; ++k) ph[k] += rint32w_p31(pm[k]);
-							}
-						} else if (has_pm || has_fpm) {
-							float pm[T], fpm[T];
-#pragma unroll
-							for (int k = 0; k < T; ++k) { pm[k] = 0.f; fpm[k] = 0.f; }
-							if (has_pm) {
-#pragma unroll
-								for (int k = 0; k < T; ++k) pm[k] = slots[f.pm_off + k * 64];
-							}
-							if (has_fpm) {
-#pragma unroll
-								for (int k = 0; k < T; ++k) fpm[k] = slots[f.fpm_off + k * 64];
-							}
-							if (has_pm) {
-#pragma unroll
-								for (int k = 0; k < T; ++k) ph[k] += pm_offset32(true, true, pm[k], fpm[k], f.fc);
-							} else {
-#pragma unroll
-								for (int k = 0; k < T; ++k) ph[k] += pm_offset32(false, true, 0.f, fpm[k], f.fc);
-							}
-						}
-						const bool reset = (f.type >> 16) & 1;
-						if (first_group) {
-							/* t = -1: the sample before the segment (wosc.h:215-231 on restart) */
-							const uint32_t nxt = __shfl_down(ph[0], 1);
-							if (l == (int)H - 1) ph[0] = reset ? nxt - SLEN : f.prev_phase;
-						}
-						if (f.tab >= 0) {
-							const HerpC23 *l23 = t23 + (size_t)f.tab * WAVE_LEN;
-							const HerpC01 *l01 = t01 + (size_t)f.tab * WAVE_LEN;
-#pragma unroll
-							for (int k = 0; k < T; ++k) {
-								const uint32_t ind = ph[k] >> SLEN_BITS;
-								Is[k] = herp_poly(l23[ind], l01[ind], ph[k]);
-							}
-						} else {
-							const uint32_t wave = (f.type >> 8) & 0xff;
-							const HerpC23 *g23 = P.g_c23 + (size_t)wave * WAVE_LEN;
-							const HerpC01 *g01 = P.g_c01 + (size_t)wave * WAVE_LEN;
-#pragma unroll
-							for (int k = 0; k < T; ++k) {
-								const uint32_t ind = ph[k] >> SLEN_BITS;
-								Is[k] = herp_poly(g23[ind], g01[ind], ph[k]);
-							}
-						}
-						if (first_group && !reset) {
-							if (l == (int)H - 1) Is[0] = f.prev_Is;
-						}
 						/* this operator's values are defined from lane p_min on
 						 * (one more lead-in sample per nesting level below it) */
 						const int p_min = (int)H - (int)(f.kind >> 24) + 1;
-						uint32_t pph[T];
-						bool zero = false;
+						bool done = false;
+						if (FK_COMMON && f.tab >= 0 && !has_fpm && !first_group && !is_last_group) {
+							/* the common case, straight-line: table in LDS, plain PM or
+							 * none, no segment edge in this group */
+							uint32_t ph[T];
+							{
+								uint32_t acc = f.phase0 + f.inc * (uint32_t)(t0 + 1);
+								const uint32_t row_inc = f.inc * C;
 #pragma unroll
-						for (int k = 0; k < T; ++k) {
-							pph[k] = lane_prev(ph[k]);
-							const double pIs = lane_prev(Is[k]);
-							const int32_t d = (int32_t)(ph[k] - pph[k]);
-							zero |= (d == 0);
-							s[k] = wosc_diff(Is[k], pIs, d, f.diff_scale, f.diff_offset);
-						}
-						if (__any(zero && l >= p_min)) {
-							/* dphase == 0: the differentiator holds its previous output
-							 * (wosc.h:251-252). Isolated cases resolve inside the row; a
-							 * run that reaches back past the lead-in goes to the block loop. */
-							bool held[T], src[T]; /* src: holds a defined output to copy from */
-#pragma unroll
-							for (int k = 0; k < T; ++k) {
-								const int t = t0 + k * (int)C;
-								const bool defined = l >= p_min && t >= 0;
-								held[k] = (ph[k] == pph[k]) && defined && t < (int)fast_total;
-								src[k] = defined && !held[k];
+								for (int k = 0; k < T; ++k) { ph[k] = acc; acc += row_inc; }
 							}
-							for (int it = 0; it < 64; ++it) {
-								bool changed = false;
+							bool ok = true;
+							if (has_pm) {
+								float pm[T];
+								bool big = false;
 #pragma unroll
 								for (int k = 0; k < T; ++k) {
-									const float sp = __shfl_up(s[k], 1);
-									const bool okp = __shfl_up(src[k], 1);
-									if (held[k] && okp && l > 0) { s[k] = sp; held[k] = false; src[k] = true; changed = true; }
+									pm[k] = slots[f.pm_off + k * 64];
+									big |= !(fabsf(pm[k]) < 0x1p20f);
 								}
-								if (!__any(changed)) break;
+								ok = !__any(big);
+#pragma unroll
+								for (int k = 0; k < T; ++k) ph[k] += rint32w_p31_small(pm[k]);
 							}
+							if (ok) {
+								const HerpC23 *l23 = t23 + (size_t)f.tab * WAVE_LEN;
+								const HerpC01 *l01 = t01 + (size_t)f.tab * WAVE_LEN;
+								double Is[T];
 #pragma unroll
-							for (int k = 0; k < T; ++k) zero_acc |= (uint32_t)held[k];
+								for (int k = 0; k < T; ++k) {
+									const uint32_t ind = ph[k] >> SLEN_BITS;
+									Is[k] = herp_poly(l23[ind], l01[ind], ph[k]);
+								}
+								if (FK_CONSTD && !has_pm && f.inc != 0) {
+									/* unmodulated: every phase step is inc, one division serves all */
+									const double x = (double)div_f32_normal(f.diff_scale, (float)(int32_t)f.inc);
+#pragma unroll
+									for (int k = 0; k < T; ++k)
+										s[k] = (float)((Is[k] - lane_prev(Is[k])) * x + (double)f.diff_offset);
+									done = true;
+								} else {
+									bool zero = false;
+#pragma unroll
+									for (int k = 0; k < T; ++k) {
+										const int32_t d = (int32_t)(ph[k] - lane_prev(ph[k]));
+										zero |= (d == 0);
+										s[k] = wosc_diff(Is[k], lane_prev(Is[k]), d, f.diff_scale, f.diff_offset);
+									}
+									done = !__any(zero && l >= p_min);
+								}
+							}
 						}
-						if (is_last_group) {
-							/* the row that holds the segment's last frame stages the state */
+						if (!done) {
+							uint32_t ph[T];
+							double Is[T];
+							/* phase0 + inc*(t+1): one multiply per lane, then adds */
+							{
+								uint32_t acc = f.phase0 + f.inc * (uint32_t)(t0 + 1);
+								const uint32_t row_inc = f.inc * C;
 #pragma unroll
-							for (int k = 0; k < T; ++k) {
-								const int t = t0 + k * (int)C;
-								if (t == (int)fast_total - 1 && l >= (int)H) {
-									DevOp &o = P.ops[f.gop];
-									o.st_prev_phase = ph[k];
-									o.st_prev_Is = Is[k];
-									o.st_prev_s = s[k];
+								for (int k = 0; k < T; ++k) { ph[k] = acc; acc += row_inc; }
+							}
+							if (has_pm && !has_fpm) {
+								float pm[T];
+								bool big = false;
+#pragma unroll
+								for (int k = 0; k < T; ++k) {
+									pm[k] = slots[f.pm_off + k * 64];
+									big |= !(fabsf(pm[k]) < 0x1p20f);
+								}
+								if (!__any(big)) {
+#pragma unroll
+									for (int k = 0; k < T; ++k) ph[k] += rint32w_p31_small(pm[k]);
+								} else {
+#pragma unroll
+									for (int k = 0; k < T; ++k) ph[k] += rint32w_p31(pm[k]);
+								}
+							} else if (has_pm || has_fpm) {
+								float pm[T], fpm[T];
+#pragma unroll
+								for (int k = 0; k < T; ++k) { pm[k] = 0.f; fpm[k] = 0.f; }
+								if (has_pm) {
+#pragma unroll
+									for (int k = 0; k < T; ++k) pm[k] = slots[f.pm_off + k * 64];
+								}
+								if (has_fpm) {
+#pragma unroll
+									for (int k = 0; k < T; ++k) fpm[k] = slots[f.fpm_off + k * 64];
+								}
+								if (has_pm) {
+#pragma unroll
+									for (int k = 0; k < T; ++k) ph[k] += pm_offset32(true, true, pm[k], fpm[k], f.fc);
+								} else {
+#pragma unroll
+									for (int k = 0; k < T; ++k) ph[k] += pm_offset32(false, true, 0.f, fpm[k], f.fc);
+								}
+							}
+							const bool reset = (f.type >> 16) & 1;
+							if (first_group) {
+								/* t = -1: the sample before the segment (wosc.h:215-231 on restart) */
+								const uint32_t nxt = __shfl_down(ph[0], 1);
+								if (l == (int)H - 1) ph[0] = reset ? nxt - SLEN : f.prev_phase;
+							}
+							if (f.tab >= 0) {
+								const HerpC23 *l23 = t23 + (size_t)f.tab * WAVE_LEN;
+								const HerpC01 *l01 = t01 + (size_t)f.tab * WAVE_LEN;
+#pragma unroll
+								for (int k = 0; k < T; ++k) {
+									const uint32_t ind = ph[k] >> SLEN_BITS;
+									Is[k] = herp_poly(l23[ind], l01[ind], ph[k]);
+								}
+							} else {
+								const uint32_t wave = (f.type >> 8) & 0xff;
+								const HerpC23 *g23 = P.g_c23 + (size_t)wave * WAVE_LEN;
+								const HerpC01 *g01 = P.g_c01 + (size_t)wave * WAVE_LEN;
+#pragma unroll
+								for (int k = 0; k < T; ++k) {
+									const uint32_t ind = ph[k] >> SLEN_BITS;
+									Is[k] = herp_poly(g23[ind], g01[ind], ph[k]);
+								}
+							}
+							if (first_group && !reset) {
+								if (l == (int)H - 1) Is[0] = f.prev_Is;
+							}
+							uint32_t pph[T];
+							bool zero = false;
+							if (FK_CONSTD && !has_pm && !has_fpm && !first_group && f.inc != 0) {
+								/* unmodulated: every phase step is inc, one division serves all */
+								const double x = (double)div_f32_normal(f.diff_scale, (float)(int32_t)f.inc);
+#pragma unroll
+								for (int k = 0; k < T; ++k) {
+									pph[k] = ph[k] - f.inc;
+									const double pIs = lane_prev(Is[k]);
+									s[k] = (float)((Is[k] - pIs) * x + (double)f.diff_offset);
+								}
+							} else {
+#pragma unroll
+								for (int k = 0; k < T; ++k) {
+									pph[k] = lane_prev(ph[k]);
+									const double pIs = lane_prev(Is[k]);
+									const int32_t d = (int32_t)(ph[k] - pph[k]);
+									zero |= (d == 0);
+									s[k] = wosc_diff(Is[k], pIs, d, f.diff_scale, f.diff_offset);
+								}
+							}
+							if (__any(zero && l >= p_min)) {
+								/* dphase == 0: the differentiator holds its previous output
+								 * (wosc.h:251-252). Isolated cases resolve inside the row; a
+								 * run that reaches back past the lead-in goes to the block loop. */
+								bool held[T], src[T]; /* src: holds a defined output to copy from */
+#pragma unroll
+								for (int k = 0; k < T; ++k) {
+									const int t = t0 + k * (int)C;
+									const bool defined = l >= p_min && t >= 0;
+									held[k] = (ph[k] == pph[k]) && defined && t < (int)fast_total;
+									src[k] = defined && !held[k];
+								}
+								for (int it = 0; it < 64; ++it) {
+									bool changed = false;
+#pragma unroll
+									for (int k = 0; k < T; ++k) {
+										const float sp = __shfl_up(s[k], 1);
+										const bool okp = __shfl_up(src[k], 1);
+										if (held[k] && okp && l > 0) { s[k] = sp; held[k] = false; src[k] = true; changed = true; }
+									}
+									if (!__any(changed)) break;
+								}
+#pragma unroll
+								for (int k = 0; k < T; ++k) zero_acc |= (uint32_t)held[k];
+							}
+							if (is_last_group) {
+								/* the row that holds the segment's last frame stages the state */
+#pragma unroll
+								for (int k = 0; k < T; ++k) {
+									const int t = t0 + k * (int)C;
+									if (t == (int)fast_total - 1 && l >= (int)H) {
+										DevOp &o = P.ops[f.gop];
+										o.st_prev_phase = ph[k];
+										o.st_prev_Is = Is[k];
+										o.st_prev_s = s[k];
+									}
 								}
 							}
 						}
