@@ -60,6 +60,7 @@ struct RenderParams {
 	const uint32_t *worklist;  /* voice rows that still need the block loop */
 	const uint32_t *work_count;
 	uint32_t n_tabs;       /* wave types staged in LDS */
+	uint32_t team_bytes;   /* LDS bytes per team (several teams per workgroup only) */
 	int8_t tab_of_wave[12];/* LDS table index per wave id, or -1 */
 	uint8_t wave_of_tab[12];
 	WaveConst wc[12];
@@ -117,6 +118,14 @@ __device__ __forceinline__ Step uni(const Step &st) {
 	union { Step s; uint32_t u[4]; } c; c.s = st;
 	c.u[0] = uni(c.u[0]); c.u[1] = uni(c.u[1]); c.u[2] = uni(c.u[2]); c.u[3] = uni(c.u[3]);
 	return c.s;
+}
+
+/* rint(p * 2^31) wrapped to 32 bits for |p| < 2^20: in f64, p + 1.5 * 2^21
+ * has an ulp of 2^-31, so the addition rounds p to a multiple of 2^-31
+ * (nearest-even, as llrintf does in the default mode) and leaves that
+ * multiple, mod 2^32, in the low word of the significand. */
+__device__ __forceinline__ uint32_t rint32w_p31_small(float p) {
+	return (uint32_t)__double2loint((double)p + 0x1.8p21);
 }
 
 /* Where the coefficient tables of one wave type are read from. */
@@ -179,38 +188,53 @@ __device__ __forceinline__ bool const_freq(const LineState &ls, bool has_mul, bo
 	return true;
 }
 
-template <int W, int T>
-__global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
+/* A team is the W waves that render one voice. V == 1: the workgroup is one
+ * team and its steps are separated by workgroup barriers. V > 1 (W == 1):
+ * every wave of the workgroup is a team of its own with a private LDS area --
+ * wave-synchronous, no barriers -- so that a CU keeps V voices in flight;
+ * that is what the serial feedback recurrences need (one lane per voice). */
+template <int V>
+__device__ __forceinline__ void team_sync() {
+	if constexpr (V == 1) __syncthreads();
+	else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+template <int W, int T, int V>
+__global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
+	static_assert(V == 1 || W == 1, "several teams per workgroup are single waves");
 	using G = Geo<W, T>;
 	extern __shared__ __align__(16) unsigned char lds[];
-	const int tid = threadIdx.x;
+	const int team = V > 1 ? (int)uni((uint32_t)threadIdx.x >> 6) : 0;
+	const int tid = V > 1 ? (int)(threadIdx.x & 63) : (int)threadIdx.x; /* within the team */
 	const int w = tid >> 6;
 	const int l = tid & 63;
 
 	HerpC23 *t23 = (HerpC23 *)lds;
 	HerpC01 *t01 = (HerpC01 *)(lds + (size_t)P.n_tabs * WAVE_LEN * sizeof(HerpC23));
-	float *slots = (float *)(lds + (size_t)P.n_tabs * WAVE_LEN * (sizeof(HerpC23) + sizeof(HerpC01)));
+	float *slots = (float *)(lds + (size_t)P.n_tabs * WAVE_LEN * (sizeof(HerpC23) + sizeof(HerpC01)) +
+			(size_t)team * P.team_bytes);
 	DevOp *ops = (DevOp *)(slots + (size_t)P.n_slots * G::SLOT);
 	Misc *misc = (Misc *)(ops + P.max_ops);
 	Step *plan = (Step *)(misc + 1); /* this voice's steps, read every block */
 
 	const uint32_t n_work = *P.work_count;
-	if (blockIdx.x >= n_work) return;
+	if (blockIdx.x * V >= n_work) return;
 
 	/* stage coefficient tables (16-byte copies) */
 	for (uint32_t t = 0; t < P.n_tabs; ++t) {
 		const uint32_t wave = P.wave_of_tab[t];
 		const uint4 *s23 = (const uint4 *)(P.g_c23 + (size_t)wave * WAVE_LEN);
 		uint4 *d23 = (uint4 *)(t23 + (size_t)t * WAVE_LEN);
-		for (uint32_t i = tid; i < WAVE_LEN; i += 64 * W) d23[i] = s23[i];
+		for (uint32_t i = threadIdx.x; i < WAVE_LEN; i += 64 * W * V) d23[i] = s23[i];
 		const uint2 *s01 = (const uint2 *)(P.g_c01 + (size_t)wave * WAVE_LEN);
 		uint2 *d01 = (uint2 *)(t01 + (size_t)t * WAVE_LEN);
-		for (uint32_t i = tid; i < WAVE_LEN; i += 64 * W) d01[i] = s01[i];
+		for (uint32_t i = threadIdx.x; i < WAVE_LEN; i += 64 * W * V) d01[i] = s01[i];
 	}
+	if (V > 1) __syncthreads(); /* tables are shared by the teams; nothing else is */
 
 	/* persistent over the work list: voices the time-parallel path finished
 	 * never get here */
-	for (uint32_t item = blockIdx.x; item < n_work; item += gridDim.x) {
+	for (uint32_t item = blockIdx.x * V + team; item < n_work; item += gridDim.x * V) {
 	const uint32_t vrow_id = P.worklist[item];
 	const VoiceDesc vd = P.voices[vrow_id];
 	const uint32_t *my_ids = P.op_ids + vd.ops_ofs;
@@ -218,7 +242,7 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 	float *prow = (vd.pan_dynamic_row != ~0u) ? P.pan + (size_t)vd.pan_dynamic_row * P.row_stride : nullptr;
 	uint32_t done = P.fast_done[vrow_id]; /* frames rendered by fast_kernel */
 	uint32_t produced = done;
-	__syncthreads(); /* previous voice's LDS contents are no longer needed */
+	team_sync<V>(); /* previous voice's LDS contents are no longer needed */
 	for (uint32_t i = tid; i < vd.nops * 64; i += 64 * W)
 		((u32_alias *)ops)[i] = ((const u32_alias *)&P.ops[my_ids[i >> 6]])[i & 63];
 	{
@@ -230,7 +254,7 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 		misc->tab_of_wave[tid] = P.tab_of_wave[tid];
 	}
 	if (tid == 0) misc->flag = 0;
-	__syncthreads();
+	team_sync<V>();
 
 	/* per-thread sample geometry: p = l*T + k, block sample j = w*(NP-1) + p - 1 */
 	const int p0 = l * T;
@@ -276,7 +300,7 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 			switch (st.kind) {
 			case ST_ZERO: {
 				float *out = slots + (size_t)st.out * G::SLOT;
-				__syncthreads();
+				team_sync<V>();
 #pragma unroll
 				for (int k = 0; k < T; ++k)
 					if (owned[k]) slot_put<W, T>(out, w, p0 + k, 0.f);
@@ -307,7 +331,7 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 				} else {
 					line_advance_hold(ls, len);
 				}
-				__syncthreads();
+				team_sync<V>();
 				if (!lazy) {
 #pragma unroll
 					for (int k = 0; k < T; ++k)
@@ -339,7 +363,7 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 #pragma unroll
 					for (int k = 0; k < T; ++k) v[k] = 0.f;
 				}
-				__syncthreads();
+				team_sync<V>();
 #pragma unroll
 				for (int k = 0; k < T; ++k)
 					if (owned[k]) slot_put<W, T>(out, w, p0 + k, v[k]);
@@ -360,7 +384,7 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 						v[k] = pv;
 					}
 				}
-				__syncthreads();
+				team_sync<V>();
 #pragma unroll
 				for (int k = 0; k < T; ++k)
 					if (owned[k]) slot_put<W, T>(par, w, p0 + k, v[k]);
@@ -509,7 +533,7 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 						}
 						const uint32_t incl = wave_incl_scan(lane_sum, l);
 						if (l == 63) misc->tot32[w] = incl;
-						__syncthreads();
+						team_sync<V>();
 						uint32_t base = phase0;
 #pragma unroll
 						for (int ww = 0; ww < W; ++ww) {
@@ -530,10 +554,11 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 						w_parallel = true;
 						const bool reset = (op_flags & OPF_OSC_RESET) && len > 0;
 						double Is[T];
-						if (halo && w == 0) {
+						{
 							/* sample before the block: carried state, or the
 							 * one-table-step restart of wosc.h:215-231 */
-							ph[0] = reset ? ph[1] - SLEN : op->prev_phase;
+							const uint32_t first = T > 1 ? ph[T > 1 ? 1 : 0] : __shfl_down(ph[0], 1);
+							if (halo && w == 0) ph[0] = reset ? first - SLEN : op->prev_phase;
 						}
 #pragma unroll
 						for (int k = 0; k < T; ++k) {
@@ -561,14 +586,25 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 						if (__any(anyzero) && l == 0) misc->flag = 1;
 					} else {
 						/* ---- serial: feedback recurrence, wosc.h:273-310 ---------- */
-						__syncthreads(); /* scratch may still be read as a slot by a lagging wave */
+						team_sync<V>(); /* scratch may still be read as a slot by a lagging wave */
+						/* everything that does not depend on the feedback is laid out
+						 * first, in parallel: base phases in the scratch slot, the
+						 * self-modulation amounts in a slot (the output slot is free
+						 * until the combine step: its old contents are in dv[]) */
+						const float *pmaS = smS;
+						if (!pmaS) {
+							LineBlock plb;
+							{ LineState t = pls0; plb = line_begin(t, len, false, 0.f); }
+#pragma unroll
+							for (int k = 0; k < T; ++k)
+								if (owned[k]) out[w * G::NP + p0 + k] = line_value(plb, (uint32_t)(jbase + k), 1.f);
+							pmaS = out;
+						}
 #pragma unroll
 						for (int k = 0; k < T; ++k)
 							if (owned[k]) scratch_u[w * G::NP + p0 + k] = ph[k];
-						__syncthreads();
+						team_sync<V>();
 						if (tid == 0 && len > 0) {
-							LineBlock plb;
-							if (sm_inline_active) { LineState t = pls0; plb = line_begin(t, len, false, 0.f); }
 							uint32_t prev_phase = op->prev_phase;
 							double prev_Is = op->prev_Is;
 							float prev_s = op->prev_s, fb_s = op->fb_s;
@@ -580,10 +616,20 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 								prev_Is = Is0;
 								prev_phase = phase00;
 							}
+							/* the loop carries only fb_s -> phase -> table -> sample; the
+							 * next sample's inputs are fetched while it runs */
+							uint32_t e = 1, r = 0; /* entry of sample 0; r counts within a wave's span */
+							float pma_n = pmaS[e];
+							uint32_t base_n = scratch_u[e];
 							for (uint32_t j = 0; j < len; ++j) {
-								const uint32_t e = entry_of<W, T>(j);
-								float pma = smS ? smS[e] : line_value(plb, j, 1.f);
-								uint32_t phase = scratch_u[e] + rint32w(fb_s * pma * 0x1p31f);
+								const float pma = pma_n;
+								const uint32_t base = base_n;
+								const uint32_t e_cur = e;
+								++e;
+								if (++r == (uint32_t)G::NP - 1) { r = 0; ++e; } /* skip the next wave's halo entry */
+								if (j + 1 < len) { pma_n = pmaS[e]; base_n = scratch_u[e]; }
+								const float p = fb_s * pma;
+								const uint32_t phase = base + (fabsf(p) < 0x1p20f ? rint32w_p31_small(p) : rint32w(p * 0x1p31f));
 								int32_t d = (int32_t)(phase - prev_phase);
 								float sv;
 								if (d == 0) {
@@ -593,7 +639,7 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 									sv = wosc_diff(Isv, prev_Is, d, wc.diff_scale, wc.diff_offset);
 									prev_Is = Isv; prev_s = sv; prev_phase = phase;
 								}
-								scratch[e] = sv;
+								scratch[e_cur] = sv;
 								fb_s = (fb_s + sv) * 0.5f;
 							}
 							op->prev_phase = prev_phase;
@@ -601,7 +647,7 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 							op->prev_s = prev_s;
 							op->fb_s = fb_s;
 						}
-						__syncthreads();
+						team_sync<V>();
 #pragma unroll
 						for (int k = 0; k < T; ++k)
 							if (owned[k]) s[k] = scratch[w * G::NP + p0 + k];
@@ -631,7 +677,7 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 					}
 					const unsigned long long incl = wave_incl_scan64(lane_sum, l);
 					if (l == 63) misc->tot64[w] = incl;
-					__syncthreads();
+					team_sync<V>();
 					unsigned long long base = op->cycle_phase;
 #pragma unroll
 					for (int ww = 0; ww < W; ++ww) {
@@ -662,7 +708,7 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 								tmp[w * G::NP + p0 + k] = cyc[k];
 							}
 						}
-						__syncthreads();
+						team_sync<V>();
 						if (tid == 0 && len > 0) {
 							LineBlock plb;
 							if (sm_inline_active) { LineState t = pls0; plb = line_begin(t, len, false, 0.f); }
@@ -683,7 +729,7 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 							op->fb_s = fb_s;
 							op->prev_s = prev_s;
 						}
-						__syncthreads();
+						team_sync<V>();
 #pragma unroll
 						for (int k = 0; k < T; ++k)
 							if (owned[k]) s[k] = scratch[w * G::NP + p0 + k];
@@ -701,7 +747,7 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 						}
 						const uint32_t incl = wave_incl_scan(lane_sum, l);
 						if (l == 63) misc->tot32[w] = incl;
-						__syncthreads();
+						team_sync<V>();
 						uint32_t base = op->noise_prev, grand = 0;
 #pragma unroll
 						for (int ww = 0; ww < W; ++ww) {
@@ -749,15 +795,15 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 				}
 
 				/* ---- barrier A: every read of operator state and input slots is done */
-				__syncthreads();
+				team_sync<V>();
 				if (w_parallel && uni(misc->flag) != 0) {
 					/* rare: dphase == 0 somewhere -> hold the previous output
 					 * (wosc.h:251-252), resolved serially over the block */
-					__syncthreads(); /* all flag reads done before it is cleared below */
+					team_sync<V>(); /* all flag reads done before it is cleared below */
 #pragma unroll
 					for (int k = 0; k < T; ++k)
 						if (owned[k]) scratch_u[w * G::NP + p0 + k] = ph[k];
-					__syncthreads();
+					team_sync<V>();
 					if (tid == 0 && len > 0) {
 						uint32_t prev_phase = op->prev_phase;
 						double prev_Is = op->prev_Is;
@@ -789,7 +835,7 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 						op->prev_s = prev_s;
 						misc->flag = 0;
 					}
-					__syncthreads();
+					team_sync<V>();
 #pragma unroll
 					for (int k = 0; k < T; ++k)
 						if (owned[k]) s[k] = scratch[w * G::NP + p0 + k];
@@ -878,13 +924,13 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 								: (pan_goal ? line_value(plb2, (uint32_t)j, 1.f) : pl.v0);
 					}
 				}
-				__syncthreads();
+				team_sync<V>();
 				if (tid == 0 && !panS) op->line[L_PAN] = pl;
 				produced += len;
 				break;
 			}
 			default:
-				__syncthreads();
+				team_sync<V>();
 				break;
 			}
 
@@ -911,7 +957,7 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 				if (tid == 0 && !inf) op->time -= len;
 			}
 			/* ---- barrier B: stores and write-backs visible to the next step ---- */
-			__syncthreads();
+			team_sync<V>();
 		}
 		done += blen;
 	}
@@ -924,7 +970,7 @@ __global__ void __launch_bounds__(64 * W) render_kernel(RenderParams P) {
 		vo.pan_row = vd.pan_dynamic_row;
 		P.vinfo[vd.out_row] = vo;
 	}
-	__syncthreads();
+	team_sync<V>();
 	for (uint32_t i = tid; i < vd.nops * 64; i += 64 * W)
 		((u32_alias *)&P.ops[my_ids[i >> 6]])[i & 63] = ((const u32_alias *)ops)[i];
 	} /* work list */
@@ -1111,14 +1157,6 @@ __device__ __forceinline__ double lane_prev(double x) {
 	const uint32_t lo = lane_prev((uint32_t)__double2loint(x));
 	const uint32_t hi = lane_prev((uint32_t)__double2hiint(x));
 	return __hiloint2double((int)hi, (int)lo);
-}
-
-/* rint(p * 2^31) wrapped to 32 bits for |p| < 2^20: in f64, p + 1.5 * 2^21
- * has an ulp of 2^-31, so the addition rounds p to a multiple of 2^-31
- * (nearest-even, as llrintf does in the default mode) and leaves that
- * multiple, mod 2^32, in the low word of the significand. */
-__device__ __forceinline__ uint32_t rint32w_p31_small(float p) {
-	return (uint32_t)__double2loint((double)p + 0x1.8p21);
 }
 
 /* Uniform (scalar-cache) load of one decoded step: the address is the same
@@ -1741,6 +1779,9 @@ public:
 		geo_ = (wt && !strcmp(wt, "8x2")) ? 0 : 1; /* default 4 waves x 4 samples per lane */
 		debug_ = getenv("SAU_AMD_DEBUG") != nullptr;
 		fast_enabled_ = getenv("SAU_AMD_NO_FAST") == nullptr;
+		/* voices per segment from which the block loop runs sixteen voices per workgroup (0: never) */
+		multi_min_ = 512;
+		if (const char *mm = getenv("SAU_AMD_MULTI_MIN")) multi_min_ = (uint32_t)atol(mm);
 		if (!ops_.ensure(cfg.op_count ? cfg.op_count : 1, err)) return false;
 		HIP_OK(hipMemsetAsync(ops_.p, 0, ops_.cap * sizeof(DevOp), stream_));
 		/* Hermite coefficient tables from the PILUTs (sau/wave.h:127-141) */
@@ -1802,15 +1843,15 @@ public:
 		return true;
 	}
 
-	template <int W, int T>
-	bool launch_render(const RenderParams &rp, uint32_t n_voices, size_t lds, std::string &err) {
+	template <int W, int T, int V>
+	bool launch_render(const RenderParams &rp, uint32_t grid, size_t lds, std::string &err) {
 		static size_t configured = 0;
 		if (lds > configured) {
-			HIP_OK(hipFuncSetAttribute((const void *)render_kernel<W, T>,
+			HIP_OK(hipFuncSetAttribute((const void *)render_kernel<W, T, V>,
 					hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 			configured = lds;
 		}
-		hipLaunchKernelGGL((render_kernel<W, T>), dim3(n_voices), dim3(64 * W), lds, stream_, rp);
+		hipLaunchKernelGGL((render_kernel<W, T, V>), dim3(grid), dim3(64 * W * V), lds, stream_, rp);
 		HIP_OK(hipGetLastError());
 		return true;
 	}
@@ -1818,21 +1859,35 @@ public:
 	bool render(const SegmentDesc &seg, std::string &err) override {
 		if (!seg.n_voices) return true;
 		++acc_launches_; /* segments rendered */
-		const uint32_t W = geo_ ? 4 : 8, T = geo_ ? 4 : 2;
-		const size_t slot_bytes = (size_t)W * 64 * T * sizeof(float);
-		/* LDS budget: slots + operator cache + misc, rest for tables */
-		size_t fixed = slot_bytes * seg.n_slots + (size_t)seg.max_ops * sizeof(DevOp) + sizeof(Misc) +
-			(size_t)seg.max_steps * sizeof(Step) + 64;
+		const size_t tab_bytes = (size_t)WAVE_LEN * (sizeof(HerpC23) + sizeof(HerpC01));
+		/* Block-loop geometry. Few voices: W waves share one voice (4x4 or 8x2
+		 * frames per lane). Many voices: sixteen single-wave teams per workgroup,
+		 * each with its own voice, so that every CU has 16 voices in flight. */
+		uint32_t W = geo_ ? 4 : 8, T = geo_ ? 4 : 2, V = 1;
+		auto team_size = [&](uint32_t w, uint32_t t) {
+			size_t b = (size_t)w * 64 * t * sizeof(float) * seg.n_slots + (size_t)seg.max_ops * sizeof(DevOp) +
+				sizeof(Misc) + (size_t)seg.max_steps * sizeof(Step) + 64;
+			return (b + 15) & ~(size_t)15;
+		};
+		if (multi_min_ && seg.n_voices >= multi_min_) {
+			const size_t need_tab = seg.wave_mask ? tab_bytes : 0;
+			if (16 * team_size(1, 2) + need_tab <= lds_limit_) { W = 1; T = 2; V = 16; }
+			else if (16 * team_size(1, 1) + need_tab <= lds_limit_) { W = 1; T = 1; V = 16; }
+		}
+		/* LDS budget: slots + operator cache + misc per team, rest for tables */
+		const size_t team_bytes = team_size(W, T);
+		size_t fixed = team_bytes * V;
 		if (fixed > lds_limit_) {
 			err = "voice too large for one workgroup's LDS (block buffers + operator states)";
 			return false;
 		}
 		RenderParams rp;
 		memset(&rp, 0, sizeof rp);
+		rp.team_bytes = (uint32_t)team_bytes;
 		uint32_t n_tabs = 0;
-		const size_t tab_bytes = (size_t)WAVE_LEN * (sizeof(HerpC23) + sizeof(HerpC01));
 		/* keep two workgroups per CU when possible: cap at half the LDS */
 		size_t budget = lds_limit_ / 2 > fixed ? lds_limit_ / 2 - fixed : 0;
+		if (V > 1) budget = lds_limit_ - fixed;
 		if (budget < tab_bytes && lds_limit_ - fixed >= tab_bytes) budget = tab_bytes;
 		for (int wv = 0; wv < 12; ++wv) {
 			rp.tab_of_wave[wv] = -1;
@@ -1945,12 +2000,19 @@ public:
 			/* Block-loop grid: persistent over the device-built work list. When the
 			 * host knows of nothing that needs it (no sweeps, FM, feedback or expiring
 			 * operators), a token grid still serves the rare dphase == 0 bail-out. */
-			block_grid_ = (seg.maybe_block || !use_fast) ? (seg.n_voices < 1024 ? seg.n_voices : 1024) : 16;
+			if (V > 1) {
+				const uint32_t full = (seg.n_voices + V - 1) / V;
+				block_grid_ = (seg.maybe_block || !use_fast) ? (full < 512 ? full : 512) : 2;
+			} else {
+				block_grid_ = (seg.maybe_block || !use_fast) ? (seg.n_voices < 1024 ? seg.n_voices : 1024) : 16;
+			}
 		}
 		TimedPair *tp = timing_on_ ? new_pair(0) : nullptr;
 		if (tp) (void)hipEventRecord(tp->a, stream_);
-		bool ok = geo_ ? launch_render<4, 4>(rp, block_grid_, lds, err)
-		               : launch_render<8, 2>(rp, block_grid_, lds, err);
+		bool ok = V > 1 ? (T == 2 ? launch_render<1, 2, 16>(rp, block_grid_, lds, err)
+		                          : launch_render<1, 1, 16>(rp, block_grid_, lds, err))
+		        : geo_ ? launch_render<4, 4, 1>(rp, block_grid_, lds, err)
+		               : launch_render<8, 2, 1>(rp, block_grid_, lds, err);
 		if (!ok) return false;
 		if (tp) (void)hipEventRecord(tp->b, stream_);
 		if (debug_) debug_dump("after render", seg);
@@ -2108,6 +2170,7 @@ private:
 	DevBuf<FastInfo> finfo_;
 	DevBuf<uint32_t> fdone_, worklist_, work_count_;
 	DevBuf<unsigned char> fsteps_;
+	uint32_t multi_min_ = 512;
 	uint32_t block_grid_ = 1;
 };
 
