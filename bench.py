@@ -21,25 +21,39 @@ sys.path.insert(0, ROOT)
 
 
 def cpu_baseline(tabs, voices):
-    """Oracle (this repo's CPU port of the reference algorithm) on a bounded sample."""
+    """The reference's own generator (oracle/_ref, built from its sources by oracle/Makefile)
+    when that library is present, else this repo's CPU restatement; bounded sample."""
     from oracle import pyoracle as po
     from saugns_amd import voicebank
-    po.oracle_use_tables(tabs)
-    po.oracle().ora_set_fastmath_forms(1)
     prg = voicebank.config3(n=voices, seconds=30)
+    if po.have_ref():
+        kind = "reference"
+        po.ref()
+
+        def render(frames):
+            return po.ref_render(prg.ptr, 44100, False, max_frames=frames, chunk=11289)
+    else:
+        kind = "port"
+        po.oracle_use_tables(tabs)
+        po.oracle().ora_set_fastmath_forms(1)
+
+        def render(frames):
+            return po.oracle_render(prg.ptr, 44100, False, max_frames=frames, chunk=11289)
     # calibrate, then run ~15 s of CPU work
     frames = 11025
     t0 = time.perf_counter()
-    po.oracle_render(prg.ptr, 44100, False, max_frames=frames, chunk=frames)
+    render(frames)
     dt = time.perf_counter() - t0
     frames = int(min(44100 * 20, max(frames, frames * 15.0 / max(dt, 1e-3))))
     t0 = time.perf_counter()
-    po.oracle_render(prg.ptr, 44100, False, max_frames=frames, chunk=11289)
+    render(frames)
     dt = time.perf_counter() - t0
     return {"value": frames / dt, "unit": "mixed mono int16 frames/s", "cores": 1,
-            "kind": "port",
+            "kind": kind,
             "sample": f"config 3 ({voices} voices x depth-3 PM), first {frames} frames "
-                      f"({frames * voices * 4:.3g} operator-samples), {dt:.1f} s on 1 host thread",
+                      f"({frames * voices * 4:.3g} operator-samples), {dt:.1f} s on 1 host thread"
+                      + (" (sauGenerator_run of the compiled reference, -O3 -ffast-math as its Makefile)"
+                         if kind == "reference" else " (oracle/sau_oracle.c)"),
             "operator_samples_per_s": frames * voices * 4 / dt}
 
 

@@ -231,7 +231,7 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 	std::vector<SegmentDesc::Stream> sdescs(streams_.size());
 	uint32_t n_main = 1, n_fpool = 0, max_ops = 1, n_pan = 0, max_steps = 1;
 	uint64_t wave_mask = 0;
-	bool maybe_block = false;
+	bool maybe_block = false, serial = false;
 	for (size_t s = 0; s < streams_.size(); ++s) {
 		Stream &st = streams_[s];
 		SegmentDesc::Stream &sd = sdescs[s];
@@ -272,9 +272,11 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 			wave_mask |= vn.plan.wave_mask;
 			/* will the time-parallel path surely cover this voice's whole run? */
 			if (vn.plan.static_block || vn.plan.no_fast) maybe_block = true;
+			if (vn.plan.selfmod) serial = true;
 			for (uint32_t id : vn.plan.op_ids) {
 				OpMirror &m = st.ops[id];
 				if (m.goal_seen || (m.line_set & (1u << L_PMA))) maybe_block = true;
+				if (m.line_set & (1u << L_PMA)) serial = true;
 				if (id != vn.carr_op && !m.time_inf) {
 					/* conservative mirror: non-carriers tick whenever the voice runs */
 					if (m.time < run_len) maybe_block = true;
@@ -299,6 +301,7 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 	seg.max_steps = max_steps;
 	seg.wave_mask = wave_mask;
 	seg.maybe_block = maybe_block;
+	seg.serial = serial;
 	return backend_->render(seg, err);
 }
 

@@ -46,6 +46,7 @@ struct SegmentDesc {
 	uint32_t n_pan_rows;
 	uint64_t wave_mask;       /* wave ids in use (bit per id) */
 	bool maybe_block;         /* some voice may need the block loop (sweeps, FM, ...) */
+	bool serial;              /* some voice may run a per-sample feedback recurrence (self-modulation) */
 };
 
 struct BackendConfig {
@@ -105,6 +106,7 @@ struct VoicePlan {
 	bool has_camods = false;
 	bool no_fast = false;          /* an operator is evaluated twice per block */
 	bool static_block = false;     /* graph has FM / feedback / R / filtered noise: block loop */
+	bool selfmod = false;          /* a self-modulation amount has modulators of its own */
 };
 
 /* Flatten the graph under `carrier` into steps. Returns false (with err) when

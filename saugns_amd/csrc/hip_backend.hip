@@ -1779,8 +1779,9 @@ public:
 		geo_ = (wt && !strcmp(wt, "8x2")) ? 0 : 1; /* default 4 waves x 4 samples per lane */
 		debug_ = getenv("SAU_AMD_DEBUG") != nullptr;
 		fast_enabled_ = getenv("SAU_AMD_NO_FAST") == nullptr;
-		/* voices per segment from which the block loop runs sixteen voices per workgroup (0: never) */
-		multi_min_ = 512;
+		/* voices per segment from which feedback voices get sixteen one-wave teams per workgroup
+		 * (0: never; 1: always, also without feedback -- tests) */
+		multi_min_ = 256;
 		if (const char *mm = getenv("SAU_AMD_MULTI_MIN")) multi_min_ = (uint32_t)atol(mm);
 		if (!ops_.ensure(cfg.op_count ? cfg.op_count : 1, err)) return false;
 		HIP_OK(hipMemsetAsync(ops_.p, 0, ops_.cap * sizeof(DevOp), stream_));
@@ -1869,7 +1870,7 @@ public:
 				sizeof(Misc) + (size_t)seg.max_steps * sizeof(Step) + 64;
 			return (b + 15) & ~(size_t)15;
 		};
-		if (multi_min_ && seg.n_voices >= multi_min_) {
+		if (multi_min_ && seg.n_voices >= multi_min_ && (seg.serial || multi_min_ == 1)) {
 			const size_t need_tab = seg.wave_mask ? tab_bytes : 0;
 			if (16 * team_size(1, 2) + need_tab <= lds_limit_) { W = 1; T = 2; V = 16; }
 			else if (16 * team_size(1, 1) + need_tab <= lds_limit_) { W = 1; T = 1; V = 16; }
@@ -2170,7 +2171,7 @@ private:
 	DevBuf<FastInfo> finfo_;
 	DevBuf<uint32_t> fdone_, worklist_, work_count_;
 	DevBuf<unsigned char> fsteps_;
-	uint32_t multi_min_ = 512;
+	uint32_t multi_min_ = 256;
 	uint32_t block_grid_ = 1;
 };
 

@@ -238,13 +238,14 @@ bool compile_voice_plan(const std::vector<OpMirror> &ops, uint32_t carrier,
 	/* closed-form (time-parallel) evaluation assumes one visit per operator */
 	out.no_fast = false;
 	out.static_block = false;
+	out.selfmod = false;
 	for (uint32_t id : out.op_ids) {
 		const OpMirror &m = ops[id];
 		if (m.type == SAU_POPT_N_raseg) out.static_block = true;
 		if (m.type == SAU_POPT_N_noise && m.wave == SAU_NOISE_N_re) out.static_block = true;
 	}
 	for (const Step &st : out.steps) {
-		if (st.kind == ST_SMLINE) out.static_block = true;
+		if (st.kind == ST_SMLINE) { out.static_block = true; out.selfmod = true; }
 		if (st.kind == ST_LINE && st.which == L_FREQ && (st.flags & SF_FORCE)) out.static_block = true;
 	}
 	{

@@ -103,3 +103,19 @@ def test_chunk_size_invariance(gpu, oracle):
     a = gpu.Generator(prg, 12000).render(stereo=True, chunk=3072)
     b = gpu.Generator(prg, 12000).render(stereo=True, chunk=997)
     assert max_diff(a, b) == 0
+
+
+@pytest.mark.parametrize("lds_limit", [None, "98304"])
+def test_corpus_single_wave_teams(gpu, lds_limit):
+    """The many-voices block-loop geometry (sixteen one-wave teams per workgroup, two frames
+    per lane, or one when LDS is short) forced onto every corpus script: bit-exact vs the oracle."""
+    import subprocess
+    import sys
+    env = dict(os.environ, SAU_AMD_MULTI_MIN="1")
+    if lds_limit:
+        env["SAU_AMD_LDS_LIMIT"] = lds_limit
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_corpus_check.py")],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.startswith("0 bad of"), out.stdout[-2000:]

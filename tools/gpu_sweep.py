@@ -24,3 +24,26 @@ if "c2b" in which: run("4096 x 1 op (flat)", vb.config2(n=4096, seconds=30))
 if "c3" in which: run("1024 x 4 ops (config 3)", vb.config3(n=1024, seconds=30))
 if "c3x4" in which: run("4096 x 4 ops", vb.config3(n=4096, seconds=30))
 if "c5" in which: run("4096 x 2 ops selfmod (c5)", vb.config5(n=4096, seconds=30), frames=11025, steps=3)
+if "c4" in which:
+    G = os.path.join(ROOT, "tests", "golden", "programs")
+    prgs = [sa.Program.from_image(open(os.path.join(G, f"config4_seed{k % 4}.saup"), "rb").read()) for k in range(64)]
+    b = sa.Batch(prgs, 44100)
+    frames, steps = 44100, 6
+    for _ in range(2): b.run(frames, fetch=False)
+    b.sync(); b.timing(reset=True); b.set_timing(int(os.environ.get("TLEVEL", "2")))
+    t0 = time.perf_counter()
+    for _ in range(steps): b.run(frames, fetch=False)
+    b.sync(); dt = time.perf_counter() - t0
+    t = b.timing_ex(); n = max(1, t["segments"])
+    print(f"config 4: 64 renders        wall {dt/steps*1e3:7.3f} ms/step  segs/step {n/steps:.1f} fast {t['fast_ms']/steps:6.3f}  block {t['block_ms']/steps:6.3f}  mix {t['mix_ms']/steps:6.3f}  aux {t['aux_ms']/steps:6.3f} ms/step -> {64*frames*steps/dt:10.3e} frames/s total")
+if "c3s" in which:
+    from saugns_amd.voicebank import Op, Line, build_program, _f32, _num
+    from saugns_amd.api import POP_PMOD
+    voices = []
+    for i in range(1024):
+        m3 = Op("sin", freq=Line(float(3 + i % 4), ratio=True), amp=_f32(0.4))
+        m2 = Op("sin", freq=Line(float(2 + i % 3), ratio=True), amp=_f32(0.7), mods={POP_PMOD: [m3]})
+        m1 = Op("sin", freq=Line(float(1 + i % 5), ratio=True), amp=_num(".2f", 0.5 + (i % 7) * 0.1), mods={POP_PMOD: [m2]})
+        voices.append(Op("sin", freq=_num(".4f", 110.0 + i * 0.731), time_ms=30000,
+                         amp=Line(1.0, goal=_f32(0.2), shape="lin"), mods={POP_PMOD: [m1]}))
+    run("1024 x 4 ops, amp sweep", build_program(voices), frames=44100, steps=4)
