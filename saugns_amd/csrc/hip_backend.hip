@@ -1000,6 +1000,7 @@ struct FastInfo {
 };
 
 struct FastStep;
+struct FastLine;
 struct FastParams {
 	const VoiceDesc *voices;
 	const Step *steps;
@@ -1015,6 +1016,7 @@ struct FastParams {
 	const HerpC23 *g_c23;
 	const HerpC01 *g_c01;
 	FastStep *fsteps;     /* [n_voices][max_steps], written by decode_kernel */
+	FastLine *flines;     /* same indexing: the ramp of a step whose line is in progress */
 	uint32_t row_stride, n_voices, n_main, max_ops, max_steps, n_tabs, np;
 	uint32_t enable;      /* 0: leave every voice to the block loop */
 	int8_t tab_of_wave[12];
@@ -1031,8 +1033,11 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 	uint32_t min_time = 0xFFFFFFFFu;
 	for (uint32_t i = 0; i < vd.nops; ++i) {
 		DevOp &o = P.ops[ids[i]];
+		/* ramps in progress: amplitude lines are closed-form per frame (sau/line.c
+		 * fills depend on the position only); frequency ramps need a phase scan,
+		 * self-modulation and pan ramps stay with the block loop */
 		for (uint32_t ln = 0; ln < L_COUNT; ++ln)
-			if (o.line[ln].flags & LP_GOAL) bad = true;
+			if ((o.line[ln].flags & LP_GOAL) && ln != L_AMP && ln != L_AMP2) bad = true;
 		if (o.type == OT_RASEG) bad = true;
 		if (o.type == OT_NOISE && o.wave == NZ_re) bad = true;
 		if (o.line[L_PMA].v0 != 0.f) bad = true; /* self-modulation is a recurrence */
@@ -1086,9 +1091,19 @@ struct FastStep {
 	uint32_t gop;       /* global operator index (state staging) */
 	double prev_Is;
 	float pan;
-	uint32_t pad;
+	uint32_t ramp;      /* nonzero: the step's line is a ramp in progress, see FastLine */
 };
 static_assert(sizeof(FastStep) == 80, "FastStep is 20 dwords");
+
+/* A line block over the whole segment (line_begin): frames [0, goal_len)
+ * follow the sweep, later ones hold. */
+struct FastLine {
+	Sweep sw;
+	uint32_t goal_len;
+	float hold;
+	uint32_t pad;
+};
+static_assert(sizeof(FastLine) == 48, "FastLine is 12 dwords");
 
 __device__ __forceinline__ FastStep uni(const FastStep &f) {
 	union { FastStep s; uint32_t u[20]; } c; c.s = f;
@@ -1111,6 +1126,7 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 	/* lane si handles step si (plan_len <= 64) */
 	bool keep = false;
 	FastStep f;
+	FastLine fl;
 	uint32_t dep = 0;
 	if ((uint32_t)l < vd.plan_len) {
 		const Step *plan = P.steps + vd.plan_ofs;
@@ -1142,10 +1158,24 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 		f.gop = ids[st.op];
 		f.prev_Is = o.prev_Is;
 		f.pan = o.line[L_PAN].v0;
-		f.pad = 0;
+		f.ramp = 0;
+		{
+			const bool line_step = st.kind == ST_LINE && st.which != L_FREQ;
+			const bool amp_inline = st.kind == ST_OSC && st.amp == NO_SLOT;
+			LineState ls = o.line[line_step ? st.which : L_AMP];
+			if ((line_step || amp_inline) && (ls.flags & LP_GOAL)) {
+				const LineBlock lb = line_begin(ls, P.info[v].total, false, 0.f);
+				fl.sw = lb.sw; fl.goal_len = lb.goal_len; fl.hold = lb.hold; fl.pad = 0;
+				f.ramp = 1;
+			}
+		}
 	}
 	const unsigned long long m = __ballot(keep);
-	if (keep) fsteps[__popcll(m & ((1ull << l) - 1ull))] = f;
+	if (keep) {
+		const uint32_t pos = (uint32_t)__popcll(m & ((1ull << l) - 1ull));
+		fsteps[pos] = f;
+		if (f.ramp) P.flines[(size_t)v * P.max_steps + pos] = fl;
+	}
 	if (l == 0) P.info[v].n_fsteps = (uint32_t)__popcll(m);
 }
 
@@ -1181,6 +1211,19 @@ __device__ __forceinline__ FastStep load_step_uniform(const FastStep *p) {
 #ifndef FK_PREFETCH
 #define FK_PREFETCH 0 /* loading the next step early measured 6 % slower (SGPR pressure) */
 #endif
+__device__ __forceinline__ FastLine load_line_uniform(const FastLine *p) {
+	const_u32_ptr q = (const_u32_ptr)(uintptr_t)p;
+	union { FastLine s; uint32_t u[12]; } c;
+#pragma unroll
+	for (int i = 0; i < 12; ++i) c.u[i] = q[i];
+	return c.s;
+}
+/* value of a ramp at frame t of the segment (lead-in frames t < 0 get the hold value: unused) */
+__device__ __forceinline__ float fast_line_value(const FastLine &fl, int t) {
+	const uint32_t i = (uint32_t)t;
+	return i < fl.goal_len ? sweep_value_inl(fl.sw, i) : fl.hold;
+}
+
 template <int T>
 __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 	constexpr int NP = 64 * T;
@@ -1225,6 +1268,7 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 
 		const uint32_t n_fsteps = uni(fi.n_fsteps);
 		const FastStep *fsteps = P.fsteps + (size_t)v * P.max_steps;
+		const FastLine *flines = P.flines + (size_t)v * P.max_steps;
 		float *vrow = P.vout + (size_t)vd.out_row * P.row_stride;
 		float *prow = (vd.pan_dynamic_row != ~0u) ? P.pan + (size_t)vd.pan_dynamic_row * P.row_stride : nullptr;
 		/* A wave renders T rows at a time; a row is 64 consecutive frames, one per
@@ -1474,6 +1518,10 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 					if (f.amp_off != ~0u) {
 #pragma unroll
 						for (int k = 0; k < T; ++k) r[k] = slots[f.amp_off + k * 64];
+					} else if (f.ramp) { /* amplitude ramp in progress, sau/line.c:65-281 */
+						const FastLine fl = load_line_uniform(flines + si);
+#pragma unroll
+						for (int k = 0; k < T; ++k) r[k] = fast_line_value(fl, t0 + k * (int)C);
 					} else {
 #pragma unroll
 						for (int k = 0; k < T; ++k) r[k] = f.ac;
@@ -1501,8 +1549,14 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 					}
 				} else if (kind == ST_LINE) {
 					/* held line: v0 (sau/line.c:435-442); ratio lines only exist for freq */
+					if (f.ramp) {
+						const FastLine fl = load_line_uniform(flines + si);
 #pragma unroll
-					for (int k = 0; k < T; ++k) slots[f.out_off + k * 64] = f.ac;
+						for (int k = 0; k < T; ++k) slots[f.out_off + k * 64] = fast_line_value(fl, t0 + k * (int)C);
+					} else {
+#pragma unroll
+						for (int k = 0; k < T; ++k) slots[f.out_off + k * 64] = f.ac;
+					}
 				} else if (kind == ST_LERP) { /* generator.c:466-467 */
 #pragma unroll
 					for (int k = 0; k < T; ++k) {
@@ -1545,7 +1599,8 @@ __global__ void __launch_bounds__(64) finalize_kernel(FastParams P) {
 		if (!(o.flags & OPF_TIME_INF)) o.time -= total;
 		for (uint32_t ln = 0; ln < L_COUNT; ++ln) {
 			LineState ls = o.line[ln];
-			line_advance_hold(ls, total);
+			if (ls.flags & LP_GOAL) (void)line_begin(ls, total, false, 0.f); /* amplitude ramps */
+			else line_advance_hold(ls, total);
 			o.line[ln] = ls;
 		}
 		if (o.type == OT_WAVE) {
@@ -1947,14 +2002,15 @@ public:
 			const bool use_fast = fast_enabled_ && (16 * area + 1024 <= lds_limit_);
 			if (!finfo_.ensure(seg.n_voices, err) || !fdone_.ensure(seg.n_voices, err) ||
 			    !worklist_.ensure(seg.n_voices, err) || !work_count_.ensure(4, err) ||
-			    !fsteps_.ensure((size_t)seg.n_voices * fmax_steps * sizeof(FastStep), err)) return false;
+			    !fsteps_.ensure((size_t)seg.n_voices * fmax_steps * sizeof(FastStep), err) ||
+			    !flines_.ensure((size_t)seg.n_voices * fmax_steps * sizeof(FastLine), err)) return false;
 			HIP_OK(hipMemsetAsync(work_count_.p, 0, sizeof(uint32_t), stream_));
 			FastParams fp;
 			memset(&fp, 0, sizeof fp);
 			fp.voices = voices_.p; fp.steps = steps_.p; fp.op_ids = op_ids_.p; fp.ops = ops_.p;
 			fp.vout = vout_.p; fp.pan = pan_.p; fp.info = finfo_.p; fp.fast_done = fdone_.p;
 			fp.worklist = worklist_.p; fp.work_count = work_count_.p; fp.vinfo = vinfo_.p;
-			fp.g_c23 = c23_.p; fp.g_c01 = c01_.p; fp.fsteps = (FastStep *)fsteps_.p;
+			fp.g_c23 = c23_.p; fp.g_c01 = c01_.p; fp.fsteps = (FastStep *)fsteps_.p; fp.flines = (FastLine *)flines_.p;
 			fp.row_stride = row_stride_; fp.n_voices = seg.n_voices; fp.n_main = seg.n_main;
 			fp.max_ops = seg.max_ops; fp.max_steps = fmax_steps; fp.np = 64;
 			fp.enable = use_fast ? 1u : 0u;
@@ -2170,7 +2226,7 @@ private:
 	int timing_level_ = 2;
 	DevBuf<FastInfo> finfo_;
 	DevBuf<uint32_t> fdone_, worklist_, work_count_;
-	DevBuf<unsigned char> fsteps_;
+	DevBuf<unsigned char> fsteps_, flines_;
 	uint32_t multi_min_ = 256;
 	uint32_t block_grid_ = 1;
 };

@@ -219,7 +219,7 @@ SAU_HD_CALL Sweep sweep_setup(uint32_t type, float v0, float vt, uint32_t pos, u
 
 /* Value of sample i of the block (i + pos inside the sweep), before any
  * ratio multiplication. sau/line.c:27-37,65-281 in ref-build forms. */
-SAU_HD_CALL float sweep_value(const Sweep &s, uint32_t i) {
+SAU_HD float sweep_value_inl(const Sweep &s, uint32_t i) {
 	switch (s.type) {
 	default:
 	case LN_sah: return s.v0;
@@ -262,6 +262,8 @@ SAU_HD_CALL float sweep_value(const Sweep &s, uint32_t i) {
 	}
 	}
 }
+
+SAU_HD_CALL float sweep_value(const Sweep &s, uint32_t i) { return sweep_value_inl(s, i); }
 
 /* ---- ramp state machine -------------------------------------------------- */
 
