@@ -126,7 +126,7 @@ def main():
         # cannot be collected from inside this process, so null when the workload differs
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_b_pmc_summary.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_c_pmc_summary.json")))
             wl = pmc["workload"]
             if wl["voices"] == args.voices and wl["frames_per_step"] == args.frames:
                 traffic = pmc["kernels"]["sauhip::fast_kernel<4>"]["hbm_bytes_per_launch_corrected"]
