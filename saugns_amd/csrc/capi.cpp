@@ -4,7 +4,9 @@
 #include "hip_backend.h"
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include <string>
+#include <vector>
 
 using sauengine::Backend;
 using sauengine::Engine;
@@ -24,8 +26,19 @@ struct sauAmdBatch {
 	sauhip::HipBackend *hip; /* NULL when a test backend was injected */
 };
 
+/* The drop-in generator renders ahead of its caller: the reference host asks
+ * for 11289 frames at a time (saugns.c:589-618), and a device round trip per
+ * such call would cost more than the rendering. Output does not depend on how
+ * the stream is cut into calls (as in the reference), so the PCM of one larger
+ * engine run is handed out piecewise. SAU_AMD_READAHEAD=<frames> sets the
+ * size, 0 turns it off. */
 struct sauGenerator {
 	sauAmdBatch batch;
+	std::vector<int16_t> ahead;
+	size_t ahead_frames = 176400; /* frames per engine run */
+	size_t pos = 0, len = 0;      /* unread part of `ahead`, in frames */
+	bool ahead_stereo = false;
+	bool more = true;             /* the engine has signal left after `ahead` */
 };
 
 /* sau/generator/noise.h:18-21 */
@@ -53,6 +66,7 @@ extern "C" sauGenerator *sau_create_Generator(const sauProgram *prg, uint32_t sr
 	if (!prg) return nullptr;
 	sauGenerator *g = new sauGenerator();
 	if (!make_batch(g->batch, &prg, 1, srate, nullptr)) { delete g; return nullptr; }
+	if (const char *ra = getenv("SAU_AMD_READAHEAD")) g->ahead_frames = (size_t)atol(ra);
 	return g;
 }
 
@@ -62,21 +76,60 @@ extern "C" void sau_destroy_Generator(sauGenerator *o) {
 	delete o;
 }
 
+static bool generator_fail(sauGenerator *o, int16_t *buf, size_t buf_len, bool stereo,
+		size_t *out_len, const std::string &err) {
+	/* the reference cannot fail here: report, give silence, end */
+	report("generator", err);
+	memset(buf, 0, sizeof(int16_t) * buf_len * (stereo ? 2 : 1));
+	if (out_len) *out_len = 0;
+	o->more = false; o->pos = o->len = 0;
+	return false;
+}
+
 extern "C" bool sauGenerator_run(sauGenerator *o, int16_t *buf, size_t buf_len,
 		bool stereo, size_t *out_len) {
-	bool more = false;
-	size_t len = 0;
 	std::string err;
-	int16_t *bufs[1] = {buf};
-	if (!o->batch.engine->run(bufs, buf_len, stereo, &more, &len, err)) {
-		/* the reference cannot fail here: report, give silence, end */
-		report("generator", err);
-		memset(buf, 0, sizeof(int16_t) * buf_len * (stereo ? 2 : 1));
-		if (out_len) *out_len = 0;
-		return false;
+	const size_t ch = stereo ? 2 : 1;
+	if (o->pos == o->len && (o->ahead_frames == 0 || buf_len >= o->ahead_frames)) {
+		/* nothing buffered and the call is large: render straight into the caller's buffer */
+		bool more = false;
+		size_t len = 0;
+		int16_t *bufs[1] = {buf};
+		if (!o->more) { memset(buf, 0, sizeof(int16_t) * buf_len * ch); if (out_len) *out_len = 0; return false; }
+		if (!o->batch.engine->run(bufs, buf_len, stereo, &more, &len, err))
+			return generator_fail(o, buf, buf_len, stereo, out_len, err);
+		o->more = more;
+		if (out_len) *out_len = len;
+		return more;
 	}
-	if (out_len) *out_len = len;
-	return more;
+	size_t filled = 0;
+	while (filled < buf_len) {
+		if (o->pos == o->len) {
+			if (!o->more) break;
+			const size_t big = buf_len > o->ahead_frames ? buf_len : o->ahead_frames;
+			o->ahead.resize(big * ch);
+			o->ahead_stereo = stereo;
+			bool more = false;
+			size_t len = 0;
+			int16_t *bufs[1] = {o->ahead.data()};
+			if (!o->batch.engine->run(bufs, big, stereo, &more, &len, err))
+				return generator_fail(o, buf, buf_len, stereo, out_len, err);
+			o->pos = 0; o->len = len; o->more = more;
+			if (len == 0) break;
+		} else if (o->ahead_stereo != stereo) {
+			return generator_fail(o, buf, buf_len, stereo, out_len,
+					"channel layout changed between calls while frames were buffered");
+		}
+		size_t n = o->len - o->pos;
+		if (n > buf_len - filled) n = buf_len - filled;
+		memcpy(buf + filled * ch, o->ahead.data() + o->pos * ch, n * ch * sizeof(int16_t));
+		filled += n;
+		o->pos += n;
+	}
+	if (filled < buf_len) /* generator.c:911-914: the rest of the buffer is silence */
+		memset(buf + filled * ch, 0, (buf_len - filled) * ch * sizeof(int16_t));
+	if (out_len) *out_len = filled;
+	return o->more || o->pos < o->len;
 }
 
 extern "C" sauAmdBatch *sauAmd_create_Batch(const sauProgram *const *prgs, size_t n,

@@ -47,3 +47,17 @@ if "c3s" in which:
         voices.append(Op("sin", freq=_num(".4f", 110.0 + i * 0.731), time_ms=30000,
                          amp=Line(1.0, goal=_f32(0.2), shape="lin"), mods={POP_PMOD: [m1]}))
     run("1024 x 4 ops, amp sweep", build_program(voices), frames=44100, steps=4)
+if "dropin" in which:
+    # the drop-in API exactly as the reference host drives it (saugns.c:589-618): 11289-frame calls,
+    # PCM copied to a host buffer every call
+    for chunk in (11289, 44100, 176400):
+        g = sa.Generator(vb.config3(n=1024, seconds=20), 44100)
+        buf = np.zeros(chunk, np.int16)
+        g.run(buf, chunk)
+        t0 = time.perf_counter(); n = 0
+        while n < 44100 * 8:
+            more, got = g.run(buf, chunk); n += got
+            if not more: break
+        dt = time.perf_counter() - t0
+        print(f"drop-in API, config 3, {chunk:6d}-frame calls: {n/dt:10.3e} frames/s ({dt/(n/chunk)*1e3:.3f} ms per call)")
+        g.close()
