@@ -1,0 +1,87 @@
+"""End-to-end drop-in check: one C host source, two link lines.
+
+Needs the compiled reference library (oracle/_ref/libsau_ref.so, built by oracle/Makefile
+from the reference's own sources; it travels to the GPU box) for its parser and as the
+CPU generator to compare with."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref")
+LIBDIR = os.path.join(ROOT, "saugns_amd")
+
+SCRIPTS = [
+    "Wsin",
+    "Wsin f220 t0.5 p[Wsin r2 a0.8 p[Wtri r3 a0.3]]",
+    "Wsaw f110 t0.4 a0.5[g0 lxpe] c-0.5[g0.5 llin]",
+    "Wsin f330 t0.3 f[Wsin f5 a20] a.r0.2[Wsin f7]",
+    "Wsin f200[g400 lexp] t0.5 p.a0.5",
+    "Rcos f40 t0.5 a0.6\nNwh t0.25 a0.1",
+]
+
+
+def _build(tmp, name, libs):
+    exe = os.path.join(tmp, name)
+    cmd = ["gcc", "-O1", "-o", exe, os.path.join(ROOT, "tests", "dropin", "host.c")] + libs
+    subprocess.check_call(cmd)
+    return exe
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "libsau_ref.so")),
+                    reason="compiled reference library not present")
+def test_same_host_two_link_lines(tmp_path, sa):
+    tmp = str(tmp_path)
+    rpath = ["-Wl,-rpath," + LIBDIR, "-Wl,-rpath," + REF]
+    gpu_exe = _build(tmp, "host_gpu", ["-L" + LIBDIR, "-lsaugns_amd", "-L" + REF, "-lsau_ref", "-lm"] + rpath)
+    cpu_exe = _build(tmp, "host_cpu", ["-L" + REF, "-lsau_ref", "-lm"] + rpath)
+    # the GPU host must resolve the generator to this repo's library
+    dbg = subprocess.run(["ldd", gpu_exe], capture_output=True, text=True).stdout
+    assert "libsaugns_amd.so" in dbg
+    for script in SCRIPTS:
+        for mode in ("mono", "stereo"):
+            env = dict(os.environ, LD_DEBUG="bindings", LD_DEBUG_OUTPUT=os.path.join(tmp, "ldd"))
+            got = subprocess.run([gpu_exe, script, mode], capture_output=True, env=env, timeout=300)
+            want = subprocess.run([cpu_exe, script, mode], capture_output=True, timeout=300)
+            assert got.returncode == 0, got.stderr[-2000:]
+            assert want.returncode == 0, want.stderr[-2000:]
+            g = np.frombuffer(got.stdout, np.int16).astype(np.int32)
+            w = np.frombuffer(want.stdout, np.int16).astype(np.int32)
+            assert len(g) == len(w) and len(w) > 0, (script, mode, len(g), len(w))
+            assert np.abs(g - w).max() <= 1, (script, mode)  # north star: +-1 LSB
+    # the dynamic linker's own record: sau_create_Generator bound into libsaugns_amd.so
+    bound = ""
+    for f in os.listdir(tmp):
+        if f.startswith("ldd."):
+            bound += open(os.path.join(tmp, f), errors="replace").read()
+    assert any("sau_create_Generator" in ln and "libsaugns_amd.so" in ln.split(" to ")[-1]
+               for ln in bound.splitlines() if " to " in ln)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "libsau_ref.so")),
+                    reason="compiled reference library not present")
+def test_link_order_binds_generator_here(tmp_path):
+    """No GPU needed: with this library ahead of the reference's in the link line, the host's
+    generator calls and the reference parser's sauNoise_names bind to this library; without a
+    GPU the constructor then fails loudly (NULL -> host exits 1), it never falls back to a CPU."""
+    from saugns_amd.build import build as build_lib
+    build_lib()
+    tmp = str(tmp_path)
+    rpath = ["-Wl,-rpath," + LIBDIR, "-Wl,-rpath," + REF]
+    exe = _build(tmp, "host_gpu", ["-L" + LIBDIR, "-lsaugns_amd", "-L" + REF, "-lsau_ref", "-lm"] + rpath)
+    env = dict(os.environ, LD_DEBUG="bindings", LD_DEBUG_OUTPUT=os.path.join(tmp, "ldd"))
+    run = subprocess.run([exe, "Wsin", "mono"], capture_output=True, env=env, timeout=300)
+    log = "".join(open(os.path.join(tmp, f), errors="replace").read()
+                  for f in os.listdir(tmp) if f.startswith("ldd."))
+
+    def bound_to(sym):
+        return [ln.split(" to ")[-1] for ln in log.splitlines() if "`%s'" % sym in ln and " to " in ln]
+    assert any("libsaugns_amd.so" in t for t in bound_to("sau_create_Generator"))
+    assert all("libsaugns_amd.so" in t for t in bound_to("sauNoise_names"))
+    import torch
+    if not torch.cuda.is_available():
+        assert run.returncode == 1 and len(run.stdout) == 0
+        assert b"no CPU fallback" in run.stderr
