@@ -74,11 +74,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    os.environ.setdefault("SAU_AMD_DEVICE", str(local_rank))
-    torch.cuda.set_device(local_rank)
+    # one process per GPU; SAU_BENCH_BACKEND=gloo lets the N>1 logic be exercised on a box with
+    # fewer GPUs than ranks (ranks then share devices; rendezvous and reductions on the CPU)
+    backend = os.environ.get("SAU_BENCH_BACKEND", "nccl")
+    dev = local_rank % max(1, torch.cuda.device_count())
+    os.environ.setdefault("SAU_AMD_DEVICE", str(dev))
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
 
     import saugns_amd as sa
     from saugns_amd import voicebank
@@ -108,7 +115,7 @@ def main():
     dt = time.perf_counter() - t0
     tm = batch.timing_ex()
     if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
