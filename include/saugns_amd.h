@@ -104,6 +104,15 @@ SAU_AMD_API size_t sauAmd_program_serialize(const sauProgram *prg, void *buf, si
 SAU_AMD_API sauProgram *sauAmd_program_load(const void *image, size_t len);
 SAU_AMD_API void sauAmd_program_free(sauProgram *prg);
 
+/* Output stage (replaces the reference's player/sndfile.c:125-210 writer fed
+ * from Player_run's chunk loop, saugns.c:589-618): render prg to a sound file.
+ * format as SGS_SNDFILE_* (player/sndfile.h:21-26); channels 1 or 2. The file
+ * is byte-identical to what the reference writer produces from the same PCM.
+ * *frames_out (may be NULL) = frames written. False on failure. */
+enum { SAU_AMD_SNDFILE_RAW = 0, SAU_AMD_SNDFILE_AU = 1, SAU_AMD_SNDFILE_WAV = 2 };
+SAU_AMD_API bool sauAmd_render_file(const sauProgram *prg, uint32_t srate, const char *path,
+		int format, int channels, uint64_t *frames_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -173,6 +173,48 @@ def oracle_render(prg, srate=44100, stereo=False, chunk=11289, max_frames=0, blo
                    chunk, max_frames, post)
 
 
+def oracle_sndfile_bytes(fmt, channels, srate, pcm):
+    """Restatement of the reference's sound file writer (player/sndfile.c): the bytes of a
+    raw (0) / AU (1) / WAV (2) file holding interleaved int16 ``pcm``.
+
+    AU: ".snd", header size 28, size field, encoding 3, rate, channels, 4 zero bytes, all
+    big-endian (63-72), samples byte-swapped (160-168); on close the size field receives the
+    FRAME count (74-80: it stores o->samples, not a byte count) unless that is >= 2^32-1.
+    WAV: canonical 44-byte PCM header, little-endian (82-99), RIFF size 36 + bytes and data
+    size = channels * frames * 2 as uint32 (101-109)."""
+    import struct
+    pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+    frames = len(pcm) // channels
+    if fmt == 0:
+        return pcm.astype("<i2").tobytes()
+    if fmt == 1:
+        size = frames if frames < 0xFFFFFFFF else 0xFFFFFFFF
+        return b".snd" + struct.pack(">IIIIII", 28, size, 3, srate, channels, 0) + pcm.astype(">i2").tobytes()
+    nbytes = (channels * frames * 2) & 0xFFFFFFFF
+    return (b"RIFF" + struct.pack("<I", (36 + nbytes) & 0xFFFFFFFF) + b"WAVE" + b"fmt " +
+            struct.pack("<IHHIIHH", 16, 1, channels, srate, channels * srate * 2, channels * 2, 16) +
+            b"data" + struct.pack("<I", nbytes) + pcm.astype("<i2").tobytes())
+
+
+def ref_write_sndfile(path, fmt, channels, srate, pcm, chunk=11289):
+    """Write ``pcm`` with the reference's own writer (player/sndfile.c in oracle/_ref)."""
+    lib = ref()
+    lib.SGS_create_SndFile.restype = C.c_void_p
+    lib.SGS_create_SndFile.argtypes = [C.c_char_p, C.c_uint, C.c_uint16, C.c_uint32]
+    lib.SGS_SndFile_write.restype = C.c_bool
+    lib.SGS_SndFile_write.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    lib.SGS_close_SndFile.argtypes = [C.c_void_p]
+    f = lib.SGS_create_SndFile(os.fsencode(path), fmt, channels, srate)
+    if not f:
+        raise RuntimeError("SGS_create_SndFile failed")
+    pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+    frames = len(pcm) // channels
+    for i in range(0, frames, chunk):
+        part = pcm[i * channels:(i + chunk) * channels].copy()  # the writer swaps in place
+        lib.SGS_SndFile_write(f, part.ctypes.data, len(part) // channels)
+    lib.SGS_close_SndFile(f)
+
+
 def oracle_use_tables(tables):
     """Give the oracle the reference's PILUTs ((12, 2048) float32)."""
     t = np.ascontiguousarray(tables, dtype=np.float32)

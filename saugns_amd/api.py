@@ -98,6 +98,12 @@ def lib():
     L.sauAmd_create_Batch_with_backend.argtypes = [C.POINTER(C.c_void_p), C.c_size_t,
                                                    C.c_uint32, C.c_void_p]
     L.sauAmd_destroy_Batch.argtypes = [C.c_void_p]
+    L.sauAmd_render_file.restype = C.c_bool
+    L.sauAmd_render_file.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_int, C.c_int,
+                                     C.POINTER(C.c_uint64)]
+    L.sauAmd_render_file_with_backend.restype = C.c_bool
+    L.sauAmd_render_file_with_backend.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_int, C.c_int,
+                                                  C.c_void_p, C.POINTER(C.c_uint64)]
     L.sauAmd_Batch_run.restype = C.c_bool
     L.sauAmd_Batch_run.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.c_bool,
                                    C.POINTER(C.c_bool), C.POINTER(C.c_size_t)]
@@ -132,6 +138,23 @@ def set_piluts(tables):
     t = np.ascontiguousarray(tables, dtype=np.float32)
     assert t.shape == (12, 2048)
     lib().sauAmd_set_piluts(t.ctypes.data)
+
+
+SNDFILE_RAW, SNDFILE_AU, SNDFILE_WAV = 0, 1, 2
+
+
+def render_file(program, srate, path, fmt=SNDFILE_WAV, channels=1, backend=None):
+    """sauAmd_render_file: render a whole program into a raw/AU/WAV file -> frames written.
+    ``backend`` (tests): a sauengine::Backend* to run the same output stage without a GPU."""
+    n = C.c_uint64()
+    if backend is None:
+        ok = lib().sauAmd_render_file(program.ptr, srate, os.fsencode(path), fmt, channels, C.byref(n))
+    else:
+        ok = lib().sauAmd_render_file_with_backend(program.ptr, srate, os.fsencode(path), fmt,
+                                                   channels, backend, C.byref(n))
+    if not ok:
+        raise RuntimeError("sauAmd_render_file failed: " + last_error())
+    return n.value
 
 
 def get_piluts():

@@ -294,7 +294,7 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 	if (descs.empty()) return true;
 	out_dirty_ = true;
 	SegmentDesc seg;
-	seg.len = len; seg.pcm_offset = offset; seg.stereo = stereo;
+	seg.len = len; seg.pcm_offset = offset; seg.stereo = stereo; seg.swap_bytes = pcm_swap_;
 	seg.voices = descs.data(); seg.n_voices = (uint32_t)descs.size();
 	seg.streams = sdescs.data(); seg.n_streams = (uint32_t)sdescs.size();
 	seg.n_slots = n_main + n_fpool; seg.n_main = n_main; seg.max_ops = max_ops; seg.n_pan_rows = n_pan;

@@ -16,6 +16,7 @@
 #include "sau_dev_types.h"
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 
@@ -28,6 +29,7 @@ struct SegmentDesc {
 	uint32_t len;             /* frames */
 	uint32_t pcm_offset;      /* frame offset into each stream's PCM row */
 	bool stereo;
+	bool swap_bytes;          /* store PCM big-endian (AU files, player/sndfile.c:160-168) */
 	/* active voices of all streams, ascending (stream, voice id) */
 	const VoiceDesc *voices;
 	uint32_t n_voices;
@@ -79,6 +81,14 @@ public:
 	/* device address of stream s PCM row, or NULL (test backends) */
 	virtual const int16_t *device_pcm(uint32_t stream) = 0;
 	virtual bool sync(std::string &err) = 0;
+	/* Output stage: queue a copy of stream s PCM [0, frames) into host memory from
+	 * alloc_host(); `slot` (0 or 1) names the copy for wait_fetch(). Later device
+	 * work is ordered behind the copy. Defaults suit CPU test backends. */
+	virtual bool fetch_pcm_async(uint32_t stream, int16_t *dst, uint32_t frames, bool stereo,
+			int slot, std::string &err) { (void)slot; return fetch_pcm(stream, dst, frames, stereo, err); }
+	virtual bool wait_fetch(int slot, std::string &err) { (void)slot; (void)err; return true; }
+	virtual void *alloc_host(size_t bytes) { return malloc(bytes); }
+	virtual void free_host(void *p) { free(p); }
 };
 
 /* ---- plan compiler (plan.cpp) -------------------------------------------- */
@@ -128,6 +138,8 @@ public:
 	bool run(int16_t *const *host_bufs, size_t buf_len, bool stereo,
 			bool *more, size_t *out_len, std::string &err);
 
+	/* PCM is produced byte-swapped from the next run on (AU output) */
+	void set_pcm_byteswap(bool on) { pcm_swap_ = on; }
 	size_t n_streams() const { return streams_.size(); }
 	Backend *backend() { return backend_; }
 	uint64_t frames_done() const { return frames_done_; }
@@ -170,6 +182,7 @@ private:
 	uint32_t total_ops_ = 0, total_voices_ = 0;
 	uint32_t reserved_frames_ = 0;
 	bool reserved_stereo_ = false;
+	bool pcm_swap_ = false;
 	bool plans_dirty_ = true;
 	/* concatenated plans as uploaded; per (stream,voice) offsets */
 	std::vector<Step> all_steps_;

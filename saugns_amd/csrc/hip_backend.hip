@@ -1645,6 +1645,7 @@ struct MixParams {
 	uint32_t row_stride;
 	uint32_t pcm_offset;
 	uint32_t stereo;
+	uint32_t swap_bytes; /* big-endian PCM for AU files (player/sndfile.c:160-168) */
 };
 
 /* generator.c:749-825: ordered voice sum (ref-build association) and PCM.
@@ -1729,10 +1730,12 @@ __global__ void __launch_bounds__(256) mix_kernel(MixParams P) {
 	if (!act) return;
 	if (P.stereo) {
 		int16_t *d = ms.pcm + 2 * (size_t)(P.pcm_offset + i);
-		d[0] = pcm16(L);
-		d[1] = pcm16(R);
+		const int16_t l16 = pcm16(L), r16 = pcm16(R);
+		d[0] = P.swap_bytes ? pcm_swap(l16) : l16;
+		d[1] = P.swap_bytes ? pcm_swap(r16) : r16;
 	} else {
-		ms.pcm[P.pcm_offset + i] = pcm16((L + R) * 0.5f);
+		const int16_t m16 = pcm16((L + R) * 0.5f);
+		ms.pcm[P.pcm_offset + i] = P.swap_bytes ? pcm_swap(m16) : m16;
 	}
 }
 
@@ -2078,6 +2081,7 @@ public:
 			mp.streams = mstreams_.p; mp.vout = vout_.p; mp.pan = pan_.p; mp.vinfo = vinfo_.p;
 			mp.row_stride = row_stride_; mp.pcm_offset = seg.pcm_offset;
 			mp.stereo = seg.stereo ? 1 : 0;
+			mp.swap_bytes = seg.swap_bytes ? 1 : 0;
 			TimedPair *tm = timing_on_ ? new_pair(1) : nullptr;
 			if (tm) (void)hipEventRecord(tm->a, stream_);
 			hipLaunchKernelGGL(mix_kernel, dim3((max_write + 255) / 256, seg.n_streams), dim3(256), 0,
@@ -2094,6 +2098,28 @@ public:
 		HIP_OK(hipStreamSynchronize(stream_));
 		return true;
 	}
+
+	/* output stage: copies into page-locked memory queue behind the mixer and
+	 * ahead of the next run's kernels on the one stream */
+	bool fetch_pcm_async(uint32_t stream, int16_t *dst, uint32_t frames, bool stereo, int slot,
+			std::string &err) override {
+		slot &= 1;
+		if (!fetch_ev_[slot]) HIP_OK(hipEventCreateWithFlags(&fetch_ev_[slot], hipEventDisableTiming));
+		HIP_OK(hipMemcpyAsync(dst, pcm_.p + pcm_row_ * stream,
+				(size_t)frames * (stereo ? 2 : 1) * sizeof(int16_t), hipMemcpyDeviceToHost, stream_));
+		HIP_OK(hipEventRecord(fetch_ev_[slot], stream_));
+		return true;
+	}
+	bool wait_fetch(int slot, std::string &err) override {
+		slot &= 1;
+		if (fetch_ev_[slot]) HIP_OK(hipEventSynchronize(fetch_ev_[slot]));
+		return true;
+	}
+	void *alloc_host(size_t bytes) override {
+		void *p = nullptr;
+		return hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+	}
+	void free_host(void *p) override { if (p) (void)hipHostFree(p); }
 
 	const int16_t *device_pcm(uint32_t stream) override { return pcm_.p ? pcm_.p + pcm_row_ * stream : nullptr; }
 
@@ -2227,6 +2253,7 @@ private:
 	DevBuf<FastInfo> finfo_;
 	DevBuf<uint32_t> fdone_, worklist_, work_count_;
 	DevBuf<unsigned char> fsteps_, flines_;
+	hipEvent_t fetch_ev_[2] = {nullptr, nullptr};
 	uint32_t multi_min_ = 256;
 	uint32_t block_grid_ = 1;
 };

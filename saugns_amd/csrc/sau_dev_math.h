@@ -733,6 +733,11 @@ SAU_HD float clampf(float x, float lo, float hi) { /* sau/math.h:133-137 */
 }
 
 /* generator.c:803,822-823 */
+/* player/sndfile.c:160-168: one sample in the other byte order */
+SAU_HD int16_t pcm_swap(int16_t v) {
+	uint16_t s = (uint16_t)v;
+	return (int16_t)(uint16_t)((s >> 8) | (s << 8));
+}
 SAU_HD int16_t pcm16(float s) {
 	s = clampf(s, -1.f, 1.f);
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -127,6 +127,19 @@ def main():
         kat[f"map_{t}"] = xa
     np.savez_compressed(os.path.join(OUT, "ramp_kat.npz"), **kat)
 
+    # ---- output stage: files written by the reference's player/sndfile.c ------------
+    import tempfile
+    snd = {}
+    base = pcm_store["config1"][:74]  # 74 mono frames = 37 stereo frames
+    for fmt, name in ((0, "raw"), (1, "au"), (2, "wav")):
+        for ch in (1, 2):
+            with tempfile.TemporaryDirectory() as d:
+                path = os.path.join(d, "x")
+                po.ref_write_sndfile(path, fmt, ch, 44100, base, chunk=16)
+                snd[f"{name}_{ch}"] = np.frombuffer(open(path, "rb").read(), np.uint8)
+    snd["pcm"] = base
+    np.savez_compressed(os.path.join(OUT, "sndfile_kat.npz"), **snd)
+
     np.savez_compressed(os.path.join(OUT, "pcm_heads.npz"), **pcm_store)
     json.dump(index, open(os.path.join(OUT, "index.json"), "w"), indent=1, sort_keys=True)
     print("programs:", len(index["corpus"]), "configs:", list(index["configs"]))

@@ -307,10 +307,12 @@ struct SeqBackend : public Backend {
 					R = (R + sv) + s_r;
 				}
 				if (seg.stereo) {
-					pcm[s][2 * (size_t)(seg.pcm_offset + i)] = pcm16(L);
-					pcm[s][2 * (size_t)(seg.pcm_offset + i) + 1] = pcm16(R);
+					int16_t l16 = pcm16(L), r16 = pcm16(R);
+					pcm[s][2 * (size_t)(seg.pcm_offset + i)] = seg.swap_bytes ? pcm_swap(l16) : l16;
+					pcm[s][2 * (size_t)(seg.pcm_offset + i) + 1] = seg.swap_bytes ? pcm_swap(r16) : r16;
 				} else {
-					pcm[s][seg.pcm_offset + i] = pcm16((L + R) * 0.5f);
+					int16_t m16 = pcm16((L + R) * 0.5f);
+					pcm[s][seg.pcm_offset + i] = seg.swap_bytes ? pcm_swap(m16) : m16;
 				}
 			}
 		}

@@ -61,3 +61,14 @@ if "dropin" in which:
         dt = time.perf_counter() - t0
         print(f"drop-in API, config 3, {chunk:6d}-frame calls: {n/dt:10.3e} frames/s ({dt/(n/chunk)*1e3:.3f} ms per call)")
         g.close()
+if "file" in which:
+    # output stage end to end: config 3, 20 s of audio into a WAV/AU file on tmpfs
+    prg = vb.config3(n=1024, seconds=20)
+    for fmt, name in ((2, "wav"), (1, "au")):
+        path = f"/dev/shm/sau_amd_sweep.{name}"
+        sa.render_file(prg, 44100, path, fmt, 1)  # warm
+        t0 = time.perf_counter()
+        n = sa.render_file(prg, 44100, path, fmt, 1)
+        dt = time.perf_counter() - t0
+        print(f"render_file {name}: {n} frames in {dt*1e3:.1f} ms -> {n/dt:10.3e} frames/s (create + render + copy + write)")
+        os.remove(path)
