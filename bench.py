@@ -136,8 +136,9 @@ def main():
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_c_pmc_summary.json")))
             wl = pmc["workload"]
             if wl["voices"] == args.voices and wl["frames_per_step"] == args.frames:
-                traffic = pmc["kernels"]["sauhip::fast_kernel<4>"]["hbm_bytes_per_launch_corrected"]
-        except (OSError, KeyError, ValueError):
+                k = [v for n, v in pmc["kernels"].items() if n.startswith("sauhip::fast_kernel<")]
+                traffic = k[0]["hbm_bytes_per_launch_corrected"]
+        except (OSError, KeyError, ValueError, IndexError):
             pass
         out = {
             "metric": "mono samples/sec/GPU @ N voices (depth-3 FM)",
@@ -155,7 +156,7 @@ def main():
                        "operator_samples_per_s": value * n_ops},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
-                         "kernel": "fast_kernel<4>", "avg_launch_ms": launch_s * 1e3,
+                         "kernel": "fast_kernel<8>", "avg_launch_ms": launch_s * 1e3,
                          "launches": tm["segments"],
                          "algorithmic_bytes_per_launch": alg_bytes},
         }

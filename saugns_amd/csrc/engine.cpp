@@ -177,6 +177,7 @@ bool Engine::handle_event(Stream &st, const EventNode &e, std::vector<OpUpdate> 
 
 bool Engine::rebuild_plans(std::string &err) {
 	all_steps_.clear();
+	all_fast_ids_.clear();
 	all_op_ids_.clear();
 	for (Stream &st : streams_) {
 		for (size_t v = 0; v < st.voices.size(); ++v) {
@@ -188,6 +189,7 @@ bool Engine::rebuild_plans(std::string &err) {
 				if (!compile_voice_plan(st.ops, vn.carr_op, vn.plan, err)) {
 					/* a voice whose carrier never got data stays silent */
 					vn.plan.steps.clear();
+					vn.plan.fast_ids.clear();
 					vn.plan.op_ids.clear();
 					if (err != "voice carrier operator was never initialised")
 						return false;
@@ -200,6 +202,8 @@ bool Engine::rebuild_plans(std::string &err) {
 			ref.ops_ofs = (uint32_t)all_op_ids_.size();
 			ref.nops = (uint32_t)vn.plan.op_ids.size();
 			all_steps_.insert(all_steps_.end(), vn.plan.steps.begin(), vn.plan.steps.end());
+			all_fast_ids_.insert(all_fast_ids_.end(), vn.plan.fast_ids.begin(), vn.plan.fast_ids.end());
+			all_fast_ids_.resize(all_steps_.size());
 			for (uint32_t id : vn.plan.op_ids)
 				all_op_ids_.push_back(st.op_base + id);
 		}
@@ -221,7 +225,7 @@ bool Engine::rebuild_plans(std::string &err) {
 			}
 	}
 	plans_dirty_ = false;
-	return backend_->upload_plans(all_steps_.data(), all_steps_.size(),
+	return backend_->upload_plans(all_steps_.data(), all_fast_ids_.data(), all_steps_.size(),
 			all_op_ids_.data(), all_op_ids_.size(), err);
 }
 
@@ -229,7 +233,7 @@ bool Engine::rebuild_plans(std::string &err) {
 bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::string &err) {
 	std::vector<VoiceDesc> descs;
 	std::vector<SegmentDesc::Stream> sdescs(streams_.size());
-	uint32_t n_main = 1, n_fpool = 0, max_ops = 1, n_pan = 0, max_steps = 1;
+	uint32_t n_main = 1, n_fpool = 0, max_ops = 1, n_pan = 0, max_steps = 1, n_fast = 1;
 	uint64_t wave_mask = 0;
 	bool maybe_block = false, serial = false;
 	for (size_t s = 0; s < streams_.size(); ++s) {
@@ -266,6 +270,7 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 			descs.push_back(d);
 			if (out_len > sd.write_len) sd.write_len = out_len;
 			n_main = std::max(n_main, vn.plan.n_main);
+			if (!vn.plan.no_fast) n_fast = std::max(n_fast, vn.plan.n_fast);
 			n_fpool = std::max(n_fpool, vn.plan.n_slots - vn.plan.n_main);
 			max_ops = std::max(max_ops, (uint32_t)vn.plan.op_ids.size());
 			max_steps = std::max(max_steps, (uint32_t)vn.plan.steps.size());
@@ -297,7 +302,7 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 	seg.len = len; seg.pcm_offset = offset; seg.stereo = stereo; seg.swap_bytes = pcm_swap_;
 	seg.voices = descs.data(); seg.n_voices = (uint32_t)descs.size();
 	seg.streams = sdescs.data(); seg.n_streams = (uint32_t)sdescs.size();
-	seg.n_slots = n_main + n_fpool; seg.n_main = n_main; seg.max_ops = max_ops; seg.n_pan_rows = n_pan;
+	seg.n_slots = n_main + n_fpool; seg.n_main = n_main; seg.n_fast = n_fast; seg.max_ops = max_ops; seg.n_pan_rows = n_pan;
 	seg.max_steps = max_steps;
 	seg.wave_mask = wave_mask;
 	seg.maybe_block = maybe_block;

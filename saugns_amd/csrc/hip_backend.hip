@@ -1004,6 +1004,7 @@ struct FastLine;
 struct FastParams {
 	const VoiceDesc *voices;
 	const Step *steps;
+	const FastIds *fast_ids; /* parallel to steps */
 	const uint32_t *op_ids;
 	DevOp *ops;
 	float *vout;
@@ -1017,7 +1018,8 @@ struct FastParams {
 	const HerpC01 *g_c01;
 	FastStep *fsteps;     /* [n_voices][max_steps], written by decode_kernel */
 	FastLine *flines;     /* same indexing: the ramp of a step whose line is in progress */
-	uint32_t row_stride, n_voices, n_main, max_ops, max_steps, n_tabs, np;
+	uint32_t row_stride, n_voices, n_fast, max_ops, max_steps, n_tabs, np;
+	uint32_t rows;        /* T of the fast_kernel<T> that will run: block buffers hold 64 * rows frames */
 	uint32_t enable;      /* 0: leave every voice to the block loop */
 	int8_t tab_of_wave[12];
 	uint8_t wave_of_tab[12];
@@ -1112,11 +1114,37 @@ __device__ __forceinline__ FastStep uni(const FastStep &f) {
 	return c.s;
 }
 
+typedef const uint32_t __attribute__((address_space(4))) *const_u32_ptr;
+#ifndef FK_GRID
+#define FK_GRID 256 /* workgroups at most: one per CU (LDS allows no more at T = 4) */
+#endif
+#ifndef FK_COMMON
+#define FK_COMMON 1
+#endif
+#ifndef FK_CONSTD
+#define FK_CONSTD 1
+#endif
+#ifndef FK_PREFETCH
+#define FK_PREFETCH 0 /* loading the next step early measured 6 % slower (SGPR pressure) */
+#endif
+__device__ __forceinline__ FastLine load_line_uniform(const FastLine *p) {
+	const_u32_ptr q = (const_u32_ptr)(uintptr_t)p;
+	union { FastLine s; uint32_t u[12]; } c;
+#pragma unroll
+	for (int i = 0; i < 12; ++i) c.u[i] = q[i];
+	return c.s;
+}
+/* value of a ramp at frame t of the segment (lead-in frames t < 0 get the hold value: unused) */
+__device__ __forceinline__ float fast_line_value(const FastLine &fl, int t) {
+	const uint32_t i = (uint32_t)t;
+	return i < fl.goal_len ? sweep_value_inl(fl.sw, i) : fl.hold;
+}
+
 /* One step of a voice's plan in immediate form (LDS offsets, constants), so
  * that a row touches no operator records: lazily-constant frequency lines
  * vanish, everything a step needs is 20 dwords in scalar registers. */
 __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
-	constexpr int NP = 64 * 4; /* fast_kernel<4> slot size */
+	const uint32_t NP = 64 * P.rows; /* frames per block buffer */
 	const uint32_t v = blockIdx.x;
 	const int l = threadIdx.x;
 	if (P.info[v].total == 0) return;
@@ -1140,11 +1168,13 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 		const DevOp &o = P.ops[ids[st.op]];
 		keep = !(st.kind == ST_LINE && st.which == L_FREQ);
 		f.kind = (uint32_t)st.kind | ((uint32_t)st.flags << 8) | ((uint32_t)st.which << 16) | (dep << 24);
-		f.out_off = st.out != NO_SLOT ? (uint32_t)st.out * NP : ~0u;
-		f.pm_off = st.pm != NO_SLOT ? (uint32_t)st.pm * NP : ~0u;
-		f.fpm_off = st.fpm != NO_SLOT ? (uint32_t)st.fpm * NP : ~0u;
-		f.amp_off = st.amp != NO_SLOT ? (uint32_t)st.amp * NP : ~0u;
-		f.aux_off = (st.kind == ST_LERP && st.freq != NO_SLOT) ? (uint32_t)st.freq * NP : ~0u;
+		/* block buffers renumbered by liveness (sau_dev_types.h): out, pm, fpm, amp, range end */
+		const FastIds cs = P.fast_ids[vd.plan_ofs + l];
+		f.out_off = cs.out != NO_SLOT ? (uint32_t)cs.out * NP : ~0u;
+		f.pm_off = cs.pm != NO_SLOT ? (uint32_t)cs.pm * NP : ~0u;
+		f.fpm_off = cs.fpm != NO_SLOT ? (uint32_t)cs.fpm * NP : ~0u;
+		f.amp_off = cs.amp != NO_SLOT ? (uint32_t)cs.amp * NP : ~0u;
+		f.aux_off = cs.aux != NO_SLOT ? (uint32_t)cs.aux * NP : ~0u;
 		const uint32_t wv = o.type == OT_WAVE ? (o.wave < 12 ? o.wave : 0) : o.wave;
 		f.type = o.type | (wv << 8) | ((o.flags & OPF_OSC_RESET) ? 1u << 16 : 0u);
 		f.fc = o.rt_fconst;
@@ -1191,7 +1221,6 @@ __device__ __forceinline__ double lane_prev(double x) {
 
 /* Uniform (scalar-cache) load of one decoded step: the address is the same
  * for the whole wave and the memory was written by an earlier kernel. */
-typedef const uint32_t __attribute__((address_space(4))) *const_u32_ptr;
 __device__ __forceinline__ FastStep load_step_uniform(const FastStep *p) {
 	const_u32_ptr q = (const_u32_ptr)(uintptr_t)p;
 	union { FastStep s; uint32_t u[20]; } c;
@@ -1202,28 +1231,6 @@ __device__ __forceinline__ FastStep load_step_uniform(const FastStep *p) {
 
 /* (A 24-byte interleaved LDS entry read with ds_read2_b64 + ds_read_b64 was
  * measured 60 % worse in bank conflicts than this split 16 + 8 byte layout.) */
-#ifndef FK_COMMON
-#define FK_COMMON 1
-#endif
-#ifndef FK_CONSTD
-#define FK_CONSTD 1
-#endif
-#ifndef FK_PREFETCH
-#define FK_PREFETCH 0 /* loading the next step early measured 6 % slower (SGPR pressure) */
-#endif
-__device__ __forceinline__ FastLine load_line_uniform(const FastLine *p) {
-	const_u32_ptr q = (const_u32_ptr)(uintptr_t)p;
-	union { FastLine s; uint32_t u[12]; } c;
-#pragma unroll
-	for (int i = 0; i < 12; ++i) c.u[i] = q[i];
-	return c.s;
-}
-/* value of a ramp at frame t of the segment (lead-in frames t < 0 get the hold value: unused) */
-__device__ __forceinline__ float fast_line_value(const FastLine &fl, int t) {
-	const uint32_t i = (uint32_t)t;
-	return i < fl.goal_len ? sweep_value_inl(fl.sw, i) : fl.hold;
-}
-
 template <int T>
 __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 	constexpr int NP = 64 * T;
@@ -1236,7 +1243,7 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 	HerpC23 *t23 = (HerpC23 *)lds;
 	HerpC01 *t01 = (HerpC01 *)(lds + (size_t)P.n_tabs * WAVE_LEN * sizeof(HerpC23));
 	unsigned char *areas = lds + (size_t)P.n_tabs * WAVE_LEN * (sizeof(HerpC23) + sizeof(HerpC01));
-	const size_t area_bytes = (size_t)P.n_main * NP * sizeof(float);
+	const size_t area_bytes = (size_t)P.n_fast * NP * sizeof(float);
 	float *slots = (float *)(areas + (size_t)w * area_bytes) + l; /* lane's column of every row */
 
 	for (uint32_t t = 0; t < P.n_tabs; ++t) {
@@ -1840,6 +1847,10 @@ public:
 		/* voices per segment from which feedback voices get sixteen one-wave teams per workgroup
 		 * (0: never; 1: always, also without feedback -- tests) */
 		multi_min_ = 256;
+		if (const char *fr = getenv("SAU_AMD_FAST_ROWS")) { /* 8 (default), 4 or 2 */
+			const int r = atoi(fr);
+			fast_rows_ = r >= 8 ? 8 : r >= 4 ? 4 : 2;
+		}
 		if (const char *mm = getenv("SAU_AMD_MULTI_MIN")) multi_min_ = (uint32_t)atol(mm);
 		if (!ops_.ensure(cfg.op_count ? cfg.op_count : 1, err)) return false;
 		HIP_OK(hipMemsetAsync(ops_.p, 0, ops_.cap * sizeof(DevOp), stream_));
@@ -1875,12 +1886,14 @@ public:
 		return true;
 	}
 
-	bool upload_plans(const Step *steps, size_t n_steps, const uint32_t *op_ids, size_t n_ids,
-			std::string &err) override {
+	bool upload_plans(const Step *steps, const FastIds *fast_ids, size_t n_steps, const uint32_t *op_ids,
+			size_t n_ids, std::string &err) override {
 		HIP_OK(hipStreamSynchronize(stream_));
-		if (!steps_.ensure(n_steps ? n_steps : 1, err) || !op_ids_.ensure(n_ids ? n_ids : 1, err))
+		if (!steps_.ensure(n_steps ? n_steps : 1, err) || !op_ids_.ensure(n_ids ? n_ids : 1, err) ||
+		    !fast_ids_.ensure(n_steps ? n_steps : 1, err))
 			return false;
 		if (n_steps) HIP_OK(hipMemcpy(steps_.p, steps, n_steps * sizeof(Step), hipMemcpyHostToDevice));
+		if (n_steps) HIP_OK(hipMemcpy(fast_ids_.p, fast_ids, n_steps * sizeof(FastIds), hipMemcpyHostToDevice));
 		if (n_ids) HIP_OK(hipMemcpy(op_ids_.p, op_ids, n_ids * sizeof(uint32_t), hipMemcpyHostToDevice));
 		return true;
 	}
@@ -1999,9 +2012,15 @@ public:
 		memcpy(rp.wc, wconst_, sizeof wconst_);
 		/* ---- time-parallel path first; the block loop continues after it ---- */
 		{
-			constexpr uint32_t FT = 4, FNP = 64 * FT;
 			const uint32_t fmax_steps = seg.max_steps < 64 ? seg.max_steps : 64;
-			const size_t area = (size_t)seg.n_main * FNP * sizeof(float);
+			/* rows per wave and pass: as many as LDS holds beside one wave table
+			 * (more rows amortise the per-step work: 8 rows measured 8 % faster
+			 * than 4, 4 rows 28 % faster than 2) */
+			uint32_t FT = fast_rows_;
+			auto area_of = [&](uint32_t t) { return (size_t)seg.n_fast * 64 * t * sizeof(float); };
+			const size_t one_tab = seg.wave_mask ? tab_bytes : 0;
+			while (FT > 2 && 16 * area_of(FT) + one_tab + 1024 > lds_limit_) FT /= 2;
+			const size_t area = area_of(FT);
 			const bool use_fast = fast_enabled_ && (16 * area + 1024 <= lds_limit_);
 			if (!finfo_.ensure(seg.n_voices, err) || !fdone_.ensure(seg.n_voices, err) ||
 			    !worklist_.ensure(seg.n_voices, err) || !work_count_.ensure(4, err) ||
@@ -2010,12 +2029,12 @@ public:
 			HIP_OK(hipMemsetAsync(work_count_.p, 0, sizeof(uint32_t), stream_));
 			FastParams fp;
 			memset(&fp, 0, sizeof fp);
-			fp.voices = voices_.p; fp.steps = steps_.p; fp.op_ids = op_ids_.p; fp.ops = ops_.p;
+			fp.voices = voices_.p; fp.steps = steps_.p; fp.fast_ids = fast_ids_.p; fp.op_ids = op_ids_.p; fp.ops = ops_.p;
 			fp.vout = vout_.p; fp.pan = pan_.p; fp.info = finfo_.p; fp.fast_done = fdone_.p;
 			fp.worklist = worklist_.p; fp.work_count = work_count_.p; fp.vinfo = vinfo_.p;
 			fp.g_c23 = c23_.p; fp.g_c01 = c01_.p; fp.fsteps = (FastStep *)fsteps_.p; fp.flines = (FastLine *)flines_.p;
-			fp.row_stride = row_stride_; fp.n_voices = seg.n_voices; fp.n_main = seg.n_main;
-			fp.max_ops = seg.max_ops; fp.max_steps = fmax_steps; fp.np = 64;
+			fp.row_stride = row_stride_; fp.n_voices = seg.n_voices; fp.n_fast = seg.n_fast;
+			fp.max_ops = seg.max_ops; fp.max_steps = fmax_steps; fp.np = 64; fp.rows = FT;
 			fp.enable = use_fast ? 1u : 0u;
 			memcpy(fp.wc, wconst_, sizeof wconst_);
 			uint32_t ft = 0;
@@ -2036,19 +2055,23 @@ public:
 			if (use_fast) {
 				hipLaunchKernelGGL(decode_kernel, dim3(seg.n_voices), dim3(64), 0, stream_, fp);
 				const size_t flds = ft * tab_bytes + 16 * area;
-				static size_t fconfigured = 0;
-				if (flds > fconfigured) {
-					HIP_OK(hipFuncSetAttribute((const void *)fast_kernel<FT>,
-							hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
-					fconfigured = flds;
+				const void *fk = FT == 8 ? (const void *)fast_kernel<8> : FT == 4 ? (const void *)fast_kernel<4>
+				                                                                  : (const void *)fast_kernel<2>;
+				static size_t fconfigured[3] = {0, 0, 0};
+				size_t &conf = fconfigured[FT == 8 ? 2 : FT == 4 ? 1 : 0];
+				if (flds > conf) {
+					HIP_OK(hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+					conf = flds;
 				}
 				/* four waves per voice when there are few voices, one CU-filling grid at most */
 				uint32_t fgrid = (seg.n_voices * 4 + 15) / 16;
-				if (fgrid > 256) fgrid = 256;
+				if (fgrid > FK_GRID) fgrid = FK_GRID;
 				if (fgrid < 1) fgrid = 1;
 				TimedPair *tf = timing_on_ ? new_pair(2) : nullptr;
 				if (tf) (void)hipEventRecord(tf->a, stream_);
-				hipLaunchKernelGGL((fast_kernel<FT>), dim3(fgrid), dim3(1024), flds, stream_, fp);
+				if (FT == 8) hipLaunchKernelGGL((fast_kernel<8>), dim3(fgrid), dim3(1024), flds, stream_, fp);
+				else if (FT == 4) hipLaunchKernelGGL((fast_kernel<4>), dim3(fgrid), dim3(1024), flds, stream_, fp);
+				else hipLaunchKernelGGL((fast_kernel<2>), dim3(fgrid), dim3(1024), flds, stream_, fp);
 				if (tf) (void)hipEventRecord(tf->b, stream_);
 			}
 			TimedPair *tz = timing_on_ ? new_pair(3) : nullptr;
@@ -2229,6 +2252,7 @@ private:
 	WaveConst wconst_[12];
 	DevBuf<DevOp> ops_;
 	DevBuf<Step> steps_;
+	DevBuf<FastIds> fast_ids_;
 	DevBuf<uint32_t> op_ids_;
 	DevBuf<VoiceDesc> voices_;
 	DevBuf<float> vout_, pan_;
@@ -2255,6 +2279,7 @@ private:
 	DevBuf<unsigned char> fsteps_, flines_;
 	hipEvent_t fetch_ev_[2] = {nullptr, nullptr};
 	uint32_t multi_min_ = 256;
+	uint32_t fast_rows_ = 8;
 	uint32_t block_grid_ = 1;
 };
 

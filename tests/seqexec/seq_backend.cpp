@@ -46,7 +46,7 @@ struct SeqBackend : public Backend {
 		for (auto &p : pcm) p.assign((size_t)n * 2, 0);
 		return true;
 	}
-	bool upload_plans(const Step *s, size_t ns, const uint32_t *ids, size_t ni, std::string &) override {
+	bool upload_plans(const Step *s, const FastIds *, size_t ns, const uint32_t *ids, size_t ni, std::string &) override {
 		steps.assign(s, s + ns); op_ids.assign(ids, ids + ni);
 		return true;
 	}
