@@ -1033,8 +1033,31 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 	const uint32_t *ids = P.op_ids + vd.ops_ofs;
 	bool bad = (vd.flags & VD_NO_FAST) != 0 || !P.enable;
 	uint32_t min_time = 0xFFFFFFFFu;
+	const Step *plan = P.steps + vd.plan_ofs;
+	/* An operator that has run out of time yields nothing, and neither it nor
+	 * anything nested in it advances (run_block gives its subtree zero
+	 * length, generator.c:686-700): such subtrees are left out below. */
+	for (uint32_t i = 0; i < vd.nops; ++i) P.ops[ids[i]].rt_frozen = 0;
+	{
+		uint32_t dep = 0, frozen_at = 0;
+		for (uint32_t si = 0; si < vd.plan_len; ++si) {
+			const Step st = plan[si];
+			DevOp &o = P.ops[ids[st.op]];
+			if (st.flags & SF_BEGIN) {
+				++dep;
+				if (!frozen_at && !(o.flags & OPF_TIME_INF) && o.time == 0) frozen_at = dep;
+			}
+			if (frozen_at) o.rt_frozen = 1;
+			if (st.flags & SF_END) {
+				if (dep == frozen_at) frozen_at = 0;
+				--dep;
+			}
+		}
+	}
+	if (P.ops[ids[vd.carr_local]].rt_frozen) bad = true; /* the voice is over (generator.c:839) */
 	for (uint32_t i = 0; i < vd.nops; ++i) {
 		DevOp &o = P.ops[ids[i]];
+		if (o.rt_frozen) continue;
 		/* ramps in progress: amplitude lines are closed-form per frame (sau/line.c
 		 * fills depend on the position only); frequency ramps need a phase scan,
 		 * self-modulation and pan ramps stay with the block loop */
@@ -1047,10 +1070,14 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 		if (!(o.flags & OPF_TIME_INF) && o.time < min_time) min_time = o.time;
 	}
 	uint32_t depth = 0, maxd = 0;
-	const Step *plan = P.steps + vd.plan_ofs;
 	for (uint32_t si = 0; si < vd.plan_len && !bad; ++si) {
 		const Step st = plan[si];
 		DevOp &o = P.ops[ids[st.op]];
+		if (o.rt_frozen) { /* nesting still counts: depths of live steps stay what they are */
+			if (st.flags & SF_BEGIN) ++depth;
+			if (st.flags & SF_END) --depth;
+			continue;
+		}
 		if (st.flags & SF_BEGIN) { ++depth; if (depth > maxd) maxd = depth; }
 		const bool freq_here = (st.kind == ST_LINE && st.which == L_FREQ) ||
 			(st.kind == ST_OSC && st.freq == NO_SLOT && o.type == OT_WAVE);
@@ -1167,6 +1194,29 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 		const Step st = plan[l];
 		const DevOp &o = P.ops[ids[st.op]];
 		keep = !(st.kind == ST_LINE && st.which == L_FREQ);
+		bool zero_fill = false;
+		if (o.rt_frozen) {
+			/* out of time: of the whole subtree only the root's final step remains,
+			 * as a zero fill of its output unless that is layered onto other
+			 * modulators' (generator.c:719-728) */
+			bool root_end = false;
+			if (st.kind == ST_OSC && (st.flags & SF_END)) {
+				/* the root is the frozen operator whose enclosing operator (if any) is live */
+				uint32_t d2 = 0, frozen_at = 0;
+				for (uint32_t q = 0; q <= (uint32_t)l; ++q) {
+					const Step sq = plan[q];
+					const DevOp &oq = P.ops[ids[sq.op]];
+					if (sq.flags & SF_BEGIN) {
+						++d2;
+						if (!frozen_at && !(oq.flags & OPF_TIME_INF) && oq.time == 0) frozen_at = d2;
+					}
+					if (q == (uint32_t)l) root_end = (d2 == frozen_at);
+					if (sq.flags & SF_END) { if (d2 == frozen_at) frozen_at = 0; --d2; }
+				}
+			}
+			zero_fill = root_end && !(st.flags & SF_LAYER) && !(st.which & OX_VOICE);
+			keep = zero_fill;
+		}
 		f.kind = (uint32_t)st.kind | ((uint32_t)st.flags << 8) | ((uint32_t)st.which << 16) | (dep << 24);
 		/* block buffers renumbered by liveness (sau_dev_types.h): out, pm, fpm, amp, range end */
 		const FastIds cs = P.fast_ids[vd.plan_ofs + l];
@@ -1189,7 +1239,10 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 		f.prev_Is = o.prev_Is;
 		f.pan = o.line[L_PAN].v0;
 		f.ramp = 0;
-		{
+		if (zero_fill) { /* becomes a constant line step */
+			f.kind = (uint32_t)ST_LINE | ((uint32_t)L_AMP << 16) | (dep << 24);
+			f.ac = 0.f;
+		} else {
 			const bool line_step = st.kind == ST_LINE && st.which != L_FREQ;
 			const bool amp_inline = st.kind == ST_OSC && st.amp == NO_SLOT;
 			LineState ls = o.line[line_step ? st.which : L_AMP];
@@ -1603,6 +1656,7 @@ __global__ void __launch_bounds__(64) finalize_kernel(FastParams P) {
 	const uint32_t total = fi.total;
 	for (uint32_t i = 0; i < vd.nops; ++i) {
 		DevOp &o = P.ops[ids[i]];
+		if (o.rt_frozen) continue; /* out of time: state stands still */
 		if (!(o.flags & OPF_TIME_INF)) o.time -= total;
 		for (uint32_t ln = 0; ln < L_COUNT; ++ln) {
 			LineState ls = o.line[ln];

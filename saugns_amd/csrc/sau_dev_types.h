@@ -45,7 +45,10 @@ struct DevOp {
 	uint32_t st_prev_phase = 0;
 	double st_prev_Is = 0;
 	float st_prev_s = 0;
-	uint32_t pad[3] = {};
+	/* per-segment: this operator or one it is nested in has run out of time, so
+	 * it produces nothing and its state stands still (generator.c:686-700) */
+	uint32_t rt_frozen = 0;
+	uint32_t pad[2] = {};
 };
 static_assert(sizeof(DevOp) == 256, "DevOp is 64 dwords");
 

@@ -120,3 +120,34 @@ def test_line_arithmetic_device_vs_host(sa):
                 bad = np.nonzero(od.view(np.uint32) != oh.view(np.uint32))[0]
                 assert len(bad) == 0, (shape, v0, vt, pos, end, hex(flags), m is not None, bad[:4], od[bad[:4]], oh[bad[:4]])
                 assert (sd == sh).all(), (shape, sd, sh)
+
+
+def check_runs(sa, oracle, voices, chunk, stereo=False):
+    """As check(), but through the batch API with one engine run per `chunk` frames, so that
+    later runs start from the state earlier ones left (expired operators, finished ramps)."""
+    oracle.oracle().ora_set_fastmath_forms(1)
+    prg = vb.build_program(voices)
+    want = oracle.oracle_render(prg.ptr, RATE, stereo)
+    got = sa.Batch([prg], RATE).render(stereo=stereo, chunk=chunk)[0]
+    assert len(got) == len(want)
+    d = np.nonzero(got != want)[0]
+    assert len(d) == 0, f"{len(d)} samples differ, first at {d[0]}"
+
+
+@pytest.mark.parametrize("chunk", [1500, 4410])
+def test_operators_out_of_time_across_runs(sa, oracle, chunk):
+    """A modulator that has run out of time yields silence and stands still (generator.c:686-700),
+    as first or later member of its list, with a subtree of its own, in PM and AM lists."""
+    first = vb.Op("sin", freq=vb.Line(3.0, ratio=True), amp=1.0, time_ms=30)
+    later = vb.Op("tri", freq=vb.Line(2.0, ratio=True), amp=0.6)
+    check_runs(sa, oracle, [vb.Op("sin", freq=146.832, time_ms=200, mods={POP_PMOD: [first, later]})], chunk)
+    first = vb.Op("sin", freq=vb.Line(3.0, ratio=True), amp=1.0)
+    later = vb.Op("tri", freq=vb.Line(2.0, ratio=True), amp=0.6, time_ms=45)
+    check_runs(sa, oracle, [vb.Op("sin", freq=146.832, time_ms=200, mods={POP_PMOD: [first, later]})], chunk)
+    inner = vb.Op("sin", freq=vb.Line(2.0, ratio=True), amp=0.5, time_ms=150)
+    outer = vb.Op("sin", freq=vb.Line(1.5, ratio=True), amp=0.9, time_ms=50, mods={POP_PMOD: [inner]})
+    check_runs(sa, oracle, [vb.Op("sin", freq=220.0, time_ms=200, mods={POP_PMOD: [outer]})], chunk)
+    am = vb.Op("sin", freq=7.0, amp=0.4, time_ms=60)
+    check_runs(sa, oracle, [vb.Op("sin", freq=330.0, time_ms=200, mods={POP_AMOD: [am]}),
+                            vb.Op("sin", freq=110.0, time_ms=120, amp=vb.Line(1.0, goal=0.1, shape="lin"))],
+               chunk, stereo=True)
