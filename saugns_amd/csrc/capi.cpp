@@ -218,6 +218,16 @@ extern "C" SAU_AMD_API int sauAmd_kat_line_device(uint32_t *state, uint32_t len,
 	memcpy(state, &st2, sizeof st2);
 	return 1;
 }
+/* Test probe: for wave id w, how many divisors make div_diff_scale differ from
+ * IEEE division (and the first such bit pattern); variant 1 is the uncorrected
+ * product a * rcp(b), which the probe must catch. -1 on a device error. */
+extern "C" SAU_AMD_API long long sauAmd_kat_div_device(uint32_t wave, int variant, uint32_t *first_bad) {
+	unsigned long long m = 0;
+	uint32_t fb = 0xffffffffu;
+	if (wave >= 12 || !sauhip::kat_div(sauengine::wave_consts()[wave].diff_scale, variant, &m, &fb)) return -1;
+	if (first_bad) *first_bad = fb;
+	return (long long)m;
+}
 extern "C" SAU_AMD_API int sauAmd_kat_line_host(uint32_t *state, uint32_t len, const float *mul, float *out) {
 	saudev::LineState st;
 	memcpy(&st, state, sizeof st);

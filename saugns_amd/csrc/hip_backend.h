@@ -19,6 +19,8 @@ public:
 /* NULL (with err) when no HIP device is usable: there is no CPU fallback. */
 HipBackend *create_hip_backend(std::string &err);
 int device_count();
+/* test probe: the differentiator's division against IEEE division, all divisors (kat_div_kernel) */
+bool kat_div(float a, int variant, unsigned long long *mismatches, uint32_t *first_bad);
 /* test probe: evaluate one line block on the device (kat_line_kernel) */
 bool kat_line(const saudev::LineState &st, uint32_t len, const float *mul, float *out,
 		saudev::LineState *st_out);

@@ -2337,6 +2337,49 @@ private:
 	uint32_t block_grid_ = 1;
 };
 
+/* Known-answer probe: div_diff_scale(a, b) against IEEE a / b for every f32 b
+ * with 1 <= |b| <= 2^31 (a superset of the rounded integers the differentiator
+ * divides by). Thread t takes the bit patterns t, t + stride, ... */
+__global__ void kat_div_kernel(float a, int variant, unsigned long long *mismatches, uint32_t *first_bad) {
+	const uint32_t lo = 0x3f800000u, hi = 0x4f000000u; /* 1.0f .. 2^31 */
+	unsigned long long bad = 0;
+	for (uint32_t bits = lo + blockIdx.x * blockDim.x + threadIdx.x; bits <= hi; bits += gridDim.x * blockDim.x) {
+		for (int sgn = 0; sgn < 2; ++sgn) {
+			const float b = bits_f(bits | (sgn ? 0x80000000u : 0u));
+			const float want = __fdiv_rn(a, b);
+			float got;
+			if (variant == 0) {
+				got = div_diff_scale(a, b);
+			} else { /* no correction: the probe must be able to see this fail */
+				got = a * __builtin_amdgcn_rcpf(b);
+			}
+			if (f_bits(want) != f_bits(got)) { ++bad; atomicMin(first_bad, bits); }
+		}
+		if (bits > hi - gridDim.x * blockDim.x) break; /* no wrap past the last pattern */
+	}
+	if (bad) atomicAdd(mismatches, bad);
+}
+
+bool kat_div(float a, int variant, unsigned long long *mismatches, uint32_t *first_bad) {
+	unsigned long long *d_m = nullptr;
+	uint32_t *d_f = nullptr;
+	bool ok = hipMalloc((void **)&d_m, sizeof *d_m) == hipSuccess && hipMalloc((void **)&d_f, sizeof *d_f) == hipSuccess;
+	if (ok) {
+		const uint32_t none = 0xffffffffu;
+		ok = hipMemset(d_m, 0, sizeof *d_m) == hipSuccess &&
+			hipMemcpy(d_f, &none, sizeof none, hipMemcpyHostToDevice) == hipSuccess;
+	}
+	if (ok) {
+		hipLaunchKernelGGL(kat_div_kernel, dim3(4096), dim3(256), 0, 0, a, variant, d_m, d_f);
+		ok = hipDeviceSynchronize() == hipSuccess &&
+			hipMemcpy(mismatches, d_m, sizeof *d_m, hipMemcpyDeviceToHost) == hipSuccess &&
+			hipMemcpy(first_bad, d_f, sizeof *d_f, hipMemcpyDeviceToHost) == hipSuccess;
+	}
+	if (d_m) (void)hipFree(d_m);
+	if (d_f) (void)hipFree(d_f);
+	return ok;
+}
+
 bool kat_line(const LineState &st, uint32_t len, const float *mul, float *out, LineState *st_out) {
 	float *d_mul = nullptr, *d_out = nullptr;
 	LineState *d_st = nullptr;

@@ -492,10 +492,28 @@ SAU_HD float div_f32_normal(float a, float b) {
 #endif
 }
 
+/* The differentiator's division, diff_scale / (float)dphase (wosc.h:253): the
+ * dividend is one of twelve per-wave constants and the divisor an integer of
+ * magnitude 1..2^31 rounded to f32.  For exactly those operands gfx950's
+ * v_rcp_f32 followed by ONE residual correction is already correctly rounded
+ * -- not in general: tests/test_gpu_units.py::test_differentiator_division_exhaustive
+ * compares it with IEEE division for every such divisor (2.1e9 of them) and
+ * every wave's constant on the device (0 mismatches; the uncorrected product
+ * a * rcp(b) differs in 7 % of the cases). */
+SAU_HD float div_diff_scale(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	float r = __builtin_amdgcn_rcpf(b);
+	float q = a * r;
+	return fmaf(fmaf(-b, q, a), r, q);
+#else
+	return a / b;
+#endif
+}
+
 /* wosc.h:250-256: one differentiated output sample */
 SAU_HD float wosc_diff(double Is, double prev_Is, int32_t phase_diff,
 		float diff_scale, float diff_offset) {
-	double x = (double)div_f32_normal(diff_scale, (float)phase_diff);
+	double x = (double)div_diff_scale(diff_scale, (float)phase_diff);
 	return (float)((Is - prev_Is) * x + (double)diff_offset);
 }
 

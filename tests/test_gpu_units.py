@@ -151,3 +151,18 @@ def test_operators_out_of_time_across_runs(sa, oracle, chunk):
     check_runs(sa, oracle, [vb.Op("sin", freq=330.0, time_ms=200, mods={POP_AMOD: [am]}),
                             vb.Op("sin", freq=110.0, time_ms=120, amp=vb.Line(1.0, goal=0.1, shape="lin"))],
                chunk, stereo=True)
+
+
+def test_differentiator_division_exhaustive(sa):
+    """diff_scale / (float)dphase (wosc.h:253) is computed as v_rcp_f32 plus one residual
+    correction; that is correctly rounded for these operands only, so it is checked against
+    IEEE division for every f32 divisor of magnitude 1..2^31 (both signs) and the diff_scale
+    of every wave. The probe is shown to discriminate: the uncorrected product fails."""
+    import ctypes as C
+    fn = sa.lib().sauAmd_kat_div_device
+    fn.restype = C.c_longlong
+    fn.argtypes = [C.c_uint32, C.c_int, C.POINTER(C.c_uint32)]
+    for wave in range(12):
+        first = C.c_uint32()
+        assert fn(wave, 0, C.byref(first)) == 0, (wave, hex(first.value))
+        assert fn(wave, 1, C.byref(first)) > 0
