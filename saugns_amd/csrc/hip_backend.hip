@@ -1063,7 +1063,6 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 		 * self-modulation and pan ramps stay with the block loop */
 		for (uint32_t ln = 0; ln < L_COUNT; ++ln)
 			if ((o.line[ln].flags & LP_GOAL) && ln != L_AMP && ln != L_AMP2) bad = true;
-		if (o.type == OT_RASEG) bad = true;
 		if (o.type == OT_NOISE && o.wave == NZ_re) bad = true;
 		if (o.line[L_PMA].v0 != 0.f) bad = true; /* self-modulation is a recurrence */
 		o.rt_fconst_valid = 0;
@@ -1079,8 +1078,9 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 			continue;
 		}
 		if (st.flags & SF_BEGIN) { ++depth; if (depth > maxd) maxd = depth; }
+		const bool is_osc = o.type == OT_WAVE || o.type == OT_RASEG;
 		const bool freq_here = (st.kind == ST_LINE && st.which == L_FREQ) ||
-			(st.kind == ST_OSC && st.freq == NO_SLOT && o.type == OT_WAVE);
+			(st.kind == ST_OSC && st.freq == NO_SLOT && is_osc);
 		if (st.kind == ST_SMLINE || st.kind == ST_ZERO) bad = true;
 		if (st.kind == ST_LINE && st.which == L_FREQ && (st.flags & SF_FORCE)) bad = true; /* FM */
 		if (st.kind == ST_OSC && st.sm != NO_SLOT) bad = true;
@@ -1095,7 +1095,7 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 			o.rt_fconst = fc;
 			o.rt_fconst_valid = 1;
 		}
-		if (st.kind == ST_OSC && o.type == OT_WAVE && st.freq != NO_SLOT && !o.rt_fconst_valid) bad = true;
+		if (st.kind == ST_OSC && is_osc && st.freq != NO_SLOT && !o.rt_fconst_valid) bad = true;
 		if (st.flags & SF_END) --depth;
 	}
 	FastInfo fi;
@@ -1237,6 +1237,19 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 		f.tab = o.type == OT_WAVE ? P.tab_of_wave[wv] : -1;
 		f.gop = ids[st.op];
 		f.prev_Is = o.prev_Is;
+		if (o.type == OT_RASEG) {
+			/* rasg.h:165-222: 64-bit cycle|phase counter, post-increment. The fields a
+			 * W oscillator uses for its table and differentiator carry R's options. */
+			const bool rate2x = (o.flags & OPF_RATE2X) != 0;
+			const unsigned long long inc64 = (unsigned long long)rint64((rate2x ? o.coeff * 2 : o.coeff) * o.rt_fconst);
+			f.inc = (uint32_t)inc64;
+			f.prev_phase = (uint32_t)(inc64 >> 32);
+			f.prev_Is = __longlong_as_double((long long)o.cycle_phase);
+			f.tab = (int32_t)((o.ras_func & 0xff) | ((o.ras_flags & 0xffff) << 8) | ((o.wave & 0x7f) << 24));
+			f.diff_scale = bits_f(o.ras_level);
+			f.diff_offset = bits_f(o.ras_alpha);
+			f.type |= rate2x ? 1u << 17 : 0u;
+		}
 		f.pan = o.line[L_PAN].v0;
 		f.ramp = 0;
 		if (zero_fill) { /* becomes a constant line step */
@@ -1550,6 +1563,28 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 								}
 							}
 						}
+					} else if (type == OT_RASEG) {
+						/* rasg.h:165-222 + 692-743: frame t reads the counter cp0 + inc * t (+ PM) */
+						const bool rate2x = (f.type >> 17) & 1;
+						const float phase_scale = rate2x ? 0x1p31f * 2 : 0x1p31f;
+						const RasParams rp = ras_params((uint32_t)f.tab & 0xff, ((uint32_t)f.tab >> 8) & 0xffff,
+								f_bits(f.diff_scale), f_bits(f.diff_offset), ((uint32_t)f.tab >> 24) & 0x7f);
+						const unsigned long long inc64 = ((unsigned long long)f.prev_phase << 32) | f.inc;
+						const unsigned long long cp0 = (unsigned long long)__double_as_longlong(f.prev_Is);
+						const bool has_pm = f.pm_off != ~0u, has_fpm = f.fpm_off != ~0u;
+#pragma unroll
+						for (int k = 0; k < T; ++k) {
+							const int t = t0 + k * (int)C;
+							unsigned long long cp = cp0 + inc64 * (unsigned long long)(long long)t;
+							if (has_pm || has_fpm)
+								cp += (unsigned long long)pm_offset(has_pm, has_fpm,
+										has_pm ? slots[f.pm_off + k * 64] : 0.f,
+										has_fpm ? slots[f.fpm_off + k * 64] : 0.f, f.fc, phase_scale);
+							uint32_t cyc;
+							float phf;
+							ras_split(cp, cyc, phf);
+							s[k] = ras_sample(rp, cyc, phf);
+						}
 					} else if (type == OT_NOISE) {
 						const uint32_t nz = (f.type >> 8) & 0xff;
 						const uint32_t n0 = f.phase0, nprev = f.prev_phase;
@@ -1671,6 +1706,10 @@ __global__ void __launch_bounds__(64) finalize_kernel(FastParams P) {
 			o.prev_Is = o.st_prev_Is;
 			o.prev_s = o.st_prev_s;
 			o.flags &= ~OPF_OSC_RESET;
+		} else if (o.type == OT_RASEG) {
+			const bool rate2x = (o.flags & OPF_RATE2X) != 0;
+			const unsigned long long inc64 = (unsigned long long)rint64((rate2x ? o.coeff * 2 : o.coeff) * o.rt_fconst);
+			o.cycle_phase += inc64 * total;
 		} else if (o.type == OT_NOISE) {
 			const uint32_t n0 = o.noise_n;
 			if (o.wave == NZ_vi) o.noise_prev = ranfast32(n0 + total - 1);
@@ -2117,8 +2156,11 @@ public:
 					HIP_OK(hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
 					conf = flds;
 				}
-				/* four waves per voice when there are few voices, one CU-filling grid at most */
-				uint32_t fgrid = (seg.n_voices * 4 + 15) / 16;
+				/* as many waves per voice as it has row groups (up to 64) when voices are
+				 * few, one CU-filling grid at most */
+				const uint32_t groups = (seg.len + (60 * FT) - 1) / (60 * FT);
+				const unsigned long long want = (unsigned long long)seg.n_voices * (groups < 64 ? groups : 64);
+				uint32_t fgrid = (uint32_t)((want + 15) / 16 > FK_GRID ? FK_GRID : (want + 15) / 16);
 				if (fgrid > FK_GRID) fgrid = FK_GRID;
 				if (fgrid < 1) fgrid = 1;
 				TimedPair *tf = timing_on_ ? new_pair(2) : nullptr;
