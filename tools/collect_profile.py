@@ -1,0 +1,40 @@
+"""Turn one round's rocprofv3 outputs under gpurun_out/ into the summaries kept in profiles/:
+    python tools/collect_profile.py r01e r01_e
+expects gpurun_out/prof_<tag>/<tag>_kernel_stats.csv, gpurun_out/bench_<tag>.json and the PMC
+passes gpurun_out/pmc_<tag>_{fetch,write,sq,inst}/*_counter_collection.csv."""
+import collections
+import csv
+import json
+import shutil
+import sys
+
+tag, name = sys.argv[1], sys.argv[2]
+shutil.copy(f"gpurun_out/prof_{tag}/{tag}_kernel_stats.csv", f"profiles/{name}_bench_kernel_stats.csv")
+open(f"profiles/{name}_bench.json", "w").write(open(f"gpurun_out/bench_{tag}.json").read().strip().splitlines()[-1] + "\n")
+out = {"command": "rocprofv3 --pmc <C> --kernel-trace --output-format csv -- python3 bench.py --steps 4 --warmup 1 --no-cpu",
+       "workload": {"voices": 1024, "operators": 4096, "frames_per_step": 176400},
+       "note": "separate passes per counter group; FETCH_SIZE/WRITE_SIZE are KB per dispatch, averaged over "
+               "dispatches; gfx950 correction: FETCH_SIZE doubled (MI355X_MICROARCH.md HBM section; confirmed "
+               "here: mix_kernel reads 1024x176400 f32 = 722.5 MB and FETCH_SIZE reports half of it), WRITE_SIZE "
+               "exact (fast_kernel writes 722.5 MB of voice rows)", "kernels": {}}
+for d, f in (("fetch", "f"), ("write", "w"), ("sq", "s"), ("inst", "i")):
+    src = f"gpurun_out/pmc_{tag}_{d}/{f}_counter_collection.csv"
+    shutil.copy(src, f"profiles/{name}_pmc_{d}_counter_collection.csv")
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(src)):
+        if "sauhip" in r["Kernel_Name"]:
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            o = out["kernels"].setdefault(k, {})
+            o.update(vgpr=int(r["VGPR_Count"]), sgpr=int(r["SGPR_Count"]), scratch=int(r["Scratch_Size"]),
+                     workgroup=int(r["Workgroup_Size"]), grid=int(r["Grid_Size"]))
+    for k, v in agg.items():
+        for c, x in v.items():
+            out["kernels"][k][c] = sum(x) / len(x)
+for k, v in out["kernels"].items():
+    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        v["hbm_bytes_per_launch_corrected"] = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
+json.dump(out, open(f"profiles/{name}_pmc_summary.json", "w"), indent=1)
+fk = [v for n, v in out["kernels"].items() if "fast_kernel" in n][0]
+rows = 1024 * 4 * 176400 / 60  # 64-lane rows incl. lead-in, per launch
+print({a: (round(b / rows, 2) if isinstance(b, float) and b > 1e6 else b) for a, b in fk.items()})
