@@ -178,6 +178,7 @@ bool Engine::handle_event(Stream &st, const EventNode &e, std::vector<OpUpdate> 
 bool Engine::rebuild_plans(std::string &err) {
 	all_steps_.clear();
 	all_fast_ids_.clear();
+	all_fast_ids_full_.clear();
 	all_op_ids_.clear();
 	for (Stream &st : streams_) {
 		for (size_t v = 0; v < st.voices.size(); ++v) {
@@ -190,6 +191,7 @@ bool Engine::rebuild_plans(std::string &err) {
 					/* a voice whose carrier never got data stays silent */
 					vn.plan.steps.clear();
 					vn.plan.fast_ids.clear();
+					vn.plan.fast_ids_full.clear();
 					vn.plan.op_ids.clear();
 					if (err != "voice carrier operator was never initialised")
 						return false;
@@ -204,6 +206,8 @@ bool Engine::rebuild_plans(std::string &err) {
 			all_steps_.insert(all_steps_.end(), vn.plan.steps.begin(), vn.plan.steps.end());
 			all_fast_ids_.insert(all_fast_ids_.end(), vn.plan.fast_ids.begin(), vn.plan.fast_ids.end());
 			all_fast_ids_.resize(all_steps_.size());
+			all_fast_ids_full_.insert(all_fast_ids_full_.end(), vn.plan.fast_ids_full.begin(), vn.plan.fast_ids_full.end());
+			all_fast_ids_full_.resize(all_steps_.size());
 			for (uint32_t id : vn.plan.op_ids)
 				all_op_ids_.push_back(st.op_base + id);
 		}
@@ -225,6 +229,7 @@ bool Engine::rebuild_plans(std::string &err) {
 			}
 	}
 	plans_dirty_ = false;
+	all_fast_ids_.insert(all_fast_ids_.end(), all_fast_ids_full_.begin(), all_fast_ids_full_.end());
 	return backend_->upload_plans(all_steps_.data(), all_fast_ids_.data(), all_steps_.size(),
 			all_op_ids_.data(), all_op_ids_.size(), err);
 }
@@ -233,7 +238,7 @@ bool Engine::rebuild_plans(std::string &err) {
 bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::string &err) {
 	std::vector<VoiceDesc> descs;
 	std::vector<SegmentDesc::Stream> sdescs(streams_.size());
-	uint32_t n_main = 1, n_fpool = 0, max_ops = 1, n_pan = 0, max_steps = 1, n_fast = 1;
+	uint32_t n_main = 1, n_fpool = 0, max_ops = 1, n_pan = 0, max_steps = 1, n_fast = 1, n_fast_full = 0;
 	uint64_t wave_mask = 0;
 	bool maybe_block = false, serial = false;
 	for (size_t s = 0; s < streams_.size(); ++s) {
@@ -276,11 +281,12 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 			max_steps = std::max(max_steps, (uint32_t)vn.plan.steps.size());
 			wave_mask |= vn.plan.wave_mask;
 			/* will the time-parallel path surely cover this voice's whole run? */
+			bool voice_block = vn.plan.static_block; /* this voice may leave the closed-form path */
 			if (vn.plan.static_block || vn.plan.no_fast) maybe_block = true;
 			if (vn.plan.selfmod) serial = true;
 			for (uint32_t id : vn.plan.op_ids) {
 				OpMirror &m = st.ops[id];
-				if (m.goal_seen || (m.line_set & (1u << L_PMA))) maybe_block = true;
+				if (m.goal_seen || (m.line_set & (1u << L_PMA))) { maybe_block = true; voice_block = true; }
 				if (m.line_set & (1u << L_PMA)) serial = true;
 				if (id != vn.carr_op && !m.time_inf) {
 					/* conservative mirror: non-carriers tick whenever the voice runs */
@@ -289,6 +295,7 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 				}
 			}
 			if (out_len < run_len) maybe_block = true;
+			if (voice_block && !vn.plan.no_fast) n_fast_full = std::max(n_fast_full, vn.plan.n_fast_full);
 		}
 		sd.n_voices = (uint32_t)descs.size() - sd.first_voice;
 		if (sd.write_len > 0) {
@@ -302,7 +309,7 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 	seg.len = len; seg.pcm_offset = offset; seg.stereo = stereo; seg.swap_bytes = pcm_swap_;
 	seg.voices = descs.data(); seg.n_voices = (uint32_t)descs.size();
 	seg.streams = sdescs.data(); seg.n_streams = (uint32_t)sdescs.size();
-	seg.n_slots = n_main + n_fpool; seg.n_main = n_main; seg.n_fast = n_fast; seg.max_ops = max_ops; seg.n_pan_rows = n_pan;
+	seg.n_slots = n_main + n_fpool; seg.n_main = n_main; seg.n_fast = n_fast; seg.n_fast_full = n_fast_full; seg.max_ops = max_ops; seg.n_pan_rows = n_pan;
 	seg.max_steps = max_steps;
 	seg.wave_mask = wave_mask;
 	seg.maybe_block = maybe_block;

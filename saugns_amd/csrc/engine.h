@@ -44,6 +44,7 @@ struct SegmentDesc {
 	uint32_t n_slots;         /* max over active plans of main + frequency slots */
 	uint32_t n_main;          /* max main-pool slots (slot_index() base) */
 	uint32_t n_fast;          /* max block buffers the time-parallel path needs (fast_slot_compact) */
+	uint32_t n_fast_full;     /* the same with frequency blocks, over voices that may need them (0: none) */
 	uint32_t max_ops;         /* max operators in any active voice */
 	uint32_t max_steps;       /* longest active plan */
 	uint32_t n_pan_rows;
@@ -68,7 +69,8 @@ public:
 	virtual bool init(const BackendConfig &cfg, std::string &err) = 0;
 	/* grow PCM / voice matrices when a caller passes a longer buffer */
 	virtual bool reserve_frames(uint32_t max_frames, bool stereo, std::string &err) = 0;
-	/* plans changed: full step array + op id lists */
+	/* plans changed: full step array + op id lists; fast_ids holds 2 * n_steps entries:
+	 * the numbering without frequency blocks, then the one with them */
 	virtual bool upload_plans(const Step *steps, const FastIds *fast_ids, size_t n_steps,
 			const uint32_t *op_ids, size_t n_ids, std::string &err) = 0;
 	/* apply operator updates in order; ops are distinct within one call */
@@ -115,6 +117,8 @@ struct VoicePlan {
 	uint32_t n_main = 0;           /* main-pool slots (ids below FSLOT_BASE) */
 	uint32_t n_fast = 0;           /* buffers live at once in the time-parallel path */
 	std::vector<FastIds> fast_ids; /* per step: block buffers renumbered by liveness */
+	uint32_t n_fast_full = 0;      /* ... counting frequency blocks too (ramps, FM) */
+	std::vector<FastIds> fast_ids_full;
 	uint64_t wave_mask = 0;
 	bool has_camods = false;
 	bool no_fast = false;          /* an operator is evaluated twice per block */
@@ -189,7 +193,7 @@ private:
 	bool plans_dirty_ = true;
 	/* concatenated plans as uploaded; per (stream,voice) offsets */
 	std::vector<Step> all_steps_;
-	std::vector<FastIds> all_fast_ids_;
+	std::vector<FastIds> all_fast_ids_, all_fast_ids_full_;
 	std::vector<uint32_t> all_op_ids_;
 	struct PlanRef { uint32_t plan_ofs, plan_len, ops_ofs, nops; };
 	std::vector<PlanRef> plan_refs_; /* indexed by global voice index */

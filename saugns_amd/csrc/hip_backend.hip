@@ -997,10 +997,12 @@ struct FastInfo {
 	uint32_t H;     /* lead-in samples per chunk */
 	uint32_t bail;  /* set when a chunk met dphase == 0 (hold-previous run) */
 	uint32_t n_fsteps; /* decoded steps of the voice (decode_kernel) */
+	uint32_t seq;   /* some oscillator's frequency varies (ramp, FM): one wave walks the voice in order, carrying phase sums */
 };
 
 struct FastStep;
 struct FastLine;
+struct FastAux;
 struct FastParams {
 	const VoiceDesc *voices;
 	const Step *steps;
@@ -1018,9 +1020,12 @@ struct FastParams {
 	const HerpC01 *g_c01;
 	FastStep *fsteps;     /* [n_voices][max_steps], written by decode_kernel */
 	FastLine *flines;     /* same indexing: the ramp of a step whose line is in progress */
+	FastAux *faux;        /* same indexing: sequential-scan extras */
 	uint32_t row_stride, n_voices, n_fast, max_ops, max_steps, n_tabs, np;
 	uint32_t rows;        /* T of the fast_kernel<T> that will run: block buffers hold 64 * rows frames */
 	uint32_t enable;      /* 0: leave every voice to the block loop */
+	uint32_t seq_enable;  /* block buffers are sized for frequency blocks: sequential-scan voices allowed */
+	uint32_t ids_full_ofs;/* offset of the with-frequency numbering in fast_ids */
 	int8_t tab_of_wave[12];
 	uint8_t wave_of_tab[12];
 	WaveConst wc[12];
@@ -1032,6 +1037,7 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 	const VoiceDesc vd = P.voices[v];
 	const uint32_t *ids = P.op_ids + vd.ops_ofs;
 	bool bad = (vd.flags & VD_NO_FAST) != 0 || !P.enable;
+	bool seq = false;
 	uint32_t min_time = 0xFFFFFFFFu;
 	const Step *plan = P.steps + vd.plan_ofs;
 	/* An operator that has run out of time yields nothing, and neither it nor
@@ -1061,8 +1067,11 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 		/* ramps in progress: amplitude lines are closed-form per frame (sau/line.c
 		 * fills depend on the position only); frequency ramps need a phase scan,
 		 * self-modulation and pan ramps stay with the block loop */
-		for (uint32_t ln = 0; ln < L_COUNT; ++ln)
-			if ((o.line[ln].flags & LP_GOAL) && ln != L_AMP && ln != L_AMP2) bad = true;
+		for (uint32_t ln = 0; ln < L_COUNT; ++ln) {
+			if (!(o.line[ln].flags & LP_GOAL)) continue;
+			if (ln == L_FREQ || ln == L_FREQ2) seq = true; /* phase becomes a running sum */
+			else if (ln != L_AMP && ln != L_AMP2) bad = true;
+		}
 		if (o.type == OT_NOISE && o.wave == NZ_re) bad = true;
 		if (o.line[L_PMA].v0 != 0.f) bad = true; /* self-modulation is a recurrence */
 		o.rt_fconst_valid = 0;
@@ -1082,25 +1091,49 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 		const bool freq_here = (st.kind == ST_LINE && st.which == L_FREQ) ||
 			(st.kind == ST_OSC && st.freq == NO_SLOT && is_osc);
 		if (st.kind == ST_SMLINE || st.kind == ST_ZERO) bad = true;
-		if (st.kind == ST_LINE && st.which == L_FREQ && (st.flags & SF_FORCE)) bad = true; /* FM */
 		if (st.kind == ST_OSC && st.sm != NO_SLOT) bad = true;
+		/* a ratio line (sau/line.c:72) multiplies by the parent's frequency: one value, or a block */
+		bool pconst = false; float pf = 0.f;
+		if (st.fmul != NO_SLOT && st.prov != NO_SLOT) {
+			const DevOp &po = P.ops[ids[st.prov]];
+			pconst = po.rt_fconst_valid != 0; pf = po.rt_fconst;
+		}
+		if (st.kind == ST_LINE || freq_here) {
+			const LineState &ls = o.line[st.kind == ST_LINE ? st.which : L_FREQ];
+			const bool g_ratio = (ls.flags & LP_GOAL_RATIO) != 0, s_ratio = (ls.flags & LP_STATE_RATIO) != 0;
+			if (st.fmul != NO_SLOT) {
+				/* a ramp whose goal and state disagree about being ratios rescales its
+				 * state by the parent's first sample (sau/line.c:358-370): block loop */
+				if ((ls.flags & LP_GOAL) && g_ratio != s_ratio) bad = true;
+				if ((s_ratio || ((ls.flags & LP_GOAL) && g_ratio)) && !pconst) seq = true;
+			}
+		}
 		if (freq_here && !bad) {
 			const LineState &fl = o.line[L_FREQ];
+			/* one value for the segment? (the block loop's const_freq) */
+			bool isconst = !(fl.flags & LP_GOAL) && !(st.kind == ST_LINE && (st.flags & SF_FORCE));
 			float fc = fl.v0;
 			if (st.fmul != NO_SLOT && (fl.flags & LP_STATE_RATIO)) {
-				const uint32_t pg = st.prov != NO_SLOT ? ids[st.prov] : 0;
-				if (st.prov == NO_SLOT || !P.ops[pg].rt_fconst_valid) bad = true;
-				else fc = fl.v0 * P.ops[pg].rt_fconst; /* sau/line.c:72 */
+				if (pconst) fc = fl.v0 * pf; /* sau/line.c:72 */
+				else isconst = false;
 			}
 			o.rt_fconst = fc;
-			o.rt_fconst_valid = 1;
+			o.rt_fconst_valid = isconst ? 1u : 0u;
+			if (!isconst) {
+				seq = true;
+				if (o.type == OT_RASEG) bad = true; /* 64-bit counter sums: block loop for now */
+			}
 		}
-		if (st.kind == ST_OSC && is_osc && st.freq != NO_SLOT && !o.rt_fconst_valid) bad = true;
+		if (st.kind == ST_OSC && is_osc && st.freq != NO_SLOT && !o.rt_fconst_valid) {
+			seq = true;
+			if (o.type == OT_RASEG) bad = true;
+		}
 		if (st.flags & SF_END) --depth;
 	}
 	FastInfo fi;
-	fi.H = maxd; fi.bail = 0; fi.n_fsteps = 0;
+	fi.H = maxd; fi.bail = 0; fi.n_fsteps = 0; fi.seq = seq ? 1u : 0u;
 	fi.total = 0;
+	if (seq && !P.seq_enable) bad = true;
 	if (!bad && vd.nops <= P.max_ops && vd.plan_len <= P.max_steps && maxd >= 1 && maxd <= P.np / 2)
 		fi.total = min(min_time, vd.run_len);
 	P.info[v] = fi;
@@ -1120,7 +1153,7 @@ struct FastStep {
 	uint32_t gop;       /* global operator index (state staging) */
 	double prev_Is;
 	float pan;
-	uint32_t ramp;      /* nonzero: the step's line is a ramp in progress, see FastLine */
+	uint32_t ramp;      /* bit 0: the step's line is a ramp in progress (FastLine); bit 1: FastAux present */
 };
 static_assert(sizeof(FastStep) == 80, "FastStep is 20 dwords");
 
@@ -1133,6 +1166,24 @@ struct FastLine {
 	uint32_t pad;
 };
 static_assert(sizeof(FastLine) == 48, "FastLine is 12 dwords");
+
+/* What only a sequential-scan voice needs of a step (FastStep.ramp bit 1): where
+ * per-frame frequencies come from and how a ratio line is multiplied. */
+enum : uint32_t {
+	FA_FVAR_SLOT = 1u << 0, /* ST_OSC: frequency per frame from block buffer freq_off */
+	FA_FVAR_LINE = 1u << 1, /* ST_OSC: frequency per frame from its own line `fl` (x multiplier) */
+	FA_MUL_GOAL = 1u << 2,  /* the ramp part of the line is a ratio: x multiplier (sau/line.c:72) */
+	FA_MUL_HOLD = 1u << 3,  /* the held part of the line is a ratio */
+};
+struct FastAux {
+	uint32_t freq_off, fmul_off; /* block buffers (float offsets) or ~0u */
+	float coeff;                 /* 2^32 / srate (wosc.h:30) */
+	uint32_t flags;              /* FA_* */
+	float mulc;                  /* the multiplier when the parent's frequency is one value */
+	uint32_t pad[3];
+	FastLine fl;                 /* ST_OSC with FA_FVAR_LINE: the frequency line's block */
+};
+static_assert(sizeof(FastAux) == 80, "FastAux is 20 dwords");
 
 __device__ __forceinline__ FastStep uni(const FastStep &f) {
 	union { FastStep s; uint32_t u[20]; } c; c.s = f;
@@ -1161,6 +1212,13 @@ __device__ __forceinline__ FastLine load_line_uniform(const FastLine *p) {
 	for (int i = 0; i < 12; ++i) c.u[i] = q[i];
 	return c.s;
 }
+__device__ __forceinline__ FastAux load_aux_uniform(const FastAux *p) {
+	const_u32_ptr q = (const_u32_ptr)(uintptr_t)p;
+	union { FastAux s; uint32_t u[20]; } c;
+#pragma unroll
+	for (int i = 0; i < 20; ++i) c.u[i] = q[i];
+	return c.s;
+}
 /* value of a ramp at frame t of the segment (lead-in frames t < 0 get the hold value: unused) */
 __device__ __forceinline__ float fast_line_value(const FastLine &fl, int t) {
 	const uint32_t i = (uint32_t)t;
@@ -1182,7 +1240,10 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 	bool keep = false;
 	FastStep f;
 	FastLine fl;
+	FastAux fa;
+	memset(&f, 0, sizeof f); memset(&fl, 0, sizeof fl); memset(&fa, 0, sizeof fa);
 	uint32_t dep = 0;
+	const uint32_t seq = P.info[v].seq;
 	if ((uint32_t)l < vd.plan_len) {
 		const Step *plan = P.steps + vd.plan_ofs;
 		/* nesting depth of this step = BEGINs up to and including it minus ENDs before it */
@@ -1193,7 +1254,8 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 		}
 		const Step st = plan[l];
 		const DevOp &o = P.ops[ids[st.op]];
-		keep = !(st.kind == ST_LINE && st.which == L_FREQ);
+		/* a frequency line is materialised only when it is not one value (sequential-scan voices) */
+		keep = !(st.kind == ST_LINE && st.which == L_FREQ && o.rt_fconst_valid);
 		bool zero_fill = false;
 		if (o.rt_frozen) {
 			/* out of time: of the whole subtree only the root's final step remains,
@@ -1219,7 +1281,7 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 		}
 		f.kind = (uint32_t)st.kind | ((uint32_t)st.flags << 8) | ((uint32_t)st.which << 16) | (dep << 24);
 		/* block buffers renumbered by liveness (sau_dev_types.h): out, pm, fpm, amp, range end */
-		const FastIds cs = P.fast_ids[vd.plan_ofs + l];
+		const FastIds cs = P.fast_ids[(seq ? P.ids_full_ofs : 0u) + vd.plan_ofs + l];
 		f.out_off = cs.out != NO_SLOT ? (uint32_t)cs.out * NP : ~0u;
 		f.pm_off = cs.pm != NO_SLOT ? (uint32_t)cs.pm * NP : ~0u;
 		f.fpm_off = cs.fpm != NO_SLOT ? (uint32_t)cs.fpm * NP : ~0u;
@@ -1256,13 +1318,53 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 			f.kind = (uint32_t)ST_LINE | ((uint32_t)L_AMP << 16) | (dep << 24);
 			f.ac = 0.f;
 		} else {
-			const bool line_step = st.kind == ST_LINE && st.which != L_FREQ;
+			const bool line_step = st.kind == ST_LINE;
 			const bool amp_inline = st.kind == ST_OSC && st.amp == NO_SLOT;
+			/* multiplier of a ratio line: the parent's frequency, one value or a block */
+			const bool have_mul = st.fmul != NO_SLOT;
+			bool pconst = false; float pf = 1.f;
+			if (have_mul && st.prov != NO_SLOT) {
+				const DevOp &po = P.ops[ids[st.prov]];
+				pconst = po.rt_fconst_valid != 0; pf = po.rt_fconst;
+			}
+			fa.freq_off = ~0u; fa.fmul_off = ~0u; fa.coeff = o.coeff; fa.flags = 0; fa.mulc = 1.f;
+			fa.pad[0] = fa.pad[1] = fa.pad[2] = 0;
+			fa.fl.goal_len = 0; fa.fl.hold = 0.f; fa.fl.pad = 0;
+			fa.fl.sw = sweep_setup(LN_sah, 0.f, 0.f, 0, 1);
 			LineState ls = o.line[line_step ? st.which : L_AMP];
-			if ((line_step || amp_inline) && (ls.flags & LP_GOAL)) {
-				const LineBlock lb = line_begin(ls, P.info[v].total, false, 0.f);
-				fl.sw = lb.sw; fl.goal_len = lb.goal_len; fl.hold = lb.hold; fl.pad = 0;
-				f.ramp = 1;
+			if (line_step || amp_inline) {
+				if (ls.flags & LP_GOAL) {
+					const LineBlock lb = line_begin(ls, P.info[v].total, line_step && have_mul, 1.f);
+					fl.sw = lb.sw; fl.goal_len = lb.goal_len; fl.hold = lb.hold; fl.pad = 0;
+					f.ramp = 1;
+					if (lb.mul_goal) fa.flags |= FA_MUL_GOAL;
+					if (lb.mul_hold) fa.flags |= FA_MUL_HOLD;
+				} else if (line_step && have_mul && (ls.flags & LP_STATE_RATIO)) {
+					fa.flags |= FA_MUL_HOLD;
+				}
+				if (fa.flags & (FA_MUL_GOAL | FA_MUL_HOLD)) {
+					if (pconst) fa.mulc = pf; else fa.fmul_off = cs.fmul != NO_SLOT ? (uint32_t)cs.fmul * NP : ~0u;
+					f.ramp |= 2;
+				}
+			}
+			const bool is_osc = o.type == OT_WAVE || o.type == OT_RASEG;
+			if (st.kind == ST_OSC && is_osc && !o.rt_fconst_valid) {
+				/* frequency per frame: from its block, or from its own line when it has no block */
+				if (st.freq != NO_SLOT) {
+					fa.flags |= FA_FVAR_SLOT;
+					fa.freq_off = cs.freq != NO_SLOT ? (uint32_t)cs.freq * NP : ~0u;
+				} else {
+					LineState fls = o.line[L_FREQ];
+					const LineBlock lb = line_begin(fls, P.info[v].total, have_mul, 1.f);
+					fa.fl.sw = lb.sw; fa.fl.goal_len = lb.goal_len; fa.fl.hold = lb.hold;
+					fa.flags |= FA_FVAR_LINE;
+					if (lb.mul_goal) fa.flags |= FA_MUL_GOAL;
+					if (lb.mul_hold) fa.flags |= FA_MUL_HOLD;
+					if (fa.flags & (FA_MUL_GOAL | FA_MUL_HOLD)) {
+						if (pconst) fa.mulc = pf; else fa.fmul_off = cs.fmul != NO_SLOT ? (uint32_t)cs.fmul * NP : ~0u;
+					}
+				}
+				f.ramp |= 2;
 			}
 		}
 	}
@@ -1270,7 +1372,8 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 	if (keep) {
 		const uint32_t pos = (uint32_t)__popcll(m & ((1ull << l) - 1ull));
 		fsteps[pos] = f;
-		if (f.ramp) P.flines[(size_t)v * P.max_steps + pos] = fl;
+		if (f.ramp & 1) P.flines[(size_t)v * P.max_steps + pos] = fl;
+		if (f.ramp & 2) P.faux[(size_t)v * P.max_steps + pos] = fa;
 	}
 	if (l == 0) P.info[v].n_fsteps = (uint32_t)__popcll(m);
 }
@@ -1309,8 +1412,9 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 	HerpC23 *t23 = (HerpC23 *)lds;
 	HerpC01 *t01 = (HerpC01 *)(lds + (size_t)P.n_tabs * WAVE_LEN * sizeof(HerpC23));
 	unsigned char *areas = lds + (size_t)P.n_tabs * WAVE_LEN * (sizeof(HerpC23) + sizeof(HerpC01));
-	const size_t area_bytes = (size_t)P.n_fast * NP * sizeof(float);
+	const size_t area_bytes = (size_t)P.n_fast * NP * sizeof(float) + (size_t)P.max_steps * sizeof(uint32_t);
 	float *slots = (float *)(areas + (size_t)w * area_bytes) + l; /* lane's column of every row */
+	uint32_t *carry = (uint32_t *)(areas + (size_t)w * area_bytes + (size_t)P.n_fast * NP * sizeof(float)); /* per step */
 
 	for (uint32_t t = 0; t < P.n_tabs; ++t) {
 		const uint32_t wave = P.wave_of_tab[t];
@@ -1342,6 +1446,11 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 		const uint32_t n_fsteps = uni(fi.n_fsteps);
 		const FastStep *fsteps = P.fsteps + (size_t)v * P.max_steps;
 		const FastLine *flines = P.flines + (size_t)v * P.max_steps;
+		const FastAux *faux = P.faux + (size_t)v * P.max_steps;
+		/* sequential-scan voices: the one wave with cstart == 0 walks every row group in order */
+		const bool seq = uni(fi.seq) != 0;
+		if (seq && cstart != 0) continue;
+		const uint32_t gstride = seq ? 1u : wpv;
 		float *vrow = P.vout + (size_t)vd.out_row * P.row_stride;
 		float *prow = (vd.pan_dynamic_row != ~0u) ? P.pan + (size_t)vd.pan_dynamic_row * P.row_stride : nullptr;
 		/* A wave renders T rows at a time; a row is 64 consecutive frames, one per
@@ -1352,7 +1461,7 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 		const uint32_t last_group = ((fast_total - 1) / C) / T; /* holds the segment's last frame */
 		uint32_t zero_acc = 0; /* nonzero: some hold-previous run could not be resolved here */
 
-		for (uint32_t cg = cstart; cg < ngroups; cg += wpv) {
+		for (uint32_t cg = cstart; cg < ngroups; cg += gstride) {
 			const int t0 = (int)(cg * T * C) - (int)H + l; /* this lane's frame in row 0 */
 			const bool first_group = (cg == 0);
 			const bool is_last_group = (cg == last_group);
@@ -1380,7 +1489,7 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 						 * (one more lead-in sample per nesting level below it) */
 						const int p_min = (int)H - (int)(f.kind >> 24) + 1;
 						bool done = false;
-						if (FK_COMMON && f.tab >= 0 && !has_fpm && !first_group && !is_last_group) {
+						if (FK_COMMON && f.tab >= 0 && !has_fpm && !first_group && !is_last_group && !(f.ramp & 2)) {
 							/* the common case, straight-line: table in LDS, plain PM or
 							 * none, no segment edge in this group */
 							uint32_t ph[T];
@@ -1434,13 +1543,53 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 						if (!done) {
 							uint32_t ph[T];
 							double Is[T];
-							/* phase0 + inc*(t+1): one multiply per lane, then adds */
-							{
+							float fv[T]; /* frequency per frame (freq-scaled PM reads it) */
+							bool fvar = false;
+							if (f.ramp & 2) {
+								/* the frequency varies (ramp, FM): phase is a running sum of per-frame
+								 * increments (wosc.h:135-169). This wave walks the voice's rows in order;
+								 * `carry` holds the accumulator at the frame before each row's new frames. */
+								const FastAux fa = load_aux_uniform(faux + si);
+								fvar = (fa.flags & (FA_FVAR_SLOT | FA_FVAR_LINE)) != 0;
+								if (fvar) {
+									uint32_t S[T];
+#pragma unroll
+									for (int k = 0; k < T; ++k) {
+										const int t = t0 + k * (int)C;
+										float v;
+										if (fa.flags & FA_FVAR_SLOT) {
+											v = slots[fa.freq_off + k * 64];
+										} else {
+											v = fast_line_value(fa.fl, t);
+											const bool in_goal = (uint32_t)t < fa.fl.goal_len;
+											if (fa.flags & (in_goal ? FA_MUL_GOAL : FA_MUL_HOLD))
+												v *= fa.fmul_off != ~0u ? slots[fa.fmul_off + k * 64] : fa.mulc;
+										}
+										fv[k] = v;
+										const uint32_t inc = (t >= 0 && t < (int)fast_total) ? rint32w(fa.coeff * v) : 0u;
+										S[k] = wave_incl_scan(inc, l);
+									}
+									uint32_t acc = first_group ? f.phase0 : carry[si];
+#pragma unroll
+									for (int k = 0; k < T; ++k) {
+										const uint32_t lead = (uint32_t)__builtin_amdgcn_readlane((int)S[k], (int)H - 1);
+										const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)S[k], 63);
+										ph[k] = acc + (S[k] - lead);
+										acc += last - lead;
+									}
+									if (l == 0) carry[si] = acc;
+								}
+							}
+							if (!fvar) {
+								/* phase0 + inc*(t+1): one multiply per lane, then adds */
 								uint32_t acc = f.phase0 + f.inc * (uint32_t)(t0 + 1);
 								const uint32_t row_inc = f.inc * C;
 #pragma unroll
-								for (int k = 0; k < T; ++k) { ph[k] = acc; acc += row_inc; }
+								for (int k = 0; k < T; ++k) { ph[k] = acc; acc += row_inc; fv[k] = f.fc; }
 							}
+							uint32_t phu[T]; /* accumulator values, before modulation */
+#pragma unroll
+							for (int k = 0; k < T; ++k) phu[k] = ph[k];
 							if (has_pm && !has_fpm) {
 								float pm[T];
 								bool big = false;
@@ -1470,10 +1619,10 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 								}
 								if (has_pm) {
 #pragma unroll
-									for (int k = 0; k < T; ++k) ph[k] += pm_offset32(true, true, pm[k], fpm[k], f.fc);
+									for (int k = 0; k < T; ++k) ph[k] += pm_offset32(true, true, pm[k], fpm[k], fv[k]);
 								} else {
 #pragma unroll
-									for (int k = 0; k < T; ++k) ph[k] += pm_offset32(false, true, 0.f, fpm[k], f.fc);
+									for (int k = 0; k < T; ++k) ph[k] += pm_offset32(false, true, 0.f, fpm[k], fv[k]);
 								}
 							}
 							const bool reset = (f.type >> 16) & 1;
@@ -1505,7 +1654,7 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 							}
 							uint32_t pph[T];
 							bool zero = false;
-							if (FK_CONSTD && !has_pm && !has_fpm && !first_group && f.inc != 0) {
+							if (FK_CONSTD && !has_pm && !has_fpm && !first_group && f.inc != 0 && !fvar) {
 								/* unmodulated: every phase step is inc, one division serves all */
 								const double x = (double)div_f32_normal(f.diff_scale, (float)(int32_t)f.inc);
 #pragma unroll
@@ -1556,6 +1705,7 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 									const int t = t0 + k * (int)C;
 									if (t == (int)fast_total - 1 && l >= (int)H) {
 										DevOp &o = P.ops[f.gop];
+										o.st_phase = phu[k];
 										o.st_prev_phase = ph[k];
 										o.st_prev_Is = Is[k];
 										o.st_prev_s = s[k];
@@ -1613,7 +1763,7 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 					if (f.amp_off != ~0u) {
 #pragma unroll
 						for (int k = 0; k < T; ++k) r[k] = slots[f.amp_off + k * 64];
-					} else if (f.ramp) { /* amplitude ramp in progress, sau/line.c:65-281 */
+					} else if (f.ramp & 1) { /* amplitude ramp in progress, sau/line.c:65-281 */
 						const FastLine fl = load_line_uniform(flines + si);
 #pragma unroll
 						for (int k = 0; k < T; ++k) r[k] = fast_line_value(fl, t0 + k * (int)C);
@@ -1645,9 +1795,25 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 				} else if (kind == ST_LINE) {
 					/* held line: v0 (sau/line.c:435-442); ratio lines only exist for freq */
 					if (f.ramp) {
-						const FastLine fl = load_line_uniform(flines + si);
+						FastLine fl;
+						fl.goal_len = 0; fl.hold = f.ac; fl.pad = 0;
+						fl.sw = sweep_setup(LN_sah, 0.f, 0.f, 0, 1);
+						if (f.ramp & 1) fl = load_line_uniform(flines + si);
+						uint32_t mflags = 0, fmul_off = ~0u;
+						float mulc = 1.f;
+						if (f.ramp & 2) { /* ratio line: x the parent's frequency (sau/line.c:72) */
+							const FastAux fa = load_aux_uniform(faux + si);
+							mflags = fa.flags; fmul_off = fa.fmul_off; mulc = fa.mulc;
+						}
 #pragma unroll
-						for (int k = 0; k < T; ++k) slots[f.out_off + k * 64] = fast_line_value(fl, t0 + k * (int)C);
+						for (int k = 0; k < T; ++k) {
+							const int t = t0 + k * (int)C;
+							float v = fast_line_value(fl, t);
+							const bool in_goal = (uint32_t)t < fl.goal_len;
+							if (mflags & (in_goal ? FA_MUL_GOAL : FA_MUL_HOLD))
+								v *= fmul_off != ~0u ? slots[fmul_off + k * 64] : mulc;
+							slots[f.out_off + k * 64] = v;
+						}
 					} else {
 #pragma unroll
 						for (int k = 0; k < T; ++k) slots[f.out_off + k * 64] = f.ac;
@@ -1700,8 +1866,8 @@ __global__ void __launch_bounds__(64) finalize_kernel(FastParams P) {
 			o.line[ln] = ls;
 		}
 		if (o.type == OT_WAVE) {
-			const uint32_t inc = rint32w(o.coeff * o.rt_fconst);
-			o.phase += inc * total;
+			if (o.rt_fconst_valid) o.phase += rint32w(o.coeff * o.rt_fconst) * total;
+			else o.phase = o.st_phase; /* running sum, staged by the sequential scan */
 			o.prev_phase = o.st_prev_phase;
 			o.prev_Is = o.st_prev_Is;
 			o.prev_s = o.st_prev_s;
@@ -1937,6 +2103,7 @@ public:
 		geo_ = (wt && !strcmp(wt, "8x2")) ? 0 : 1; /* default 4 waves x 4 samples per lane */
 		debug_ = getenv("SAU_AMD_DEBUG") != nullptr;
 		fast_enabled_ = getenv("SAU_AMD_NO_FAST") == nullptr;
+		seq_enabled_ = getenv("SAU_AMD_NO_SEQ") == nullptr; /* sequential-scan voices in the time-parallel kernel */
 		/* voices per segment from which feedback voices get sixteen one-wave teams per workgroup
 		 * (0: never; 1: always, also without feedback -- tests) */
 		multi_min_ = 256;
@@ -1983,10 +2150,11 @@ public:
 			size_t n_ids, std::string &err) override {
 		HIP_OK(hipStreamSynchronize(stream_));
 		if (!steps_.ensure(n_steps ? n_steps : 1, err) || !op_ids_.ensure(n_ids ? n_ids : 1, err) ||
-		    !fast_ids_.ensure(n_steps ? n_steps : 1, err))
+		    !fast_ids_.ensure(n_steps ? 2 * n_steps : 1, err))
 			return false;
 		if (n_steps) HIP_OK(hipMemcpy(steps_.p, steps, n_steps * sizeof(Step), hipMemcpyHostToDevice));
-		if (n_steps) HIP_OK(hipMemcpy(fast_ids_.p, fast_ids, n_steps * sizeof(FastIds), hipMemcpyHostToDevice));
+		if (n_steps) HIP_OK(hipMemcpy(fast_ids_.p, fast_ids, 2 * n_steps * sizeof(FastIds), hipMemcpyHostToDevice));
+		n_steps_total_ = (uint32_t)n_steps;
 		if (n_ids) HIP_OK(hipMemcpy(op_ids_.p, op_ids, n_ids * sizeof(uint32_t), hipMemcpyHostToDevice));
 		return true;
 	}
@@ -2110,7 +2278,13 @@ public:
 			 * (more rows amortise the per-step work: 8 rows measured 8 % faster
 			 * than 4, 4 rows 28 % faster than 2) */
 			uint32_t FT = fast_rows_;
-			auto area_of = [&](uint32_t t) { return (size_t)seg.n_fast * 64 * t * sizeof(float); };
+			/* block buffers: without frequency blocks, or with them when some voice may need
+			 * the sequential scan (ramped or modulated frequencies) */
+			const bool seq_ok = seq_enabled_ && seg.n_fast_full > 0;
+			const uint32_t n_fast = seq_ok && seg.n_fast_full > seg.n_fast ? seg.n_fast_full : seg.n_fast;
+			auto area_of = [&](uint32_t t) {
+				return (size_t)n_fast * 64 * t * sizeof(float) + (size_t)fmax_steps * sizeof(uint32_t);
+			};
 			const size_t one_tab = seg.wave_mask ? tab_bytes : 0;
 			while (FT > 2 && 16 * area_of(FT) + one_tab + 1024 > lds_limit_) FT /= 2;
 			const size_t area = area_of(FT);
@@ -2118,15 +2292,17 @@ public:
 			if (!finfo_.ensure(seg.n_voices, err) || !fdone_.ensure(seg.n_voices, err) ||
 			    !worklist_.ensure(seg.n_voices, err) || !work_count_.ensure(4, err) ||
 			    !fsteps_.ensure((size_t)seg.n_voices * fmax_steps * sizeof(FastStep), err) ||
-			    !flines_.ensure((size_t)seg.n_voices * fmax_steps * sizeof(FastLine), err)) return false;
+			    !flines_.ensure((size_t)seg.n_voices * fmax_steps * sizeof(FastLine), err) ||
+			    !faux_.ensure((size_t)seg.n_voices * fmax_steps * sizeof(FastAux), err)) return false;
 			HIP_OK(hipMemsetAsync(work_count_.p, 0, sizeof(uint32_t), stream_));
 			FastParams fp;
 			memset(&fp, 0, sizeof fp);
 			fp.voices = voices_.p; fp.steps = steps_.p; fp.fast_ids = fast_ids_.p; fp.op_ids = op_ids_.p; fp.ops = ops_.p;
 			fp.vout = vout_.p; fp.pan = pan_.p; fp.info = finfo_.p; fp.fast_done = fdone_.p;
 			fp.worklist = worklist_.p; fp.work_count = work_count_.p; fp.vinfo = vinfo_.p;
-			fp.g_c23 = c23_.p; fp.g_c01 = c01_.p; fp.fsteps = (FastStep *)fsteps_.p; fp.flines = (FastLine *)flines_.p;
-			fp.row_stride = row_stride_; fp.n_voices = seg.n_voices; fp.n_fast = seg.n_fast;
+			fp.g_c23 = c23_.p; fp.g_c01 = c01_.p; fp.fsteps = (FastStep *)fsteps_.p; fp.flines = (FastLine *)flines_.p; fp.faux = (FastAux *)faux_.p;
+			fp.row_stride = row_stride_; fp.n_voices = seg.n_voices; fp.n_fast = n_fast;
+			fp.seq_enable = seq_ok ? 1u : 0u; fp.ids_full_ofs = n_steps_total_;
 			fp.max_ops = seg.max_ops; fp.max_steps = fmax_steps; fp.np = 64; fp.rows = FT;
 			fp.enable = use_fast ? 1u : 0u;
 			memcpy(fp.wc, wconst_, sizeof wconst_);
@@ -2175,6 +2351,20 @@ public:
 			hipLaunchKernelGGL(finalize_kernel, dim3((seg.n_voices + 63) / 64), dim3(64), 0, stream_, fp);
 			if (tz) (void)hipEventRecord(tz->b, stream_);
 			HIP_OK(hipGetLastError());
+			if (debug_ && use_fast) {
+				(void)hipStreamSynchronize(stream_);
+				FastInfo fi0;
+				(void)hipMemcpy(&fi0, finfo_.p, sizeof fi0, hipMemcpyDeviceToHost);
+				fprintf(stderr, "[sau-amd] fast: voice 0 total %u H %u bail %u steps %u seq %u; n_fast %u rows %u\n",
+						fi0.total, fi0.H, fi0.bail, fi0.n_fsteps, fi0.seq, n_fast, FT);
+				std::vector<FastStep> fs(fi0.n_fsteps < 64 ? fi0.n_fsteps : 64);
+				if (!fs.empty()) (void)hipMemcpy(fs.data(), fsteps_.p, fs.size() * sizeof(FastStep), hipMemcpyDeviceToHost);
+				for (size_t i = 0; i < fs.size(); ++i)
+					fprintf(stderr, "[sau-amd]   step %zu kind %u flags %#x which %u dep %u out %d pm %d fpm %d amp %d aux %d type %#x inc %u ac %g fc %g ramp %u\n",
+							i, fs[i].kind & 0xff, (fs[i].kind >> 8) & 0xff, (fs[i].kind >> 16) & 0xff, fs[i].kind >> 24,
+							(int)fs[i].out_off, (int)fs[i].pm_off, (int)fs[i].fpm_off, (int)fs[i].amp_off, (int)fs[i].aux_off,
+							fs[i].type, fs[i].inc, fs[i].ac, fs[i].fc, fs[i].ramp);
+			}
 			rp.fast_done = fdone_.p; rp.worklist = worklist_.p; rp.work_count = work_count_.p;
 			/* Block-loop grid: persistent over the device-built work list. When the
 			 * host knows of nothing that needs it (no sweeps, FM, feedback or expiring
@@ -2348,7 +2538,8 @@ private:
 	WaveConst wconst_[12];
 	DevBuf<DevOp> ops_;
 	DevBuf<Step> steps_;
-	DevBuf<FastIds> fast_ids_;
+	DevBuf<FastIds> fast_ids_; /* [2][n_steps_total_]: without / with frequency blocks */
+	uint32_t n_steps_total_ = 0;
 	DevBuf<uint32_t> op_ids_;
 	DevBuf<VoiceDesc> voices_;
 	DevBuf<float> vout_, pan_;
@@ -2372,10 +2563,11 @@ private:
 	int timing_level_ = 2;
 	DevBuf<FastInfo> finfo_;
 	DevBuf<uint32_t> fdone_, worklist_, work_count_;
-	DevBuf<unsigned char> fsteps_, flines_;
+	DevBuf<unsigned char> fsteps_, flines_, faux_;
 	hipEvent_t fetch_ev_[2] = {nullptr, nullptr};
 	uint32_t multi_min_ = 256;
 	uint32_t fast_rows_ = 8;
+	bool seq_enabled_ = true;
 	uint32_t block_grid_ = 1;
 };
 

@@ -259,9 +259,15 @@ bool compile_voice_plan(const std::vector<OpMirror> &ops, uint32_t carrier,
 		}
 	}
 	out.fast_ids.assign(out.steps.size(), FastIds());
+	out.fast_ids_full.assign(out.steps.size(), FastIds());
 	out.n_fast = fast_slot_compact(out.steps.data(), (uint32_t)out.steps.size(),
-			out.steps.empty() ? nullptr : (uint8_t *)out.fast_ids.data());
-	if (out.n_fast == 0xffffffffu) { out.n_fast = 0; out.no_fast = true; }
+			out.steps.empty() ? nullptr : out.fast_ids.data(), false);
+	out.n_fast_full = fast_slot_compact(out.steps.data(), (uint32_t)out.steps.size(),
+			out.steps.empty() ? nullptr : out.fast_ids_full.data(), true);
+	if (out.n_fast == 0xffffffffu || out.n_fast_full == 0xffffffffu) {
+		out.n_fast = out.n_fast_full = 0;
+		out.no_fast = true;
+	}
 	return !c.failed;
 }
 

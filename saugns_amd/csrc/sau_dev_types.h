@@ -48,7 +48,8 @@ struct DevOp {
 	/* per-segment: this operator or one it is nested in has run out of time, so
 	 * it produces nothing and its state stands still (generator.c:686-700) */
 	uint32_t rt_frozen = 0;
-	uint32_t pad[2] = {};
+	uint32_t st_phase = 0;   /* accumulator at the segment's last frame (sequential scan) */
+	uint32_t pad[1] = {};
 };
 static_assert(sizeof(DevOp) == 256, "DevOp is 64 dwords");
 
@@ -133,61 +134,72 @@ struct Step {
 static_assert(sizeof(Step) == 16, "Step is 4 dwords");
 
 /* Block buffers as the time-parallel path sees them. It reads a step's inputs
- * into registers before it stores the step's output and never materialises
- * frequency blocks, so far fewer buffers are live at once than the block
- * loop's plan names: a depth-D modulator chain needs one. This walks a plan,
- * frees each buffer at its last read and hands out the lowest free number.
- * Returns the count of compact buffers (0xffffffff: more than 64); when
- * `ids` is given, ids[8*i + 0..4] receive step i's out, pm, fpm, amp and LERP
- * range-end buffers (NO_SLOT where unused). Runs on the host when a plan is
- * compiled; the ids travel to the device beside the steps (FastIds). */
-struct FastIds { uint8_t out, pm, fpm, amp, aux, pad[3]; };
+ * into registers before it stores the step's output, so far fewer buffers are
+ * live at once than the block loop's plan names: a depth-D modulator chain
+ * needs one. This walks a plan, frees each buffer at its last read and hands
+ * out the lowest free number. Two flavours: without frequency blocks (every
+ * oscillator frequency is one value for the segment: they are never
+ * materialised) and with them (frequency ramps, FM: the sequential-scan mode).
+ * Returns the count of compact buffers (0xffffffff: more than 64); when `ids`
+ * is given, ids[i] receives step i's buffers (NO_SLOT where unused). Runs on
+ * the host when a plan is compiled; the ids travel to the device beside the
+ * steps. */
+struct FastIds { uint8_t out, pm, fpm, amp, aux /* LERP range end */, freq, fmul, pad; };
 static_assert(sizeof(FastIds) == 8, "FastIds is 2 dwords");
-SAU_HD uint32_t fast_slot_compact(const Step *plan, uint32_t n, uint8_t *ids) {
-	uint8_t last[FSLOT_BASE];
-	uint8_t map[FSLOT_BASE];
-	for (uint32_t s = 0; s < FSLOT_BASE; ++s) { last[s] = 0xff; map[s] = NO_SLOT; }
+SAU_HD uint32_t fast_slot_compact(const Step *plan, uint32_t n, FastIds *ids, bool with_freq) {
+	const uint32_t limit = with_freq ? 250u : (uint32_t)FSLOT_BASE;
+	uint8_t last[256];
+	uint8_t map[256];
+	for (uint32_t s = 0; s < 256; ++s) { last[s] = 0xff; map[s] = NO_SLOT; }
 	for (uint32_t i = 0; i < n && i < 0xff; ++i) {
 		const Step st = plan[i];
-		uint8_t rd[4] = {NO_SLOT, NO_SLOT, NO_SLOT, NO_SLOT};
-		if (st.kind == ST_OSC) { rd[0] = st.pm; rd[1] = st.fpm; rd[2] = st.amp; if (st.flags & SF_LAYER) rd[3] = st.out; }
+		uint8_t rd[6] = {NO_SLOT, NO_SLOT, NO_SLOT, NO_SLOT, NO_SLOT, NO_SLOT};
+		if (st.kind == ST_OSC) { rd[0] = st.pm; rd[1] = st.fpm; rd[2] = st.amp; if (st.flags & SF_LAYER) rd[3] = st.out; rd[4] = st.freq; rd[5] = st.fmul; }
 		else if (st.kind == ST_LERP) { rd[0] = st.out; rd[1] = st.freq; rd[2] = st.pm; }
 		else if (st.kind == ST_VOICE) { rd[0] = st.out; rd[1] = st.pm; }
-		for (int k = 0; k < 4; ++k) if (rd[k] < FSLOT_BASE) last[rd[k]] = (uint8_t)i;
+		else if (st.kind == ST_LINE) { rd[0] = st.fmul; }
+		for (int k = 0; k < 6; ++k) if (rd[k] < limit) last[rd[k]] = (uint8_t)i;
 	}
 	unsigned long long used = 0;
 	uint32_t count = 0;
-	if (ids) for (uint32_t i = 0; i < 8 * n; ++i) ids[i] = NO_SLOT;
+	if (ids) {
+		FastIds none;
+		none.out = none.pm = none.fpm = none.amp = none.aux = none.freq = none.fmul = none.pad = NO_SLOT;
+		for (uint32_t i = 0; i < n; ++i) ids[i] = none;
+	}
 	for (uint32_t i = 0; i < n && i < 0xff; ++i) {
 		const Step st = plan[i];
-		if (st.kind == ST_LINE && st.which == L_FREQ) continue; /* never materialised here */
-		uint8_t rd[4] = {NO_SLOT, NO_SLOT, NO_SLOT, NO_SLOT};
+		if (!with_freq && st.kind == ST_LINE && st.which == L_FREQ) continue; /* never materialised */
+		uint8_t rd[6] = {NO_SLOT, NO_SLOT, NO_SLOT, NO_SLOT, NO_SLOT, NO_SLOT};
 		bool writes = false;
-		if (st.kind == ST_OSC) { rd[0] = st.pm; rd[1] = st.fpm; rd[2] = st.amp; if (st.flags & SF_LAYER) rd[3] = st.out; writes = !(st.which & OX_VOICE); }
+		if (st.kind == ST_OSC) { rd[0] = st.pm; rd[1] = st.fpm; rd[2] = st.amp; if (st.flags & SF_LAYER) rd[3] = st.out; rd[4] = st.freq; rd[5] = st.fmul; writes = !(st.which & OX_VOICE); }
 		else if (st.kind == ST_LERP) { rd[0] = st.out; rd[1] = st.freq; rd[2] = st.pm; writes = true; }
 		else if (st.kind == ST_VOICE) { rd[0] = st.out; rd[1] = st.pm; }
-		else if (st.kind == ST_LINE) writes = true;
-		uint8_t got[5] = {NO_SLOT, NO_SLOT, NO_SLOT, NO_SLOT, NO_SLOT};
+		else if (st.kind == ST_LINE) { rd[0] = st.fmul; writes = true; }
+		FastIds got;
+		got.out = got.pm = got.fpm = got.amp = got.aux = got.freq = got.fmul = got.pad = NO_SLOT;
 		if (st.kind == ST_OSC) {
-			got[1] = st.pm < FSLOT_BASE ? map[st.pm] : NO_SLOT;
-			got[2] = st.fpm < FSLOT_BASE ? map[st.fpm] : NO_SLOT;
-			got[3] = st.amp < FSLOT_BASE ? map[st.amp] : NO_SLOT;
+			if (st.pm < limit) got.pm = map[st.pm];
+			if (st.fpm < limit) got.fpm = map[st.fpm];
+			if (st.amp < limit) got.amp = map[st.amp];
+			if (st.freq < limit) got.freq = map[st.freq];
+			if (st.fmul < limit) got.fmul = map[st.fmul];
 		} else if (st.kind == ST_LERP) {
-			got[4] = st.freq < FSLOT_BASE ? map[st.freq] : NO_SLOT;
-			got[1] = st.pm < FSLOT_BASE ? map[st.pm] : NO_SLOT;
+			if (st.freq < limit) got.aux = map[st.freq];
+			if (st.pm < limit) got.pm = map[st.pm];
 		} else if (st.kind == ST_VOICE) {
-			got[1] = st.pm < FSLOT_BASE ? map[st.pm] : NO_SLOT;
+			if (st.pm < limit) got.pm = map[st.pm];
+		} else if (st.kind == ST_LINE) {
+			if (st.fmul < limit) got.fmul = map[st.fmul];
 		}
 		/* inputs read for the last time here give their buffer back before the
 		 * output is placed (the output may then land on one of them) */
-		for (int k = 0; k < 4; ++k) {
+		for (int k = 0; k < 6; ++k) {
 			const uint8_t s = rd[k];
-			if (s < FSLOT_BASE && last[s] == i && map[s] != NO_SLOT && !(writes && s == st.out)) {
-				used &= ~(1ull << map[s]);
-				/* map[s] stays: a later write to s would be a new value with no reader */
-			}
+			if (s < limit && last[s] == i && map[s] != NO_SLOT && !(writes && s == st.out))
+				used &= ~(1ull << map[s]); /* map[s] stays: a later write to s is a new value */
 		}
-		if ((writes || st.kind == ST_VOICE) && st.out < FSLOT_BASE) {
+		if ((writes || st.kind == ST_VOICE) && st.out < limit) {
 			if (writes && (map[st.out] == NO_SLOT || !((used >> map[st.out]) & 1ull))) {
 				uint32_t c = 0;
 				while (c < 64 && ((used >> c) & 1ull)) ++c;
@@ -197,9 +209,9 @@ SAU_HD uint32_t fast_slot_compact(const Step *plan, uint32_t n, uint8_t *ids) {
 				if (c + 1 > count) count = c + 1;
 				if (last[st.out] == 0xff || last[st.out] < i) used &= ~(1ull << c); /* nobody reads it */
 			}
-			got[0] = map[st.out];
+			got.out = map[st.out];
 		}
-		if (ids) { for (int k = 0; k < 5; ++k) ids[8 * i + k] = got[k]; }
+		if (ids) ids[i] = got;
 	}
 	return count;
 }
