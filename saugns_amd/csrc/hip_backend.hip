@@ -120,6 +120,20 @@ __device__ __forceinline__ Step uni(const Step &st) {
 	return c.s;
 }
 
+/* inclusive sum over the 64 lanes with DPP moves (no LDS): four shifts inside
+ * each row of 16, then the rows' totals passed on with row_bcast 15 and 31 */
+__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
+#define SAU_DPP_ADD(ctrl, rmask) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xf, false)
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112 /* row_shr:2 */, 0xf, 0xf, true);
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114 /* row_shr:4 */, 0xf, 0xf, true);
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118 /* row_shr:8 */, 0xf, 0xf, true);
+	SAU_DPP_ADD(0x142 /* row_bcast:15 */, 0xa);
+	SAU_DPP_ADD(0x143 /* row_bcast:31 */, 0xc);
+#undef SAU_DPP_ADD
+	return v;
+}
+
 /* rint(p * 2^31) wrapped to 32 bits for |p| < 2^20: in f64, p + 1.5 * 2^21
  * has an ulp of 2^-31, so the addition rounds p to a multiple of 2^-31
  * (nearest-even, as llrintf does in the default mode) and leaves that
@@ -1031,6 +1045,15 @@ struct FastParams {
 	WaveConst wc[12];
 };
 
+/* the operator whose frequency line most recently filled block `slot` before step si (0xff: none) */
+__device__ __forceinline__ uint32_t block_owner(const Step *plan, uint32_t si, uint32_t slot) {
+	for (uint32_t q = si; q-- > 0;) {
+		const Step sq = plan[q];
+		if (sq.kind == ST_LINE && sq.which == L_FREQ && sq.out == slot) return sq.op;
+	}
+	return 0xff;
+}
+
 __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 	const uint32_t v = blockIdx.x * 64 + threadIdx.x;
 	if (v >= P.n_voices) return;
@@ -1075,6 +1098,7 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 		if (o.type == OT_NOISE && o.wave == NZ_re) bad = true;
 		if (o.line[L_PMA].v0 != 0.f) bad = true; /* self-modulation is a recurrence */
 		o.rt_fconst_valid = 0;
+		o.rt_fblk_valid = 0;
 		if (!(o.flags & OPF_TIME_INF) && o.time < min_time) min_time = o.time;
 	}
 	uint32_t depth = 0, maxd = 0;
@@ -1094,9 +1118,23 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 		if (st.kind == ST_OSC && st.sm != NO_SLOT) bad = true;
 		/* a ratio line (sau/line.c:72) multiplies by the parent's frequency: one value, or a block */
 		bool pconst = false; float pf = 0.f;
-		if (st.fmul != NO_SLOT && st.prov != NO_SLOT) {
-			const DevOp &po = P.ops[ids[st.prov]];
-			pconst = po.rt_fconst_valid != 0; pf = po.rt_fconst;
+		if (st.fmul != NO_SLOT && st.fmul >= FSLOT_BASE) {
+			/* the parent's frequency block as it stands when this step reads it: one value if
+			 * the parent's line is held and nothing has been added into the block yet (the
+			 * first FM modulator of a plain carrier sees exactly that, generator.c:448-477) */
+			const uint32_t ow = block_owner(plan, si, st.fmul);
+			if (ow != 0xff) {
+				const DevOp &po = P.ops[ids[ow]];
+				pconst = po.rt_fblk_valid != 0; pf = po.rt_fconst;
+			} else if (st.prov != NO_SLOT) {
+				const DevOp &po = P.ops[ids[st.prov]];
+				pconst = po.rt_fconst_valid != 0; pf = po.rt_fconst;
+			}
+		}
+		/* anything added into a frequency block makes it per-frame */
+		if ((st.kind == ST_OSC || st.kind == ST_LERP) && st.out != NO_SLOT && st.out >= FSLOT_BASE) {
+			const uint32_t ow = block_owner(plan, si, st.out);
+			if (ow != 0xff) P.ops[ids[ow]].rt_fblk_valid = 0;
 		}
 		if (st.kind == ST_LINE || freq_here) {
 			const LineState &ls = o.line[st.kind == ST_LINE ? st.which : L_FREQ];
@@ -1119,6 +1157,9 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 			}
 			o.rt_fconst = fc;
 			o.rt_fconst_valid = isconst ? 1u : 0u;
+			/* the block itself (before modulators are added) holds one value? */
+			o.rt_fblk_valid = (isconst || (st.kind == ST_LINE && (st.flags & SF_FORCE) && !(fl.flags & LP_GOAL) &&
+					!((fl.flags & LP_STATE_RATIO) && st.fmul != NO_SLOT && !pconst))) ? 1u : 0u;
 			if (!isconst) {
 				seq = true;
 				if (o.type == OT_RASEG) bad = true; /* 64-bit counter sums: block loop for now */
@@ -1566,8 +1607,12 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 												v *= fa.fmul_off != ~0u ? slots[fa.fmul_off + k * 64] : fa.mulc;
 										}
 										fv[k] = v;
-										const uint32_t inc = (t >= 0 && t < (int)fast_total) ? rint32w(fa.coeff * v) : 0u;
-										S[k] = wave_incl_scan(inc, l);
+										const float x = fa.coeff * v;
+										/* llrintf(x) mod 2^32 (wosc.h:145): adding 1.5 * 2^52 in f64 rounds to the nearest
+										 * integer and leaves it in the low word; exact while |x| < 2^51 */
+										const uint32_t r = fabsf(x) < 0x1p50f ? (uint32_t)__double2loint((double)x + 0x1.8p52) : rint32w(x);
+										const uint32_t inc = (t >= 0 && t < (int)fast_total) ? r : 0u;
+										S[k] = wave_incl_scan_dpp(inc);
 									}
 									uint32_t acc = first_group ? f.phase0 : carry[si];
 #pragma unroll

@@ -49,7 +49,7 @@ struct DevOp {
 	 * it produces nothing and its state stands still (generator.c:686-700) */
 	uint32_t rt_frozen = 0;
 	uint32_t st_phase = 0;   /* accumulator at the segment's last frame (sequential scan) */
-	uint32_t pad[1] = {};
+	uint32_t rt_fblk_valid = 0; /* per-segment: its frequency block holds one value (rt_fconst) so far */
 };
 static_assert(sizeof(DevOp) == 256, "DevOp is 64 dwords");
 
