@@ -156,7 +156,7 @@ def main():
                        "operator_samples_per_s": value * n_ops},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
-                         "kernel": "fast_kernel<8>", "avg_launch_ms": launch_s * 1e3,
+                         "kernel": "fast_kernel<8, false>", "avg_launch_ms": launch_s * 1e3,
                          "launches": tm["segments"],
                          "algorithmic_bytes_per_launch": alg_bytes},
         }

@@ -1011,12 +1011,15 @@ struct FastInfo {
 	uint32_t H;     /* lead-in samples per chunk */
 	uint32_t bail;  /* set when a chunk met dphase == 0 (hold-previous run) */
 	uint32_t n_fsteps; /* decoded steps of the voice (decode_kernel) */
-	uint32_t seq;   /* some oscillator's frequency varies (ramp, FM): one wave walks the voice in order, carrying phase sums */
+	uint32_t seq;   /* some oscillator's frequency varies (ramp, FM): phases are running sums. 1: one wave walks the
+	                 * voice in order, carrying them; 2: two passes, every wave (no sum depends on another) */
+	uint32_t n_scan; /* oscillators with running-sum phases (two-pass voices) */
 };
 
 struct FastStep;
 struct FastLine;
 struct FastAux;
+constexpr uint32_t FAST_MAX_SCAN = 8; /* oscillators with running-sum phases per two-pass voice */
 struct FastParams {
 	const VoiceDesc *voices;
 	const Step *steps;
@@ -1040,6 +1043,9 @@ struct FastParams {
 	uint32_t enable;      /* 0: leave every voice to the block loop */
 	uint32_t seq_enable;  /* block buffers are sized for frequency blocks: sequential-scan voices allowed */
 	uint32_t ids_full_ofs;/* offset of the with-frequency numbering in fast_ids */
+	uint32_t mode;        /* fast_kernel: 0 one pass; 1 sums of phase increments per row group only; 2 final pass */
+	uint32_t *scan;       /* [n_voices][FAST_MAX_SCAN][scan_groups]: those sums, then (scan_kernel) their prefixes */
+	uint32_t scan_groups;
 	int8_t tab_of_wave[12];
 	uint8_t wave_of_tab[12];
 	WaveConst wc[12];
@@ -1171,8 +1177,51 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 		}
 		if (st.flags & SF_END) --depth;
 	}
+	/* Two passes suffice when no running sum depends on another one: the per-frame
+	 * increments of every such oscillator (its frequency inputs) must not depend on
+	 * the output of an oscillator whose phase is itself a running sum. Forward
+	 * data-flow over the block buffers ("tainted" = depends on such an output). */
+	uint32_t seq_kind = seq ? 1u : 0u, n_scan_out = 0;
+	if (seq && !bad) {
+		unsigned long long taint[4] = {0, 0, 0, 0};
+		auto tainted = [&](uint32_t sl) -> bool {
+			if (sl == NO_SLOT) return false;
+			const unsigned long long w = (sl >> 6) == 0 ? taint[0] : (sl >> 6) == 1 ? taint[1] : (sl >> 6) == 2 ? taint[2] : taint[3];
+			return (w >> (sl & 63)) & 1ull;
+		};
+		auto set_taint = [&](uint32_t sl, bool on, bool keep_old) {
+			if (sl == NO_SLOT) return;
+			const unsigned long long bit = 1ull << (sl & 63);
+#pragma unroll
+			for (int q = 0; q < 4; ++q)
+				if ((int)(sl >> 6) == q) taint[q] = (taint[q] & (keep_old ? ~0ull : ~bit)) | (on ? bit : 0ull);
+		};
+		bool two = true;
+		uint32_t n_scan = 0;
+		for (uint32_t si = 0; si < vd.plan_len; ++si) {
+			const Step st = plan[si];
+			const DevOp &o = P.ops[ids[st.op]];
+			if (o.rt_frozen) continue;
+			if (st.kind == ST_LINE) {
+				set_taint(st.out, tainted(st.fmul), false);
+			} else if (st.kind == ST_LERP) {
+				set_taint(st.out, tainted(st.freq) || tainted(st.pm), true);
+			} else if (st.kind == ST_OSC) {
+				const bool fvar = (o.type == OT_WAVE || o.type == OT_RASEG) && !o.rt_fconst_valid;
+				if (fvar) {
+					if (tainted(st.freq) || tainted(st.fmul)) two = false;
+					++n_scan;
+				}
+				const bool t = fvar || tainted(st.pm) || tainted(st.fpm) || tainted(st.amp) ||
+					tainted(st.freq) || tainted(st.fmul);
+				if (!(st.which & OX_VOICE)) set_taint(st.out, t, (st.flags & SF_LAYER) != 0);
+			}
+		}
+		if (two && n_scan <= FAST_MAX_SCAN && P.scan) seq_kind = 2;
+		n_scan_out = n_scan;
+	}
 	FastInfo fi;
-	fi.H = maxd; fi.bail = 0; fi.n_fsteps = 0; fi.seq = seq ? 1u : 0u;
+	fi.H = maxd; fi.bail = 0; fi.n_fsteps = 0; fi.seq = seq_kind; fi.n_scan = n_scan_out;
 	fi.total = 0;
 	if (seq && !P.seq_enable) bad = true;
 	if (!bad && vd.nops <= P.max_ops && vd.plan_len <= P.max_steps && maxd >= 1 && maxd <= P.np / 2)
@@ -1194,7 +1243,8 @@ struct FastStep {
 	uint32_t gop;       /* global operator index (state staging) */
 	double prev_Is;
 	float pan;
-	uint32_t ramp;      /* bit 0: the step's line is a ramp in progress (FastLine); bit 1: FastAux present */
+	uint32_t ramp;      /* bit 0: the step's line is a ramp in progress (FastLine); bit 1: FastAux present;
+	                     * bit 2: pass 1 of a two-pass voice runs this step */
 };
 static_assert(sizeof(FastStep) == 80, "FastStep is 20 dwords");
 
@@ -1221,7 +1271,7 @@ struct FastAux {
 	float coeff;                 /* 2^32 / srate (wosc.h:30) */
 	uint32_t flags;              /* FA_* */
 	float mulc;                  /* the multiplier when the parent's frequency is one value */
-	uint32_t pad[3];
+	uint32_t pad[3];             /* [0]: index among the voice's running-sum oscillators (two-pass) */
 	FastLine fl;                 /* ST_OSC with FA_FVAR_LINE: the frequency line's block */
 };
 static_assert(sizeof(FastAux) == 80, "FastAux is 20 dwords");
@@ -1264,6 +1314,29 @@ __device__ __forceinline__ FastAux load_aux_uniform(const FastAux *p) {
 __device__ __forceinline__ float fast_line_value(const FastLine &fl, int t) {
 	const uint32_t i = (uint32_t)t;
 	return i < fl.goal_len ? sweep_value_inl(fl.sw, i) : fl.hold;
+}
+
+/* Between the two passes: the sums of phase increments per row group become
+ * exclusive prefixes (what the accumulator has gained before each group). */
+__global__ void __launch_bounds__(64) scan_kernel(FastParams P) {
+	const uint32_t v = blockIdx.x;
+	const int l = threadIdx.x;
+	const FastInfo fi = P.info[v];
+	if (fi.seq != 2 || fi.total == 0) return;
+	const uint32_t C = 64u - fi.H;
+	const uint32_t nrows = (fi.total + C - 1) / C;
+	const uint32_t ngroups = (nrows + P.rows - 1) / P.rows;
+	for (uint32_t x = 0; x < fi.n_scan && x < FAST_MAX_SCAN; ++x) {
+		uint32_t *a = P.scan + ((size_t)v * FAST_MAX_SCAN + x) * P.scan_groups;
+		uint32_t carry = 0;
+		for (uint32_t base = 0; base < ngroups; base += 64) {
+			const bool in = base + (uint32_t)l < ngroups;
+			const uint32_t val = in ? a[base + l] : 0u;
+			const uint32_t incl = wave_incl_scan_dpp(val);
+			if (in) a[base + l] = carry + (incl - val);
+			carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+		}
+	}
 }
 
 /* One step of a voice's plan in immediate form (LDS offsets, constants), so
@@ -1389,6 +1462,42 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 				}
 			}
 			const bool is_osc = o.type == OT_WAVE || o.type == OT_RASEG;
+			if (seq == 2) {
+				/* Pass 1 of a two-pass voice only runs what the phase increments need.
+				 * Backward data-flow over the compact block buffers: a step is needed if it
+				 * writes a buffer some later needed step (or a running-sum oscillator's
+				 * frequency input) reads. */
+				unsigned long long want = 0;
+				bool mine = false;
+				uint32_t xi = 0;
+				for (uint32_t q = vd.plan_len; q-- > 0;) {
+					const Step sq = plan[q];
+					const DevOp &oq = P.ops[ids[sq.op]];
+					if (oq.rt_frozen) continue;
+					if (sq.kind == ST_LINE && sq.which == L_FREQ && oq.rt_fconst_valid) continue; /* dropped */
+					const FastIds cq = P.fast_ids[P.ids_full_ofs + vd.plan_ofs + q];
+					auto bit = [](uint8_t id) -> unsigned long long { return id != NO_SLOT ? 1ull << id : 0ull; };
+					const bool q_fvar = sq.kind == ST_OSC && (oq.type == OT_WAVE || oq.type == OT_RASEG) && !oq.rt_fconst_valid;
+					bool needed = false;
+					if (q_fvar) {
+						needed = true; /* as a sums-only step */
+						want |= bit(cq.freq) | bit(cq.fmul);
+						if (q < (uint32_t)l) ++xi;
+					} else {
+						const bool writes = sq.kind == ST_LINE || sq.kind == ST_LERP ||
+							(sq.kind == ST_OSC && !(sq.which & OX_VOICE));
+						if (writes && (want & bit(cq.out))) {
+							needed = true;
+							const bool rmw = sq.kind == ST_LERP || (sq.kind == ST_OSC && (sq.flags & SF_LAYER));
+							if (!rmw) want &= ~bit(cq.out);
+							want |= bit(cq.pm) | bit(cq.fpm) | bit(cq.amp) | bit(cq.aux) | bit(cq.freq) | bit(cq.fmul);
+						}
+					}
+					if (q == (uint32_t)l) mine = needed;
+				}
+				if (mine) f.ramp |= 4;
+				fa.pad[0] = xi;
+			}
 			if (st.kind == ST_OSC && is_osc && !o.rt_fconst_valid) {
 				/* frequency per frame: from its block, or from its own line when it has no block */
 				if (st.freq != NO_SLOT) {
@@ -1441,7 +1550,9 @@ __device__ __forceinline__ FastStep load_step_uniform(const FastStep *p) {
 
 /* (A 24-byte interleaved LDS entry read with ds_read2_b64 + ds_read_b64 was
  * measured 60 % worse in bank conflicts than this split 16 + 8 byte layout.) */
-template <int T>
+/* SCAN: built with the running-sum code (frequency ramps, FM); the plain build
+ * stays as lean as the closed-form voices need it (27 % faster on them). */
+template <int T, bool SCAN>
 __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 	constexpr int NP = 64 * T;
 	constexpr int W = 16;
@@ -1489,9 +1600,13 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 		const FastLine *flines = P.flines + (size_t)v * P.max_steps;
 		const FastAux *faux = P.faux + (size_t)v * P.max_steps;
 		/* sequential-scan voices: the one wave with cstart == 0 walks every row group in order */
-		const bool seq = uni(fi.seq) != 0;
+		const uint32_t seq_kind = SCAN ? uni(fi.seq) : 0u;
+		const bool seq = SCAN && seq_kind == 1;    /* one wave, in order */
+		const bool two = SCAN && seq_kind == 2;    /* two passes, every wave */
+		if (SCAN && P.mode == 1 && !two) continue; /* pass 1 only concerns two-pass voices */
 		if (seq && cstart != 0) continue;
 		const uint32_t gstride = seq ? 1u : wpv;
+		uint32_t *scan = two ? P.scan + (size_t)v * FAST_MAX_SCAN * P.scan_groups : nullptr;
 		float *vrow = P.vout + (size_t)vd.out_row * P.row_stride;
 		float *prow = (vd.pan_dynamic_row != ~0u) ? P.pan + (size_t)vd.pan_dynamic_row * P.row_stride : nullptr;
 		/* A wave renders T rows at a time; a row is 64 consecutive frames, one per
@@ -1518,6 +1633,7 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 #endif
 				const uint32_t kind = f.kind & 0xff;
 				const uint32_t flags = (f.kind >> 8) & 0xff;
+				if (SCAN && P.mode == 1 && !(f.ramp & 4)) continue; /* pass 1: not needed for any phase increment */
 				if (kind == ST_OSC) {
 					const uint32_t type = f.type & 0xff;
 					const bool wave_env = (flags & SF_WAVE_ENV) != 0;
@@ -1586,7 +1702,7 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 							double Is[T];
 							float fv[T]; /* frequency per frame (freq-scaled PM reads it) */
 							bool fvar = false;
-							if (f.ramp & 2) {
+							if (SCAN && (f.ramp & 2)) {
 								/* the frequency varies (ramp, FM): phase is a running sum of per-frame
 								 * increments (wosc.h:135-169). This wave walks the voice's rows in order;
 								 * `carry` holds the accumulator at the frame before each row's new frames. */
@@ -1614,7 +1730,11 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 										const uint32_t inc = (t >= 0 && t < (int)fast_total) ? r : 0u;
 										S[k] = wave_incl_scan_dpp(inc);
 									}
-									uint32_t acc = first_group ? f.phase0 : carry[si];
+									/* the accumulator at the frame before this group's first new frame: carried by
+									 * this wave (in-order voices), or the prefix of all earlier groups' sums */
+									uint32_t *sums = two ? scan + (size_t)fa.pad[0] * P.scan_groups : nullptr;
+									uint32_t acc = two ? (P.mode == 1 ? 0u : f.phase0 + sums[cg])
+									                   : (first_group ? f.phase0 : carry[si]);
 #pragma unroll
 									for (int k = 0; k < T; ++k) {
 										const uint32_t lead = (uint32_t)__builtin_amdgcn_readlane((int)S[k], (int)H - 1);
@@ -1622,7 +1742,14 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 										ph[k] = acc + (S[k] - lead);
 										acc += last - lead;
 									}
-									if (l == 0) carry[si] = acc;
+									if (two) {
+										if (P.mode == 1) { /* pass 1 ends here for this oscillator */
+											if (l == 0) sums[cg] = acc;
+											continue;
+										}
+									} else if (l == 0) {
+										carry[si] = acc;
+									}
 								}
 							}
 							if (!fvar) {
@@ -1632,9 +1759,11 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 #pragma unroll
 								for (int k = 0; k < T; ++k) { ph[k] = acc; acc += row_inc; fv[k] = f.fc; }
 							}
-							uint32_t phu[T]; /* accumulator values, before modulation */
+							uint32_t phu[SCAN ? T : 1]; /* accumulator values, before modulation */
+							if (SCAN) {
 #pragma unroll
-							for (int k = 0; k < T; ++k) phu[k] = ph[k];
+								for (int k = 0; k < T; ++k) phu[SCAN ? k : 0] = ph[k];
+							}
 							if (has_pm && !has_fpm) {
 								float pm[T];
 								bool big = false;
@@ -1750,7 +1879,7 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 									const int t = t0 + k * (int)C;
 									if (t == (int)fast_total - 1 && l >= (int)H) {
 										DevOp &o = P.ops[f.gop];
-										o.st_phase = phu[k];
+										if (SCAN) o.st_phase = phu[SCAN ? k : 0];
 										o.st_prev_phase = ph[k];
 										o.st_prev_Is = Is[k];
 										o.st_prev_s = s[k];
@@ -1846,7 +1975,7 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 						if (f.ramp & 1) fl = load_line_uniform(flines + si);
 						uint32_t mflags = 0, fmul_off = ~0u;
 						float mulc = 1.f;
-						if (f.ramp & 2) { /* ratio line: x the parent's frequency (sau/line.c:72) */
+						if (SCAN && (f.ramp & 2)) { /* ratio line: x the parent's frequency (sau/line.c:72) */
 							const FastAux fa = load_aux_uniform(faux + si);
 							mflags = fa.flags; fmul_off = fa.fmul_off; mulc = fa.mulc;
 						}
@@ -2148,7 +2277,8 @@ public:
 		geo_ = (wt && !strcmp(wt, "8x2")) ? 0 : 1; /* default 4 waves x 4 samples per lane */
 		debug_ = getenv("SAU_AMD_DEBUG") != nullptr;
 		fast_enabled_ = getenv("SAU_AMD_NO_FAST") == nullptr;
-		seq_enabled_ = getenv("SAU_AMD_NO_SEQ") == nullptr; /* sequential-scan voices in the time-parallel kernel */
+		seq_enabled_ = getenv("SAU_AMD_NO_SEQ") == nullptr; /* running-sum phases in the time-parallel kernel */
+		two_pass_enabled_ = getenv("SAU_AMD_NO_TWO_PASS") == nullptr; /* ... in two passes where possible */
 		/* voices per segment from which feedback voices get sixteen one-wave teams per workgroup
 		 * (0: never; 1: always, also without feedback -- tests) */
 		multi_min_ = 256;
@@ -2348,6 +2478,13 @@ public:
 			fp.g_c23 = c23_.p; fp.g_c01 = c01_.p; fp.fsteps = (FastStep *)fsteps_.p; fp.flines = (FastLine *)flines_.p; fp.faux = (FastAux *)faux_.p;
 			fp.row_stride = row_stride_; fp.n_voices = seg.n_voices; fp.n_fast = n_fast;
 			fp.seq_enable = seq_ok ? 1u : 0u; fp.ids_full_ofs = n_steps_total_;
+			fp.scan = nullptr; fp.scan_groups = 0; fp.mode = 0;
+			if (seq_ok && two_pass_enabled_) {
+				/* row groups per voice at most: rows hold at least 32 new frames (H <= 32) */
+				fp.scan_groups = seg.len / (32 * FT) + 2;
+				if (!scan_.ensure((size_t)seg.n_voices * FAST_MAX_SCAN * fp.scan_groups, err)) return false;
+				fp.scan = scan_.p;
+			}
 			fp.max_ops = seg.max_ops; fp.max_steps = fmax_steps; fp.np = 64; fp.rows = FT;
 			fp.enable = use_fast ? 1u : 0u;
 			memcpy(fp.wc, wconst_, sizeof wconst_);
@@ -2369,10 +2506,14 @@ public:
 			if (use_fast) {
 				hipLaunchKernelGGL(decode_kernel, dim3(seg.n_voices), dim3(64), 0, stream_, fp);
 				const size_t flds = ft * tab_bytes + 16 * area;
-				const void *fk = FT == 8 ? (const void *)fast_kernel<8> : FT == 4 ? (const void *)fast_kernel<4>
-				                                                                  : (const void *)fast_kernel<2>;
-				static size_t fconfigured[3] = {0, 0, 0};
-				size_t &conf = fconfigured[FT == 8 ? 2 : FT == 4 ? 1 : 0];
+				const bool scan_build = seq_ok; /* some voice may need running-sum phases */
+				const void *fk = scan_build
+					? (FT == 8 ? (const void *)fast_kernel<8, true> : FT == 4 ? (const void *)fast_kernel<4, true>
+					                                                          : (const void *)fast_kernel<2, true>)
+					: (FT == 8 ? (const void *)fast_kernel<8, false> : FT == 4 ? (const void *)fast_kernel<4, false>
+					                                                           : (const void *)fast_kernel<2, false>);
+				static size_t fconfigured[6] = {0, 0, 0, 0, 0, 0};
+				size_t &conf = fconfigured[(FT == 8 ? 2 : FT == 4 ? 1 : 0) + (scan_build ? 3 : 0)];
 				if (flds > conf) {
 					HIP_OK(hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
 					conf = flds;
@@ -2386,9 +2527,26 @@ public:
 				if (fgrid < 1) fgrid = 1;
 				TimedPair *tf = timing_on_ ? new_pair(2) : nullptr;
 				if (tf) (void)hipEventRecord(tf->a, stream_);
-				if (FT == 8) hipLaunchKernelGGL((fast_kernel<8>), dim3(fgrid), dim3(1024), flds, stream_, fp);
-				else if (FT == 4) hipLaunchKernelGGL((fast_kernel<4>), dim3(fgrid), dim3(1024), flds, stream_, fp);
-				else hipLaunchKernelGGL((fast_kernel<2>), dim3(fgrid), dim3(1024), flds, stream_, fp);
+				auto launch_fast = [&](uint32_t mode) {
+					fp.mode = mode;
+					if (scan_build) {
+						if (FT == 8) hipLaunchKernelGGL((fast_kernel<8, true>), dim3(fgrid), dim3(1024), flds, stream_, fp);
+						else if (FT == 4) hipLaunchKernelGGL((fast_kernel<4, true>), dim3(fgrid), dim3(1024), flds, stream_, fp);
+						else hipLaunchKernelGGL((fast_kernel<2, true>), dim3(fgrid), dim3(1024), flds, stream_, fp);
+					} else {
+						if (FT == 8) hipLaunchKernelGGL((fast_kernel<8, false>), dim3(fgrid), dim3(1024), flds, stream_, fp);
+						else if (FT == 4) hipLaunchKernelGGL((fast_kernel<4, false>), dim3(fgrid), dim3(1024), flds, stream_, fp);
+						else hipLaunchKernelGGL((fast_kernel<2, false>), dim3(fgrid), dim3(1024), flds, stream_, fp);
+					}
+				};
+				if (fp.scan) {
+					/* some voice may have running-sum phases: sums per row group, their prefixes, final pass */
+					launch_fast(1);
+					hipLaunchKernelGGL(scan_kernel, dim3(seg.n_voices), dim3(64), 0, stream_, fp);
+					launch_fast(2);
+				} else {
+					launch_fast(0);
+				}
 				if (tf) (void)hipEventRecord(tf->b, stream_);
 			}
 			TimedPair *tz = timing_on_ ? new_pair(3) : nullptr;
@@ -2609,10 +2767,11 @@ private:
 	DevBuf<FastInfo> finfo_;
 	DevBuf<uint32_t> fdone_, worklist_, work_count_;
 	DevBuf<unsigned char> fsteps_, flines_, faux_;
+	DevBuf<uint32_t> scan_;
 	hipEvent_t fetch_ev_[2] = {nullptr, nullptr};
 	uint32_t multi_min_ = 256;
 	uint32_t fast_rows_ = 8;
-	bool seq_enabled_ = true;
+	bool seq_enabled_ = true, two_pass_enabled_ = true;
 	uint32_t block_grid_ = 1;
 };
 
