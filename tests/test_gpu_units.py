@@ -166,3 +166,27 @@ def test_differentiator_division_exhaustive(sa):
         first = C.c_uint32()
         assert fn(wave, 0, C.byref(first)) == 0, (wave, hex(first.value))
         assert fn(wave, 1, C.byref(first)) > 0
+
+
+@pytest.mark.parametrize("chunk", [1500, 20000])
+def test_running_sum_phases_across_runs(sa, oracle, chunk):
+    """Ramped and modulated frequencies (phase = running sum of per-frame increments,
+    wosc.h:135-169) through the time-parallel kernel: two-pass voices (FM by constant-frequency
+    modulators, glide with ratio children, range-FM) and in-order voices (nested FM), with the
+    state handed from one engine run to the next."""
+    fm = vb.Op("sin", freq=vb.Line(2.0, ratio=True), amp=40.0,
+               mods={POP_PMOD: [vb.Op("tri", freq=vb.Line(3.0, ratio=True), amp=0.5)]})
+    check_runs(sa, oracle, [vb.Op("sin", freq=220.0, time_ms=300, mods={POP_FMOD: [fm]})], chunk)
+    child = vb.Op("sin", freq=vb.Line(2.0, ratio=True), amp=0.7)
+    check_runs(sa, oracle, [vb.Op("sin", freq=vb.Line(110.0, goal=440.0, shape="exp"), time_ms=300,
+                                  mods={POP_PMOD: [child]})], chunk)
+    r1 = vb.Op("sin", freq=vb.Line(0.5, ratio=True), amp=1.0)
+    f1 = vb.Op("sin", freq=5.0, amp=30.0)
+    check_runs(sa, oracle, [vb.Op("saw", freq=200.0, freq2=400.0, time_ms=300,
+                                  mods={POP_RFMOD: [r1], POP_FMOD: [f1]})], chunk)
+    inner = vb.Op("sin", freq=7.0, amp=15.0)
+    outer = vb.Op("sin", freq=55.0, amp=60.0, mods={POP_FMOD: [inner]})
+    check_runs(sa, oracle, [vb.Op("sin", freq=330.0, time_ms=300, mods={POP_FMOD: [outer]}),
+                            vb.Op("sin", freq=vb.Line(300.0, goal=100.0, shape="lin"), time_ms=200,
+                                  mods={POP_FPMOD: [vb.Op("sin", freq=vb.Line(2.0, ratio=True), amp=1.5)]})],
+               chunk, stereo=True)
