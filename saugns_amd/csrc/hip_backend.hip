@@ -1550,8 +1550,443 @@ __device__ __forceinline__ FastStep load_step_uniform(const FastStep *p) {
 
 /* (A 24-byte interleaved LDS entry read with ds_read2_b64 + ds_read_b64 was
  * measured 60 % worse in bank conflicts than this split 16 + 8 byte layout.) */
-/* SCAN: built with the running-sum code (frequency ramps, FM); the plain build
- * stays as lean as the closed-form voices need it (27 % faster on them). */
+/* One voice's share of this wave's work. SCAN: built with the running-sum code
+ * (frequency ramps, FM); the plain build stays as lean as closed-form voices
+ * need it (the same code with the running-sum branches compiled in was 27 %
+ * slower on them), and a kernel that may meet both kinds holds both copies. */
+template <int T, bool SCAN>
+__device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v, const FastInfo &fi,
+		float *slots, uint32_t *carry, const HerpC23 *t23, const HerpC01 *t01, const int l,
+		const uint32_t wpv, const uint32_t cstart) {
+	constexpr int NP = 64 * T;
+	(void)NP;
+	const uint32_t fast_total = uni(fi.total);
+	if (fast_total == 0) return;
+	const VoiceDesc vd = P.voices[v];
+	const uint32_t *ids = P.op_ids + vd.ops_ofs;
+	const uint32_t H = uni(fi.H);
+
+	const uint32_t n_fsteps = uni(fi.n_fsteps);
+	const FastStep *fsteps = P.fsteps + (size_t)v * P.max_steps;
+	const FastLine *flines = P.flines + (size_t)v * P.max_steps;
+	const FastAux *faux = P.faux + (size_t)v * P.max_steps;
+	/* sequential-scan voices: the one wave with cstart == 0 walks every row group in order */
+	const uint32_t seq_kind = SCAN ? uni(fi.seq) : 0u;
+	const bool seq = SCAN && seq_kind == 1;    /* one wave, in order */
+	const bool two = SCAN && seq_kind == 2;    /* two passes, every wave */
+	if (SCAN && P.mode == 1 && !two) return; /* pass 1 only concerns two-pass voices */
+	if (seq && cstart != 0) return;
+	const uint32_t gstride = seq ? 1u : wpv;
+	uint32_t *scan = two ? P.scan + (size_t)v * FAST_MAX_SCAN * P.scan_groups : nullptr;
+	float *vrow = P.vout + (size_t)vd.out_row * P.row_stride;
+	float *prow = (vd.pan_dynamic_row != ~0u) ? P.pan + (size_t)vd.pan_dynamic_row * P.row_stride : nullptr;
+	/* A wave renders T rows at a time; a row is 64 consecutive frames, one per
+	 * lane, of which the first H are lead-in (recomputed, not stored). */
+	const uint32_t C = 64u - H;                       /* new frames per row */
+	const uint32_t nrows = (fast_total + C - 1) / C;
+	const uint32_t ngroups = (nrows + T - 1) / T;
+	const uint32_t last_group = ((fast_total - 1) / C) / T; /* holds the segment's last frame */
+	uint32_t zero_acc = 0; /* nonzero: some hold-previous run could not be resolved here */
+
+	for (uint32_t cg = cstart; cg < ngroups; cg += gstride) {
+		const int t0 = (int)(cg * T * C) - (int)H + l; /* this lane's frame in row 0 */
+		const bool first_group = (cg == 0);
+		const bool is_last_group = (cg == last_group);
+#if FK_PREFETCH
+		FastStep fnext = load_step_uniform(fsteps);
+#endif
+		for (uint32_t si = 0; si < n_fsteps; ++si) {
+#if FK_PREFETCH
+			const FastStep f = fnext;
+			fnext = load_step_uniform(fsteps + (si + 1 < n_fsteps ? si + 1 : si)); /* in flight during this step */
+#else
+			const FastStep f = load_step_uniform(fsteps + si);
+#endif
+			const uint32_t kind = f.kind & 0xff;
+			const uint32_t flags = (f.kind >> 8) & 0xff;
+			if (SCAN && P.mode == 1 && !(f.ramp & 4)) continue; /* pass 1: not needed for any phase increment */
+			if (kind == ST_OSC) {
+				const uint32_t type = f.type & 0xff;
+				const bool wave_env = (flags & SF_WAVE_ENV) != 0;
+				const bool layer = (flags & SF_LAYER) != 0;
+				const bool to_voice = ((f.kind >> 16) & OX_VOICE) != 0;
+				float s[T];
+				if (type == OT_WAVE) {
+					const bool has_pm = f.pm_off != ~0u, has_fpm = f.fpm_off != ~0u;
+					/* this operator's values are defined from lane p_min on
+					 * (one more lead-in sample per nesting level below it) */
+					const int p_min = (int)H - (int)(f.kind >> 24) + 1;
+					bool done = false;
+					if (FK_COMMON && f.tab >= 0 && !has_fpm && !first_group && !is_last_group && !(f.ramp & 2)) {
+						/* the common case, straight-line: table in LDS, plain PM or
+						 * none, no segment edge in this group */
+						uint32_t ph[T];
+						{
+							uint32_t acc = f.phase0 + f.inc * (uint32_t)(t0 + 1);
+							const uint32_t row_inc = f.inc * C;
+#pragma unroll
+							for (int k = 0; k < T; ++k) { ph[k] = acc; acc += row_inc; }
+						}
+						bool ok = true;
+						if (has_pm) {
+							float pm[T];
+							bool big = false;
+#pragma unroll
+							for (int k = 0; k < T; ++k) {
+								pm[k] = slots[f.pm_off + k * 64];
+								big |= !(fabsf(pm[k]) < 0x1p20f);
+							}
+							ok = !__any(big);
+#pragma unroll
+							for (int k = 0; k < T; ++k) ph[k] += rint32w_p31_small(pm[k]);
+						}
+						if (ok) {
+							const HerpC23 *l23 = t23 + (size_t)f.tab * WAVE_LEN;
+							const HerpC01 *l01 = t01 + (size_t)f.tab * WAVE_LEN;
+							double Is[T];
+#pragma unroll
+							for (int k = 0; k < T; ++k) {
+								const uint32_t ind = ph[k] >> SLEN_BITS;
+								Is[k] = herp_poly(l23[ind], l01[ind], ph[k]);
+							}
+							if (FK_CONSTD && !has_pm && f.inc != 0) {
+								/* unmodulated: every phase step is inc, one division serves all */
+								const double x = (double)div_f32_normal(f.diff_scale, (float)(int32_t)f.inc);
+#pragma unroll
+								for (int k = 0; k < T; ++k)
+									s[k] = (float)((Is[k] - lane_prev(Is[k])) * x + (double)f.diff_offset);
+								done = true;
+							} else {
+								bool zero = false;
+#pragma unroll
+								for (int k = 0; k < T; ++k) {
+									const int32_t d = (int32_t)(ph[k] - lane_prev(ph[k]));
+									zero |= (d == 0);
+									s[k] = wosc_diff(Is[k], lane_prev(Is[k]), d, f.diff_scale, f.diff_offset);
+								}
+								done = !__any(zero && l >= p_min);
+							}
+						}
+					}
+					if (!done) {
+						uint32_t ph[T];
+						double Is[T];
+						float fv[T]; /* frequency per frame (freq-scaled PM reads it) */
+						bool fvar = false;
+						if (SCAN && (f.ramp & 2)) {
+							/* the frequency varies (ramp, FM): phase is a running sum of per-frame
+							 * increments (wosc.h:135-169). This wave walks the voice's rows in order;
+							 * `carry` holds the accumulator at the frame before each row's new frames. */
+							const FastAux fa = load_aux_uniform(faux + si);
+							fvar = (fa.flags & (FA_FVAR_SLOT | FA_FVAR_LINE)) != 0;
+							if (fvar) {
+								uint32_t S[T];
+#pragma unroll
+								for (int k = 0; k < T; ++k) {
+									const int t = t0 + k * (int)C;
+									float v;
+									if (fa.flags & FA_FVAR_SLOT) {
+										v = slots[fa.freq_off + k * 64];
+									} else {
+										v = fast_line_value(fa.fl, t);
+										const bool in_goal = (uint32_t)t < fa.fl.goal_len;
+										if (fa.flags & (in_goal ? FA_MUL_GOAL : FA_MUL_HOLD))
+											v *= fa.fmul_off != ~0u ? slots[fa.fmul_off + k * 64] : fa.mulc;
+									}
+									fv[k] = v;
+									const float x = fa.coeff * v;
+									/* llrintf(x) mod 2^32 (wosc.h:145): adding 1.5 * 2^52 in f64 rounds to the nearest
+									 * integer and leaves it in the low word; exact while |x| < 2^51 */
+									const uint32_t r = fabsf(x) < 0x1p50f ? (uint32_t)__double2loint((double)x + 0x1.8p52) : rint32w(x);
+									const uint32_t inc = (t >= 0 && t < (int)fast_total) ? r : 0u;
+									S[k] = wave_incl_scan_dpp(inc);
+								}
+								/* the accumulator at the frame before this group's first new frame: carried by
+								 * this wave (in-order voices), or the prefix of all earlier groups' sums */
+								uint32_t *sums = two ? scan + (size_t)fa.pad[0] * P.scan_groups : nullptr;
+								uint32_t acc = two ? (P.mode == 1 ? 0u : f.phase0 + sums[cg])
+								                   : (first_group ? f.phase0 : carry[si]);
+#pragma unroll
+								for (int k = 0; k < T; ++k) {
+									const uint32_t lead = (uint32_t)__builtin_amdgcn_readlane((int)S[k], (int)H - 1);
+									const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)S[k], 63);
+									ph[k] = acc + (S[k] - lead);
+									acc += last - lead;
+								}
+								if (two) {
+									if (P.mode == 1) { /* pass 1 ends here for this oscillator */
+										if (l == 0) sums[cg] = acc;
+										continue;
+									}
+								} else if (l == 0) {
+									carry[si] = acc;
+								}
+							}
+						}
+						if (!fvar) {
+							/* phase0 + inc*(t+1): one multiply per lane, then adds */
+							uint32_t acc = f.phase0 + f.inc * (uint32_t)(t0 + 1);
+							const uint32_t row_inc = f.inc * C;
+#pragma unroll
+							for (int k = 0; k < T; ++k) { ph[k] = acc; acc += row_inc; fv[k] = f.fc; }
+						}
+						uint32_t phu[SCAN ? T : 1]; /* accumulator values, before modulation */
+						if (SCAN) {
+#pragma unroll
+							for (int k = 0; k < T; ++k) phu[SCAN ? k : 0] = ph[k];
+						}
+						if (has_pm && !has_fpm) {
+							float pm[T];
+							bool big = false;
+#pragma unroll
+							for (int k = 0; k < T; ++k) {
+								pm[k] = slots[f.pm_off + k * 64];
+								big |= !(fabsf(pm[k]) < 0x1p20f);
+							}
+							if (!__any(big)) {
+#pragma unroll
+								for (int k = 0; k < T; ++k) ph[k] += rint32w_p31_small(pm[k]);
+							} else {
+#pragma unroll
+								for (int k = 0; k < T; ++k) ph[k] += rint32w_p31(pm[k]);
+							}
+						} else if (has_pm || has_fpm) {
+							float pm[T], fpm[T];
+#pragma unroll
+							for (int k = 0; k < T; ++k) { pm[k] = 0.f; fpm[k] = 0.f; }
+							if (has_pm) {
+#pragma unroll
+								for (int k = 0; k < T; ++k) pm[k] = slots[f.pm_off + k * 64];
+							}
+							if (has_fpm) {
+#pragma unroll
+								for (int k = 0; k < T; ++k) fpm[k] = slots[f.fpm_off + k * 64];
+							}
+							if (has_pm) {
+#pragma unroll
+								for (int k = 0; k < T; ++k) ph[k] += pm_offset32(true, true, pm[k], fpm[k], fv[k]);
+							} else {
+#pragma unroll
+								for (int k = 0; k < T; ++k) ph[k] += pm_offset32(false, true, 0.f, fpm[k], fv[k]);
+							}
+						}
+						const bool reset = (f.type >> 16) & 1;
+						if (first_group) {
+							/* t = -1: the sample before the segment (wosc.h:215-231 on restart) */
+							const uint32_t nxt = __shfl_down(ph[0], 1);
+							if (l == (int)H - 1) ph[0] = reset ? nxt - SLEN : f.prev_phase;
+						}
+						if (f.tab >= 0) {
+							const HerpC23 *l23 = t23 + (size_t)f.tab * WAVE_LEN;
+							const HerpC01 *l01 = t01 + (size_t)f.tab * WAVE_LEN;
+#pragma unroll
+							for (int k = 0; k < T; ++k) {
+								const uint32_t ind = ph[k] >> SLEN_BITS;
+								Is[k] = herp_poly(l23[ind], l01[ind], ph[k]);
+							}
+						} else {
+							const uint32_t wave = (f.type >> 8) & 0xff;
+							const HerpC23 *g23 = P.g_c23 + (size_t)wave * WAVE_LEN;
+							const HerpC01 *g01 = P.g_c01 + (size_t)wave * WAVE_LEN;
+#pragma unroll
+							for (int k = 0; k < T; ++k) {
+								const uint32_t ind = ph[k] >> SLEN_BITS;
+								Is[k] = herp_poly(g23[ind], g01[ind], ph[k]);
+							}
+						}
+						if (first_group && !reset) {
+							if (l == (int)H - 1) Is[0] = f.prev_Is;
+						}
+						uint32_t pph[T];
+						bool zero = false;
+						if (FK_CONSTD && !has_pm && !has_fpm && !first_group && f.inc != 0 && !fvar) {
+							/* unmodulated: every phase step is inc, one division serves all */
+							const double x = (double)div_f32_normal(f.diff_scale, (float)(int32_t)f.inc);
+#pragma unroll
+							for (int k = 0; k < T; ++k) {
+								pph[k] = ph[k] - f.inc;
+								const double pIs = lane_prev(Is[k]);
+								s[k] = (float)((Is[k] - pIs) * x + (double)f.diff_offset);
+							}
+						} else {
+#pragma unroll
+							for (int k = 0; k < T; ++k) {
+								pph[k] = lane_prev(ph[k]);
+								const double pIs = lane_prev(Is[k]);
+								const int32_t d = (int32_t)(ph[k] - pph[k]);
+								zero |= (d == 0);
+								s[k] = wosc_diff(Is[k], pIs, d, f.diff_scale, f.diff_offset);
+							}
+						}
+						if (__any(zero && l >= p_min)) {
+							/* dphase == 0: the differentiator holds its previous output
+							 * (wosc.h:251-252). Isolated cases resolve inside the row; a
+							 * run that reaches back past the lead-in goes to the block loop. */
+							bool held[T], src[T]; /* src: holds a defined output to copy from */
+#pragma unroll
+							for (int k = 0; k < T; ++k) {
+								const int t = t0 + k * (int)C;
+								const bool defined = l >= p_min && t >= 0;
+								held[k] = (ph[k] == pph[k]) && defined && t < (int)fast_total;
+								src[k] = defined && !held[k];
+							}
+							for (int it = 0; it < 64; ++it) {
+								bool changed = false;
+#pragma unroll
+								for (int k = 0; k < T; ++k) {
+									const float sp = __shfl_up(s[k], 1);
+									const bool okp = __shfl_up(src[k], 1);
+									if (held[k] && okp && l > 0) { s[k] = sp; held[k] = false; src[k] = true; changed = true; }
+								}
+								if (!__any(changed)) break;
+							}
+#pragma unroll
+							for (int k = 0; k < T; ++k) zero_acc |= (uint32_t)held[k];
+						}
+						if (is_last_group) {
+							/* the row that holds the segment's last frame stages the state */
+#pragma unroll
+							for (int k = 0; k < T; ++k) {
+								const int t = t0 + k * (int)C;
+								if (t == (int)fast_total - 1 && l >= (int)H) {
+									DevOp &o = P.ops[f.gop];
+									if (SCAN) o.st_phase = phu[SCAN ? k : 0];
+									o.st_prev_phase = ph[k];
+									o.st_prev_Is = Is[k];
+									o.st_prev_s = s[k];
+								}
+							}
+						}
+					}
+				} else if (type == OT_RASEG) {
+					/* rasg.h:165-222 + 692-743: frame t reads the counter cp0 + inc * t (+ PM) */
+					const bool rate2x = (f.type >> 17) & 1;
+					const float phase_scale = rate2x ? 0x1p31f * 2 : 0x1p31f;
+					const RasParams rp = ras_params((uint32_t)f.tab & 0xff, ((uint32_t)f.tab >> 8) & 0xffff,
+							f_bits(f.diff_scale), f_bits(f.diff_offset), ((uint32_t)f.tab >> 24) & 0x7f);
+					const unsigned long long inc64 = ((unsigned long long)f.prev_phase << 32) | f.inc;
+					const unsigned long long cp0 = (unsigned long long)__double_as_longlong(f.prev_Is);
+					const bool has_pm = f.pm_off != ~0u, has_fpm = f.fpm_off != ~0u;
+#pragma unroll
+					for (int k = 0; k < T; ++k) {
+						const int t = t0 + k * (int)C;
+						unsigned long long cp = cp0 + inc64 * (unsigned long long)(long long)t;
+						if (has_pm || has_fpm)
+							cp += (unsigned long long)pm_offset(has_pm, has_fpm,
+									has_pm ? slots[f.pm_off + k * 64] : 0.f,
+									has_fpm ? slots[f.fpm_off + k * 64] : 0.f, f.fc, phase_scale);
+						uint32_t cyc;
+						float phf;
+						ras_split(cp, cyc, phf);
+						s[k] = ras_sample(rp, cyc, phf);
+					}
+				} else if (type == OT_NOISE) {
+					const uint32_t nz = (f.type >> 8) & 0xff;
+					const uint32_t n0 = f.phase0, nprev = f.prev_phase;
+#pragma unroll
+					for (int k = 0; k < T; ++k) {
+						const int t = t0 + k * (int)C;
+						const uint32_t n = n0 + (uint32_t)t;
+						if (nz == NZ_vi) {
+							uint32_t s1 = ranfast32(n);
+							uint32_t s0 = t == 0 ? nprev : ranfast32(n - 1);
+							s[k] = fscalei((s1 / 2) - (s0 / 2), 0x1p-31f);
+						} else if (nz == NZ_bv) {
+							int32_t s1 = noise_bv_term(n);
+							int32_t s0 = t == 0 ? (int32_t)nprev : noise_bv_term(n - 1);
+							s[k] = (float)(s1 - s0);
+						} else {
+							s[k] = noise_stateless(nz, n);
+						}
+					}
+				} else { /* OT_AMP: generator.c:517-518 */
+#pragma unroll
+					for (int k = 0; k < T; ++k) s[k] = 1.f;
+				}
+				/* amplitude and combine: generator.c:384-440 */
+				float r[T];
+				if (f.amp_off != ~0u) {
+#pragma unroll
+					for (int k = 0; k < T; ++k) r[k] = slots[f.amp_off + k * 64];
+				} else if (f.ramp & 1) { /* amplitude ramp in progress, sau/line.c:65-281 */
+					const FastLine fl = load_line_uniform(flines + si);
+#pragma unroll
+					for (int k = 0; k < T; ++k) r[k] = fast_line_value(fl, t0 + k * (int)C);
+				} else {
+#pragma unroll
+					for (int k = 0; k < T; ++k) r[k] = f.ac;
+				}
+				if (layer) {
+#pragma unroll
+					for (int k = 0; k < T; ++k)
+						r[k] = mix_combine(slots[f.out_off + k * 64], s[k], r[k], wave_env, true);
+				} else if (wave_env) {
+#pragma unroll
+					for (int k = 0; k < T; ++k) r[k] = mix_combine(0.f, s[k], r[k], true, false);
+				} else {
+#pragma unroll
+					for (int k = 0; k < T; ++k) r[k] = s[k] * r[k];
+				}
+				if (to_voice) {
+#pragma unroll
+					for (int k = 0; k < T; ++k) {
+						const int t = t0 + k * (int)C;
+						if (l >= (int)H && t < (int)fast_total) vrow[t] = r[k];
+					}
+				} else {
+#pragma unroll
+					for (int k = 0; k < T; ++k) slots[f.out_off + k * 64] = r[k];
+				}
+			} else if (kind == ST_LINE) {
+				/* held line: v0 (sau/line.c:435-442); ratio lines only exist for freq */
+				if (f.ramp) {
+					FastLine fl;
+					fl.goal_len = 0; fl.hold = f.ac; fl.pad = 0;
+					fl.sw = sweep_setup(LN_sah, 0.f, 0.f, 0, 1);
+					if (f.ramp & 1) fl = load_line_uniform(flines + si);
+					uint32_t mflags = 0, fmul_off = ~0u;
+					float mulc = 1.f;
+					if (SCAN && (f.ramp & 2)) { /* ratio line: x the parent's frequency (sau/line.c:72) */
+						const FastAux fa = load_aux_uniform(faux + si);
+						mflags = fa.flags; fmul_off = fa.fmul_off; mulc = fa.mulc;
+					}
+#pragma unroll
+					for (int k = 0; k < T; ++k) {
+						const int t = t0 + k * (int)C;
+						float v = fast_line_value(fl, t);
+						const bool in_goal = (uint32_t)t < fl.goal_len;
+						if (mflags & (in_goal ? FA_MUL_GOAL : FA_MUL_HOLD))
+							v *= fmul_off != ~0u ? slots[fmul_off + k * 64] : mulc;
+						slots[f.out_off + k * 64] = v;
+					}
+				} else {
+#pragma unroll
+					for (int k = 0; k < T; ++k) slots[f.out_off + k * 64] = f.ac;
+				}
+			} else if (kind == ST_LERP) { /* generator.c:466-467 */
+#pragma unroll
+				for (int k = 0; k < T; ++k) {
+					float pv = slots[f.out_off + k * 64];
+					pv += (slots[f.aux_off + k * 64] - pv) * slots[f.pm_off + k * 64];
+					slots[f.out_off + k * 64] = pv;
+				}
+			} else if (kind == ST_VOICE) { /* generator.c:749-788 with pan modulators */
+#pragma unroll
+				for (int k = 0; k < T; ++k) {
+					const int t = t0 + k * (int)C;
+					if (l >= (int)H && t < (int)fast_total) {
+						vrow[t] = slots[f.out_off + k * 64];
+						if (prow) prow[t] = f.pm_off != ~0u ? slots[f.pm_off + k * 64] : f.pan;
+					}
+				}
+			}
+		}
+	}
+	if (__any(zero_acc) && l == 0) atomicOr(&P.info[v].bail, 1u);
+
+}
+
+/* SCAN: the kernel may meet voices with running-sum phases (it then holds both builds of fast_voice). */
 template <int T, bool SCAN>
 __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 	constexpr int NP = 64 * T;
@@ -1589,429 +2024,10 @@ __global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
 
 	for (; v < NV; v += vstride) {
 		const FastInfo fi = P.info[v];
-		const uint32_t fast_total = uni(fi.total);
-		if (fast_total == 0) continue;
-		const VoiceDesc vd = P.voices[v];
-		const uint32_t *ids = P.op_ids + vd.ops_ofs;
-		const uint32_t H = uni(fi.H);
-
-		const uint32_t n_fsteps = uni(fi.n_fsteps);
-		const FastStep *fsteps = P.fsteps + (size_t)v * P.max_steps;
-		const FastLine *flines = P.flines + (size_t)v * P.max_steps;
-		const FastAux *faux = P.faux + (size_t)v * P.max_steps;
-		/* sequential-scan voices: the one wave with cstart == 0 walks every row group in order */
 		const uint32_t seq_kind = SCAN ? uni(fi.seq) : 0u;
-		const bool seq = SCAN && seq_kind == 1;    /* one wave, in order */
-		const bool two = SCAN && seq_kind == 2;    /* two passes, every wave */
-		if (SCAN && P.mode == 1 && !two) continue; /* pass 1 only concerns two-pass voices */
-		if (seq && cstart != 0) continue;
-		const uint32_t gstride = seq ? 1u : wpv;
-		uint32_t *scan = two ? P.scan + (size_t)v * FAST_MAX_SCAN * P.scan_groups : nullptr;
-		float *vrow = P.vout + (size_t)vd.out_row * P.row_stride;
-		float *prow = (vd.pan_dynamic_row != ~0u) ? P.pan + (size_t)vd.pan_dynamic_row * P.row_stride : nullptr;
-		/* A wave renders T rows at a time; a row is 64 consecutive frames, one per
-		 * lane, of which the first H are lead-in (recomputed, not stored). */
-		const uint32_t C = 64u - H;                       /* new frames per row */
-		const uint32_t nrows = (fast_total + C - 1) / C;
-		const uint32_t ngroups = (nrows + T - 1) / T;
-		const uint32_t last_group = ((fast_total - 1) / C) / T; /* holds the segment's last frame */
-		uint32_t zero_acc = 0; /* nonzero: some hold-previous run could not be resolved here */
-
-		for (uint32_t cg = cstart; cg < ngroups; cg += gstride) {
-			const int t0 = (int)(cg * T * C) - (int)H + l; /* this lane's frame in row 0 */
-			const bool first_group = (cg == 0);
-			const bool is_last_group = (cg == last_group);
-#if FK_PREFETCH
-			FastStep fnext = load_step_uniform(fsteps);
-#endif
-			for (uint32_t si = 0; si < n_fsteps; ++si) {
-#if FK_PREFETCH
-				const FastStep f = fnext;
-				fnext = load_step_uniform(fsteps + (si + 1 < n_fsteps ? si + 1 : si)); /* in flight during this step */
-#else
-				const FastStep f = load_step_uniform(fsteps + si);
-#endif
-				const uint32_t kind = f.kind & 0xff;
-				const uint32_t flags = (f.kind >> 8) & 0xff;
-				if (SCAN && P.mode == 1 && !(f.ramp & 4)) continue; /* pass 1: not needed for any phase increment */
-				if (kind == ST_OSC) {
-					const uint32_t type = f.type & 0xff;
-					const bool wave_env = (flags & SF_WAVE_ENV) != 0;
-					const bool layer = (flags & SF_LAYER) != 0;
-					const bool to_voice = ((f.kind >> 16) & OX_VOICE) != 0;
-					float s[T];
-					if (type == OT_WAVE) {
-						const bool has_pm = f.pm_off != ~0u, has_fpm = f.fpm_off != ~0u;
-						/* this operator's values are defined from lane p_min on
-						 * (one more lead-in sample per nesting level below it) */
-						const int p_min = (int)H - (int)(f.kind >> 24) + 1;
-						bool done = false;
-						if (FK_COMMON && f.tab >= 0 && !has_fpm && !first_group && !is_last_group && !(f.ramp & 2)) {
-							/* the common case, straight-line: table in LDS, plain PM or
-							 * none, no segment edge in this group */
-							uint32_t ph[T];
-							{
-								uint32_t acc = f.phase0 + f.inc * (uint32_t)(t0 + 1);
-								const uint32_t row_inc = f.inc * C;
-#pragma unroll
-								for (int k = 0; k < T; ++k) { ph[k] = acc; acc += row_inc; }
-							}
-							bool ok = true;
-							if (has_pm) {
-								float pm[T];
-								bool big = false;
-#pragma unroll
-								for (int k = 0; k < T; ++k) {
-									pm[k] = slots[f.pm_off + k * 64];
-									big |= !(fabsf(pm[k]) < 0x1p20f);
-								}
-								ok = !__any(big);
-#pragma unroll
-								for (int k = 0; k < T; ++k) ph[k] += rint32w_p31_small(pm[k]);
-							}
-							if (ok) {
-								const HerpC23 *l23 = t23 + (size_t)f.tab * WAVE_LEN;
-								const HerpC01 *l01 = t01 + (size_t)f.tab * WAVE_LEN;
-								double Is[T];
-#pragma unroll
-								for (int k = 0; k < T; ++k) {
-									const uint32_t ind = ph[k] >> SLEN_BITS;
-									Is[k] = herp_poly(l23[ind], l01[ind], ph[k]);
-								}
-								if (FK_CONSTD && !has_pm && f.inc != 0) {
-									/* unmodulated: every phase step is inc, one division serves all */
-									const double x = (double)div_f32_normal(f.diff_scale, (float)(int32_t)f.inc);
-#pragma unroll
-									for (int k = 0; k < T; ++k)
-										s[k] = (float)((Is[k] - lane_prev(Is[k])) * x + (double)f.diff_offset);
-									done = true;
-								} else {
-									bool zero = false;
-#pragma unroll
-									for (int k = 0; k < T; ++k) {
-										const int32_t d = (int32_t)(ph[k] - lane_prev(ph[k]));
-										zero |= (d == 0);
-										s[k] = wosc_diff(Is[k], lane_prev(Is[k]), d, f.diff_scale, f.diff_offset);
-									}
-									done = !__any(zero && l >= p_min);
-								}
-							}
-						}
-						if (!done) {
-							uint32_t ph[T];
-							double Is[T];
-							float fv[T]; /* frequency per frame (freq-scaled PM reads it) */
-							bool fvar = false;
-							if (SCAN && (f.ramp & 2)) {
-								/* the frequency varies (ramp, FM): phase is a running sum of per-frame
-								 * increments (wosc.h:135-169). This wave walks the voice's rows in order;
-								 * `carry` holds the accumulator at the frame before each row's new frames. */
-								const FastAux fa = load_aux_uniform(faux + si);
-								fvar = (fa.flags & (FA_FVAR_SLOT | FA_FVAR_LINE)) != 0;
-								if (fvar) {
-									uint32_t S[T];
-#pragma unroll
-									for (int k = 0; k < T; ++k) {
-										const int t = t0 + k * (int)C;
-										float v;
-										if (fa.flags & FA_FVAR_SLOT) {
-											v = slots[fa.freq_off + k * 64];
-										} else {
-											v = fast_line_value(fa.fl, t);
-											const bool in_goal = (uint32_t)t < fa.fl.goal_len;
-											if (fa.flags & (in_goal ? FA_MUL_GOAL : FA_MUL_HOLD))
-												v *= fa.fmul_off != ~0u ? slots[fa.fmul_off + k * 64] : fa.mulc;
-										}
-										fv[k] = v;
-										const float x = fa.coeff * v;
-										/* llrintf(x) mod 2^32 (wosc.h:145): adding 1.5 * 2^52 in f64 rounds to the nearest
-										 * integer and leaves it in the low word; exact while |x| < 2^51 */
-										const uint32_t r = fabsf(x) < 0x1p50f ? (uint32_t)__double2loint((double)x + 0x1.8p52) : rint32w(x);
-										const uint32_t inc = (t >= 0 && t < (int)fast_total) ? r : 0u;
-										S[k] = wave_incl_scan_dpp(inc);
-									}
-									/* the accumulator at the frame before this group's first new frame: carried by
-									 * this wave (in-order voices), or the prefix of all earlier groups' sums */
-									uint32_t *sums = two ? scan + (size_t)fa.pad[0] * P.scan_groups : nullptr;
-									uint32_t acc = two ? (P.mode == 1 ? 0u : f.phase0 + sums[cg])
-									                   : (first_group ? f.phase0 : carry[si]);
-#pragma unroll
-									for (int k = 0; k < T; ++k) {
-										const uint32_t lead = (uint32_t)__builtin_amdgcn_readlane((int)S[k], (int)H - 1);
-										const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)S[k], 63);
-										ph[k] = acc + (S[k] - lead);
-										acc += last - lead;
-									}
-									if (two) {
-										if (P.mode == 1) { /* pass 1 ends here for this oscillator */
-											if (l == 0) sums[cg] = acc;
-											continue;
-										}
-									} else if (l == 0) {
-										carry[si] = acc;
-									}
-								}
-							}
-							if (!fvar) {
-								/* phase0 + inc*(t+1): one multiply per lane, then adds */
-								uint32_t acc = f.phase0 + f.inc * (uint32_t)(t0 + 1);
-								const uint32_t row_inc = f.inc * C;
-#pragma unroll
-								for (int k = 0; k < T; ++k) { ph[k] = acc; acc += row_inc; fv[k] = f.fc; }
-							}
-							uint32_t phu[SCAN ? T : 1]; /* accumulator values, before modulation */
-							if (SCAN) {
-#pragma unroll
-								for (int k = 0; k < T; ++k) phu[SCAN ? k : 0] = ph[k];
-							}
-							if (has_pm && !has_fpm) {
-								float pm[T];
-								bool big = false;
-#pragma unroll
-								for (int k = 0; k < T; ++k) {
-									pm[k] = slots[f.pm_off + k * 64];
-									big |= !(fabsf(pm[k]) < 0x1p20f);
-								}
-								if (!__any(big)) {
-#pragma unroll
-									for (int k = 0; k < T; ++k) ph[k] += rint32w_p31_small(pm[k]);
-								} else {
-#pragma unroll
-									for (int k = 0; k < T; ++k) ph[k] += rint32w_p31(pm[k]);
-								}
-							} else if (has_pm || has_fpm) {
-								float pm[T], fpm[T];
-#pragma unroll
-								for (int k = 0; k < T; ++k) { pm[k] = 0.f; fpm[k] = 0.f; }
-								if (has_pm) {
-#pragma unroll
-									for (int k = 0; k < T; ++k) pm[k] = slots[f.pm_off + k * 64];
-								}
-								if (has_fpm) {
-#pragma unroll
-									for (int k = 0; k < T; ++k) fpm[k] = slots[f.fpm_off + k * 64];
-								}
-								if (has_pm) {
-#pragma unroll
-									for (int k = 0; k < T; ++k) ph[k] += pm_offset32(true, true, pm[k], fpm[k], fv[k]);
-								} else {
-#pragma unroll
-									for (int k = 0; k < T; ++k) ph[k] += pm_offset32(false, true, 0.f, fpm[k], fv[k]);
-								}
-							}
-							const bool reset = (f.type >> 16) & 1;
-							if (first_group) {
-								/* t = -1: the sample before the segment (wosc.h:215-231 on restart) */
-								const uint32_t nxt = __shfl_down(ph[0], 1);
-								if (l == (int)H - 1) ph[0] = reset ? nxt - SLEN : f.prev_phase;
-							}
-							if (f.tab >= 0) {
-								const HerpC23 *l23 = t23 + (size_t)f.tab * WAVE_LEN;
-								const HerpC01 *l01 = t01 + (size_t)f.tab * WAVE_LEN;
-#pragma unroll
-								for (int k = 0; k < T; ++k) {
-									const uint32_t ind = ph[k] >> SLEN_BITS;
-									Is[k] = herp_poly(l23[ind], l01[ind], ph[k]);
-								}
-							} else {
-								const uint32_t wave = (f.type >> 8) & 0xff;
-								const HerpC23 *g23 = P.g_c23 + (size_t)wave * WAVE_LEN;
-								const HerpC01 *g01 = P.g_c01 + (size_t)wave * WAVE_LEN;
-#pragma unroll
-								for (int k = 0; k < T; ++k) {
-									const uint32_t ind = ph[k] >> SLEN_BITS;
-									Is[k] = herp_poly(g23[ind], g01[ind], ph[k]);
-								}
-							}
-							if (first_group && !reset) {
-								if (l == (int)H - 1) Is[0] = f.prev_Is;
-							}
-							uint32_t pph[T];
-							bool zero = false;
-							if (FK_CONSTD && !has_pm && !has_fpm && !first_group && f.inc != 0 && !fvar) {
-								/* unmodulated: every phase step is inc, one division serves all */
-								const double x = (double)div_f32_normal(f.diff_scale, (float)(int32_t)f.inc);
-#pragma unroll
-								for (int k = 0; k < T; ++k) {
-									pph[k] = ph[k] - f.inc;
-									const double pIs = lane_prev(Is[k]);
-									s[k] = (float)((Is[k] - pIs) * x + (double)f.diff_offset);
-								}
-							} else {
-#pragma unroll
-								for (int k = 0; k < T; ++k) {
-									pph[k] = lane_prev(ph[k]);
-									const double pIs = lane_prev(Is[k]);
-									const int32_t d = (int32_t)(ph[k] - pph[k]);
-									zero |= (d == 0);
-									s[k] = wosc_diff(Is[k], pIs, d, f.diff_scale, f.diff_offset);
-								}
-							}
-							if (__any(zero && l >= p_min)) {
-								/* dphase == 0: the differentiator holds its previous output
-								 * (wosc.h:251-252). Isolated cases resolve inside the row; a
-								 * run that reaches back past the lead-in goes to the block loop. */
-								bool held[T], src[T]; /* src: holds a defined output to copy from */
-#pragma unroll
-								for (int k = 0; k < T; ++k) {
-									const int t = t0 + k * (int)C;
-									const bool defined = l >= p_min && t >= 0;
-									held[k] = (ph[k] == pph[k]) && defined && t < (int)fast_total;
-									src[k] = defined && !held[k];
-								}
-								for (int it = 0; it < 64; ++it) {
-									bool changed = false;
-#pragma unroll
-									for (int k = 0; k < T; ++k) {
-										const float sp = __shfl_up(s[k], 1);
-										const bool okp = __shfl_up(src[k], 1);
-										if (held[k] && okp && l > 0) { s[k] = sp; held[k] = false; src[k] = true; changed = true; }
-									}
-									if (!__any(changed)) break;
-								}
-#pragma unroll
-								for (int k = 0; k < T; ++k) zero_acc |= (uint32_t)held[k];
-							}
-							if (is_last_group) {
-								/* the row that holds the segment's last frame stages the state */
-#pragma unroll
-								for (int k = 0; k < T; ++k) {
-									const int t = t0 + k * (int)C;
-									if (t == (int)fast_total - 1 && l >= (int)H) {
-										DevOp &o = P.ops[f.gop];
-										if (SCAN) o.st_phase = phu[SCAN ? k : 0];
-										o.st_prev_phase = ph[k];
-										o.st_prev_Is = Is[k];
-										o.st_prev_s = s[k];
-									}
-								}
-							}
-						}
-					} else if (type == OT_RASEG) {
-						/* rasg.h:165-222 + 692-743: frame t reads the counter cp0 + inc * t (+ PM) */
-						const bool rate2x = (f.type >> 17) & 1;
-						const float phase_scale = rate2x ? 0x1p31f * 2 : 0x1p31f;
-						const RasParams rp = ras_params((uint32_t)f.tab & 0xff, ((uint32_t)f.tab >> 8) & 0xffff,
-								f_bits(f.diff_scale), f_bits(f.diff_offset), ((uint32_t)f.tab >> 24) & 0x7f);
-						const unsigned long long inc64 = ((unsigned long long)f.prev_phase << 32) | f.inc;
-						const unsigned long long cp0 = (unsigned long long)__double_as_longlong(f.prev_Is);
-						const bool has_pm = f.pm_off != ~0u, has_fpm = f.fpm_off != ~0u;
-#pragma unroll
-						for (int k = 0; k < T; ++k) {
-							const int t = t0 + k * (int)C;
-							unsigned long long cp = cp0 + inc64 * (unsigned long long)(long long)t;
-							if (has_pm || has_fpm)
-								cp += (unsigned long long)pm_offset(has_pm, has_fpm,
-										has_pm ? slots[f.pm_off + k * 64] : 0.f,
-										has_fpm ? slots[f.fpm_off + k * 64] : 0.f, f.fc, phase_scale);
-							uint32_t cyc;
-							float phf;
-							ras_split(cp, cyc, phf);
-							s[k] = ras_sample(rp, cyc, phf);
-						}
-					} else if (type == OT_NOISE) {
-						const uint32_t nz = (f.type >> 8) & 0xff;
-						const uint32_t n0 = f.phase0, nprev = f.prev_phase;
-#pragma unroll
-						for (int k = 0; k < T; ++k) {
-							const int t = t0 + k * (int)C;
-							const uint32_t n = n0 + (uint32_t)t;
-							if (nz == NZ_vi) {
-								uint32_t s1 = ranfast32(n);
-								uint32_t s0 = t == 0 ? nprev : ranfast32(n - 1);
-								s[k] = fscalei((s1 / 2) - (s0 / 2), 0x1p-31f);
-							} else if (nz == NZ_bv) {
-								int32_t s1 = noise_bv_term(n);
-								int32_t s0 = t == 0 ? (int32_t)nprev : noise_bv_term(n - 1);
-								s[k] = (float)(s1 - s0);
-							} else {
-								s[k] = noise_stateless(nz, n);
-							}
-						}
-					} else { /* OT_AMP: generator.c:517-518 */
-#pragma unroll
-						for (int k = 0; k < T; ++k) s[k] = 1.f;
-					}
-					/* amplitude and combine: generator.c:384-440 */
-					float r[T];
-					if (f.amp_off != ~0u) {
-#pragma unroll
-						for (int k = 0; k < T; ++k) r[k] = slots[f.amp_off + k * 64];
-					} else if (f.ramp & 1) { /* amplitude ramp in progress, sau/line.c:65-281 */
-						const FastLine fl = load_line_uniform(flines + si);
-#pragma unroll
-						for (int k = 0; k < T; ++k) r[k] = fast_line_value(fl, t0 + k * (int)C);
-					} else {
-#pragma unroll
-						for (int k = 0; k < T; ++k) r[k] = f.ac;
-					}
-					if (layer) {
-#pragma unroll
-						for (int k = 0; k < T; ++k)
-							r[k] = mix_combine(slots[f.out_off + k * 64], s[k], r[k], wave_env, true);
-					} else if (wave_env) {
-#pragma unroll
-						for (int k = 0; k < T; ++k) r[k] = mix_combine(0.f, s[k], r[k], true, false);
-					} else {
-#pragma unroll
-						for (int k = 0; k < T; ++k) r[k] = s[k] * r[k];
-					}
-					if (to_voice) {
-#pragma unroll
-						for (int k = 0; k < T; ++k) {
-							const int t = t0 + k * (int)C;
-							if (l >= (int)H && t < (int)fast_total) vrow[t] = r[k];
-						}
-					} else {
-#pragma unroll
-						for (int k = 0; k < T; ++k) slots[f.out_off + k * 64] = r[k];
-					}
-				} else if (kind == ST_LINE) {
-					/* held line: v0 (sau/line.c:435-442); ratio lines only exist for freq */
-					if (f.ramp) {
-						FastLine fl;
-						fl.goal_len = 0; fl.hold = f.ac; fl.pad = 0;
-						fl.sw = sweep_setup(LN_sah, 0.f, 0.f, 0, 1);
-						if (f.ramp & 1) fl = load_line_uniform(flines + si);
-						uint32_t mflags = 0, fmul_off = ~0u;
-						float mulc = 1.f;
-						if (SCAN && (f.ramp & 2)) { /* ratio line: x the parent's frequency (sau/line.c:72) */
-							const FastAux fa = load_aux_uniform(faux + si);
-							mflags = fa.flags; fmul_off = fa.fmul_off; mulc = fa.mulc;
-						}
-#pragma unroll
-						for (int k = 0; k < T; ++k) {
-							const int t = t0 + k * (int)C;
-							float v = fast_line_value(fl, t);
-							const bool in_goal = (uint32_t)t < fl.goal_len;
-							if (mflags & (in_goal ? FA_MUL_GOAL : FA_MUL_HOLD))
-								v *= fmul_off != ~0u ? slots[fmul_off + k * 64] : mulc;
-							slots[f.out_off + k * 64] = v;
-						}
-					} else {
-#pragma unroll
-						for (int k = 0; k < T; ++k) slots[f.out_off + k * 64] = f.ac;
-					}
-				} else if (kind == ST_LERP) { /* generator.c:466-467 */
-#pragma unroll
-					for (int k = 0; k < T; ++k) {
-						float pv = slots[f.out_off + k * 64];
-						pv += (slots[f.aux_off + k * 64] - pv) * slots[f.pm_off + k * 64];
-						slots[f.out_off + k * 64] = pv;
-					}
-				} else if (kind == ST_VOICE) { /* generator.c:749-788 with pan modulators */
-#pragma unroll
-					for (int k = 0; k < T; ++k) {
-						const int t = t0 + k * (int)C;
-						if (l >= (int)H && t < (int)fast_total) {
-							vrow[t] = slots[f.out_off + k * 64];
-							if (prow) prow[t] = f.pm_off != ~0u ? slots[f.pm_off + k * 64] : f.pan;
-						}
-					}
-				}
-			}
-		}
-		if (__any(zero_acc) && l == 0) atomicOr(&P.info[v].bail, 1u);
+		if (SCAN && P.mode == 1 && seq_kind != 2) continue; /* pass 1 only concerns two-pass voices */
+		if (SCAN && seq_kind != 0) fast_voice<T, true>(P, v, fi, slots, carry, t23, t01, l, wpv, cstart);
+		else fast_voice<T, false>(P, v, fi, slots, carry, t23, t01, l, wpv, cstart);
 	}
 }
 
