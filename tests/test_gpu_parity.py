@@ -115,7 +115,7 @@ def test_corpus_single_wave_teams(gpu, lds_limit):
     if lds_limit:
         env["SAU_AMD_LDS_LIMIT"] = lds_limit
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_corpus_check.py")],
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_corpus_check.py")],
                          env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.startswith("0 bad of"), out.stdout[-2000:]
