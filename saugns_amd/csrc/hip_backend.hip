@@ -1062,6 +1062,7 @@ __device__ __forceinline__ uint32_t block_owner(const Step *plan, uint32_t si, u
 
 __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 	const uint32_t v = blockIdx.x * 64 + threadIdx.x;
+	if (v == 0) *P.work_count = 0; /* finalize_kernel (a later launch) builds the block loop's work list */
 	if (v >= P.n_voices) return;
 	const VoiceDesc vd = P.voices[v];
 	const uint32_t *ids = P.op_ids + vd.ops_ofs;
@@ -1987,8 +1988,11 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 }
 
 /* SCAN: the kernel may meet voices with running-sum phases (it then holds both builds of fast_voice). */
+#ifndef FK_MINB
+#define FK_MINB 1
+#endif
 template <int T, bool SCAN>
-__global__ void __launch_bounds__(1024) fast_kernel(FastParams P) {
+__global__ void __launch_bounds__(1024, FK_MINB) fast_kernel(FastParams P) {
 	constexpr int NP = 64 * T;
 	constexpr int W = 16;
 	extern __shared__ __align__(16) unsigned char lds[];
@@ -2435,25 +2439,43 @@ public:
 		if (!mstreams_.ensure(seg.n_streams, err)) return false;
 		/* descriptors go through page-locked staging that is reused once the
 		 * previous segment's copies have left it */
-		if (copy_pending_) { HIP_OK(hipEventSynchronize(copy_done_)); copy_pending_ = false; }
-		if (!h_voices_.ensure(seg.n_voices, err) || !h_ms_.ensure(seg.n_streams, err)) return false;
-		memcpy(h_voices_.p, seg.voices, seg.n_voices * sizeof(VoiceDesc));
-		HIP_OK(hipMemcpyAsync(voices_.p, h_voices_.p, seg.n_voices * sizeof(VoiceDesc),
-				hipMemcpyHostToDevice, stream_));
-		MixStream *ms = h_ms_.p;
+		/* in steady state (no event between two segments) the descriptors repeat: upload only changes */
+		ms_host_.resize(seg.n_streams);
 		uint32_t max_write = 0;
 		for (uint32_t s = 0; s < seg.n_streams; ++s) {
-			ms[s].first_row = seg.streams[s].first_voice;
-			ms[s].n_rows = seg.streams[s].n_voices;
-			ms[s].amp_scale = seg.streams[s].amp_scale;
-			ms[s].write_len = seg.streams[s].write_len;
-			ms[s].pcm = pcm_.p + pcm_row_ * s;
-			if (ms[s].write_len > max_write) max_write = ms[s].write_len;
+			MixStream &m = ms_host_[s];
+			memset(&m, 0, sizeof m);
+			m.first_row = seg.streams[s].first_voice;
+			m.n_rows = seg.streams[s].n_voices;
+			m.amp_scale = seg.streams[s].amp_scale;
+			m.write_len = seg.streams[s].write_len;
+			m.pcm = pcm_.p + pcm_row_ * s;
+			if (m.write_len > max_write) max_write = m.write_len;
 		}
-		HIP_OK(hipMemcpyAsync(mstreams_.p, ms, seg.n_streams * sizeof(MixStream),
-				hipMemcpyHostToDevice, stream_));
-		HIP_OK(hipEventRecord(copy_done_, stream_));
-		copy_pending_ = true;
+		const bool same_voices = voices_sent_.size() == seg.n_voices && voices_dev_ == voices_.p &&
+			memcmp(voices_sent_.data(), seg.voices, seg.n_voices * sizeof(VoiceDesc)) == 0;
+		const bool same_ms = ms_sent_.size() == seg.n_streams && ms_dev_ == mstreams_.p &&
+			memcmp(ms_sent_.data(), ms_host_.data(), seg.n_streams * sizeof(MixStream)) == 0;
+		if (!same_voices || !same_ms) {
+			if (copy_pending_) { HIP_OK(hipEventSynchronize(copy_done_)); copy_pending_ = false; }
+			if (!h_voices_.ensure(seg.n_voices, err) || !h_ms_.ensure(seg.n_streams, err)) return false;
+			if (!same_voices) {
+				memcpy(h_voices_.p, seg.voices, seg.n_voices * sizeof(VoiceDesc));
+				HIP_OK(hipMemcpyAsync(voices_.p, h_voices_.p, seg.n_voices * sizeof(VoiceDesc),
+						hipMemcpyHostToDevice, stream_));
+				voices_sent_.assign(seg.voices, seg.voices + seg.n_voices);
+				voices_dev_ = voices_.p;
+			}
+			if (!same_ms) {
+				memcpy(h_ms_.p, ms_host_.data(), seg.n_streams * sizeof(MixStream));
+				HIP_OK(hipMemcpyAsync(mstreams_.p, h_ms_.p, seg.n_streams * sizeof(MixStream),
+						hipMemcpyHostToDevice, stream_));
+				ms_sent_ = ms_host_;
+				ms_dev_ = mstreams_.p;
+			}
+			HIP_OK(hipEventRecord(copy_done_, stream_));
+			copy_pending_ = true;
+		}
 		rp.voices = voices_.p; rp.steps = steps_.p; rp.op_ids = op_ids_.p; rp.ops = ops_.p;
 		rp.vout = vout_.p; rp.pan = pan_.p; rp.vinfo = vinfo_.p;
 		rp.g_c23 = c23_.p; rp.g_c01 = c01_.p;
@@ -2485,7 +2507,6 @@ public:
 			    !fsteps_.ensure((size_t)seg.n_voices * fmax_steps * sizeof(FastStep), err) ||
 			    !flines_.ensure((size_t)seg.n_voices * fmax_steps * sizeof(FastLine), err) ||
 			    !faux_.ensure((size_t)seg.n_voices * fmax_steps * sizeof(FastAux), err)) return false;
-			HIP_OK(hipMemsetAsync(work_count_.p, 0, sizeof(uint32_t), stream_));
 			FastParams fp;
 			memset(&fp, 0, sizeof fp);
 			fp.voices = voices_.p; fp.steps = steps_.p; fp.fast_ids = fast_ids_.p; fp.op_ids = op_ids_.p; fp.ops = ops_.p;
@@ -2771,6 +2792,9 @@ private:
 	DevBuf<WaveConst> wc_;
 	PinBuf<VoiceDesc> h_voices_;
 	PinBuf<MixStream> h_ms_;
+	std::vector<VoiceDesc> voices_sent_;   /* what the device copies hold */
+	std::vector<MixStream> ms_sent_, ms_host_;
+	const void *voices_dev_ = nullptr, *ms_dev_ = nullptr;
 	hipEvent_t copy_done_ = nullptr;
 	bool copy_pending_ = false;
 	std::vector<TimedPair> events_;
