@@ -2038,20 +2038,24 @@ __global__ void __launch_bounds__(1024, FK_MINB) fast_kernel(FastParams P) {
 /* Apply the closed forms to the operator state, or hand the whole segment
  * to the block loop when a chunk had to bail out. */
 __global__ void __launch_bounds__(64) finalize_kernel(FastParams P) {
-	const uint32_t v = blockIdx.x * 64 + threadIdx.x;
+	/* one thread per (voice, operator); the voice's own bookkeeping goes to its operator 0 */
+	const uint32_t gid = blockIdx.x * 64 + threadIdx.x;
+	const uint32_t v = gid / P.max_ops, i = gid % P.max_ops;
 	if (v >= P.n_voices) return;
 	const FastInfo fi = P.info[v];
 	const VoiceDesc vd = P.voices[v];
 	if (fi.total == 0 || fi.bail) {
-		P.fast_done[v] = 0;
-		P.worklist[atomicAdd(P.work_count, 1u)] = v;
+		if (i == 0) {
+			P.fast_done[v] = 0;
+			P.worklist[atomicAdd(P.work_count, 1u)] = v;
+		}
 		return;
 	}
 	const uint32_t *ids = P.op_ids + vd.ops_ofs;
 	const uint32_t total = fi.total;
-	for (uint32_t i = 0; i < vd.nops; ++i) {
+	if (i < vd.nops) {
 		DevOp &o = P.ops[ids[i]];
-		if (o.rt_frozen) continue; /* out of time: state stands still */
+		if (!o.rt_frozen) { /* (out of time: state stands still) */
 		if (!(o.flags & OPF_TIME_INF)) o.time -= total;
 		for (uint32_t ln = 0; ln < L_COUNT; ++ln) {
 			LineState ls = o.line[ln];
@@ -2076,7 +2080,9 @@ __global__ void __launch_bounds__(64) finalize_kernel(FastParams P) {
 			else if (o.wave == NZ_bv) o.noise_prev = (uint32_t)noise_bv_term(n0 + total - 1);
 			o.noise_n = n0 + total;
 		}
+		}
 	}
+	if (i != 0) return;
 	P.fast_done[v] = total;
 	if (total < vd.run_len) {
 		P.worklist[atomicAdd(P.work_count, 1u)] = v;
@@ -2588,7 +2594,8 @@ public:
 			}
 			TimedPair *tz = timing_on_ ? new_pair(3) : nullptr;
 			if (tz) (void)hipEventRecord(tz->a, stream_);
-			hipLaunchKernelGGL(finalize_kernel, dim3((seg.n_voices + 63) / 64), dim3(64), 0, stream_, fp);
+			hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)(((size_t)seg.n_voices * fp.max_ops + 63) / 64)), dim3(64), 0,
+					stream_, fp);
 			if (tz) (void)hipEventRecord(tz->b, stream_);
 			HIP_OK(hipGetLastError());
 			if (debug_ && use_fast) {
