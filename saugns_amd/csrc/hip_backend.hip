@@ -134,6 +134,26 @@ __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
 	return v;
 }
 
+__device__ __forceinline__ unsigned long long wave_incl_scan64_dpp(unsigned long long v) {
+#define SAU_DPP_ADD64(ctrl, rmask, bc) do { \
+		const uint32_t lo_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, ctrl, rmask, 0xf, bc); \
+		const uint32_t hi_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), ctrl, rmask, 0xf, bc); \
+		v += ((unsigned long long)hi_ << 32) | lo_; } while (0)
+	SAU_DPP_ADD64(0x111, 0xf, true);
+	SAU_DPP_ADD64(0x112, 0xf, true);
+	SAU_DPP_ADD64(0x114, 0xf, true);
+	SAU_DPP_ADD64(0x118, 0xf, true);
+	SAU_DPP_ADD64(0x142, 0xa, false);
+	SAU_DPP_ADD64(0x143, 0xc, false);
+#undef SAU_DPP_ADD64
+	return v;
+}
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int lane) {
+	const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane);
+	const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
+	return ((unsigned long long)hi << 32) | lo;
+}
+
 /* rint(p * 2^31) wrapped to 32 bits for |p| < 2^20: in f64, p + 1.5 * 2^21
  * has an ulp of 2^-31, so the addition rounds p to a multiple of 2^-31
  * (nearest-even, as llrintf does in the default mode) and leaves that
@@ -1013,13 +1033,16 @@ struct FastInfo {
 	uint32_t n_fsteps; /* decoded steps of the voice (decode_kernel) */
 	uint32_t seq;   /* some oscillator's frequency varies (ramp, FM): phases are running sums. 1: one wave walks the
 	                 * voice in order, carrying them; 2: two passes, every wave (no sum depends on another) */
-	uint32_t n_scan; /* oscillators with running-sum phases (two-pass voices) */
+	uint32_t n_scan; /* oscillators with running-sum phases (multi-pass voices) */
+	uint32_t levels; /* deepest level among them (1: no sum depends on another) */
+	uint32_t lvl_bits; /* 2 bits per such oscillator, in plan order: its level */
 };
 
 struct FastStep;
 struct FastLine;
 struct FastAux;
-constexpr uint32_t FAST_MAX_SCAN = 8; /* oscillators with running-sum phases per two-pass voice */
+constexpr uint32_t FAST_MAX_SCAN = 8;   /* oscillators with running-sum phases per multi-pass voice */
+constexpr uint32_t FAST_MAX_LEVELS = 2; /* running sums that depend on running sums: that many sum passes */
 struct FastParams {
 	const VoiceDesc *voices;
 	const Step *steps;
@@ -1043,9 +1066,12 @@ struct FastParams {
 	uint32_t enable;      /* 0: leave every voice to the block loop */
 	uint32_t seq_enable;  /* block buffers are sized for frequency blocks: sequential-scan voices allowed */
 	uint32_t ids_full_ofs;/* offset of the with-frequency numbering in fast_ids */
-	uint32_t mode;        /* fast_kernel: 0 one pass; 1 sums of phase increments per row group only; 2 final pass */
-	uint32_t *scan;       /* [n_voices][FAST_MAX_SCAN][scan_groups]: those sums, then (scan_kernel) their prefixes */
+	uint32_t mode;        /* fast_kernel: 0 the only pass; 1..FAST_MAX_LEVELS: sums of phase increments of that level;
+	                       * FAST_MAX_LEVELS + 1: final pass. scan_kernel: the level whose sums to prefix */
+	unsigned long long *scan; /* [n_voices][FAST_MAX_SCAN][scan_groups]: those sums (W: mod 2^32; R: 64 bits), then
+	                           * (scan_kernel) their prefixes */
 	uint32_t scan_groups;
+	uint32_t *pass_flags; /* [FAST_MAX_LEVELS]: some voice of the segment needs that sum pass (set by analyze_kernel) */
 	int8_t tab_of_wave[12];
 	uint8_t wave_of_tab[12];
 	WaveConst wc[12];
@@ -1167,62 +1193,78 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 			/* the block itself (before modulators are added) holds one value? */
 			o.rt_fblk_valid = (isconst || (st.kind == ST_LINE && (st.flags & SF_FORCE) && !(fl.flags & LP_GOAL) &&
 					!((fl.flags & LP_STATE_RATIO) && st.fmul != NO_SLOT && !pconst))) ? 1u : 0u;
-			if (!isconst) {
-				seq = true;
-				if (o.type == OT_RASEG) bad = true; /* 64-bit counter sums: block loop for now */
-			}
+			if (!isconst) seq = true;
 		}
-		if (st.kind == ST_OSC && is_osc && st.freq != NO_SLOT && !o.rt_fconst_valid) {
-			seq = true;
-			if (o.type == OT_RASEG) bad = true;
-		}
+		if (st.kind == ST_OSC && is_osc && st.freq != NO_SLOT && !o.rt_fconst_valid) seq = true;
 		if (st.flags & SF_END) --depth;
 	}
 	/* Two passes suffice when no running sum depends on another one: the per-frame
 	 * increments of every such oscillator (its frequency inputs) must not depend on
 	 * the output of an oscillator whose phase is itself a running sum. Forward
 	 * data-flow over the block buffers ("tainted" = depends on such an output). */
-	uint32_t seq_kind = seq ? 1u : 0u, n_scan_out = 0;
+	/* Several passes instead of one wave in order: a running sum can be computed by all
+	 * waves once the sums it depends on are known. Level 1: its per-frame increments (its
+	 * frequency inputs) depend on no other running-sum oscillator's output; level n + 1:
+	 * they depend on level-n outputs. Forward data-flow over the block buffers, two bits
+	 * per buffer: the deepest level its contents depend on. */
+	uint32_t seq_kind = seq ? 1u : 0u, n_scan_out = 0, levels_out = 0, lvl_bits_out = 0;
 	if (seq && !bad) {
-		unsigned long long taint[4] = {0, 0, 0, 0};
-		auto tainted = [&](uint32_t sl) -> bool {
-			if (sl == NO_SLOT) return false;
-			const unsigned long long w = (sl >> 6) == 0 ? taint[0] : (sl >> 6) == 1 ? taint[1] : (sl >> 6) == 2 ? taint[2] : taint[3];
-			return (w >> (sl & 63)) & 1ull;
+		unsigned long long t0[4] = {0, 0, 0, 0}, t1[4] = {0, 0, 0, 0};
+		auto level_of = [&](uint32_t sl) -> uint32_t {
+			if (sl == NO_SLOT) return 0;
+			const uint32_t q = sl >> 6;
+			const unsigned long long a = q == 0 ? t0[0] : q == 1 ? t0[1] : q == 2 ? t0[2] : t0[3];
+			const unsigned long long b = q == 0 ? t1[0] : q == 1 ? t1[1] : q == 2 ? t1[2] : t1[3];
+			return (uint32_t)((a >> (sl & 63)) & 1ull) | ((uint32_t)((b >> (sl & 63)) & 1ull) << 1);
 		};
-		auto set_taint = [&](uint32_t sl, bool on, bool keep_old) {
+		auto set_level = [&](uint32_t sl, uint32_t lv, bool keep_max) {
 			if (sl == NO_SLOT) return;
+			if (keep_max) { const uint32_t old = level_of(sl); if (old > lv) lv = old; }
 			const unsigned long long bit = 1ull << (sl & 63);
 #pragma unroll
 			for (int q = 0; q < 4; ++q)
-				if ((int)(sl >> 6) == q) taint[q] = (taint[q] & (keep_old ? ~0ull : ~bit)) | (on ? bit : 0ull);
+				if ((int)(sl >> 6) == q) {
+					t0[q] = (t0[q] & ~bit) | ((lv & 1) ? bit : 0ull);
+					t1[q] = (t1[q] & ~bit) | ((lv & 2) ? bit : 0ull);
+				}
 		};
-		bool two = true;
+		auto max2 = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+		bool multi = true;
 		uint32_t n_scan = 0;
 		for (uint32_t si = 0; si < vd.plan_len; ++si) {
 			const Step st = plan[si];
-			const DevOp &o = P.ops[ids[st.op]];
+			DevOp &o = P.ops[ids[st.op]];
 			if (o.rt_frozen) continue;
 			if (st.kind == ST_LINE) {
-				set_taint(st.out, tainted(st.fmul), false);
+				set_level(st.out, level_of(st.fmul), false);
 			} else if (st.kind == ST_LERP) {
-				set_taint(st.out, tainted(st.freq) || tainted(st.pm), true);
+				set_level(st.out, max2(level_of(st.freq), level_of(st.pm)), true);
 			} else if (st.kind == ST_OSC) {
 				const bool fvar = (o.type == OT_WAVE || o.type == OT_RASEG) && !o.rt_fconst_valid;
+				uint32_t lv = max2(max2(level_of(st.pm), level_of(st.fpm)), max2(level_of(st.amp),
+						max2(level_of(st.freq), level_of(st.fmul))));
 				if (fvar) {
-					if (tainted(st.freq) || tainted(st.fmul)) two = false;
+					const uint32_t mine = 1 + max2(level_of(st.freq), level_of(st.fmul));
+					if (mine > FAST_MAX_LEVELS || n_scan >= FAST_MAX_SCAN) multi = false;
+					else {
+						lvl_bits_out |= mine << (2 * n_scan);
+						if (mine > levels_out) levels_out = mine;
+						o.rt_fblk_valid = mine; /* (its first meaning is over: from here on the operator's level) */
+					}
 					++n_scan;
+					lv = max2(lv, mine > 3 ? 3u : mine);
 				}
-				const bool t = fvar || tainted(st.pm) || tainted(st.fpm) || tainted(st.amp) ||
-					tainted(st.freq) || tainted(st.fmul);
-				if (!(st.which & OX_VOICE)) set_taint(st.out, t, (st.flags & SF_LAYER) != 0);
+				if (!(st.which & OX_VOICE)) set_level(st.out, lv, (st.flags & SF_LAYER) != 0);
 			}
 		}
-		if (two && n_scan <= FAST_MAX_SCAN && P.scan) seq_kind = 2;
+		if (multi && P.scan) {
+			seq_kind = 2;
+			for (uint32_t p = 0; p < levels_out && p < FAST_MAX_LEVELS; ++p) atomicOr(&P.pass_flags[p], 1u);
+		}
 		n_scan_out = n_scan;
 	}
 	FastInfo fi;
-	fi.H = maxd; fi.bail = 0; fi.n_fsteps = 0; fi.seq = seq_kind; fi.n_scan = n_scan_out;
+	fi.H = maxd; fi.bail = 0; fi.n_fsteps = 0; fi.seq = seq_kind; fi.n_scan = n_scan_out; fi.levels = levels_out; fi.lvl_bits = lvl_bits_out;
 	fi.total = 0;
 	if (seq && !P.seq_enable) bad = true;
 	if (!bad && vd.nops <= P.max_ops && vd.plan_len <= P.max_steps && maxd >= 1 && maxd <= P.np / 2)
@@ -1245,7 +1287,7 @@ struct FastStep {
 	double prev_Is;
 	float pan;
 	uint32_t ramp;      /* bit 0: the step's line is a ramp in progress (FastLine); bit 1: FastAux present;
-	                     * bit 2: pass 1 of a two-pass voice runs this step */
+	                     * bit 2 + p: sum pass p + 1 of a multi-pass voice runs this step */
 };
 static_assert(sizeof(FastStep) == 80, "FastStep is 20 dwords");
 
@@ -1272,17 +1314,11 @@ struct FastAux {
 	float coeff;                 /* 2^32 / srate (wosc.h:30) */
 	uint32_t flags;              /* FA_* */
 	float mulc;                  /* the multiplier when the parent's frequency is one value */
-	uint32_t pad[3];             /* [0]: index among the voice's running-sum oscillators (two-pass) */
+	uint32_t pad[3];             /* multi-pass voices: [0] index among the voice's running-sum oscillators, [1] its level */
 	FastLine fl;                 /* ST_OSC with FA_FVAR_LINE: the frequency line's block */
 };
 static_assert(sizeof(FastAux) == 80, "FastAux is 20 dwords");
 
-__device__ __forceinline__ FastStep uni(const FastStep &f) {
-	union { FastStep s; uint32_t u[20]; } c; c.s = f;
-#pragma unroll
-	for (int i = 0; i < 20; ++i) c.u[i] = uni(c.u[i]);
-	return c.s;
-}
 
 typedef const uint32_t __attribute__((address_space(4))) *const_u32_ptr;
 #ifndef FK_GRID
@@ -1322,20 +1358,22 @@ __device__ __forceinline__ float fast_line_value(const FastLine &fl, int t) {
 __global__ void __launch_bounds__(64) scan_kernel(FastParams P) {
 	const uint32_t v = blockIdx.x;
 	const int l = threadIdx.x;
+	if (P.pass_flags[P.mode - 1] == 0) return;
 	const FastInfo fi = P.info[v];
 	if (fi.seq != 2 || fi.total == 0) return;
 	const uint32_t C = 64u - fi.H;
 	const uint32_t nrows = (fi.total + C - 1) / C;
 	const uint32_t ngroups = (nrows + P.rows - 1) / P.rows;
 	for (uint32_t x = 0; x < fi.n_scan && x < FAST_MAX_SCAN; ++x) {
-		uint32_t *a = P.scan + ((size_t)v * FAST_MAX_SCAN + x) * P.scan_groups;
-		uint32_t carry = 0;
+		if (((fi.lvl_bits >> (2 * x)) & 3u) != P.mode) continue; /* sums of this pass only */
+		unsigned long long *a = P.scan + ((size_t)v * FAST_MAX_SCAN + x) * P.scan_groups;
+		unsigned long long carry = 0;
 		for (uint32_t base = 0; base < ngroups; base += 64) {
 			const bool in = base + (uint32_t)l < ngroups;
-			const uint32_t val = in ? a[base + l] : 0u;
-			const uint32_t incl = wave_incl_scan_dpp(val);
+			const unsigned long long val = in ? a[base + l] : 0ull;
+			const unsigned long long incl = wave_incl_scan64_dpp(val);
 			if (in) a[base + l] = carry + (incl - val);
-			carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+			carry += readlane64(incl, 63);
 		}
 	}
 }
@@ -1468,8 +1506,9 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 				 * Backward data-flow over the compact block buffers: a step is needed if it
 				 * writes a buffer some later needed step (or a running-sum oscillator's
 				 * frequency input) reads. */
-				unsigned long long want = 0;
-				bool mine = false;
+				unsigned long long want[FAST_MAX_LEVELS];
+				bool mine[FAST_MAX_LEVELS];
+				for (uint32_t p = 0; p < FAST_MAX_LEVELS; ++p) { want[p] = 0; mine[p] = false; }
 				uint32_t xi = 0;
 				for (uint32_t q = vd.plan_len; q-- > 0;) {
 					const Step sq = plan[q];
@@ -1479,24 +1518,29 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 					const FastIds cq = P.fast_ids[P.ids_full_ofs + vd.plan_ofs + q];
 					auto bit = [](uint8_t id) -> unsigned long long { return id != NO_SLOT ? 1ull << id : 0ull; };
 					const bool q_fvar = sq.kind == ST_OSC && (oq.type == OT_WAVE || oq.type == OT_RASEG) && !oq.rt_fconst_valid;
-					bool needed = false;
-					if (q_fvar) {
-						needed = true; /* as a sums-only step */
-						want |= bit(cq.freq) | bit(cq.fmul);
-						if (q < (uint32_t)l) ++xi;
-					} else {
-						const bool writes = sq.kind == ST_LINE || sq.kind == ST_LERP ||
-							(sq.kind == ST_OSC && !(sq.which & OX_VOICE));
-						if (writes && (want & bit(cq.out))) {
-							needed = true;
-							const bool rmw = sq.kind == ST_LERP || (sq.kind == ST_OSC && (sq.flags & SF_LAYER));
-							if (!rmw) want &= ~bit(cq.out);
-							want |= bit(cq.pm) | bit(cq.fpm) | bit(cq.amp) | bit(cq.aux) | bit(cq.freq) | bit(cq.fmul);
+					const uint32_t q_level = q_fvar ? oq.rt_fblk_valid : 0u; /* analyze_kernel left the level there */
+					if (q_fvar && q < (uint32_t)l) ++xi;
+					const bool writes = sq.kind == ST_LINE || sq.kind == ST_LERP ||
+						(sq.kind == ST_OSC && !(sq.which & OX_VOICE));
+					const bool rmw = sq.kind == ST_LERP || (sq.kind == ST_OSC && (sq.flags & SF_LAYER));
+					for (uint32_t p = 0; p < FAST_MAX_LEVELS; ++p) { /* sum pass p + 1 */
+						bool needed = false;
+						if (q_fvar && q_level == p + 1) {
+							needed = true; /* as a sums-only step */
+							want[p] |= bit(cq.freq) | bit(cq.fmul);
+						} else if (!(q_fvar && q_level > p + 1)) {
+							/* an ordinary producer (running sums of lower levels have their prefixes by now) */
+							if (writes && (want[p] & bit(cq.out))) {
+								needed = true;
+								if (!rmw) want[p] &= ~bit(cq.out);
+								want[p] |= bit(cq.pm) | bit(cq.fpm) | bit(cq.amp) | bit(cq.aux) | bit(cq.freq) | bit(cq.fmul);
+							}
 						}
+						if (q == (uint32_t)l) mine[p] = needed;
 					}
-					if (q == (uint32_t)l) mine = needed;
 				}
-				if (mine) f.ramp |= 4;
+				for (uint32_t p = 0; p < FAST_MAX_LEVELS; ++p) if (mine[p]) f.ramp |= 4u << p;
+				fa.pad[1] = (o.type == OT_WAVE || o.type == OT_RASEG) && !o.rt_fconst_valid ? o.rt_fblk_valid : 0u;
 				fa.pad[0] = xi;
 			}
 			if (st.kind == ST_OSC && is_osc && !o.rt_fconst_valid) {
@@ -1557,14 +1601,13 @@ __device__ __forceinline__ FastStep load_step_uniform(const FastStep *p) {
  * slower on them), and a kernel that may meet both kinds holds both copies. */
 template <int T, bool SCAN>
 __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v, const FastInfo &fi,
-		float *slots, uint32_t *carry, const HerpC23 *t23, const HerpC01 *t01, const int l,
+		float *slots, unsigned long long *carry, const HerpC23 *t23, const HerpC01 *t01, const int l,
 		const uint32_t wpv, const uint32_t cstart) {
 	constexpr int NP = 64 * T;
 	(void)NP;
 	const uint32_t fast_total = uni(fi.total);
 	if (fast_total == 0) return;
 	const VoiceDesc vd = P.voices[v];
-	const uint32_t *ids = P.op_ids + vd.ops_ofs;
 	const uint32_t H = uni(fi.H);
 
 	const uint32_t n_fsteps = uni(fi.n_fsteps);
@@ -1575,10 +1618,9 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 	const uint32_t seq_kind = SCAN ? uni(fi.seq) : 0u;
 	const bool seq = SCAN && seq_kind == 1;    /* one wave, in order */
 	const bool two = SCAN && seq_kind == 2;    /* two passes, every wave */
-	if (SCAN && P.mode == 1 && !two) return; /* pass 1 only concerns two-pass voices */
 	if (seq && cstart != 0) return;
 	const uint32_t gstride = seq ? 1u : wpv;
-	uint32_t *scan = two ? P.scan + (size_t)v * FAST_MAX_SCAN * P.scan_groups : nullptr;
+	unsigned long long *scan = two ? P.scan + (size_t)v * FAST_MAX_SCAN * P.scan_groups : nullptr;
 	float *vrow = P.vout + (size_t)vd.out_row * P.row_stride;
 	float *prow = (vd.pan_dynamic_row != ~0u) ? P.pan + (size_t)vd.pan_dynamic_row * P.row_stride : nullptr;
 	/* A wave renders T rows at a time; a row is 64 consecutive frames, one per
@@ -1605,7 +1647,8 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 #endif
 			const uint32_t kind = f.kind & 0xff;
 			const uint32_t flags = (f.kind >> 8) & 0xff;
-			if (SCAN && P.mode == 1 && !(f.ramp & 4)) continue; /* pass 1: not needed for any phase increment */
+			const bool sum_pass = SCAN && P.mode != 0 && P.mode <= FAST_MAX_LEVELS;
+			if (sum_pass && !(f.ramp & (2u << P.mode))) continue; /* not needed for this pass's phase increments */
 			if (kind == ST_OSC) {
 				const uint32_t type = f.type & 0xff;
 				const bool wave_env = (flags & SF_WAVE_ENV) != 0;
@@ -1704,9 +1747,10 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 								}
 								/* the accumulator at the frame before this group's first new frame: carried by
 								 * this wave (in-order voices), or the prefix of all earlier groups' sums */
-								uint32_t *sums = two ? scan + (size_t)fa.pad[0] * P.scan_groups : nullptr;
-								uint32_t acc = two ? (P.mode == 1 ? 0u : f.phase0 + sums[cg])
-								                   : (first_group ? f.phase0 : carry[si]);
+								unsigned long long *sums = two ? scan + (size_t)fa.pad[0] * P.scan_groups : nullptr;
+								const bool sum_me = two && P.mode == fa.pad[1]; /* this pass computes this oscillator's sums */
+								uint32_t acc = two ? (sum_me ? 0u : f.phase0 + (uint32_t)sums[cg])
+								                   : (first_group ? f.phase0 : (uint32_t)carry[si]);
 #pragma unroll
 								for (int k = 0; k < T; ++k) {
 									const uint32_t lead = (uint32_t)__builtin_amdgcn_readlane((int)S[k], (int)H - 1);
@@ -1715,12 +1759,12 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 									acc += last - lead;
 								}
 								if (two) {
-									if (P.mode == 1) { /* pass 1 ends here for this oscillator */
-										if (l == 0) sums[cg] = acc;
+									if (sum_me) { /* this pass ends here for this oscillator */
+										if (l == 0) sums[cg] = (unsigned long long)acc;
 										continue;
 									}
 								} else if (l == 0) {
-									carry[si] = acc;
+									carry[si] = (unsigned long long)acc;
 								}
 							}
 						}
@@ -1868,14 +1912,76 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 					const unsigned long long inc64 = ((unsigned long long)f.prev_phase << 32) | f.inc;
 					const unsigned long long cp0 = (unsigned long long)__double_as_longlong(f.prev_Is);
 					const bool has_pm = f.pm_off != ~0u, has_fpm = f.fpm_off != ~0u;
+					unsigned long long cpv[T]; /* the counter each frame reads (post-increment), before PM */
+					float fv[T];
+					bool fvar = false;
+					if (SCAN && (f.ramp & 2)) {
+						/* the frequency varies: the counter is a running sum of 64-bit increments */
+						const FastAux fa = load_aux_uniform(faux + si);
+						fvar = (fa.flags & (FA_FVAR_SLOT | FA_FVAR_LINE)) != 0;
+						if (fvar) {
+							const float rcoeff = rate2x ? fa.coeff * 2 : fa.coeff;
+							unsigned long long S[T], incv[T];
+#pragma unroll
+							for (int k = 0; k < T; ++k) {
+								const int t = t0 + k * (int)C;
+								float v;
+								if (fa.flags & FA_FVAR_SLOT) {
+									v = slots[fa.freq_off + k * 64];
+								} else {
+									v = fast_line_value(fa.fl, t);
+									const bool in_goal = (uint32_t)t < fa.fl.goal_len;
+									if (fa.flags & (in_goal ? FA_MUL_GOAL : FA_MUL_HOLD))
+										v *= fa.fmul_off != ~0u ? slots[fa.fmul_off + k * 64] : fa.mulc;
+								}
+								fv[k] = v;
+								incv[k] = (t >= 0 && t < (int)fast_total) ? (unsigned long long)rint64(rcoeff * v) : 0ull;
+								S[k] = wave_incl_scan64_dpp(incv[k]);
+							}
+							unsigned long long *sums = two ? scan + (size_t)fa.pad[0] * P.scan_groups : nullptr;
+							const bool sum_me = two && P.mode == fa.pad[1];
+							unsigned long long acc = two ? (sum_me ? 0ull : cp0 + sums[cg])
+							                             : (first_group ? cp0 : carry[si]);
+#pragma unroll
+							for (int k = 0; k < T; ++k) {
+								const unsigned long long lead = readlane64(S[k], (int)H - 1);
+								const unsigned long long last = readlane64(S[k], 63);
+								cpv[k] = acc + (S[k] - lead) - incv[k];
+								acc += last - lead;
+							}
+							if (two) {
+								if (sum_me) {
+									if (l == 0) sums[cg] = acc;
+									continue;
+								}
+							} else if (l == 0) {
+								carry[si] = acc;
+							}
+							if (is_last_group) { /* the counter after the segment's last frame */
+#pragma unroll
+								for (int k = 0; k < T; ++k) {
+									const int t = t0 + k * (int)C;
+									if (t == (int)fast_total - 1 && l >= (int)H)
+										P.ops[f.gop].st_prev_Is = __longlong_as_double((long long)(cpv[k] + incv[k]));
+								}
+							}
+						}
+					}
+					if (!fvar) {
+#pragma unroll
+						for (int k = 0; k < T; ++k) {
+							const int t = t0 + k * (int)C;
+							cpv[k] = cp0 + inc64 * (unsigned long long)(long long)t;
+							fv[k] = f.fc;
+						}
+					}
 #pragma unroll
 					for (int k = 0; k < T; ++k) {
-						const int t = t0 + k * (int)C;
-						unsigned long long cp = cp0 + inc64 * (unsigned long long)(long long)t;
+						unsigned long long cp = cpv[k];
 						if (has_pm || has_fpm)
 							cp += (unsigned long long)pm_offset(has_pm, has_fpm,
 									has_pm ? slots[f.pm_off + k * 64] : 0.f,
-									has_fpm ? slots[f.fpm_off + k * 64] : 0.f, f.fc, phase_scale);
+									has_fpm ? slots[f.fpm_off + k * 64] : 0.f, fv[k], phase_scale);
 						uint32_t cyc;
 						float phf;
 						ras_split(cp, cyc, phf);
@@ -1999,13 +2105,15 @@ __global__ void __launch_bounds__(1024, FK_MINB) fast_kernel(FastParams P) {
 	const int tid = threadIdx.x;
 	const int w = (int)uni((uint32_t)tid >> 6);
 	const int l = tid & 63;
+	/* a sum pass nobody needs costs a launch, not a table staging */
+	if (SCAN && P.mode != 0 && P.mode <= FAST_MAX_LEVELS && P.pass_flags[P.mode - 1] == 0) return;
 
 	HerpC23 *t23 = (HerpC23 *)lds;
 	HerpC01 *t01 = (HerpC01 *)(lds + (size_t)P.n_tabs * WAVE_LEN * sizeof(HerpC23));
 	unsigned char *areas = lds + (size_t)P.n_tabs * WAVE_LEN * (sizeof(HerpC23) + sizeof(HerpC01));
-	const size_t area_bytes = (size_t)P.n_fast * NP * sizeof(float) + (size_t)P.max_steps * sizeof(uint32_t);
+	const size_t area_bytes = (size_t)P.n_fast * NP * sizeof(float) + (size_t)P.max_steps * sizeof(unsigned long long);
 	float *slots = (float *)(areas + (size_t)w * area_bytes) + l; /* lane's column of every row */
-	uint32_t *carry = (uint32_t *)(areas + (size_t)w * area_bytes + (size_t)P.n_fast * NP * sizeof(float)); /* per step */
+	unsigned long long *carry = (unsigned long long *)(areas + (size_t)w * area_bytes + (size_t)P.n_fast * NP * sizeof(float)); /* per step */
 
 	for (uint32_t t = 0; t < P.n_tabs; ++t) {
 		const uint32_t wave = P.wave_of_tab[t];
@@ -2029,7 +2137,8 @@ __global__ void __launch_bounds__(1024, FK_MINB) fast_kernel(FastParams P) {
 	for (; v < NV; v += vstride) {
 		const FastInfo fi = P.info[v];
 		const uint32_t seq_kind = SCAN ? uni(fi.seq) : 0u;
-		if (SCAN && P.mode == 1 && seq_kind != 2) continue; /* pass 1 only concerns two-pass voices */
+		if (SCAN && P.mode != 0 && P.mode <= FAST_MAX_LEVELS && (seq_kind != 2 || uni(fi.levels) < P.mode))
+			continue; /* a sum pass only concerns multi-pass voices that deep */
 		if (SCAN && seq_kind != 0) fast_voice<T, true>(P, v, fi, slots, carry, t23, t01, l, wpv, cstart);
 		else fast_voice<T, false>(P, v, fi, slots, carry, t23, t01, l, wpv, cstart);
 	}
@@ -2041,6 +2150,7 @@ __global__ void __launch_bounds__(64) finalize_kernel(FastParams P) {
 	/* one thread per (voice, operator); the voice's own bookkeeping goes to its operator 0 */
 	const uint32_t gid = blockIdx.x * 64 + threadIdx.x;
 	const uint32_t v = gid / P.max_ops, i = gid % P.max_ops;
+	if (gid < FAST_MAX_LEVELS && P.pass_flags) P.pass_flags[gid] = 0; /* for the next segment's analyze_kernel */
 	if (v >= P.n_voices) return;
 	const FastInfo fi = P.info[v];
 	const VoiceDesc vd = P.voices[v];
@@ -2073,7 +2183,8 @@ __global__ void __launch_bounds__(64) finalize_kernel(FastParams P) {
 		} else if (o.type == OT_RASEG) {
 			const bool rate2x = (o.flags & OPF_RATE2X) != 0;
 			const unsigned long long inc64 = (unsigned long long)rint64((rate2x ? o.coeff * 2 : o.coeff) * o.rt_fconst);
-			o.cycle_phase += inc64 * total;
+			if (o.rt_fconst_valid) o.cycle_phase += inc64 * total;
+			else o.cycle_phase = (unsigned long long)__double_as_longlong(o.st_prev_Is); /* running sum, staged */
 		} else if (o.type == OT_NOISE) {
 			const uint32_t n0 = o.noise_n;
 			if (o.wave == NZ_vi) o.noise_prev = ranfast32(n0 + total - 1);
@@ -2497,12 +2608,14 @@ public:
 			 * (more rows amortise the per-step work: 8 rows measured 8 % faster
 			 * than 4, 4 rows 28 % faster than 2) */
 			uint32_t FT = fast_rows_;
+			/* the build with the running-sum code needs more registers: 8 rows per pass would spill */
+			if (seq_enabled_ && seg.n_fast_full > 0 && FT > 4) FT = 4;
 			/* block buffers: without frequency blocks, or with them when some voice may need
 			 * the sequential scan (ramped or modulated frequencies) */
 			const bool seq_ok = seq_enabled_ && seg.n_fast_full > 0;
 			const uint32_t n_fast = seq_ok && seg.n_fast_full > seg.n_fast ? seg.n_fast_full : seg.n_fast;
 			auto area_of = [&](uint32_t t) {
-				return (size_t)n_fast * 64 * t * sizeof(float) + (size_t)fmax_steps * sizeof(uint32_t);
+				return (size_t)n_fast * 64 * t * sizeof(float) + (size_t)fmax_steps * sizeof(unsigned long long);
 			};
 			const size_t one_tab = seg.wave_mask ? tab_bytes : 0;
 			while (FT > 2 && 16 * area_of(FT) + one_tab + 1024 > lds_limit_) FT /= 2;
@@ -2528,6 +2641,11 @@ public:
 				if (!scan_.ensure((size_t)seg.n_voices * FAST_MAX_SCAN * fp.scan_groups, err)) return false;
 				fp.scan = scan_.p;
 			}
+			if (!pass_flags_.p) {
+				if (!pass_flags_.ensure(FAST_MAX_LEVELS, err)) return false;
+				HIP_OK(hipMemsetAsync(pass_flags_.p, 0, pass_flags_.cap * sizeof(uint32_t), stream_));
+			}
+			fp.pass_flags = pass_flags_.p;
 			fp.max_ops = seg.max_ops; fp.max_steps = fmax_steps; fp.np = 64; fp.rows = FT;
 			fp.enable = use_fast ? 1u : 0u;
 			memcpy(fp.wc, wconst_, sizeof wconst_);
@@ -2584,9 +2702,11 @@ public:
 				};
 				if (fp.scan) {
 					/* some voice may have running-sum phases: sums per row group, their prefixes, final pass */
-					launch_fast(1);
-					hipLaunchKernelGGL(scan_kernel, dim3(seg.n_voices), dim3(64), 0, stream_, fp);
-					launch_fast(2);
+					for (uint32_t pass = 1; pass <= FAST_MAX_LEVELS; ++pass) {
+						launch_fast(pass);
+						hipLaunchKernelGGL(scan_kernel, dim3(seg.n_voices), dim3(64), 0, stream_, fp);
+					}
+					launch_fast(FAST_MAX_LEVELS + 1);
 				} else {
 					launch_fast(0);
 				}
@@ -2814,7 +2934,8 @@ private:
 	DevBuf<FastInfo> finfo_;
 	DevBuf<uint32_t> fdone_, worklist_, work_count_;
 	DevBuf<unsigned char> fsteps_, flines_, faux_;
-	DevBuf<uint32_t> scan_;
+	DevBuf<unsigned long long> scan_;
+	DevBuf<uint32_t> pass_flags_;
 	hipEvent_t fetch_ev_[2] = {nullptr, nullptr};
 	uint32_t multi_min_ = 256;
 	uint32_t fast_rows_ = 8;
