@@ -169,14 +169,20 @@ struct TabRef {
 	bool in_lds;
 };
 
+/* LDS copies are read through LDS-typed pointers: a pointer that may be either
+ * kind compiles to flat loads, which cost several times a ds_read and, in the
+ * serial feedback loops, sat on the critical path of every sample. */
+typedef const double __attribute__((address_space(3))) *lds_f64_ptr;
+typedef const float __attribute__((address_space(3))) *lds_f32_ptr;
 __device__ __forceinline__ double herp_lookup(const TabRef &t, uint32_t phase) {
 	uint32_t ind = phase >> SLEN_BITS;
 	HerpC23 hi;
 	HerpC01 lo;
 	if (t.in_lds) {
-		const HerpC23 *p23 = (const HerpC23 *)__builtin_assume_aligned(t.c23, 16);
-		hi = p23[ind];
-		lo = t.c01[ind];
+		lds_f64_ptr p23 = (lds_f64_ptr)(const double *)(t.c23 + ind);
+		lds_f32_ptr p01 = (lds_f32_ptr)(const float *)(t.c01 + ind);
+		hi.c3 = p23[0]; hi.c2 = p23[1];
+		lo.c1 = p01[0]; lo.c0 = p01[1];
 	} else {
 		hi = t.c23[ind];
 		lo = t.c01[ind];
