@@ -240,7 +240,7 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 	std::vector<SegmentDesc::Stream> sdescs(streams_.size());
 	uint32_t n_main = 1, n_fpool = 0, max_ops = 1, n_pan = 0, max_steps = 1, n_fast = 1, n_fast_full = 0;
 	uint64_t wave_mask = 0;
-	bool maybe_block = false, serial = false;
+	bool maybe_block = false, serial = false, may_scan = false;
 	for (size_t s = 0; s < streams_.size(); ++s) {
 		Stream &st = streams_[s];
 		SegmentDesc::Stream &sd = sdescs[s];
@@ -295,7 +295,10 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 				}
 			}
 			if (out_len < run_len) maybe_block = true;
-			if (voice_block && !vn.plan.no_fast) n_fast_full = std::max(n_fast_full, vn.plan.n_fast_full);
+			if (voice_block && !vn.plan.no_fast) {
+				n_fast_full = std::max(n_fast_full, vn.plan.n_fast_full);
+				may_scan = true;
+			}
 		}
 		sd.n_voices = (uint32_t)descs.size() - sd.first_voice;
 		if (sd.write_len > 0) {
@@ -314,6 +317,7 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 	seg.wave_mask = wave_mask;
 	seg.maybe_block = maybe_block;
 	seg.serial = serial;
+	seg.may_scan = may_scan;
 	return backend_->render(seg, err);
 }
 

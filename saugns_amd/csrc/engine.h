@@ -44,7 +44,8 @@ struct SegmentDesc {
 	uint32_t n_slots;         /* max over active plans of main + frequency slots */
 	uint32_t n_main;          /* max main-pool slots (slot_index() base) */
 	uint32_t n_fast;          /* max block buffers the time-parallel path needs (fast_slot_compact) */
-	uint32_t n_fast_full;     /* the same with frequency blocks, over voices that may need them (0: none) */
+	uint32_t n_fast_full;     /* the same with frequency blocks, over voices that may need them */
+	bool may_scan;            /* some voice may have ramped or modulated frequencies (running-sum phases) */
 	uint32_t max_ops;         /* max operators in any active voice */
 	uint32_t max_steps;       /* longest active plan */
 	uint32_t n_pan_rows;

@@ -2642,10 +2642,10 @@ public:
 			 * than 4, 4 rows 28 % faster than 2) */
 			uint32_t FT = fast_rows_;
 			/* the build with the running-sum code needs more registers: 8 rows per pass would spill */
-			if (seq_enabled_ && seg.n_fast_full > 0 && FT > 4) FT = 4;
+			if (seq_enabled_ && seg.may_scan && FT > 4) FT = 4;
 			/* block buffers: without frequency blocks, or with them when some voice may need
 			 * the sequential scan (ramped or modulated frequencies) */
-			const bool seq_ok = seq_enabled_ && seg.n_fast_full > 0;
+			const bool seq_ok = seq_enabled_ && seg.may_scan;
 			const uint32_t n_fast = seq_ok && seg.n_fast_full > seg.n_fast ? seg.n_fast_full : seg.n_fast;
 			auto area_of = [&](uint32_t t) {
 				return (size_t)n_fast * 64 * t * sizeof(float) + (size_t)fmax_steps * sizeof(unsigned long long);
