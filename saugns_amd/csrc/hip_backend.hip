@@ -1471,8 +1471,32 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 			f.diff_offset = bits_f(o.ras_alpha);
 			f.type |= rate2x ? 1u << 17 : 0u;
 		}
-		f.pan = (st.kind == ST_OSC && o.type == OT_WAVE) ? o.prev_s : o.line[L_PAN].v0;
+		f.pan = o.line[L_PAN].v0;
 		f.ramp = 0;
+		if (o.type == OT_AMP) f.fc = 1.f;
+		if (st.kind == ST_OSC && o.type == OT_WAVE && !zero_fill && st.pm == NO_SLOT && st.fpm == NO_SLOT &&
+		    o.rt_fconst_valid && f.inc == 0 && ((o.flags & OPF_OSC_RESET) || o.prev_phase == o.phase)) {
+			/* Frequency 0, unmodulated: the phase never moves and the differentiator holds its
+			 * output (wosc.h:251-252) -- the value it had, or on a restart the one the first
+			 * frame computes against phase - one table step (wosc.h:215-231). The step becomes
+			 * a constant source; the state the segment leaves behind is known right here. */
+			float held = o.prev_s;
+			double Is0 = o.prev_Is;
+			uint32_t pprev = o.prev_phase;
+			if (o.flags & OPF_OSC_RESET) {
+				const HerpC23 *g23 = P.g_c23 + (size_t)wv * WAVE_LEN;
+				const HerpC01 *g01 = P.g_c01 + (size_t)wv * WAVE_LEN;
+				const uint32_t pa = o.phase, pb = o.phase - SLEN;
+				Is0 = herp_poly(g23[pa >> SLEN_BITS], g01[pa >> SLEN_BITS], pa);
+				const double IsP = herp_poly(g23[pb >> SLEN_BITS], g01[pb >> SLEN_BITS], pb);
+				held = wosc_diff(Is0, IsP, (int32_t)SLEN, P.wc[wv].diff_scale, P.wc[wv].diff_offset);
+				pprev = pa;
+			}
+			DevOp &ow = P.ops[ids[st.op]];
+			ow.st_phase = o.phase; ow.st_prev_phase = pprev; ow.st_prev_Is = Is0; ow.st_prev_s = held;
+			f.type = OT_AMP;
+			f.fc = held;
+		}
 		if (zero_fill) { /* becomes a constant line step */
 			f.kind = (uint32_t)ST_LINE | ((uint32_t)L_AMP << 16) | (dep << 24);
 			f.ac = 0.f;
@@ -1667,34 +1691,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 					 * (one more lead-in sample per nesting level below it) */
 					const int p_min = (int)H - (int)(f.kind >> 24) + 1;
 					bool done = false;
-					const bool reset0 = (f.type >> 16) & 1;
-					if (!has_pm && !has_fpm && f.inc == 0 && !(f.ramp & 2) && (reset0 || f.prev_phase == f.phase0)) {
-						/* frequency 0, unmodulated: the phase never moves, the differentiator holds its
-						 * output (wosc.h:251-252) -- the value it had, or on a restart the one the first
-						 * frame computes against phase - one table step (wosc.h:215-231) */
-						float held = f.pan; /* decode_kernel put prev_s there for oscillator steps */
-						double Is0 = f.prev_Is;
-						if (reset0) {
-							const uint32_t wave = (f.type >> 8) & 0xff;
-							const HerpC23 *g23 = P.g_c23 + (size_t)wave * WAVE_LEN;
-							const HerpC01 *g01 = P.g_c01 + (size_t)wave * WAVE_LEN;
-							const uint32_t pa = f.phase0, pb = f.phase0 - SLEN;
-							Is0 = herp_poly(g23[pa >> SLEN_BITS], g01[pa >> SLEN_BITS], pa);
-							const double IsP = herp_poly(g23[pb >> SLEN_BITS], g01[pb >> SLEN_BITS], pb);
-							held = wosc_diff(Is0, IsP, (int32_t)SLEN, f.diff_scale, f.diff_offset);
-						}
-#pragma unroll
-						for (int k = 0; k < T; ++k) s[k] = held;
-						if (is_last_group && l == 0) {
-							DevOp &o = P.ops[f.gop];
-							o.st_phase = f.phase0;
-							o.st_prev_phase = reset0 ? f.phase0 : f.prev_phase;
-							o.st_prev_Is = Is0;
-							o.st_prev_s = held;
-						}
-						done = true;
-					}
-					if (!done && FK_COMMON && f.tab >= 0 && !has_fpm && !first_group && !is_last_group && !(f.ramp & 2)) {
+					if (FK_COMMON && f.tab >= 0 && !has_fpm && !first_group && !is_last_group && !(f.ramp & 2)) {
 						/* the common case, straight-line: table in LDS, plain PM or
 						 * none, no segment edge in this group */
 						uint32_t ph[T];
@@ -2039,9 +2036,9 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 							s[k] = noise_stateless(nz, n);
 						}
 					}
-				} else { /* OT_AMP: generator.c:517-518 */
+				} else { /* OT_AMP (generator.c:517-518: 1), or an oscillator whose output stands still */
 #pragma unroll
-					for (int k = 0; k < T; ++k) s[k] = 1.f;
+					for (int k = 0; k < T; ++k) s[k] = f.fc;
 				}
 				/* amplitude and combine: generator.c:384-440 */
 				float r[T];
