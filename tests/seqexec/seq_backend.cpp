@@ -15,6 +15,9 @@ using namespace sauengine;
 
 namespace {
 
+/* what the host control plane asked of the most recent segment (host-logic tests) */
+static uint32_t g_last_counts[5];
+
 struct SeqBackend : public Backend {
 	BackendConfig cfg;
 	uint32_t block;
@@ -289,6 +292,8 @@ struct SeqBackend : public Backend {
 	}
 
 	bool render(const SegmentDesc &seg, std::string &) override {
+		g_last_counts[0] = seg.n_main; g_last_counts[1] = seg.n_fast; g_last_counts[2] = seg.n_fast_full;
+		g_last_counts[3] = seg.may_scan ? 1u : 0u; g_last_counts[4] = seg.serial ? 1u : 0u;
 		std::vector<std::vector<float>> vout(seg.n_voices), pan(seg.n_voices);
 		std::vector<float> pan_const(seg.n_voices, 0.f);
 		for (uint32_t v = 0; v < seg.n_voices; ++v) {
@@ -327,6 +332,10 @@ struct SeqBackend : public Backend {
 };
 
 } /* namespace */
+
+extern "C" __attribute__((visibility("default"))) void seq_backend_last_counts(uint32_t *out5) {
+	for (int i = 0; i < 5; ++i) out5[i] = g_last_counts[i];
+}
 
 extern "C" __attribute__((visibility("default"))) void *seq_backend_create(uint32_t block_len) {
 	return new SeqBackend(block_len ? block_len : 1024);

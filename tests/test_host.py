@@ -115,3 +115,31 @@ def test_voicebank_builder_equals_parser_images(sa):
     for ln in ("pan", "amp", "freq"):
         la, lb = getattr(oa, ln).contents, getattr(ob, ln).contents
         assert (la.v0, la.vt, la.time_ms, la.type, la.flags) == (lb.v0, lb.vt, lb.time_ms, lb.type, lb.flags)
+
+
+def test_block_buffer_numbering(sa, seqexec):
+    """Host side of the time-parallel path: block buffers renumbered by liveness when a plan is
+    compiled (fast_slot_compact). A depth-3 PM chain needs one buffer where the block loop's plan
+    names five; frequency blocks are only counted for voices that may have running-sum phases."""
+    import ctypes as C
+    from saugns_amd import voicebank as vb
+    from saugns_amd.api import POP_FMOD, POP_PMOD
+
+    def counts(voices):
+        prg = vb.build_program(voices)
+        b = sa.Batch([prg], 44100, backend=seqexec.seq_backend_create(256))
+        b.run(512, stereo=False, fetch=False)
+        out = (C.c_uint32 * 5)()
+        seqexec.seq_backend_last_counts(out)
+        return dict(zip(("n_main", "n_fast", "n_fast_full", "may_scan", "serial"), list(out)))
+
+    m3 = vb.Op("sin", freq=vb.Line(3.0, ratio=True), amp=0.4)
+    m2 = vb.Op("sin", freq=vb.Line(2.0, ratio=True), amp=0.7, mods={POP_PMOD: [m3]})
+    m1 = vb.Op("sin", freq=vb.Line(1.0, ratio=True), amp=0.5, mods={POP_PMOD: [m2]})
+    c = counts([vb.Op("sin", freq=110.0, time_ms=100, mods={POP_PMOD: [m1]})])
+    assert c["n_main"] == 5 and c["n_fast"] == 1 and not c["may_scan"] and not c["serial"]
+    fm = vb.Op("sin", freq=vb.Line(2.0, ratio=True), amp=30.0)
+    c = counts([vb.Op("sin", freq=220.0, time_ms=100, mods={POP_FMOD: [fm]})])
+    assert c["may_scan"] and c["n_fast_full"] >= 1 and c["n_fast_full"] >= c["n_fast"]
+    c = counts([vb.Op("sin", freq=220.0, pm_a=0.5, time_ms=100)])
+    assert c["serial"]
