@@ -1500,6 +1500,9 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 		if (zero_fill) { /* becomes a constant line step */
 			f.kind = (uint32_t)ST_LINE | ((uint32_t)L_AMP << 16) | (dep << 24);
 			f.ac = 0.f;
+			/* every sum pass runs it: whatever reads its buffer there must find the zeros (the
+			 * backward data-flow below does not look inside subtrees that are out of time) */
+			f.ramp = (4u << FAST_MAX_LEVELS) - 4u;
 		} else {
 			const bool line_step = st.kind == ST_LINE;
 			const bool amp_inline = st.kind == ST_OSC && st.amp == NO_SLOT;

@@ -190,3 +190,47 @@ def test_running_sum_phases_across_runs(sa, oracle, chunk):
                             vb.Op("sin", freq=vb.Line(300.0, goal=100.0, shape="lin"), time_ms=200,
                                   mods={POP_FPMOD: [vb.Op("sin", freq=vb.Line(2.0, ratio=True), amp=1.5)]})],
                chunk, stereo=True)
+
+
+def _random_voice(rng, depth=0):
+    """A random operator tree: every modulator list kind, ramps on any line, ratio and absolute
+    frequencies, operators shorter than their carrier, now and then self-modulation."""
+    lists = [POP_PMOD, POP_FMOD, POP_AMOD, POP_RAMOD, POP_RFMOD, POP_FPMOD]
+    shape = lambda: LINES[int(rng.integers(len(LINES)))]
+    if depth == 0:
+        f = float(rng.uniform(60, 900))
+        freq = vb.Line(f, goal=float(rng.uniform(60, 900)), shape=shape()) if rng.random() < 0.3 else f
+    else:
+        r = float(rng.choice([0.25, 0.5, 1.0, 1.5, 2.0, 3.0]))
+        if rng.random() < 0.6:
+            freq = vb.Line(r, goal=r * float(rng.uniform(0.5, 2)), shape=shape(), ratio=True) \
+                if rng.random() < 0.2 else vb.Line(r, ratio=True)
+        else:
+            freq = float(rng.uniform(0.5, 400))
+    a0 = float(rng.uniform(0.1, 1.0)) * (40.0 if rng.random() < 0.15 else 1.0)
+    amp = vb.Line(a0, goal=float(rng.uniform(0, 1)), shape=shape()) if rng.random() < 0.3 else a0
+    mods = {}
+    if depth < 3:
+        for use in lists:
+            if rng.random() < (0.35 if depth == 0 else 0.2):
+                mods[use] = [_random_voice(rng, depth + 1) for _ in range(int(rng.integers(1, 3)))]
+    kw = {}
+    if POP_RAMOD in mods:
+        kw["amp2"] = float(rng.uniform(0, 1))
+    if POP_RFMOD in mods:
+        kw["freq2"] = float(rng.uniform(60, 900)) if depth == 0 else vb.Line(float(rng.uniform(0.5, 3)), ratio=True)
+    if rng.random() < 0.08:
+        kw["pm_a"] = float(rng.uniform(0.1, 0.9))
+    time_ms = int(rng.integers(40, 160)) if depth == 0 else (int(rng.integers(10, 120)) if rng.random() < 0.2 else None)
+    return vb.Op(WAVES[int(rng.integers(len(WAVES)))], freq=freq, amp=amp, time_ms=time_ms,
+                 phase=float(rng.uniform(0, 1)), mods=mods, **kw)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_operator_graphs(sa, oracle, seed):
+    """Random graphs through whichever kernels they land in (closed form, running sums in one,
+    two or three passes or in order, block loop), in one engine run and cut into several."""
+    rng = np.random.default_rng(1000 + seed)
+    voices = [_random_voice(rng) for _ in range(int(rng.integers(1, 4)))]
+    check(sa, oracle, voices, stereo=bool(seed & 1))
+    check_runs(sa, oracle, voices, chunk=int(rng.integers(700, 3000)), stereo=bool(seed & 1))
