@@ -1092,6 +1092,15 @@ __device__ __forceinline__ uint32_t block_owner(const Step *plan, uint32_t si, u
 	return 0xff;
 }
 
+/* does voice-local operator `op` take frequency-scaled phase modulation? */
+__device__ __forceinline__ bool op_has_fpm(const Step *plan, uint32_t n, uint32_t op) {
+	for (uint32_t q = 0; q < n; ++q) {
+		const Step sq = plan[q];
+		if (sq.kind == ST_OSC && sq.op == op) return sq.fpm != NO_SLOT;
+	}
+	return false;
+}
+
 __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 	const uint32_t v = blockIdx.x * 64 + threadIdx.x;
 	if (v == 0) *P.work_count = 0; /* finalize_kernel (a later launch) builds the block loop's work list */
@@ -1138,6 +1147,7 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 		if (o.line[L_PMA].v0 != 0.f) bad = true; /* self-modulation is a recurrence */
 		o.rt_fconst_valid = 0;
 		o.rt_fblk_valid = 0;
+		o.st_phase = 0; /* until the kernels stage into it: see "modulated blocks" below */
 		if (!(o.flags & OPF_TIME_INF) && o.time < min_time) min_time = o.time;
 	}
 	uint32_t depth = 0, maxd = 0;
@@ -1170,10 +1180,21 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 				pconst = po.rt_fconst_valid != 0; pf = po.rt_fconst;
 			}
 		}
-		/* anything added into a frequency block makes it per-frame */
+		/* Anything added into a frequency block makes it per-frame: a modulated block. Its
+		 * contents are exact only from the lane its writers are (nesting depth wd: lane
+		 * H - wd + 1). Whoever multiplies by it -- ratio lines of operators nested in its
+		 * owner, directly or through blocks derived from it -- must not need it earlier:
+		 * a reader at depth d sums increments from lane H - d + 1 on (one earlier when it
+		 * scales a phase modulator by its frequency). Deeper readers: block loop.
+		 * (st_phase holds wd while this kernel runs; 0: not a modulated block.) */
 		if ((st.kind == ST_OSC || st.kind == ST_LERP) && st.out != NO_SLOT && st.out >= FSLOT_BASE) {
 			const uint32_t ow = block_owner(plan, si, st.out);
-			if (ow != 0xff) P.ops[ids[ow]].rt_fblk_valid = 0;
+			if (ow != 0xff) {
+				DevOp &oo = P.ops[ids[ow]];
+				oo.rt_fblk_valid = 0;
+				const uint32_t wd = st.kind == ST_OSC ? depth : depth + 1;
+				if (oo.st_phase == 0 || wd < oo.st_phase) oo.st_phase = wd;
+			}
 		}
 		if (st.kind == ST_LINE || freq_here) {
 			const LineState &ls = o.line[st.kind == ST_LINE ? st.which : L_FREQ];
@@ -1182,7 +1203,19 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 				/* a ramp whose goal and state disagree about being ratios rescales its
 				 * state by the parent's first sample (sau/line.c:358-370): block loop */
 				if ((ls.flags & LP_GOAL) && g_ratio != s_ratio) bad = true;
-				if ((s_ratio || ((ls.flags & LP_GOAL) && g_ratio)) && !pconst) seq = true;
+				if ((s_ratio || ((ls.flags & LP_GOAL) && g_ratio)) && !pconst) {
+					seq = true;
+					if (st.fmul >= FSLOT_BASE) {
+						const uint32_t ow = block_owner(plan, si, st.fmul);
+						const uint32_t wd = ow != 0xff ? P.ops[ids[ow]].st_phase : 0u;
+						if (wd) {
+							if (depth + (op_has_fpm(plan, vd.plan_len, st.op) ? 1u : 0u) > wd) bad = true;
+							/* this operator's own block derives from the modulated one */
+							if (st.kind == ST_LINE && st.which == L_FREQ && (o.st_phase == 0 || wd < o.st_phase))
+								o.st_phase = wd;
+						}
+					}
+				}
 			}
 		}
 		if (freq_here && !bad) {

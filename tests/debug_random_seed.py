@@ -28,3 +28,12 @@ for ck in ([chunk_override] if chunk_override else [4000000, chunk]):
     got = sa.Batch([prg], 44100).render(stereo=stereo, chunk=ck)[0]
     d = np.nonzero(got != want)[0]
     print("chunk", ck, "frames", len(want) // (2 if stereo else 1), "diffs", len(d), "first", d[:4], "max", int(np.abs(got.astype(int) - want.astype(int)).max()) if len(d) else 0)
+if len(d):
+    print("diff frames:", sorted(set((d // (2 if stereo else 1)).tolist()))[:40])
+    # which voice? render each voice alone
+    for vi, v in enumerate(voices):
+        p1 = vb.build_program([v])
+        w1 = po.oracle_render(p1.ptr, 44100, stereo)
+        g1 = sa.Batch([p1], 44100).render(stereo=stereo, chunk=ck)[0]
+        dd = np.nonzero(g1 != w1)[0]
+        print(" voice", vi, "alone: diffs", len(dd), sorted(set((dd // (2 if stereo else 1)).tolist()))[:12])

@@ -1,0 +1,25 @@
+"""Debug aid: many seeds of the random operator-graph parity check (prints the failing ones)."""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import saugns_amd as sa
+from saugns_amd import voicebank as vb
+from oracle import pyoracle as po
+import test_gpu_units as tu
+tabs = np.fromfile(os.path.join(ROOT, "tests/golden/piluts_ref.f32"), dtype="<f4").reshape(12, 2048)
+sa.set_piluts(tabs); po.oracle_use_tables(tabs); po.oracle().ora_set_fastmath_forms(1)
+lo, hi = int(sys.argv[1]), int(sys.argv[2])
+bad = []
+for seed in range(lo, hi):
+    rng = np.random.default_rng(1000 + seed)
+    voices = [tu._random_voice(rng) for _ in range(int(rng.integers(1, 4)))]
+    chunk = int(rng.integers(700, 3000))
+    stereo = bool(seed & 1)
+    prg = vb.build_program(voices)
+    want = po.oracle_render(prg.ptr, 44100, stereo)
+    for ck in (4000000, chunk):
+        got = sa.Batch([prg], 44100).render(stereo=stereo, chunk=ck)[0]
+        if len(got) != len(want) or (got != want).any():
+            bad.append((seed, ck)); print("FAIL seed", seed, "chunk", ck, flush=True)
+print("checked", hi - lo, "seeds;", len(bad), "failures", bad)

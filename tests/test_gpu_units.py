@@ -226,7 +226,7 @@ def _random_voice(rng, depth=0):
                  phase=float(rng.uniform(0, 1)), mods=mods, **kw)
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(64))
 def test_random_operator_graphs(sa, oracle, seed):
     """Random graphs through whichever kernels they land in (closed form, running sums in one,
     two or three passes or in order, block loop), in one engine run and cut into several."""
