@@ -38,7 +38,11 @@ class Op:
     """One operator of a voice tree (only what configs 1-5 style banks need)."""
 
     def __init__(self, wave="sin", freq=None, amp=1.0, time_ms=None, phase=0.0,
-                 amp2=None, freq2=None, pm_a=None, mods=None, op_type=POPT_WAVE):
+                 amp2=None, freq2=None, pm_a=None, mods=None, op_type=POPT_WAVE,
+                 ras=None, noise=0, seed=0):
+        """W operator by default. op_type=POPT_RASEG: ``ras`` = (line shape name, function id,
+        function flags) as sauRasOpt (sau/program.h:126-163); op_type=POPT_NOISE: ``noise`` = id."""
+        self.ras, self.noise, self.seed = ras, noise, seed
         self.wave = wave
         self.freq = freq if isinstance(freq, Line) or freq is None else Line(freq)
         self.amp = amp if isinstance(amp, Line) else Line(amp)
@@ -120,12 +124,19 @@ def build_program(voices, ampmult=1.0, default_mod_ms=1000):
             p = _mk_line(keep, ln, t_ms, rp)
             if p: setattr(od, name, p)
         od.phase = cyclepos(op.phase)
-        od.seed = 0
+        od.seed = op.seed
         od.use_type = use
         od.type = op.op_type
         od.mode.ras.word = 0
         od.mode.ras.alpha = 0
-        od.mode.main = WAVES.index(op.wave)
+        if op.op_type == api.POPT_RASEG:
+            line, func, flags = op.ras
+            # line | flags << 8 | func << 18 | level << 24, with the "set" bits of what is given
+            od.mode.ras.word = LINES.index(line) | ((flags & 0x3f) | (1 << 6) | (1 << 7)) << 8 | (func & 0x3f) << 18
+        elif op.op_type == api.POPT_NOISE:
+            od.mode.main = op.noise
+        else:
+            od.mode.main = WAVES.index(op.wave)
         for u, lst in op.mods.items():
             arr = (C.c_uint32 * (1 + len(lst)))(len(lst), *[m._id for m in lst])
             keep.append(arr)

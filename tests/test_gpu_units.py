@@ -5,7 +5,7 @@ import pytest
 from conftest import max_diff
 from saugns_amd import voicebank as vb
 from saugns_amd.api import (LINES, POP_AMOD, POP_APMOD, POP_FMOD, POP_FPMOD, POP_PMOD,
-                            POP_RAMOD, POP_RFMOD, WAVES)
+                            POP_RAMOD, POP_RFMOD, POPT_NOISE, POPT_RASEG, WAVES)
 
 pytestmark = pytest.mark.gpu
 RATE = 44100
@@ -222,6 +222,14 @@ def _random_voice(rng, depth=0):
     if rng.random() < 0.08:
         kw["pm_a"] = float(rng.uniform(0.1, 0.9))
     time_ms = int(rng.integers(40, 160)) if depth == 0 else (int(rng.integers(10, 120)) if rng.random() < 0.2 else None)
+    kind = rng.random()
+    if kind < 0.15 and "pm_a" not in kw:  # R oscillator: random line shape, function and function flags
+        kw.update(op_type=POPT_RASEG, seed=int(rng.integers(1 << 32)),
+                  ras=(LINES[int(rng.integers(len(LINES)))], int(rng.integers(6)), int(rng.integers(32))))
+    elif kind < 0.22 and depth > 0 and not mods:  # noise source (all but the recurrent red noise)
+        kw.pop("freq2", None)
+        return vb.Op(amp=amp, time_ms=time_ms, op_type=POPT_NOISE, seed=int(rng.integers(1 << 32)),
+                     noise=int(rng.choice([0, 1, 2, 3, 5, 6])), **{k: v for k, v in kw.items() if k == "amp2"})
     return vb.Op(WAVES[int(rng.integers(len(WAVES)))], freq=freq, amp=amp, time_ms=time_ms,
                  phase=float(rng.uniform(0, 1)), mods=mods, **kw)
 

@@ -112,3 +112,26 @@ def test_against_live_reference_when_present(oracle, sa, index):
         a = oracle.ref_render(prg.ptr, 12000, True)
         b = oracle.oracle_render(prg.ptr, 12000, True)
         assert max_diff(a, b) == 0, key
+
+
+def test_r_oscillator_options_vs_reference(oracle):
+    """Every line shape x segment function of the R oscillator, with a spread of function flag
+    combinations, on programs the parser-free builder makes: the restatement stays within 1 LSB of
+    the compiled reference (the differences are the fast-math forms of a few perlin maps)."""
+    if not oracle.have_ref():
+        pytest.skip("compiled reference not present")
+    from saugns_amd import voicebank as vb
+    from saugns_amd.api import LINES, POPT_RASEG
+    oracle.oracle().ora_set_fastmath_forms(2)
+    worst = 0
+    for line in LINES:
+        for func in range(6):
+            for flags in (0, 1, 2, 4, 8, 16, 9, 25, 31):
+                v = vb.Op(freq=233.0, amp=0.8, time_ms=20, op_type=POPT_RASEG, seed=12345,
+                          ras=(line, func, flags))
+                prg = vb.build_program([v])
+                a = oracle.oracle_render(prg.ptr, 44100, False)
+                b = oracle.ref_render(prg.ptr, 44100, False)
+                assert len(a) == len(b)
+                worst = max(worst, int(np.abs(a.astype(np.int32) - b.astype(np.int32)).max()))
+    assert worst <= 1
