@@ -1141,7 +1141,9 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 		for (uint32_t ln = 0; ln < L_COUNT; ++ln) {
 			if (!(o.line[ln].flags & LP_GOAL)) continue;
 			if (ln == L_FREQ || ln == L_FREQ2) seq = true; /* phase becomes a running sum */
-			else if (ln != L_AMP && ln != L_AMP2) bad = true;
+			else if (ln == L_PAN) { /* fine when the plan gives the pan line a step of its own */
+				if (!(vd.plan_len && plan[vd.plan_len - 1].kind == ST_VOICE)) bad = true;
+			} else if (ln != L_AMP && ln != L_AMP2) bad = true;
 		}
 		if (o.type == OT_NOISE && o.wave == NZ_re) bad = true;
 		if (o.line[L_PMA].v0 != 0.f) bad = true; /* self-modulation is a recurrence */

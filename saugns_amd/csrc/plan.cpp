@@ -221,11 +221,14 @@ bool compile_voice_plan(const std::vector<OpMirror> &ops, uint32_t carrier,
 	uint8_t F = c.eval(carrier, V, NO_SLOT, NO_SLOT, false, false, out.has_camods);
 	const uint8_t cprov = out.carr_local < 255 ? (uint8_t)out.carr_local : NO_SLOT;
 	uint8_t Pn = NO_SLOT;
-	if (out.has_camods) { /* generator.c:756-771 */
+	/* a pan ramp pending when the plan is made also gets its own line step, so that the
+	 * time-parallel path sees it as one more ramp (any event recompiles the voice's plan) */
+	const bool pan_ramp = (cm.pan.flags & LP_GOAL) != 0;
+	if (out.has_camods || pan_ramp) { /* generator.c:756-771 */
 		Pn = c.alloc();
 		Step &pl = c.emit(ST_LINE, out.carr_local);
 		pl.which = L_PAN; pl.out = Pn; pl.tmp = L_PAN; pl.flags |= SF_FORCE;
-		c.children(camods, Pn, F, F != NO_SLOT ? cprov : NO_SLOT, false, true);
+		if (out.has_camods) c.children(camods, Pn, F, F != NO_SLOT ? cprov : NO_SLOT, false, true);
 		Step &v = c.emit(ST_VOICE, out.carr_local);
 		v.out = V; v.pm = Pn;
 	} else {

@@ -39,10 +39,11 @@ class Op:
 
     def __init__(self, wave="sin", freq=None, amp=1.0, time_ms=None, phase=0.0,
                  amp2=None, freq2=None, pm_a=None, mods=None, op_type=POPT_WAVE,
-                 ras=None, noise=0, seed=0):
+                 ras=None, noise=0, seed=0, pan=None):
         """W operator by default. op_type=POPT_RASEG: ``ras`` = (line shape name, function id,
         function flags) as sauRasOpt (sau/program.h:126-163); op_type=POPT_NOISE: ``noise`` = id."""
         self.ras, self.noise, self.seed = ras, noise, seed
+        self.pan = pan if isinstance(pan, Line) or pan is None else Line(pan)  # carriers only
         self.wave = wave
         self.freq = freq if isinstance(freq, Line) or freq is None else Line(freq)
         self.amp = amp if isinstance(amp, Line) else Line(amp)
@@ -116,7 +117,7 @@ def build_program(voices, ampmult=1.0, default_mod_ms=1000):
         od.time.v_ms = t_ms
         od.time.flags = TIMEP_SET if op.time_ms is not None else \
             (TIMEP_SET | TIMEP_DEFAULT | TIMEP_IMPLICIT)
-        p = _mk_line(keep, Line(0.0) if carrier else None, t_ms)
+        p = _mk_line(keep, (op.pan or Line(0.0)) if carrier else None, t_ms)
         if p: od.pan = p
         for name, ln, rp in (("amp", op.amp, False), ("amp2", op.amp2, True),
                              ("freq", op.freq, False), ("freq2", op.freq2, True),

@@ -222,6 +222,9 @@ def _random_voice(rng, depth=0):
     if rng.random() < 0.08:
         kw["pm_a"] = float(rng.uniform(0.1, 0.9))
     time_ms = int(rng.integers(40, 160)) if depth == 0 else (int(rng.integers(10, 120)) if rng.random() < 0.2 else None)
+    if depth == 0 and rng.random() < 0.35:  # carrier pan, held or ramped
+        p0 = float(rng.uniform(-1, 1))
+        kw["pan"] = vb.Line(p0, goal=float(rng.uniform(-1, 1)), shape=shape()) if rng.random() < 0.6 else p0
     kind = rng.random()
     if kind < 0.15 and "pm_a" not in kw:  # R oscillator: random line shape, function and function flags
         kw.update(op_type=POPT_RASEG, seed=int(rng.integers(1 << 32)),
