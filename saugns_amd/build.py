@@ -42,6 +42,19 @@ def build_variant(name, defines):
 def build(force=False, verbose=False):
     if not force and not _stale():
         return LIB
+    # several ranks of one node may get here at once: one builds, the others wait and re-check
+    import fcntl
+    with open(os.path.join(HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():
+                return LIB
+            return _build(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build(verbose):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     for src in SOURCES:
