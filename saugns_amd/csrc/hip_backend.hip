@@ -2587,6 +2587,8 @@ public:
 			if (16 * team_size(1, 2) + need_tab <= lds_limit_) { W = 1; T = 2; V = 16; }
 			else if (16 * team_size(1, 1) + need_tab <= lds_limit_) { W = 1; T = 1; V = 16; }
 		}
+		/* a voice with very many block buffers: one wave, one frame per lane (256 B per buffer) */
+		if (V == 1 && team_size(W, T) > lds_limit_) { W = 1; T = 1; }
 		/* LDS budget: slots + operator cache + misc per team, rest for tables */
 		const size_t team_bytes = team_size(W, T);
 		size_t fixed = team_bytes * V;
@@ -2815,6 +2817,7 @@ public:
 		if (tp) (void)hipEventRecord(tp->a, stream_);
 		bool ok = V > 1 ? (T == 2 ? launch_render<1, 2, 16>(rp, block_grid_, lds, err)
 		                          : launch_render<1, 1, 16>(rp, block_grid_, lds, err))
+		        : (W == 1) ? launch_render<1, 1, 1>(rp, block_grid_, lds, err)
 		        : geo_ ? launch_render<4, 4, 1>(rp, block_grid_, lds, err)
 		               : launch_render<8, 2, 1>(rp, block_grid_, lds, err);
 		if (!ok) return false;

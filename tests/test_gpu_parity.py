@@ -151,3 +151,19 @@ def test_config4_full_checksums(gpu, index):
         ref = index["configs"][f"config4_seed{k}"]
         assert len(pcm) == ref["frames"]
         assert hashlib.sha256(pcm.tobytes()).hexdigest() == ref["sha256"]
+
+
+@pytest.mark.parametrize("env", [{"SAU_AMD_LDS_LIMIT": "40000"},
+                                 {"SAU_AMD_LDS_LIMIT": "30000", "SAU_AMD_NO_FAST": "1"},
+                                 {"SAU_AMD_FAST_ROWS": "2", "SAU_AMD_NO_TWO_PASS": "1"}])
+def test_corpus_under_tight_lds_and_alternative_builds(gpu, env):
+    """Every corpus script with little LDS (wave tables read from HBM, the one-wave one-frame-per-lane
+    block-loop geometry for voices with many block buffers) and with the smaller builds of the
+    time-parallel kernel: bit-exact vs the oracle."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_corpus_check.py")],
+                         env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.startswith("0 bad of"), out.stdout[-2000:]
