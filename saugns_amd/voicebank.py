@@ -89,10 +89,15 @@ def _mk_line(keep, ln, time_ms, is_r_par=False):
     return C.pointer(s)
 
 
-def build_program(voices, ampmult=1.0, default_mod_ms=1000):
-    """voices: list of carrier Ops (each with .time_ms) -> BuiltProgram."""
+def build_program(voices, ampmult=1.0, default_mod_ms=1000, updates=()):
+    """voices: list of carrier Ops (each with .time_ms) -> BuiltProgram.
+
+    updates: later events in the shape the parser gives compound steps (``Wsin f200 t1; f300[g400]``):
+    tuples (at_ms, voice index, Op of that voice's tree, {"freq"|"amp"|"amp2"|"freq2"|"pan": Line,
+    "time_ms": int}); lines with ``state=False`` only set a goal."""
     keep = []
-    events = (SauEvent * len(voices))()
+    updates = sorted(updates, key=lambda u: u[0])
+    events = (SauEvent * (len(voices) + len(updates)))()
     next_id = [0]
     depth_max = [0]
     dur = 0
@@ -160,9 +165,49 @@ def build_program(voices, ampmult=1.0, default_mod_ms=1000):
         ev.op_list = None
         ev.op_data = arr
         dur = max(dur, carr.time_ms)
+    use_of = {}
+
+    def note_uses(op, use):
+        use_of[id(op)] = use
+        for u, lst in op.mods.items():
+            for m in lst:
+                note_uses(m, u)
+
+    for carr in voices:
+        note_uses(carr, POP_CARR)
+    now = 0
+    for k, (at_ms, vi, op, what) in enumerate(updates):
+        od = SauOpData()
+        od.id = op._id
+        od.params = 0
+        t_ms = what.get("time_ms")
+        if t_ms is not None:
+            od.params |= 1  # SAU_POPP_TIME
+            od.time.v_ms = t_ms
+            od.time.flags = TIMEP_SET
+        line_ms = t_ms if t_ms is not None else (op.time_ms if op.time_ms is not None else default_mod_ms)
+        for name, rp in (("amp", False), ("amp2", True), ("freq", False), ("freq2", True), ("pan", False)):
+            if name in what:
+                p = _mk_line(keep, what[name], line_ms, rp)
+                setattr(od, name, p)
+        od.use_type = use_of[id(op)]
+        od.type = op.op_type
+        arr = (SauOpData * 1)(od)
+        keep.append(arr)
+        ev = events[len(voices) + k]
+        ev.wait_ms = at_ms - now
+        now = at_ms
+        ev.vo_id = vi
+        ev.carr_op_id = voices[vi]._id
+        ev.op_count = 0
+        ev.op_data_count = 1
+        ev.op_list = None
+        ev.op_data = arr
+        if t_ms is not None and op is voices[vi]:
+            dur = max(dur, at_ms + t_ms)
     prg = SauProgram()
     prg.events = events
-    prg.ev_count = len(voices)
+    prg.ev_count = len(voices) + len(updates)
     prg.mode = api.PMODE_AMP_DIV_VOICES
     prg.vo_count = len(voices)
     prg.op_count = next_id[0]

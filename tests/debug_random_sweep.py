@@ -10,13 +10,15 @@ import test_gpu_units as tu
 tabs = np.fromfile(os.path.join(ROOT, "tests/golden/piluts_ref.f32"), dtype="<f4").reshape(12, 2048)
 sa.set_piluts(tabs); po.oracle_use_tables(tabs); po.oracle().ora_set_fastmath_forms(1)
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
+events = len(sys.argv) > 3 and sys.argv[3] == "events"
 bad = []
 for seed in range(lo, hi):
-    rng = np.random.default_rng(1000 + seed)
+    rng = np.random.default_rng((5000 if events else 1000) + seed)
     voices = [tu._random_voice(rng) for _ in range(int(rng.integers(1, 4)))]
+    ups = tu._random_updates(rng, voices) if events else ()
     chunk = int(rng.integers(700, 3000))
     stereo = bool(seed & 1)
-    prg = vb.build_program(voices)
+    prg = vb.build_program(voices, updates=ups)
     want = po.oracle_render(prg.ptr, 44100, stereo)
     for ck in (4000000, chunk):
         got = sa.Batch([prg], 44100).render(stereo=stereo, chunk=ck)[0]

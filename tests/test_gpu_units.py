@@ -237,6 +237,70 @@ def _random_voice(rng, depth=0):
                  phase=float(rng.uniform(0, 1)), mods=mods, **kw)
 
 
+def _random_updates(rng, voices):
+    """Later events on random operators of random voices: new values and/or new ramps for
+    amplitude, frequency or pan, and new durations for carriers (as compound steps give)."""
+    def nodes(op, acc):
+        acc.append(op)
+        for lst in op.mods.values():
+            for m in lst:
+                nodes(m, acc)
+        return acc
+    shape = lambda: LINES[int(rng.integers(len(LINES)))]
+    ups = []
+    for vi, carr in enumerate(voices):
+        t_end = carr.time_ms
+        for _ in range(int(rng.integers(0, 4))):
+            at = int(rng.integers(5, max(6, t_end - 5)))
+            ops = nodes(carr, [])
+            op = ops[int(rng.integers(len(ops)))]
+            what = {}
+            kind = rng.random()
+            has_freq = op.op_type != POPT_NOISE and op.freq is not None
+            if kind < 0.45 or not has_freq:
+                g = float(rng.uniform(0, 1))
+                what["amp"] = vb.Line(float(rng.uniform(0.1, 1)), goal=g if rng.random() < 0.7 else None,
+                                      shape=shape(), state=bool(rng.random() < 0.5) or rng.random() < 0.3)
+                if what["amp"].goal is None:
+                    what["amp"].state = True
+            elif kind < 0.85:
+                ratio = op.freq.ratio
+                v = float(rng.choice([0.5, 1.0, 2.0, 3.0])) if ratio else float(rng.uniform(50, 800))
+                g = v * float(rng.uniform(0.5, 2.0))
+                what["freq"] = vb.Line(v, goal=g if rng.random() < 0.6 else None, shape=shape(), ratio=ratio,
+                                       state=bool(rng.random() < 0.6))
+                if what["freq"].goal is None:
+                    what["freq"].state = True
+            elif op is carr:
+                what["pan"] = vb.Line(float(rng.uniform(-1, 1)), goal=float(rng.uniform(-1, 1)) if rng.random() < 0.6 else None,
+                                      shape=shape())
+            else:
+                what["amp"] = vb.Line(float(rng.uniform(0.1, 1)))
+            if op is carr and rng.random() < 0.5:
+                what["time_ms"] = int(rng.integers(10, 120))
+                t_end = at + what["time_ms"]
+            ups.append((at, vi, op, what))
+    return ups
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_graphs_with_later_events(sa, oracle, seed):
+    """Random graphs whose operators receive later events (new values, new ramps, new durations):
+    the state every kernel leaves behind must be what the next segment's kernels expect."""
+    rng = np.random.default_rng(5000 + seed)
+    voices = [_random_voice(rng) for _ in range(int(rng.integers(1, 4)))]
+    ups = _random_updates(rng, voices)
+    oracle.oracle().ora_set_fastmath_forms(1)
+    prg = vb.build_program(voices, updates=ups)
+    stereo = bool(seed & 1)
+    want = oracle.oracle_render(prg.ptr, RATE, stereo)
+    for chunk in (4000000, int(rng.integers(700, 3000))):
+        got = sa.Batch([prg], RATE).render(stereo=stereo, chunk=chunk)[0]
+        assert len(got) == len(want)
+        d = np.nonzero(got != want)[0]
+        assert len(d) == 0, f"chunk {chunk}: {len(d)} samples differ, first at {d[0]}"
+
+
 @pytest.mark.parametrize("seed", range(64))
 def test_random_operator_graphs(sa, oracle, seed):
     """Random graphs through whichever kernels they land in (closed form, running sums in one,
