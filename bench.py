@@ -93,7 +93,7 @@ def main():
                        dtype="<f4").reshape(12, 2048)
     sa.set_piluts(tabs)
 
-    seconds = max(1, (args.frames * (args.steps + args.warmup)) // 44100 + 2)
+    seconds = max(1, (args.frames * (args.steps + args.warmup + 1)) // 44100 + 2)
     prg = voicebank.config3(n=args.voices, seconds=seconds)
     batch = sa.Batch([prg], 44100)
 
@@ -121,6 +121,17 @@ def main():
 
     frames_total = args.frames * args.steps * world
     value = frames_total / dt
+    # the only exchange of the whole job is this after-the-fact reduction of
+    # {frames rendered, PCM checksum} for the scaling report (outside the timed region)
+    pcm = batch.run(args.frames, stereo=False)[0]
+    tally = [args.frames * args.steps, int(np.asarray(pcm, dtype=np.int64).sum() & 0x7FFFFFFF)]
+    mine = list(tally)
+    if world > 1:
+        t = torch.tensor(tally, device="cuda" if backend == "nccl" else "cpu", dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        tally = [int(x) for x in t.tolist()]
+    if tally[0] != frames_total or tally[1] != mine[1] * world:
+        raise SystemExit(f"rank {rank}: ranks disagree on the rendered PCM ({tally} vs {mine} x {world})")
     if rank == 0:
         n_ops = args.voices * 4
         # 8 B per operator-sample (one f32 write + one f32 read of every
@@ -152,6 +163,7 @@ def main():
                                    f"{args.frames} frames per step, per GPU",
                        "voices": args.voices, "operators": n_ops,
                        "frames_per_step": args.frames,
+                       "frames_all_ranks": tally[0], "pcm_checksum_all_ranks": tally[1],
                        "voice_samples_per_s": value * args.voices,
                        "operator_samples_per_s": value * n_ops},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",

@@ -94,6 +94,8 @@ def lib():
                                    C.POINTER(C.c_size_t)]
     L.sauAmd_create_Batch.restype = C.c_void_p
     L.sauAmd_create_Batch.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint32]
+    L.sauAmd_create_Generator_with_backend.restype = C.c_void_p
+    L.sauAmd_create_Generator_with_backend.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     L.sauAmd_create_Batch_with_backend.restype = C.c_void_p
     L.sauAmd_create_Batch_with_backend.argtypes = [C.POINTER(C.c_void_p), C.c_size_t,
                                                    C.c_uint32, C.c_void_p]
@@ -201,9 +203,12 @@ class Program:
 class Generator:
     """sau_create_Generator / sauGenerator_run / sau_destroy_Generator."""
 
-    def __init__(self, program, srate):
+    def __init__(self, program, srate, backend=None):
         self._prg = program  # borrowed by the C side: keep alive
-        self._g = lib().sau_create_Generator(program.ptr, srate)
+        if backend is None:
+            self._g = lib().sau_create_Generator(program.ptr, srate)
+        else:  # tests: an injected backend (owned by the generator from here on)
+            self._g = lib().sauAmd_create_Generator_with_backend(program.ptr, srate, backend)
         if not self._g:
             raise RuntimeError("sau_create_Generator returned NULL: " + last_error())
 

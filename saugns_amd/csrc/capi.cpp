@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -30,15 +31,20 @@ struct sauAmdBatch {
  * for 11289 frames at a time (saugns.c:589-618), and a device round trip per
  * such call would cost more than the rendering. Output does not depend on how
  * the stream is cut into calls (as in the reference), so the PCM of one larger
- * engine run is handed out piecewise. SAU_AMD_READAHEAD=<frames> sets the
- * size, 0 turns it off. */
+ * engine run is handed out piecewise, from two page-locked buffers: while the
+ * host consumes one, the device renders and copies the next run into the other.
+ * SAU_AMD_READAHEAD=<frames> sets the size of a run, 0 turns the scheme off. */
 struct sauGenerator {
 	sauAmdBatch batch;
-	std::vector<int16_t> ahead;
-	size_t ahead_frames = 176400; /* frames per engine run */
-	size_t pos = 0, len = 0;      /* unread part of `ahead`, in frames */
+	int16_t *slot[2] = {nullptr, nullptr}; /* backend->alloc_host() */
+	size_t slot_cap[2] = {0, 0};           /* int16 values */
+	size_t ahead_frames = 176400;          /* frames per engine run */
+	int cur = 0;                           /* the slot being handed out */
+	size_t pos = 0, len = 0;               /* its unread part, in frames */
+	bool queued = false;                   /* a run into slot[cur^1] has been issued */
+	size_t q_len = 0;
 	bool ahead_stereo = false;
-	bool more = true;             /* the engine has signal left after `ahead` */
+	bool more = true;                      /* the engine has signal left after everything issued */
 };
 
 /* sau/generator/noise.h:18-21 */
@@ -52,26 +58,49 @@ static bool make_batch(sauAmdBatch &b, const sauProgram *const *prgs, size_t n,
 	b.engine = nullptr;
 	b.hip = nullptr;
 	Backend *be = injected;
+	const auto t0 = std::chrono::steady_clock::now();
 	if (!be) {
 		b.hip = sauhip::create_hip_backend(err);
 		if (!b.hip) { report("generator", err); return false; }
 		be = b.hip;
 	}
+	const auto t1 = std::chrono::steady_clock::now();
 	b.engine = Engine::create(prgs, n, srate, be, err);
 	if (!b.engine) { b.hip = nullptr; report("generator", err); return false; }
+	if (getenv("SAU_AMD_DEBUG_CREATE")) {
+		const auto t2 = std::chrono::steady_clock::now();
+		fprintf(stderr, "saugns_amd: backend object %.3f ms, engine (program conversion, device state) %.3f ms\n",
+				std::chrono::duration<double, std::milli>(t1 - t0).count(),
+				std::chrono::duration<double, std::milli>(t2 - t1).count());
+	}
 	return true;
 }
 
-extern "C" sauGenerator *sau_create_Generator(const sauProgram *prg, uint32_t srate) {
+static sauGenerator *make_generator(const sauProgram *prg, uint32_t srate, Backend *injected) {
 	if (!prg) return nullptr;
 	sauGenerator *g = new sauGenerator();
-	if (!make_batch(g->batch, &prg, 1, srate, nullptr)) { delete g; return nullptr; }
+	if (!make_batch(g->batch, &prg, 1, srate, injected)) { delete g; return nullptr; }
 	if (const char *ra = getenv("SAU_AMD_READAHEAD")) g->ahead_frames = (size_t)atol(ra);
 	return g;
 }
 
+extern "C" sauGenerator *sau_create_Generator(const sauProgram *prg, uint32_t srate) {
+	return make_generator(prg, srate, nullptr);
+}
+
+/* test hook: the drop-in generator over an injected backend (tests/seqexec) */
+extern "C" SAU_AMD_API sauGenerator *sauAmd_create_Generator_with_backend(const sauProgram *prg,
+		uint32_t srate, void *backend) {
+	return make_generator(prg, srate, (Backend *)backend);
+}
+
 extern "C" void sau_destroy_Generator(sauGenerator *o) {
 	if (!o) return;
+	Backend *be = o->batch.engine->backend();
+	std::string err;
+	(void)be->sync(err); /* a queued run may still be writing into a slot */
+	be->free_host(o->slot[0]);
+	be->free_host(o->slot[1]);
 	delete o->batch.engine;
 	delete o;
 }
@@ -82,15 +111,39 @@ static bool generator_fail(sauGenerator *o, int16_t *buf, size_t buf_len, bool s
 	report("generator", err);
 	memset(buf, 0, sizeof(int16_t) * buf_len * (stereo ? 2 : 1));
 	if (out_len) *out_len = 0;
-	o->more = false; o->pos = o->len = 0;
+	o->more = false; o->pos = o->len = 0; o->queued = false;
 	return false;
+}
+
+/* Start the next engine run; its PCM lands in the slot not being handed out. */
+static bool generator_issue(sauGenerator *o, size_t frames, bool stereo, std::string &err) {
+	const int k = o->cur ^ 1;
+	const size_t ch = stereo ? 2 : 1;
+	Backend *be = o->batch.engine->backend();
+	if (o->slot_cap[k] < frames * ch) {
+		be->free_host(o->slot[k]);
+		o->slot_cap[k] = 0;
+		o->slot[k] = (int16_t *)be->alloc_host(frames * ch * sizeof(int16_t));
+		if (!o->slot[k]) { err = "out of page-locked memory"; return false; }
+		o->slot_cap[k] = frames * ch;
+	}
+	bool more = false;
+	size_t len = 0;
+	/* PCM stays on the device; the copy queues behind the mixer */
+	if (!o->batch.engine->run(nullptr, frames, stereo, &more, &len, err)) return false;
+	if (len && !be->fetch_pcm_async(0, o->slot[k], (uint32_t)len, stereo, k, err)) return false;
+	o->queued = true;
+	o->q_len = len;
+	o->more = more;
+	o->ahead_stereo = stereo;
+	return true;
 }
 
 extern "C" bool sauGenerator_run(sauGenerator *o, int16_t *buf, size_t buf_len,
 		bool stereo, size_t *out_len) {
 	std::string err;
 	const size_t ch = stereo ? 2 : 1;
-	if (o->pos == o->len && (o->ahead_frames == 0 || buf_len >= o->ahead_frames)) {
+	if (o->pos == o->len && !o->queued && (o->ahead_frames == 0 || buf_len >= o->ahead_frames)) {
 		/* nothing buffered and the call is large: render straight into the caller's buffer */
 		bool more = false;
 		size_t len = 0;
@@ -102,34 +155,37 @@ extern "C" bool sauGenerator_run(sauGenerator *o, int16_t *buf, size_t buf_len,
 		if (out_len) *out_len = len;
 		return more;
 	}
+	if ((o->pos < o->len || o->queued) && o->ahead_stereo != stereo)
+		return generator_fail(o, buf, buf_len, stereo, out_len,
+				"channel layout changed between calls while frames were buffered");
+	const size_t big = buf_len > o->ahead_frames ? buf_len : o->ahead_frames;
 	size_t filled = 0;
 	while (filled < buf_len) {
 		if (o->pos == o->len) {
-			if (!o->more) break;
-			const size_t big = buf_len > o->ahead_frames ? buf_len : o->ahead_frames;
-			o->ahead.resize(big * ch);
-			o->ahead_stereo = stereo;
-			bool more = false;
-			size_t len = 0;
-			int16_t *bufs[1] = {o->ahead.data()};
-			if (!o->batch.engine->run(bufs, big, stereo, &more, &len, err))
+			if (!o->queued) {
+				if (!o->more) break;
+				if (!generator_issue(o, big, stereo, err))
+					return generator_fail(o, buf, buf_len, stereo, out_len, err);
+			}
+			if (!o->batch.engine->backend()->wait_fetch(o->cur ^ 1, err))
 				return generator_fail(o, buf, buf_len, stereo, out_len, err);
-			o->pos = 0; o->len = len; o->more = more;
-			if (len == 0) break;
-		} else if (o->ahead_stereo != stereo) {
-			return generator_fail(o, buf, buf_len, stereo, out_len,
-					"channel layout changed between calls while frames were buffered");
+			o->cur ^= 1;
+			o->pos = 0; o->len = o->q_len; o->queued = false;
+			/* the device goes on with the run after this one while the host consumes */
+			if (o->more && !generator_issue(o, big, stereo, err))
+				return generator_fail(o, buf, buf_len, stereo, out_len, err);
+			if (o->len == 0) { if (!o->queued) break; continue; }
 		}
 		size_t n = o->len - o->pos;
 		if (n > buf_len - filled) n = buf_len - filled;
-		memcpy(buf + filled * ch, o->ahead.data() + o->pos * ch, n * ch * sizeof(int16_t));
+		memcpy(buf + filled * ch, o->slot[o->cur] + o->pos * ch, n * ch * sizeof(int16_t));
 		filled += n;
 		o->pos += n;
 	}
 	if (filled < buf_len) /* generator.c:911-914: the rest of the buffer is silence */
 		memset(buf + filled * ch, 0, (buf_len - filled) * ch * sizeof(int16_t));
 	if (out_len) *out_len = filled;
-	return o->more || o->pos < o->len;
+	return o->more || o->queued || o->pos < o->len;
 }
 
 extern "C" sauAmdBatch *sauAmd_create_Batch(const sauProgram *const *prgs, size_t n,

@@ -26,6 +26,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <map>
+#include <mutex>
+#include <string>
 #include <vector>
 
 namespace sauhip {
@@ -2411,39 +2414,161 @@ __global__ void kat_line_kernel(LineState st, uint32_t len, const float *mul, fl
 #define HIP_OK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
 	err = std::string(#call) + ": " + hipGetErrorString(e_); return false; } } while (0)
 
-template <typename T> struct DevBuf {
-	T *p = nullptr;
-	size_t cap = 0;
-	bool ensure(size_t n, std::string &err, bool keep = false) {
-		if (n <= cap) return true;
-		size_t want = n + n / 4 + 16;
-		T *q = nullptr;
-		HIP_OK(hipMalloc((void **)&q, want * sizeof(T)));
-		if (keep && p && cap) {
-			hipError_t e = hipMemcpy(q, p, cap * sizeof(T), hipMemcpyDeviceToDevice);
-			if (e != hipSuccess) { err = hipGetErrorString(e); return false; }
-		}
-		if (p) (void)hipFree(p);
-		p = q; cap = want;
+/* Device and page-locked buffers are recycled through a process-wide pool: a host that renders one
+ * script after another (saugns.c:583-621 once per script) would otherwise pay about twenty
+ * hipMalloc/hipFree pairs, each a device-wide synchronisation, per generator. Blocks are handed
+ * back only after the owning stream has drained (the destructor and grow() see to that). */
+class BufPool {
+public:
+	static BufPool &get() { static BufPool *g = new BufPool; return *g; } /* never destroyed: HIP may be gone by then */
+	static size_t bucket(size_t bytes) {
+		size_t b = 4096;
+		while (b * 2 <= bytes) b <<= 1;
+		const size_t q = b / 8; /* eight size classes per octave */
+		return (bytes + q - 1) / q * q;
+	}
+	void *take(bool pinned, size_t bytes) {
+		int dev = 0;
+		(void)hipGetDevice(&dev);
+		std::lock_guard<std::mutex> lk(mu_);
+		auto &m = pinned ? pin_ : dev_[dev & 15];
+		auto it = m.find(bytes);
+		if (it == m.end()) return nullptr;
+		void *q = it->second;
+		m.erase(it);
+		(pinned ? held_pin_ : held_dev_) -= bytes;
+		return q;
+	}
+	/* false: the pool is full, the caller frees the block */
+	bool give(bool pinned, void *q, size_t bytes) {
+		int dev = 0;
+		(void)hipGetDevice(&dev);
+		std::lock_guard<std::mutex> lk(mu_);
+		size_t &held = pinned ? held_pin_ : held_dev_;
+		if (held + bytes > (pinned ? (size_t)1 << 30 : (size_t)16 << 30)) return false;
+		(pinned ? pin_ : dev_[dev & 15]).emplace(bytes, q);
+		held += bytes;
 		return true;
 	}
-	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+private:
+	std::mutex mu_;
+	std::multimap<size_t, void *> dev_[16], pin_;
+	size_t held_dev_ = 0, held_pin_ = 0;
 };
 
-template <typename T> struct PinBuf { /* page-locked staging for async H2D */
+/* Streams too: creating one sets up a hardware queue, milliseconds on this runtime. */
+class StreamPool {
+public:
+	static StreamPool &get() { static StreamPool *g = new StreamPool; return *g; }
+	hipStream_t take(int dev) {
+		std::lock_guard<std::mutex> lk(mu_);
+		auto &v = free_[dev & 15];
+		if (v.empty()) return nullptr;
+		hipStream_t s = v.back();
+		v.pop_back();
+		return s;
+	}
+	void give(int dev, hipStream_t s) {
+		std::lock_guard<std::mutex> lk(mu_);
+		auto &v = free_[dev & 15];
+		if (v.size() < 8) v.push_back(s); else (void)hipStreamDestroy(s);
+	}
+private:
+	std::mutex mu_;
+	std::vector<hipStream_t> free_[16];
+};
+
+static void *pool_alloc(bool pinned, size_t &bytes, std::string &err) {
+	bytes = BufPool::bucket(bytes);
+	void *q = BufPool::get().take(pinned, bytes);
+	if (q) return q;
+	hipError_t e = pinned ? hipHostMalloc(&q, bytes, hipHostMallocDefault) : hipMalloc(&q, bytes);
+	if (e != hipSuccess) { err = std::string(pinned ? "hipHostMalloc: " : "hipMalloc: ") + hipGetErrorString(e); return nullptr; }
+	return q;
+}
+static void pool_free(bool pinned, void *q, size_t bytes) {
+	if (!q) return;
+	if (!BufPool::get().give(pinned, q, bytes)) { if (pinned) (void)hipHostFree(q); else (void)hipFree(q); }
+}
+
+template <typename T, bool PINNED> struct PoolBuf {
 	T *p = nullptr;
-	size_t cap = 0;
-	bool ensure(size_t n, std::string &err) {
+	size_t cap = 0, bytes = 0;
+	PoolBuf() = default;
+	PoolBuf(const PoolBuf &) = delete;
+	PoolBuf &operator=(const PoolBuf &) = delete;
+	~PoolBuf() { release(); }
+	/* growing replaces the block: the caller has drained the stream that used the old one */
+	bool ensure(size_t n, std::string &err, bool keep = false) {
 		if (n <= cap) return true;
-		size_t want = n + n / 4 + 16;
-		if (p) (void)hipHostFree(p);
-		p = nullptr; cap = 0;
-		HIP_OK(hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault));
-		cap = want;
+		size_t nbytes = (n + n / 4 + 16) * sizeof(T);
+		T *q = (T *)pool_alloc(PINNED, nbytes, err);
+		if (!q) return false;
+		if (keep && p && cap) {
+			hipError_t e = PINNED ? (memcpy(q, p, cap * sizeof(T)), hipSuccess)
+			                      : hipMemcpy(q, p, cap * sizeof(T), hipMemcpyDeviceToDevice);
+			if (e != hipSuccess) { err = hipGetErrorString(e); return false; }
+		}
+		if (p) { (void)hipDeviceSynchronize(); pool_free(PINNED, p, bytes); }
+		p = q; bytes = nbytes; cap = nbytes / sizeof(T);
 		return true;
 	}
-	void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+	void release() { pool_free(PINNED, p, bytes); p = nullptr; cap = 0; bytes = 0; }
 };
+template <typename T> using DevBuf = PoolBuf<T, false>;
+template <typename T> using PinBuf = PoolBuf<T, true>; /* page-locked staging for async copies */
+
+/* Hermite coefficient tables (sau/wave.h:127-141 evaluated per table entry) are a function of the
+ * PILUTs alone: built and uploaded once per device and table set, shared by every generator. */
+struct TableSet {
+	int dev;
+	std::vector<float> piluts;
+	WaveConst wconst[12];
+	HerpC23 *c23;
+	HerpC01 *c01;
+	WaveConst *wc;
+};
+static const TableSet *shared_tables(const float *piluts, const WaveConst *wconst, std::string &err) {
+	static std::mutex mu;
+	static std::vector<TableSet *> sets;
+	int dev = 0;
+	(void)hipGetDevice(&dev);
+	std::lock_guard<std::mutex> lk(mu);
+	for (const TableSet *t : sets)
+		if (t->dev == dev && !memcmp(t->piluts.data(), piluts, (size_t)12 * WAVE_LEN * sizeof(float)) &&
+		    !memcmp(t->wconst, wconst, sizeof t->wconst))
+			return t;
+	std::vector<HerpC23> h23((size_t)12 * WAVE_LEN);
+	std::vector<HerpC01> h01((size_t)12 * WAVE_LEN);
+	for (uint32_t wv = 0; wv < 12; ++wv)
+		for (uint32_t i = 0; i < WAVE_LEN; ++i) {
+			if (!herp_c1_scalable(piluts + (size_t)wv * WAVE_LEN, i)) {
+				err = "wave table has slopes below 2^-100: unsupported";
+				return nullptr;
+			}
+			herp_coeffs(piluts + (size_t)wv * WAVE_LEN, i,
+					h23[(size_t)wv * WAVE_LEN + i], h01[(size_t)wv * WAVE_LEN + i]);
+		}
+	TableSet *t = new TableSet;
+	t->dev = dev;
+	t->piluts.assign(piluts, piluts + (size_t)12 * WAVE_LEN);
+	memcpy(t->wconst, wconst, sizeof t->wconst);
+	t->c23 = nullptr; t->c01 = nullptr; t->wc = nullptr;
+	hipError_t e = hipMalloc((void **)&t->c23, h23.size() * sizeof(HerpC23));
+	if (e == hipSuccess) e = hipMalloc((void **)&t->c01, h01.size() * sizeof(HerpC01));
+	if (e == hipSuccess) e = hipMalloc((void **)&t->wc, 12 * sizeof(WaveConst));
+	if (e == hipSuccess) e = hipMemcpy(t->c23, h23.data(), h23.size() * sizeof(HerpC23), hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipMemcpy(t->c01, h01.data(), h01.size() * sizeof(HerpC01), hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipMemcpy(t->wc, wconst, 12 * sizeof(WaveConst), hipMemcpyHostToDevice);
+	if (e != hipSuccess) {
+		err = std::string("wave tables: ") + hipGetErrorString(e);
+		(void)hipFree(t->c23); (void)hipFree(t->c01); (void)hipFree(t->wc);
+		delete t;
+		return nullptr;
+	}
+	sets.push_back(t); /* generators keep plain pointers: sets live as long as the process (0.6 MB each) */
+	return t;
+}
 
 int device_count() {
 	int n = 0;
@@ -2454,14 +2579,12 @@ int device_count() {
 class HipBackendImpl : public HipBackend {
 public:
 	~HipBackendImpl() override {
-		ops_.release(); steps_.release(); op_ids_.release(); voices_.release();
-		vout_.release(); pan_.release(); vinfo_.release(); pcm_.release();
-		recs_.release(); mstreams_.release(); c23_.release(); c01_.release(); wc_.release();
-		finfo_.release(); fdone_.release(); worklist_.release(); work_count_.release();
-		h_voices_.release(); h_ms_.release();
+		/* the buffers go back to the pool (member destructors): nothing may still be using them */
+		if (stream_) (void)hipStreamSynchronize(stream_);
 		if (copy_done_) (void)hipEventDestroy(copy_done_);
+		for (int i = 0; i < 2; ++i) if (fetch_ev_[i]) (void)hipEventDestroy(fetch_ev_[i]);
 		for (auto &e : events_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-		if (stream_) (void)hipStreamDestroy(stream_);
+		if (stream_) StreamPool::get().give(dev_, stream_); /* drained above */
 	}
 
 	bool init(const BackendConfig &cfg, std::string &err) override {
@@ -2470,12 +2593,22 @@ public:
 		const char *env = getenv("SAU_AMD_DEVICE");
 		if (env) dev = atoi(env);
 		HIP_OK(hipSetDevice(dev));
-		HIP_OK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+		dev_ = dev;
+		stream_ = StreamPool::get().take(dev);
+		if (!stream_) HIP_OK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
 		HIP_OK(hipEventCreateWithFlags(&copy_done_, hipEventDisableTiming));
-		hipDeviceProp_t prop;
-		HIP_OK(hipGetDeviceProperties(&prop, dev));
-		lds_limit_ = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor
-		                                                    : prop.sharedMemPerBlock;
+		static std::mutex prop_mu;
+		static size_t dev_lds[16]; /* per device: hipGetDeviceProperties costs a millisecond */
+		{
+			std::lock_guard<std::mutex> lk(prop_mu);
+			if (!dev_lds[dev & 15]) {
+				hipDeviceProp_t prop;
+				HIP_OK(hipGetDeviceProperties(&prop, dev));
+				dev_lds[dev & 15] = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor
+				                                                          : prop.sharedMemPerBlock;
+			}
+			lds_limit_ = dev_lds[dev & 15];
+		}
 		if (lds_limit_ > 160 * 1024) lds_limit_ = 160 * 1024;
 		if (const char *ll = getenv("SAU_AMD_LDS_LIMIT")) lds_limit_ = (size_t)atol(ll);
 		const char *wt = getenv("SAU_AMD_GEOMETRY"); /* "8x2" (default) or "4x4" */
@@ -2494,23 +2627,8 @@ public:
 		if (const char *mm = getenv("SAU_AMD_MULTI_MIN")) multi_min_ = (uint32_t)atol(mm);
 		if (!ops_.ensure(cfg.op_count ? cfg.op_count : 1, err)) return false;
 		HIP_OK(hipMemsetAsync(ops_.p, 0, ops_.cap * sizeof(DevOp), stream_));
-		/* Hermite coefficient tables from the PILUTs (sau/wave.h:127-141) */
-		std::vector<HerpC23> h23((size_t)12 * WAVE_LEN);
-		std::vector<HerpC01> h01((size_t)12 * WAVE_LEN);
-		for (uint32_t wv = 0; wv < 12; ++wv)
-			for (uint32_t i = 0; i < WAVE_LEN; ++i) {
-				if (!herp_c1_scalable(cfg.piluts + (size_t)wv * WAVE_LEN, i)) {
-					err = "wave table has slopes below 2^-100: unsupported";
-					return false;
-				}
-				herp_coeffs(cfg.piluts + (size_t)wv * WAVE_LEN, i,
-						h23[(size_t)wv * WAVE_LEN + i], h01[(size_t)wv * WAVE_LEN + i]);
-			}
-		if (!c23_.ensure(h23.size(), err) || !c01_.ensure(h01.size(), err) || !wc_.ensure(12, err))
-			return false;
-		HIP_OK(hipMemcpy(c23_.p, h23.data(), h23.size() * sizeof(HerpC23), hipMemcpyHostToDevice));
-		HIP_OK(hipMemcpy(c01_.p, h01.data(), h01.size() * sizeof(HerpC01), hipMemcpyHostToDevice));
-		HIP_OK(hipMemcpy(wc_.p, cfg.wconst, 12 * sizeof(WaveConst), hipMemcpyHostToDevice));
+		tables_ = shared_tables(cfg.piluts, cfg.wconst, err);
+		if (!tables_) return false;
 		memcpy(wconst_, cfg.wconst, sizeof wconst_);
 		return true;
 	}
@@ -2545,7 +2663,7 @@ public:
 		if (!recs_.ensure(n, err)) return false;
 		HIP_OK(hipMemcpy(recs_.p, recs, n * sizeof(OpUpdate), hipMemcpyHostToDevice));
 		hipLaunchKernelGGL(event_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream_,
-				ops_.p, recs_.p, (uint32_t)n, wc_.p);
+				ops_.p, recs_.p, (uint32_t)n, tables_->wc);
 		HIP_OK(hipGetLastError());
 		return true;
 	}
@@ -2665,7 +2783,7 @@ public:
 		}
 		rp.voices = voices_.p; rp.steps = steps_.p; rp.op_ids = op_ids_.p; rp.ops = ops_.p;
 		rp.vout = vout_.p; rp.pan = pan_.p; rp.vinfo = vinfo_.p;
-		rp.g_c23 = c23_.p; rp.g_c01 = c01_.p;
+		rp.g_c23 = tables_->c23; rp.g_c01 = tables_->c01;
 		rp.row_stride = row_stride_; rp.seg_len = seg.len;
 		rp.n_slots = seg.n_slots; rp.max_ops = seg.max_ops; rp.n_tabs = n_tabs;
 		rp.max_steps = seg.max_steps; rp.n_main = seg.n_main;
@@ -2701,7 +2819,7 @@ public:
 			fp.voices = voices_.p; fp.steps = steps_.p; fp.fast_ids = fast_ids_.p; fp.op_ids = op_ids_.p; fp.ops = ops_.p;
 			fp.vout = vout_.p; fp.pan = pan_.p; fp.info = finfo_.p; fp.fast_done = fdone_.p;
 			fp.worklist = worklist_.p; fp.work_count = work_count_.p; fp.vinfo = vinfo_.p;
-			fp.g_c23 = c23_.p; fp.g_c01 = c01_.p; fp.fsteps = (FastStep *)fsteps_.p; fp.flines = (FastLine *)flines_.p; fp.faux = (FastAux *)faux_.p;
+			fp.g_c23 = tables_->c23; fp.g_c01 = tables_->c01; fp.fsteps = (FastStep *)fsteps_.p; fp.flines = (FastLine *)flines_.p; fp.faux = (FastAux *)faux_.p;
 			fp.row_stride = row_stride_; fp.n_voices = seg.n_voices; fp.n_fast = n_fast;
 			fp.seq_enable = seq_ok ? 1u : 0u; fp.ids_full_ofs = n_steps_total_;
 			fp.scan = nullptr; fp.scan_groups = 0; fp.mode = 0;
@@ -2840,9 +2958,15 @@ public:
 	}
 
 	bool fetch_pcm(uint32_t stream, int16_t *dst, uint32_t frames, bool stereo, std::string &err) override {
-		HIP_OK(hipMemcpyAsync(dst, pcm_.p + pcm_row_ * stream,
-				(size_t)frames * (stereo ? 2 : 1) * sizeof(int16_t), hipMemcpyDeviceToHost, stream_));
+		const size_t n = (size_t)frames * (stereo ? 2 : 1);
+		/* the caller's memory is pageable: a device copy straight into it costs milliseconds of
+		 * pinning per call, so the PCM goes through a page-locked block (unless dst is one) */
+		const bool pinned = host_blocks_.count(dst) != 0;
+		if (!pinned && !h_pcm_.ensure(n, err)) return false;
+		HIP_OK(hipMemcpyAsync(pinned ? dst : h_pcm_.p, pcm_.p + pcm_row_ * stream, n * sizeof(int16_t),
+				hipMemcpyDeviceToHost, stream_));
 		HIP_OK(hipStreamSynchronize(stream_));
+		if (!pinned) memcpy(dst, h_pcm_.p, n * sizeof(int16_t));
 		return true;
 	}
 
@@ -2863,10 +2987,18 @@ public:
 		return true;
 	}
 	void *alloc_host(size_t bytes) override {
-		void *p = nullptr;
-		return hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+		std::string err;
+		void *p = pool_alloc(true, bytes, err);
+		if (p) host_blocks_[p] = bytes;
+		return p;
 	}
-	void free_host(void *p) override { if (p) (void)hipHostFree(p); }
+	void free_host(void *p) override {
+		auto it = host_blocks_.find(p);
+		if (it == host_blocks_.end()) return;
+		(void)hipStreamSynchronize(stream_);
+		pool_free(true, p, it->second);
+		host_blocks_.erase(it);
+	}
 
 	const int16_t *device_pcm(uint32_t stream) override { return pcm_.p ? pcm_.p + pcm_row_ * stream : nullptr; }
 
@@ -2985,11 +3117,10 @@ private:
 	DevBuf<int16_t> pcm_;
 	DevBuf<OpUpdate> recs_;
 	DevBuf<MixStream> mstreams_;
-	DevBuf<HerpC23> c23_;
-	DevBuf<HerpC01> c01_;
-	DevBuf<WaveConst> wc_;
+	const TableSet *tables_ = nullptr;
 	PinBuf<VoiceDesc> h_voices_;
 	PinBuf<MixStream> h_ms_;
+	PinBuf<int16_t> h_pcm_; /* fetch_pcm() staging */
 	std::vector<VoiceDesc> voices_sent_;   /* what the device copies hold */
 	std::vector<MixStream> ms_sent_, ms_host_;
 	const void *voices_dev_ = nullptr, *ms_dev_ = nullptr;
@@ -3008,6 +3139,8 @@ private:
 	DevBuf<unsigned long long> scan_;
 	DevBuf<uint32_t> pass_flags_;
 	hipEvent_t fetch_ev_[2] = {nullptr, nullptr};
+	int dev_ = 0;
+	std::map<void *, size_t> host_blocks_; /* alloc_host() blocks and their pool sizes */
 	uint32_t multi_min_ = 256;
 	uint32_t fast_rows_ = 8;
 	bool seq_enabled_ = true, two_pass_enabled_ = true;

@@ -90,6 +90,41 @@ def test_run_return_values_match_reference_semantics(sa, oracle, seqexec):
     lib.ora_destroy(g)
 
 
+@pytest.mark.parametrize("readahead", ["", "0", "3000", "20000"])
+def test_dropin_generator_call_sizes(sa, oracle, seqexec, readahead, monkeypatch):
+    """sauGenerator_run hands the PCM of larger engine runs out piecewise from two buffers:
+    (more, out_len) and the samples of every call equal the reference generator's
+    (generator.c:905-973), whatever the call size and the size of a run."""
+    if readahead:
+        monkeypatch.setenv("SAU_AMD_READAHEAD", readahead)
+    oracle.oracle().ora_set_fastmath_forms(1)
+    lib = oracle.oracle()
+    for key, stereo, call in (("devtests__voice-reuse", False, 3001), ("examples__tests__scales", True, 11289),
+                              ("examples__dull_seq-fm_pm", False, 25000), ("devtests__voice-reuse", True, 1)):
+        prg = load_program(sa, key)
+        ch = 2 if stereo else 1
+        o = lib.ora_create(prg.ptr, 12000)
+        g = sa.Generator(prg, 12000, backend=seqexec.seq_backend_create(1016))
+        want = np.zeros(call * ch, np.int16)
+        got = np.full(call * ch, 77, np.int16)
+        n = C.c_size_t()
+        for i in range(200000 if call > 1 else 5000):
+            more_o = bool(lib.ora_run(o, want.ctypes.data, call, stereo, C.byref(n)))
+            more, out_len = g.run(got, call, stereo)
+            assert (more, out_len) == (more_o, n.value), (key, i)
+            assert (got == want).all(), (key, i)
+            if not more_o:
+                break
+        else:
+            assert call == 1
+        # past the end: silence, zero frames, false -- as often as asked
+        more, out_len = g.run(got, call, stereo)
+        if call > 1:
+            assert (more, out_len) == (False, 0) and not got.any()
+        g.close()
+        lib.ora_destroy(o)
+
+
 def test_batch_streams_are_independent(sa, oracle, seqexec):
     """Programs with different event timelines in one batch == each alone."""
     oracle.oracle().ora_set_fastmath_forms(1)

@@ -53,9 +53,10 @@ if "dropin" in which:
     for chunk in (11289, 44100, 176400):
         g = sa.Generator(vb.config3(n=1024, seconds=20), 44100)
         buf = np.zeros(chunk, np.int16)
-        g.run(buf, chunk)
+        for _ in range(3):
+            g.run(buf, chunk)
         t0 = time.perf_counter(); n = 0
-        while n < 44100 * 8:
+        while n < 44100 * 12:
             more, got = g.run(buf, chunk); n += got
             if not more: break
         dt = time.perf_counter() - t0
@@ -72,6 +73,28 @@ if "file" in which:
         dt = time.perf_counter() - t0
         print(f"render_file {name}: {n} frames in {dt*1e3:.1f} ms -> {n/dt:10.3e} frames/s (create + render + copy + write)")
         os.remove(path)
+if "front" in which:
+    # what the host pays around the kernels -- generator creation (program
+    # conversion, device allocation, state upload), the first call (all t=0 events applied, plans
+    # built and uploaded) and a whole 10 s render through the drop-in API, create to destroy
+    for name, mk in (("config 3", lambda: vb.config3(n=1024, seconds=10)),
+                     ("config 5", lambda: vb.config5(n=4096, seconds=10))):
+        for rep in range(2):
+            prg = mk()
+            buf = np.zeros(176400, np.int16)
+            t0 = time.perf_counter()
+            g = sa.Generator(prg, 44100)
+            t1 = time.perf_counter()
+            more, got = g.run(buf, 11289)
+            t2 = time.perf_counter(); n = got
+            while more:
+                more, got = g.run(buf, 176400); n += got
+            t3 = time.perf_counter()
+            g.close()
+            t4 = time.perf_counter()
+            print(f"front-end {name} (pass {rep}): create {1e3*(t1-t0):.2f} ms, first call {1e3*(t2-t1):.2f} ms, "
+                  f"remaining {n-11289} frames {1e3*(t3-t2):.2f} ms, destroy {1e3*(t4-t3):.2f} ms; "
+                  f"whole job {n/(t4-t0):.3e} frames/s")
 if "c3x" in which:
     from saugns_amd.voicebank import Op, Line, build_program, _f32, _num
     from saugns_amd.api import POP_PMOD
