@@ -193,6 +193,79 @@ __device__ __forceinline__ double herp_lookup(const TabRef &t, uint32_t phase) {
 	return herp_poly(hi, lo, phase);
 }
 
+/* One wave type's tables as LDS addresses (32-bit) or global pointers. */
+template <bool LDS> struct TabAt;
+typedef const HerpC23 __attribute__((address_space(3))) *lds_c23_ptr;
+typedef const HerpC01 __attribute__((address_space(3))) *lds_c01_ptr;
+template <> struct TabAt<true> {
+	lds_c23_ptr c23; lds_c01_ptr c01;
+	__device__ __forceinline__ explicit TabAt(const TabRef &t)
+		: c23((lds_c23_ptr)t.c23), c01((lds_c01_ptr)t.c01) {}
+	__device__ __forceinline__ double lookup(uint32_t phase) const {
+		const uint32_t ind = phase >> SLEN_BITS;
+		HerpC23 hi; HerpC01 lo;
+		hi.c3 = c23[ind].c3; hi.c2 = c23[ind].c2;
+		lo.c1 = c01[ind].c1; lo.c0 = c01[ind].c0;
+		return herp_poly(hi, lo, phase);
+	}
+};
+template <> struct TabAt<false> {
+	const HerpC23 *c23; const HerpC01 *c01;
+	__device__ __forceinline__ explicit TabAt(const TabRef &t) : c23(t.c23), c01(t.c01) {}
+	__device__ __forceinline__ double lookup(uint32_t phase) const {
+		const uint32_t ind = phase >> SLEN_BITS;
+		return herp_poly(c23[ind], c01[ind], phase);
+	}
+};
+
+/* Carried state of one W oscillator in its feedback loop. */
+struct SelfmodState {
+	uint32_t prev_phase;
+	double prev_Is;
+	float prev_s, fb_s;
+};
+
+/* wosc.h:273-310 for one block, one lane: the loop carries only
+ * fb_s -> phase -> table -> sample. Base phases and self-modulation amounts
+ * were laid out in LDS by the whole wave; entry e of sample j is j + 1 plus
+ * one skipped (halo) entry per `span` samples. The next sample's inputs are
+ * fetched while the current one is computed; a repeated phase holds the
+ * previous sample (wosc.h:292-293), decided by selects, not by a branch. */
+template <bool LDS>
+__device__ __forceinline__ void selfmod_serial(const TabRef &tab, SelfmodState &st, const WaveConst &wc,
+		const float *pmaS, const u32_alias *baseS, float *outS, uint32_t len, uint32_t span) {
+	const TabAt<LDS> at(tab);
+	uint32_t prev_phase = st.prev_phase;
+	double prev_Is = st.prev_Is;
+	float prev_s = st.prev_s, fb_s = st.fb_s;
+	uint32_t e = 1, r = 0;
+	float pma_n = pmaS[e];
+	uint32_t base_n = baseS[e];
+	for (uint32_t j = 0; j < len; ++j) {
+		const float pma = pma_n;
+		const uint32_t base = base_n;
+		const uint32_t e_cur = e;
+		++e;
+		if (++r == span) { r = 0; ++e; } /* skip the next wave's halo entry */
+		if (j + 1 < len) { pma_n = pmaS[e]; base_n = baseS[e]; }
+		const float p = fb_s * pma;
+		uint32_t ofs = rint32w_p31_small(p);
+		if (__builtin_expect(!(fabsf(p) < 0x1p20f), 0)) ofs = rint32w(p * 0x1p31f);
+		const uint32_t phase = base + ofs;
+		const int32_t d = (int32_t)(phase - prev_phase);
+		const double Isv = at.lookup(phase);
+		const float sv_new = wosc_diff(Isv, prev_Is, d, wc.diff_scale, wc.diff_offset);
+		const bool hold = d == 0;
+		const float sv = hold ? prev_s : sv_new;
+		prev_Is = hold ? prev_Is : Isv;
+		prev_phase = phase; /* equal to the old one when held */
+		prev_s = sv;
+		outS[e_cur] = sv;
+		fb_s = (fb_s + sv) * 0.5f;
+	}
+	st.prev_phase = prev_phase; st.prev_Is = prev_Is; st.prev_s = prev_s; st.fb_s = fb_s;
+}
+
 template <int W, int T>
 struct Geo {
 	static constexpr int NP = 64 * T;        /* slot entries per wave */
@@ -246,6 +319,7 @@ template <int W, int T, int V>
 __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 	static_assert(V == 1 || W == 1, "several teams per workgroup are single waves");
 	using G = Geo<W, T>;
+	constexpr int NTHREADS = 64 * W * V;
 	extern __shared__ __align__(16) unsigned char lds[];
 	const int team = V > 1 ? (int)uni((uint32_t)threadIdx.x >> 6) : 0;
 	const int tid = V > 1 ? (int)(threadIdx.x & 63) : (int)threadIdx.x; /* within the team */
@@ -268,10 +342,10 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 		const uint32_t wave = P.wave_of_tab[t];
 		const uint4 *s23 = (const uint4 *)(P.g_c23 + (size_t)wave * WAVE_LEN);
 		uint4 *d23 = (uint4 *)(t23 + (size_t)t * WAVE_LEN);
-		for (uint32_t i = threadIdx.x; i < WAVE_LEN; i += 64 * W * V) d23[i] = s23[i];
+		for (uint32_t i = threadIdx.x; i < WAVE_LEN; i += NTHREADS) d23[i] = s23[i];
 		const uint2 *s01 = (const uint2 *)(P.g_c01 + (size_t)wave * WAVE_LEN);
 		uint2 *d01 = (uint2 *)(t01 + (size_t)t * WAVE_LEN);
-		for (uint32_t i = threadIdx.x; i < WAVE_LEN; i += 64 * W * V) d01[i] = s01[i];
+		for (uint32_t i = threadIdx.x; i < WAVE_LEN; i += NTHREADS) d01[i] = s01[i];
 	}
 	if (V > 1) __syncthreads(); /* tables are shared by the teams; nothing else is */
 
@@ -659,32 +733,15 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 								prev_Is = Is0;
 								prev_phase = phase00;
 							}
-							/* the loop carries only fb_s -> phase -> table -> sample; the
-							 * next sample's inputs are fetched while it runs */
-							uint32_t e = 1, r = 0; /* entry of sample 0; r counts within a wave's span */
-							float pma_n = pmaS[e];
-							uint32_t base_n = scratch_u[e];
-							for (uint32_t j = 0; j < len; ++j) {
-								const float pma = pma_n;
-								const uint32_t base = base_n;
-								const uint32_t e_cur = e;
-								++e;
-								if (++r == (uint32_t)G::NP - 1) { r = 0; ++e; } /* skip the next wave's halo entry */
-								if (j + 1 < len) { pma_n = pmaS[e]; base_n = scratch_u[e]; }
-								const float p = fb_s * pma;
-								const uint32_t phase = base + (fabsf(p) < 0x1p20f ? rint32w_p31_small(p) : rint32w(p * 0x1p31f));
-								int32_t d = (int32_t)(phase - prev_phase);
-								float sv;
-								if (d == 0) {
-									sv = prev_s;
-								} else {
-									double Isv = herp_lookup(tab, phase);
-									sv = wosc_diff(Isv, prev_Is, d, wc.diff_scale, wc.diff_offset);
-									prev_Is = Isv; prev_s = sv; prev_phase = phase;
-								}
-								scratch[e_cur] = sv;
-								fb_s = (fb_s + sv) * 0.5f;
+							SelfmodState ss;
+							ss.prev_phase = prev_phase; ss.prev_Is = prev_Is; ss.prev_s = prev_s; ss.fb_s = fb_s;
+							const uint32_t span = W > 1 ? (uint32_t)G::NP - 1 : ~0u;
+							if (tab.in_lds) {
+								selfmod_serial<true>(tab, ss, wc, pmaS, scratch_u, scratch, len, span);
+							} else {
+								selfmod_serial<false>(tab, ss, wc, pmaS, scratch_u, scratch, len, span);
 							}
+							prev_phase = ss.prev_phase; prev_Is = ss.prev_Is; prev_s = ss.prev_s; fb_s = ss.fb_s;
 							op->prev_phase = prev_phase;
 							op->prev_Is = prev_Is;
 							op->prev_s = prev_s;
@@ -2702,7 +2759,11 @@ public:
 		};
 		if (multi_min_ && seg.n_voices >= multi_min_ && (seg.serial || multi_min_ == 1)) {
 			const size_t need_tab = seg.wave_mask ? tab_bytes : 0;
-			if (16 * team_size(1, 2) + need_tab <= lds_limit_) { W = 1; T = 2; V = 16; }
+			/* longer blocks amortise the per-step bookkeeping: 255 samples per block measured
+			 * 14 % faster than 127 on BASELINE config 5 */
+			if (16 * team_size(1, 4) + need_tab <= lds_limit_) { W = 1; T = 4; V = 16; }
+			else if (16 * team_size(1, 3) + need_tab <= lds_limit_) { W = 1; T = 3; V = 16; }
+			else if (16 * team_size(1, 2) + need_tab <= lds_limit_) { W = 1; T = 2; V = 16; }
 			else if (16 * team_size(1, 1) + need_tab <= lds_limit_) { W = 1; T = 1; V = 16; }
 		}
 		/* a voice with very many block buffers: one wave, one frame per lane (256 B per buffer) */
@@ -2933,7 +2994,9 @@ public:
 		}
 		TimedPair *tp = timing_on_ ? new_pair(0) : nullptr;
 		if (tp) (void)hipEventRecord(tp->a, stream_);
-		bool ok = V > 1 ? (T == 2 ? launch_render<1, 2, 16>(rp, block_grid_, lds, err)
+		bool ok = V > 1 ? (T == 4 ? launch_render<1, 4, 16>(rp, block_grid_, lds, err)
+		                 : T == 3 ? launch_render<1, 3, 16>(rp, block_grid_, lds, err)
+		                 : T == 2 ? launch_render<1, 2, 16>(rp, block_grid_, lds, err)
 		                          : launch_render<1, 1, 16>(rp, block_grid_, lds, err))
 		        : (W == 1) ? launch_render<1, 1, 1>(rp, block_grid_, lds, err)
 		        : geo_ ? launch_render<4, 4, 1>(rp, block_grid_, lds, err)

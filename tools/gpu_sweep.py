@@ -24,6 +24,9 @@ if "c2b" in which: run("4096 x 1 op (flat)", vb.config2(n=4096, seconds=30))
 if "c3" in which: run("1024 x 4 ops (config 3)", vb.config3(n=1024, seconds=30))
 if "c3x4" in which: run("4096 x 4 ops", vb.config3(n=4096, seconds=30))
 if "c5" in which: run("4096 x 2 ops selfmod (c5)", vb.config5(n=4096, seconds=30), frames=11025, steps=3)
+if "c5n" in which:  # config 5 voices in other counts (C5N=<voices>,<voices>...)
+    for n in [int(x) for x in os.environ.get("C5N", "3840,1920,960,240,15").split(",")]:
+        run(f"{n} x 2 ops selfmod", vb.config5(n=n, seconds=30), frames=11025, steps=3)
 if "c4" in which:
     G = os.path.join(ROOT, "tests", "golden", "programs")
     prgs = [sa.Program.from_image(open(os.path.join(G, f"config4_seed{k % 4}.saup"), "rb").read()) for k in range(64)]
