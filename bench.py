@@ -48,13 +48,53 @@ def cpu_baseline(tabs, voices):
     t0 = time.perf_counter()
     render(frames)
     dt = time.perf_counter() - t0
+    multi = cpu_baseline_all_cores(voices, frames_1core=frames / dt)
     return {"value": frames / dt, "unit": "mixed mono int16 frames/s", "cores": 1,
-            "kind": kind,
+            "kind": kind, "all_cores": multi,
             "sample": f"config 3 ({voices} voices x depth-3 PM), first {frames} frames "
                       f"({frames * voices * 4:.3g} operator-samples), {dt:.1f} s on 1 host thread"
                       + (" (sauGenerator_run of the compiled reference, -O3 -ffast-math as its Makefile)"
                          if kind == "reference" else " (oracle/sau_oracle.c)"),
             "operator_samples_per_s": frames * voices * 4 / dt}
+
+
+def cpu_baseline_all_cores(voices, frames_1core):
+    """the same bank with its voices partitioned over all host cores, one process
+    each (the reference is single-threaded; its voices only meet in the final per-frame sum)."""
+    import subprocess
+    import tempfile
+    n = max(1, min(os.cpu_count() or 1, voices))
+    per = [voices // n + (1 if i < voices % n else 0) for i in range(n)]
+    # about 8 s per worker at the single-core rate measured above
+    frames = int(min(44100 * 60, max(2205, 8.0 * frames_1core * voices / max(per))))
+    go = os.path.join(tempfile.mkdtemp(prefix="sau_bench_"), "go")
+    procs, first = [], 0
+    for c in per:
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "cpu_worker.py"),
+                                       str(first), str(c), str(frames), go],
+                                      stdout=subprocess.PIPE, text=True))
+        first += c
+    try:
+        for p in procs:
+            if p.stdout.readline().strip() != "ready":
+                raise RuntimeError("worker failed to start")
+        open(go, "w").close()
+        secs = [float(p.stdout.readline()) for p in procs]
+    except (RuntimeError, ValueError) as e:
+        for p in procs:
+            p.kill()
+        return {"error": str(e)}
+    finally:
+        for p in procs:
+            p.wait()
+        try:
+            os.remove(go)
+            os.rmdir(os.path.dirname(go))
+        except OSError:
+            pass
+    return {"value": frames / max(secs), "unit": "mixed mono int16 frames/s", "cores": n,
+            "sample": f"same bank, voices partitioned over {n} processes ({min(per)}-{max(per)} voices each), "
+                      f"first {frames} frames, slowest process {max(secs):.1f} s"}
 
 
 def main():

@@ -245,10 +245,11 @@ def config2(n=256, seconds=10):
     return build_program(voices)
 
 
-def config3(n=1024, seconds=10):
-    """n voices, each carrier + 3-deep PM chain (the headline workload)."""
+def config3(n=1024, seconds=10, first=0):
+    """n voices, each carrier + 3-deep PM chain (the headline workload); `first` shifts the
+    voice indices (voices first .. first+n-1 of a larger bank)."""
     voices = []
-    for i in range(n):
+    for i in range(first, first + n):
         m3 = Op("sin", freq=Line(float(3 + i % 4), ratio=True), amp=_f32(0.4))
         m2 = Op("sin", freq=Line(float(2 + i % 3), ratio=True), amp=_f32(0.7),
                 mods={POP_PMOD: [m3]})
