@@ -65,6 +65,24 @@ def test_gpu_corpus(gpu, oracle, index, heads):
     assert worst_ref <= 1  # tolerance of the north star: +-1 LSB int16
 
 
+@pytest.mark.parametrize("rate", [8000, 22050, 44100, 48000, 96000])
+def test_gpu_corpus_other_sample_rates(gpu, oracle, index, rate):
+    """Sample rate enters through the phase coefficients (wosc.h:57, rasg.h:126), every
+    ms -> samples conversion with its carry (generator.c:148-160) and the ramp lengths: the
+    whole corpus again at other rates, bit-exact vs the oracle (which equals the compiled
+    reference bit for bit at these rates too: tests/test_oracle.py)."""
+    oracle.oracle().ora_set_fastmath_forms(1)
+    bad = []
+    for key in _corpus_keys(index):
+        prg = load_program(gpu, key)
+        stereo = rate in (44100, 96000)
+        want = oracle.oracle_render(prg.ptr, rate, stereo)
+        got = gpu.Generator(prg, rate).render(stereo=stereo, chunk=50000)
+        if len(got) != len(want) or max_diff(got, want) != 0:
+            bad.append(key)
+    assert not bad, f"GPU != oracle at {rate} Hz for {bad}"
+
+
 @pytest.mark.parametrize("name,n", [("config2", 11025), ("config3", 11025)])
 def test_voicebank_heads(gpu, heads, index, name, n):
     """Configs 2/3 at full voice count, first 0.25 s, against the reference's PCM."""

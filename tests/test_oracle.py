@@ -114,6 +114,20 @@ def test_against_live_reference_when_present(oracle, sa, index):
         assert max_diff(a, b) == 0, key
 
 
+@pytest.mark.parametrize("rate", [8000, 22050, 48000])
+def test_corpus_other_sample_rates_vs_reference(oracle, sa, index, rate):
+    """The whole corpus at other sample rates (first 4 s of each script), straight against the
+    compiled reference: the restatement is bit-exact there too."""
+    if not oracle.have_ref():
+        pytest.skip("compiled reference not present")
+    oracle.oracle().ora_set_fastmath_forms(2)
+    for key in sorted(index["corpus"]):
+        prg = load_program(sa, key)
+        a = oracle.oracle_render(prg.ptr, rate, True, max_frames=rate * 4)
+        b = oracle.ref_render(prg.ptr, rate, True, max_frames=rate * 4)
+        assert len(a) == len(b) and max_diff(a, b) == 0, key
+
+
 def test_r_oscillator_options_vs_reference(oracle):
     """Every line shape x segment function of the R oscillator, with a spread of function flag
     combinations, on programs the parser-free builder makes: the restatement stays within 1 LSB of
