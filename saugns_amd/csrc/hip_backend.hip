@@ -2638,7 +2638,6 @@ public:
 	~HipBackendImpl() override {
 		/* the buffers go back to the pool (member destructors): nothing may still be using them */
 		if (stream_) (void)hipStreamSynchronize(stream_);
-		if (copy_done_) (void)hipEventDestroy(copy_done_);
 		for (int i = 0; i < 2; ++i) if (fetch_ev_[i]) (void)hipEventDestroy(fetch_ev_[i]);
 		for (auto &e : events_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
 		if (stream_) StreamPool::get().give(dev_, stream_); /* drained above */
@@ -2653,7 +2652,6 @@ public:
 		dev_ = dev;
 		stream_ = StreamPool::get().take(dev);
 		if (!stream_) HIP_OK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-		HIP_OK(hipEventCreateWithFlags(&copy_done_, hipEventDisableTiming));
 		static std::mutex prop_mu;
 		static size_t dev_lds[16]; /* per device: hipGetDeviceProperties costs a millisecond */
 		{
@@ -2701,24 +2699,47 @@ public:
 		return true;
 	}
 
+	/* Host data for the device goes through a page-locked arena and asynchronous copies on the
+	 * generator's stream: the copies are ordered behind the kernels still reading the old
+	 * contents, and the host goes on to prepare the next segment instead of waiting (a script
+	 * with many events is a chain of short segments). The arena is reused from its start once
+	 * the stream has drained. */
+	void *stage(const void *src, size_t bytes, std::string &err) {
+		const size_t need = (bytes + 63) & ~(size_t)63;
+		if (arena_used_ + need > arena_.cap) {
+			hipError_t e = hipStreamSynchronize(stream_);
+			if (e != hipSuccess) { err = std::string("hipStreamSynchronize: ") + hipGetErrorString(e); return nullptr; }
+			arena_used_ = 0;
+			const size_t want = need > ((size_t)4 << 20) ? need : ((size_t)4 << 20);
+			if (want > arena_.cap && !arena_.ensure(want, err)) return nullptr;
+		}
+		void *p = arena_.p + arena_used_;
+		arena_used_ += need;
+		memcpy(p, src, bytes);
+		return p;
+	}
+	bool send(void *dst, const void *src, size_t bytes, std::string &err) {
+		if (!bytes) return true;
+		void *h = stage(src, bytes, err);
+		if (!h) return false;
+		HIP_OK(hipMemcpyAsync(dst, h, bytes, hipMemcpyHostToDevice, stream_));
+		return true;
+	}
+
 	bool upload_plans(const Step *steps, const FastIds *fast_ids, size_t n_steps, const uint32_t *op_ids,
 			size_t n_ids, std::string &err) override {
-		HIP_OK(hipStreamSynchronize(stream_));
 		if (!steps_.ensure(n_steps ? n_steps : 1, err) || !op_ids_.ensure(n_ids ? n_ids : 1, err) ||
 		    !fast_ids_.ensure(n_steps ? 2 * n_steps : 1, err))
 			return false;
-		if (n_steps) HIP_OK(hipMemcpy(steps_.p, steps, n_steps * sizeof(Step), hipMemcpyHostToDevice));
-		if (n_steps) HIP_OK(hipMemcpy(fast_ids_.p, fast_ids, 2 * n_steps * sizeof(FastIds), hipMemcpyHostToDevice));
 		n_steps_total_ = (uint32_t)n_steps;
-		if (n_ids) HIP_OK(hipMemcpy(op_ids_.p, op_ids, n_ids * sizeof(uint32_t), hipMemcpyHostToDevice));
-		return true;
+		return send(steps_.p, steps, n_steps * sizeof(Step), err) &&
+			send(fast_ids_.p, fast_ids, 2 * n_steps * sizeof(FastIds), err) &&
+			send(op_ids_.p, op_ids, n_ids * sizeof(uint32_t), err);
 	}
 
 	bool apply_updates(const OpUpdate *recs, size_t n, std::string &err) override {
 		if (!n) return true;
-		HIP_OK(hipStreamSynchronize(stream_));
-		if (!recs_.ensure(n, err)) return false;
-		HIP_OK(hipMemcpy(recs_.p, recs, n * sizeof(OpUpdate), hipMemcpyHostToDevice));
+		if (!recs_.ensure(n, err) || !send(recs_.p, recs, n * sizeof(OpUpdate), err)) return false;
 		hipLaunchKernelGGL(event_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream_,
 				ops_.p, recs_.p, (uint32_t)n, tables_->wc);
 		HIP_OK(hipGetLastError());
@@ -2822,25 +2843,15 @@ public:
 			memcmp(voices_sent_.data(), seg.voices, seg.n_voices * sizeof(VoiceDesc)) == 0;
 		const bool same_ms = ms_sent_.size() == seg.n_streams && ms_dev_ == mstreams_.p &&
 			memcmp(ms_sent_.data(), ms_host_.data(), seg.n_streams * sizeof(MixStream)) == 0;
-		if (!same_voices || !same_ms) {
-			if (copy_pending_) { HIP_OK(hipEventSynchronize(copy_done_)); copy_pending_ = false; }
-			if (!h_voices_.ensure(seg.n_voices, err) || !h_ms_.ensure(seg.n_streams, err)) return false;
-			if (!same_voices) {
-				memcpy(h_voices_.p, seg.voices, seg.n_voices * sizeof(VoiceDesc));
-				HIP_OK(hipMemcpyAsync(voices_.p, h_voices_.p, seg.n_voices * sizeof(VoiceDesc),
-						hipMemcpyHostToDevice, stream_));
-				voices_sent_.assign(seg.voices, seg.voices + seg.n_voices);
-				voices_dev_ = voices_.p;
-			}
-			if (!same_ms) {
-				memcpy(h_ms_.p, ms_host_.data(), seg.n_streams * sizeof(MixStream));
-				HIP_OK(hipMemcpyAsync(mstreams_.p, h_ms_.p, seg.n_streams * sizeof(MixStream),
-						hipMemcpyHostToDevice, stream_));
-				ms_sent_ = ms_host_;
-				ms_dev_ = mstreams_.p;
-			}
-			HIP_OK(hipEventRecord(copy_done_, stream_));
-			copy_pending_ = true;
+		if (!same_voices) {
+			if (!send(voices_.p, seg.voices, seg.n_voices * sizeof(VoiceDesc), err)) return false;
+			voices_sent_.assign(seg.voices, seg.voices + seg.n_voices);
+			voices_dev_ = voices_.p;
+		}
+		if (!same_ms) {
+			if (!send(mstreams_.p, ms_host_.data(), seg.n_streams * sizeof(MixStream), err)) return false;
+			ms_sent_ = ms_host_;
+			ms_dev_ = mstreams_.p;
 		}
 		rp.voices = voices_.p; rp.steps = steps_.p; rp.op_ids = op_ids_.p; rp.ops = ops_.p;
 		rp.vout = vout_.p; rp.pan = pan_.p; rp.vinfo = vinfo_.p;
@@ -3067,6 +3078,7 @@ public:
 
 	bool sync(std::string &err) override {
 		HIP_OK(hipStreamSynchronize(stream_));
+		arena_used_ = 0; /* every staged copy has left the arena */
 		return true;
 	}
 
@@ -3181,14 +3193,12 @@ private:
 	DevBuf<OpUpdate> recs_;
 	DevBuf<MixStream> mstreams_;
 	const TableSet *tables_ = nullptr;
-	PinBuf<VoiceDesc> h_voices_;
-	PinBuf<MixStream> h_ms_;
 	PinBuf<int16_t> h_pcm_; /* fetch_pcm() staging */
+	PinBuf<unsigned char> arena_; /* stage() */
+	size_t arena_used_ = 0;
 	std::vector<VoiceDesc> voices_sent_;   /* what the device copies hold */
 	std::vector<MixStream> ms_sent_, ms_host_;
 	const void *voices_dev_ = nullptr, *ms_dev_ = nullptr;
-	hipEvent_t copy_done_ = nullptr;
-	bool copy_pending_ = false;
 	std::vector<TimedPair> events_;
 	size_t n_used_ = 0;
 	bool timing_on_ = false;
