@@ -1,4 +1,6 @@
 """GPU unit parity: one feature of the operator graph at a time, bit-exact vs the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -309,3 +311,32 @@ def test_random_operator_graphs(sa, oracle, seed):
     voices = [_random_voice(rng) for _ in range(int(rng.integers(1, 4)))]
     check(sa, oracle, voices, stereo=bool(seed & 1))
     check_runs(sa, oracle, voices, chunk=int(rng.integers(700, 3000)), stereo=bool(seed & 1))
+
+
+@pytest.mark.gpu
+def test_deep_and_wide_graphs(sa, oracle):
+    """Nesting at the limit (64 levels of PM) and 300 modulators in one list, on the device."""
+    from saugns_amd.voicebank import Op, Line
+    oracle.oracle().ora_set_fastmath_forms(1)
+    op = None
+    for d in range(64):
+        top = d == 63
+        op = Op("sin", freq=200.0 if top else Line(2.0, ratio=True), amp=0.5, time_ms=300 if top else None,
+                mods={POP_PMOD: [op]} if op else {})
+    mods = [Op("sin", freq=Line(float(1 + i % 7), ratio=True), amp=0.1) for i in range(300)]
+    wide = Op("sin", freq=200.0, amp=0.5, time_ms=300, mods={POP_PMOD: mods})
+    for voices in ([op], [wide]):
+        prg = vb.build_program(voices)
+        want = oracle.oracle_render(prg.ptr, RATE, False)
+        for env in ({}, {"SAU_AMD_NO_FAST": "1"}):
+            old = {k: os.environ.get(k) for k in env}
+            os.environ.update(env)
+            try:
+                got = sa.Batch([prg], RATE).render(stereo=False, chunk=5000)[0]
+            finally:
+                for k, v in old.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+            assert len(got) == len(want) and (got == want).all(), env

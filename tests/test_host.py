@@ -178,3 +178,40 @@ def test_block_buffer_numbering(sa, seqexec):
     assert c["may_scan"] and c["n_fast_full"] >= 1 and c["n_fast_full"] >= c["n_fast"]
     c = counts([vb.Op("sin", freq=220.0, pm_a=0.5, time_ms=100)])
     assert c["serial"]
+
+
+def _pm_chain(depth):
+    from saugns_amd.voicebank import Op, Line
+    from saugns_amd.api import POP_PMOD
+    op = None
+    for d in range(depth):
+        top = d == depth - 1
+        op = Op("sin", freq=200.0 if top else Line(2.0, ratio=True), amp=0.5, time_ms=50 if top else None,
+                mods={POP_PMOD: [op]} if op else {})
+    return op
+
+
+def test_limits_beyond_the_reference(sa, oracle, seqexec):
+    """nesting up to 64 renders (bit-exact), deeper is refused with a
+    message and silence (the reference host then simply ends: generator.c:905 cannot fail);
+    any number of modulators in one list is fine (they share a block buffer)."""
+    from saugns_amd import voicebank
+    from saugns_amd.voicebank import Op, Line
+    from saugns_amd.api import POP_PMOD
+    oracle.oracle().ora_set_fastmath_forms(1)
+    for depth in (63, 64):
+        prg = voicebank.build_program([_pm_chain(depth)])
+        got = sa.Batch([prg], 12000, backend=seqexec.seq_backend_create(256)).render()[0]
+        assert max_diff(got, oracle.oracle_render(prg.ptr, 12000, False)) == 0
+    prg = voicebank.build_program([_pm_chain(65)])
+    with pytest.raises(RuntimeError, match="nesting deeper than 64"):
+        sa.Batch([prg], 12000, backend=seqexec.seq_backend_create(256)).render()
+    g = sa.Generator(prg, 12000, backend=seqexec.seq_backend_create(256))
+    buf = np.full(1000, 5, np.int16)
+    assert g.run(buf, 1000) == (False, 0) and not buf.any()
+    assert "nesting deeper than 64" in sa.last_error()
+    g.close()
+    mods = [Op("sin", freq=Line(float(1 + i % 7), ratio=True), amp=0.1) for i in range(300)]
+    prg = voicebank.build_program([Op("sin", freq=200.0, amp=0.5, time_ms=50, mods={POP_PMOD: mods})])
+    got = sa.Batch([prg], 12000, backend=seqexec.seq_backend_create(256)).render()[0]
+    assert max_diff(got, oracle.oracle_render(prg.ptr, 12000, False)) == 0
