@@ -231,23 +231,26 @@ struct SelfmodState {
  * one skipped (halo) entry per `span` samples. The next sample's inputs are
  * fetched while the current one is computed; a repeated phase holds the
  * previous sample (wosc.h:292-293), decided by selects, not by a branch. */
-template <bool LDS>
+template <bool LDS, int SPAN /* samples per wave span when several waves share a block, else 0 */>
 __device__ __forceinline__ void selfmod_serial(const TabRef &tab, SelfmodState &st, const WaveConst &wc,
-		const float *pmaS, const u32_alias *baseS, float *outS, uint32_t len, uint32_t span) {
+		const float *pmaS, u32_alias *baseS /* also receives the samples */, uint32_t len) {
+	typedef uint32_t __attribute__((address_space(3))) *lds_u32_w;
 	const TabAt<LDS> at(tab);
 	uint32_t prev_phase = st.prev_phase;
 	double prev_Is = st.prev_Is;
 	float prev_s = st.prev_s, fb_s = st.fb_s;
-	uint32_t e = 1, r = 0;
-	float pma_n = pmaS[e];
-	uint32_t base_n = baseS[e];
+	lds_f32_ptr pm = (lds_f32_ptr)pmaS + 1; /* entry of the current sample */
+	lds_u32_w bs = (lds_u32_w)(uint32_t *)baseS + 1;
+	uint32_t r = 0;
+	float pma_n = *pm;
+	uint32_t base_n = *bs;
 	for (uint32_t j = 0; j < len; ++j) {
 		const float pma = pma_n;
 		const uint32_t base = base_n;
-		const uint32_t e_cur = e;
-		++e;
-		if (++r == span) { r = 0; ++e; } /* skip the next wave's halo entry */
-		if (j + 1 < len) { pma_n = pmaS[e]; base_n = baseS[e]; }
+		const lds_u32_w cur = bs;
+		++pm; ++bs;
+		if (SPAN && ++r == (uint32_t)SPAN) { r = 0; ++pm; ++bs; } /* skip the next wave's halo entry */
+		if (j + 1 < len) { pma_n = *pm; base_n = *bs; }
 		const float p = fb_s * pma;
 		uint32_t ofs = rint32w_p31_small(p);
 		if (__builtin_expect(!(fabsf(p) < 0x1p20f), 0)) ofs = rint32w(p * 0x1p31f);
@@ -260,7 +263,7 @@ __device__ __forceinline__ void selfmod_serial(const TabRef &tab, SelfmodState &
 		prev_Is = hold ? prev_Is : Isv;
 		prev_phase = phase; /* equal to the old one when held */
 		prev_s = sv;
-		outS[e_cur] = sv;
+		*cur = f_bits(sv);
 		fb_s = (fb_s + sv) * 0.5f;
 	}
 	st.prev_phase = prev_phase; st.prev_Is = prev_Is; st.prev_s = prev_s; st.fb_s = fb_s;
@@ -735,12 +738,9 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 							}
 							SelfmodState ss;
 							ss.prev_phase = prev_phase; ss.prev_Is = prev_Is; ss.prev_s = prev_s; ss.fb_s = fb_s;
-							const uint32_t span = W > 1 ? (uint32_t)G::NP - 1 : ~0u;
-							if (tab.in_lds) {
-								selfmod_serial<true>(tab, ss, wc, pmaS, scratch_u, scratch, len, span);
-							} else {
-								selfmod_serial<false>(tab, ss, wc, pmaS, scratch_u, scratch, len, span);
-							}
+							constexpr int SPAN = W > 1 ? G::NP - 1 : 0;
+							if (tab.in_lds) selfmod_serial<true, SPAN>(tab, ss, wc, pmaS, scratch_u, len);
+							else selfmod_serial<false, SPAN>(tab, ss, wc, pmaS, scratch_u, len);
 							prev_phase = ss.prev_phase; prev_Is = ss.prev_Is; prev_s = ss.prev_s; fb_s = ss.fb_s;
 							op->prev_phase = prev_phase;
 							op->prev_Is = prev_Is;
