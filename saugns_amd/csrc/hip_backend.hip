@@ -440,12 +440,14 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 				if (!lazy) {
 					/* the provider's block may be a single value (never stored) */
 					const bool mconst = mul && pconst;
-					LineBlock lb = line_begin(ls, len, mul != nullptr, mul ? (mconst ? pf : mul[1]) : 0.f);
+					const float m0 = mul ? (mconst ? pf : mul[1]) : 0.f;
+					LineBlock lb = line_block_v(ls, len, mul != nullptr, m0);
+					line_begin_state(ls, len, mul != nullptr, m0);
 #pragma unroll
 					for (int k = 0; k < T; ++k) {
 						if (owned[k]) {
 							float m = mul ? (mconst ? pf : mul[w * G::NP + p0 + k]) : 1.f;
-							v[k] = line_value(lb, (uint32_t)(jbase + k), m);
+							v[k] = line_value_v(lb, (uint32_t)(jbase + k), m);
 						}
 					}
 				} else {
@@ -474,10 +476,11 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 				const bool active = (ls.v0 != 0.f) || (ls.flags & LP_GOAL);
 				float v[T];
 				if (active) {
-					LineBlock lb = line_begin(ls, len, false, 0.f);
+					LineBlock lb = line_block_v(ls, len, false, 0.f);
+					line_begin_state(ls, len, false, 0.f);
 #pragma unroll
 					for (int k = 0; k < T; ++k)
-						v[k] = owned[k] ? line_value(lb, (uint32_t)(jbase + k), 1.f) : 0.f;
+						v[k] = owned[k] ? line_value_v(lb, (uint32_t)(jbase + k), 1.f) : 0.f;
 				} else {
 					line_skip(ls, len);
 #pragma unroll
@@ -542,10 +545,13 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 						fls = uni(op->line[L_FREQ]);
 						fconst = const_freq(fls, fmul != nullptr, pconst, pf, fc);
 						mconst = fmul && pconst;
-						if (!fconst)
-							flb = line_begin(fls, len, fmul != nullptr, fmul ? (mconst ? pf : fmul[1]) : 0.f);
-						else
+						if (!fconst) {
+							const float m0 = fmul ? (mconst ? pf : fmul[1]) : 0.f;
+							flb = line_block_v(fls, len, fmul != nullptr, m0);
+							line_begin_state(fls, len, fmul != nullptr, m0);
+						} else {
 							line_advance_hold(fls, len);
+						}
 					} else if (pconst) { /* own frequency block was never stored */
 						fconst = true; fc = pf;
 					}
@@ -560,10 +566,11 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 #pragma unroll
 						for (int k = 0; k < T; ++k) av[k] = ac;
 					} else {
-						const LineBlock alb = line_begin(als, len, false, 0.f);
+						const LineBlock alb = line_block_v(als, len, false, 0.f);
+						line_begin_state(als, len, false, 0.f);
 #pragma unroll
 						for (int k = 0; k < T; ++k)
-							av[k] = owned[k] ? line_value(alb, (uint32_t)(jbase + k), 1.f) : 0.f;
+							av[k] = owned[k] ? line_value_v(alb, (uint32_t)(jbase + k), 1.f) : 0.f;
 					}
 				} else {
 #pragma unroll
@@ -581,7 +588,7 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 					pls = uni(op->line[L_PMA]);
 					pls0 = pls;
 					sm_inline_active = (pls.v0 != 0.f) || (pls.flags & LP_GOAL);
-					if (sm_inline_active) (void)line_begin(pls, len, false, 0.f);
+					if (sm_inline_active) line_begin_state(pls, len, false, 0.f);
 					else line_skip(pls, len);
 				}
 				const bool selfmod = is_osc && (smS != nullptr || sm_inline_active);
@@ -644,7 +651,7 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 								const int e = w * G::NP + p0 + k;
 								const int j = jbase + k;
 								float f = fslot ? fslot[e]
-								                : line_value(flb, (uint32_t)j, fmul ? (mconst ? pf : fmul[e]) : 1.f);
+								                : line_value_v(flb, (uint32_t)j, fmul ? (mconst ? pf : fmul[e]) : 1.f);
 								if (owned[k]) inc[k] = rint32w(coeff * f);
 								ofs[k] = (uint32_t)pm_offset(pmS != nullptr, fpmS != nullptr,
 										pmS ? pmS[e] : 0.f, fpmS ? fpmS[e] : 0.f, f, 0x1p31f);
@@ -714,10 +721,10 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 						const float *pmaS = smS;
 						if (!pmaS) {
 							LineBlock plb;
-							{ LineState t = pls0; plb = line_begin(t, len, false, 0.f); }
+							plb = line_block_v(pls0, len, false, 0.f);
 #pragma unroll
 							for (int k = 0; k < T; ++k)
-								if (owned[k]) out[w * G::NP + p0 + k] = line_value(plb, (uint32_t)(jbase + k), 1.f);
+								if (owned[k]) out[w * G::NP + p0 + k] = line_value_v(plb, (uint32_t)(jbase + k), 1.f);
 							pmaS = out;
 						}
 #pragma unroll
@@ -768,7 +775,7 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 							const int e = w * G::NP + p0 + k;
 							const int j = jbase + k;
 							float f = fconst ? fc : (fslot ? fslot[e]
-							                : line_value(flb, (uint32_t)j, fmul ? (mconst ? pf : fmul[e]) : 1.f));
+							                : line_value_v(flb, (uint32_t)j, fmul ? (mconst ? pf : fmul[e]) : 1.f));
 							inc[k] = (unsigned long long)rint64(coeff * f);
 							ofs[k] = (unsigned long long)pm_offset(pmS != nullptr, fpmS != nullptr,
 									pmS ? pmS[e] : 0.f, fpmS ? fpmS[e] : 0.f, f, phase_scale);
@@ -811,11 +818,11 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 						team_sync<V>();
 						if (tid == 0 && len > 0) {
 							LineBlock plb;
-							if (sm_inline_active) { LineState t = pls0; plb = line_begin(t, len, false, 0.f); }
+							if (sm_inline_active) plb = line_block_v(pls0, len, false, 0.f);
 							float fb_s = op->fb_s, prev_s = op->prev_s;
 							for (uint32_t j = 0; j < len; ++j) {
 								const uint32_t e = entry_of<W, T>(j);
-								float pma_v = smS ? smS[e] : line_value(plb, j, 1.f);
+								float pma_v = smS ? smS[e] : line_value_v(plb, j, 1.f);
 								float pm_a = fb_s * pma_v * 0.5f;
 								float phase = scratch[e] + pm_a;
 								int32_t cycle_adj = (int32_t)floorf(phase);
@@ -951,7 +958,7 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 				if (to_voice) { /* generator.c:749-788; the sum over voices is mix_kernel */
 					pl = uni(op->line[L_PAN]);
 					pan_goal = (pl.flags & LP_GOAL) != 0;
-					if (pan_goal) plb2 = line_begin(pl, len, false, 0.f);
+					if (pan_goal) { plb2 = line_block_v(pl, len, false, 0.f); line_begin_state(pl, len, false, 0.f); }
 					else line_skip(pl, len);
 				}
 #pragma unroll
@@ -961,7 +968,7 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 						if (to_voice) {
 							const int j = jbase + k;
 							vrow[done + j] = r;
-							if (prow) prow[done + j] = pan_goal ? line_value(plb2, (uint32_t)j, 1.f) : pl.v0;
+							if (prow) prow[done + j] = pan_goal ? line_value_v(plb2, (uint32_t)j, 1.f) : pl.v0;
 						} else {
 							slot_put<W, T>(out, w, p0 + k, r);
 						}
@@ -1010,7 +1017,7 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 				LineBlock plb2;
 				const bool pan_goal = !panS && (pl.flags & LP_GOAL);
 				if (!panS) {
-					if (pan_goal) plb2 = line_begin(pl, len, false, 0.f);
+					if (pan_goal) { plb2 = line_block_v(pl, len, false, 0.f); line_begin_state(pl, len, false, 0.f); }
 					else line_skip(pl, len);
 				}
 #pragma unroll
@@ -1021,7 +1028,7 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 						vrow[done + j] = src[e];
 						if (prow)
 							prow[done + j] = panS ? panS[e]
-								: (pan_goal ? line_value(plb2, (uint32_t)j, 1.f) : pl.v0);
+								: (pan_goal ? line_value_v(plb2, (uint32_t)j, 1.f) : pl.v0);
 					}
 				}
 				team_sync<V>();

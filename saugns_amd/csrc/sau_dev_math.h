@@ -301,7 +301,7 @@ SAU_HD void line_advance_hold(LineState &o, uint32_t len) {
 
 /* have_mul: a ratio buffer exists; mul0: its first value (only read when the
  * state/goal ratio flags disagree, sau/line.c:358-370). */
-SAU_HD_CALL LineBlock line_begin(LineState &o, uint32_t len, bool have_mul, float mul0) {
+SAU_HD LineBlock line_begin_body(LineState &o, uint32_t len, bool have_mul, float mul0) {
 	LineBlock b;
 	b.goal_len = 0; b.mul_goal = false; b.mul_hold = false; b.hold = 0.f;
 	b.sw = sweep_setup(LN_sah, 0.f, 0.f, 0, 1);
@@ -355,9 +355,55 @@ SAU_HD_CALL LineBlock line_begin(LineState &o, uint32_t len, bool have_mul, floa
 	return b;
 }
 
+SAU_HD_CALL LineBlock line_begin(LineState &o, uint32_t len, bool have_mul, float mul0) {
+	return line_begin_body(o, len, have_mul, mul0);
+}
+
 SAU_HD_CALL float line_value(const LineBlock &b, uint32_t i, float mul_i) {
 	if (i < b.goal_len) {
 		float v = sweep_value(b.sw, i);
+		return b.mul_goal ? v * mul_i : v;
+	}
+	return b.mul_hold ? b.hold * mul_i : b.hold;
+}
+
+/* The same two for callers that keep line states and blocks in registers: arguments and
+ * results by value (a reference parameter of a real call pins the caller's object in scratch
+ * memory, and every later use of it becomes a memory round trip -- measured at about 2 us per
+ * plan step in the block loop). line_begin() = line_block_v() for the block +
+ * line_begin_state() for the state it leaves behind. */
+SAU_HD_CALL LineBlock line_block_v(LineState o, uint32_t len, bool have_mul, float mul0) {
+	return line_begin_body(o, len, have_mul, mul0);
+}
+SAU_HD void line_begin_state(LineState &o, uint32_t len, bool have_mul, float mul0) {
+	if (!(o.flags & LP_GOAL)) {
+		line_advance_hold(o, len);
+		return;
+	}
+	if (o.flags & LP_GOAL_RATIO) {
+		if (!(o.flags & LP_STATE_RATIO)) {
+			if (have_mul) o.v0 /= mul0;
+			o.flags |= LP_STATE_RATIO;
+		}
+	} else if (o.flags & LP_STATE_RATIO) {
+		if (have_mul) o.v0 *= mul0;
+		o.flags &= ~LP_STATE_RATIO;
+	}
+	uint32_t glen = 0;
+	if (o.pos < o.end) {
+		glen = o.end - o.pos;
+		if (glen > len) glen = len;
+	}
+	o.pos += glen;
+	if (o.pos >= o.end) {
+		o.v0 = o.vt;
+		o.pos = 0;
+		o.flags &= ~(LP_GOAL | LP_GOAL_RATIO | LP_TIME);
+	}
+}
+SAU_HD_CALL float line_value_v(LineBlock b, uint32_t i, float mul_i) {
+	if (i < b.goal_len) {
+		float v = sweep_value_inl(b.sw, i);
 		return b.mul_goal ? v * mul_i : v;
 	}
 	return b.mul_hold ? b.hold * mul_i : b.hold;
