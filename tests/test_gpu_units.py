@@ -340,3 +340,30 @@ def test_deep_and_wide_graphs(sa, oracle):
                     else:
                         os.environ[k] = v
             assert len(got) == len(want) and (got == want).all(), env
+
+
+@pytest.mark.gpu
+def test_two_generators_alternately_on_device(sa, oracle):
+    """Two generators of one program at two rates, called in turn from one thread (the host's
+    `split_gen` arrangement, saugns.c:585), each rendering ahead on its own stream and pooled
+    buffers: neither disturbs the other."""
+    from conftest import load_program
+    oracle.oracle().ora_set_fastmath_forms(1)
+    prg = load_program(sa, "examples__dull_seq-fm_pm")
+    rates = (44100, 48000)
+    want = [oracle.oracle_render(prg.ptr, r, True) for r in rates]
+    gens = [sa.Generator(prg, r) for r in rates]
+    outs = [[], []]
+    bufs = [np.zeros(2 * 11289, np.int16), np.zeros(2 * 12288, np.int16)]
+    alive = [True, True]
+    while any(alive):
+        for i, g in enumerate(gens):
+            if alive[i]:
+                more, n = g.run(bufs[i], len(bufs[i]) // 2, True)
+                outs[i].append(bufs[i][: 2 * n].copy())
+                alive[i] = more
+    for g in gens:
+        g.close()
+    for i in range(2):
+        got = np.concatenate(outs[i])
+        assert len(got) == len(want[i]) and (got == want[i]).all()

@@ -215,3 +215,26 @@ def test_limits_beyond_the_reference(sa, oracle, seqexec):
     prg = voicebank.build_program([Op("sin", freq=200.0, amp=0.5, time_ms=50, mods={POP_PMOD: mods})])
     got = sa.Batch([prg], 12000, backend=seqexec.seq_backend_create(256)).render()[0]
     assert max_diff(got, oracle.oracle_render(prg.ptr, 12000, False)) == 0
+
+
+def test_two_generators_alternately(sa, oracle, seqexec):
+    """saugns.c:585 creates a second generator at the device rate (`split_gen`) and calls both in
+    turn from one thread: the two must not share mutable state (threading row)."""
+    oracle.oracle().ora_set_fastmath_forms(1)
+    prg = load_program(sa, "examples__dull_seq-fm_pm")
+    rates = (12000, 16000)
+    want = [oracle.oracle_render(prg.ptr, r, True) for r in rates]
+    gens = [sa.Generator(prg, r, backend=seqexec.seq_backend_create(1016)) for r in rates]
+    outs = [[], []]
+    bufs = [np.zeros(2 * 3000, np.int16), np.zeros(2 * 4000, np.int16)]
+    alive = [True, True]
+    while any(alive):
+        for i, g in enumerate(gens):
+            if alive[i]:
+                more, n = g.run(bufs[i], len(bufs[i]) // 2, True)
+                outs[i].append(bufs[i][: 2 * n].copy())
+                alive[i] = more
+    for g in gens:
+        g.close()
+    for i in range(2):
+        assert max_diff(np.concatenate(outs[i]), want[i]) == 0
