@@ -4,8 +4,8 @@
     python bench.py --gpus N --steps K --warmup W
 
 One step = one pass of the generator hot path over one batch: every rank
-renders `--frames` frames (default 176400 = 4 s at 44.1 kHz) of BASELINE
-config 3 (1024 voices, each carrier + 3-deep PM chain; 4096 operators) with
+renders `--frames` frames (default 441000 = the whole 10 s of the script at 44.1 kHz)
+of BASELINE config 3 (1024 voices, each carrier + 3-deep PM chain; 4096 operators) with
 program state, block buffers and PCM resident in HBM.  Ranks hold independent
 voice banks (the path has no exchange step: SURVEY.md 8e), so scaling is weak
 and `value` is the sum over ranks of mixed mono output frames per second.
@@ -102,7 +102,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=176400)
+    ap.add_argument("--frames", type=int, default=441000)
     ap.add_argument("--voices", type=int, default=1024)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -184,7 +184,7 @@ def main():
         # cannot be collected from inside this process, so null when the workload differs
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_h_pmc_summary.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_i_pmc_summary.json")))
             wl = pmc["workload"]
             if wl["voices"] == args.voices and wl["frames_per_step"] == args.frames:
                 k = [v for n, v in pmc["kernels"].items() if n.startswith("sauhip::fast_kernel<")]

@@ -1116,6 +1116,16 @@ struct FastLine;
 struct FastAux;
 constexpr uint32_t FAST_MAX_SCAN = 8;   /* oscillators with running-sum phases per multi-pass voice */
 constexpr uint32_t FAST_MAX_LEVELS = 2; /* running sums that depend on running sums: that many sum passes */
+/* A repeated phase (the output holds, wosc.h:251-252) on the first lane an operator's values are
+ * defined in cannot take the held output from the lane before. What that spoils is exactly the
+ * first owned frame of the row (one lane per nesting level upwards). fast_kernel notes such row
+ * groups per voice and repair_kernel evaluates them once more FAST_REPAIR_SHIFT frames earlier,
+ * where that frame lies in the middle of a row, storing only that frame. Through-zero PM makes
+ * exact repeats a several-per-10-s event for a 1024-voice bank and one in 64 of them falls on
+ * such a lane; each used to send its voice's whole segment to the block loop (8.5 ms for 10 s). */
+constexpr uint32_t FAST_REPAIR_SHIFT = 24; /* H + shift < 64 (H <= 32) */
+constexpr uint32_t FAST_MAX_REPAIR = 15;   /* noted row groups per voice and segment; more: block loop */
+constexpr uint32_t FAST_REPAIR_WORDS = 2 + 2 * FAST_MAX_REPAIR; /* count, pad, then (group, rows) pairs */
 struct FastParams {
 	const VoiceDesc *voices;
 	const Step *steps;
@@ -1144,7 +1154,10 @@ struct FastParams {
 	unsigned long long *scan; /* [n_voices][FAST_MAX_SCAN][scan_groups]: those sums (W: mod 2^32; R: 64 bits), then
 	                           * (scan_kernel) their prefixes */
 	uint32_t scan_groups;
-	uint32_t *pass_flags; /* [FAST_MAX_LEVELS]: some voice of the segment needs that sum pass (set by analyze_kernel) */
+	uint32_t *pass_flags; /* [FAST_MAX_LEVELS]: some voice of the segment needs that sum pass (set by analyze_kernel);
+	                       * [FAST_MAX_LEVELS]: some voice has row groups noted for repair_kernel */
+	uint32_t *repair;     /* [voice][FAST_REPAIR_WORDS] */
+	uint32_t repair_on;   /* 0: such voices go to the block loop (SAU_AMD_NO_REPAIR, tests) */
 	int8_t tab_of_wave[12];
 	uint8_t wave_of_tab[12];
 	WaveConst wc[12];
@@ -1379,6 +1392,7 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 		fi.total = min(min_time, vd.run_len);
 	P.info[v] = fi;
 	P.fast_done[v] = 0;
+	P.repair[(size_t)v * FAST_REPAIR_WORDS] = 0;
 }
 
 /* One step of a voice's plan, decoded once per voice per wave into immediate
@@ -1734,7 +1748,7 @@ __device__ __forceinline__ FastStep load_step_uniform(const FastStep *p) {
  * (frequency ramps, FM); the plain build stays as lean as closed-form voices
  * need it (the same code with the running-sum branches compiled in was 27 %
  * slower on them), and a kernel that may meet both kinds holds both copies. */
-template <int T, bool SCAN>
+template <int T, bool SCAN, bool REPAIR = false>
 __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v, const FastInfo &fi,
 		float *slots, unsigned long long *carry, const HerpC23 *t23, const HerpC01 *t01, const int l,
 		const uint32_t wpv, const uint32_t cstart) {
@@ -1766,10 +1780,17 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 	const uint32_t last_group = ((fast_total - 1) / C) / T; /* holds the segment's last frame */
 	uint32_t zero_acc = 0; /* nonzero: some hold-previous run could not be resolved here */
 
-	for (uint32_t cg = cstart; cg < ngroups; cg += gstride) {
-		const int t0 = (int)(cg * T * C) - (int)H + l; /* this lane's frame in row 0 */
+	uint32_t *const rep = P.repair + (size_t)v * FAST_REPAIR_WORDS;
+	/* REPAIR: the noted row groups instead of all, each evaluated FAST_REPAIR_SHIFT frames early */
+	const uint32_t n_iter = REPAIR ? min(uni(rep[0]), FAST_MAX_REPAIR) : ngroups;
+	for (uint32_t it = cstart; it < n_iter; it += gstride) {
+		const uint32_t cg = REPAIR ? uni(rep[2 + 2 * it]) : it;
+		const uint32_t repair_rows = REPAIR ? uni(rep[3 + 2 * it]) : 0u;
+		const int t0 = (int)(cg * T * C) - (int)H + l - (REPAIR ? (int)FAST_REPAIR_SHIFT : 0); /* this lane's frame in row 0 */
 		const bool first_group = (cg == 0);
 		const bool is_last_group = (cg == last_group);
+		uint32_t held_rows = 0; /* rows with a hold this evaluation could not resolve */
+		(void)repair_rows;
 #if FK_PREFETCH
 		FastStep fnext = load_step_uniform(fsteps);
 #endif
@@ -2021,7 +2042,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 								if (!__any(changed)) break;
 							}
 #pragma unroll
-							for (int k = 0; k < T; ++k) zero_acc |= (uint32_t)held[k];
+							for (int k = 0; k < T; ++k) held_rows |= __any(held[k]) ? (1u << k) : 0u;
 						}
 						if (is_last_group) {
 							/* the row that holds the segment's last frame stages the state */
@@ -2173,7 +2194,8 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 #pragma unroll
 					for (int k = 0; k < T; ++k) {
 						const int t = t0 + k * (int)C;
-						if (l >= (int)H && t < (int)fast_total) vrow[t] = r[k];
+						const bool mine = REPAIR ? (l == (int)(H + FAST_REPAIR_SHIFT) && ((repair_rows >> k) & 1u)) : (l >= (int)H);
+						if (mine && t < (int)fast_total) vrow[t] = r[k];
 					}
 				} else {
 #pragma unroll
@@ -2216,12 +2238,33 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 #pragma unroll
 				for (int k = 0; k < T; ++k) {
 					const int t = t0 + k * (int)C;
-					if (l >= (int)H && t < (int)fast_total) {
+					const bool mine = REPAIR ? (l == (int)(H + FAST_REPAIR_SHIFT) && ((repair_rows >> k) & 1u)) : (l >= (int)H);
+					if (mine && t < (int)fast_total) {
 						vrow[t] = slots[f.out_off + k * 64];
 						if (prow) prow[t] = f.pm_off != ~0u ? slots[f.pm_off + k * 64] : f.pan;
 					}
 				}
 			}
+		}
+		if (held_rows) {
+			/* to the repair pass -- unless this is it, the group touches an end of the segment
+			 * (carried state sits at fixed lanes there) or the voice has running sums */
+			bool noted = false;
+			if (!REPAIR && !SCAN && P.repair_on && !first_group && !is_last_group &&
+			    (int)(cg * T * C) - (int)H >= (int)FAST_REPAIR_SHIFT) {
+				uint32_t at = 0;
+				if (l == 0) at = atomicAdd(&rep[0], 1u);
+				at = uni(at);
+				if (at < FAST_MAX_REPAIR) {
+					if (l == 0) {
+						rep[2 + 2 * at] = cg;
+						rep[3 + 2 * at] = held_rows;
+						atomicOr(&P.pass_flags[FAST_MAX_LEVELS], 1u);
+					}
+					noted = true;
+				}
+			}
+			if (!noted) zero_acc = 1;
 		}
 	}
 	if (__any(zero_acc) && l == 0) atomicOr(&P.info[v].bail, 1u);
@@ -2279,13 +2322,48 @@ __global__ void __launch_bounds__(1024, FK_MINB) fast_kernel(FastParams P) {
 	}
 }
 
+/* The row groups fast_kernel noted (see FAST_REPAIR_SHIFT): same workgroup shape and LDS layout. */
+template <int T>
+__global__ void __launch_bounds__(1024) repair_kernel(FastParams P) {
+	constexpr int NP = 64 * T;
+	constexpr int W = 16;
+	extern __shared__ __align__(16) unsigned char lds[];
+	if (P.pass_flags[FAST_MAX_LEVELS] == 0) return; /* the usual case */
+	const int tid = threadIdx.x;
+	const int w = (int)uni((uint32_t)tid >> 6);
+	const int l = tid & 63;
+	HerpC23 *t23 = (HerpC23 *)lds;
+	HerpC01 *t01 = (HerpC01 *)(lds + (size_t)P.n_tabs * WAVE_LEN * sizeof(HerpC23));
+	unsigned char *areas = lds + (size_t)P.n_tabs * WAVE_LEN * (sizeof(HerpC23) + sizeof(HerpC01));
+	const size_t area_bytes = (size_t)P.n_fast * NP * sizeof(float) + (size_t)P.max_steps * sizeof(unsigned long long);
+	float *slots = (float *)(areas + (size_t)w * area_bytes) + l;
+	unsigned long long *carry = (unsigned long long *)(areas + (size_t)w * area_bytes + (size_t)P.n_fast * NP * sizeof(float));
+	for (uint32_t t = 0; t < P.n_tabs; ++t) {
+		const uint32_t wave = P.wave_of_tab[t];
+		const uint4 *s23 = (const uint4 *)(P.g_c23 + (size_t)wave * WAVE_LEN);
+		uint4 *d23 = (uint4 *)(t23 + (size_t)t * WAVE_LEN);
+		for (uint32_t i = tid; i < WAVE_LEN; i += 64 * W) d23[i] = s23[i];
+		const uint2 *s01 = (const uint2 *)(P.g_c01 + (size_t)wave * WAVE_LEN);
+		uint2 *d01 = (uint2 *)(t01 + (size_t)t * WAVE_LEN);
+		for (uint32_t i = tid; i < WAVE_LEN; i += 64 * W) d01[i] = s01[i];
+	}
+	__syncthreads();
+	/* one wave per voice with noted groups */
+	for (uint32_t v = blockIdx.x * W + (uint32_t)w; v < P.n_voices; v += gridDim.x * W) {
+		if (uni(P.repair[(size_t)v * FAST_REPAIR_WORDS]) == 0) continue;
+		const FastInfo fi = P.info[v];
+		if (uni(fi.total) == 0 || uni(fi.seq) != 0) continue;
+		fast_voice<T, false, true>(P, v, fi, slots, carry, t23, t01, l, 1u, 0u);
+	}
+}
+
 /* Apply the closed forms to the operator state, or hand the whole segment
  * to the block loop when a chunk had to bail out. */
 __global__ void __launch_bounds__(64) finalize_kernel(FastParams P) {
 	/* one thread per (voice, operator); the voice's own bookkeeping goes to its operator 0 */
 	const uint32_t gid = blockIdx.x * 64 + threadIdx.x;
 	const uint32_t v = gid / P.max_ops, i = gid % P.max_ops;
-	if (gid < FAST_MAX_LEVELS && P.pass_flags) P.pass_flags[gid] = 0; /* for the next segment's analyze_kernel */
+	if (gid <= FAST_MAX_LEVELS && P.pass_flags) P.pass_flags[gid] = 0; /* for the next segment's kernels */
 	if (v >= P.n_voices) return;
 	const FastInfo fi = P.info[v];
 	const VoiceDesc vd = P.voices[v];
@@ -2909,10 +2987,13 @@ public:
 				fp.scan = scan_.p;
 			}
 			if (!pass_flags_.p) {
-				if (!pass_flags_.ensure(FAST_MAX_LEVELS, err)) return false;
+				if (!pass_flags_.ensure(FAST_MAX_LEVELS + 1, err)) return false;
 				HIP_OK(hipMemsetAsync(pass_flags_.p, 0, pass_flags_.cap * sizeof(uint32_t), stream_));
 			}
 			fp.pass_flags = pass_flags_.p;
+			if (!repair_.ensure((size_t)seg.n_voices * FAST_REPAIR_WORDS, err)) return false;
+			fp.repair = repair_.p;
+			fp.repair_on = getenv("SAU_AMD_NO_REPAIR") ? 0u : 1u;
 			fp.max_ops = seg.max_ops; fp.max_steps = fmax_steps; fp.np = 64; fp.rows = FT;
 			fp.enable = use_fast ? 1u : 0u;
 			memcpy(fp.wc, wconst_, sizeof wconst_);
@@ -2976,6 +3057,21 @@ public:
 					launch_fast(FAST_MAX_LEVELS + 1);
 				} else {
 					launch_fast(0);
+				}
+				{ /* row groups noted for a second evaluation: returns at once when there are none */
+					const void *rk = FT == 8 ? (const void *)repair_kernel<8> : FT == 4 ? (const void *)repair_kernel<4>
+					                                                                    : (const void *)repair_kernel<2>;
+					static size_t rconfigured[3] = {0, 0, 0};
+					size_t &rconf = rconfigured[FT == 8 ? 2 : FT == 4 ? 1 : 0];
+					if (flds > rconf) {
+						HIP_OK(hipFuncSetAttribute(rk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+						rconf = flds;
+					}
+					const uint32_t rgrid = (seg.n_voices + 15) / 16 < 64 ? (seg.n_voices + 15) / 16 : 64;
+					fp.mode = 0;
+					if (FT == 8) hipLaunchKernelGGL((repair_kernel<8>), dim3(rgrid), dim3(1024), flds, stream_, fp);
+					else if (FT == 4) hipLaunchKernelGGL((repair_kernel<4>), dim3(rgrid), dim3(1024), flds, stream_, fp);
+					else hipLaunchKernelGGL((repair_kernel<2>), dim3(rgrid), dim3(1024), flds, stream_, fp);
 				}
 				if (tf) (void)hipEventRecord(tf->b, stream_);
 			}
@@ -3217,7 +3313,7 @@ private:
 	DevBuf<uint32_t> fdone_, worklist_, work_count_;
 	DevBuf<unsigned char> fsteps_, flines_, faux_;
 	DevBuf<unsigned long long> scan_;
-	DevBuf<uint32_t> pass_flags_;
+	DevBuf<uint32_t> pass_flags_, repair_;
 	hipEvent_t fetch_ev_[2] = {nullptr, nullptr};
 	int dev_ = 0;
 	std::map<void *, size_t> host_blocks_; /* alloc_host() blocks and their pool sizes */

@@ -367,3 +367,43 @@ def test_two_generators_alternately_on_device(sa, oracle):
     for i in range(2):
         got = np.concatenate(outs[i])
         assert len(got) == len(want[i]) and (got == want[i]).all()
+
+
+def _through_zero_bank(n, seconds):
+    """Slow carriers under slow, deep PM: the phase step passes through zero twice per modulator
+    cycle and changes by only a few units per sample there, so exactly repeated phases
+    (wosc.h:251-252: the output holds) happen every few seconds per voice."""
+    from saugns_amd.voicebank import Op, Line
+    voices = []
+    for i in range(n):
+        m = Op("sin", freq=Line(0.5, ratio=True), amp=vb._f32(0.7 + 0.3 * ((i * 7) % 16) / 16.0))
+        voices.append(Op("sin", freq=vb._num(".4f", 0.8 + i * 0.0131), amp=1.0, time_ms=seconds * 1000,
+                         mods={POP_PMOD: [m]}))
+    return vb.build_program(voices)
+
+
+@pytest.mark.gpu
+def test_repeated_phases_at_row_starts_stay_on_the_fast_path(sa, oracle):
+    """Hundreds of exactly repeated phases, some of them on the first lane an operator is defined
+    in: bit-exact, and made good by repair_kernel (the row group once more, shifted) -- no voice
+    is handed to the block loop (which would take milliseconds per voice here)."""
+    oracle.oracle().ora_set_fastmath_forms(1)
+    prg = _through_zero_bank(256, 20)
+    want = oracle.oracle_render(prg.ptr, RATE, False)
+    b = sa.Batch([prg], RATE)
+    b.set_timing(2)
+    got = b.render(stereo=False, chunk=441000)[0]
+    t = b.timing_ex()
+    assert len(got) == len(want) and (got == want).all()
+    assert t["block_ms"] < 1.0, t
+    # the case is real: without the repair pass some voices do go to the block loop (still bit-exact)
+    os.environ["SAU_AMD_NO_REPAIR"] = "1"
+    try:
+        b = sa.Batch([prg], RATE)
+        b.set_timing(2)
+        got = b.render(stereo=False, chunk=441000)[0]
+        t = b.timing_ex()
+    finally:
+        del os.environ["SAU_AMD_NO_REPAIR"]
+    assert (got == want).all()
+    assert t["block_ms"] > 1.0, t
