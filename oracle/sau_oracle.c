@@ -1239,7 +1239,12 @@ static void rasg_run_selfmod(Op *n, size_t len, float *main_buf,
 		}
 		float s = shape_val(line, phase, a, b);
 		main_buf[i] = s;
-		n->fb_s = (n->fb_s + s + n->prev_s) * 0.5f;
+		/* rasg.h:277 writes (fb_s + s + prev_s) * 0.5f; every one of the six compiled
+		 * sauRasG_map_*_s loops of the reference build (-ffast-math) adds the two carried
+		 * values first -- one ulp apart at times, which the hashed line shapes
+		 * (uwh, ncl, nhl) turn into a different sample */
+		if (g_fm_forms) n->fb_s = ((n->fb_s + n->prev_s) + s) * 0.5f;
+		else n->fb_s = (n->fb_s + s + n->prev_s) * 0.5f;
 		n->prev_s = s;
 	}
 }

@@ -830,7 +830,7 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 								phase -= (float)cycle_adj;
 								float sv = ras_sample(rp, cycle, phase);
 								scratch[e] = sv;
-								fb_s = (fb_s + sv + prev_s) * 0.5f;
+								fb_s = ((fb_s + prev_s) + sv) * 0.5f; /* the reference build's association (see the oracle) */
 								prev_s = sv;
 							}
 							op->fb_s = fb_s;

@@ -209,7 +209,7 @@ struct SeqBackend : public Backend {
 								phase -= (float)adj;
 								float sv = ras_sample(rp, cycle, phase);
 								s[j] = sv;
-								op.fb_s = (op.fb_s + sv + op.prev_s) * 0.5f;
+								op.fb_s = ((op.fb_s + op.prev_s) + sv) * 0.5f;
 								op.prev_s = sv;
 							}
 						}

@@ -407,3 +407,46 @@ def test_repeated_phases_at_row_starts_stay_on_the_fast_path(sa, oracle):
         del os.environ["SAU_AMD_NO_REPAIR"]
     assert (got == want).all()
     assert t["block_ms"] > 1.0, t
+
+
+@pytest.mark.parametrize("wave", WAVES)
+def test_wave_types_modulated_and_fed_back(sa, oracle, wave):
+    """SURVEY 8c fixture list: each wave type x {plain, PM, self-modulation} (plain: test_wave_types)."""
+    m = vb.Op(wave, freq=vb.Line(2.0, ratio=True), amp=0.6)
+    check(sa, oracle, [vb.Op(wave, freq=277.2, time_ms=60, phase=0.2, mods={POP_PMOD: [m]})])
+    check(sa, oracle, [vb.Op(wave, freq=277.2, time_ms=60, pm_a=0.4)])
+    inner = vb.Op(wave, freq=vb.Line(3.0, ratio=True), amp=0.5, pm_a=0.3)
+    check(sa, oracle, [vb.Op(wave, freq=138.6, time_ms=60, mods={POP_PMOD: [inner]})])
+
+
+def test_noise_types(sa, oracle):
+    """The seven noise generators (noise.h:41-185), as carriers and as phase modulators."""
+    from saugns_amd.api import POPT_NOISE
+    for nz in range(7):
+        for seed in (0, 1, 0x9e3779b9):
+            check(sa, oracle, [vb.Op(amp=0.7, time_ms=40, op_type=POPT_NOISE, noise=nz, seed=seed)], chunk=700)
+        n = vb.Op(amp=0.2, op_type=POPT_NOISE, noise=nz, seed=7)
+        check(sa, oracle, [vb.Op("sin", freq=300.0, time_ms=40, mods={POP_PMOD: [n]})])
+
+
+@pytest.mark.parametrize("line", LINES)
+def test_r_oscillator_options(sa, oracle, line):
+    """R oscillator: every line shape x segment function x a spread of function flags
+    (rasg.h:299-743), plain, as a PM source with PM of its own, and self-modulated
+    (rasg.h:242-294). tests/test_oracle.py pins the same grid against the compiled reference."""
+    from saugns_amd.api import POPT_RASEG
+    oracle.oracle().ora_set_fastmath_forms(1)
+    for func in range(6):
+        voices = []
+        for k, flags in enumerate((0, 1, 2, 4, 8, 16, 9, 25, 31)):
+            voices.append(vb.Op(freq=180.0 + 31.0 * k, amp=0.8, time_ms=25 + k, op_type=POPT_RASEG,
+                                seed=12345 + k, ras=(line, func, flags)))
+        check(sa, oracle, voices, stereo=True, chunk=900)
+        m = vb.Op("sin", freq=vb.Line(0.5, ratio=True), amp=0.4)
+        r = vb.Op(freq=vb.Line(2.0, ratio=True), amp=0.6, op_type=POPT_RASEG, seed=99, ras=(line, func, 9),
+                  mods={POP_PMOD: [m]})
+        check(sa, oracle, [vb.Op("sin", freq=220.0, time_ms=40, mods={POP_PMOD: [r]})])
+        fed_back = [vb.Op(freq=150.0 + 17.0 * k, amp=0.7, time_ms=40, op_type=POPT_RASEG, seed=5 + flags,
+                          ras=(line, func, flags), pm_a=(0.5, 1.5)[k & 1])
+                    for k, flags in enumerate((0, 1, 2, 4, 8, 16, 9, 25, 31))]
+        check(sa, oracle, fed_back, chunk=1100)

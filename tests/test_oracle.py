@@ -149,3 +149,25 @@ def test_r_oscillator_options_vs_reference(oracle):
                 assert len(a) == len(b)
                 worst = max(worst, int(np.abs(a.astype(np.int32) - b.astype(np.int32)).max()))
     assert worst <= 1
+
+
+def test_r_oscillator_self_modulation_vs_reference(oracle):
+    """R oscillator with feedback (rasg.h:242-294): every line shape x function x flag spread x two
+    feedback amounts, bit-exact against the compiled reference. The hashed line shapes (uwh, ncl,
+    nhl) turn a one-ulp difference of the carried feedback value into a different sample, which is
+    how the reference build's association of `fb_s + s + prev_s` was found."""
+    if not oracle.have_ref():
+        pytest.skip("compiled reference not present")
+    from saugns_amd import voicebank as vb
+    from saugns_amd.api import LINES, POPT_RASEG
+    oracle.oracle().ora_set_fastmath_forms(2)
+    for line in LINES:
+        for func in range(6):
+            for flags in (0, 1, 2, 4, 8, 16, 9, 25, 31):
+                for pma in (0.5, 1.5):
+                    v = vb.Op(freq=150.0, amp=0.7, time_ms=40, op_type=POPT_RASEG, seed=5 + flags,
+                              ras=(line, func, flags), pm_a=pma)
+                    prg = vb.build_program([v])
+                    a = oracle.oracle_render(prg.ptr, 44100, True)
+                    b = oracle.ref_render(prg.ptr, 44100, True)
+                    assert len(a) == len(b) and max_diff(a, b) == 0, (line, func, flags, pma)
