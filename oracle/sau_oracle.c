@@ -1182,8 +1182,15 @@ static void rasg_run(Op *n, size_t len, float *main_buf, float *end_a,
 			(flags & (SAU_RAS_O_HALFSHAPE | SAU_RAS_O_ZIGZAG)) ? 1.f : g_perlin_amp[line];
 		for (size_t i = 0; i < len; ++i) {
 			float phase = main_buf[i];
-			end_a[i] *= perlin_amp * phase;
-			end_b[i] *= perlin_amp * (phase - 1.f);
+			if (g_fm_forms) {
+				/* the reference build's block loop (vector body and scalar tail):
+				 * (a * phase) * amp, (b * amp) * (phase - 1) */
+				end_a[i] = (end_a[i] * phase) * perlin_amp;
+				end_b[i] = (end_b[i] * perlin_amp) * (phase - 1.f);
+			} else {
+				end_a[i] *= perlin_amp * phase;
+				end_b[i] *= perlin_amp * (phase - 1.f);
+			}
 		}
 	}
 	if (flags & SAU_RAS_O_HALFSHAPE) {

@@ -804,7 +804,7 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 					if (!selfmod) {
 #pragma unroll
 						for (int k = 0; k < T; ++k)
-							if (owned[k]) s[k] = ras_sample(rp, cyc[k], phf[k]); /* rasg.h:692-743 */
+							if (owned[k]) s[k] = ras_sample(rp, cyc[k], phf[k], true); /* rasg.h:692-743 */
 					} else {
 						/* rasg.h:242-280 per-sample form with feedback */
 						u32_alias *tmp = (u32_alias *)(slots + (size_t)st.tmp * G::SLOT);
@@ -828,7 +828,7 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 								int32_t cycle_adj = (int32_t)floorf(phase);
 								uint32_t cycle = tmp[e] + (uint32_t)cycle_adj;
 								phase -= (float)cycle_adj;
-								float sv = ras_sample(rp, cycle, phase);
+								float sv = ras_sample(rp, cycle, phase, false);
 								scratch[e] = sv;
 								fb_s = ((fb_s + prev_s) + sv) * 0.5f; /* the reference build's association (see the oracle) */
 								prev_s = sv;
@@ -2141,7 +2141,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 						uint32_t cyc;
 						float phf;
 						ras_split(cp, cyc, phf);
-						s[k] = ras_sample(rp, cyc, phf);
+						s[k] = ras_sample(rp, cyc, phf, true);
 					}
 				} else if (type == OT_NOISE) {
 					const uint32_t nz = (f.type >> 8) & 0xff;

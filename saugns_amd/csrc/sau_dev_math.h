@@ -747,14 +747,22 @@ SAU_HD void ras_ends(const RasParams &c, uint32_t cycle, float &a, float &b) {
 	}
 }
 
-/* One output value from cycle index and in-cycle phase in [0,1):
- * rasg.h:692-743 (block form) == rasg.h:254-275 (per-sample form). */
-SAU_HD float ras_sample(const RasParams &c, uint32_t cycle, float phase) {
+/* One output value from cycle index and in-cycle phase in [0,1): rasg.h:692-743 (block form,
+ * `block` true) or rasg.h:254-275 (per-sample form of the feedback loop). The two differ in the
+ * reference build only in how -ffast-math associated the Perlin scaling: the block loop (vector
+ * body and scalar tail alike) computes (a * phase) * amp and (b * amp) * (phase - 1), the six
+ * per-sample loops keep the source's a * (amp * phase) and b * (amp * (phase - 1)). */
+SAU_HD float ras_sample(const RasParams &c, uint32_t cycle, float phase, bool block) {
 	float a, b;
 	ras_ends(c, cycle, a, b);
 	if (c.flags & RO_PERLIN) {
-		a *= c.perlin_amp * phase;
-		b *= c.perlin_amp * (phase - 1.f);
+		if (block) {
+			a = (a * phase) * c.perlin_amp;
+			b = (b * c.perlin_amp) * (phase - 1.f);
+		} else {
+			a *= c.perlin_amp * phase;
+			b *= c.perlin_amp * (phase - 1.f);
+		}
 	}
 	if (c.flags & RO_HALFSHAPE) {
 		float mx = a < b ? b : a;

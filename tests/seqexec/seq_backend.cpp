@@ -200,14 +200,14 @@ struct SeqBackend : public Backend {
 							op.cycle_phase += (uint64_t)rint64(coeff * fv[j]);
 							uint32_t cyc; float ph;
 							ras_split(cp, cyc, ph);
-							if (!selfmod) s[j] = ras_sample(rp, cyc, ph);
+							if (!selfmod) s[j] = ras_sample(rp, cyc, ph, true);
 							else { /* rasg.h:242-280 */
 								float pm_a = op.fb_s * pv[j] * 0.5f;
 								float phase = ph + pm_a;
 								int32_t adj = (int32_t)floorf(phase);
 								uint32_t cycle = cyc + (uint32_t)adj;
 								phase -= (float)adj;
-								float sv = ras_sample(rp, cycle, phase);
+								float sv = ras_sample(rp, cycle, phase, false);
 								s[j] = sv;
 								op.fb_s = ((op.fb_s + op.prev_s) + sv) * 0.5f;
 								op.prev_s = sv;
