@@ -197,7 +197,7 @@ def test_running_sum_phases_across_runs(sa, oracle, chunk):
 def _random_voice(rng, depth=0):
     """A random operator tree: every modulator list kind, ramps on any line, ratio and absolute
     frequencies, operators shorter than their carrier, now and then self-modulation."""
-    lists = [POP_PMOD, POP_FMOD, POP_AMOD, POP_RAMOD, POP_RFMOD, POP_FPMOD]
+    lists = [POP_PMOD, POP_FMOD, POP_AMOD, POP_RAMOD, POP_RFMOD, POP_FPMOD, POP_APMOD]
     shape = lambda: LINES[int(rng.integers(len(LINES)))]
     if depth == 0:
         f = float(rng.uniform(60, 900))
@@ -221,20 +221,21 @@ def _random_voice(rng, depth=0):
         kw["amp2"] = float(rng.uniform(0, 1))
     if POP_RFMOD in mods:
         kw["freq2"] = float(rng.uniform(60, 900)) if depth == 0 else vb.Line(float(rng.uniform(0.5, 3)), ratio=True)
-    if rng.random() < 0.08:
-        kw["pm_a"] = float(rng.uniform(0.1, 0.9))
+    if rng.random() < 0.08 or POP_APMOD in mods:  # feedback, constant or ramped amount
+        p0 = float(rng.uniform(0.1, 0.9))
+        kw["pm_a"] = vb.Line(p0, goal=float(rng.uniform(0, 1.5)), shape=shape()) if rng.random() < 0.3 else p0
     time_ms = int(rng.integers(40, 160)) if depth == 0 else (int(rng.integers(10, 120)) if rng.random() < 0.2 else None)
     if depth == 0 and rng.random() < 0.35:  # carrier pan, held or ramped
         p0 = float(rng.uniform(-1, 1))
         kw["pan"] = vb.Line(p0, goal=float(rng.uniform(-1, 1)), shape=shape()) if rng.random() < 0.6 else p0
     kind = rng.random()
-    if kind < 0.15 and "pm_a" not in kw:  # R oscillator: random line shape, function and function flags
+    if kind < 0.15:  # R oscillator: random line shape, function and function flags
         kw.update(op_type=POPT_RASEG, seed=int(rng.integers(1 << 32)),
                   ras=(LINES[int(rng.integers(len(LINES)))], int(rng.integers(6)), int(rng.integers(32))))
-    elif kind < 0.22 and depth > 0 and not mods:  # noise source (all but the recurrent red noise)
+    elif kind < 0.22 and depth > 0 and not mods:  # noise source
         kw.pop("freq2", None)
         return vb.Op(amp=amp, time_ms=time_ms, op_type=POPT_NOISE, seed=int(rng.integers(1 << 32)),
-                     noise=int(rng.choice([0, 1, 2, 3, 5, 6])), **{k: v for k, v in kw.items() if k == "amp2"})
+                     noise=int(rng.integers(7)), **{k: v for k, v in kw.items() if k == "amp2"})
     return vb.Op(WAVES[int(rng.integers(len(WAVES)))], freq=freq, amp=amp, time_ms=time_ms,
                  phase=float(rng.uniform(0, 1)), mods=mods, **kw)
 
