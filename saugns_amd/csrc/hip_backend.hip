@@ -1054,11 +1054,13 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 							slot_put<W, T>(out, w, p0 + k, 0.f);
 					}
 				}
-				if (depth == 0) {
+				if (depth == 0 && st.op == vd.carr_local) {
 					/* carrier finished: voice-level steps run for its length */
 					cur_len = len;
 					if (len == 0) block_ended = true; /* generator.c:842 */
 				} else {
+					/* (a pan modulator ending at the voice's level gives the length back to
+					 * the steps after it: generator.c:762-771 run them for the carrier's) */
 					cur_len = outer;
 				}
 				if (tid == 0 && !inf) op->time -= len;

@@ -280,7 +280,9 @@ struct SeqBackend : public Backend {
 						op.time -= len;
 					}
 					--depth;
-					if (depth == 0) { cur_len = len; if (len == 0) ended = true; }
+					/* the carrier's end sets the length of the voice-level steps (generator.c:839-846);
+					 * a pan modulator ending at this level gives the length back (generator.c:762-771) */
+					if (depth == 0 && st.op == vd.carr_local) { cur_len = len; if (len == 0) ended = true; }
 					else cur_len = stack[depth];
 				}
 			}

@@ -6,7 +6,7 @@ import pytest
 
 from conftest import max_diff
 from saugns_amd import voicebank as vb
-from saugns_amd.api import (LINES, POP_AMOD, POP_APMOD, POP_FMOD, POP_FPMOD, POP_PMOD,
+from saugns_amd.api import (LINES, POP_AMOD, POP_APMOD, POP_CAMOD, POP_FMOD, POP_FPMOD, POP_PMOD,
                             POP_RAMOD, POP_RFMOD, POPT_NOISE, POPT_RASEG, WAVES)
 
 pytestmark = pytest.mark.gpu
@@ -216,6 +216,8 @@ def _random_voice(rng, depth=0):
         for use in lists:
             if rng.random() < (0.35 if depth == 0 else 0.2):
                 mods[use] = [_random_voice(rng, depth + 1) for _ in range(int(rng.integers(1, 3)))]
+    if depth == 0 and rng.random() < 0.25:  # pan modulators (generator.c:749-788)
+        mods[POP_CAMOD] = [_random_voice(rng, depth + 1) for _ in range(int(rng.integers(1, 3)))]
     kw = {}
     if POP_RAMOD in mods:
         kw["amp2"] = float(rng.uniform(0, 1))
@@ -451,3 +453,18 @@ def test_r_oscillator_options(sa, oracle, line):
                           ras=(line, func, flags), pm_a=(0.5, 1.5)[k & 1])
                     for k, flags in enumerate((0, 1, 2, 4, 8, 16, 9, 25, 31))]
         check(sa, oracle, fed_back, chunk=1100)
+
+
+def test_pan_modulators(sa, oracle):
+    """Pan modulator lists (generator.c:749-788): lasting as long as the carrier, shorter (the voice
+    goes on with the pan line alone), longer, nested, beside a pan ramp; stereo and mono."""
+    for mod_ms in (None, 30, 70, 200):
+        m = vb.Op("spa", freq=vb.Line(1.0, ratio=True), amp=0.48, time_ms=mod_ms)
+        inner = vb.Op("sin", freq=vb.Line(3.0, ratio=True), amp=0.5, time_ms=50)
+        m2 = vb.Op("sin", freq=7.0, amp=0.3, mods={POP_PMOD: [inner]})
+        voices = [vb.Op("tri", freq=144.3, amp=0.7, time_ms=136, pan=0.25, mods={POP_CAMOD: [m]}),
+                  vb.Op("sin", freq=300.0, amp=0.5, time_ms=100, pan=vb.Line(-0.5, goal=0.5, shape="cos"),
+                        mods={POP_CAMOD: [m2, vb.Op("saw", freq=2.0, amp=0.2, time_ms=mod_ms)]})]
+        for stereo in (True, False):
+            check(sa, oracle, voices, stereo=stereo, chunk=4000000)
+            check(sa, oracle, voices, stereo=stereo, chunk=777)

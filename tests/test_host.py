@@ -238,3 +238,21 @@ def test_two_generators_alternately(sa, oracle, seqexec):
         g.close()
     for i in range(2):
         assert max_diff(np.concatenate(outs[i]), want[i]) == 0
+
+
+def test_pan_modulator_shorter_than_its_carrier(sa, oracle, seqexec):
+    """generator.c:762-771: pan modulators run for the carrier's length and add nothing once their
+    own time is over; the voice goes on with the pan line alone (the steps after a pan modulator
+    get the carrier's length back)."""
+    from saugns_amd import voicebank
+    from saugns_amd.voicebank import Op, Line
+    from saugns_amd.api import POP_CAMOD
+    oracle.oracle().ora_set_fastmath_forms(1)
+    for mod_ms in (None, 30, 70, 200):
+        m = Op("spa", freq=Line(1.0, ratio=True), amp=0.48, time_ms=mod_ms)
+        c = Op("tri", freq=144.3, amp=0.7, time_ms=136, pan=0.25, mods={POP_CAMOD: [m]})
+        prg = voicebank.build_program([c])
+        want = oracle.oracle_render(prg.ptr, 12000, True)
+        for block, chunk in ((1016, 11289), (64, 500)):
+            got = sa.Batch([prg], 12000, backend=seqexec.seq_backend_create(block)).render(stereo=True, chunk=chunk)[0]
+            assert max_diff(got, want) == 0, (mod_ms, block)
