@@ -93,8 +93,10 @@ def build_program(voices, ampmult=1.0, default_mod_ms=1000, updates=()):
     """voices: list of carrier Ops (each with .time_ms) -> BuiltProgram.
 
     updates: later events in the shape the parser gives compound steps (``Wsin f200 t1; f300[g400]``):
-    tuples (at_ms, voice index, Op of that voice's tree, {"freq"|"amp"|"amp2"|"freq2"|"pan": Line,
-    "time_ms": int}); lines with ``state=False`` only set a goal."""
+    tuples (at_ms, voice index, Op of that voice's tree, {"freq"|"amp"|"amp2"|"freq2"|"pan"|"pm_a": Line,
+    "time_ms": int, "wave": name (W) | "noise": index (N) | "ras": (line, func, flags) (R),
+    "phase": cycles, "seed": int, "mods": {list use: [Ops already in the tree, possibly none]}});
+    lines with ``state=False`` only set a goal. What an event may carry: generator.c:283-343."""
     keep = []
     updates = sorted(updates, key=lambda u: u[0])
     events = (SauEvent * (len(voices) + len(updates)))()
@@ -186,10 +188,33 @@ def build_program(voices, ampmult=1.0, default_mod_ms=1000, updates=()):
             od.time.v_ms = t_ms
             od.time.flags = TIMEP_SET
         line_ms = t_ms if t_ms is not None else (op.time_ms if op.time_ms is not None else default_mod_ms)
-        for name, rp in (("amp", False), ("amp2", True), ("freq", False), ("freq2", True), ("pan", False)):
+        for name, rp in (("amp", False), ("amp2", True), ("freq", False), ("freq2", True), ("pan", False),
+                         ("pm_a", False)):
             if name in what:
                 p = _mk_line(keep, what[name], line_ms, rp)
                 setattr(od, name, p)
+        od.mode.ras.word = 0
+        od.mode.ras.alpha = 0
+        if "wave" in what:
+            od.params |= 2  # SAU_POPP_MODE
+            od.mode.main = WAVES.index(what["wave"])
+        if "noise" in what:
+            od.params |= 2
+            od.mode.main = what["noise"]
+        if "ras" in what:
+            od.params |= 2
+            line, func, flags = what["ras"]
+            od.mode.ras.word = LINES.index(line) | ((flags & 0x3f) | (1 << 6) | (1 << 7)) << 8 | (func & 0x3f) << 18
+        if "phase" in what:
+            od.params |= 4  # SAU_POPP_PHASE
+            od.phase = cyclepos(what["phase"])
+        if "seed" in what:
+            od.params |= 8  # SAU_POPP_SEED
+            od.seed = what["seed"]
+        for u, lst in what.get("mods", {}).items():
+            arr = (C.c_uint32 * (1 + len(lst)))(len(lst), *[m._id for m in lst])
+            keep.append(arr)
+            setattr(od, _LIST_FIELDS[u], C.addressof(arr))
         od.use_type = use_of[id(op)]
         od.type = op.op_type
         arr = (SauOpData * 1)(od)

@@ -7,7 +7,7 @@ import pytest
 from conftest import max_diff
 from saugns_amd import voicebank as vb
 from saugns_amd.api import (LINES, POP_AMOD, POP_APMOD, POP_CAMOD, POP_FMOD, POP_FPMOD, POP_PMOD,
-                            POP_RAMOD, POP_RFMOD, POPT_NOISE, POPT_RASEG, WAVES)
+                            POP_RAMOD, POP_RFMOD, POPT_NOISE, POPT_RASEG, POPT_WAVE, WAVES)
 
 pytestmark = pytest.mark.gpu
 RATE = 44100
@@ -284,6 +284,27 @@ def _random_updates(rng, voices):
             if op is carr and rng.random() < 0.5:
                 what["time_ms"] = int(rng.integers(10, 120))
                 t_end = at + what["time_ms"]
+            # what else an event may carry (generator.c:283-343): a new wave / noise / R option
+            # word, a phase or seed reset, a self-modulation amount, replaced modulator lists
+            if rng.random() < 0.25:
+                if op.op_type == POPT_NOISE:
+                    what["noise"] = int(rng.integers(7))
+                elif op.op_type == POPT_RASEG:
+                    what["ras"] = (LINES[int(rng.integers(len(LINES)))], int(rng.integers(6)), int(rng.integers(32)))
+                else:
+                    what["wave"] = WAVES[int(rng.integers(len(WAVES)))]
+            if rng.random() < 0.2 and op.op_type != POPT_NOISE:
+                what["phase"] = float(rng.uniform(0, 1))
+            if rng.random() < 0.15 and op.op_type != POPT_WAVE:
+                what["seed"] = int(rng.integers(1 << 32))
+            if rng.random() < 0.12 and op.op_type != POPT_NOISE and op.pm_a is not None:
+                what["pm_a"] = vb.Line(float(rng.uniform(0, 1)), goal=float(rng.uniform(0, 1)) if rng.random() < 0.5 else None,
+                                      shape=shape())
+            if rng.random() < 0.2 and op.mods:
+                use = sorted(op.mods)[int(rng.integers(len(op.mods)))]
+                if use != POP_CAMOD or op is carr:
+                    keep_n = int(rng.integers(0, len(op.mods[use]) + 1))
+                    what["mods"] = {use: list(op.mods[use][:keep_n])}
             ups.append((at, vi, op, what))
     return ups
 
