@@ -153,20 +153,29 @@ def build_program(voices, ampmult=1.0, default_mod_ms=1000, updates=()):
 
     for v, carr in enumerate(voices):
         assign_ids(carr)
+    # events in time order: a voice may start later (`carrier.start_ms`, as a script's `/t` gives);
+    # at equal times voices come first, then updates, each in the order given
+    timeline = [(getattr(carr, "start_ms", 0) or 0, 0, v) for v, carr in enumerate(voices)] + \
+               [(u[0], 1, k) for k, u in enumerate(updates)]
+    timeline.sort()
+    slot_of_voice = {v: i for i, (_, kind, v) in enumerate(timeline) if kind == 0}
+    slot_of_update = {k: i for i, (_, kind, k) in enumerate(timeline) if kind == 1}
+    time_of_slot = [t for t, _, _ in timeline]
     for v, carr in enumerate(voices):
         ods = []
         emit(carr, POP_CARR, 0, ods)
         arr = (SauOpData * len(ods))(*ods)
         keep.append(arr)
-        ev = events[v]
-        ev.wait_ms = 0
+        i = slot_of_voice[v]
+        ev = events[i]
+        ev.wait_ms = time_of_slot[i] - (time_of_slot[i - 1] if i else 0)
         ev.vo_id = v
         ev.carr_op_id = carr._id
         ev.op_count = 0
         ev.op_data_count = len(ods)
         ev.op_list = None
         ev.op_data = arr
-        dur = max(dur, carr.time_ms)
+        dur = max(dur, time_of_slot[i] + carr.time_ms)
     use_of = {}
 
     def note_uses(op, use):
@@ -177,7 +186,6 @@ def build_program(voices, ampmult=1.0, default_mod_ms=1000, updates=()):
 
     for carr in voices:
         note_uses(carr, POP_CARR)
-    now = 0
     for k, (at_ms, vi, op, what) in enumerate(updates):
         od = SauOpData()
         od.id = op._id
@@ -219,9 +227,9 @@ def build_program(voices, ampmult=1.0, default_mod_ms=1000, updates=()):
         od.type = op.op_type
         arr = (SauOpData * 1)(od)
         keep.append(arr)
-        ev = events[len(voices) + k]
-        ev.wait_ms = at_ms - now
-        now = at_ms
+        i = slot_of_update[k]
+        ev = events[i]
+        ev.wait_ms = time_of_slot[i] - (time_of_slot[i - 1] if i else 0)
         ev.vo_id = vi
         ev.carr_op_id = voices[vi]._id
         ev.op_count = 0

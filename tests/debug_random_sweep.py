@@ -15,6 +15,7 @@ bad = []
 for seed in range(lo, hi):
     rng = np.random.default_rng((5000 if events else 1000) + seed)
     voices = [tu._random_voice(rng) for _ in range(int(rng.integers(1, 4)))]
+    if events: tu._random_starts(rng, voices)
     ups = tu._random_updates(rng, voices) if events else ()
     chunk = int(rng.integers(700, 3000))
     stereo = bool(seed & 1)

@@ -242,6 +242,13 @@ def _random_voice(rng, depth=0):
                  phase=float(rng.uniform(0, 1)), mods=mods, **kw)
 
 
+def _random_starts(rng, voices):
+    """Some voices begin later than the first (a script's timing separators)."""
+    for carr in voices[1:]:
+        if rng.random() < 0.5:
+            carr.start_ms = int(rng.integers(1, 90))
+
+
 def _random_updates(rng, voices):
     """Later events on random operators of random voices: new values and/or new ramps for
     amplitude, frequency or pan, and new durations for carriers (as compound steps give)."""
@@ -254,9 +261,10 @@ def _random_updates(rng, voices):
     shape = lambda: LINES[int(rng.integers(len(LINES)))]
     ups = []
     for vi, carr in enumerate(voices):
-        t_end = carr.time_ms
+        t0 = getattr(carr, "start_ms", 0) or 0
+        t_end = t0 + carr.time_ms
         for _ in range(int(rng.integers(0, 4))):
-            at = int(rng.integers(5, max(6, t_end - 5)))
+            at = int(rng.integers(t0 + 5, max(t0 + 6, t_end - 5)))
             ops = nodes(carr, [])
             op = ops[int(rng.integers(len(ops)))]
             what = {}
@@ -315,6 +323,7 @@ def test_random_graphs_with_later_events(sa, oracle, seed):
     the state every kernel leaves behind must be what the next segment's kernels expect."""
     rng = np.random.default_rng(5000 + seed)
     voices = [_random_voice(rng) for _ in range(int(rng.integers(1, 4)))]
+    _random_starts(rng, voices)
     ups = _random_updates(rng, voices)
     oracle.oracle().ora_set_fastmath_forms(1)
     prg = vb.build_program(voices, updates=ups)

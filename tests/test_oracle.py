@@ -190,6 +190,8 @@ def test_random_operator_graphs_vs_reference(oracle, events):
     for seed in range(60):
         rng = np.random.default_rng((5000 if events else 1000) + seed)
         voices = [tu._random_voice(rng) for _ in range(int(rng.integers(1, 4)))]
+        if events:
+            tu._random_starts(rng, voices)
         ups = tu._random_updates(rng, voices) if events else ()
         prg = vb.build_program(voices, updates=ups)
         a = oracle.oracle_render(prg.ptr, 44100, True)
