@@ -498,3 +498,22 @@ def test_pan_modulators(sa, oracle):
         for stereo in (True, False):
             check(sa, oracle, voices, stereo=stereo, chunk=4000000)
             check(sa, oracle, voices, stereo=stereo, chunk=777)
+
+
+@pytest.mark.parametrize("stereo", [False, True])
+def test_batch_of_different_programs(sa, oracle, stereo):
+    """sauAmd_create_Batch over 24 random programs with their own event timelines, lengths and
+    voice counts: every stream equals its own single render (streams share launches, nothing else)."""
+    oracle.oracle().ora_set_fastmath_forms(1)
+    prgs, wants = [], []
+    for seed in range(24):
+        rng = np.random.default_rng(9000 + seed)
+        voices = [_random_voice(rng) for _ in range(int(rng.integers(1, 4)))]
+        _random_starts(rng, voices)
+        prg = vb.build_program(voices, updates=_random_updates(rng, voices))
+        prgs.append(prg)
+        wants.append(oracle.oracle_render(prg.ptr, RATE, stereo))
+    for chunk in (4000000, 1777):
+        outs = sa.Batch(prgs, RATE).render(stereo=stereo, chunk=chunk)
+        for k, (got, want) in enumerate(zip(outs, wants)):
+            assert len(got) == len(want) and (got == want).all(), (k, chunk)
