@@ -89,7 +89,7 @@ def _mk_line(keep, ln, time_ms, is_r_par=False):
     return C.pointer(s)
 
 
-def build_program(voices, ampmult=1.0, default_mod_ms=1000, updates=()):
+def build_program(voices, ampmult=1.0, default_mod_ms=1000, updates=(), amp_div_voices=True):
     """voices: list of carrier Ops (each with .time_ms) -> BuiltProgram.
 
     updates: later events in the shape the parser gives compound steps (``Wsin f200 t1; f300[g400]``):
@@ -241,7 +241,7 @@ def build_program(voices, ampmult=1.0, default_mod_ms=1000, updates=()):
     prg = SauProgram()
     prg.events = events
     prg.ev_count = len(voices) + len(updates)
-    prg.mode = api.PMODE_AMP_DIV_VOICES
+    prg.mode = api.PMODE_AMP_DIV_VOICES if amp_div_voices else 0
     prg.vo_count = len(voices)
     prg.op_count = next_id[0]
     prg.op_nest_depth = depth_max[0]

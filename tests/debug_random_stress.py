@@ -37,7 +37,8 @@ for seed in range(lo, hi):
     ups = tu._random_updates(rng, voices)
     rate = int(rng.choice([44100, 48000, 22050]))
     stereo = bool(seed & 1)
-    prg = vb.build_program(voices, updates=ups, ampmult=float(rng.choice([1.0, 0.5, 2.0])))
+    prg = vb.build_program(voices, updates=ups, ampmult=float(rng.choice([1.0, 0.5, 2.0])),
+                           amp_div_voices=bool(rng.random() < 0.7))
     for ck in (4000000, int(rng.integers(3000, 30000))):
         want = po.oracle_render(prg.ptr, rate, stereo, chunk=ck)
         got = po.ref_render(prg.ptr, rate, stereo, chunk=ck) if use_ref else sa.Batch([prg], rate).render(stereo=stereo, chunk=ck)[0]
