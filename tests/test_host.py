@@ -256,3 +256,25 @@ def test_pan_modulator_shorter_than_its_carrier(sa, oracle, seqexec):
         for block, chunk in ((1016, 11289), (64, 500)):
             got = sa.Batch([prg], 12000, backend=seqexec.seq_backend_create(block)).render(stereo=True, chunk=chunk)[0]
             assert max_diff(got, want) == 0, (mod_ms, block)
+
+
+def test_program_images_of_random_programs(sa, oracle):
+    """sauAmd_program_serialize / sauAmd_program_load over programs with every operator type,
+    modulator list and event kind: the loaded image renders the same samples (oracle) and
+    serializes to the same bytes again."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_gpu_units as tu
+    from saugns_amd import voicebank as vb
+    oracle.oracle().ora_set_fastmath_forms(1)
+    for seed in range(40):
+        rng = np.random.default_rng(5000 + seed)
+        voices = [tu._random_voice(rng) for _ in range(int(rng.integers(1, 4)))]
+        tu._random_starts(rng, voices)
+        prg = vb.build_program(voices, updates=tu._random_updates(rng, voices))
+        blob = prg.image()
+        back = sa.Program.from_image(blob)
+        assert back.image() == blob, seed
+        a = oracle.oracle_render(prg.ptr, 22050, True)
+        b = oracle.oracle_render(back.ptr, 22050, True)
+        assert len(a) == len(b) and max_diff(a, b) == 0, seed
