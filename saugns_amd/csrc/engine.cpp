@@ -1,6 +1,9 @@
 /* engine.cpp -- host control plane (see engine.h). */
 #include "engine.h"
 #include <algorithm>
+#include <chrono>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace sauengine {
@@ -341,6 +344,7 @@ bool Engine::run(int16_t *const *host_bufs, size_t buf_len, bool stereo,
 	std::vector<uint8_t> touched(total_ops_, 0);
 	uint32_t pos = 0, remaining = total;
 	while (remaining > 0) {
+		const auto t_loop = std::chrono::steady_clock::now();
 		for (Stream &st : streams_) {
 			bool split = false;
 			while (st.event < st.events.size()) {
@@ -357,8 +361,19 @@ bool Engine::run(int16_t *const *host_bufs, size_t buf_len, bool stereo,
 				st.event_pos = 0;
 			}
 		}
+		const bool trace = getenv("SAU_AMD_DEBUG_CREATE") != nullptr;
+		const auto t_ev = std::chrono::steady_clock::now();
+		if (trace && std::chrono::duration<double, std::milli>(t_ev - t_loop).count() > 0.05)
+			fprintf(stderr, "saugns_amd: segment at %u: events applied on the host in %.3f ms\n", pos,
+					std::chrono::duration<double, std::milli>(t_ev - t_loop).count());
 		if (!flush_updates(batch, touched, err)) return false;
+		const auto t_fl = std::chrono::steady_clock::now();
+		const bool was_dirty = plans_dirty_;
 		if (plans_dirty_ && !rebuild_plans(err)) return false;
+		if (trace && was_dirty)
+			fprintf(stderr, "saugns_amd: segment at %u: flush of operator updates %.3f ms, plans %.3f ms\n", pos,
+					std::chrono::duration<double, std::milli>(t_fl - t_ev).count(),
+					std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_fl).count());
 		uint32_t seg = remaining;
 		for (Stream &st : streams_) {
 			if (st.event < st.events.size()) {
