@@ -35,7 +35,7 @@ struct SeqBackend : public Backend {
 	bool init(const BackendConfig &c, std::string &) override {
 		cfg = c;
 		ops.assign(c.op_count ? c.op_count : 1, DevOp());
-		memset(ops.data(), 0, ops.size() * sizeof(DevOp));
+		memset((void *)ops.data(), 0, ops.size() * sizeof(DevOp)); /* as the device buffer starts: all zero bytes */
 		c23.resize(12 * WAVE_LEN); c01.resize(12 * WAVE_LEN);
 		for (uint32_t w = 0; w < 12; ++w)
 			for (uint32_t i = 0; i < WAVE_LEN; ++i)
