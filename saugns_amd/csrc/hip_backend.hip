@@ -1111,6 +1111,7 @@ struct FastInfo {
 	uint32_t n_scan; /* oscillators with running-sum phases (multi-pass voices) */
 	uint32_t levels; /* deepest level among them (1: no sum depends on another) */
 	uint32_t lvl_bits; /* 2 bits per such oscillator, in plan order: its level */
+	uint32_t xlead;  /* lead-in lanes beyond the nesting depth (ratio frequencies below modulated blocks); in H */
 };
 
 struct FastStep;
@@ -1232,9 +1233,37 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 		o.rt_fconst_valid = 0;
 		o.rt_fblk_valid = 0;
 		o.st_phase = 0; /* until the kernels stage into it: see "modulated blocks" below */
+		o.st_prev_phase = 0; /* likewise: extra lead-in of the operator while this kernel and decode_kernel run */
 		if (!(o.flags & OPF_TIME_INF) && o.time < min_time) min_time = o.time;
 	}
 	uint32_t depth = 0, maxd = 0;
+	/* Extra lead-in per block buffer, over what its writer's nesting depth gives: contents exact
+	 * from lane H - depth + 1 + extra. 0..7 in three bit planes over the 256 buffer ids. It
+	 * arises where a ratio frequency multiplies by a modulated frequency block written at a
+	 * smaller depth than the reader's (see "modulated block" below) and travels up the
+	 * operator tree with the data. */
+	unsigned long long x0[4] = {0, 0, 0, 0}, x1[4] = {0, 0, 0, 0}, x2[4] = {0, 0, 0, 0};
+	auto extra_of = [&](uint32_t sl) -> uint32_t {
+		if (sl == NO_SLOT) return 0;
+		const uint32_t q = sl >> 6, sh = sl & 63;
+		const unsigned long long a = q == 0 ? x0[0] : q == 1 ? x0[1] : q == 2 ? x0[2] : x0[3];
+		const unsigned long long b = q == 0 ? x1[0] : q == 1 ? x1[1] : q == 2 ? x1[2] : x1[3];
+		const unsigned long long c = q == 0 ? x2[0] : q == 1 ? x2[1] : q == 2 ? x2[2] : x2[3];
+		return (uint32_t)((a >> sh) & 1ull) | ((uint32_t)((b >> sh) & 1ull) << 1) | ((uint32_t)((c >> sh) & 1ull) << 2);
+	};
+	auto set_extra = [&](uint32_t sl, uint32_t x, bool keep_max) {
+		if (sl == NO_SLOT) return;
+		if (keep_max) { const uint32_t old = extra_of(sl); if (old > x) x = old; }
+		const unsigned long long bit = 1ull << (sl & 63);
+#pragma unroll
+		for (int q = 0; q < 4; ++q)
+			if ((int)(sl >> 6) == q) {
+				x0[q] = (x0[q] & ~bit) | ((x & 1) ? bit : 0ull);
+				x1[q] = (x1[q] & ~bit) | ((x & 2) ? bit : 0ull);
+				x2[q] = (x2[q] & ~bit) | ((x & 4) ? bit : 0ull);
+			}
+	};
+	uint32_t x_carrier = 0;
 	for (uint32_t si = 0; si < vd.plan_len && !bad; ++si) {
 		const Step st = plan[si];
 		DevOp &o = P.ops[ids[st.op]];
@@ -1269,8 +1298,12 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 		 * H - wd + 1). Whoever multiplies by it -- ratio lines of operators nested in its
 		 * owner, directly or through blocks derived from it -- must not need it earlier:
 		 * a reader at depth d sums increments from lane H - d + 1 on (one earlier when it
-		 * scales a phase modulator by its frequency). Deeper readers: block loop.
+		 * scales a phase modulator by its frequency). A deeper reader gets that many lanes of
+		 * extra lead-in (and so does everything that consumes its output, up to the carrier:
+		 * the voice's rows get H + extra lead-in lanes).
 		 * (st_phase holds wd while this kernel runs; 0: not a modulated block.) */
+		uint32_t x_step = 0; /* this step's output: extra lead-in of what it reads */
+		if (st.kind == ST_LERP) x_step = extra_of(st.freq) > extra_of(st.pm) ? extra_of(st.freq) : extra_of(st.pm);
 		if ((st.kind == ST_OSC || st.kind == ST_LERP) && st.out != NO_SLOT && st.out >= FSLOT_BASE) {
 			const uint32_t ow = block_owner(plan, si, st.out);
 			if (ow != 0xff) {
@@ -1293,7 +1326,10 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 						const uint32_t ow = block_owner(plan, si, st.fmul);
 						const uint32_t wd = ow != 0xff ? P.ops[ids[ow]].st_phase : 0u;
 						if (wd) {
-							if (depth + (op_has_fpm(plan, vd.plan_len, st.op) ? 1u : 0u) > wd) bad = true;
+							const uint32_t need = depth + (op_has_fpm(plan, vd.plan_len, st.op) ? 1u : 0u);
+							/* the block is exact from lane H - wd + 1 + its own extra; this reader
+							 * would sum from lane H - need + 1 */
+							x_step = (need > wd ? need - wd : 0u) + extra_of(st.fmul);
 							/* this operator's own block derives from the modulated one */
 							if (st.kind == ST_LINE && st.which == L_FREQ && (o.st_phase == 0 || wd < o.st_phase))
 								o.st_phase = wd;
@@ -1319,6 +1355,29 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 			if (!isconst) seq = true;
 		}
 		if (st.kind == ST_OSC && is_osc && st.freq != NO_SLOT && !o.rt_fconst_valid) seq = true;
+		/* extra lead-in: what this step reads, what its own ratio frequency needs, to what it writes */
+		if (st.kind == ST_LINE) {
+			/* the block made here is as exact as the one it multiplies by; what the operator itself
+			 * needs on top waits in st_prev_phase for its oscillator step */
+			if (x_step > 7) bad = true;
+			set_extra(st.out, extra_of(st.fmul), false);
+			if (st.which == L_FREQ) o.st_prev_phase = x_step;
+		} else if (st.kind == ST_LERP) {
+			if (x_step > 7) bad = true;
+			set_extra(st.out, x_step, true);
+		} else if (st.kind == ST_OSC) {
+			uint32_t x = x_step > o.st_prev_phase ? x_step : o.st_prev_phase; /* its own frequency's need */
+			const uint32_t in[5] = {extra_of(st.freq), extra_of(st.pm), extra_of(st.fpm), extra_of(st.amp), extra_of(st.sm)};
+#pragma unroll
+			for (int k = 0; k < 5; ++k) if (in[k] > x) x = in[k];
+			if (x > 7) bad = true;
+			o.st_prev_phase = x; /* for decode_kernel (the kernels stage into this field only later) */
+			if (st.op == vd.carr_local) x_carrier = x;
+			if (!(st.which & OX_VOICE)) set_extra(st.out, x, (st.flags & SF_LAYER) != 0 || st.out >= FSLOT_BASE);
+		} else if (st.kind == ST_VOICE) {
+			const uint32_t x = extra_of(st.out) > extra_of(st.pm) ? extra_of(st.out) : extra_of(st.pm);
+			if (x > x_carrier) x_carrier = x;
+		}
 		if (st.flags & SF_END) --depth;
 	}
 	/* Two passes suffice when no running sum depends on another one: the per-frame
@@ -1387,10 +1446,10 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 		n_scan_out = n_scan;
 	}
 	FastInfo fi;
-	fi.H = maxd; fi.bail = 0; fi.n_fsteps = 0; fi.seq = seq_kind; fi.n_scan = n_scan_out; fi.levels = levels_out; fi.lvl_bits = lvl_bits_out;
+	fi.H = maxd + x_carrier; fi.xlead = x_carrier; fi.bail = 0; fi.n_fsteps = 0; fi.seq = seq_kind; fi.n_scan = n_scan_out; fi.levels = levels_out; fi.lvl_bits = lvl_bits_out;
 	fi.total = 0;
 	if (seq && !P.seq_enable) bad = true;
-	if (!bad && vd.nops <= P.max_ops && vd.plan_len <= P.max_steps && maxd >= 1 && maxd <= P.np / 2)
+	if (!bad && vd.nops <= P.max_ops && vd.plan_len <= P.max_steps && maxd >= 1 && maxd + x_carrier <= P.np / 2)
 		fi.total = min(min_time, vd.run_len);
 	P.info[v] = fi;
 	P.fast_done[v] = 0;
@@ -1556,7 +1615,11 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 			zero_fill = root_end && !(st.flags & SF_LAYER) && !(st.which & OX_VOICE);
 			keep = zero_fill;
 		}
-		f.kind = (uint32_t)st.kind | ((uint32_t)st.flags << 8) | ((uint32_t)st.which << 16) | (dep << 24);
+		/* nesting depth as the row sees it: lanes of extra lead-in the voice has (analyze_kernel)
+		 * minus those this operator needs itself -- its values count as defined from lane
+		 * H - depth + 1 */
+		const uint32_t eff_dep = dep + P.info[v].xlead - min(P.ops[ids[st.op]].st_prev_phase, P.info[v].xlead);
+		f.kind = (uint32_t)st.kind | ((uint32_t)st.flags << 8) | ((uint32_t)st.which << 16) | (eff_dep << 24);
 		/* block buffers renumbered by liveness (sau_dev_types.h): out, pm, fpm, amp, range end */
 		const FastIds cs = P.fast_ids[(seq ? P.ids_full_ofs : 0u) + vd.plan_ofs + l];
 		f.out_off = cs.out != NO_SLOT ? (uint32_t)cs.out * NP : ~0u;

@@ -519,3 +519,31 @@ def test_batch_of_different_programs(sa, oracle, stereo):
         outs = sa.Batch(prgs, RATE).render(stereo=stereo, chunk=chunk)
         for k, (got, want) in enumerate(zip(outs, wants)):
             assert len(got) == len(want) and (got == want).all(), (k, chunk)
+
+
+def test_ratio_chains_below_modulated_frequencies(sa, oracle):
+    """Ratio-frequency modulators nested deeper than the modulators that write into an ancestor's
+    frequency block (a classic FM patch: vibrato on the carrier, a ratio PM stack under it): the
+    rows get extra lead-in lanes instead of the voice going to the block loop. With frequency-scaled
+    PM (one lane more), range-FM, and an FM'd modulator inside the stack."""
+    def stack(fpm=False):
+        m3 = vb.Op("sin", freq=vb.Line(3.0, ratio=True), amp=0.4)
+        m2 = vb.Op("tri", freq=vb.Line(2.0, ratio=True), amp=0.7, mods={(POP_FPMOD if fpm else POP_PMOD): [m3]})
+        return vb.Op("sin", freq=vb.Line(1.0, ratio=True), amp=0.9, mods={POP_PMOD: [m2]})
+    vib = lambda f, a: vb.Op("sin", freq=f, amp=a)
+    voices = [
+        vb.Op("sin", freq=220.0, time_ms=400, mods={POP_PMOD: [stack()], POP_FMOD: [vib(5.0, 30.0)]}),
+        vb.Op("sin", freq=330.0, time_ms=350, mods={POP_PMOD: [stack(fpm=True)], POP_FMOD: [vib(7.0, 12.0)]}),
+        vb.Op("saw", freq=110.0, freq2=220.0, time_ms=300,
+              mods={POP_PMOD: [stack()], POP_RFMOD: [vb.Op("sin", freq=vb.Line(0.25, ratio=True), amp=1.0)]}),
+    ]
+    inner_fm = vb.Op("sin", freq=vb.Line(0.5, ratio=True), amp=0.8,
+                     mods={POP_FMOD: [vib(3.0, 20.0)], POP_PMOD: [vb.Op("sin", freq=vb.Line(2.0, ratio=True), amp=0.5,
+                           mods={POP_PMOD: [vb.Op("sin", freq=vb.Line(3.0, ratio=True), amp=0.3)]})]})
+    voices.append(vb.Op("sin", freq=180.0, time_ms=300, mods={POP_PMOD: [inner_fm], POP_FMOD: [vib(4.0, 25.0)]}))
+    for chunk in (4000000, 5000, 997):
+        check(sa, oracle, voices, stereo=True, chunk=chunk)
+    b = sa.Batch([vb.build_program(voices)], RATE)
+    b.set_timing(2)
+    b.render(stereo=False, chunk=4000000)
+    assert b.timing_ex()["block_ms"] < 1.0  # none of them needed the block loop
