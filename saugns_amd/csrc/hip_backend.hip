@@ -1446,6 +1446,11 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 		n_scan_out = n_scan;
 	}
 	FastInfo fi;
+	/* Running-sum voices get one more lead-in lane than their data flow needs: a repeated phase on
+	 * the first lane an operator is defined in then spoils nothing that is stored (what it spoils
+	 * climbs one lane per nesting level and ends on the lane before the first stored one), where
+	 * closed-form voices have repair_kernel for that case (see FAST_REPAIR_SHIFT). */
+	if (seq) ++x_carrier;
 	fi.H = maxd + x_carrier; fi.xlead = x_carrier; fi.bail = 0; fi.n_fsteps = 0; fi.seq = seq_kind; fi.n_scan = n_scan_out; fi.levels = levels_out; fi.lvl_bits = lvl_bits_out;
 	fi.total = 0;
 	if (seq && !P.seq_enable) bad = true;
@@ -2107,7 +2112,12 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 								if (!__any(changed)) break;
 							}
 #pragma unroll
-							for (int k = 0; k < T; ++k) held_rows |= __any(held[k]) ? (1u << k) : 0u;
+							for (int k = 0; k < T; ++k) {
+								/* running-sum voices have a lane of slack (analyze_kernel): a hold left on the
+								 * operator's first defined lane is harmless there */
+								if (SCAN && l == p_min) held[k] = false;
+								held_rows |= __any(held[k]) ? (1u << k) : 0u;
+							}
 						}
 						if (is_last_group) {
 							/* the row that holds the segment's last frame stages the state */
