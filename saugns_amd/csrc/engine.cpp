@@ -381,6 +381,29 @@ bool Engine::run(int16_t *const *host_bufs, size_t buf_len, bool stereo,
 				if (wt < seg) seg = wt;
 			}
 		}
+		/* An operator that runs out of time inside a segment leaves its voice to the block loop
+		 * from that frame to the segment's end (the time-parallel path renders a voice up to its
+		 * first such frame); in the next segment it is simply left out. So a long segment ends
+		 * soon after the earliest such frame -- on a grid, so that staggered envelopes cost a
+		 * handful of segments per run, not one each. (The mirrored times are conservative: an
+		 * operator may in fact stop earlier, which costs one superfluous cut.) */
+		constexpr uint32_t EXPIRY_GRID = 8192;
+		if (seg > EXPIRY_GRID) {
+			uint32_t first = seg;
+			for (Stream &st : streams_)
+				for (uint32_t v = st.voice; v < st.voices.size(); ++v) {
+					const VoiceHost &vn = st.voices[v];
+					if (vn.duration == 0 || vn.carr_op >= st.ops.size()) continue;
+					for (uint32_t id : vn.plan.op_ids) {
+						const OpMirror &m = st.ops[id];
+						if (id != vn.carr_op && !m.time_inf && m.time > 0 && m.time < first) first = m.time;
+					}
+				}
+			if (first < seg) {
+				const uint32_t cut = (first + EXPIRY_GRID - 1) / EXPIRY_GRID * EXPIRY_GRID;
+				if (cut < seg) seg = cut;
+			}
+		}
 		for (Stream &st : streams_)
 			if (st.event < st.events.size()) st.event_pos += seg;
 		if (!render_segment(seg, pos, stereo, err)) return false;
