@@ -547,3 +547,31 @@ def test_ratio_chains_below_modulated_frequencies(sa, oracle):
     b.set_timing(2)
     b.render(stereo=False, chunk=4000000)
     assert b.timing_ex()["block_ms"] < 1.0  # none of them needed the block loop
+
+
+@pytest.mark.parametrize("env", [{"SAU_AMD_FAST_ROWS": "2"}, {"SAU_AMD_NO_TWO_PASS": "1"}, {"SAU_AMD_NO_SEQ": "1"},
+                                 {"SAU_AMD_LDS_LIMIT": "65536"}, {"SAU_AMD_MULTI_MIN": "1"}])
+def test_random_graphs_in_other_kernel_configurations(sa, oracle, env):
+    """The random programs with events through the other builds and modes of the kernels: two rows per
+    pass, running sums by one wave in order, no running sums in the time-parallel path at all, a
+    tight LDS budget, single-wave teams in the block loop."""
+    oracle.oracle().ora_set_fastmath_forms(1)
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        for seed in range(100, 124):
+            rng = np.random.default_rng(5000 + seed)
+            voices = [_random_voice(rng) for _ in range(int(rng.integers(1, 4)))]
+            _random_starts(rng, voices)
+            prg = vb.build_program(voices, updates=_random_updates(rng, voices))
+            stereo = bool(seed & 1)
+            chunk = int(rng.integers(700, 3000))
+            want = oracle.oracle_render(prg.ptr, RATE, stereo, chunk=chunk)
+            got = sa.Batch([prg], RATE).render(stereo=stereo, chunk=chunk)[0]
+            assert len(got) == len(want) and (got == want).all(), (seed, env)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
