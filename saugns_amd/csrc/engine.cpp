@@ -140,7 +140,10 @@ bool Engine::handle_event(Stream &st, const EventNode &e, std::vector<OpUpdate> 
 		for (uint32_t l = 0; l < L_COUNT; ++l) {
 			u.line[l] = make_line_update(src[l], srate_);
 			if (src[l]) m.line_set |= (uint8_t)(1u << l);
-			if (src[l] && (src[l]->flags & SAU_LINEP_GOAL)) m.goal_seen = true;
+			if (src[l] && (src[l]->flags & SAU_LINEP_GOAL)) {
+				m.goal_seen = true;
+				if (l == L_FREQ || l == L_FREQ2) m.freq_goal_seen = true;
+			}
 		}
 		line_copy(m.pan, u.line[L_PAN]);
 		if (od->params & SAU_POPP_TIME) {
@@ -237,6 +240,42 @@ bool Engine::rebuild_plans(std::string &err) {
 			all_op_ids_.data(), all_op_ids_.size(), err);
 }
 
+/* How deep running sums may nest in this operator's subtree (see fast_kernel's running sums):
+ * an oscillator whose frequency varies is a running sum one level above the deepest such
+ * oscillator its frequency depends on. Conservative: a frequency sweep ever given counts as still
+ * running, every child as a ratio child. Returns the level of what the operator puts out; `need`
+ * collects the deepest oscillator level. The device takes the exact decision and falls back to
+ * one wave in order when a voice is deeper than the passes launched. */
+uint32_t Engine::estimate_sum_levels(const Stream &st, uint32_t op, uint32_t parent_dep, bool parent_varies,
+		uint32_t &need, uint32_t nest) const {
+	if (op >= st.ops.size() || nest > 64) return 0;
+	const OpMirror &m = st.ops[op];
+	auto count = [](const sauProgramIDArr *a) { return a ? a->count : 0u; };
+	const sauProgramIDArr *fm = m.mods[SAU_POP_N_fmod], *rfm = m.mods[SAU_POP_N_rfmod];
+	uint32_t dep = parent_dep;
+	const bool varies = parent_varies || m.freq_goal_seen || count(fm) || count(rfm);
+	uint32_t out = 0;
+	for (const sauProgramIDArr *lst : {fm, rfm})
+		for (uint32_t i = 0; i < count(lst); ++i) {
+			const uint32_t o = estimate_sum_levels(st, lst->ids[i], parent_dep, parent_varies || m.freq_goal_seen, need, nest + 1);
+			if (o > dep) dep = o;
+			if (o > out) out = o;
+		}
+	const bool osc = m.type == SAU_POPT_N_wave || m.type == SAU_POPT_N_raseg;
+	const uint32_t own = (osc && varies) ? 1 + dep : 0;
+	if (own > need) need = own;
+	if (own > out) out = own;
+	for (int use = 1; use < SAU_POP_NAMED; ++use) {
+		if (use == SAU_POP_N_fmod || use == SAU_POP_N_rfmod) continue;
+		const sauProgramIDArr *lst = m.mods[use];
+		for (uint32_t i = 0; i < count(lst); ++i) {
+			const uint32_t o = estimate_sum_levels(st, lst->ids[i], dep, varies, need, nest + 1);
+			if (o > out) out = o;
+		}
+	}
+	return out;
+}
+
 /* generator.c:854-878 (run_for_time) + 833-846 (run_voice), one segment. */
 bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::string &err) {
 	std::vector<VoiceDesc> descs;
@@ -244,6 +283,7 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 	uint32_t n_main = 1, n_fpool = 0, max_ops = 1, n_pan = 0, max_steps = 1, n_fast = 1, n_fast_full = 0;
 	uint64_t wave_mask = 0;
 	bool maybe_block = false, serial = false, may_scan = false;
+	uint32_t sum_levels = 0;
 	for (size_t s = 0; s < streams_.size(); ++s) {
 		Stream &st = streams_[s];
 		SegmentDesc::Stream &sd = sdescs[s];
@@ -301,6 +341,7 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 			if (voice_block && !vn.plan.no_fast) {
 				n_fast_full = std::max(n_fast_full, vn.plan.n_fast_full);
 				may_scan = true;
+				if (sum_levels < 3) (void)estimate_sum_levels(st, vn.carr_op, 0, false, sum_levels, 0);
 			}
 		}
 		sd.n_voices = (uint32_t)descs.size() - sd.first_voice;
@@ -321,6 +362,7 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 	seg.maybe_block = maybe_block;
 	seg.serial = serial;
 	seg.may_scan = may_scan;
+	seg.sum_levels = sum_levels;
 	return backend_->render(seg, err);
 }
 

@@ -46,6 +46,7 @@ struct SegmentDesc {
 	uint32_t n_fast;          /* max block buffers the time-parallel path needs (fast_slot_compact) */
 	uint32_t n_fast_full;     /* the same with frequency blocks, over voices that may need them */
 	bool may_scan;            /* some voice may have ramped or modulated frequencies (running-sum phases) */
+	uint32_t sum_levels = 2; /* running sums nested that deep may occur (host estimate; the device checks) */
 	uint32_t max_ops;         /* max operators in any active voice */
 	uint32_t max_steps;       /* longest active plan */
 	uint32_t n_pan_rows;
@@ -107,6 +108,7 @@ struct OpMirror { /* host-side knowledge about one operator */
 	const sauProgramIDArr *mods[SAU_POP_NAMED] = {}; /* by use type; [0] unused */
 	uint8_t wave = 0;
 	bool goal_seen = false;           /* some event gave one of its lines a sweep */
+	bool freq_goal_seen = false;      /* ... one of its frequency lines */
 	OpMirror() { pan = LineState{0, 0, 0, 0, 0, 0}; }
 };
 
@@ -182,6 +184,8 @@ private:
 	bool flush_updates(std::vector<OpUpdate> &batch, std::vector<uint8_t> &touched,
 			std::string &err);
 	bool rebuild_plans(std::string &err);
+	uint32_t estimate_sum_levels(const Stream &st, uint32_t op, uint32_t parent_dep, bool parent_varies,
+			uint32_t &need, uint32_t nest) const;
 	bool render_segment(uint32_t len, uint32_t offset, bool stereo, std::string &err);
 
 	Backend *backend_ = nullptr;

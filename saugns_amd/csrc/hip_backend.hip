@@ -1118,7 +1118,8 @@ struct FastStep;
 struct FastLine;
 struct FastAux;
 constexpr uint32_t FAST_MAX_SCAN = 8;   /* oscillators with running-sum phases per multi-pass voice */
-constexpr uint32_t FAST_MAX_LEVELS = 2; /* running sums that depend on running sums: that many sum passes */
+constexpr uint32_t FAST_MAX_LEVELS = 3; /* running sums that depend on running sums: at most that many sum passes
+                                         * (FastParams.sum_levels of them are launched for a segment) */
 /* A repeated phase (the output holds, wosc.h:251-252) on the first lane an operator's values are
  * defined in cannot take the held output from the lane before. What that spoils is exactly the
  * first owned frame of the row (one lane per nesting level upwards). fast_kernel notes such row
@@ -1152,8 +1153,9 @@ struct FastParams {
 	uint32_t enable;      /* 0: leave every voice to the block loop */
 	uint32_t seq_enable;  /* block buffers are sized for frequency blocks: sequential-scan voices allowed */
 	uint32_t ids_full_ofs;/* offset of the with-frequency numbering in fast_ids */
-	uint32_t mode;        /* fast_kernel: 0 the only pass; 1..FAST_MAX_LEVELS: sums of phase increments of that level;
-	                       * FAST_MAX_LEVELS + 1: final pass. scan_kernel: the level whose sums to prefix */
+	uint32_t mode;        /* fast_kernel: 0 the only pass; 1..sum_levels: sums of phase increments of that level;
+	                       * sum_levels + 1: final pass. scan_kernel: the level whose sums to prefix */
+	uint32_t sum_levels;  /* sum passes this segment's launch sequence has (2, or 3 when the host expects that depth) */
 	unsigned long long *scan; /* [n_voices][FAST_MAX_SCAN][scan_groups]: those sums (W: mod 2^32; R: 64 bits), then
 	                           * (scan_kernel) their prefixes */
 	uint32_t scan_groups;
@@ -1427,7 +1429,7 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 						max2(level_of(st.freq), level_of(st.fmul))));
 				if (fvar) {
 					const uint32_t mine = 1 + max2(level_of(st.freq), level_of(st.fmul));
-					if (mine > FAST_MAX_LEVELS || n_scan >= FAST_MAX_SCAN) multi = false;
+					if (mine > P.sum_levels || n_scan >= FAST_MAX_SCAN) multi = false; /* deeper: one wave, in order */
 					else {
 						lvl_bits_out |= mine << (2 * n_scan);
 						if (mine > levels_out) levels_out = mine;
@@ -1441,7 +1443,7 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 		}
 		if (multi && P.scan) {
 			seq_kind = 2;
-			for (uint32_t p = 0; p < levels_out && p < FAST_MAX_LEVELS; ++p) atomicOr(&P.pass_flags[p], 1u);
+			for (uint32_t p = 0; p < levels_out && p < P.sum_levels; ++p) atomicOr(&P.pass_flags[p], 1u);
 		}
 		n_scan_out = n_scan;
 	}
@@ -1873,7 +1875,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 #endif
 			const uint32_t kind = f.kind & 0xff;
 			const uint32_t flags = (f.kind >> 8) & 0xff;
-			const bool sum_pass = SCAN && P.mode != 0 && P.mode <= FAST_MAX_LEVELS;
+			const bool sum_pass = SCAN && P.mode != 0 && P.mode <= P.sum_levels;
 			if (sum_pass && !(f.ramp & (2u << P.mode))) continue; /* not needed for this pass's phase increments */
 			if (kind == ST_OSC) {
 				const uint32_t type = f.type & 0xff;
@@ -2359,7 +2361,7 @@ __global__ void __launch_bounds__(1024, FK_MINB) fast_kernel(FastParams P) {
 	const int w = (int)uni((uint32_t)tid >> 6);
 	const int l = tid & 63;
 	/* a sum pass nobody needs costs a launch, not a table staging */
-	if (SCAN && P.mode != 0 && P.mode <= FAST_MAX_LEVELS && P.pass_flags[P.mode - 1] == 0) return;
+	if (SCAN && P.mode != 0 && P.mode <= P.sum_levels && P.pass_flags[P.mode - 1] == 0) return;
 
 	HerpC23 *t23 = (HerpC23 *)lds;
 	HerpC01 *t01 = (HerpC01 *)(lds + (size_t)P.n_tabs * WAVE_LEN * sizeof(HerpC23));
@@ -2390,7 +2392,7 @@ __global__ void __launch_bounds__(1024, FK_MINB) fast_kernel(FastParams P) {
 	for (; v < NV; v += vstride) {
 		const FastInfo fi = P.info[v];
 		const uint32_t seq_kind = SCAN ? uni(fi.seq) : 0u;
-		if (SCAN && P.mode != 0 && P.mode <= FAST_MAX_LEVELS && (seq_kind != 2 || uni(fi.levels) < P.mode))
+		if (SCAN && P.mode != 0 && P.mode <= P.sum_levels && (seq_kind != 2 || uni(fi.levels) < P.mode))
 			continue; /* a sum pass only concerns multi-pass voices that deep */
 		if (SCAN && seq_kind != 0) fast_voice<T, true>(P, v, fi, slots, carry, t23, t01, l, wpv, cstart);
 		else fast_voice<T, false>(P, v, fi, slots, carry, t23, t01, l, wpv, cstart);
@@ -3066,6 +3068,7 @@ public:
 				HIP_OK(hipMemsetAsync(pass_flags_.p, 0, pass_flags_.cap * sizeof(uint32_t), stream_));
 			}
 			fp.pass_flags = pass_flags_.p;
+			fp.sum_levels = seg.sum_levels >= FAST_MAX_LEVELS ? FAST_MAX_LEVELS : 2u;
 			if (!repair_.ensure((size_t)seg.n_voices * FAST_REPAIR_WORDS, err)) return false;
 			fp.repair = repair_.p;
 			fp.repair_on = getenv("SAU_AMD_NO_REPAIR") ? 0u : 1u;
@@ -3125,11 +3128,11 @@ public:
 				};
 				if (fp.scan) {
 					/* some voice may have running-sum phases: sums per row group, their prefixes, final pass */
-					for (uint32_t pass = 1; pass <= FAST_MAX_LEVELS; ++pass) {
+					for (uint32_t pass = 1; pass <= fp.sum_levels; ++pass) {
 						launch_fast(pass);
 						hipLaunchKernelGGL(scan_kernel, dim3(seg.n_voices), dim3(64), 0, stream_, fp);
 					}
-					launch_fast(FAST_MAX_LEVELS + 1);
+					launch_fast(fp.sum_levels + 1);
 				} else {
 					launch_fast(0);
 				}
