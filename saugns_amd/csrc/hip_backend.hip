@@ -1321,7 +1321,12 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 			if (st.fmul != NO_SLOT) {
 				/* a ramp whose goal and state disagree about being ratios rescales its
 				 * state by the parent's first sample (sau/line.c:358-370): block loop */
-				if ((ls.flags & LP_GOAL) && g_ratio != s_ratio) bad = true;
+				if ((ls.flags & LP_GOAL) && g_ratio != s_ratio) {
+					/* fine when the parent's frequency is one value for the segment: decode_kernel and
+					 * finalize_kernel then apply the rescaling with it */
+					const bool parent_const = st.prov != NO_SLOT && P.ops[ids[st.prov]].rt_fconst_valid != 0;
+					if (!parent_const) bad = true;
+				}
 				if ((s_ratio || ((ls.flags & LP_GOAL) && g_ratio)) && !pconst) {
 					seq = true;
 					if (st.fmul >= FSLOT_BASE) {
@@ -1708,7 +1713,7 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 			LineState ls = o.line[line_step ? st.which : L_AMP];
 			if (line_step || amp_inline) {
 				if (ls.flags & LP_GOAL) {
-					const LineBlock lb = line_begin(ls, P.info[v].total, line_step && have_mul, 1.f);
+					const LineBlock lb = line_begin(ls, P.info[v].total, line_step && have_mul, pconst ? pf : 1.f);
 					fl.sw = lb.sw; fl.goal_len = lb.goal_len; fl.hold = lb.hold; fl.pad = 0;
 					f.ramp = 1;
 					if (lb.mul_goal) fa.flags |= FA_MUL_GOAL;
@@ -1771,7 +1776,7 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 					fa.freq_off = cs.freq != NO_SLOT ? (uint32_t)cs.freq * NP : ~0u;
 				} else {
 					LineState fls = o.line[L_FREQ];
-					const LineBlock lb = line_begin(fls, P.info[v].total, have_mul, 1.f);
+					const LineBlock lb = line_begin(fls, P.info[v].total, have_mul, pconst ? pf : 1.f);
 					fa.fl.sw = lb.sw; fa.fl.goal_len = lb.goal_len; fa.fl.hold = lb.hold;
 					fa.flags |= FA_FVAR_LINE;
 					if (lb.mul_goal) fa.flags |= FA_MUL_GOAL;
@@ -2459,8 +2464,27 @@ __global__ void __launch_bounds__(64) finalize_kernel(FastParams P) {
 		if (!(o.flags & OPF_TIME_INF)) o.time -= total;
 		for (uint32_t ln = 0; ln < L_COUNT; ++ln) {
 			LineState ls = o.line[ln];
-			if (ls.flags & LP_GOAL) (void)line_begin(ls, total, false, 0.f); /* amplitude ramps */
-			else line_advance_hold(ls, total);
+			if (ls.flags & LP_GOAL) {
+				/* a frequency ramp whose goal and state disagree about being ratios rescales its
+				 * state by the parent's frequency (sau/line.c:358-370); such a voice only comes
+				 * this way when that frequency is one value (analyze_kernel) */
+				bool have_mul = false; float mul0 = 0.f;
+				const bool g_ratio = (ls.flags & LP_GOAL_RATIO) != 0, s_ratio = (ls.flags & LP_STATE_RATIO) != 0;
+				if ((ln == L_FREQ || ln == L_FREQ2) && g_ratio != s_ratio) {
+					const Step *plan = P.steps + vd.plan_ofs;
+					for (uint32_t si = 0; si < vd.plan_len; ++si) {
+						const Step st = plan[si];
+						if (st.op != i || st.fmul == NO_SLOT || st.prov == NO_SLOT) continue;
+						if ((st.kind == ST_LINE && st.which == ln) || (st.kind == ST_OSC && ln == L_FREQ)) {
+							have_mul = true; mul0 = P.ops[ids[st.prov]].rt_fconst;
+							break;
+						}
+					}
+				}
+				(void)line_begin(ls, total, have_mul, mul0);
+			} else {
+				line_advance_hold(ls, total);
+			}
 			o.line[ln] = ls;
 		}
 		if (o.type == OT_WAVE) {

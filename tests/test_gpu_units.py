@@ -284,6 +284,11 @@ def _random_updates(rng, voices):
                                        state=bool(rng.random() < 0.6))
                 if what["freq"].goal is None:
                     what["freq"].state = True
+                elif not what["freq"].state and op is not carr and rng.random() < 0.25:
+                    # a goal of the other kind than the state (absolute <-> ratio of the parent): the
+                    # ramp starts from the state rescaled by the parent's frequency (sau/line.c:358-370)
+                    what["freq"].ratio = not ratio
+                    what["freq"].goal = float(rng.uniform(50, 800)) if ratio else float(rng.choice([0.5, 1.0, 2.0, 3.0]))
             elif op is carr:
                 what["pan"] = vb.Line(float(rng.uniform(-1, 1)), goal=float(rng.uniform(-1, 1)) if rng.random() < 0.6 else None,
                                       shape=shape())
