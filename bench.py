@@ -184,7 +184,7 @@ def main():
         # cannot be collected from inside this process, so null when the workload differs
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_l_pmc_summary.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_m_pmc_summary.json")))
             wl = pmc["workload"]
             if wl["voices"] == args.voices and wl["frames_per_step"] == args.frames:
                 k = [v for n, v in pmc["kernels"].items() if n.startswith("sauhip::fast_kernel<")]
