@@ -3323,6 +3323,17 @@ public:
 		{
 			uint32_t wc = 0;
 			(void)hipMemcpy(&wc, work_count_.p, 4, hipMemcpyDeviceToHost);
+			{ /* voices the time-parallel path did not finish */
+				std::vector<FastInfo> all(seg.n_voices);
+				(void)hipMemcpy(all.data(), finfo_.p, all.size() * sizeof(FastInfo), hipMemcpyDeviceToHost);
+				uint32_t shown = 0;
+				for (size_t v = 0; v < all.size() && shown < 16; ++v)
+					if (all[v].bail || all[v].total < seg.voices[v].run_len) {
+						fprintf(stderr, "  voice %zu: fast total %u of %u, bail %u, H %u, seq %u\n", v, all[v].total,
+								seg.voices[v].run_len, all[v].bail, all[v].H, all[v].seq);
+						++shown;
+					}
+			}
 			std::vector<VoiceOut> vi(seg.n_voices < 4 ? seg.n_voices : 4);
 			std::vector<uint32_t> fd(vi.size());
 			std::vector<FastInfo> fi(vi.size());
