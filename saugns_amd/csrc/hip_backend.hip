@@ -2123,6 +2123,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 								/* running-sum voices have a lane of slack (analyze_kernel): a hold left on the
 								 * operator's first defined lane is harmless there */
 								if (SCAN && l == p_min) held[k] = false;
+								if (held[k]) rep[1] = ((uint32_t)(l - p_min) << 24) | ((uint32_t)k << 20) | (si << 12) | (cg & 0xfff); /* debug */
 								held_rows |= __any(held[k]) ? (1u << k) : 0u;
 							}
 						}
@@ -3329,8 +3330,10 @@ public:
 				uint32_t shown = 0;
 				for (size_t v = 0; v < all.size() && shown < 16; ++v)
 					if (all[v].bail || all[v].total < seg.voices[v].run_len) {
-						fprintf(stderr, "  voice %zu: fast total %u of %u, bail %u, H %u, seq %u\n", v, all[v].total,
-								seg.voices[v].run_len, all[v].bail, all[v].H, all[v].seq);
+						uint32_t dbg = 0;
+						(void)hipMemcpy(&dbg, repair_.p + v * FAST_REPAIR_WORDS + 1, 4, hipMemcpyDeviceToHost);
+						fprintf(stderr, "  voice %zu: fast total %u of %u, bail %u, H %u, seq %u; last unresolved hold: lane p_min+%u row %u step %u group %u (mod 4096)\n", v, all[v].total,
+								seg.voices[v].run_len, all[v].bail, all[v].H, all[v].seq, dbg >> 24, (dbg >> 20) & 15, (dbg >> 12) & 255, dbg & 0xfff);
 						++shown;
 					}
 			}
