@@ -77,3 +77,26 @@ def test_render_file_gpu(sa, oracle, index, tmp_path):
                 n = sa.render_file(prg, rate, path, fmt, ch)
                 assert n == len(pcm[ch]) // ch
                 assert open(path, "rb").read() == oracle.oracle_sndfile_bytes(fmt, ch, rate, pcm[ch]), (name, ch)
+
+
+@pytest.mark.gpu
+def test_render_file_random_programs_gpu(sa, oracle, tmp_path):
+    """Randomized programs with events (tests/test_gpu_units.py) through the output stage: the WAV
+    and AU files equal the restated writer fed with the oracle's PCM for the stage's own run size."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_gpu_units as tu
+    from saugns_amd import voicebank as vb
+    oracle.oracle().ora_set_fastmath_forms(1)
+    for seed in range(200, 212):
+        rng = np.random.default_rng(5000 + seed)
+        voices = [tu._random_voice(rng) for _ in range(int(rng.integers(1, 4)))]
+        tu._random_starts(rng, voices)
+        prg = vb.build_program(voices, updates=tu._random_updates(rng, voices))
+        ch = 1 + (seed & 1)
+        fmt = 1 + (seed >> 1 & 1)
+        pcm = oracle.oracle_render(prg.ptr, 48000, ch == 2, chunk=176400)
+        path = str(tmp_path / f"r{seed}")
+        n = sa.render_file(prg, 48000, path, fmt, ch)
+        assert n == len(pcm) // ch
+        assert open(path, "rb").read() == oracle.oracle_sndfile_bytes(fmt, ch, 48000, pcm), seed
