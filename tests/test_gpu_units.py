@@ -580,3 +580,22 @@ def test_random_graphs_in_other_kernel_configurations(sa, oracle, env):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def test_dropin_generator_on_random_programs(sa, oracle):
+    """sau_create_Generator / sauGenerator_run with the host's 11289-frame calls (and odd sizes) on
+    randomized programs with events; long ones, so that the read-ahead hands out several device runs
+    from its two buffers. The device runs are 176400 frames: the oracle is asked for the same."""
+    oracle.oracle().ora_set_fastmath_forms(1)
+    for seed in range(300, 308):
+        rng = np.random.default_rng(5000 + seed)
+        voices = [_random_voice(rng) for _ in range(int(rng.integers(1, 4)))]
+        for carr in voices:  # 4 .. 16 s: more than one 176400-frame run
+            carr.time_ms = int(carr.time_ms * 100)
+        _random_starts(rng, voices)
+        prg = vb.build_program(voices, updates=_random_updates(rng, voices))
+        stereo = bool(seed & 1)
+        want = oracle.oracle_render(prg.ptr, RATE, stereo, chunk=176400)
+        for call in (11289, 4099):
+            got = sa.Generator(prg, RATE).render(stereo=stereo, chunk=call)
+            assert len(got) == len(want) and (got == want).all(), (seed, call)
