@@ -61,6 +61,13 @@ SAU_AMD_API void sauAmd_destroy_Batch(sauAmdBatch *b);
 SAU_AMD_API bool sauAmd_Batch_run(sauAmdBatch *b, int16_t *const *bufs, size_t buf_len,
 		bool stereo, bool *more, size_t *out_len);
 
+/* The reference restarts its <= 1024-frame rendering blocks at every sauGenerator_run call
+ * (generator.c:854-878), and the positions of held lines move block by block (sau/line.c:385-398),
+ * so a render depends -- in rare event sequences -- on the caller's buffer size. By default each
+ * sauAmd_Batch_run call stands for one such call. frames > 0: a run covers consecutive calls of
+ * that many frames each (rendering far ahead of a host that asks for 11289 frames at a time). */
+SAU_AMD_API void sauAmd_Batch_set_call_len(sauAmdBatch *b, size_t frames);
+
 /* Device address of stream i's PCM row of the last run (hipMalloc memory). */
 SAU_AMD_API const int16_t *sauAmd_Batch_device_pcm(sauAmdBatch *b, size_t stream);
 

@@ -109,6 +109,7 @@ def lib():
     L.sauAmd_Batch_run.restype = C.c_bool
     L.sauAmd_Batch_run.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.c_bool,
                                    C.POINTER(C.c_bool), C.POINTER(C.c_size_t)]
+    L.sauAmd_Batch_set_call_len.argtypes = [C.c_void_p, C.c_size_t]
     L.sauAmd_Batch_device_pcm.restype = C.c_void_p
     L.sauAmd_Batch_device_pcm.argtypes = [C.c_void_p, C.c_size_t]
     L.sauAmd_Batch_sync.restype = C.c_bool
@@ -286,6 +287,11 @@ class Batch:
                 break
         res = [np.concatenate(o) if o else np.zeros(0, np.int16) for o in outs]
         return [r[: max_frames * ch] for r in res] if max_frames else res
+
+    def set_call_len(self, frames):
+        """The sauGenerator_run call size whose block lattice the batch reproduces (0: every run
+        is one call)."""
+        lib().sauAmd_Batch_set_call_len(self._b, frames)
 
     def sync(self):
         if not lib().sauAmd_Batch_sync(self._b):

@@ -143,12 +143,17 @@ extern "C" bool sauGenerator_run(sauGenerator *o, int16_t *buf, size_t buf_len,
 		bool stereo, size_t *out_len) {
 	std::string err;
 	const size_t ch = stereo ? 2 : 1;
+	if (buf_len == 0) {
+		if (out_len) *out_len = 0;
+		return o->more || o->queued || o->pos < o->len;
+	}
 	if (o->pos == o->len && !o->queued && (o->ahead_frames == 0 || buf_len >= o->ahead_frames)) {
 		/* nothing buffered and the call is large: render straight into the caller's buffer */
 		bool more = false;
 		size_t len = 0;
 		int16_t *bufs[1] = {buf};
 		if (!o->more) { memset(buf, 0, sizeof(int16_t) * buf_len * ch); if (out_len) *out_len = 0; return false; }
+		o->batch.engine->set_call_len(0); /* this run is the host's call */
 		if (!o->batch.engine->run(bufs, buf_len, stereo, &more, &len, err))
 			return generator_fail(o, buf, buf_len, stereo, out_len, err);
 		o->more = more;
@@ -158,7 +163,12 @@ extern "C" bool sauGenerator_run(sauGenerator *o, int16_t *buf, size_t buf_len,
 	if ((o->pos < o->len || o->queued) && o->ahead_stereo != stereo)
 		return generator_fail(o, buf, buf_len, stereo, out_len,
 				"channel layout changed between calls while frames were buffered");
-	const size_t big = buf_len > o->ahead_frames ? buf_len : o->ahead_frames;
+	/* An engine run covers whole host calls, so that it starts where one of them does: the
+	 * reference's block lattice restarts at every call (generator.c:854-878; Lattice in
+	 * sau_dev_math.h), and the engine lays it out for calls of this size. A host that changes its
+	 * call size mid-stream (saugns.c never does) gets the new lattice from the next run on. */
+	const size_t big = buf_len >= o->ahead_frames ? buf_len : o->ahead_frames / buf_len * buf_len;
+	o->batch.engine->set_call_len(buf_len);
 	size_t filled = 0;
 	while (filled < buf_len) {
 		if (o->pos == o->len) {
@@ -221,6 +231,10 @@ extern "C" bool sauAmd_Batch_run(sauAmdBatch *b, int16_t *const *bufs, size_t bu
 		return false;
 	}
 	return true;
+}
+
+extern "C" void sauAmd_Batch_set_call_len(sauAmdBatch *b, size_t frames) {
+	b->engine->set_call_len(frames);
 }
 
 extern "C" const int16_t *sauAmd_Batch_device_pcm(sauAmdBatch *b, size_t stream) {
@@ -287,7 +301,7 @@ extern "C" SAU_AMD_API long long sauAmd_kat_div_device(uint32_t wave, int varian
 extern "C" SAU_AMD_API int sauAmd_kat_line_host(uint32_t *state, uint32_t len, const float *mul, float *out) {
 	saudev::LineState st;
 	memcpy(&st, state, sizeof st);
-	saudev::LineBlock lb = saudev::line_begin(st, len, mul != nullptr, mul ? mul[0] : 0.f);
+	saudev::LineBlock lb = saudev::line_begin(st, len, mul != nullptr, mul ? mul[0] : 0.f, saudev::lattice_none(), 0);
 	for (uint32_t j = 0; j < len; ++j) out[j] = saudev::line_value(lb, j, mul ? mul[j] : 1.f);
 	memcpy(state, &st, sizeof st);
 	return 1;

@@ -290,6 +290,18 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 		sd.first_voice = (uint32_t)descs.size();
 		sd.amp_scale = st.amp_scale;
 		sd.write_len = 0;
+		/* the reference's spans: from a call start or this program's latest event, to the call's
+		 * end or its next event (generator.c:917-946) */
+		Lattice lat;
+		lat.call_len = lat_call_;
+		lat.e0 = st.since_event < seg_call_pos_ ? (uint32_t)st.since_event : seg_call_pos_;
+		lat.span_left = lat_call_ - seg_call_pos_;
+		if (st.event < st.events.size()) {
+			/* (event_pos was advanced past this segment already) */
+			const uint32_t wt = st.events[st.event].wait - (st.event_pos - len);
+			if (wt < lat.span_left) lat.span_left = wt;
+		}
+		st.since_event += len;
 		for (uint32_t v = st.voice; v < st.voices.size(); ++v) {
 			VoiceHost &vn = st.voices[v];
 			if (vn.duration == 0) continue;
@@ -313,8 +325,9 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 			bool dyn = (carr.pan.flags & LP_GOAL) || vn.plan.has_camods;
 			d.pan_dynamic_row = dyn ? n_pan++ : ~0u;
 			d.flags = vn.plan.no_fast ? VD_NO_FAST : 0;
-			if (dyn) line_begin(carr.pan, out_len, false, 0.f);
-			else line_skip(carr.pan, out_len);
+			d.lat = lat;
+			if (dyn) line_begin(carr.pan, out_len, false, 0.f, lat, 0);
+			else line_skip(carr.pan, out_len, lat, 0);
 			descs.push_back(d);
 			if (out_len > sd.write_len) sd.write_len = out_len;
 			n_main = std::max(n_main, vn.plan.n_main);
@@ -382,6 +395,10 @@ bool Engine::run(int16_t *const *host_bufs, size_t buf_len, bool stereo,
 		out_dirty_ = false;
 	}
 	for (Stream &st : streams_) { st.call_gen = 0; st.part_start = 0; st.part_gen = 0; }
+	{
+		const uint32_t want = call_len_ ? call_len_ : (total ? total : 1u);
+		if (want != lat_call_ || !call_len_) { lat_call_ = want; call_phase_ = 0; }
+	}
 	std::vector<OpUpdate> batch;
 	std::vector<uint8_t> touched(total_ops_, 0);
 	uint32_t pos = 0, remaining = total;
@@ -401,6 +418,7 @@ bool Engine::run(int16_t *const *host_bufs, size_t buf_len, bool stereo,
 				if (!handle_event(st, e, batch, touched, err)) return false;
 				++st.event;
 				st.event_pos = 0;
+				st.since_event = 0;
 			}
 		}
 		const bool trace = getenv("SAU_AMD_DEBUG_CREATE") != nullptr;
@@ -448,11 +466,13 @@ bool Engine::run(int16_t *const *host_bufs, size_t buf_len, bool stereo,
 		}
 		for (Stream &st : streams_)
 			if (st.event < st.events.size()) st.event_pos += seg;
+		seg_call_pos_ = (uint32_t)(((uint64_t)call_phase_ + pos) % lat_call_);
 		if (!render_segment(seg, pos, stereo, err)) return false;
 		pos += seg;
 		remaining -= seg;
 	}
 	frames_done_ += total;
+	call_phase_ = (uint32_t)(((uint64_t)call_phase_ + total) % lat_call_);
 	for (size_t s = 0; s < streams_.size(); ++s) {
 		Stream &st = streams_[s];
 		st.call_gen += st.part_gen;

@@ -148,6 +148,12 @@ public:
 	bool run(int16_t *const *host_bufs, size_t buf_len, bool stereo,
 			bool *more, size_t *out_len, std::string &err);
 
+	/* The size of the sauGenerator_run calls whose block lattice the engine reproduces (see
+	 * Lattice in sau_dev_math.h): the reference starts a new <= 1024-frame block at every call
+	 * (generator.c:854-878). 0 (default): every run() is one such call; otherwise a run() covers
+	 * calls of that many frames each (read-ahead, file output). */
+	void set_call_len(size_t frames) { call_len_ = frames > UINT32_MAX ? UINT32_MAX : (uint32_t)frames; }
+
 	/* PCM is produced byte-swapped from the next run on (AU output) */
 	void set_pcm_byteswap(bool on) { pcm_swap_ = on; }
 	size_t n_streams() const { return streams_.size(); }
@@ -176,6 +182,7 @@ private:
 		std::vector<OpMirror> ops;
 		/* per-call output length accounting (generator.c:938-949) */
 		size_t call_gen = 0, part_start = 0, part_gen = 0;
+		uint64_t since_event = 0; /* frames since this program's latest event */
 	};
 
 	Engine() {}
@@ -204,6 +211,10 @@ private:
 	std::vector<PlanRef> plan_refs_; /* indexed by global voice index */
 	bool out_dirty_ = false;         /* PCM written since last clear */
 	uint64_t frames_done_ = 0;
+	uint32_t call_len_ = 0;          /* set_call_len() */
+	uint32_t lat_call_ = 0;          /* call size of the lattice in force */
+	uint32_t call_phase_ = 0;        /* frames into the reference's current call at the start of run() */
+	uint32_t seg_call_pos_ = 0;      /* ... at the start of the segment being rendered */
 };
 
 /* tables.cpp */

@@ -362,6 +362,8 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 	float *prow = (vd.pan_dynamic_row != ~0u) ? P.pan + (size_t)vd.pan_dynamic_row * P.row_stride : nullptr;
 	uint32_t done = P.fast_done[vrow_id]; /* frames rendered by fast_kernel */
 	uint32_t produced = done;
+	Lattice lat;
+	lat.e0 = uni(vd.lat.e0); lat.span_left = uni(vd.lat.span_left); lat.call_len = uni(vd.lat.call_len);
 	team_sync<V>(); /* previous voice's LDS contents are no longer needed */
 	for (uint32_t i = tid; i < vd.nops * 64; i += 64 * W)
 		((u32_alias *)ops)[i] = ((const u32_alias *)&P.ops[my_ids[i >> 6]])[i & 63];
@@ -442,7 +444,7 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 					const bool mconst = mul && pconst;
 					const float m0 = mul ? (mconst ? pf : mul[1]) : 0.f;
 					LineBlock lb = line_block_v(ls, len, mul != nullptr, m0);
-					line_begin_state(ls, len, mul != nullptr, m0);
+					line_begin_state(ls, len, mul != nullptr, m0, lat, done);
 #pragma unroll
 					for (int k = 0; k < T; ++k) {
 						if (owned[k]) {
@@ -451,7 +453,7 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 						}
 					}
 				} else {
-					line_advance_hold(ls, len);
+					line_advance_hold(ls, len, lat, done);
 				}
 				team_sync<V>();
 				if (!lazy) {
@@ -464,7 +466,7 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 					if (st.which == L_FREQ) { op->rt_fconst_valid = lazy ? 1u : 0u; op->rt_fconst = fc; }
 					if (st.flags & SF_SKIP2) {
 						LineState l2 = op->line[st.tmp];
-						line_skip(l2, len);
+						line_skip(l2, len, lat, done);
 						op->line[st.tmp] = l2;
 					}
 				}
@@ -477,12 +479,12 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 				float v[T];
 				if (active) {
 					LineBlock lb = line_block_v(ls, len, false, 0.f);
-					line_begin_state(ls, len, false, 0.f);
+					line_begin_state(ls, len, false, 0.f, lat, done);
 #pragma unroll
 					for (int k = 0; k < T; ++k)
 						v[k] = owned[k] ? line_value_v(lb, (uint32_t)(jbase + k), 1.f) : 0.f;
 				} else {
-					line_skip(ls, len);
+					line_skip(ls, len, lat, done);
 #pragma unroll
 					for (int k = 0; k < T; ++k) v[k] = 0.f;
 				}
@@ -548,9 +550,9 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 						if (!fconst) {
 							const float m0 = fmul ? (mconst ? pf : fmul[1]) : 0.f;
 							flb = line_block_v(fls, len, fmul != nullptr, m0);
-							line_begin_state(fls, len, fmul != nullptr, m0);
+							line_begin_state(fls, len, fmul != nullptr, m0, lat, done);
 						} else {
-							line_advance_hold(fls, len);
+							line_advance_hold(fls, len, lat, done);
 						}
 					} else if (pconst) { /* own frequency block was never stored */
 						fconst = true; fc = pf;
@@ -562,12 +564,12 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 					als = uni(op->line[L_AMP]);
 					if (!(als.flags & LP_GOAL)) {
 						const float ac = als.v0; /* held: sau/line.c:435-442 */
-						line_advance_hold(als, len);
+						line_advance_hold(als, len, lat, done);
 #pragma unroll
 						for (int k = 0; k < T; ++k) av[k] = ac;
 					} else {
 						const LineBlock alb = line_block_v(als, len, false, 0.f);
-						line_begin_state(als, len, false, 0.f);
+						line_begin_state(als, len, false, 0.f, lat, done);
 #pragma unroll
 						for (int k = 0; k < T; ++k)
 							av[k] = owned[k] ? line_value_v(alb, (uint32_t)(jbase + k), 1.f) : 0.f;
@@ -588,8 +590,8 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 					pls = uni(op->line[L_PMA]);
 					pls0 = pls;
 					sm_inline_active = (pls.v0 != 0.f) || (pls.flags & LP_GOAL);
-					if (sm_inline_active) line_begin_state(pls, len, false, 0.f);
-					else line_skip(pls, len);
+					if (sm_inline_active) line_begin_state(pls, len, false, 0.f, lat, done);
+					else line_skip(pls, len, lat, done);
 				}
 				const bool selfmod = is_osc && (smS != nullptr || sm_inline_active);
 
@@ -958,8 +960,8 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 				if (to_voice) { /* generator.c:749-788; the sum over voices is mix_kernel */
 					pl = uni(op->line[L_PAN]);
 					pan_goal = (pl.flags & LP_GOAL) != 0;
-					if (pan_goal) { plb2 = line_block_v(pl, len, false, 0.f); line_begin_state(pl, len, false, 0.f); }
-					else line_skip(pl, len);
+					if (pan_goal) { plb2 = line_block_v(pl, len, false, 0.f); line_begin_state(pl, len, false, 0.f, lat, done); }
+					else line_skip(pl, len, lat, done);
 				}
 #pragma unroll
 				for (int k = 0; k < T; ++k) {
@@ -992,7 +994,7 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 					if (f_inline) {
 						op->line[L_FREQ] = fls;
 						LineState l2 = op->line[L_FREQ2];
-						line_skip(l2, len);
+						line_skip(l2, len, lat, done);
 						op->line[L_FREQ2] = l2;
 						op->rt_fconst_valid = fconst ? 1u : 0u;
 						op->rt_fconst = fc;
@@ -1000,7 +1002,7 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 					if (a_inline) {
 						op->line[L_AMP] = als;
 						LineState l2 = op->line[L_AMP2];
-						line_skip(l2, len);
+						line_skip(l2, len, lat, done);
 						op->line[L_AMP2] = l2;
 					}
 					if (is_osc && (st.flags & SF_SM_INLINE)) op->line[L_PMA] = pls;
@@ -1017,8 +1019,8 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 				LineBlock plb2;
 				const bool pan_goal = !panS && (pl.flags & LP_GOAL);
 				if (!panS) {
-					if (pan_goal) { plb2 = line_block_v(pl, len, false, 0.f); line_begin_state(pl, len, false, 0.f); }
-					else line_skip(pl, len);
+					if (pan_goal) { plb2 = line_block_v(pl, len, false, 0.f); line_begin_state(pl, len, false, 0.f, lat, done); }
+					else line_skip(pl, len, lat, done);
 				}
 #pragma unroll
 				for (int k = 0; k < T; ++k) {
@@ -1713,7 +1715,7 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 			LineState ls = o.line[line_step ? st.which : L_AMP];
 			if (line_step || amp_inline) {
 				if (ls.flags & LP_GOAL) {
-					const LineBlock lb = line_begin(ls, P.info[v].total, line_step && have_mul, pconst ? pf : 1.f);
+					const LineBlock lb = line_begin(ls, P.info[v].total, line_step && have_mul, pconst ? pf : 1.f, lattice_none(), 0);
 					fl.sw = lb.sw; fl.goal_len = lb.goal_len; fl.hold = lb.hold; fl.pad = 0;
 					f.ramp = 1;
 					if (lb.mul_goal) fa.flags |= FA_MUL_GOAL;
@@ -1776,7 +1778,7 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 					fa.freq_off = cs.freq != NO_SLOT ? (uint32_t)cs.freq * NP : ~0u;
 				} else {
 					LineState fls = o.line[L_FREQ];
-					const LineBlock lb = line_begin(fls, P.info[v].total, have_mul, pconst ? pf : 1.f);
+					const LineBlock lb = line_begin(fls, P.info[v].total, have_mul, pconst ? pf : 1.f, lattice_none(), 0);
 					fa.fl.sw = lb.sw; fa.fl.goal_len = lb.goal_len; fa.fl.hold = lb.hold;
 					fa.flags |= FA_FVAR_LINE;
 					if (lb.mul_goal) fa.flags |= FA_MUL_GOAL;
@@ -2463,16 +2465,27 @@ __global__ void __launch_bounds__(64) finalize_kernel(FastParams P) {
 		DevOp &o = P.ops[ids[i]];
 		if (!o.rt_frozen) { /* (out of time: state stands still) */
 		if (!(o.flags & OPF_TIME_INF)) o.time -= total;
+		const bool o_osc = o.type == OT_WAVE || o.type == OT_RASEG;
+		const Step *plan = P.steps + vd.plan_ofs;
 		for (uint32_t ln = 0; ln < L_COUNT; ++ln) {
+			/* the lines the reference runs or skips for this operator (generator.c:505-664, 756-762) */
+			if (ln == L_PAN && i != vd.carr_local) continue;
+			if (!o_osc && (ln == L_FREQ || ln == L_FREQ2 || ln == L_PMA)) continue;
 			LineState ls = o.line[ln];
 			if (ls.flags & LP_GOAL) {
+				/* a range partner without range modulators is skipped, not run (generator.c:468-470) */
+				bool skipped = false;
+				if (ln == L_FREQ2 || ln == L_AMP2) {
+					skipped = true;
+					for (uint32_t si = 0; si < vd.plan_len; ++si)
+						if (plan[si].op == i && plan[si].kind == ST_LINE && plan[si].which == ln) { skipped = false; break; }
+				}
 				/* a frequency ramp whose goal and state disagree about being ratios rescales its
 				 * state by the parent's frequency (sau/line.c:358-370); such a voice only comes
 				 * this way when that frequency is one value (analyze_kernel) */
 				bool have_mul = false; float mul0 = 0.f;
 				const bool g_ratio = (ls.flags & LP_GOAL_RATIO) != 0, s_ratio = (ls.flags & LP_STATE_RATIO) != 0;
-				if ((ln == L_FREQ || ln == L_FREQ2) && g_ratio != s_ratio) {
-					const Step *plan = P.steps + vd.plan_ofs;
+				if (!skipped && (ln == L_FREQ || ln == L_FREQ2) && g_ratio != s_ratio) {
 					for (uint32_t si = 0; si < vd.plan_len; ++si) {
 						const Step st = plan[si];
 						if (st.op != i || st.fmul == NO_SLOT || st.prov == NO_SLOT) continue;
@@ -2482,9 +2495,10 @@ __global__ void __launch_bounds__(64) finalize_kernel(FastParams P) {
 						}
 					}
 				}
-				(void)line_begin(ls, total, have_mul, mul0);
+				if (skipped) line_skip(ls, total, vd.lat, 0);
+				else (void)line_begin(ls, total, have_mul, mul0, vd.lat, 0);
 			} else {
-				line_advance_hold(ls, total);
+				line_advance_hold(ls, total, vd.lat, 0);
 			}
 			o.line[ln] = ls;
 		}
@@ -2645,7 +2659,7 @@ __global__ void event_kernel(DevOp *ops, const OpUpdate *recs, uint32_t n, const
 __global__ void kat_line_kernel(LineState st, uint32_t len, const float *mul, float *out,
 		LineState *st_out) {
 	LineState ls = st;
-	LineBlock lb = line_begin(ls, len, mul != nullptr, mul ? mul[0] : 0.f);
+	LineBlock lb = line_begin(ls, len, mul != nullptr, mul ? mul[0] : 0.f, lattice_none(), 0);
 	for (uint32_t j = threadIdx.x; j < len; j += blockDim.x)
 		out[j] = line_value(lb, j, mul ? mul[j] : 1.f);
 	if (threadIdx.x == 0) *st_out = ls;

@@ -271,8 +271,116 @@ struct LineState { /* device copy of sauLine minus time_ms */
 	float v0, vt;
 	uint32_t pos, end;
 	uint32_t type;  /* LN_* */
-	uint32_t flags; /* LP_* */
+	uint32_t flags; /* LP_* in the low byte; lattice carry above (LPX_*) */
 };
+
+/* The reference renders in blocks of at most 1024 frames that start anew at every
+ * sauGenerator_run call and at every event (generator.c:854-878, 917-946), and a line
+ * without a sweep moves its position once per such block, all at once: advance_len
+ * (sau/line.c:385-398) adds the block's length and, when that reaches `end`, restarts
+ * the position at 0 *for the whole block* and drops LP_TIME; sauLine_run/sauLine_skip
+ * (430-445, 456-473) do the same when a sweep's goal is reached inside a block -- the
+ * rest of that block does not count. The position then keeps cycling block by block.
+ * It is observed only by sauLine_copy at an event (305-309: `end -= pos`), where it
+ * decides the length of a sweep that inherits its time. This backend renders segments
+ * that are cut elsewhere (other programs' events, read-ahead runs spanning many host
+ * calls, its own blocks), so a held line walks the reference's block lattice
+ * explicitly: Lattice says where the reference's blocks lie within the segment, and
+ * the line carries, in the upper bits of `flags`, the frames it has run in the
+ * reference block that is still open (LPX_PEND) and whether that block is the one in
+ * which its sweep ended (LPX_SKIP). */
+constexpr uint32_t LAT_BLOCK = 1024;      /* generator.c:24 BUF_LEN */
+constexpr uint32_t LPX_SKIP = 1u << 15;
+constexpr uint32_t LPX_PEND_SHIFT = 16;   /* 11 bits: 0..1024 */
+constexpr uint32_t LPX_PEND_MASK = 0x7ffu << LPX_PEND_SHIFT;
+
+struct Lattice {
+	uint32_t e0;        /* frames between the start of the reference's current span (call start or this
+	                     * program's latest event, whichever is later) and the segment's first frame */
+	uint32_t span_left; /* frames from the segment's first frame to that span's end (call end or this
+	                     * program's next event) */
+	uint32_t call_len;  /* length of the spans after it: the host's call size */
+};
+SAU_HD Lattice lattice_none() { Lattice l; l.e0 = 0; l.span_left = 0xffffffffu; l.call_len = 0xffffffffu; return l; }
+
+/* advance_len (sau/line.c:385-398) for k >= 1 consecutive blocks of b >= 1 frames each, closed form */
+SAU_HD void line_hold_blocks(LineState &o, uint32_t b, uint32_t k) {
+	if (o.pos >= o.end) { /* restarts with the first block */
+		o.pos = 0;
+		o.flags &= ~LP_TIME;
+		if (--k == 0 || o.end == 0) return;
+	}
+	/* blocks until the position reaches the end */
+	const uint32_t left = o.end - o.pos;
+	const uint32_t j = left / b + (left % b ? 1u : 0u);
+	if (k < j) { o.pos += k * b; return; }
+	o.flags &= ~LP_TIME;
+	k -= j;
+	const uint32_t q = o.end / b + (o.end % b ? 1u : 0u); /* period of the cycle from 0 */
+	o.pos = (k % q) * b;
+}
+
+/* one reference block of `b` frames has ended for a held line */
+SAU_HD void line_hold_block_end(LineState &o, uint32_t b) {
+	if (o.flags & LPX_SKIP) o.flags &= ~LPX_SKIP; /* its sweep ended inside this block: sau/line.c:436 pos = 0 stands */
+	else if (b) line_hold_blocks(o, b, 1);
+}
+
+/* what is still open belongs to a reference block that has ended since (the operator stopped
+ * inside it, or an event cut it short): called at span starts and before sauLine_copy */
+SAU_HD void line_lat_flush(LineState &o) {
+	const uint32_t pend = (o.flags & LPX_PEND_MASK) >> LPX_PEND_SHIFT;
+	if (!(o.flags & LP_GOAL) && (pend || (o.flags & LPX_SKIP))) line_hold_block_end(o, pend);
+	o.flags &= ~(LPX_PEND_MASK | LPX_SKIP);
+}
+
+/* A held line runs n more frames, the first of them frame `off` of the segment. */
+SAU_HD void line_hold_lat(LineState &o, uint32_t n, const Lattice &lat, uint32_t off) {
+	uint32_t pend = (o.flags & LPX_PEND_MASK) >> LPX_PEND_SHIFT;
+	o.flags &= ~LPX_PEND_MASK;
+	while (true) {
+		/* the span frame `off` lies in: position within it, frames to its end */
+		uint32_t sp, rem;
+		if (off < lat.span_left) { sp = lat.e0 + off; rem = lat.span_left - off; }
+		else {
+			const uint32_t r = (off - lat.span_left) % lat.call_len;
+			sp = r; rem = lat.call_len - r;
+		}
+		if (sp == 0 && (pend || (o.flags & LPX_SKIP))) { line_hold_block_end(o, pend); pend = 0; }
+		if (n == 0) break;
+		uint32_t m = n < rem ? n : rem; /* frames run within this span */
+		const bool to_end = m == rem;
+		n -= m; off += m;
+		const uint32_t in_blk = sp % LAT_BLOCK;
+		if (in_blk || pend || (o.flags & LPX_SKIP)) { /* a block that is already open */
+			uint32_t b = LAT_BLOCK - in_blk;
+			if (b > rem) b = rem;
+			if (m < b) { pend += m; break; }
+			line_hold_block_end(o, pend + b);
+			pend = 0; m -= b;
+		}
+		const uint32_t full = m / LAT_BLOCK, tail = m % LAT_BLOCK;
+		if (full) line_hold_blocks(o, LAT_BLOCK, full);
+		if (tail) {
+			if (to_end) line_hold_blocks(o, tail, 1); /* the span's last, shorter block */
+			else { pend = tail; break; }
+		}
+		if (n == 0 && !to_end) break;
+	}
+	o.flags |= pend << LPX_PEND_SHIFT;
+}
+
+/* a sweep's goal was reached with frame `at` of the segment the next to come: unless a reference
+ * block ends right there, the rest of the current one does not move the position */
+SAU_HD void line_goal_end_lat(LineState &o, const Lattice &lat, uint32_t at) {
+	uint32_t sp;
+	bool span_end;
+	if (at < lat.span_left) { sp = lat.e0 + at; span_end = false; }
+	else { sp = (at - lat.span_left) % lat.call_len; span_end = sp == 0; }
+	o.flags &= ~LPX_PEND_MASK;
+	if (span_end || sp % LAT_BLOCK == 0) o.flags &= ~LPX_SKIP;
+	else o.flags |= LPX_SKIP;
+}
 
 /* What one block of `len` samples of a line looks like: samples [0,goal_len)
  * follow the sweep, the rest hold a constant; each part optionally multiplied
@@ -287,36 +395,21 @@ struct LineBlock {
 
 /* The no-sweep part of sauLine_run: advance_len (sau/line.c:385-398). After it
  * the block holds v0 (times the ratio buffer when LP_STATE_RATIO). */
-SAU_HD void line_advance_hold(LineState &o, uint32_t len) {
-	if (o.pos < o.end) {
-		uint32_t l = o.end - o.pos;
-		if (l > len) l = len;
-		o.pos += l;
-	}
-	if (o.pos >= o.end) {
-		o.pos = 0;
-		o.flags &= ~LP_TIME;
-	}
+SAU_HD void line_advance_hold(LineState &o, uint32_t len, const Lattice &lat, uint32_t off) {
+	line_hold_lat(o, len, lat, off);
 }
 
 /* have_mul: a ratio buffer exists; mul0: its first value (only read when the
- * state/goal ratio flags disagree, sau/line.c:358-370). */
-SAU_HD LineBlock line_begin_body(LineState &o, uint32_t len, bool have_mul, float mul0) {
+ * state/goal ratio flags disagree, sau/line.c:358-370). `off`: the segment frame the
+ * block starts at (see Lattice). */
+SAU_HD LineBlock line_begin_body(LineState &o, uint32_t len, bool have_mul, float mul0,
+		const Lattice &lat, uint32_t off) {
 	LineBlock b;
 	b.goal_len = 0; b.mul_goal = false; b.mul_hold = false; b.hold = 0.f;
 	b.sw = sweep_setup(LN_sah, 0.f, 0.f, 0, 1);
 	bool hold;
 	if (!(o.flags & LP_GOAL)) {
-		/* advance_len, sau/line.c:385-398 */
-		if (o.pos < o.end) {
-			uint32_t l = o.end - o.pos;
-			if (l > len) l = len;
-			o.pos += l;
-		}
-		if (o.pos >= o.end) {
-			o.pos = 0;
-			o.flags &= ~LP_TIME;
-		}
+		line_hold_lat(o, len, lat, off);
 		hold = true;
 	} else {
 		bool mul = have_mul;
@@ -346,6 +439,8 @@ SAU_HD LineBlock line_begin_body(LineState &o, uint32_t len, bool have_mul, floa
 			o.v0 = o.vt;
 			o.pos = 0;
 			o.flags &= ~(LP_GOAL | LP_GOAL_RATIO | LP_TIME);
+			line_goal_end_lat(o, lat, off + glen);
+			line_hold_lat(o, len - glen, lat, off + glen);
 		}
 	}
 	if (hold) {
@@ -355,8 +450,9 @@ SAU_HD LineBlock line_begin_body(LineState &o, uint32_t len, bool have_mul, floa
 	return b;
 }
 
-SAU_HD_CALL LineBlock line_begin(LineState &o, uint32_t len, bool have_mul, float mul0) {
-	return line_begin_body(o, len, have_mul, mul0);
+SAU_HD_CALL LineBlock line_begin(LineState &o, uint32_t len, bool have_mul, float mul0,
+		const Lattice &lat, uint32_t off) {
+	return line_begin_body(o, len, have_mul, mul0, lat, off);
 }
 
 SAU_HD_CALL float line_value(const LineBlock &b, uint32_t i, float mul_i) {
@@ -373,11 +469,12 @@ SAU_HD_CALL float line_value(const LineBlock &b, uint32_t i, float mul_i) {
  * plan step in the block loop). line_begin() = line_block_v() for the block +
  * line_begin_state() for the state it leaves behind. */
 SAU_HD_CALL LineBlock line_block_v(LineState o, uint32_t len, bool have_mul, float mul0) {
-	return line_begin_body(o, len, have_mul, mul0);
+	return line_begin_body(o, len, have_mul, mul0, lattice_none(), 0);
 }
-SAU_HD void line_begin_state(LineState &o, uint32_t len, bool have_mul, float mul0) {
+SAU_HD void line_begin_state(LineState &o, uint32_t len, bool have_mul, float mul0,
+		const Lattice &lat, uint32_t off) {
 	if (!(o.flags & LP_GOAL)) {
-		line_advance_hold(o, len);
+		line_hold_lat(o, len, lat, off);
 		return;
 	}
 	if (o.flags & LP_GOAL_RATIO) {
@@ -399,6 +496,8 @@ SAU_HD void line_begin_state(LineState &o, uint32_t len, bool have_mul, float mu
 		o.v0 = o.vt;
 		o.pos = 0;
 		o.flags &= ~(LP_GOAL | LP_GOAL_RATIO | LP_TIME);
+		line_goal_end_lat(o, lat, off + glen);
+		line_hold_lat(o, len - glen, lat, off + glen);
 	}
 }
 SAU_HD_CALL float line_value_v(LineBlock b, uint32_t i, float mul_i) {
@@ -410,21 +509,26 @@ SAU_HD_CALL float line_value_v(LineBlock b, uint32_t i, float mul_i) {
 }
 
 /* sau/line.c:456-473 */
-SAU_HD void line_skip(LineState &o, uint32_t len) {
+SAU_HD void line_skip(LineState &o, uint32_t len, const Lattice &lat, uint32_t off) {
+	if (!(o.flags & LP_GOAL)) {
+		line_hold_lat(o, len, lat, off);
+		return;
+	}
+	uint32_t l = 0;
 	if (o.pos < o.end) {
-		uint32_t l = o.end - o.pos;
+		l = o.end - o.pos;
 		if (l > len) l = len;
 		o.pos += l;
 	}
 	if (o.pos >= o.end) {
 		o.pos = 0;
 		o.flags &= ~LP_TIME;
-		if (!(o.flags & LP_GOAL))
-			return;
 		o.v0 = o.vt;
 		if (o.flags & LP_GOAL_RATIO) o.flags |= LP_STATE_RATIO;
 		else o.flags &= ~LP_STATE_RATIO;
 		o.flags &= ~(LP_GOAL | LP_GOAL_RATIO);
+		line_goal_end_lat(o, lat, off + l);
+		line_hold_lat(o, len - l, lat, off + l);
 	}
 }
 
@@ -440,6 +544,7 @@ struct LineUpdate {
 SAU_HD void line_copy(LineState &o, const LineUpdate &src) {
 	if (!src.flags)
 		return;
+	line_lat_flush(o); /* an event ends the reference's block */
 	uint32_t mask = 0;
 	if (src.flags & LP_STATE) {
 		o.v0 = src.v0;
@@ -448,7 +553,7 @@ SAU_HD void line_copy(LineState &o, const LineUpdate &src) {
 		if (src.flags & LP_GOAL) {
 			/* sauLine_get(o, &f, 1, NULL): value at the current position */
 			LineState t = o;
-			LineBlock b = line_begin(t, 1, false, 0.f);
+			LineBlock b = line_begin(t, 1, false, 0.f, lattice_none(), 0);
 			/* line_begin advanced a copy; only the ratio-flag side effect
 			 * of sauLine_get persists in the reference (v0 is untouched
 			 * without a ratio buffer). */

@@ -225,6 +225,7 @@ struct VoiceDesc {
 	uint32_t out_row;            /* row in the voice output matrix */
 	uint32_t pan_dynamic_row;    /* row of the pan matrix, or ~0u */
 	uint32_t flags;              /* VD_* */
+	Lattice lat;                 /* where the reference's blocks lie in this segment, for the voice's program */
 };
 
 enum : uint32_t {

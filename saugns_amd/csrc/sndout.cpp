@@ -98,7 +98,12 @@ bool render_file(const sauProgram *prg, uint32_t srate, const char *path, int fo
 	if (!engine) return false;
 	const bool stereo = channels == 2;
 	engine->set_pcm_byteswap(format == SAU_AMD_SNDFILE_AU);
-	const size_t chunk = 176400; /* frames per device run */
+	/* Player_run asks the generator for 256 ms at a time (saugns.c:471,526: ch_len); the
+	 * reference's block lattice restarts at each of those calls, so a device run covers whole ones */
+	size_t call = (size_t)((uint64_t)256 * srate / 1000);
+	if (call == 0) call = 1;
+	engine->set_call_len(call);
+	const size_t chunk = call >= 176400 ? call : 176400 / call * call; /* frames per device run */
 	const size_t bytes = chunk * (size_t)channels * sizeof(int16_t);
 	int16_t *host[2] = {(int16_t *)backend->alloc_host(bytes), (int16_t *)backend->alloc_host(bytes)};
 	SndOut out;

@@ -101,20 +101,20 @@ struct SeqBackend : public Backend {
 					break;
 				case ST_LINE: {
 					const float *mul = st.fmul != NO_SLOT ? slot[st.fmul].data() : nullptr;
-					LineBlock lb = line_begin(op.line[st.which], len, mul != nullptr, mul ? mul[0] : 0.f);
+					LineBlock lb = line_begin(op.line[st.which], len, mul != nullptr, mul ? mul[0] : 0.f, vd.lat, done);
 					for (uint32_t j = 0; j < len; ++j)
 						slot[st.out][j] = line_value(lb, j, mul ? mul[j] : 1.f);
-					if (st.flags & SF_SKIP2) line_skip(op.line[st.tmp], len);
+					if (st.flags & SF_SKIP2) line_skip(op.line[st.tmp], len, vd.lat, done);
 					break;
 				}
 				case ST_SMLINE: {
 					LineState &ls = op.line[L_PMA];
 					bool active = (ls.v0 != 0.f) || (ls.flags & LP_GOAL);
 					if (active) {
-						LineBlock lb = line_begin(ls, len, false, 0.f);
+						LineBlock lb = line_begin(ls, len, false, 0.f, vd.lat, done);
 						for (uint32_t j = 0; j < len; ++j) slot[st.out][j] = line_value(lb, j, 1.f);
 					} else {
-						line_skip(ls, len);
+						line_skip(ls, len, vd.lat, done);
 						for (uint32_t j = 0; j < len; ++j) slot[st.out][j] = 0.f;
 					}
 					break;
@@ -139,25 +139,25 @@ struct SeqBackend : public Backend {
 					if (is_osc) {
 						if (fslot) for (uint32_t j = 0; j < len; ++j) fv[j] = fslot[j];
 						else {
-							LineBlock lb = line_begin(op.line[L_FREQ], len, fmul != nullptr, fmul ? fmul[0] : 0.f);
+							LineBlock lb = line_begin(op.line[L_FREQ], len, fmul != nullptr, fmul ? fmul[0] : 0.f, vd.lat, done);
 							for (uint32_t j = 0; j < len; ++j) fv[j] = line_value(lb, j, fmul ? fmul[j] : 1.f);
-							line_skip(op.line[L_FREQ2], len);
+							line_skip(op.line[L_FREQ2], len, vd.lat, done);
 						}
 					}
 					if (ampS) for (uint32_t j = 0; j < len; ++j) av[j] = ampS[j];
 					else {
-						LineBlock lb = line_begin(op.line[L_AMP], len, false, 0.f);
+						LineBlock lb = line_begin(op.line[L_AMP], len, false, 0.f, vd.lat, done);
 						for (uint32_t j = 0; j < len; ++j) av[j] = line_value(lb, j, 1.f);
-						line_skip(op.line[L_AMP2], len);
+						line_skip(op.line[L_AMP2], len, vd.lat, done);
 					}
 					bool selfmod = is_osc && smS != nullptr;
 					if (is_osc && (st.flags & SF_SM_INLINE)) {
 						LineState &pl = op.line[L_PMA];
 						if ((pl.v0 != 0.f) || (pl.flags & LP_GOAL)) {
-							LineBlock lb = line_begin(pl, len, false, 0.f);
+							LineBlock lb = line_begin(pl, len, false, 0.f, vd.lat, done);
 							for (uint32_t j = 0; j < len; ++j) pv[j] = line_value(lb, j, 1.f);
 							selfmod = true;
-						} else line_skip(pl, len);
+						} else line_skip(pl, len, vd.lat, done);
 					} else if (smS) for (uint32_t j = 0; j < len; ++j) pv[j] = smS[j];
 					if (type == OT_WAVE) {
 						const WaveConst &k = wc[op.wave];
@@ -248,7 +248,7 @@ struct SeqBackend : public Backend {
 						LineState &pl = op.line[L_PAN];
 						LineBlock lb;
 						bool goal = (pl.flags & LP_GOAL) != 0;
-						if (goal) lb = line_begin(pl, len, false, 0.f); else line_skip(pl, len);
+						if (goal) lb = line_begin(pl, len, false, 0.f, vd.lat, done); else line_skip(pl, len, vd.lat, done);
 						for (uint32_t j = 0; j < len; ++j) {
 							vrow[done + j] = slot[st.out][j];
 							if (!prow.empty()) prow[done + j] = goal ? line_value(lb, j, 1.f) : pl.v0;
@@ -262,7 +262,7 @@ struct SeqBackend : public Backend {
 					const float *panS = st.pm != NO_SLOT ? slot[st.pm].data() : nullptr;
 					LineBlock lb;
 					bool goal = !panS && (pl.flags & LP_GOAL);
-					if (!panS) { if (goal) lb = line_begin(pl, len, false, 0.f); else line_skip(pl, len); }
+					if (!panS) { if (goal) lb = line_begin(pl, len, false, 0.f, vd.lat, done); else line_skip(pl, len, vd.lat, done); }
 					for (uint32_t j = 0; j < len; ++j) {
 						vrow[done + j] = slot[st.out][j];
 						if (!prow.empty())

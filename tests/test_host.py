@@ -278,3 +278,77 @@ def test_program_images_of_random_programs(sa, oracle):
         a = oracle.oracle_render(prg.ptr, 22050, True)
         b = oracle.oracle_render(back.ptr, 22050, True)
         assert len(a) == len(b) and max_diff(a, b) == 0, seed
+
+
+@pytest.mark.parametrize("rate", [44100, 96000])
+def test_line_positions_follow_the_reference_block_lattice(sa, oracle, seqexec, rate):
+    """Same program, call sizes 1746 / 11289 / whole: the oracle (which renders in the reference's
+    own blocks) and the engine agree sample for sample at each -- whatever blocks the backend
+    itself renders in, alone or beside another program whose events cut the segments elsewhere,
+    and through the read-ahead of the drop-in generator. (That the renders differ between call
+    sizes is the reference's behaviour; asserted so that the programs keep exercising it.)"""
+    from saugns_amd import voicebank as vb
+    from lattice_cases import expiry_value_goal_program
+    oracle.oracle().ora_set_fastmath_forms(1)
+    seen_dependence = False
+    for seed in range(6):
+        prg = expiry_value_goal_program(seed)
+        renders = {}
+        for chunk in (1746, 11289, 400000):
+            want = oracle.oracle_render(prg.ptr, rate, True, chunk=chunk)
+            renders[chunk] = want
+            if oracle.have_ref():
+                oracle.oracle().ora_set_fastmath_forms(2)
+                ref = oracle.ref_render(prg.ptr, rate, True, chunk=chunk)
+                assert max_diff(oracle.oracle_render(prg.ptr, rate, True, chunk=chunk), ref) == 0, (seed, chunk)
+                oracle.oracle().ora_set_fastmath_forms(1)
+            for block in ((333, 1016, 50000) if seed < 2 else (1016,)):
+                got = sa.Batch([prg], rate, backend=seqexec.seq_backend_create(block)).render(stereo=True, chunk=chunk)[0]
+                assert max_diff(got, want) == 0, (seed, chunk, block)
+        if any((renders[1746] != renders[c]).any() for c in (11289, 400000)):
+            seen_dependence = True
+        # beside a program with many events of its own (segments end where they fall)
+        busy_voices = [vb.Op("sin", freq=150.0, time_ms=3500)]
+        busy = vb.build_program(busy_voices, updates=[(k * 53 + 7, 0, busy_voices[0], {"amp": vb.Line(0.5 + 0.01 * (k % 7))})
+                                                       for k in range(60)])
+        got = sa.Batch([prg, busy], rate, backend=seqexec.seq_backend_create(1016)).render(stereo=True, chunk=11289)[0]
+        assert max_diff(got, renders[11289]) == 0, (seed, "batch")
+        # drop-in generator: engine runs of 4 host calls
+        os.environ["SAU_AMD_READAHEAD"] = str(4 * 1746 + 100)
+        try:
+            got = sa.Generator(prg, rate, backend=seqexec.seq_backend_create(1016)).render(stereo=True, chunk=1746)
+        finally:
+            del os.environ["SAU_AMD_READAHEAD"]
+        assert max_diff(got, renders[1746]) == 0, (seed, "read-ahead")
+    assert seen_dependence, "none of the programs depends on the call size: the test has lost its subject"
+
+
+@pytest.mark.parametrize("rate", [8000, 44100, 96000])
+def test_random_lattice_programs(sa, oracle, seqexec, rate):
+    """Random operator trees with (value-only, then goal-only) events on lines whose time has run out
+    (tests/lattice_cases.py): engine runs of any length over host calls of another, backend blocks
+    of a third -- sample for sample the oracle at that call size; the oracle itself equals the
+    compiled reference there."""
+    from lattice_cases import lattice_case
+    dep = 0
+    for seed in range(40):
+        rng = np.random.default_rng(77000 + seed)
+        prg = lattice_case(rng)
+        call, run = int(rng.integers(300, 3000)), int(rng.integers(1000, 30000))
+        block = int(rng.choice([64, 1016, 4000]))
+        stereo = bool(seed & 1)
+        oracle.oracle().ora_set_fastmath_forms(0)
+        a = oracle.oracle_render(prg.ptr, rate, stereo, chunk=call)
+        b = oracle.oracle_render(prg.ptr, rate, stereo, chunk=4000000)
+        dep += len(a) != len(b) or bool((a != b).any())
+        if oracle.have_ref() and seed < 12:
+            oracle.oracle().ora_set_fastmath_forms(2)
+            assert max_diff(oracle.oracle_render(prg.ptr, rate, stereo, chunk=call),
+                            oracle.ref_render(prg.ptr, rate, stereo, chunk=call)) == 0, seed
+        oracle.oracle().ora_set_fastmath_forms(1)
+        want = oracle.oracle_render(prg.ptr, rate, stereo, chunk=call)
+        bt = sa.Batch([prg], rate, backend=seqexec.seq_backend_create(block))
+        bt.set_call_len(call)
+        got = bt.render(stereo=stereo, chunk=run)[0]
+        assert max_diff(got, want) == 0, (seed, call, run, block)
+    assert dep >= 8, "too few of the programs depend on the call size"
