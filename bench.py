@@ -1,16 +1,27 @@
 #!/usr/bin/env python3
 """bench.py -- headline metric of BASELINE.json on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload config3|config4|config5]
 
-One step = one pass of the generator hot path over one batch: every rank
-renders `--frames` frames (default 441000 = the whole 10 s of the script at 44.1 kHz)
-of BASELINE config 3 (1024 voices, each carrier + 3-deep PM chain; 4096 operators) with
-program state, block buffers and PCM resident in HBM.  Ranks hold independent
-voice banks (the path has no exchange step: SURVEY.md 8e), so scaling is weak
-and `value` is the sum over ranks of mixed mono output frames per second.
+One step = one pass of the generator hot path over one batch, program state, block buffers and PCM
+resident in HBM:
+
+* config3 (default, the configuration the metric is quoted on): every rank renders `--frames`
+  frames (default 441000 = the script's whole 10 s at 44.1 kHz) of BASELINE config 3 -- 1024
+  voices, each a carrier with a 3-deep PM chain, 4096 operators. Ranks hold independent voice
+  banks (the path has no exchange step): weak scaling, `value` = mixed mono output
+  frames per second summed over ranks. The first step's PCM is checked against the reference's
+  SHA-256 (tests/golden/index.json) before anything is timed.
+* config4 (the north star's multi-GPU case): examples/rainy_thunder.sau with seed = k, k = 0..511
+  (tests/golden/config4_seeds.npz), 64 renders per GPU: rank r renders seeds
+  shard_range(64 * N, r, N) as one batch; a step = those 64 scripts from generator creation to
+  their last frame (60 s each). No data-path collective; the ranks all-reduce {frames, checksum}
+  afterwards, and every render's SHA-256 is compared with the reference's.
+* config5: 4096 voices with self-feedback FM + range AM + ramps (the feedback-recurrence stress);
+  a step = the script's whole 10 s from generator creation on; the PCM's SHA-256 is checked.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -18,14 +29,46 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
-def cpu_baseline(tabs, voices):
-    """The reference's own generator (oracle/_ref, built from its sources by oracle/Makefile)
-    when that library is present, else this repo's CPU restatement; bounded sample."""
+def kernel_source_hash():
+    """Identity of the kernels a PMC summary under profiles/ was collected on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "saugns_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def profile_traffic(workload, kernel_prefix):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this
+    command (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE; counters cannot be read
+    from inside the process). Only a summary collected on these very kernel sources counts."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for f in sorted(os.listdir(pdir)):
+        if not f.endswith("_pmc_summary.json"):
+            continue
+        try:
+            pmc = json.load(open(os.path.join(pdir, f)))
+            if pmc.get("kernel_source_sha") != kernel_source_hash():
+                continue
+            if pmc.get("workload", {}).get("name") != workload:
+                continue
+            k = [v for n, v in pmc["kernels"].items() if kernel_prefix in n]
+            best = (k[0]["hbm_bytes_per_launch_corrected"], "profiles/" + f)
+        except (OSError, KeyError, ValueError, IndexError):
+            pass
+    return best if best else (None, None)
+
+
+def cpu_reference(make_prg, what, voices, ops_per_voice, tabs, all_cores=False):
+    """The reference's own generator (oracle/_ref, built from its sources by oracle/Makefile) when
+    that library is present, else this repo's CPU restatement; a bounded sample of the workload."""
     from oracle import pyoracle as po
-    from saugns_amd import voicebank
-    prg = voicebank.config3(n=voices, seconds=30)
+    prg = make_prg()
     if po.have_ref():
         kind = "reference"
         po.ref()
@@ -39,8 +82,7 @@ def cpu_baseline(tabs, voices):
 
         def render(frames):
             return po.oracle_render(prg.ptr, 44100, False, max_frames=frames, chunk=11289)
-    # calibrate, then run ~15 s of CPU work
-    frames = 11025
+    frames = 2205  # calibrate, then run ~15 s of CPU work
     t0 = time.perf_counter()
     render(frames)
     dt = time.perf_counter() - t0
@@ -48,18 +90,19 @@ def cpu_baseline(tabs, voices):
     t0 = time.perf_counter()
     render(frames)
     dt = time.perf_counter() - t0
-    multi = cpu_baseline_all_cores(voices, frames_1core=frames / dt)
-    return {"value": frames / dt, "unit": "mixed mono int16 frames/s", "cores": 1,
-            "kind": kind, "all_cores": multi,
-            "sample": f"config 3 ({voices} voices x depth-3 PM), first {frames} frames "
-                      f"({frames * voices * 4:.3g} operator-samples), {dt:.1f} s on 1 host thread"
-                      + (" (sauGenerator_run of the compiled reference, -O3 -ffast-math as its Makefile)"
-                         if kind == "reference" else " (oracle/sau_oracle.c)"),
-            "operator_samples_per_s": frames * voices * 4 / dt}
+    out = {"value": frames / dt, "unit": "mixed mono int16 frames/s", "cores": 1, "kind": kind,
+           "sample": f"{what}, first {frames} frames ({frames * voices * ops_per_voice:.3g} operator-samples), "
+                     f"{dt:.1f} s on 1 host thread"
+                     + (" (sauGenerator_run of the compiled reference, -O3 -ffast-math as its Makefile)"
+                        if kind == "reference" else " (oracle/sau_oracle.c)"),
+           "operator_samples_per_s": frames * voices * ops_per_voice / dt}
+    if all_cores:
+        out["all_cores"] = cpu_baseline_all_cores(voices, frames_1core=frames / dt)
+    return out
 
 
 def cpu_baseline_all_cores(voices, frames_1core):
-    """the same bank with its voices partitioned over all host cores, one process
+    """the config-3 bank with its voices partitioned over all host cores, one process
     each (the reference is single-threaded; its voices only meet in the final per-frame sum)."""
     import subprocess
     import tempfile
@@ -97,126 +140,316 @@ def cpu_baseline_all_cores(voices, frames_1core):
                       f"first {frames} frames, slowest process {max(secs):.1f} s"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=441000)
-    ap.add_argument("--voices", type=int, default=1024)
-    ap.add_argument("--no-cpu", action="store_true")
-    args = ap.parse_args()
-
+def sha256(a):
     import numpy as np
-    import torch
-    import torch.distributed as dist
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    # one process per GPU; SAU_BENCH_BACKEND=gloo lets the N>1 logic be exercised on a box with
-    # fewer GPUs than ranks (ranks then share devices; rendezvous and reductions on the CPU)
-    backend = os.environ.get("SAU_BENCH_BACKEND", "nccl")
-    dev = local_rank % max(1, torch.cuda.device_count())
-    os.environ.setdefault("SAU_AMD_DEVICE", str(dev))
-    torch.cuda.set_device(dev)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
-        else:
-            dist.init_process_group(backend)
 
-    import saugns_amd as sa
+class Ranks:
+    """One process per GPU; torch.distributed (backend "nccl" = RCCL) only for the barrier, the
+    max-over-ranks clock and the after-the-fact report."""
+
+    def __init__(self):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        # SAU_BENCH_BACKEND=gloo lets the N>1 logic be exercised on a box with fewer GPUs than
+        # ranks (ranks then share devices; rendezvous and reductions on the CPU)
+        self.backend = os.environ.get("SAU_BENCH_BACKEND", "nccl")
+        dev = local_rank % max(1, torch.cuda.device_count())
+        os.environ.setdefault("SAU_AMD_DEVICE", str(dev))
+        torch.cuda.set_device(dev)
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+            else:
+                dist.init_process_group(self.backend)
+        self.tdev = "cuda" if self.backend == "nccl" else "cpu"
+
+    def barrier(self, batches=()):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+        for b in batches:
+            b.sync()
+
+    def max(self, x):
+        if self.world == 1:
+            return x
+        t = self.torch.tensor([x], device=self.tdev, dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum(self, ints):
+        if self.world == 1:
+            return [int(x) for x in ints]
+        t = self.torch.tensor([int(x) for x in ints], device=self.tdev, dtype=self.torch.int64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return [int(x) for x in t.tolist()]
+
+    def close(self):
+        if self.world > 1:
+            self.dist.destroy_process_group()
+
+
+def run_config3(args, R, sa, tabs):
+    import numpy as np
     from saugns_amd import voicebank
-    tabs = np.fromfile(os.path.join(ROOT, "tests", "golden", "piluts_ref.f32"),
-                       dtype="<f4").reshape(12, 2048)
-    sa.set_piluts(tabs)
-
-    seconds = max(1, (args.frames * (args.steps + args.warmup + 1)) // 44100 + 2)
+    index = json.load(open(os.path.join(GOLDEN, "index.json")))
+    seconds = max(1, (args.frames * (args.steps + args.warmup + 2)) // 44100 + 2)
     prg = voicebank.config3(n=args.voices, seconds=seconds)
     batch = sa.Batch([prg], 44100)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        batch.sync()
-
+    # what is about to be timed is the reference's render: the first step (the script's first 10 s)
+    verified = None
+    pcm = batch.run(args.frames, stereo=False)[0]
+    if args.voices == 1024 and args.frames == 441000:
+        got, want = sha256(pcm[0]), index["configs"]["config3"]["sha256"]
+        if got != want:
+            raise SystemExit(f"rank {R.rank}: first step's PCM {got[:16]} is not the reference's {want[:16]}")
+        verified = {"sha256": got, "equals": "tests/golden/index.json configs.config3.sha256 (compiled reference)"}
     for _ in range(args.warmup):
         batch.run(args.frames, stereo=False, fetch=False)
-    barrier()
+    R.barrier([batch])
     batch.timing_ex(reset=True)
     batch.set_timing(1)  # HIP events around the dominant kernel only, on its own stream
     t0 = time.perf_counter()
     for _ in range(args.steps):
         batch.run(args.frames, stereo=False, fetch=False)
-    barrier()
-    dt = time.perf_counter() - t0
+    R.barrier([batch])
+    dt = R.max(time.perf_counter() - t0)
     tm = batch.timing_ex()
-    if world > 1:
-        t = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    frames_total = args.frames * args.steps * world
-    value = frames_total / dt
+    frames_total = args.frames * args.steps * R.world
     # SURVEY.md 8e: the only exchange of the whole job is this after-the-fact reduction of
     # {frames rendered, PCM checksum} for the scaling report (outside the timed region)
     pcm = batch.run(args.frames, stereo=False)[0]
-    tally = [args.frames * args.steps, int(np.asarray(pcm, dtype=np.int64).sum() & 0x7FFFFFFF)]
-    mine = list(tally)
-    if world > 1:
-        t = torch.tensor(tally, device="cuda" if backend == "nccl" else "cpu", dtype=torch.int64)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        tally = [int(x) for x in t.tolist()]
-    if tally[0] != frames_total or tally[1] != mine[1] * world:
-        raise SystemExit(f"rank {rank}: ranks disagree on the rendered PCM ({tally} vs {mine} x {world})")
-    if rank == 0:
-        n_ops = args.voices * 4
-        # 8 B per operator-sample (one f32 write + one f32 read of every
-        # operator's block output) + 2 B per output frame, per launch of the kernel
-        alg_bytes = (n_ops * 8 + 2) * args.frames
-        launch_s = (tm["fast_ms"] / 1e3) / max(1, tm["segments"])
-        achieved = alg_bytes / launch_s / 1e9 if launch_s > 0 else 0.0
-        # HBM bytes per launch of the same kernel on the same workload, from the committed
-        # PMC passes (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); counters
-        # cannot be collected from inside this process, so null when the workload differs
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_m_pmc_summary.json")))
-            wl = pmc["workload"]
-            if wl["voices"] == args.voices and wl["frames_per_step"] == args.frames:
-                k = [v for n, v in pmc["kernels"].items() if n.startswith("sauhip::fast_kernel<")]
-                traffic = k[0]["hbm_bytes_per_launch_corrected"]
-        except (OSError, KeyError, ValueError, IndexError):
-            pass
-        out = {
-            "metric": "mono samples/sec/GPU @ N voices (depth-3 FM)",
-            "value": value, "unit": "mixed mono int16 frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32 (f64 table interpolation, u32 phase)",
-            "data": "synthetic",
-            "config": {"workload": f"BASELINE config 3: {args.voices} voices x (carrier + 3-deep "
-                                   f"PM chain) = {n_ops} operators, 44.1 kHz mono, "
-                                   f"{args.frames} frames per step, per GPU",
-                       "voices": args.voices, "operators": n_ops,
-                       "frames_per_step": args.frames,
-                       "frames_all_ranks": tally[0], "pcm_checksum_all_ranks": tally[1],
-                       "voice_samples_per_s": value * args.voices,
-                       "operator_samples_per_s": value * n_ops},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": traffic,
-                         "kernel": "fast_kernel<8, false>", "avg_launch_ms": launch_s * 1e3,
-                         "launches": tm["segments"],
-                         "algorithmic_bytes_per_launch": alg_bytes},
-        }
-        if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline(tabs, args.voices)
+    mine = [args.frames * args.steps, int(np.asarray(pcm, dtype=np.int64).sum() & 0x7FFFFFFF)]
+    tally = R.sum(mine)
+    if tally[0] != frames_total or tally[1] != mine[1] * R.world:
+        raise SystemExit(f"rank {R.rank}: ranks disagree on the rendered PCM ({tally} vs {mine} x {R.world})")
+    if R.rank != 0:
+        return None
+    n_ops = args.voices * 4
+    # SURVEY.md 8d: 8 B per operator-sample (one f32 write + one f32 read of every operator's
+    # block output) + 2 B per output frame, per launch of the kernel
+    alg_bytes = (n_ops * 8 + 2) * args.frames
+    launch_s = (tm["fast_ms"] / 1e3) / max(1, tm["segments"])
+    achieved = alg_bytes / launch_s / 1e9 if launch_s > 0 else 0.0
+    traffic, source = profile_traffic("config3", "fast_kernel<") if verified else (None, None)
+    out = {
+        "metric": "mono samples/sec/GPU @ N voices (depth-3 FM)",
+        "value": frames_total / dt, "unit": "mixed mono int16 frames/s",
+        "n_gpus": R.world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32 (f64 table interpolation, u32 phase)",
+        "data": "synthetic",
+        "config": {"workload": f"BASELINE config 3: {args.voices} voices x (carrier + 3-deep "
+                               f"PM chain) = {n_ops} operators, 44.1 kHz mono, "
+                               f"{args.frames} frames per step, per GPU",
+                   "voices": args.voices, "operators": n_ops, "frames_per_step": args.frames,
+                   "frames_all_ranks": tally[0], "pcm_checksum_all_ranks": tally[1],
+                   "first_step_verified": verified,
+                   "voice_samples_per_s": frames_total / dt * args.voices,
+                   "operator_samples_per_s": frames_total / dt * n_ops},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                     "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": source,
+                     "kernel": "fast_kernel<8, false>", "avg_launch_ms": launch_s * 1e3,
+                     "launches": tm["segments"], "algorithmic_bytes_per_launch": alg_bytes},
+    }
+    if not args.no_cpu and R.world == 1:
+        out["cpu_baseline"] = cpu_reference(lambda: voicebank.config3(n=args.voices, seconds=30),
+                                            f"config 3 ({args.voices} voices x depth-3 PM)", args.voices, 4,
+                                            tabs, all_cores=True)
+    return out
+
+
+def run_config4(args, R, sa, tabs):
+    import numpy as np
+    from saugns_amd.shard import shard_range
+    fx = np.load(os.path.join(GOLDEN, "config4_seeds.npz"))
+    per_gpu = args.renders
+    total = min(512, per_gpu * R.world)
+    a, b = shard_range(total, R.rank, R.world)
+    prgs = [sa.Program.from_image(fx["images"][k].tobytes()) for k in range(a, b)]
+    frames_each = int(fx["frames"][0])
+    run_len = 441000
+
+    def step(fetch, timing=None):
+        batch = sa.Batch(prgs, 44100)
+        batch.set_call_len(11289)  # the reference host's call size (saugns.c:471,526)
+        if timing is not None:
+            batch.set_timing(2)
+        outs = [[] for _ in prgs]
+        alive, n = True, 0
+        while alive:
+            pcm, more, lens = batch.run(run_len, stereo=False, fetch=fetch)
+            if fetch:
+                for i in range(len(prgs)):
+                    outs[i].append(pcm[i, :lens[i]].copy())
+            n += sum(lens)
+            alive = any(more)
+        batch.sync()
+        if timing is not None:
+            t = batch.timing_ex()
+            for k in timing:
+                timing[k] += t[k]
+        batch.close()
+        return n, outs
+
+    for _ in range(args.warmup):
+        step(False)
+    R.barrier()
+    tm = {"fast_ms": 0.0, "block_ms": 0.0, "mix_ms": 0.0, "aux_ms": 0.0, "segments": 0}
+    t0 = time.perf_counter()
+    frames_mine = 0
+    for _ in range(args.steps):
+        frames_mine += step(False, tm)[0]
+    R.barrier()
+    dt = R.max(time.perf_counter() - t0)
+    # after the timed region: every render against the reference's SHA-256, then the ranks' report
+    n, outs = step(True)
+    bad = [a + i for i, o in enumerate(outs) if sha256(np.concatenate(o)) != str(fx["sha256"][a + i])]
+    if bad:
+        raise SystemExit(f"rank {R.rank}: renders {bad[:8]} differ from the reference's SHA-256")
+    checksum = sum(int(np.concatenate(o).astype(np.int64).sum()) for o in outs) & 0x7FFFFFFFFFFF
+    tally = R.sum([frames_mine, n, checksum, len(prgs)])
+    if tally[0] != args.steps * frames_each * total or tally[3] != total:
+        raise SystemExit(f"rank {R.rank}: frame count {tally} does not add up to {total} renders")
+    if R.rank != 0:
+        return None
+    # 7 operators per render (2 voices): 8 B per operator-sample + 2 B per output frame
+    alg = (7 * 8 + 2) * frames_each * len(prgs)
+    kern_s = tm["fast_ms"] / 1e3 / args.steps
+    achieved = alg / kern_s / 1e9 if kern_s > 0 else 0.0
+    return {
+        "metric": "mono samples/sec, examples/rainy_thunder.sau x 512 renders sharded over GPUs",
+        "value": tally[0] / dt, "unit": "mixed mono int16 frames/s summed over renders",
+        "n_gpus": R.world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32 (u64 cycle counters, u32 phase)", "data": "synthetic",
+        "config": {"workload": f"BASELINE config 4: rainy_thunder.sau with seed=k, {len(prgs)} renders per GPU "
+                               f"(seeds shard_range({total}, rank, {R.world})), 60 s at 44.1 kHz mono each; one step = "
+                               f"the rank's renders from generator creation to the last frame",
+                   "renders_all_ranks": tally[3], "frames_all_ranks": tally[0],
+                   "pcm_checksum_all_ranks": tally[2],
+                   "verified": f"SHA-256 of every one of the {total} renders equals the compiled reference's "
+                               "(tests/golden/config4_seeds.npz)"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                     "frac": achieved / 8000.0, "traffic": None, "traffic_source": None,
+                     "kernel": "fast_kernel<4, true> (two sum passes + final pass per segment)",
+                     "kernel_ms_per_step": kern_s * 1e3, "other_kernels_ms_per_step":
+                     {k: tm[k] / args.steps for k in ("block_ms", "mix_ms", "aux_ms")},
+                     "segments_per_step": tm["segments"] / args.steps,
+                     "algorithmic_bytes_per_step": alg,
+                     "note": "128 voices per GPU cannot fill 256 CUs: this workload is bound by the launch "
+                             "sequence per segment, not by a roofline"},
+    }
+
+
+def run_config5(args, R, sa, tabs):
+    import numpy as np
+    from saugns_amd import voicebank
+    index = json.load(open(os.path.join(GOLDEN, "index.json")))
+    prg = voicebank.config5(n=args.voices5, seconds=10)
+    frames = 441000
+
+    def step(fetch, timing=None):
+        batch = sa.Batch([prg], 44100)
+        if timing is not None:
+            batch.set_timing(2)
+        pcm = batch.run(frames, stereo=False, fetch=fetch)[0]
+        batch.sync()
+        if timing is not None:
+            t = batch.timing_ex()
+            for k in timing:
+                timing[k] += t[k]
+        batch.close()
+        return pcm
+
+    pcm = step(True)
+    verified = None
+    if args.voices5 == 4096:
+        got, want = sha256(pcm[0]), index["configs"]["config5"]["sha256"]
+        if got != want:
+            raise SystemExit(f"rank {R.rank}: config 5 PCM {got[:16]} is not the reference's {want[:16]}")
+        verified = {"sha256": got, "equals": "tests/golden/index.json configs.config5.sha256 (compiled reference)"}
+    for _ in range(args.warmup):
+        step(False)
+    R.barrier()
+    tm = {"fast_ms": 0.0, "block_ms": 0.0, "mix_ms": 0.0, "aux_ms": 0.0, "segments": 0}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(False, tm)
+    R.barrier()
+    dt = R.max(time.perf_counter() - t0)
+    mine = [frames * args.steps, int(np.asarray(pcm, dtype=np.int64).sum() & 0x7FFFFFFF)]
+    tally = R.sum(mine)
+    if tally[0] != frames * args.steps * R.world or tally[1] != mine[1] * R.world:
+        raise SystemExit(f"rank {R.rank}: ranks disagree ({tally} vs {mine} x {R.world})")
+    if R.rank != 0:
+        return None
+    n_ops = args.voices5 * 2
+    alg = (n_ops * 8 + 2) * frames
+    dom = max(("block_ms", "fast_ms"), key=lambda k: tm[k])
+    kern_s = tm[dom] / 1e3 / args.steps
+    achieved = alg / kern_s / 1e9 if kern_s > 0 else 0.0
+    out = {
+        "metric": "mono samples/sec/GPU @ N voices (self-feedback FM + AM + ramps)",
+        "value": tally[0] / dt, "unit": "mixed mono int16 frames/s",
+        "n_gpus": R.world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32 (f64 table interpolation, u32 phase)", "data": "synthetic",
+        "config": {"workload": f"BASELINE config 5: {args.voices5} voices x (self-modulated carrier with frequency, "
+                               f"amplitude and feedback ramps + range-AM modulator) = {n_ops} operators, 44.1 kHz mono; "
+                               f"one step = the script's whole 10 s ({frames} frames) from generator creation on",
+                   "voices": args.voices5, "operators": n_ops, "frames_per_step": frames,
+                   "frames_all_ranks": tally[0], "pcm_checksum_all_ranks": tally[1], "verified": verified,
+                   "operator_samples_per_s": tally[0] / dt * n_ops},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                     "frac": achieved / 8000.0, "traffic": None, "traffic_source": None,
+                     "kernel": "feedback recurrence + block loop (" + dom + ")",
+                     "kernel_ms_per_step": kern_s * 1e3,
+                     "all_kernels_ms_per_step": {k: tm[k] / args.steps for k in ("fast_ms", "block_ms", "mix_ms", "aux_ms")},
+                     "segments_per_step": tm["segments"] / args.steps,
+                     "algorithmic_bytes_per_step": alg},
+    }
+    if not args.no_cpu and R.world == 1:
+        out["cpu_baseline"] = cpu_reference(lambda: voicebank.config5(n=args.voices5, seconds=10),
+                                            f"config 5 ({args.voices5} feedback voices)", args.voices5, 2, tabs)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", choices=["config3", "config4", "config5"], default="config3")
+    ap.add_argument("--frames", type=int, default=441000, help="config3: frames per step")
+    ap.add_argument("--voices", type=int, default=1024, help="config3: voices")
+    ap.add_argument("--renders", type=int, default=64, help="config4: renders per GPU")
+    ap.add_argument("--voices5", type=int, default=4096, help="config5: voices")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+    defaults = {"config3": (20, 3), "config4": (5, 1), "config5": (5, 1)}[args.workload]
+    if args.steps is None:
+        args.steps = defaults[0]
+    if args.warmup is None:
+        args.warmup = defaults[1]
+
+    import numpy as np
+    R = Ranks()
+    import saugns_amd as sa
+    tabs = np.fromfile(os.path.join(GOLDEN, "piluts_ref.f32"), dtype="<f4").reshape(12, 2048)
+    sa.set_piluts(tabs)
+    out = {"config3": run_config3, "config4": run_config4, "config5": run_config5}[args.workload](args, R, sa, tabs)
+    if out is not None:
+        out["roofline"]["kernel_source_sha"] = kernel_source_hash()
         print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    R.close()
 
 
 if __name__ == "__main__":

@@ -2703,12 +2703,20 @@ public:
 		(void)hipGetDevice(&dev);
 		std::lock_guard<std::mutex> lk(mu_);
 		size_t &held = pinned ? held_pin_ : held_dev_;
-		if (held + bytes > (pinned ? (size_t)1 << 30 : (size_t)16 << 30)) return false;
+		/* what the pool may keep between generators: 16 GiB of the 288 GB of HBM, 1 GiB page-locked;
+		 * SAU_AMD_POOL_MB / SAU_AMD_PINNED_POOL_MB set other caps (0: keep nothing) */
+		static const size_t cap_dev = env_mb("SAU_AMD_POOL_MB", (size_t)16 << 10);
+		static const size_t cap_pin = env_mb("SAU_AMD_PINNED_POOL_MB", (size_t)1 << 10);
+		if (held + bytes > (pinned ? cap_pin : cap_dev)) return false;
 		(pinned ? pin_ : dev_[dev & 15]).emplace(bytes, q);
 		held += bytes;
 		return true;
 	}
 private:
+	static size_t env_mb(const char *name, size_t def_mb) {
+		const char *v = getenv(name);
+		return (v ? (size_t)atoll(v) : def_mb) << 20;
+	}
 	std::mutex mu_;
 	std::multimap<size_t, void *> dev_[16], pin_;
 	size_t held_dev_ = 0, held_pin_ = 0;
@@ -2836,7 +2844,13 @@ int device_count() {
 
 class HipBackendImpl : public HipBackend {
 public:
+	/* every entry point runs on this backend's device, whatever the host thread's current one is
+	 * (another generator on another GPU, torch.cuda.set_device): allocations, the pools (keyed by
+	 * the current device) and launches all follow it */
+	void use_device() { (void)hipSetDevice(dev_); }
+
 	~HipBackendImpl() override {
+		use_device();
 		/* the buffers go back to the pool (member destructors): nothing may still be using them */
 		if (stream_) (void)hipStreamSynchronize(stream_);
 		for (int i = 0; i < 2; ++i) if (fetch_ev_[i]) (void)hipEventDestroy(fetch_ev_[i]);
@@ -2867,7 +2881,7 @@ public:
 		}
 		if (lds_limit_ > 160 * 1024) lds_limit_ = 160 * 1024;
 		if (const char *ll = getenv("SAU_AMD_LDS_LIMIT")) lds_limit_ = (size_t)atol(ll);
-		const char *wt = getenv("SAU_AMD_GEOMETRY"); /* "8x2" (default) or "4x4" */
+		const char *wt = getenv("SAU_AMD_GEOMETRY"); /* "4x4" (default) or "8x2" */
 		geo_ = (wt && !strcmp(wt, "8x2")) ? 0 : 1; /* default 4 waves x 4 samples per lane */
 		debug_ = getenv("SAU_AMD_DEBUG") != nullptr;
 		fast_enabled_ = getenv("SAU_AMD_NO_FAST") == nullptr;
@@ -2890,6 +2904,7 @@ public:
 	}
 
 	bool reserve_frames(uint32_t max_frames, bool stereo, std::string &err) override {
+		use_device();
 		HIP_OK(hipStreamSynchronize(stream_));
 		row_stride_ = (max_frames + 63) & ~63u;
 		pcm_row_ = (size_t)row_stride_ * 2; /* room for stereo */
@@ -2929,6 +2944,7 @@ public:
 
 	bool upload_plans(const Step *steps, const FastIds *fast_ids, size_t n_steps, const uint32_t *op_ids,
 			size_t n_ids, std::string &err) override {
+		use_device();
 		if (!steps_.ensure(n_steps ? n_steps : 1, err) || !op_ids_.ensure(n_ids ? n_ids : 1, err) ||
 		    !fast_ids_.ensure(n_steps ? 2 * n_steps : 1, err))
 			return false;
@@ -2939,6 +2955,7 @@ public:
 	}
 
 	bool apply_updates(const OpUpdate *recs, size_t n, std::string &err) override {
+		use_device();
 		if (!n) return true;
 		if (!recs_.ensure(n, err) || !send(recs_.p, recs, n * sizeof(OpUpdate), err)) return false;
 		hipLaunchKernelGGL(event_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream_,
@@ -2948,6 +2965,7 @@ public:
 	}
 
 	bool clear_pcm(uint32_t frames, bool stereo, std::string &err) override {
+		use_device();
 		(void)frames; (void)stereo;
 		if (pcm_.p) HIP_OK(hipMemsetAsync(pcm_.p, 0, pcm_row_ * cfg_.n_streams * sizeof(int16_t), stream_));
 		return true;
@@ -2955,11 +2973,11 @@ public:
 
 	template <int W, int T, int V>
 	bool launch_render(const RenderParams &rp, uint32_t grid, size_t lds, std::string &err) {
-		static size_t configured = 0;
-		if (lds > configured) {
+		static size_t configured[16]; /* per device (function attributes are per device) */
+		if (lds > configured[dev_ & 15]) {
 			HIP_OK(hipFuncSetAttribute((const void *)render_kernel<W, T, V>,
 					hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-			configured = lds;
+			configured[dev_ & 15] = lds;
 		}
 		hipLaunchKernelGGL((render_kernel<W, T, V>), dim3(grid), dim3(64 * W * V), lds, stream_, rp);
 		HIP_OK(hipGetLastError());
@@ -2967,6 +2985,7 @@ public:
 	}
 
 	bool render(const SegmentDesc &seg, std::string &err) override {
+		use_device();
 		if (!seg.n_voices) return true;
 		++acc_launches_; /* segments rendered */
 		const size_t tab_bytes = (size_t)WAVE_LEN * (sizeof(HerpC23) + sizeof(HerpC01));
@@ -3138,8 +3157,8 @@ public:
 					                                                          : (const void *)fast_kernel<2, true>)
 					: (FT == 8 ? (const void *)fast_kernel<8, false> : FT == 4 ? (const void *)fast_kernel<4, false>
 					                                                           : (const void *)fast_kernel<2, false>);
-				static size_t fconfigured[6] = {0, 0, 0, 0, 0, 0};
-				size_t &conf = fconfigured[(FT == 8 ? 2 : FT == 4 ? 1 : 0) + (scan_build ? 3 : 0)];
+				static size_t fconfigured[16][6];
+				size_t &conf = fconfigured[dev_ & 15][(FT == 8 ? 2 : FT == 4 ? 1 : 0) + (scan_build ? 3 : 0)];
 				if (flds > conf) {
 					HIP_OK(hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
 					conf = flds;
@@ -3178,8 +3197,8 @@ public:
 				{ /* row groups noted for a second evaluation: returns at once when there are none */
 					const void *rk = FT == 8 ? (const void *)repair_kernel<8> : FT == 4 ? (const void *)repair_kernel<4>
 					                                                                    : (const void *)repair_kernel<2>;
-					static size_t rconfigured[3] = {0, 0, 0};
-					size_t &rconf = rconfigured[FT == 8 ? 2 : FT == 4 ? 1 : 0];
+					static size_t rconfigured[16][3];
+					size_t &rconf = rconfigured[dev_ & 15][FT == 8 ? 2 : FT == 4 ? 1 : 0];
 					if (flds > rconf) {
 						HIP_OK(hipFuncSetAttribute(rk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
 						rconf = flds;
@@ -3252,6 +3271,7 @@ public:
 	}
 
 	bool fetch_pcm(uint32_t stream, int16_t *dst, uint32_t frames, bool stereo, std::string &err) override {
+		use_device();
 		const size_t n = (size_t)frames * (stereo ? 2 : 1);
 		/* the caller's memory is pageable: a device copy straight into it costs milliseconds of
 		 * pinning per call, so the PCM goes through a page-locked block (unless dst is one) */
@@ -3269,6 +3289,7 @@ public:
 	bool fetch_pcm_async(uint32_t stream, int16_t *dst, uint32_t frames, bool stereo, int slot,
 			std::string &err) override {
 		slot &= 1;
+		use_device();
 		if (!fetch_ev_[slot]) HIP_OK(hipEventCreateWithFlags(&fetch_ev_[slot], hipEventDisableTiming));
 		HIP_OK(hipMemcpyAsync(dst, pcm_.p + pcm_row_ * stream,
 				(size_t)frames * (stereo ? 2 : 1) * sizeof(int16_t), hipMemcpyDeviceToHost, stream_));
@@ -3281,12 +3302,14 @@ public:
 		return true;
 	}
 	void *alloc_host(size_t bytes) override {
+		use_device();
 		std::string err;
 		void *p = pool_alloc(true, bytes, err);
 		if (p) host_blocks_[p] = bytes;
 		return p;
 	}
 	void free_host(void *p) override {
+		use_device();
 		auto it = host_blocks_.find(p);
 		if (it == host_blocks_.end()) return;
 		(void)hipStreamSynchronize(stream_);
@@ -3297,6 +3320,7 @@ public:
 	const int16_t *device_pcm(uint32_t stream) override { return pcm_.p ? pcm_.p + pcm_row_ * stream : nullptr; }
 
 	bool sync(std::string &err) override {
+		use_device();
 		HIP_OK(hipStreamSynchronize(stream_));
 		arena_used_ = 0; /* every staged copy has left the arena */
 		return true;

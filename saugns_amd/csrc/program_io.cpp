@@ -101,10 +101,15 @@ extern "C" size_t sauAmd_program_serialize(const sauProgram *prg, void *buf, siz
 }
 
 namespace {
-template <typename T> bool fix(T *&field, uint8_t *base, size_t len, size_t need) {
+/* An offset field becomes a pointer to `count` objects of `size` bytes, all inside the image:
+ * 8-byte aligned (as the writer lays blocks out), past the header, no overflow in the product;
+ * 0 is NULL and only allowed when nothing is counted there. */
+template <typename T> bool fix(T *&field, uint8_t *base, size_t len, size_t size, size_t count,
+		bool null_ok_when_empty = true) {
 	uint64_t off = (uint64_t)(uintptr_t)field;
-	if (off == 0) { field = nullptr; return true; }
-	if (off > len || need > len - off) return false;
+	if (off == 0) { field = nullptr; return count == 0 && null_ok_when_empty; }
+	if (off % 8 != 0 || off < 16 + sizeof(sauProgram) || off > len) return false;
+	if (size && count > (len - off) / size) return false;
 	field = (T *)(base + off);
 	return true;
 }
@@ -115,26 +120,30 @@ extern "C" sauProgram *sauAmd_program_load(const void *image, size_t len) {
 		return nullptr;
 	uint64_t total;
 	memcpy(&total, (const uint8_t *)image + 8, 8);
-	if (total > len) return nullptr;
+	if (total > len || total < 16 + sizeof(sauProgram)) return nullptr;
 	uint8_t *base = (uint8_t *)malloc(total);
 	if (!base) return nullptr;
 	memcpy(base, image, total);
 	sauProgram *prg = (sauProgram *)(base + 16);
-	bool ok = fix(prg->events, base, total, sizeof(sauProgramEvent) * prg->ev_count);
+	bool ok = fix(prg->events, base, total, sizeof(sauProgramEvent), prg->ev_count);
 	for (size_t i = 0; ok && i < prg->ev_count; ++i) {
 		sauProgramEvent *ev = (sauProgramEvent *)&prg->events[i];
-		ok = ok && fix(ev->op_list, base, total, sizeof(sauProgramOpRef) * ev->op_count);
-		ok = ok && fix(ev->op_data, base, total, sizeof(sauProgramOpData) * ev->op_data_count);
-		for (size_t k = 0; ok && ev->op_data && k < ev->op_data_count; ++k) {
+		if (ev->op_list == nullptr) ev->op_count = 0; /* (the list is optional: generator.c never reads it) */
+		ok = ok && fix(ev->op_list, base, total, sizeof(sauProgramOpRef), ev->op_count);
+		ok = ok && fix(ev->op_data, base, total, sizeof(sauProgramOpData), ev->op_data_count);
+		for (size_t k = 0; ok && k < ev->op_data_count; ++k) {
 			sauProgramOpData *od = (sauProgramOpData *)&ev->op_data[k];
 			sauLine **lines[] = {&od->pan, &od->amp, &od->amp2, &od->freq, &od->freq2, &od->pm_a};
-			for (sauLine **l : lines) ok = ok && fix(*l, base, total, sizeof(sauLine));
+			for (sauLine **l : lines) ok = ok && (*l == nullptr || fix(*l, base, total, sizeof(sauLine), 1));
 			const sauProgramIDArr **arrs[] = {&od->camods, &od->amods, &od->ramods, &od->fmods,
 				&od->rfmods, &od->pmods, &od->apmods, &od->fpmods};
 			for (const sauProgramIDArr **a : arrs) {
-				ok = ok && fix(*a, base, total, sizeof(uint32_t));
-				if (ok && *a)
-					ok = ((uint8_t *)(*a) - base) + sizeof(uint32_t) * (1 + (size_t)(*a)->count) <= total;
+				if (*a == nullptr) continue;
+				ok = ok && fix(*a, base, total, sizeof(uint32_t), 1);
+				if (ok) {
+					const size_t at = (size_t)((const uint8_t *)(*a) - base);
+					ok = (*a)->count <= (total - at) / sizeof(uint32_t) - 1;
+				}
 			}
 		}
 	}

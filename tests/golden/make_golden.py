@@ -35,7 +35,47 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
+def config4_all(index):
+    """BASELINE config 4 as stated: examples/rainy_thunder.sau with the CLI predefine seed=k,
+    k = 0..511 (sau/parser.c:1170, sau/math.c:35-41), 60 s at 44.1 kHz mono each. All 512 program
+    images in one array (they differ in three R-oscillator seeds) + the SHA-256 of every full
+    render by the compiled reference."""
+    images, shas, frames = [], [], []
+    for k in range(512):
+        p = po.ref_build_program(REF + "/examples/rainy_thunder.sau", is_path=True, predefs={"seed": k})
+        images.append(np.frombuffer(sa.Program.borrow(p).image(), np.uint8))
+        pcm = po.ref_render(p, 44100, False)
+        shas.append(sha(pcm))
+        frames.append(len(pcm))
+        po.ref_discard_program(p)
+    assert len({len(i) for i in images}) == 1
+    np.savez_compressed(os.path.join(OUT, "config4_seeds.npz"), images=np.stack(images),
+                        sha256=np.array(shas), frames=np.array(frames, np.int64))
+    index["configs"]["config4_all"] = {"renders": 512, "frames_each": int(frames[0]),
+                                       "sha256_of_sha256s": hashlib.sha256("".join(shas).encode()).hexdigest()}
+
+
+def config5_full(index):
+    """The whole 10 s of config 5 (4096 feedback voices) through the compiled reference: ~90 s of CPU."""
+    p = po.ref_build_program(voicebank.config_scripts()["config5"])
+    pcm = po.ref_render(p, 44100, False)
+    index["configs"]["config5"]["frames"] = int(len(pcm))
+    index["configs"]["config5"]["sha256"] = sha(pcm)
+
+
+def update_only(what):
+    """Add fixtures to an existing tests/golden/ without touching the others:
+    python tests/golden/make_golden.py --only config4_all,config5_full"""
+    path = os.path.join(OUT, "index.json")
+    index = json.load(open(path))
+    for w in what:
+        {"config4_all": config4_all, "config5_full": config5_full}[w](index)
+    json.dump(index, open(path, "w"), indent=1, sort_keys=True)
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "--only":
+        return update_only(sys.argv[2].split(","))
     os.makedirs(os.path.join(OUT, "programs"), exist_ok=True)
     tables = po.ref_piluts()
     tables.astype("<f4").tofile(os.path.join(OUT, "piluts_ref.f32"))
@@ -141,6 +181,8 @@ def main():
     np.savez_compressed(os.path.join(OUT, "sndfile_kat.npz"), **snd)
 
     np.savez_compressed(os.path.join(OUT, "pcm_heads.npz"), **pcm_store)
+    config4_all(index)
+    config5_full(index)
     json.dump(index, open(os.path.join(OUT, "index.json"), "w"), indent=1, sort_keys=True)
     print("programs:", len(index["corpus"]), "configs:", list(index["configs"]))
 

@@ -36,10 +36,16 @@ def test_two_rank_gloo_batch(tmp_path):
         sa.set_piluts(tabs)
         seq = C.CDLL(os.path.join(%r, "tests", "seqexec", "libseqexec.so"))
         seq.seq_backend_create.restype = C.c_void_p; seq.seq_backend_create.argtypes = [C.c_uint32]
+        # as bench.py --workload config4 shards them: seeds of tests/golden/config4_seeds.npz (all 512
+        # of BASELINE config 4), here two renders per rank
+        fx = np.load(os.path.join(GOLDEN, "config4_seeds.npz"))
         keys = ["config4_seed%%d" %% k for k in range(4)]
-        a, b = shard_range(len(keys), rank, world)
-        prgs = [load_program(sa, k) for k in keys[a:b]]
-        outs = sa.Batch(prgs, 44100, backend=seq.seq_backend_create(1016)).render(chunk=11025, max_frames=11025)
+        a, b = shard_range(2 * world, rank, world)
+        assert (a, b) == (2 * rank, 2 * rank + 2)
+        prgs = [sa.Program.from_image(fx["images"][k].tobytes()) for k in range(a, b)]
+        batch = sa.Batch(prgs, 44100, backend=seq.seq_backend_create(1016))
+        batch.set_call_len(11289)
+        outs = batch.render(chunk=11025, max_frames=11025)
         heads = np.load(os.path.join(GOLDEN, "pcm_heads.npz"))
         for k, pcm in zip(keys[a:b], outs):
             assert int(np.abs(pcm.astype(int) - heads[k][:11025].astype(int)).max()) <= 1, k

@@ -492,6 +492,69 @@ def test_r_oscillator_options(sa, oracle, line):
         check(sa, oracle, fed_back, chunk=1100)
 
 
+def amp_operator_cases():
+    """The A (amplitude) operator, generator.c:505-520 run_block_amp / README.SAU:61-62: a source
+    of 1.0 scaled by its amplitude parameter -- every ramp shape, amplitude and range-amplitude
+    modulators of its own, a duration shorter than its parent's -- in every role: carrier (a DC
+    level), amplitude / range-amplitude / frequency / range-frequency / phase / frequency-scaled
+    phase / self-modulation-amount / pan modulator, alone and layered beside other modulators.
+    -> list of (name, voices, later events)."""
+    from saugns_amd.api import POPT_AMP
+    A = lambda amp, **kw: vb.Op(amp=amp, op_type=POPT_AMP, **kw)
+    cases = []
+    for shape in LINES:
+        cases.append((f"carrier ramp {shape}", [A(vb.Line(0.1, goal=0.9, shape=shape), time_ms=30)], ()))
+        cases.append((f"amod ramp {shape}", [vb.Op("sin", freq=300.0, amp=0.2, time_ms=30,
+                                                  mods={POP_AMOD: [A(vb.Line(0.0, goal=0.7, shape=shape))]})], ()))
+    lfo = lambda f=6.0, a=0.5: vb.Op("sin", freq=f, amp=a)
+    cases += [
+        ("carrier held", [A(0.6, time_ms=25), A(-0.3, time_ms=40, pan=0.5)], ()),
+        ("carrier with amods and ramods", [A(0.4, amp2=0.9, time_ms=60, mods={POP_AMOD: [lfo(9.0, 0.2)], POP_RAMOD: [lfo(4.0, 1.0)]})], ()),
+        ("ramod source", [vb.Op("tri", freq=220.0, amp=0.2, amp2=0.9, time_ms=50,
+                                mods={POP_RAMOD: [A(vb.Line(0.0, goal=1.0, shape="cos"))]})], ()),
+        ("ramod source layered", [vb.Op("tri", freq=220.0, amp=0.2, amp2=0.9, time_ms=50,
+                                        mods={POP_RAMOD: [lfo(5.0, 1.0), A(0.5)]})], ()),
+        ("fmod source", [vb.Op("sin", freq=200.0, time_ms=50, mods={POP_FMOD: [A(vb.Line(0.0, goal=150.0, shape="lin"))]})], ()),
+        ("rfmod source", [vb.Op("sin", freq=200.0, freq2=400.0, time_ms=50,
+                                mods={POP_RFMOD: [A(vb.Line(0.0, goal=1.0, shape="sqe"))]})], ()),
+        ("pmod source", [vb.Op("sin", freq=200.0, time_ms=50, mods={POP_PMOD: [A(vb.Line(0.0, goal=2.0, shape="xpe")), lfo(3.0, 0.5)]})], ()),
+        ("fpmod source", [vb.Op("sin", freq=200.0, time_ms=50, mods={POP_FPMOD: [A(vb.Line(0.0, goal=30.0, shape="lin"))]})], ()),
+        ("apmod source", [vb.Op("sin", freq=200.0, time_ms=50, pm_a=0.3, mods={POP_APMOD: [A(vb.Line(0.0, goal=0.6, shape="lin"))]})], ()),
+        ("camod source", [vb.Op("sin", freq=200.0, time_ms=50, pan=-0.4, mods={POP_CAMOD: [A(vb.Line(0.0, goal=0.8, shape="lin"))]})], ()),
+        ("shorter than its parent", [vb.Op("sin", freq=250.0, amp=0.1, time_ms=60,
+                                           mods={POP_AMOD: [A(0.5, time_ms=20), lfo(7.0, 0.2)], POP_PMOD: [A(0.25, time_ms=35)]})], ()),
+        ("nested", [vb.Op("sin", freq=250.0, time_ms=60, mods={POP_PMOD: [
+            vb.Op("sin", freq=vb.Line(2.0, ratio=True), amp=0.1, mods={POP_AMOD: [A(0.7, mods={POP_AMOD: [lfo(11.0, 0.3)]})]})]})], ()),
+        ("in an R oscillator", [vb.Op(freq=180.0, amp=0.3, time_ms=50, op_type=POPT_RASEG, seed=77, ras=("cos", 1, 0),
+                                      mods={POP_AMOD: [A(vb.Line(0.0, goal=0.5, shape="lin"))], POP_FMOD: [A(40.0)]})], ()),
+    ]
+    # later events on an A operator: new value, new ramp, new duration
+    a1 = A(0.5)
+    c1 = vb.Op("sin", freq=300.0, amp=0.2, time_ms=80, mods={POP_AMOD: [a1]})
+    cases.append(("events on a modulator", [c1], [(20, 0, a1, {"amp": vb.Line(0.1)}),
+                                                  (35, 0, a1, {"amp": vb.Line(0.0, goal=0.9, shape="cos", state=False)}),
+                                                  (60, 0, a1, {"amp": vb.Line(0.3, goal=0.0, shape="lin"), "time_ms": 10})]))
+    c2 = A(0.3, time_ms=40)
+    cases.append(("events on a carrier", [c2], [(15, 0, c2, {"amp": vb.Line(0.0, goal=0.8, shape="lin", state=False)}),
+                                                 (30, 0, c2, {"amp": vb.Line(0.5), "time_ms": 30})]))
+    return cases
+
+
+def test_amp_operator(sa, oracle):
+    """A operator in every role (amp_operator_cases), bit-exact vs the oracle; tests/test_oracle.py
+    pins the oracle on the same cases against the compiled reference."""
+    oracle.oracle().ora_set_fastmath_forms(1)
+    for name, voices, ups in amp_operator_cases():
+        prg = vb.build_program(voices, updates=ups)
+        for stereo, chunk in ((True, 4000000), (False, 777)):
+            want = oracle.oracle_render(prg.ptr, RATE, stereo, chunk=chunk)
+            for path in ("drop-in", "batch"):
+                got = (sa.Generator(prg, RATE).render(stereo=stereo, chunk=chunk) if path == "drop-in"
+                       else sa.Batch([prg], RATE).render(stereo=stereo, chunk=chunk)[0])
+                assert len(got) == len(want) and (got == want).all(), (name, stereo, chunk, path)
+        assert np.abs(want.astype(np.int32)).max() > 0, name
+
+
 def test_pan_modulators(sa, oracle):
     """Pan modulator lists (generator.c:749-788): lasting as long as the carrier, shorter (the voice
     goes on with the pan line alone), longer, nested, beside a pan ramp; stereo and mono."""

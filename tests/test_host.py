@@ -352,3 +352,56 @@ def test_random_lattice_programs(sa, oracle, seqexec, rate):
         got = bt.render(stereo=stereo, chunk=run)[0]
         assert max_diff(got, want) == 0, (seed, call, run, block)
     assert dep >= 8, "too few of the programs depend on the call size"
+
+
+def test_malformed_program_images_are_rejected(sa):
+    """sauAmd_program_load on damaged images: NULL (ValueError here), never a wild access."""
+    import struct
+    blob = bytearray(open(os.path.join(GOLDEN, "programs", "config1.saup"), "rb").read())
+    good = sa.Program.from_image(bytes(blob))
+    assert good.struct.ev_count >= 1
+    total = struct.unpack_from("<Q", blob, 8)[0]
+    assert total == len(blob)
+
+    def rejected(b):
+        with pytest.raises(ValueError):
+            sa.Program.from_image(bytes(b))
+
+    for bad_total in (0, 8, 16, 79, total + 8, 2 ** 63):  # size field vs header and buffer
+        b = bytearray(blob); struct.pack_into("<Q", b, 8, bad_total); rejected(b)
+    ev_off = struct.unpack_from("<Q", blob, 16)[0]       # sauProgram.events (offset form)
+    b = bytearray(blob); struct.pack_into("<Q", b, 16, 0); rejected(b)             # events counted, none there
+    b = bytearray(blob); struct.pack_into("<Q", b, 16, ev_off + 4); rejected(b)    # misaligned
+    b = bytearray(blob); struct.pack_into("<Q", b, 16, 8); rejected(b)             # inside the header
+    b = bytearray(blob); struct.pack_into("<Q", b, 24, 2 ** 61); rejected(b)       # ev_count * 40 wraps
+    b = bytearray(blob); struct.pack_into("<Q", b, 24, total); rejected(b)         # more events than bytes
+    # first event: op_data_count / op_data offset (sauProgramEvent: wait u32, vo u16, carr u32, op_count u32,
+    # op_data_count u32, op_list ptr, op_data ptr)
+    b = bytearray(blob); struct.pack_into("<I", b, ev_off + 16, 0x7fffffff); rejected(b)
+    b = bytearray(blob); struct.pack_into("<Q", b, ev_off + 32, 0); rejected(b)
+    b = bytearray(blob); struct.pack_into("<Q", b, ev_off + 32, total - 8); rejected(b)
+    rejected(blob[: total // 2])
+    rejected(b"SAUPIMG1" + bytes(200))
+    # every single-byte corruption of the pointer-bearing part either loads or is rejected cleanly
+    rng = np.random.default_rng(5)
+    for _ in range(400):
+        b = bytearray(blob)
+        b[int(rng.integers(8, len(b)))] = int(rng.integers(256))
+        try:
+            sa.Program.from_image(bytes(b))
+        except ValueError:
+            pass
+
+
+def test_amp_operator_through_the_plan(sa, oracle, seqexec):
+    """A operator cases (tests/test_gpu_units.py::amp_operator_cases) through the engine and the
+    plan format, executed sequentially: bit-exact vs the oracle."""
+    import test_gpu_units as tu
+    from saugns_amd import voicebank as vb
+    oracle.oracle().ora_set_fastmath_forms(1)
+    for name, voices, ups in tu.amp_operator_cases():
+        prg = vb.build_program(voices, updates=ups)
+        want = oracle.oracle_render(prg.ptr, 44100, True, chunk=777)
+        for block in (64, 1016):
+            got = sa.Batch([prg], 44100, backend=seqexec.seq_backend_create(block)).render(stereo=True, chunk=777)[0]
+            assert max_diff(got, want) == 0, (name, block)

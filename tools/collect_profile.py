@@ -12,9 +12,13 @@ tag, name = sys.argv[1], sys.argv[2]
 shutil.copy(f"gpurun_out/prof_{tag}/{tag}_kernel_stats.csv", f"profiles/{name}_bench_kernel_stats.csv")
 bench_line = open(f"gpurun_out/bench_{tag}.json").read().strip().splitlines()[-1]
 open(f"profiles/{name}_bench.json", "w").write(bench_line + "\n")
-frames_per_step = json.loads(bench_line)["config"]["frames_per_step"]
+bench = json.loads(bench_line)
+frames_per_step = bench["config"]["frames_per_step"]
 out = {"command": "rocprofv3 --pmc <C> --kernel-trace --output-format csv -- python3 bench.py --steps 4 --warmup 1 --no-cpu",
-       "workload": {"voices": 1024, "operators": 4096, "frames_per_step": frames_per_step},
+       "workload": {"name": "config3", "voices": bench["config"]["voices"], "operators": bench["config"]["operators"],
+                    "frames_per_step": frames_per_step},
+       # bench.py reports `traffic` from this file only while the kernel sources are the ones profiled
+       "kernel_source_sha": bench["roofline"].get("kernel_source_sha"),
        "note": "separate passes per counter group; FETCH_SIZE/WRITE_SIZE are KB per dispatch, averaged over "
                "dispatches; gfx950 correction: FETCH_SIZE doubled (MI355X_MICROARCH.md HBM section; confirmed "
                "here: mix_kernel reads voices x frames f32 and FETCH_SIZE reports half of it), WRITE_SIZE "
@@ -38,5 +42,5 @@ for k, v in out["kernels"].items():
         v["hbm_bytes_per_launch_corrected"] = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
 json.dump(out, open(f"profiles/{name}_pmc_summary.json", "w"), indent=1)
 fk = [v for n, v in out["kernels"].items() if "fast_kernel" in n][0]
-rows = 1024 * 4 * frames_per_step / 60  # 64-lane rows incl. lead-in, per launch
+rows = bench["config"]["operators"] * frames_per_step / 60  # 64-lane rows incl. lead-in, per launch
 print({a: (round(b / rows, 2) if isinstance(b, float) and b > 1e6 else b) for a, b in fk.items()})
