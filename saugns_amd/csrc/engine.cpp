@@ -283,7 +283,7 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 	uint32_t n_main = 1, n_fpool = 0, max_ops = 1, n_pan = 0, max_steps = 1, n_fast = 1, n_fast_full = 0;
 	uint64_t wave_mask = 0;
 	bool maybe_block = false, serial = false, may_scan = false;
-	uint32_t sum_levels = 0;
+	uint32_t sum_levels = 0, n_chain_rows = 0;
 	for (size_t s = 0; s < streams_.size(); ++s) {
 		Stream &st = streams_[s];
 		SegmentDesc::Stream &sd = sdescs[s];
@@ -326,6 +326,8 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 			d.pan_dynamic_row = dyn ? n_pan++ : ~0u;
 			d.flags = vn.plan.no_fast ? VD_NO_FAST : 0;
 			d.lat = lat;
+			d.chain_base = n_chain_rows; d.n_chain = vn.plan.n_chain;
+			n_chain_rows += vn.plan.n_chain;
 			if (dyn) line_begin(carr.pan, out_len, false, 0.f, lat, 0);
 			else line_skip(carr.pan, out_len, lat, 0);
 			descs.push_back(d);
@@ -376,6 +378,7 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 	seg.serial = serial;
 	seg.may_scan = may_scan;
 	seg.sum_levels = sum_levels;
+	seg.n_chain_rows = n_chain_rows;
 	return backend_->render(seg, err);
 }
 
@@ -450,10 +453,12 @@ bool Engine::run(int16_t *const *host_bufs, size_t buf_len, bool stereo,
 		constexpr uint32_t EXPIRY_GRID = 8192;
 		if (seg > EXPIRY_GRID) {
 			uint32_t first = seg;
+			bool chains = false;
 			for (Stream &st : streams_)
 				for (uint32_t v = st.voice; v < st.voices.size(); ++v) {
 					const VoiceHost &vn = st.voices[v];
 					if (vn.duration == 0 || vn.carr_op >= st.ops.size()) continue;
+					if (vn.plan.n_chain) chains = true;
 					for (uint32_t id : vn.plan.op_ids) {
 						const OpMirror &m = st.ops[id];
 						if (id != vn.carr_op && !m.time_inf && m.time > 0 && m.time < first) first = m.time;
@@ -463,6 +468,7 @@ bool Engine::run(int16_t *const *host_bufs, size_t buf_len, bool stereo,
 				const uint32_t cut = (first + EXPIRY_GRID - 1) / EXPIRY_GRID * EXPIRY_GRID;
 				if (cut < seg) seg = cut;
 			}
+			if (chains && seg > CHAIN_SEG) seg = CHAIN_SEG; /* rows in HBM carry one segment of every recurrence */
 		}
 		for (Stream &st : streams_)
 			if (st.event < st.events.size()) st.event_pos += seg;

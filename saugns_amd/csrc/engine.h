@@ -53,6 +53,7 @@ struct SegmentDesc {
 	uint64_t wave_mask;       /* wave ids in use (bit per id) */
 	bool maybe_block;         /* some voice may need the block loop (sweeps, FM, ...) */
 	bool serial;              /* some voice may run a per-sample feedback recurrence (self-modulation) */
+	uint32_t n_chain_rows = 0;/* row pairs the voices' chain_base/n_chain span */
 };
 
 struct BackendConfig {
@@ -127,6 +128,7 @@ struct VoicePlan {
 	bool no_fast = false;          /* an operator is evaluated twice per block */
 	bool static_block = false;     /* graph has FM / feedback / R / filtered noise: block loop */
 	bool selfmod = false;          /* a self-modulation amount has modulators of its own */
+	uint32_t n_chain = 0;          /* oscillator steps that may run a feedback recurrence (step_may_chain) */
 };
 
 /* Flatten the graph under `carrier` into steps. Returns false (with err) when
@@ -135,6 +137,10 @@ bool compile_voice_plan(const std::vector<OpMirror> &ops, uint32_t carrier,
 		VoicePlan &out, std::string &err);
 
 /* ---- engine ---------------------------------------------------------------- */
+
+/* Segments with feedback voices are at most this long: the recurrences' inputs and outputs pass
+ * through per-chain rows in HBM, sized for one segment. */
+constexpr uint32_t CHAIN_SEG = 65536;
 
 class Engine {
 public:

@@ -1114,6 +1114,7 @@ struct FastInfo {
 	uint32_t levels; /* deepest level among them (1: no sum depends on another) */
 	uint32_t lvl_bits; /* 2 bits per such oscillator, in plan order: its level */
 	uint32_t xlead;  /* lead-in lanes beyond the nesting depth (ratio frequencies below modulated blocks); in H */
+	uint32_t n_chain; /* self-modulated oscillators handed to chain_kernel this segment */
 };
 
 struct FastStep;
@@ -1132,6 +1133,10 @@ constexpr uint32_t FAST_MAX_LEVELS = 3; /* running sums that depend on running s
 constexpr uint32_t FAST_REPAIR_SHIFT = 24; /* H + shift < 64 (H <= 32) */
 constexpr uint32_t FAST_MAX_REPAIR = 15;   /* noted row groups per voice and segment; more: block loop */
 constexpr uint32_t FAST_REPAIR_WORDS = 2 + 2 * FAST_MAX_REPAIR; /* count, pad, then (group, rows) pairs */
+constexpr uint32_t FAST_FLAGS = FAST_MAX_LEVELS + 2; /* pass_flags words */
+constexpr uint32_t FR_CHAIN_IN = 4u << FAST_MAX_LEVELS; /* FastStep.ramp: the chain-input pass runs this step */
+constexpr uint32_t FT_CHAIN = 1u << 18;     /* FastStep.type: a feedback chain (rows = bits of FastStep.pan) */
+constexpr uint32_t CHAIN_MARK = 0xC4A10001u; /* DevOp.ras_level of a W operator: chain_kernel staged its state */
 struct FastParams {
 	const VoiceDesc *voices;
 	const Step *steps;
@@ -1162,9 +1167,19 @@ struct FastParams {
 	                           * (scan_kernel) their prefixes */
 	uint32_t scan_groups;
 	uint32_t *pass_flags; /* [FAST_MAX_LEVELS]: some voice of the segment needs that sum pass (set by analyze_kernel);
-	                       * [FAST_MAX_LEVELS]: some voice has row groups noted for repair_kernel */
+	                       * [FAST_MAX_LEVELS]: some voice has row groups noted for repair_kernel;
+	                       * [FAST_MAX_LEVELS + 1]: some voice has feedback chains */
 	uint32_t *repair;     /* [voice][FAST_REPAIR_WORDS] */
 	uint32_t repair_on;   /* 0: such voices go to the block loop (SAU_AMD_NO_REPAIR, tests) */
+	/* feedback recurrences (wosc.h:273-310) out of the time-parallel passes: a pair of rows per chain in HBM --
+	 * base phases, then (in place) the samples; self-modulation amounts -- and what chain_kernel needs to run it */
+	float *chain_rows;    /* [n_chain_rows][2][chain_stride], or NULL: such voices go to the block loop */
+	uint32_t chain_stride, n_chain_rows;
+	ChainDesc *chain_desc;
+	FastLine *fplines;    /* [voice][max_steps]: the self-modulation amount line of a chain step without a block for it */
+	uint32_t n_ctabs;     /* wave tables chain_kernel stages in LDS */
+	int8_t ctab_of_wave[12];
+	uint8_t cwave_of_tab[12];
 	int8_t tab_of_wave[12];
 	uint8_t wave_of_tab[12];
 	WaveConst wc[12];
@@ -1202,6 +1217,10 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 	 * anything nested in it advances (run_block gives its subtree zero
 	 * length, generator.c:686-700): such subtrees are left out below. */
 	for (uint32_t i = 0; i < vd.nops; ++i) P.ops[ids[i]].rt_frozen = 0;
+	if (P.chain_desc)
+		for (uint32_t k = 0; k < vd.n_chain; ++k) P.chain_desc[vd.chain_base + k].n = 0;
+	const bool chain_ok = P.chain_rows != nullptr && P.scan != nullptr;
+	bool has_chain = false;
 	{
 		uint32_t dep = 0, frozen_at = 0;
 		for (uint32_t si = 0; si < vd.plan_len; ++si) {
@@ -1230,10 +1249,13 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 			if (ln == L_FREQ || ln == L_FREQ2) seq = true; /* phase becomes a running sum */
 			else if (ln == L_PAN) { /* fine when the plan gives the pan line a step of its own */
 				if (!(vd.plan_len && plan[vd.plan_len - 1].kind == ST_VOICE)) bad = true;
-			} else if (ln != L_AMP && ln != L_AMP2) bad = true;
+			} else if (ln == L_PMA) { if (!(chain_ok && o.type == OT_WAVE)) bad = true; }
+			else if (ln != L_AMP && ln != L_AMP2) bad = true;
 		}
 		if (o.type == OT_NOISE && o.wave == NZ_re) bad = true;
-		if (o.line[L_PMA].v0 != 0.f) bad = true; /* self-modulation is a recurrence */
+		/* self-modulation is a recurrence: W oscillators' go to chain_kernel, R's to the block loop */
+		if (o.line[L_PMA].v0 != 0.f && !(chain_ok && o.type == OT_WAVE)) bad = true;
+		if (o.type == OT_WAVE) o.ras_level = 0; /* (CHAIN_MARK of an earlier segment) */
 		o.rt_fconst_valid = 0;
 		o.rt_fblk_valid = 0;
 		o.st_phase = 0; /* until the kernels stage into it: see "modulated blocks" below */
@@ -1280,8 +1302,12 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 		const bool is_osc = o.type == OT_WAVE || o.type == OT_RASEG;
 		const bool freq_here = (st.kind == ST_LINE && st.which == L_FREQ) ||
 			(st.kind == ST_OSC && st.freq == NO_SLOT && is_osc);
-		if (st.kind == ST_SMLINE || st.kind == ST_ZERO) bad = true;
-		if (st.kind == ST_OSC && st.sm != NO_SLOT) bad = true;
+		if (st.kind == ST_ZERO) bad = true;
+		if (st.kind == ST_SMLINE && !(chain_ok && o.type == OT_WAVE)) bad = true;
+		if (st.kind == ST_OSC && st.sm != NO_SLOT && !(chain_ok && o.type == OT_WAVE)) bad = true;
+		if (step_may_chain(st) && o.type == OT_WAVE &&
+		    (st.sm != NO_SLOT || o.line[L_PMA].v0 != 0.f || (o.line[L_PMA].flags & LP_GOAL)))
+			has_chain = true;
 		/* a ratio line (sau/line.c:72) multiplies by the parent's frequency: one value, or a block */
 		bool pconst = false; float pf = 0.f;
 		if (st.fmul != NO_SLOT && st.fmul >= FSLOT_BASE) {
@@ -1398,6 +1424,42 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 	 * frequency inputs) depend on no other running-sum oscillator's output; level n + 1:
 	 * they depend on level-n outputs. Forward data-flow over the block buffers, two bits
 	 * per buffer: the deepest level its contents depend on. */
+	/* Feedback chains: the recurrence's inputs (frequency, phase modulators, amounts) must not depend on any
+	 * chain's output, and no running sum may either -- the sum passes and the chain-input pass run before
+	 * chain_kernel. Forward data-flow, one bit per block buffer ("depends on a chain's output"). */
+	if (has_chain && !bad) {
+		unsigned long long c0[4] = {0, 0, 0, 0};
+		auto dep = [&](uint32_t sl) -> bool {
+			if (sl == NO_SLOT) return false;
+			const uint32_t q = sl >> 6;
+			const unsigned long long a = q == 0 ? c0[0] : q == 1 ? c0[1] : q == 2 ? c0[2] : c0[3];
+			return ((a >> (sl & 63)) & 1ull) != 0;
+		};
+		auto set_dep = [&](uint32_t sl, bool v, bool keep) {
+			if (sl == NO_SLOT) return;
+			const unsigned long long bit = 1ull << (sl & 63);
+#pragma unroll
+			for (int q = 0; q < 4; ++q)
+				if ((int)(sl >> 6) == q) c0[q] = v ? (c0[q] | bit) : (keep ? c0[q] : (c0[q] & ~bit));
+		};
+		for (uint32_t si = 0; si < vd.plan_len && !bad; ++si) {
+			const Step st = plan[si];
+			const DevOp &o = P.ops[ids[st.op]];
+			if (o.rt_frozen) continue;
+			if (st.kind == ST_LINE) set_dep(st.out, dep(st.fmul), false);
+			else if (st.kind == ST_SMLINE) set_dep(st.out, false, false);
+			else if (st.kind == ST_LERP) set_dep(st.out, dep(st.freq) || dep(st.pm), true);
+			else if (st.kind == ST_OSC) {
+				const bool in_dep = dep(st.pm) || dep(st.fpm) || dep(st.freq) || dep(st.fmul) || dep(st.sm);
+				const bool chain = step_may_chain(st) && o.type == OT_WAVE &&
+					(st.sm != NO_SLOT || o.line[L_PMA].v0 != 0.f || (o.line[L_PMA].flags & LP_GOAL));
+				const bool fvar = (o.type == OT_WAVE || o.type == OT_RASEG) && !o.rt_fconst_valid;
+				if (chain && in_dep) bad = true;
+				if (fvar && (dep(st.freq) || dep(st.fmul))) bad = true;
+				if (!(st.which & OX_VOICE)) set_dep(st.out, chain || in_dep || dep(st.amp), (st.flags & SF_LAYER) != 0);
+			}
+		}
+	}
 	uint32_t seq_kind = seq ? 1u : 0u, n_scan_out = 0, levels_out = 0, lvl_bits_out = 0;
 	if (seq && !bad) {
 		unsigned long long t0[4] = {0, 0, 0, 0}, t1[4] = {0, 0, 0, 0};
@@ -1454,15 +1516,23 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 		}
 		n_scan_out = n_scan;
 	}
+	if (has_chain && !bad) {
+		if (seq_kind == 1) bad = true; /* (one wave in order: not with chains) */
+		else {
+			seq_kind = 2; /* multi-pass voice, possibly without sums */
+			atomicOr(&P.pass_flags[FAST_MAX_LEVELS + 1], 1u);
+		}
+	}
 	FastInfo fi;
 	/* Running-sum voices get one more lead-in lane than their data flow needs: a repeated phase on
 	 * the first lane an operator is defined in then spoils nothing that is stored (what it spoils
 	 * climbs one lane per nesting level and ends on the lane before the first stored one), where
 	 * closed-form voices have repair_kernel for that case (see FAST_REPAIR_SHIFT). */
-	if (seq) ++x_carrier;
+	if (seq || has_chain) ++x_carrier;
+	fi.n_chain = has_chain && !bad ? 1u : 0u;
 	fi.H = maxd + x_carrier; fi.xlead = x_carrier; fi.bail = 0; fi.n_fsteps = 0; fi.seq = seq_kind; fi.n_scan = n_scan_out; fi.levels = levels_out; fi.lvl_bits = lvl_bits_out;
 	fi.total = 0;
-	if (seq && !P.seq_enable) bad = true;
+	if ((seq || has_chain) && !P.seq_enable) bad = true;
 	if (!bad && vd.nops <= P.max_ops && vd.plan_len <= P.max_steps && maxd >= 1 && maxd + x_carrier <= P.np / 2)
 		fi.total = min(min_time, vd.run_len);
 	P.info[v] = fi;
@@ -1589,9 +1659,10 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 	/* lane si handles step si (plan_len <= 64) */
 	bool keep = false;
 	FastStep f;
-	FastLine fl;
+	FastLine fl, pl;
 	FastAux fa;
-	memset(&f, 0, sizeof f); memset(&fl, 0, sizeof fl); memset(&fa, 0, sizeof fa);
+	memset(&f, 0, sizeof f); memset(&fl, 0, sizeof fl); memset(&fa, 0, sizeof fa); memset(&pl, 0, sizeof pl);
+	bool is_chain = false, chain_line = false;
 	uint32_t dep = 0;
 	const uint32_t seq = P.info[v].seq;
 	if ((uint32_t)l < vd.plan_len) {
@@ -1606,6 +1677,10 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 		const DevOp &o = P.ops[ids[st.op]];
 		/* a frequency line is materialised only when it is not one value (sequential-scan voices) */
 		keep = !(st.kind == ST_LINE && st.which == L_FREQ && o.rt_fconst_valid);
+		/* a W oscillator whose self-modulation is on (generator.c:479-498, wosc.h:273-310): chain_kernel's */
+		is_chain = !o.rt_frozen && step_may_chain(st) && o.type == OT_WAVE &&
+			(st.sm != NO_SLOT || o.line[L_PMA].v0 != 0.f || (o.line[L_PMA].flags & LP_GOAL));
+		const uint32_t st_which = st.kind == ST_SMLINE ? (uint32_t)L_PMA : (uint32_t)st.which; /* (ST_SMLINE = the pm_a line into a block) */
 		bool zero_fill = false;
 		if (o.rt_frozen) {
 			/* out of time: of the whole subtree only the root's final step remains,
@@ -1633,7 +1708,7 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 		 * minus those this operator needs itself -- its values count as defined from lane
 		 * H - depth + 1 */
 		const uint32_t eff_dep = dep + P.info[v].xlead - min(P.ops[ids[st.op]].st_prev_phase, P.info[v].xlead);
-		f.kind = (uint32_t)st.kind | ((uint32_t)st.flags << 8) | ((uint32_t)st.which << 16) | (eff_dep << 24);
+		f.kind = (uint32_t)(st.kind == ST_SMLINE ? (uint8_t)ST_LINE : st.kind) | ((uint32_t)st.flags << 8) | (st_which << 16) | (eff_dep << 24);
 		/* block buffers renumbered by liveness (sau_dev_types.h): out, pm, fpm, amp, range end */
 		const FastIds cs = P.fast_ids[(seq ? P.ids_full_ofs : 0u) + vd.plan_ofs + l];
 		f.out_off = cs.out != NO_SLOT ? (uint32_t)cs.out * NP : ~0u;
@@ -1641,13 +1716,14 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 		f.fpm_off = cs.fpm != NO_SLOT ? (uint32_t)cs.fpm * NP : ~0u;
 		f.amp_off = cs.amp != NO_SLOT ? (uint32_t)cs.amp * NP : ~0u;
 		f.aux_off = cs.aux != NO_SLOT ? (uint32_t)cs.aux * NP : ~0u;
+		if (st.kind == ST_OSC) f.aux_off = cs.sm != NO_SLOT ? (uint32_t)cs.sm * NP : ~0u; /* self-modulation amounts */
 		const uint32_t wv = o.type == OT_WAVE ? (o.wave < 12 ? o.wave : 0) : o.wave;
 		f.type = o.type | (wv << 8) | ((o.flags & OPF_OSC_RESET) ? 1u << 16 : 0u);
 		f.fc = o.rt_fconst;
 		f.inc = rint32w(o.coeff * o.rt_fconst);
 		f.phase0 = o.type == OT_NOISE ? o.noise_n : o.phase;
 		f.prev_phase = o.type == OT_NOISE ? o.noise_prev : o.prev_phase;
-		f.ac = (st.kind == ST_LINE) ? o.line[st.which].v0 : o.line[L_AMP].v0;
+		f.ac = (st.kind == ST_LINE || st.kind == ST_SMLINE) ? o.line[st_which].v0 : o.line[L_AMP].v0;
 		f.diff_scale = o.type == OT_WAVE ? P.wc[wv].diff_scale : 0.f;
 		f.diff_offset = o.type == OT_WAVE ? P.wc[wv].diff_offset : 0.f;
 		f.tab = o.type == OT_WAVE ? P.tab_of_wave[wv] : -1;
@@ -1669,7 +1745,23 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 		f.pan = o.line[L_PAN].v0;
 		f.ramp = 0;
 		if (o.type == OT_AMP) f.fc = 1.f;
-		if (st.kind == ST_OSC && o.type == OT_WAVE && !zero_fill && st.pm == NO_SLOT && st.fpm == NO_SLOT &&
+		if (is_chain && !zero_fill) {
+			uint32_t k = 0; /* its row pair: chains of the voice in plan order, as the host counted them */
+			for (uint32_t q = 0; q < (uint32_t)l; ++q) if (step_may_chain(plan[q])) ++k;
+			const uint32_t row = vd.chain_base + k;
+			f.type |= FT_CHAIN;
+			f.pan = bits_f(row);
+			ChainDesc cd;
+			cd.n = P.info[v].total; cd.gop = ids[st.op]; cd.wave = wv; cd.pad = 0;
+			P.chain_desc[row] = cd;
+			if (st.sm == NO_SLOT) { /* the amounts come from the line itself */
+				LineState pls = o.line[L_PMA];
+				const LineBlock lb = line_begin(pls, P.info[v].total, false, 0.f, lattice_none(), 0);
+				pl.sw = lb.sw; pl.goal_len = lb.goal_len; pl.hold = lb.hold; pl.pad = 0;
+				chain_line = true;
+			}
+		}
+		if (st.kind == ST_OSC && o.type == OT_WAVE && !zero_fill && !is_chain && st.pm == NO_SLOT && st.fpm == NO_SLOT &&
 		    o.rt_fconst_valid && f.inc == 0 && ((o.flags & OPF_OSC_RESET) || o.prev_phase == o.phase)) {
 			/* Frequency 0, unmodulated: the phase never moves and the differentiator holds its
 			 * output (wosc.h:251-252) -- the value it had, or on a restart the one the first
@@ -1697,9 +1789,9 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 			f.ac = 0.f;
 			/* every sum pass runs it: whatever reads its buffer there must find the zeros (the
 			 * backward data-flow below does not look inside subtrees that are out of time) */
-			f.ramp = (4u << FAST_MAX_LEVELS) - 4u;
+			f.ramp = ((4u << FAST_MAX_LEVELS) - 4u) | FR_CHAIN_IN;
 		} else {
-			const bool line_step = st.kind == ST_LINE;
+			const bool line_step = st.kind == ST_LINE || st.kind == ST_SMLINE;
 			const bool amp_inline = st.kind == ST_OSC && st.amp == NO_SLOT;
 			/* multiplier of a ratio line: the parent's frequency, one value or a block */
 			const bool have_mul = st.fmul != NO_SLOT;
@@ -1712,7 +1804,7 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 			fa.pad[0] = fa.pad[1] = fa.pad[2] = 0;
 			fa.fl.goal_len = 0; fa.fl.hold = 0.f; fa.fl.pad = 0;
 			fa.fl.sw = sweep_setup(LN_sah, 0.f, 0.f, 0, 1);
-			LineState ls = o.line[line_step ? st.which : L_AMP];
+			LineState ls = o.line[line_step ? st_which : L_AMP];
 			if (line_step || amp_inline) {
 				if (ls.flags & LP_GOAL) {
 					const LineBlock lb = line_begin(ls, P.info[v].total, line_step && have_mul, pconst ? pf : 1.f, lattice_none(), 0);
@@ -1737,6 +1829,8 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 				unsigned long long want[FAST_MAX_LEVELS];
 				bool mine[FAST_MAX_LEVELS];
 				for (uint32_t p = 0; p < FAST_MAX_LEVELS; ++p) { want[p] = 0; mine[p] = false; }
+				unsigned long long want_c = 0; /* the chain-input pass: what the chains' inputs need */
+				bool mine_c = false;
 				uint32_t xi = 0;
 				for (uint32_t q = vd.plan_len; q-- > 0;) {
 					const Step sq = plan[q];
@@ -1748,9 +1842,23 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 					const bool q_fvar = sq.kind == ST_OSC && (oq.type == OT_WAVE || oq.type == OT_RASEG) && !oq.rt_fconst_valid;
 					const uint32_t q_level = q_fvar ? oq.rt_fblk_valid : 0u; /* analyze_kernel left the level there */
 					if (q_fvar && q < (uint32_t)l) ++xi;
-					const bool writes = sq.kind == ST_LINE || sq.kind == ST_LERP ||
+					const bool writes = sq.kind == ST_LINE || sq.kind == ST_LERP || sq.kind == ST_SMLINE ||
 						(sq.kind == ST_OSC && !(sq.which & OX_VOICE));
 					const bool rmw = sq.kind == ST_LERP || (sq.kind == ST_OSC && (sq.flags & SF_LAYER));
+					{
+						const bool q_chain = step_may_chain(sq) && oq.type == OT_WAVE &&
+							(sq.sm != NO_SLOT || oq.line[L_PMA].v0 != 0.f || (oq.line[L_PMA].flags & LP_GOAL));
+						bool needed = false;
+						if (q_chain) {
+							needed = true; /* writes its inputs to the rows, nothing else */
+							want_c |= bit(cq.freq) | bit(cq.fmul) | bit(cq.pm) | bit(cq.fpm) | bit(cq.sm);
+						} else if (writes && (want_c & bit(cq.out))) {
+							needed = true;
+							if (!rmw) want_c &= ~bit(cq.out);
+							want_c |= bit(cq.pm) | bit(cq.fpm) | bit(cq.amp) | bit(cq.aux) | bit(cq.freq) | bit(cq.fmul) | bit(cq.sm);
+						}
+						if (q == (uint32_t)l) mine_c = needed;
+					}
 					for (uint32_t p = 0; p < FAST_MAX_LEVELS; ++p) { /* sum pass p + 1 */
 						bool needed = false;
 						if (q_fvar && q_level == p + 1) {
@@ -1768,6 +1876,7 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 					}
 				}
 				for (uint32_t p = 0; p < FAST_MAX_LEVELS; ++p) if (mine[p]) f.ramp |= 4u << p;
+				if (mine_c) f.ramp |= FR_CHAIN_IN;
 				fa.pad[1] = (o.type == OT_WAVE || o.type == OT_RASEG) && !o.rt_fconst_valid ? o.rt_fblk_valid : 0u;
 				fa.pad[0] = xi;
 			}
@@ -1797,6 +1906,7 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 		fsteps[pos] = f;
 		if (f.ramp & 1) P.flines[(size_t)v * P.max_steps + pos] = fl;
 		if (f.ramp & 2) P.faux[(size_t)v * P.max_steps + pos] = fa;
+		if (chain_line) P.fplines[(size_t)v * P.max_steps + pos] = pl;
 	}
 	if (l == 0) P.info[v].n_fsteps = (uint32_t)__popcll(m);
 }
@@ -1884,19 +1994,30 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 			const uint32_t flags = (f.kind >> 8) & 0xff;
 			const bool sum_pass = SCAN && P.mode != 0 && P.mode <= P.sum_levels;
 			if (sum_pass && !(f.ramp & (2u << P.mode))) continue; /* not needed for this pass's phase increments */
+			const bool chain_in = SCAN && P.mode == P.sum_levels + 2; /* the pass that writes the chains' inputs */
+			if (chain_in && !(f.ramp & FR_CHAIN_IN)) continue;
 			if (kind == ST_OSC) {
 				const uint32_t type = f.type & 0xff;
 				const bool wave_env = (flags & SF_WAVE_ENV) != 0;
 				const bool layer = (flags & SF_LAYER) != 0;
 				const bool to_voice = ((f.kind >> 16) & OX_VOICE) != 0;
 				float s[T];
-				if (type == OT_WAVE) {
+				const bool chain = SCAN && (f.type & FT_CHAIN) != 0;
+				if (type == OT_WAVE && chain && P.mode == P.sum_levels + 1) { /* (the final pass) */
+					/* a feedback chain: chain_kernel has run it; its samples are in the row */
+					const float *crow = P.chain_rows + (size_t)2 * f_bits(f.pan) * P.chain_stride;
+#pragma unroll
+					for (int k = 0; k < T; ++k) {
+						const int t = t0 + k * (int)C;
+						s[k] = (t >= 0 && t < (int)fast_total) ? crow[t] : 0.f;
+					}
+				} else if (type == OT_WAVE) {
 					const bool has_pm = f.pm_off != ~0u, has_fpm = f.fpm_off != ~0u;
 					/* this operator's values are defined from lane p_min on
 					 * (one more lead-in sample per nesting level below it) */
 					const int p_min = (int)H - (int)(f.kind >> 24) + 1;
 					bool done = false;
-					if (FK_COMMON && f.tab >= 0 && !has_fpm && !first_group && !is_last_group && !(f.ramp & 2)) {
+					if (FK_COMMON && f.tab >= 0 && !has_fpm && !first_group && !is_last_group && !(f.ramp & 2) && !chain) {
 						/* the common case, straight-line: table in LDS, plain PM or
 						 * none, no segment edge in this group */
 						uint32_t ph[T];
@@ -2049,6 +2170,26 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 #pragma unroll
 								for (int k = 0; k < T; ++k) ph[k] += pm_offset32(false, true, 0.f, fpm[k], fv[k]);
 							}
+						}
+						if (chain) {
+							/* chain-input pass: base phases (accumulator + phase modulation; the feedback term is
+							 * chain_kernel's) and self-modulation amounts to the chain's rows, nothing else */
+							float *brow = P.chain_rows + (size_t)2 * f_bits(f.pan) * P.chain_stride;
+							float *arow = brow + P.chain_stride;
+							FastLine pl;
+							const bool from_line = f.aux_off == ~0u;
+							if (from_line) pl = load_line_uniform(P.fplines + (size_t)v * P.max_steps + si);
+#pragma unroll
+							for (int k = 0; k < T; ++k) {
+								const int t = t0 + k * (int)C;
+								const float a = from_line ? fast_line_value(pl, t) : slots[f.aux_off + k * 64];
+								if (l >= (int)H && t >= 0 && t < (int)fast_total) {
+									((u32_alias *)brow)[t] = ph[k];
+									arow[t] = a;
+									if (t == (int)fast_total - 1) P.ops[f.gop].st_phase = phu[SCAN ? k : 0];
+								}
+							}
+							continue;
 						}
 						const bool reset = (f.type >> 16) & 1;
 						if (first_group) {
@@ -2370,6 +2511,7 @@ __global__ void __launch_bounds__(1024, FK_MINB) fast_kernel(FastParams P) {
 	const int l = tid & 63;
 	/* a sum pass nobody needs costs a launch, not a table staging */
 	if (SCAN && P.mode != 0 && P.mode <= P.sum_levels && P.pass_flags[P.mode - 1] == 0) return;
+	if (SCAN && P.mode == P.sum_levels + 2 && P.pass_flags[FAST_MAX_LEVELS + 1] == 0) return; /* no chains */
 
 	HerpC23 *t23 = (HerpC23 *)lds;
 	HerpC01 *t01 = (HerpC01 *)(lds + (size_t)P.n_tabs * WAVE_LEN * sizeof(HerpC23));
@@ -2402,6 +2544,8 @@ __global__ void __launch_bounds__(1024, FK_MINB) fast_kernel(FastParams P) {
 		const uint32_t seq_kind = SCAN ? uni(fi.seq) : 0u;
 		if (SCAN && P.mode != 0 && P.mode <= P.sum_levels && (seq_kind != 2 || uni(fi.levels) < P.mode))
 			continue; /* a sum pass only concerns multi-pass voices that deep */
+		if (SCAN && P.mode == P.sum_levels + 2 && (seq_kind != 2 || uni(fi.n_chain) == 0))
+			continue; /* the chain-input pass only concerns voices with feedback chains */
 		if (SCAN && seq_kind != 0) fast_voice<T, true>(P, v, fi, slots, carry, t23, t01, l, wpv, cstart);
 		else fast_voice<T, false>(P, v, fi, slots, carry, t23, t01, l, wpv, cstart);
 	}
@@ -2442,13 +2586,160 @@ __global__ void __launch_bounds__(1024) repair_kernel(FastParams P) {
 	}
 }
 
+/* ======================================================================== */
+/* feedback chains: lanes = voices                                          */
+/* ======================================================================== */
+/* The self-modulation recurrence (wosc.h:273-310: feedback -> phase -> table -> sample -> feedback) is one
+ * dependent chain per operator, about a hundred nanoseconds per sample whatever the width of the machine.
+ * The block loop ran one such chain on one lane of a wave; here a wave runs sixty-four, one per lane, and
+ * nothing but the chain: the time-parallel passes have put every chain's base phases (accumulator + phase
+ * modulation) and self-modulation amounts into a pair of rows in HBM (fast_voice, chain-input pass), the
+ * samples go back into the first row, and the final pass takes them from there (amplitude, mixing into
+ * the parent, voice output). Rows are read and written sixteen frames per lane at a time (four 16-byte
+ * accesses, the next batch in flight while the current one is computed); the only state a lane carries is
+ * the oscillator's. One wave per workgroup, so that every wave has a CU's LDS port and issue slots to
+ * itself: 4096 chains are 64 waves on 64 CUs, and the render takes frames x chain latency. */
+template <bool LDS_TAB, bool TAIL>
+__device__ __forceinline__ void chain_batch(const uint4 *bq, const float4 *aq, float4 *sq, uint32_t t, uint32_t n,
+		uint32_t tab23, uint32_t tab01, const HerpC23 *g23, const HerpC01 *g01, float dscale, float doff,
+		uint32_t &prev_phase, double &prev_Is, float &prev_s, float &fb_s) {
+	typedef const double __attribute__((address_space(3))) *lds_f64;
+	typedef const float __attribute__((address_space(3))) *lds_f32;
+#pragma unroll
+	for (int u = 0; u < 4; ++u) {
+		const uint32_t b4[4] = {bq[u].x, bq[u].y, bq[u].z, bq[u].w};
+		const float a4[4] = {aq[u].x, aq[u].y, aq[u].z, aq[u].w};
+		float s4[4];
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			const float p = fb_s * a4[j];
+			uint32_t ofs = rint32w_p31_small(p);
+			if (__builtin_expect(!(fabsf(p) < 0x1p20f), 0)) ofs = rint32w(p * 0x1p31f);
+			const uint32_t phase = b4[j] + ofs;
+			const int32_t d = (int32_t)(phase - prev_phase);
+			const uint32_t ind = phase >> SLEN_BITS;
+			HerpC23 hi; HerpC01 lo;
+			if (LDS_TAB) {
+				lds_f64 p23 = (lds_f64)(uintptr_t)(tab23 + ind * (uint32_t)sizeof(HerpC23));
+				lds_f32 p01 = (lds_f32)(uintptr_t)(tab01 + ind * (uint32_t)sizeof(HerpC01));
+				hi.c3 = p23[0]; hi.c2 = p23[1]; lo.c1 = p01[0]; lo.c0 = p01[1];
+			} else {
+				hi = g23[ind]; lo = g01[ind];
+			}
+			const double Isv = herp_poly(hi, lo, phase);
+			const float sv_new = wosc_diff(Isv, prev_Is, d, dscale, doff);
+			bool hold = d == 0; /* wosc.h:292-293: a repeated phase holds the previous sample */
+			const bool act = !TAIL || t + (uint32_t)(4 * u + j) < n;
+			if (TAIL) hold = hold || !act;
+			const float sv = hold ? prev_s : sv_new;
+			prev_Is = hold ? prev_Is : Isv;
+			prev_phase = (TAIL && !act) ? prev_phase : phase; /* (equal to the old one when held) */
+			prev_s = sv;
+			s4[j] = sv;
+			const float fb_n = (fb_s + sv) * 0.5f;
+			fb_s = (TAIL && !act) ? fb_s : fb_n;
+		}
+		sq[u] = make_float4(s4[0], s4[1], s4[2], s4[3]);
+	}
+}
+
+__global__ void __launch_bounds__(64) chain_kernel(FastParams P) {
+	extern __shared__ __align__(16) unsigned char lds[];
+	if (P.pass_flags[FAST_MAX_LEVELS + 1] == 0) return; /* no voice of the segment has a chain */
+	const int l = threadIdx.x;
+	const uint32_t c = blockIdx.x * 64 + (uint32_t)l;
+	ChainDesc cd;
+	cd.n = 0; cd.gop = 0; cd.wave = 0; cd.pad = 0;
+	if (c < P.n_chain_rows) cd = P.chain_desc[c];
+	if (cd.n == 0) { cd.gop = 0; cd.wave = 0; } /* an unused row pair: only `n` of its descriptor is set */
+	const uint32_t n = cd.n;
+	if (!__any(n != 0)) return;
+	HerpC23 *t23 = (HerpC23 *)lds;
+	HerpC01 *t01 = (HerpC01 *)(lds + (size_t)P.n_ctabs * WAVE_LEN * sizeof(HerpC23));
+	for (uint32_t t = 0; t < P.n_ctabs; ++t) {
+		const uint32_t wave = P.cwave_of_tab[t];
+		const uint4 *s23 = (const uint4 *)(P.g_c23 + (size_t)wave * WAVE_LEN);
+		uint4 *d23 = (uint4 *)(t23 + (size_t)t * WAVE_LEN);
+		for (uint32_t i = l; i < WAVE_LEN; i += 64) d23[i] = s23[i];
+		const uint2 *s01 = (const uint2 *)(P.g_c01 + (size_t)wave * WAVE_LEN);
+		uint2 *d01 = (uint2 *)(t01 + (size_t)t * WAVE_LEN);
+		for (uint32_t i = l; i < WAVE_LEN; i += 64) d01[i] = s01[i];
+	}
+	__syncthreads();
+	const uint32_t wave = cd.wave < 12 ? cd.wave : 0;
+	const int ti = P.ctab_of_wave[wave];
+	const bool all_lds = __all(n == 0 || ti >= 0) != 0;
+	const uint32_t tab23 = (uint32_t)(uintptr_t)(t23 + (size_t)(ti >= 0 ? ti : 0) * WAVE_LEN);
+	const uint32_t tab01 = (uint32_t)(uintptr_t)(t01 + (size_t)(ti >= 0 ? ti : 0) * WAVE_LEN);
+	const HerpC23 *g23 = P.g_c23 + (size_t)wave * WAVE_LEN;
+	const HerpC01 *g01 = P.g_c01 + (size_t)wave * WAVE_LEN;
+	const float dscale = P.wc[wave].diff_scale, doff = P.wc[wave].diff_offset;
+	DevOp &o = P.ops[cd.gop];
+	uint32_t prev_phase = o.prev_phase;
+	double prev_Is = o.prev_Is;
+	float prev_s = o.prev_s, fb_s = o.fb_s;
+	/* idle lanes run along on row pair 0 (reads only) */
+	float *brow = P.chain_rows + (size_t)2 * (n ? c : 0u) * P.chain_stride;
+	const uint4 *bp = (const uint4 *)brow;
+	const float4 *ap = (const float4 *)(brow + P.chain_stride);
+	float4 *op = (float4 *)brow;
+	if (n && (o.flags & OPF_OSC_RESET)) { /* wosc.h:215-231 with the first base phase, as the block loop does */
+		const uint32_t phase00 = ((const u32_alias *)brow)[0];
+		const uint32_t pa = phase00 - SLEN;
+		prev_Is = herp_poly(g23[pa >> SLEN_BITS], g01[pa >> SLEN_BITS], pa);
+		const double Is0 = herp_poly(g23[phase00 >> SLEN_BITS], g01[phase00 >> SLEN_BITS], phase00);
+		prev_s = wosc_diff(Is0, prev_Is, (int32_t)SLEN, dscale, doff);
+		prev_Is = Is0;
+		prev_phase = phase00;
+	}
+	/* frames every lane with work has (in whole batches): those need no per-frame bounds */
+	uint32_t n_all = n ? (n & ~15u) : 0xfffffff0u, n_max = n;
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) {
+		n_all = min(n_all, (uint32_t)__shfl_xor((int)n_all, d));
+		n_max = max(n_max, (uint32_t)__shfl_xor((int)n_max, d));
+	}
+	n_all = uni(n_all); n_max = uni(n_max);
+	uint4 bq[4]; float4 aq[4];
+#pragma unroll
+	for (int u = 0; u < 4; ++u) { bq[u] = bp[u]; aq[u] = ap[u]; }
+	for (uint32_t t = 0; t < n_max; t += 16) {
+		uint4 bn[4]; float4 an[4];
+		const uint32_t nx = (t + 16 < n_max) ? (t + 16) / 4 : 0; /* next batch, in flight during this one */
+#pragma unroll
+		for (int u = 0; u < 4; ++u) { bn[u] = bp[nx + u]; an[u] = ap[nx + u]; }
+		float4 sq[4];
+		if (t + 16 <= n_all) {
+			if (all_lds) chain_batch<true, false>(bq, aq, sq, t, n, tab23, tab01, g23, g01, dscale, doff, prev_phase, prev_Is, prev_s, fb_s);
+			else chain_batch<false, false>(bq, aq, sq, t, n, tab23, tab01, g23, g01, dscale, doff, prev_phase, prev_Is, prev_s, fb_s);
+		} else {
+			if (all_lds) chain_batch<true, true>(bq, aq, sq, t, n, tab23, tab01, g23, g01, dscale, doff, prev_phase, prev_Is, prev_s, fb_s);
+			else chain_batch<false, true>(bq, aq, sq, t, n, tab23, tab01, g23, g01, dscale, doff, prev_phase, prev_Is, prev_s, fb_s);
+		}
+		if (t < n) {
+#pragma unroll
+			for (int u = 0; u < 4; ++u) op[t / 4 + u] = sq[u];
+		}
+#pragma unroll
+		for (int u = 0; u < 4; ++u) { bq[u] = bn[u]; aq[u] = an[u]; }
+	}
+	if (n) { /* staged: finalize_kernel makes it the operator's state unless the voice's segment is redone */
+		o.st_prev_phase = prev_phase;
+		o.st_prev_Is = prev_Is;
+		o.st_prev_s = prev_s;
+		o.ras_alpha = f_bits(fb_s);
+		o.ras_level = CHAIN_MARK;
+	}
+}
+
+
 /* Apply the closed forms to the operator state, or hand the whole segment
  * to the block loop when a chunk had to bail out. */
 __global__ void __launch_bounds__(64) finalize_kernel(FastParams P) {
 	/* one thread per (voice, operator); the voice's own bookkeeping goes to its operator 0 */
 	const uint32_t gid = blockIdx.x * 64 + threadIdx.x;
 	const uint32_t v = gid / P.max_ops, i = gid % P.max_ops;
-	if (gid <= FAST_MAX_LEVELS && P.pass_flags) P.pass_flags[gid] = 0; /* for the next segment's kernels */
+	if (gid < FAST_FLAGS && P.pass_flags) P.pass_flags[gid] = 0; /* for the next segment's kernels */
 	if (v >= P.n_voices) return;
 	const FastInfo fi = P.info[v];
 	const VoiceDesc vd = P.voices[v];
@@ -2509,6 +2800,10 @@ __global__ void __launch_bounds__(64) finalize_kernel(FastParams P) {
 			o.prev_Is = o.st_prev_Is;
 			o.prev_s = o.st_prev_s;
 			o.flags &= ~OPF_OSC_RESET;
+			if (o.ras_level == CHAIN_MARK) { /* a feedback chain: chain_kernel staged the rest of its state */
+				o.fb_s = bits_f(o.ras_alpha);
+				o.ras_level = 0;
+			}
 		} else if (o.type == OT_RASEG) {
 			const bool rate2x = (o.flags & OPF_RATE2X) != 0;
 			const unsigned long long inc64 = (unsigned long long)rint64((rate2x ? o.coeff * 2 : o.coeff) * o.rt_fconst);
@@ -2886,6 +3181,7 @@ public:
 		debug_ = getenv("SAU_AMD_DEBUG") != nullptr;
 		fast_enabled_ = getenv("SAU_AMD_NO_FAST") == nullptr;
 		seq_enabled_ = getenv("SAU_AMD_NO_SEQ") == nullptr; /* running-sum phases in the time-parallel kernel */
+		chain_enabled_ = getenv("SAU_AMD_NO_CHAIN") == nullptr; /* feedback recurrences with lanes = voices */
 		two_pass_enabled_ = getenv("SAU_AMD_NO_TWO_PASS") == nullptr; /* ... in two passes where possible */
 		/* voices per segment from which feedback voices get sixteen one-wave teams per workgroup
 		 * (0: never; 1: always, also without feedback -- tests) */
@@ -3122,7 +3418,7 @@ public:
 				fp.scan = scan_.p;
 			}
 			if (!pass_flags_.p) {
-				if (!pass_flags_.ensure(FAST_MAX_LEVELS + 1, err)) return false;
+				if (!pass_flags_.ensure(FAST_FLAGS, err)) return false;
 				HIP_OK(hipMemsetAsync(pass_flags_.p, 0, pass_flags_.cap * sizeof(uint32_t), stream_));
 			}
 			fp.pass_flags = pass_flags_.p;
@@ -3132,6 +3428,28 @@ public:
 			fp.repair_on = getenv("SAU_AMD_NO_REPAIR") ? 0u : 1u;
 			fp.max_ops = seg.max_ops; fp.max_steps = fmax_steps; fp.np = 64; fp.rows = FT;
 			fp.enable = use_fast ? 1u : 0u;
+			/* feedback chains: a pair of rows per chain in HBM, one segment long (the engine keeps segments
+			 * with such voices within CHAIN_SEG frames); without them those voices take the block loop */
+			const bool chains = chain_enabled_ && use_fast && fp.scan && seg.serial && seg.n_chain_rows &&
+				seg.len <= sauengine::CHAIN_SEG;
+			if (chains) {
+				const uint32_t cstride = (seg.len + 63) & ~63u;
+				if (!chain_rows_.ensure((size_t)seg.n_chain_rows * 2 * cstride + 64, err) ||
+				    !chain_desc_.ensure(seg.n_chain_rows, err) ||
+				    !fplines_.ensure((size_t)seg.n_voices * fmax_steps * sizeof(FastLine), err)) return false;
+				fp.chain_rows = chain_rows_.p; fp.chain_stride = cstride; fp.n_chain_rows = seg.n_chain_rows;
+				fp.chain_desc = chain_desc_.p; fp.fplines = (FastLine *)fplines_.p;
+				uint32_t ct = 0;
+				for (int wv = 0; wv < 12; ++wv) {
+					fp.ctab_of_wave[wv] = -1;
+					if (((seg.wave_mask >> wv) & 1) && (ct + 1) * tab_bytes + 1024 <= lds_limit_) {
+						fp.ctab_of_wave[wv] = (int8_t)ct;
+						fp.cwave_of_tab[ct] = (uint8_t)wv;
+						++ct;
+					}
+				}
+				fp.n_ctabs = ct;
+			}
 			memcpy(fp.wc, wconst_, sizeof wconst_);
 			uint32_t ft = 0;
 			for (int wv = 0; wv < 12; ++wv) {
@@ -3189,6 +3507,19 @@ public:
 					for (uint32_t pass = 1; pass <= fp.sum_levels; ++pass) {
 						launch_fast(pass);
 						hipLaunchKernelGGL(scan_kernel, dim3(seg.n_voices), dim3(64), 0, stream_, fp);
+					}
+					if (fp.chain_rows) { /* the chains' inputs, then the chains themselves: lanes = voices */
+						launch_fast(fp.sum_levels + 2);
+						const size_t clds = (size_t)fp.n_ctabs * tab_bytes;
+						static size_t cconfigured[16];
+						if (clds > cconfigured[dev_ & 15]) {
+							HIP_OK(hipFuncSetAttribute((const void *)chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds));
+							cconfigured[dev_ & 15] = clds;
+						}
+						TimedPair *tc = timing_on_ ? new_pair(0) : nullptr; /* counted with the block loop it replaces */
+						if (tc) (void)hipEventRecord(tc->a, stream_);
+						hipLaunchKernelGGL(chain_kernel, dim3((seg.n_chain_rows + 63) / 64), dim3(64), clds, stream_, fp);
+						if (tc) (void)hipEventRecord(tc->b, stream_);
 					}
 					launch_fast(fp.sum_levels + 1);
 				} else {
@@ -3473,7 +3804,10 @@ private:
 	std::map<void *, size_t> host_blocks_; /* alloc_host() blocks and their pool sizes */
 	uint32_t multi_min_ = 256;
 	uint32_t fast_rows_ = 8;
-	bool seq_enabled_ = true, two_pass_enabled_ = true;
+	bool seq_enabled_ = true, two_pass_enabled_ = true, chain_enabled_ = true;
+	DevBuf<float> chain_rows_;
+	DevBuf<ChainDesc> chain_desc_;
+	DevBuf<unsigned char> fplines_;
 	uint32_t block_grid_ = 1;
 };
 

@@ -247,7 +247,9 @@ bool compile_voice_plan(const std::vector<OpMirror> &ops, uint32_t carrier,
 		if (m.type == SAU_POPT_N_raseg) out.static_block = true;
 		if (m.type == SAU_POPT_N_noise && m.wave == SAU_NOISE_N_re) out.static_block = true;
 	}
+	out.n_chain = 0;
 	for (const Step &st : out.steps) {
+		if (step_may_chain(st)) ++out.n_chain;
 		if (st.kind == ST_SMLINE) { out.static_block = true; out.selfmod = true; }
 		if (st.kind == ST_LINE && st.which == L_FREQ && (st.flags & SF_FORCE)) out.static_block = true;
 	}

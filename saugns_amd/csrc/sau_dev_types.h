@@ -144,46 +144,50 @@ static_assert(sizeof(Step) == 16, "Step is 4 dwords");
  * is given, ids[i] receives step i's buffers (NO_SLOT where unused). Runs on
  * the host when a plan is compiled; the ids travel to the device beside the
  * steps. */
-struct FastIds { uint8_t out, pm, fpm, amp, aux /* LERP range end */, freq, fmul, pad; };
+struct FastIds { uint8_t out, pm, fpm, amp, aux /* LERP range end */, freq, fmul, sm /* self-modulation amounts */; };
 static_assert(sizeof(FastIds) == 8, "FastIds is 2 dwords");
 SAU_HD uint32_t fast_slot_compact(const Step *plan, uint32_t n, FastIds *ids, bool with_freq) {
 	const uint32_t limit = with_freq ? 250u : (uint32_t)FSLOT_BASE;
+	constexpr int NR = 7;
 	uint8_t last[256];
 	uint8_t map[256];
 	for (uint32_t s = 0; s < 256; ++s) { last[s] = 0xff; map[s] = NO_SLOT; }
-	for (uint32_t i = 0; i < n && i < 0xff; ++i) {
-		const Step st = plan[i];
-		uint8_t rd[6] = {NO_SLOT, NO_SLOT, NO_SLOT, NO_SLOT, NO_SLOT, NO_SLOT};
-		if (st.kind == ST_OSC) { rd[0] = st.pm; rd[1] = st.fpm; rd[2] = st.amp; if (st.flags & SF_LAYER) rd[3] = st.out; rd[4] = st.freq; rd[5] = st.fmul; }
+	auto reads_of = [](const Step &st, uint8_t *rd) {
+		for (int k = 0; k < NR; ++k) rd[k] = NO_SLOT;
+		if (st.kind == ST_OSC) { rd[0] = st.pm; rd[1] = st.fpm; rd[2] = st.amp; if (st.flags & SF_LAYER) rd[3] = st.out; rd[4] = st.freq; rd[5] = st.fmul; rd[6] = st.sm; }
 		else if (st.kind == ST_LERP) { rd[0] = st.out; rd[1] = st.freq; rd[2] = st.pm; }
 		else if (st.kind == ST_VOICE) { rd[0] = st.out; rd[1] = st.pm; }
 		else if (st.kind == ST_LINE) { rd[0] = st.fmul; }
-		for (int k = 0; k < 6; ++k) if (rd[k] < limit) last[rd[k]] = (uint8_t)i;
+	};
+	for (uint32_t i = 0; i < n && i < 0xff; ++i) {
+		uint8_t rd[NR];
+		reads_of(plan[i], rd);
+		for (int k = 0; k < NR; ++k) if (rd[k] < limit) last[rd[k]] = (uint8_t)i;
 	}
 	unsigned long long used = 0;
 	uint32_t count = 0;
 	if (ids) {
 		FastIds none;
-		none.out = none.pm = none.fpm = none.amp = none.aux = none.freq = none.fmul = none.pad = NO_SLOT;
+		none.out = none.pm = none.fpm = none.amp = none.aux = none.freq = none.fmul = none.sm = NO_SLOT;
 		for (uint32_t i = 0; i < n; ++i) ids[i] = none;
 	}
 	for (uint32_t i = 0; i < n && i < 0xff; ++i) {
 		const Step st = plan[i];
 		if (!with_freq && st.kind == ST_LINE && st.which == L_FREQ) continue; /* never materialised */
-		uint8_t rd[6] = {NO_SLOT, NO_SLOT, NO_SLOT, NO_SLOT, NO_SLOT, NO_SLOT};
+		uint8_t rd[NR];
+		reads_of(st, rd);
 		bool writes = false;
-		if (st.kind == ST_OSC) { rd[0] = st.pm; rd[1] = st.fpm; rd[2] = st.amp; if (st.flags & SF_LAYER) rd[3] = st.out; rd[4] = st.freq; rd[5] = st.fmul; writes = !(st.which & OX_VOICE); }
-		else if (st.kind == ST_LERP) { rd[0] = st.out; rd[1] = st.freq; rd[2] = st.pm; writes = true; }
-		else if (st.kind == ST_VOICE) { rd[0] = st.out; rd[1] = st.pm; }
-		else if (st.kind == ST_LINE) { rd[0] = st.fmul; writes = true; }
+		if (st.kind == ST_OSC) writes = !(st.which & OX_VOICE);
+		else if (st.kind == ST_LERP || st.kind == ST_LINE || st.kind == ST_SMLINE) writes = true;
 		FastIds got;
-		got.out = got.pm = got.fpm = got.amp = got.aux = got.freq = got.fmul = got.pad = NO_SLOT;
+		got.out = got.pm = got.fpm = got.amp = got.aux = got.freq = got.fmul = got.sm = NO_SLOT;
 		if (st.kind == ST_OSC) {
 			if (st.pm < limit) got.pm = map[st.pm];
 			if (st.fpm < limit) got.fpm = map[st.fpm];
 			if (st.amp < limit) got.amp = map[st.amp];
 			if (st.freq < limit) got.freq = map[st.freq];
 			if (st.fmul < limit) got.fmul = map[st.fmul];
+			if (st.sm < limit) got.sm = map[st.sm];
 		} else if (st.kind == ST_LERP) {
 			if (st.freq < limit) got.aux = map[st.freq];
 			if (st.pm < limit) got.pm = map[st.pm];
@@ -194,7 +198,7 @@ SAU_HD uint32_t fast_slot_compact(const Step *plan, uint32_t n, FastIds *ids, bo
 		}
 		/* inputs read for the last time here give their buffer back before the
 		 * output is placed (the output may then land on one of them) */
-		for (int k = 0; k < 6; ++k) {
+		for (int k = 0; k < NR; ++k) {
 			const uint8_t s = rd[k];
 			if (s < limit && last[s] == i && map[s] != NO_SLOT && !(writes && s == st.out))
 				used &= ~(1ull << map[s]); /* map[s] stays: a later write to s is a new value */
@@ -216,6 +220,19 @@ SAU_HD uint32_t fast_slot_compact(const Step *plan, uint32_t n, FastIds *ids, bo
 	return count;
 }
 
+/* A self-modulated W oscillator ("chain": wosc.h:273-310) as the time-parallel path handles it: its
+ * inputs (base phases, self-modulation amounts) go to a pair of rows in HBM, chain_kernel runs the
+ * per-sample recurrence with one lane per chain, the final pass reads the samples back. */
+SAU_HD bool step_may_chain(const Step &st) {
+	return st.kind == ST_OSC && ((st.flags & SF_SM_INLINE) || st.sm != NO_SLOT);
+}
+struct ChainDesc {
+	uint32_t n;      /* frames to run this segment (0: row pair unused) */
+	uint32_t gop;    /* the operator's state (global index) */
+	uint32_t wave;
+	uint32_t pad;
+};
+
 /* One voice of one render stream, for one segment launch. */
 struct VoiceDesc {
 	uint32_t plan_ofs, plan_len; /* into the step array */
@@ -226,6 +243,7 @@ struct VoiceDesc {
 	uint32_t pan_dynamic_row;    /* row of the pan matrix, or ~0u */
 	uint32_t flags;              /* VD_* */
 	Lattice lat;                 /* where the reference's blocks lie in this segment, for the voice's program */
+	uint32_t chain_base, n_chain;/* row pairs for its self-modulated oscillators (step_may_chain steps, in plan order) */
 };
 
 enum : uint32_t {

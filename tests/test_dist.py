@@ -22,7 +22,7 @@ def test_shard_ranges_cover_everything():
             assert got == list(range(total))
 
 
-def test_two_rank_gloo_batch(tmp_path):
+def test_two_rank_gloo_batch(tmp_path, seqexec):  # (the fixture rebuilds libseqexec.so when stale)
     script = textwrap.dedent("""
         import os, sys, ctypes as C
         sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
