@@ -1135,6 +1135,7 @@ constexpr uint32_t FAST_MAX_REPAIR = 15;   /* noted row groups per voice and seg
 constexpr uint32_t FAST_REPAIR_WORDS = 2 + 2 * FAST_MAX_REPAIR; /* count, pad, then (group, rows) pairs */
 constexpr uint32_t FAST_FLAGS = FAST_MAX_LEVELS + 2; /* pass_flags words */
 constexpr uint32_t FR_CHAIN_IN = 4u << FAST_MAX_LEVELS; /* FastStep.ramp: the chain-input pass runs this step */
+constexpr uint32_t FR_FINAL_SKIP = 8u << FAST_MAX_LEVELS; /* ... the final pass does not: only chains' inputs needed it */
 constexpr uint32_t FT_CHAIN = 1u << 18;     /* FastStep.type: a feedback chain (rows = bits of FastStep.pan) */
 constexpr uint32_t CHAIN_MARK = 0xC4A10001u; /* DevOp.ras_level of a W operator: chain_kernel staged its state */
 struct FastParams {
@@ -1184,6 +1185,17 @@ struct FastParams {
 	uint8_t wave_of_tab[12];
 	WaveConst wc[12];
 };
+
+/* a W oscillator step whose self-modulation is on (generator.c:479-498, wosc.h:273-310): chain_kernel's */
+__device__ __forceinline__ bool step_is_chain(const Step &st, const DevOp &o) {
+	return !o.rt_frozen && step_may_chain(st) && o.type == OT_WAVE &&
+		(st.sm != NO_SLOT || o.line[L_PMA].v0 != 0.f || (o.line[L_PMA].flags & LP_GOAL));
+}
+/* ... and whose varying frequency is its only phase input: chain_kernel sums the phase increments itself
+ * (a sum pass and a scan less), the chain-input pass hands it increments instead of base phases */
+__device__ __forceinline__ bool step_is_chain_acc(const Step &st, const DevOp &o) {
+	return step_is_chain(st, o) && !o.rt_fconst_valid && st.pm == NO_SLOT && st.fpm == NO_SLOT;
+}
 
 /* the operator whose frequency line most recently filled block `slot` before step si (0xff: none) */
 __device__ __forceinline__ uint32_t block_owner(const Step *plan, uint32_t si, uint32_t slot) {
@@ -1493,7 +1505,8 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 			} else if (st.kind == ST_LERP) {
 				set_level(st.out, max2(level_of(st.freq), level_of(st.pm)), true);
 			} else if (st.kind == ST_OSC) {
-				const bool fvar = (o.type == OT_WAVE || o.type == OT_RASEG) && !o.rt_fconst_valid;
+				const bool fvar = (o.type == OT_WAVE || o.type == OT_RASEG) && !o.rt_fconst_valid &&
+					!(chain_ok && step_is_chain_acc(st, o));
 				uint32_t lv = max2(max2(level_of(st.pm), level_of(st.fpm)), max2(level_of(st.amp),
 						max2(level_of(st.freq), level_of(st.fmul))));
 				if (fvar) {
@@ -1617,7 +1630,7 @@ __device__ __forceinline__ FastAux load_aux_uniform(const FastAux *p) {
 /* value of a ramp at frame t of the segment (lead-in frames t < 0 get the hold value: unused) */
 __device__ __forceinline__ float fast_line_value(const FastLine &fl, int t) {
 	const uint32_t i = (uint32_t)t;
-	return i < fl.goal_len ? sweep_value_inl(fl.sw, i) : fl.hold;
+	return i < fl.goal_len ? sweep_value_inl<true>(fl.sw, i) : fl.hold;
 }
 
 /* Between the two passes: the sums of phase increments per row group become
@@ -1678,8 +1691,7 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 		/* a frequency line is materialised only when it is not one value (sequential-scan voices) */
 		keep = !(st.kind == ST_LINE && st.which == L_FREQ && o.rt_fconst_valid);
 		/* a W oscillator whose self-modulation is on (generator.c:479-498, wosc.h:273-310): chain_kernel's */
-		is_chain = !o.rt_frozen && step_may_chain(st) && o.type == OT_WAVE &&
-			(st.sm != NO_SLOT || o.line[L_PMA].v0 != 0.f || (o.line[L_PMA].flags & LP_GOAL));
+		is_chain = step_is_chain(st, o);
 		const uint32_t st_which = st.kind == ST_SMLINE ? (uint32_t)L_PMA : (uint32_t)st.which; /* (ST_SMLINE = the pm_a line into a block) */
 		bool zero_fill = false;
 		if (o.rt_frozen) {
@@ -1752,7 +1764,8 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 			f.type |= FT_CHAIN;
 			f.pan = bits_f(row);
 			ChainDesc cd;
-			cd.n = P.info[v].total; cd.gop = ids[st.op]; cd.wave = wv; cd.pad = 0;
+			cd.n = P.info[v].total; cd.gop = ids[st.op]; cd.wave = wv;
+			cd.pad = step_is_chain_acc(st, o) ? 1u : 0u; /* 1: the first row holds phase increments */
 			P.chain_desc[row] = cd;
 			if (st.sm == NO_SLOT) { /* the amounts come from the line itself */
 				LineState pls = o.line[L_PMA];
@@ -1831,6 +1844,8 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 				for (uint32_t p = 0; p < FAST_MAX_LEVELS; ++p) { want[p] = 0; mine[p] = false; }
 				unsigned long long want_c = 0; /* the chain-input pass: what the chains' inputs need */
 				bool mine_c = false;
+				unsigned long long want_f = 0; /* the final pass: what the voice's output needs, chains read from their rows */
+				bool mine_f = false;
 				uint32_t xi = 0;
 				for (uint32_t q = vd.plan_len; q-- > 0;) {
 					const Step sq = plan[q];
@@ -1839,15 +1854,15 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 					if (sq.kind == ST_LINE && sq.which == L_FREQ && oq.rt_fconst_valid) continue; /* dropped */
 					const FastIds cq = P.fast_ids[P.ids_full_ofs + vd.plan_ofs + q];
 					auto bit = [](uint8_t id) -> unsigned long long { return id != NO_SLOT ? 1ull << id : 0ull; };
-					const bool q_fvar = sq.kind == ST_OSC && (oq.type == OT_WAVE || oq.type == OT_RASEG) && !oq.rt_fconst_valid;
+					const bool q_fvar = sq.kind == ST_OSC && (oq.type == OT_WAVE || oq.type == OT_RASEG) && !oq.rt_fconst_valid &&
+						!step_is_chain_acc(sq, oq);
 					const uint32_t q_level = q_fvar ? oq.rt_fblk_valid : 0u; /* analyze_kernel left the level there */
 					if (q_fvar && q < (uint32_t)l) ++xi;
 					const bool writes = sq.kind == ST_LINE || sq.kind == ST_LERP || sq.kind == ST_SMLINE ||
 						(sq.kind == ST_OSC && !(sq.which & OX_VOICE));
 					const bool rmw = sq.kind == ST_LERP || (sq.kind == ST_OSC && (sq.flags & SF_LAYER));
 					{
-						const bool q_chain = step_may_chain(sq) && oq.type == OT_WAVE &&
-							(sq.sm != NO_SLOT || oq.line[L_PMA].v0 != 0.f || (oq.line[L_PMA].flags & LP_GOAL));
+						const bool q_chain = step_is_chain(sq, oq);
 						bool needed = false;
 						if (q_chain) {
 							needed = true; /* writes its inputs to the rows, nothing else */
@@ -1858,6 +1873,17 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 							want_c |= bit(cq.pm) | bit(cq.fpm) | bit(cq.amp) | bit(cq.aux) | bit(cq.freq) | bit(cq.fmul) | bit(cq.sm);
 						}
 						if (q == (uint32_t)l) mine_c = needed;
+						bool needed_f = sq.kind == ST_VOICE || (sq.kind == ST_OSC && (sq.which & OX_VOICE));
+						if (!needed_f && writes && (want_f & bit(cq.out))) {
+							needed_f = true;
+							if (!rmw) want_f &= ~bit(cq.out);
+						}
+						if (needed_f) {
+							if (sq.kind == ST_VOICE) want_f |= bit(cq.out) | bit(cq.pm);
+							else if (q_chain) want_f |= bit(cq.amp);
+							else want_f |= bit(cq.pm) | bit(cq.fpm) | bit(cq.amp) | bit(cq.aux) | bit(cq.freq) | bit(cq.fmul) | bit(cq.sm);
+						}
+						if (q == (uint32_t)l) mine_f = needed_f;
 					}
 					for (uint32_t p = 0; p < FAST_MAX_LEVELS; ++p) { /* sum pass p + 1 */
 						bool needed = false;
@@ -1877,7 +1903,10 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 				}
 				for (uint32_t p = 0; p < FAST_MAX_LEVELS; ++p) if (mine[p]) f.ramp |= 4u << p;
 				if (mine_c) f.ramp |= FR_CHAIN_IN;
-				fa.pad[1] = (o.type == OT_WAVE || o.type == OT_RASEG) && !o.rt_fconst_valid ? o.rt_fblk_valid : 0u;
+				/* what only chains' inputs needed has run (and staged its state) in the chain-input pass */
+				if (P.info[v].n_chain && !mine_f && (mine_c || st.kind == ST_LINE || st.kind == ST_SMLINE || st.kind == ST_LERP))
+					f.ramp |= FR_FINAL_SKIP;
+				fa.pad[1] = (o.type == OT_WAVE || o.type == OT_RASEG) && !o.rt_fconst_valid && !step_is_chain_acc(st, o) ? o.rt_fblk_valid : 0u;
 				fa.pad[0] = xi;
 			}
 			if (st.kind == ST_OSC && is_osc && !o.rt_fconst_valid) {
@@ -1897,6 +1926,7 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 					}
 				}
 				f.ramp |= 2;
+				if (step_is_chain_acc(st, o)) fa.pad[2] = 1; /* increments to the chain's row, no sums */
 			}
 		}
 	}
@@ -1996,6 +2026,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 			if (sum_pass && !(f.ramp & (2u << P.mode))) continue; /* not needed for this pass's phase increments */
 			const bool chain_in = SCAN && P.mode == P.sum_levels + 2; /* the pass that writes the chains' inputs */
 			if (chain_in && !(f.ramp & FR_CHAIN_IN)) continue;
+			if (SCAN && P.mode == P.sum_levels + 1 && (f.ramp & FR_FINAL_SKIP)) continue;
 			if (kind == ST_OSC) {
 				const uint32_t type = f.type & 0xff;
 				const bool wave_env = (flags & SF_WAVE_ENV) != 0;
@@ -2099,7 +2130,26 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 									 * integer and leaves it in the low word; exact while |x| < 2^51 */
 									const uint32_t r = fabsf(x) < 0x1p50f ? (uint32_t)__double2loint((double)x + 0x1.8p52) : rint32w(x);
 									const uint32_t inc = (t >= 0 && t < (int)fast_total) ? r : 0u;
-									S[k] = wave_incl_scan_dpp(inc);
+									if (chain && fa.pad[2]) S[k] = inc; /* chain_kernel does the summing */
+									else S[k] = wave_incl_scan_dpp(inc);
+								}
+								if (chain && fa.pad[2]) {
+									/* chain-input pass of a chain that accumulates its own phase: increments and amounts */
+									float *brow = P.chain_rows + (size_t)2 * f_bits(f.pan) * P.chain_stride;
+									float *arow = brow + P.chain_stride;
+									FastLine pl;
+									const bool from_line = f.aux_off == ~0u;
+									if (from_line) pl = load_line_uniform(P.fplines + (size_t)v * P.max_steps + si);
+#pragma unroll
+									for (int k = 0; k < T; ++k) {
+										const int t = t0 + k * (int)C;
+										const float a = from_line ? fast_line_value(pl, t) : slots[f.aux_off + k * 64];
+										if (l >= (int)H && t >= 0 && t < (int)fast_total) {
+											((u32_alias *)brow)[t] = S[k];
+											arow[t] = a;
+										}
+									}
+									continue;
 								}
 								/* the accumulator at the frame before this group's first new frame: carried by
 								 * this wave (in-order voices), or the prefix of all earlier groups' sums */
@@ -2599,12 +2649,19 @@ __global__ void __launch_bounds__(1024) repair_kernel(FastParams P) {
  * accesses, the next batch in flight while the current one is computed); the only state a lane carries is
  * the oscillator's. One wave per workgroup, so that every wave has a CU's LDS port and issue slots to
  * itself: 4096 chains are 64 waves on 64 CUs, and the render takes frames x chain latency. */
-template <bool LDS_TAB, bool TAIL>
+/* SMALL: every feedback offset of the batch is known to stay below 2^20 cycles in magnitude, where the short
+ * rounding form is exact (rint32w_p31_small) -- no per-sample test on the chain; the caller verifies the bound
+ * it assumed for |fb_s| afterwards (fb_max) and redoes the batch without SMALL if it was exceeded. */
+template <bool LDS_TAB, bool TAIL, bool SMALL>
 __device__ __forceinline__ void chain_batch(const uint4 *bq, const float4 *aq, float4 *sq, uint32_t t, uint32_t n,
+		bool acc_mode, uint32_t &acc,
 		uint32_t tab23, uint32_t tab01, const HerpC23 *g23, const HerpC01 *g01, float dscale, float doff,
-		uint32_t &prev_phase, double &prev_Is, float &prev_s, float &fb_s) {
-	typedef const double __attribute__((address_space(3))) *lds_f64;
-	typedef const float __attribute__((address_space(3))) *lds_f32;
+		uint32_t &prev_phase, double &prev_Is, float &prev_s, float &fb_s, float &fb_max) {
+	/* one 16-byte and one 8-byte LDS read per sample (ds_read_b128 / ds_read_b64): the entries are that aligned */
+	typedef double __attribute__((ext_vector_type(2))) f64x2;
+	typedef float __attribute__((ext_vector_type(2))) f32x2;
+	typedef const f64x2 __attribute__((address_space(3))) *lds_f64x2;
+	typedef const f32x2 __attribute__((address_space(3))) *lds_f32x2;
 #pragma unroll
 	for (int u = 0; u < 4; ++u) {
 		const uint32_t b4[4] = {bq[u].x, bq[u].y, bq[u].z, bq[u].w};
@@ -2614,15 +2671,18 @@ __device__ __forceinline__ void chain_batch(const uint4 *bq, const float4 *aq, f
 		for (int j = 0; j < 4; ++j) {
 			const float p = fb_s * a4[j];
 			uint32_t ofs = rint32w_p31_small(p);
-			if (__builtin_expect(!(fabsf(p) < 0x1p20f), 0)) ofs = rint32w(p * 0x1p31f);
-			const uint32_t phase = b4[j] + ofs;
+			if (!SMALL) { if (__builtin_expect(!(fabsf(p) < 0x1p20f), 0)) ofs = rint32w(p * 0x1p31f); }
+			/* the row holds base phases, or phase increments this lane sums (wosc.h:145, pre-increment) */
+			const uint32_t acc_n = acc + b4[j];
+			if (!TAIL || t + (uint32_t)(4 * u + j) < n) acc = acc_n;
+			const uint32_t phase = (acc_mode ? acc_n : b4[j]) + ofs;
 			const int32_t d = (int32_t)(phase - prev_phase);
 			const uint32_t ind = phase >> SLEN_BITS;
 			HerpC23 hi; HerpC01 lo;
 			if (LDS_TAB) {
-				lds_f64 p23 = (lds_f64)(uintptr_t)(tab23 + ind * (uint32_t)sizeof(HerpC23));
-				lds_f32 p01 = (lds_f32)(uintptr_t)(tab01 + ind * (uint32_t)sizeof(HerpC01));
-				hi.c3 = p23[0]; hi.c2 = p23[1]; lo.c1 = p01[0]; lo.c0 = p01[1];
+				const f64x2 c23 = *(lds_f64x2)(uintptr_t)(tab23 + ind * (uint32_t)sizeof(HerpC23));
+				const f32x2 c01 = *(lds_f32x2)(uintptr_t)(tab01 + ind * (uint32_t)sizeof(HerpC01));
+				hi.c3 = c23.x; hi.c2 = c23.y; lo.c1 = c01.x; lo.c0 = c01.y;
 			} else {
 				hi = g23[ind]; lo = g01[ind];
 			}
@@ -2638,6 +2698,7 @@ __device__ __forceinline__ void chain_batch(const uint4 *bq, const float4 *aq, f
 			s4[j] = sv;
 			const float fb_n = (fb_s + sv) * 0.5f;
 			fb_s = (TAIL && !act) ? fb_s : fb_n;
+			if (SMALL) fb_max = fmaxf(fb_max, fabsf(fb_n)) + fb_n * 0.f; /* (beside the chain, not on it; NaN and Inf stick) */
 		}
 		sq[u] = make_float4(s4[0], s4[1], s4[2], s4[3]);
 	}
@@ -2683,8 +2744,10 @@ __global__ void __launch_bounds__(64) chain_kernel(FastParams P) {
 	const uint4 *bp = (const uint4 *)brow;
 	const float4 *ap = (const float4 *)(brow + P.chain_stride);
 	float4 *op = (float4 *)brow;
+	const bool acc_mode = cd.pad != 0;
+	uint32_t acc = o.phase;
 	if (n && (o.flags & OPF_OSC_RESET)) { /* wosc.h:215-231 with the first base phase, as the block loop does */
-		const uint32_t phase00 = ((const u32_alias *)brow)[0];
+		const uint32_t phase00 = ((const u32_alias *)brow)[0] + (acc_mode ? acc : 0u);
 		const uint32_t pa = phase00 - SLEN;
 		prev_Is = herp_poly(g23[pa >> SLEN_BITS], g01[pa >> SLEN_BITS], pa);
 		const double Is0 = herp_poly(g23[phase00 >> SLEN_BITS], g01[phase00 >> SLEN_BITS], phase00);
@@ -2709,13 +2772,31 @@ __global__ void __launch_bounds__(64) chain_kernel(FastParams P) {
 #pragma unroll
 		for (int u = 0; u < 4; ++u) { bn[u] = bp[nx + u]; an[u] = ap[nx + u]; }
 		float4 sq[4];
-		if (t + 16 <= n_all) {
-			if (all_lds) chain_batch<true, false>(bq, aq, sq, t, n, tab23, tab01, g23, g01, dscale, doff, prev_phase, prev_Is, prev_s, fb_s);
-			else chain_batch<false, false>(bq, aq, sq, t, n, tab23, tab01, g23, g01, dscale, doff, prev_phase, prev_Is, prev_s, fb_s);
-		} else {
-			if (all_lds) chain_batch<true, true>(bq, aq, sq, t, n, tab23, tab01, g23, g01, dscale, doff, prev_phase, prev_Is, prev_s, fb_s);
-			else chain_batch<false, true>(bq, aq, sq, t, n, tab23, tab01, g23, g01, dscale, doff, prev_phase, prev_Is, prev_s, fb_s);
+		/* the short rounding form needs |fb_s * amount| < 2^20: amounts below 2^14 and |fb_s| <= 64 (checked after) */
+		float a_max = 0.f;
+#pragma unroll
+		for (int u = 0; u < 4; ++u)
+			a_max = fmaxf(fmaxf(a_max, fmaxf(fabsf(aq[u].x), fabsf(aq[u].y))), fmaxf(fabsf(aq[u].z), fabsf(aq[u].w)));
+		const uint32_t s_prev_phase = prev_phase; const double s_prev_Is = prev_Is;
+		const float s_prev_s = prev_s, s_fb_s = fb_s;
+		const uint32_t s_acc = acc;
+		float fb_max = fabsf(fb_s);
+		bool small = !__any(!(a_max < 0x1p14f));
+		const bool tail = !(t + 16 <= n_all);
+#define SAU_CHAIN_BATCH(L, TL, SM) chain_batch<L, TL, SM>(bq, aq, sq, t, n, acc_mode, acc, tab23, tab01, g23, g01, dscale, doff, prev_phase, prev_Is, prev_s, fb_s, fb_max)
+		if (small) {
+			if (all_lds) { if (tail) SAU_CHAIN_BATCH(true, true, true); else SAU_CHAIN_BATCH(true, false, true); }
+			else { if (tail) SAU_CHAIN_BATCH(false, true, true); else SAU_CHAIN_BATCH(false, false, true); }
+			if (__any(!(fb_max <= 64.f))) { /* (never seen: feedback is an average of samples) */
+				small = false;
+				prev_phase = s_prev_phase; prev_Is = s_prev_Is; prev_s = s_prev_s; fb_s = s_fb_s; acc = s_acc;
+			}
 		}
+		if (!small) {
+			if (all_lds) { if (tail) SAU_CHAIN_BATCH(true, true, false); else SAU_CHAIN_BATCH(true, false, false); }
+			else { if (tail) SAU_CHAIN_BATCH(false, true, false); else SAU_CHAIN_BATCH(false, false, false); }
+		}
+#undef SAU_CHAIN_BATCH
 		if (t < n) {
 #pragma unroll
 			for (int u = 0; u < 4; ++u) op[t / 4 + u] = sq[u];
@@ -2729,6 +2810,7 @@ __global__ void __launch_bounds__(64) chain_kernel(FastParams P) {
 		o.st_prev_s = prev_s;
 		o.ras_alpha = f_bits(fb_s);
 		o.ras_level = CHAIN_MARK;
+		if (acc_mode) o.st_phase = acc;
 	}
 }
 

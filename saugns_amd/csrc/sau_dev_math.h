@@ -219,6 +219,7 @@ SAU_HD_CALL Sweep sweep_setup(uint32_t type, float v0, float vt, uint32_t pos, u
 
 /* Value of sample i of the block (i + pos inside the sweep), before any
  * ratio multiplication. sau/line.c:27-37,65-281 in ref-build forms. */
+template <bool INL = false>
 SAU_HD float sweep_value_inl(const Sweep &s, uint32_t i) {
 	switch (s.type) {
 	default:
@@ -233,6 +234,11 @@ SAU_HD float sweep_value_inl(const Sweep &s, uint32_t i) {
 	}
 	case LN_xpe: case LN_lge: case LN_smo: {
 		float x = (float)(i + s.pos) * s.inv_time;
+		if (INL) { /* the three shapes in place (the time-parallel kernels: a real call per value costs more than the value) */
+			if (s.type == LN_xpe) return s.vt + (s.v0 - s.vt) * expramp6(1.f - x);
+			if (s.type == LN_lge) return s.v0 + (s.vt - s.v0) * expramp6(x);
+			return s.v0 + (((s.vt - s.v0) * x) * (x * x)) * ((x * 6.f + -15.f) * x + 10.f);
+		}
 		return shape_val(s.type, x, s.v0, s.vt);
 	}
 	case LN_sqe: {
