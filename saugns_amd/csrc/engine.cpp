@@ -248,7 +248,7 @@ bool Engine::rebuild_plans(std::string &err) {
  * one wave in order when a voice is deeper than the passes launched. */
 uint32_t Engine::estimate_sum_levels(const Stream &st, uint32_t op, uint32_t parent_dep, bool parent_varies,
 		uint32_t &need, uint32_t nest) const {
-	if (op >= st.ops.size() || nest > 64) return 0;
+	if (op >= st.ops.size() || nest > MAX_NEST) return 0;
 	const OpMirror &m = st.ops[op];
 	auto count = [](const sauProgramIDArr *a) { return a ? a->count : 0u; };
 	const sauProgramIDArr *fm = m.mods[SAU_POP_N_fmod], *rfm = m.mods[SAU_POP_N_rfmod];

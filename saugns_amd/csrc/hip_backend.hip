@@ -72,7 +72,7 @@ struct RenderParams {
 struct Misc {
 	WaveConst wc[12];      /* per-wave constants, copied from the launch parameters */
 	int32_t tab_of_wave[12];
-	uint32_t len_stack[MAX_NEST + 1];
+	uint16_t len_stack[MAX_NEST + 1]; /* block lengths per nesting level (<= 1024 each) */
 	uint32_t tot32[16];
 	unsigned long long tot64[16];
 	uint32_t flag;
@@ -406,7 +406,7 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 			DevOp *op = &ops[st.op];
 			const uint32_t op_flags = uni(op->flags);
 			if (st.flags & SF_BEGIN) { /* generator.c:694-698 */
-				if (tid == 0) misc->len_stack[depth] = cur_len;
+				if (tid == 0) misc->len_stack[depth] = (uint16_t)cur_len;
 				++depth;
 				const uint32_t op_time = uni(op->time);
 				if (!(op_flags & OPF_TIME_INF) && op_time < cur_len) cur_len = op_time;
@@ -1046,7 +1046,7 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 			if (st.flags & SF_END) { /* generator.c:719-728; runs after barrier A of ST_OSC */
 				const bool inf = (op_flags & OPF_TIME_INF) != 0;
 				--depth;
-				const uint32_t outer = (st.flags & SF_BEGIN) ? parent_len : uni(misc->len_stack[depth]);
+				const uint32_t outer = (st.flags & SF_BEGIN) ? parent_len : uni((uint32_t)misc->len_stack[depth]);
 				if (!inf && !(st.flags & SF_LAYER) && !(st.which & OX_VOICE)) {
 					float *out = slots + (size_t)st.out * G::SLOT;
 #pragma unroll

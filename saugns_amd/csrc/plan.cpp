@@ -129,7 +129,7 @@ struct Compiler {
 			return NO_SLOT;
 		}
 		if (path.size() >= MAX_NEST) {
-			failed = true; err = "operator nesting deeper than 64";
+			failed = true; err = "operator nesting deeper than 255";
 			return NO_SLOT;
 		}
 		const OpMirror &m = ops[op];

@@ -258,7 +258,7 @@ struct VoiceOut {
 	uint32_t pan_row;   /* row of the pan matrix when has_pan */
 };
 
-constexpr uint32_t MAX_NEST = 64; /* deepest operator nesting a plan may have */
+constexpr uint32_t MAX_NEST = 255; /* deepest operator nesting a plan may have: sauProgram.op_nest_depth is a uint8 (sau/program.h:259) */
 
 } /* namespace saudev */
 #endif

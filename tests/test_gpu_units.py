@@ -662,3 +662,17 @@ def test_dropin_generator_on_random_programs(sa, oracle):
         for call in (11289, 4099):
             got = sa.Generator(prg, RATE).render(stereo=stereo, chunk=call)
             assert len(got) == len(want) and (got == want).all(), (seed, call)
+
+
+def test_deep_nesting(sa, oracle):
+    """Nesting far beyond what scripts use: straight PM chains of 65 and 120 levels (one wave, one
+    frame per lane, about 240 block buffers in LDS), bit-exact vs the oracle."""
+    def chain(depth):
+        op = None
+        for d in range(depth):
+            top = d == depth - 1
+            op = vb.Op("sin", freq=200.0 if top else vb.Line(2.0, ratio=True), amp=0.5,
+                       time_ms=40 if top else None, mods={POP_PMOD: [op]} if op else {})
+        return op
+    for depth in (33, 65, 120):
+        check(sa, oracle, [chain(depth)], chunk=1500)
