@@ -111,6 +111,35 @@ SAU_AMD_API size_t sauAmd_program_serialize(const sauProgram *prg, void *buf, si
 SAU_AMD_API sauProgram *sauAmd_program_load(const void *image, size_t len);
 SAU_AMD_API void sauAmd_program_free(sauProgram *prg);
 
+/* Voice banks without the parser (for a 1024-voice bank sau_build_Program,
+ * sau/parser.c:2092, takes longer than the whole render here). Operators are given as a flat array: carriers
+ * (use == SAU_POP_N_carr, one voice each, in time order) and modulators naming their parent's index and how it
+ * uses them. The result is laid out as the parser lays out the equivalent script -- one event per voice,
+ * operator data in post-order, ids in pre-order, line and time flags of freshly created operators -- and is
+ * accepted by sau_create_Generator / sauAmd_create_Batch like any other program. */
+typedef struct sauAmdLineDesc {
+	uint8_t present;   /* 0: the parameter is not given (the generator's default applies) */
+	uint8_t has_goal;  /* a sweep to `goal` over the operator's time */
+	uint8_t ratio;     /* frequency lines: value is a ratio of the parent's frequency */
+	uint8_t shape;     /* SAU_LINE_N_* */
+	float v0, goal;
+} sauAmdLineDesc;
+typedef struct sauAmdOpDesc {
+	uint32_t parent;   /* index of the operator this one modulates (ignored for carriers) */
+	uint32_t use;      /* SAU_POP_N_* */
+	uint32_t type;     /* SAU_POPT_N_* */
+	uint32_t mode;     /* W: wave id; N: noise id; R: line | function flags << 8 | function << 16 */
+	uint32_t time_ms;  /* 0: implicit (lasts as long as its parent), lines then take default_mod_ms */
+	uint32_t start_ms; /* carriers: when the voice begins */
+	uint32_t phase;    /* cycle fraction, 2^32 = one turn */
+	uint32_t seed;
+	sauAmdLineDesc pan, amp, amp2, freq, freq2, pm_a;
+} sauAmdOpDesc;
+/* NULL on a malformed description (parent out of range, cycles, voices out of time order). */
+SAU_AMD_API sauProgram *sauAmd_build_bank(const sauAmdOpDesc *ops, size_t n_ops, float ampmult,
+		uint32_t default_mod_ms);
+SAU_AMD_API void sauAmd_free_bank(sauProgram *prg);
+
 /* Output stage (replaces the reference's player/sndfile.c:125-210 writer fed
  * from Player_run's chunk loop, saugns.c:589-618): render prg to a sound file.
  * format as SGS_SNDFILE_* (player/sndfile.h:21-26); channels 1 or 2. The file

@@ -78,6 +78,19 @@ TIMEP_SET, TIMEP_DEFAULT, TIMEP_IMPLICIT = 1, 2, 4
 PMODE_AMP_DIV_VOICES = 1
 
 
+class LineDesc(C.Structure):
+    _fields_ = [("present", C.c_uint8), ("has_goal", C.c_uint8), ("ratio", C.c_uint8), ("shape", C.c_uint8),
+                ("v0", C.c_float), ("goal", C.c_float)]
+
+
+class OpDesc(C.Structure):
+    """sauAmdOpDesc (include/saugns_amd.h): one operator of a voice bank for sauAmd_build_bank."""
+    _fields_ = [("parent", C.c_uint32), ("use", C.c_uint32), ("type", C.c_uint32), ("mode", C.c_uint32),
+                ("time_ms", C.c_uint32), ("start_ms", C.c_uint32), ("phase", C.c_uint32), ("seed", C.c_uint32),
+                ("pan", LineDesc), ("amp", LineDesc), ("amp2", LineDesc), ("freq", LineDesc),
+                ("freq2", LineDesc), ("pm_a", LineDesc)]
+
+
 def lib():
     """Load (building if stale) libsaugns_amd.so and declare its C ABI."""
     global _lib
@@ -129,6 +142,9 @@ def lib():
     L.sauAmd_program_load.restype = C.c_void_p
     L.sauAmd_program_load.argtypes = [C.c_void_p, C.c_size_t]
     L.sauAmd_program_free.argtypes = [C.c_void_p]
+    L.sauAmd_build_bank.restype = C.c_void_p
+    L.sauAmd_build_bank.argtypes = [C.c_void_p, C.c_size_t, C.c_float, C.c_uint32]
+    L.sauAmd_free_bank.argtypes = [C.c_void_p]
     _lib = L
     return L
 

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsaugns_amd.so")
-SOURCES = ["capi.cpp", "engine.cpp", "plan.cpp", "tables.cpp", "program_io.cpp", "sndout.cpp",
+SOURCES = ["capi.cpp", "engine.cpp", "plan.cpp", "tables.cpp", "program_io.cpp", "sndout.cpp", "bank_builder.cpp",
            "hip_backend.hip"]
 HEADERS = ["engine.h", "hip_backend.h", "sau_dev_math.h", "sau_dev_ops.h",
            "sau_dev_types.h", "../../include/sau_abi.h", "../../include/saugns_amd.h"]

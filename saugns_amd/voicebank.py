@@ -319,3 +319,54 @@ def config_scripts():
                    f"p.a{0.3+(i%8)*0.1:.2f}[g0.1 llin] a1[g0.2 lxpe].r0.2[Wsin f{3+i%9}] t10"
                    for i in range(4096))
     return {"config2": c2, "config3": c3, "config5": c5}
+
+
+# ---- the same banks through the C ABI's builder (sauAmd_build_bank) --------------------------
+
+def _line_desc(ln):
+    d = api.LineDesc()
+    if ln is not None:
+        d.present, d.has_goal, d.ratio = 1, int(ln.goal is not None), int(bool(ln.ratio))
+        d.shape, d.v0, d.goal = LINES.index(ln.shape), ln.v0, (ln.goal if ln.goal is not None else 0.0)
+    return d
+
+
+def flatten(voices):
+    """Op trees -> (ctypes array of sauAmdOpDesc, count) for sauAmd_build_bank."""
+    flat = []
+
+    def visit(op, use, parent):
+        me = len(flat)
+        flat.append((op, use, parent))
+        for u in sorted(op.mods):
+            for m in op.mods[u]:
+                visit(m, u, me)
+
+    for carr in voices:
+        visit(carr, POP_CARR, 0)
+    arr = (api.OpDesc * len(flat))()
+    for i, (op, use, parent) in enumerate(flat):
+        d = arr[i]
+        d.parent, d.use, d.type = parent, use, op.op_type
+        if op.op_type == api.POPT_RASEG:
+            line, func, flags = op.ras
+            d.mode = LINES.index(line) | (flags & 0x3f) << 8 | (func & 0x3f) << 16
+        elif op.op_type == api.POPT_NOISE:
+            d.mode = op.noise
+        else:
+            d.mode = WAVES.index(op.wave)
+        d.time_ms = op.time_ms or 0
+        d.start_ms = getattr(op, "start_ms", 0) or 0
+        d.phase, d.seed = cyclepos(op.phase), op.seed
+        d.pan, d.amp, d.amp2 = _line_desc(op.pan), _line_desc(op.amp), _line_desc(op.amp2)
+        d.freq, d.freq2, d.pm_a = _line_desc(op.freq), _line_desc(op.freq2), _line_desc(op.pm_a)
+    return arr, len(flat)
+
+
+def build_bank_c(voices, ampmult=1.0, default_mod_ms=1000):
+    """build_program(voices) through sauAmd_build_bank (no later events)."""
+    arr, n = flatten(voices)
+    p = api.lib().sauAmd_build_bank(arr, n, ampmult, default_mod_ms)
+    if not p:
+        raise ValueError("sauAmd_build_bank rejected the description")
+    return api.Program(p, free=api.lib().sauAmd_free_bank)

@@ -406,3 +406,41 @@ def test_amp_operator_through_the_plan(sa, oracle, seqexec):
         for block in (64, 1016):
             got = sa.Batch([prg], 44100, backend=seqexec.seq_backend_create(block)).render(stereo=True, chunk=777)[0]
             assert max_diff(got, want) == 0, (name, block)
+
+
+def test_bank_builder_in_the_c_abi(sa, oracle):
+    """sauAmd_build_bank (parser-free voice banks) lays programs out as the Python builder
+    does (which tests/test_host.py::test_voicebank_builder_equals_parser_images pins on parser-made
+    images): the oracle renders both to the same PCM, for the BASELINE banks and random trees; bad
+    descriptions are refused."""
+    import test_gpu_units as tu
+    from saugns_amd import voicebank as vb
+    from saugns_amd.api import OpDesc
+    oracle.oracle().ora_set_fastmath_forms(1)
+
+    def voices_of(kind):
+        if kind == "config3":
+            return [vb.Op("sin", freq=110.0 + i * 0.731, time_ms=300, mods={6: [
+                vb.Op("sin", freq=vb.Line(float(1 + i % 5), ratio=True), amp=0.5, mods={6: [
+                    vb.Op("sin", freq=vb.Line(2.0, ratio=True), amp=0.7)]})]}) for i in range(24)]
+        rng = np.random.default_rng(kind)
+        vs = [tu._random_voice(rng) for _ in range(3)]
+        for k, v in enumerate(vs):
+            v.start_ms = 10 * k
+        return vs
+
+    for kind in ["config3"] + list(range(12)):
+        a = vb.build_program(voices_of(kind))
+        b = vb.build_bank_c(voices_of(kind))
+        assert (a.struct.ev_count, a.struct.vo_count, a.struct.op_count, a.struct.op_nest_depth, a.struct.duration_ms) == \
+               (b.struct.ev_count, b.struct.vo_count, b.struct.op_count, b.struct.op_nest_depth, b.struct.duration_ms), kind
+        pa = oracle.oracle_render(a.ptr, 44100, True)
+        pb = oracle.oracle_render(b.ptr, 44100, True)
+        assert len(pa) == len(pb) and (pa == pb).all(), kind
+    bad = (OpDesc * 2)()
+    bad[0].use, bad[1].use, bad[1].parent = 0, 6, 7  # parent out of range
+    assert not sa.lib().sauAmd_build_bank(bad, 2, 1.0, 1000)
+    bad[1].parent = 1  # its own parent
+    assert not sa.lib().sauAmd_build_bank(bad, 2, 1.0, 1000)
+    bad[0].use = 6; bad[0].parent = 1; bad[1].parent = 0  # no carrier
+    assert not sa.lib().sauAmd_build_bank(bad, 2, 1.0, 1000)

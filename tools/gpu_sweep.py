@@ -136,3 +136,48 @@ if "mixed" in which:
         if kind == POP_FMOD: m1.amp = Line(30.0)
         voices.append(Op("sin", freq=_num(".4f", 110.0 + i * 0.731), time_ms=30000, mods={kind: [m1]}))
     run("1024 x 4 ops, 1/16 of the voices FM", build_program(voices), frames=44100, steps=4)
+if "f4" in which:
+    # what a whole job costs besides rendering. The reference's parser
+    # (sau_build_Program through oracle/_ref, where that library is present), this repo's two parser-free
+    # builders, generator creation, the first call (every t = 0 event applied), the rest of the render.
+    from oracle import pyoracle as po
+    scripts = vb.config_scripts()
+    for name, mk, voices_of in (("config 3", lambda: vb.config3(n=1024, seconds=10), None),
+                                ("config 5", lambda: vb.config5(n=4096, seconds=10), None)):
+        key = "config3" if name == "config 3" else "config5"
+        parse_ms = None
+        if po.have_ref():
+            po.ref()
+            t0 = time.perf_counter()
+            p = po.ref_build_program(scripts[key])
+            parse_ms = 1e3 * (time.perf_counter() - t0)
+            po.ref_discard_program(p)
+        t0 = time.perf_counter(); prg = mk(); py_ms = 1e3 * (time.perf_counter() - t0)
+        # the same bank through the C ABI's builder: flatten once (host's own data), then time the call
+        import ctypes as C
+        if key == "config3":
+            from saugns_amd.voicebank import Op, Line, _f32, _num
+            from saugns_amd.api import POP_PMOD
+            voices = []
+            for i in range(1024):
+                m3 = Op("sin", freq=Line(float(3 + i % 4), ratio=True), amp=_f32(0.4))
+                m2 = Op("sin", freq=Line(float(2 + i % 3), ratio=True), amp=_f32(0.7), mods={POP_PMOD: [m3]})
+                m1 = Op("sin", freq=Line(float(1 + i % 5), ratio=True), amp=_num(".2f", 0.5 + (i % 7) * 0.1), mods={POP_PMOD: [m2]})
+                voices.append(Op("sin", freq=_num(".4f", 110.0 + i * 0.731), time_ms=10000, mods={POP_PMOD: [m1]}))
+            arr, n = vb.flatten(voices)
+            t0 = time.perf_counter()
+            for _ in range(10): q = sa.lib().sauAmd_build_bank(arr, n, 1.0, 1000); sa.lib().sauAmd_free_bank(q)
+            c_ms = 1e3 * (time.perf_counter() - t0) / 10
+        else:
+            c_ms = float("nan")
+        for rep in range(2):
+            buf = np.zeros(176400, np.int16)
+            t0 = time.perf_counter(); g = sa.Generator(prg, 44100); t1 = time.perf_counter()
+            more, got = g.run(buf, 11289); t2 = time.perf_counter(); n = got
+            while more:
+                more, got = g.run(buf, 176400); n += got
+            t3 = time.perf_counter(); g.close(); t4 = time.perf_counter()
+        print(f"f-4 {name}: reference parser {parse_ms if parse_ms is None else round(parse_ms, 2)} ms | builders: Python {py_ms:.1f} ms, "
+              f"sauAmd_build_bank {c_ms:.2f} ms | create {1e3*(t1-t0):.2f} ms, first call {1e3*(t2-t1):.2f} ms, rest of {n} frames "
+              f"{1e3*(t3-t2):.2f} ms, destroy {1e3*(t4-t3):.2f} ms -> whole job without parsing {n/(t4-t0):.3e} frames/s"
+              + (f", with the reference parser {n/(t4-t0+parse_ms/1e3):.3e}" if parse_ms else ""))
