@@ -41,6 +41,39 @@ for k, v in out["kernels"].items():
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         v["hbm_bytes_per_launch_corrected"] = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
 json.dump(out, open(f"profiles/{name}_pmc_summary.json", "w"), indent=1)
+# the other workloads' bench lines and kernel statistics, when the round measured them
+import os
+for wl in ("c5", "c4"):
+    b = f"gpurun_out/bench_{tag}_{wl}.json"
+    if os.path.exists(b):
+        line = open(b).read().strip().splitlines()[-1]
+        open(f"profiles/{name}_{wl}_bench.json", "w").write(line + "\n")
+    st = f"gpurun_out/prof_{tag}_{wl}/{tag}_{wl}_kernel_stats.csv"
+    if os.path.exists(st):
+        shutil.copy(st, f"profiles/{name}_{wl}_kernel_stats.csv")
+# config 5: per-kernel HBM bytes and instruction counts (averages per launch)
+c5 = {}
+for d, f in (("c5_mem", "m"), ("c5_inst", "i")):
+    src = f"gpurun_out/pmc_{tag}_{d}/{f}_counter_collection.csv"
+    if not os.path.exists(src):
+        continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(src)):
+        if "sauhip" in r["Kernel_Name"]:
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        for c, x in v.items():
+            c5.setdefault(k, {})[c] = sum(x) / len(x)
+            c5[k]["launches"] = len(x)
+if c5:
+    for k, v in c5.items():
+        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            v["hbm_bytes_per_launch_corrected"] = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
+    json.dump({"command": "rocprofv3 --pmc <C> --kernel-trace -- python3 bench.py --workload config5 --steps 1 --warmup 0 --no-cpu",
+               "note": "averages per launch over the run (segments of 65536 frames, the last one shorter); "
+                       "zero-work launches of a pass nobody needs are included in that pass's average",
+               "kernels": c5}, open(f"profiles/{name}_c5_pmc_summary.json", "w"), indent=1)
 fk = [v for n, v in out["kernels"].items() if "fast_kernel" in n][0]
 rows = bench["config"]["operators"] * frames_per_step / 60  # 64-lane rows incl. lead-in, per launch
 print({a: (round(b / rows, 2) if isinstance(b, float) and b > 1e6 else b) for a, b in fk.items()})
