@@ -53,7 +53,7 @@ for wl in ("c5", "c4"):
         shutil.copy(st, f"profiles/{name}_{wl}_kernel_stats.csv")
 # config 5: per-kernel HBM bytes and instruction counts (averages per launch)
 c5 = {}
-for d, f in (("c5_mem", "m"), ("c5_inst", "i")):
+for d, f in (("c5_fetch", "m"), ("c5_write", "m"), ("c5_inst", "i")):
     src = f"gpurun_out/pmc_{tag}_{d}/{f}_counter_collection.csv"
     if not os.path.exists(src):
         continue
