@@ -1120,6 +1120,8 @@ struct FastInfo {
 struct FastStep;
 struct FastLine;
 struct FastAux;
+struct ChainDesc;
+constexpr uint32_t CHAIN_DESC_WORDS = 32;
 constexpr uint32_t FAST_MAX_SCAN = 8;   /* oscillators with running-sum phases per multi-pass voice */
 constexpr uint32_t FAST_MAX_LEVELS = 3; /* running sums that depend on running sums: at most that many sum passes
                                          * (FastParams.sum_levels of them are launched for a segment) */
@@ -1179,6 +1181,8 @@ struct FastParams {
 	ChainDesc *chain_desc;
 	FastLine *fplines;    /* [voice][max_steps]: the self-modulation amount line of a chain step without a block for it */
 	uint32_t n_ctabs;     /* wave tables chain_kernel stages in LDS */
+	uint32_t chain_inline;/* chains fed from their own lines by chain_kernel's feeder wave (SAU_AMD_CHAIN_INLINE; off:
+	                       * measured slower) */
 	int8_t ctab_of_wave[12];
 	uint8_t cwave_of_tab[12];
 	int8_t tab_of_wave[12];
@@ -1195,6 +1199,39 @@ __device__ __forceinline__ bool step_is_chain(const Step &st, const DevOp &o) {
  * (a sum pass and a scan less), the chain-input pass hands it increments instead of base phases */
 __device__ __forceinline__ bool step_is_chain_acc(const Step &st, const DevOp &o) {
 	return step_is_chain(st, o) && !o.rt_fconst_valid && st.pm == NO_SLOT && st.fpm == NO_SLOT;
+}
+
+/* ... and all of whose inputs are its own lines: a frequency that is one value, or its frequency line alone
+ * (times a parent frequency that is one value) with nothing added into its block, amounts from its pm_a line.
+ * chain_kernel's feeder wave evaluates those itself; the chain-input pass has nothing to do for it.
+ * line_step: the plan index of the ST_LINE step that fills its frequency block, or ~0u. */
+__device__ __forceinline__ bool step_is_chain_inline(bool enabled, const Step *plan, uint32_t si, const uint32_t *ids, const DevOp *ops,
+		uint32_t *line_step) {
+	if (!enabled) { *line_step = ~0u; return false; }
+	const Step st = plan[si];
+	const DevOp &o = ops[ids[st.op]];
+	*line_step = ~0u;
+	if (!step_is_chain(st, o) || st.pm != NO_SLOT || st.fpm != NO_SLOT || st.sm != NO_SLOT) return false;
+	if (o.rt_fconst_valid) return true;
+	uint32_t fmul = st.fmul, prov = st.prov;
+	if (st.freq != NO_SLOT) {
+		uint32_t q = si;
+		bool found = false;
+		while (q-- > 0) { /* its block: written by its own line step and by nothing since */
+			const Step sq = plan[q];
+			if (sq.kind == ST_LINE && sq.which == L_FREQ && sq.op == st.op && sq.out == st.freq) { found = true; break; }
+			if ((sq.kind == ST_OSC || sq.kind == ST_LERP || sq.kind == ST_LINE || sq.kind == ST_SMLINE) && sq.out == st.freq) return false;
+		}
+		if (!found) return false;
+		*line_step = q;
+		fmul = plan[q].fmul; prov = plan[q].prov;
+	}
+	if (fmul != NO_SLOT) { /* a ratio of the parent's frequency: only when that is one value */
+		const LineState &fl = o.line[L_FREQ];
+		const bool ratio = (fl.flags & LP_STATE_RATIO) || ((fl.flags & LP_GOAL) && (fl.flags & LP_GOAL_RATIO));
+		if (ratio && !(prov != NO_SLOT && ops[ids[prov]].rt_fconst_valid)) return false;
+	}
+	return true;
 }
 
 /* the operator whose frequency line most recently filled block `slot` before step si (0xff: none) */
@@ -1230,7 +1267,8 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 	 * length, generator.c:686-700): such subtrees are left out below. */
 	for (uint32_t i = 0; i < vd.nops; ++i) P.ops[ids[i]].rt_frozen = 0;
 	if (P.chain_desc)
-		for (uint32_t k = 0; k < vd.n_chain; ++k) P.chain_desc[vd.chain_base + k].n = 0;
+		for (uint32_t k = 0; k < vd.n_chain; ++k) /* ChainDesc.n (its first word; the type is defined further down) */
+			((uint32_t *)P.chain_desc)[(size_t)(vd.chain_base + k) * CHAIN_DESC_WORDS] = 0;
 	const bool chain_ok = P.chain_rows != nullptr && P.scan != nullptr;
 	bool has_chain = false;
 	{
@@ -1581,6 +1619,27 @@ struct FastLine {
 };
 static_assert(sizeof(FastLine) == 48, "FastLine is 12 dwords");
 
+/* What chain_kernel needs to run one feedback chain for a segment (written by decode_kernel). */
+enum : uint32_t {
+	CM_BASE = 0,   /* first row: base phases (accumulator + phase modulation), second: self-modulation amounts */
+	CM_INC = 1,    /* first row: phase increments (the chain sums them), second: amounts */
+	CM_INLINE = 2, /* no input rows: frequency and amounts are the operator's own lines, evaluated by the feeder wave */
+};
+enum : uint32_t { CL_FCONST = 1, CL_MUL_GOAL = 2, CL_MUL_HOLD = 4 };
+struct ChainDesc {
+	uint32_t n;      /* frames to run this segment (0: row pair unused; the other fields are then unset) */
+	uint32_t gop;    /* the operator's state (global index) */
+	uint32_t wave;
+	uint32_t mode;   /* CM_* */
+	float coeff;     /* CM_INLINE: 2^32 / srate */
+	uint32_t inc_const; /* ... the phase increment when the frequency is one value (CL_FCONST) */
+	uint32_t lflags; /* CL_* */
+	float mulc;      /* ... multiplier of a ratio line (the parent's frequency, one value) */
+	FastLine fl;     /* ... frequency line over the segment */
+	FastLine pl;     /* ... self-modulation amount line */
+};
+static_assert(sizeof(ChainDesc) == 4 * CHAIN_DESC_WORDS && offsetof(ChainDesc, n) == 0, "ChainDesc is 32 dwords, n first");
+
 /* What only a sequential-scan voice needs of a step (FastStep.ramp bit 1): where
  * per-frame frequencies come from and how a ratio line is multiplied. */
 enum : uint32_t {
@@ -1675,7 +1734,7 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 	FastLine fl, pl;
 	FastAux fa;
 	memset(&f, 0, sizeof f); memset(&fl, 0, sizeof fl); memset(&fa, 0, sizeof fa); memset(&pl, 0, sizeof pl);
-	bool is_chain = false, chain_line = false;
+	bool is_chain = false, chain_line = false, chain_inline = false;
 	uint32_t dep = 0;
 	const uint32_t seq = P.info[v].seq;
 	if ((uint32_t)l < vd.plan_len) {
@@ -1764,15 +1823,39 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 			f.type |= FT_CHAIN;
 			f.pan = bits_f(row);
 			ChainDesc cd;
+			memset(&cd, 0, sizeof cd);
 			cd.n = P.info[v].total; cd.gop = ids[st.op]; cd.wave = wv;
-			cd.pad = step_is_chain_acc(st, o) ? 1u : 0u; /* 1: the first row holds phase increments */
-			P.chain_desc[row] = cd;
+			cd.mode = step_is_chain_acc(st, o) ? CM_INC : CM_BASE;
 			if (st.sm == NO_SLOT) { /* the amounts come from the line itself */
 				LineState pls = o.line[L_PMA];
 				const LineBlock lb = line_begin(pls, P.info[v].total, false, 0.f, lattice_none(), 0);
 				pl.sw = lb.sw; pl.goal_len = lb.goal_len; pl.hold = lb.hold; pl.pad = 0;
 				chain_line = true;
 			}
+			uint32_t lstep = ~0u;
+			if (step_is_chain_inline(P.chain_inline != 0, plan, (uint32_t)l, ids, P.ops, &lstep)) {
+				chain_inline = true;
+				cd.mode = CM_INLINE;
+				cd.coeff = o.coeff;
+				cd.pl = pl;
+				cd.mulc = 1.f;
+				if (o.rt_fconst_valid) {
+					cd.lflags = CL_FCONST;
+					cd.inc_const = rint32w(o.coeff * o.rt_fconst);
+				} else {
+					const Step ls = lstep != ~0u ? plan[lstep] : st;
+					const bool have_mul = ls.fmul != NO_SLOT;
+					float pf = 1.f;
+					if (have_mul && ls.prov != NO_SLOT) pf = P.ops[ids[ls.prov]].rt_fconst;
+					LineState fls = o.line[L_FREQ];
+					const LineBlock lb = line_begin(fls, P.info[v].total, have_mul, pf, lattice_none(), 0);
+					cd.fl.sw = lb.sw; cd.fl.goal_len = lb.goal_len; cd.fl.hold = lb.hold; cd.fl.pad = 0;
+					if (lb.mul_goal) cd.lflags |= CL_MUL_GOAL;
+					if (lb.mul_hold) cd.lflags |= CL_MUL_HOLD;
+					cd.mulc = pf;
+				}
+			}
+			P.chain_desc[row] = cd;
 		}
 		if (st.kind == ST_OSC && o.type == OT_WAVE && !zero_fill && !is_chain && st.pm == NO_SLOT && st.fpm == NO_SLOT &&
 		    o.rt_fconst_valid && f.inc == 0 && ((o.flags & OPF_OSC_RESET) || o.prev_phase == o.phase)) {
@@ -1863,8 +1946,12 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 					const bool rmw = sq.kind == ST_LERP || (sq.kind == ST_OSC && (sq.flags & SF_LAYER));
 					{
 						const bool q_chain = step_is_chain(sq, oq);
+						uint32_t q_ls = ~0u;
+						const bool q_inline = q_chain && step_is_chain_inline(P.chain_inline != 0, plan, q, ids, P.ops, &q_ls);
 						bool needed = false;
-						if (q_chain) {
+						if (q_inline) {
+							/* its inputs are its own lines: the feeder wave of chain_kernel evaluates them */
+						} else if (q_chain) {
 							needed = true; /* writes its inputs to the rows, nothing else */
 							want_c |= bit(cq.freq) | bit(cq.fmul) | bit(cq.pm) | bit(cq.fpm) | bit(cq.sm);
 						} else if (writes && (want_c & bit(cq.out))) {
@@ -1939,6 +2026,9 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 		if (chain_line) P.fplines[(size_t)v * P.max_steps + pos] = pl;
 	}
 	if (l == 0) P.info[v].n_fsteps = (uint32_t)__popcll(m);
+	/* chains the chain-input pass has to feed (the others are fed by chain_kernel's own feeder wave) */
+	const unsigned long long mc = __ballot(is_chain && keep && !chain_inline);
+	if (l == 0) P.info[v].n_chain = (uint32_t)__popcll(mc);
 }
 
 /* lane l receives lane l-1's value (lane 0: zero; it is lead-in) */
@@ -2642,19 +2732,28 @@ __global__ void __launch_bounds__(1024) repair_kernel(FastParams P) {
 /* The self-modulation recurrence (wosc.h:273-310: feedback -> phase -> table -> sample -> feedback) is one
  * dependent chain per operator, about a hundred nanoseconds per sample whatever the width of the machine.
  * The block loop ran one such chain on one lane of a wave; here a wave runs sixty-four, one per lane, and
- * nothing but the chain: the time-parallel passes have put every chain's base phases (accumulator + phase
- * modulation) and self-modulation amounts into a pair of rows in HBM (fast_voice, chain-input pass), the
- * samples go back into the first row, and the final pass takes them from there (amplitude, mixing into
- * the parent, voice output). Rows are read and written sixteen frames per lane at a time (four 16-byte
- * accesses, the next batch in flight while the current one is computed); the only state a lane carries is
- * the oscillator's. One wave per workgroup, so that every wave has a CU's LDS port and issue slots to
- * itself: 4096 chains are 64 waves on 64 CUs, and the render takes frames x chain latency. */
+ * nothing but the chain. A workgroup is two waves. The CHAIN wave reads its inputs -- base phases and
+ * self-modulation amounts, sixteen frames per lane at a time -- from LDS, runs the recurrence and leaves the
+ * samples in LDS. The FEEDER wave moves everything else: it fetches the next batch of inputs from the chains'
+ * row pairs in HBM (written by the time-parallel passes: fast_voice, chain-input pass), sums phase increments
+ * for chains that get those instead of base phases, or -- for chains whose inputs are just their own
+ * frequency and amount lines -- evaluates the lines itself, so that such voices need no chain-input pass at
+ * all; and it stores the previous batch of samples to the chain's first row, where the final pass takes them
+ * (amplitude, mixing into the parent, voice output). One barrier per batch. 4096 chains are 64 workgroups on
+ * 64 CUs, and the render takes frames x chain latency. */
+constexpr uint32_t CHAIN_BATCH = 16;               /* frames per lane and batch */
+constexpr uint32_t CHAIN_IO_WORDS = CHAIN_BATCH * 64; /* one array of one batch */
+constexpr size_t CHAIN_IO_BYTES = (size_t)(2 * 2 + 2) * CHAIN_IO_WORDS * 4; /* in[2][2] + out[2] */
+
+/* LDS layout of a batch array: frame 4q + r of lane l at word (q * 64 + l) * 4 + r -- a lane's four 16-byte
+ * accesses are conflict-free */
+__device__ __forceinline__ uint32_t chain_io_word(uint32_t q, int l) { return (q * 64u + (uint32_t)l) * 4u; }
+
 /* SMALL: every feedback offset of the batch is known to stay below 2^20 cycles in magnitude, where the short
  * rounding form is exact (rint32w_p31_small) -- no per-sample test on the chain; the caller verifies the bound
  * it assumed for |fb_s| afterwards (fb_max) and redoes the batch without SMALL if it was exceeded. */
 template <bool LDS_TAB, bool TAIL, bool SMALL>
 __device__ __forceinline__ void chain_batch(const uint4 *bq, const float4 *aq, float4 *sq, uint32_t t, uint32_t n,
-		bool acc_mode, uint32_t &acc,
 		uint32_t tab23, uint32_t tab01, const HerpC23 *g23, const HerpC01 *g01, float dscale, float doff,
 		uint32_t &prev_phase, double &prev_Is, float &prev_s, float &fb_s, float &fb_max) {
 	/* one 16-byte and one 8-byte LDS read per sample (ds_read_b128 / ds_read_b64): the entries are that aligned */
@@ -2672,10 +2771,7 @@ __device__ __forceinline__ void chain_batch(const uint4 *bq, const float4 *aq, f
 			const float p = fb_s * a4[j];
 			uint32_t ofs = rint32w_p31_small(p);
 			if (!SMALL) { if (__builtin_expect(!(fabsf(p) < 0x1p20f), 0)) ofs = rint32w(p * 0x1p31f); }
-			/* the row holds base phases, or phase increments this lane sums (wosc.h:145, pre-increment) */
-			const uint32_t acc_n = acc + b4[j];
-			if (!TAIL || t + (uint32_t)(4 * u + j) < n) acc = acc_n;
-			const uint32_t phase = (acc_mode ? acc_n : b4[j]) + ofs;
+			const uint32_t phase = b4[j] + ofs;
 			const int32_t d = (int32_t)(phase - prev_phase);
 			const uint32_t ind = phase >> SLEN_BITS;
 			HerpC23 hi; HerpC01 lo;
@@ -2704,29 +2800,99 @@ __device__ __forceinline__ void chain_batch(const uint4 *bq, const float4 *aq, f
 	}
 }
 
-__global__ void __launch_bounds__(64) chain_kernel(FastParams P) {
+/* Sixteen consecutive values of a line, frames [t, t + 16) of the segment. Lanes hold different lines: the shape
+ * is tested once per batch and shape (not once per value), each shape's loop compiled with its type known. */
+template <uint32_t TYPE>
+__device__ __forceinline__ void line_batch_shape(const FastLine &fl, uint32_t t, float *out) {
+	if (fl.sw.type != TYPE) return;
+	Sweep sw = fl.sw;
+	sw.type = TYPE;
+#pragma unroll
+	for (uint32_t j = 0; j < CHAIN_BATCH; ++j)
+		if (t + j < fl.goal_len) out[j] = sweep_value_inl<true>(sw, t + j);
+}
+__device__ __forceinline__ void line_batch(const FastLine &fl, uint32_t t, float *out) {
+#pragma unroll
+	for (uint32_t j = 0; j < CHAIN_BATCH; ++j) out[j] = fl.hold;
+	if (t >= fl.goal_len) return;
+	line_batch_shape<LN_cos>(fl, t, out); line_batch_shape<LN_lin>(fl, t, out); line_batch_shape<LN_sah>(fl, t, out);
+	line_batch_shape<LN_xpe>(fl, t, out); line_batch_shape<LN_lge>(fl, t, out); line_batch_shape<LN_sqe>(fl, t, out);
+	line_batch_shape<LN_cub>(fl, t, out); line_batch_shape<LN_smo>(fl, t, out); line_batch_shape<LN_ncl>(fl, t, out);
+	line_batch_shape<LN_nhl>(fl, t, out); line_batch_shape<LN_uwh>(fl, t, out);
+	/* (LN_exp / LN_log were resolved to xpe / lge when the sweep was set up: sau/line.c:125-148) */
+}
+
+/* the feeder's share of one batch: inputs of frames [t, t + 16) into the LDS arrays */
+__device__ __forceinline__ void chain_feed(const ChainDesc &cd, bool live, int l, uint32_t t, uint32_t *acc,
+		const uint4 *bp, const float4 *ap, uint32_t *in_base, float *in_amt) {
+	if (!live) return;
+	uint32_t a = *acc, a_end = *acc; /* a_end: the accumulator after the segment's last frame, should it fall in this batch */
+	if (cd.mode == CM_INLINE) {
+		/* frequency and amounts from the operator's own lines (sau/line.c fills are functions of the position) */
+		float fv[CHAIN_BATCH], m[CHAIN_BATCH];
+		uint32_t b[CHAIN_BATCH];
+		line_batch(cd.pl, t, m);
+		if (!(cd.lflags & CL_FCONST)) line_batch(cd.fl, t, fv);
+#pragma unroll
+		for (uint32_t j = 0; j < CHAIN_BATCH; ++j) {
+			const uint32_t i = t + j;
+			uint32_t inc = cd.inc_const;
+			if (!(cd.lflags & CL_FCONST)) {
+				float v = fv[j];
+				if (cd.lflags & (i < cd.fl.goal_len ? CL_MUL_GOAL : CL_MUL_HOLD)) v *= cd.mulc;
+				const float x = cd.coeff * v;
+				inc = fabsf(x) < 0x1p50f ? (uint32_t)__double2loint((double)x + 0x1.8p52) : rint32w(x);
+			}
+			a += inc; /* wosc.h:145: pre-increment */
+			if (i < cd.n) a_end = a;
+			b[j] = a;
+		}
+#pragma unroll
+		for (uint32_t q = 0; q < 4; ++q) {
+			*(uint4 *)(in_base + chain_io_word(q, l)) = make_uint4(b[4 * q], b[4 * q + 1], b[4 * q + 2], b[4 * q + 3]);
+			*(float4 *)(in_amt + chain_io_word(q, l)) = make_float4(m[4 * q], m[4 * q + 1], m[4 * q + 2], m[4 * q + 3]);
+		}
+		*acc = a_end;
+		return;
+	}
+#pragma unroll
+	for (uint32_t q = 0; q < 4; ++q) {
+		uint4 b = bp[t / 4 + q];
+		if (cd.mode == CM_INC) { /* phase increments: summed here */
+			const uint32_t i = t + 4 * q;
+			b.x += a; b.y += b.x; b.z += b.y; b.w += b.z;
+			a = b.w;
+			a_end = i + 3 < cd.n ? b.w : i + 2 < cd.n ? b.z : i + 1 < cd.n ? b.y : i < cd.n ? b.x : a_end;
+		}
+		*(uint4 *)(in_base + chain_io_word(q, l)) = b;
+		*(float4 *)(in_amt + chain_io_word(q, l)) = ap[t / 4 + q];
+	}
+	*acc = a_end;
+}
+
+__global__ void __launch_bounds__(128) chain_kernel(FastParams P) {
 	extern __shared__ __align__(16) unsigned char lds[];
 	if (P.pass_flags[FAST_MAX_LEVELS + 1] == 0) return; /* no voice of the segment has a chain */
-	const int l = threadIdx.x;
+	const int l = threadIdx.x & 63;
+	const bool feeder = uni((uint32_t)threadIdx.x >> 6) != 0;
 	const uint32_t c = blockIdx.x * 64 + (uint32_t)l;
 	ChainDesc cd;
-	cd.n = 0; cd.gop = 0; cd.wave = 0; cd.pad = 0;
-	if (c < P.n_chain_rows) cd = P.chain_desc[c];
-	if (cd.n == 0) { cd.gop = 0; cd.wave = 0; } /* an unused row pair: only `n` of its descriptor is set */
+	memset(&cd, 0, sizeof cd);
+	if (c < P.n_chain_rows && P.chain_desc[c].n != 0) cd = P.chain_desc[c]; /* (an unused pair has only `n` set) */
 	const uint32_t n = cd.n;
 	if (!__any(n != 0)) return;
 	HerpC23 *t23 = (HerpC23 *)lds;
 	HerpC01 *t01 = (HerpC01 *)(lds + (size_t)P.n_ctabs * WAVE_LEN * sizeof(HerpC23));
+	uint32_t *io = (uint32_t *)(lds + (size_t)P.n_ctabs * WAVE_LEN * (sizeof(HerpC23) + sizeof(HerpC01)));
 	for (uint32_t t = 0; t < P.n_ctabs; ++t) {
 		const uint32_t wave = P.cwave_of_tab[t];
 		const uint4 *s23 = (const uint4 *)(P.g_c23 + (size_t)wave * WAVE_LEN);
 		uint4 *d23 = (uint4 *)(t23 + (size_t)t * WAVE_LEN);
-		for (uint32_t i = l; i < WAVE_LEN; i += 64) d23[i] = s23[i];
+		for (uint32_t i = threadIdx.x; i < WAVE_LEN; i += 128) d23[i] = s23[i];
 		const uint2 *s01 = (const uint2 *)(P.g_c01 + (size_t)wave * WAVE_LEN);
 		uint2 *d01 = (uint2 *)(t01 + (size_t)t * WAVE_LEN);
-		for (uint32_t i = l; i < WAVE_LEN; i += 64) d01[i] = s01[i];
+		for (uint32_t i = threadIdx.x; i < WAVE_LEN; i += 128) d01[i] = s01[i];
 	}
-	__syncthreads();
 	const uint32_t wave = cd.wave < 12 ? cd.wave : 0;
 	const int ti = P.ctab_of_wave[wave];
 	const bool all_lds = __all(n == 0 || ti >= 0) != 0;
@@ -2736,18 +2902,51 @@ __global__ void __launch_bounds__(64) chain_kernel(FastParams P) {
 	const HerpC01 *g01 = P.g_c01 + (size_t)wave * WAVE_LEN;
 	const float dscale = P.wc[wave].diff_scale, doff = P.wc[wave].diff_offset;
 	DevOp &o = P.ops[cd.gop];
-	uint32_t prev_phase = o.prev_phase;
-	double prev_Is = o.prev_Is;
-	float prev_s = o.prev_s, fb_s = o.fb_s;
-	/* idle lanes run along on row pair 0 (reads only) */
+	/* row pair of the chain (idle lanes: pair 0, reads only) */
 	float *brow = P.chain_rows + (size_t)2 * (n ? c : 0u) * P.chain_stride;
 	const uint4 *bp = (const uint4 *)brow;
 	const float4 *ap = (const float4 *)(brow + P.chain_stride);
 	float4 *op = (float4 *)brow;
-	const bool acc_mode = cd.pad != 0;
-	uint32_t acc = o.phase;
+	uint32_t n_all = n ? (n & ~(CHAIN_BATCH - 1)) : 0xfffffff0u, n_max = n;
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) {
+		n_all = min(n_all, (uint32_t)__shfl_xor((int)n_all, d));
+		n_max = max(n_max, (uint32_t)__shfl_xor((int)n_max, d));
+	}
+	n_all = uni(n_all); n_max = uni(n_max);
+	/* in[b][0]: base phases, in[b][1]: amounts, then out[b]: samples; b = batch & 1 */
+	auto in_base = [&](uint32_t b) { return io + (size_t)(2 * b) * CHAIN_IO_WORDS; };
+	auto in_amt = [&](uint32_t b) { return (float *)(io + (size_t)(2 * b + 1) * CHAIN_IO_WORDS); };
+	auto out_s = [&](uint32_t b) { return (float *)(io + (size_t)(4 + b) * CHAIN_IO_WORDS); };
+	const uint32_t n_batches = (n_max + CHAIN_BATCH - 1) / CHAIN_BATCH;
+	if (feeder) {
+		uint32_t acc = o.phase; /* CM_INC, CM_INLINE: the phase accumulator */
+		/* step k: feed batch k while the chain wave runs batch k - 1, store the samples of batch k - 2 */
+		for (uint32_t k = 0; k <= n_batches; ++k) {
+			if (k < n_batches && k * CHAIN_BATCH < n)
+				chain_feed(cd, true, l, k * CHAIN_BATCH, &acc, bp, ap, in_base(k & 1), in_amt(k & 1));
+			if (k >= 2 && (k - 2) * CHAIN_BATCH < n) {
+				const float *sq = out_s(k & 1);
+#pragma unroll
+				for (uint32_t q = 0; q < 4; ++q) op[(k - 2) * CHAIN_BATCH / 4 + q] = *(const float4 *)(sq + chain_io_word(q, l));
+			}
+			__syncthreads(); /* (the first one also: tables staged) */
+		}
+		if (n_batches && (n_batches - 1) * CHAIN_BATCH < n) {
+			const float *sq = out_s((n_batches - 1) & 1);
+#pragma unroll
+			for (uint32_t q = 0; q < 4; ++q) op[(n_batches - 1) * CHAIN_BATCH / 4 + q] = *(const float4 *)(sq + chain_io_word(q, l));
+		}
+		if (n && cd.mode != CM_BASE && !(cd.mode == CM_INLINE && (cd.lflags & CL_FCONST))) o.st_phase = acc;
+		return;
+	}
+	/* ---- the chain wave ---- */
+	uint32_t prev_phase = o.prev_phase;
+	double prev_Is = o.prev_Is;
+	float prev_s = o.prev_s, fb_s = o.fb_s;
+	__syncthreads();
 	if (n && (o.flags & OPF_OSC_RESET)) { /* wosc.h:215-231 with the first base phase, as the block loop does */
-		const uint32_t phase00 = ((const u32_alias *)brow)[0] + (acc_mode ? acc : 0u);
+		const uint32_t phase00 = in_base(0)[chain_io_word(0, l)];
 		const uint32_t pa = phase00 - SLEN;
 		prev_Is = herp_poly(g23[pa >> SLEN_BITS], g01[pa >> SLEN_BITS], pa);
 		const double Is0 = herp_poly(g23[phase00 >> SLEN_BITS], g01[phase00 >> SLEN_BITS], phase00);
@@ -2755,23 +2954,13 @@ __global__ void __launch_bounds__(64) chain_kernel(FastParams P) {
 		prev_Is = Is0;
 		prev_phase = phase00;
 	}
-	/* frames every lane with work has (in whole batches): those need no per-frame bounds */
-	uint32_t n_all = n ? (n & ~15u) : 0xfffffff0u, n_max = n;
+	for (uint32_t k = 0; k < n_batches; ++k) {
+		const uint32_t t = k * CHAIN_BATCH;
+		uint4 bq[4]; float4 aq[4]; float4 sq[4];
+		const uint32_t *ib = in_base(k & 1);
+		const float *ia = in_amt(k & 1);
 #pragma unroll
-	for (int d = 32; d >= 1; d >>= 1) {
-		n_all = min(n_all, (uint32_t)__shfl_xor((int)n_all, d));
-		n_max = max(n_max, (uint32_t)__shfl_xor((int)n_max, d));
-	}
-	n_all = uni(n_all); n_max = uni(n_max);
-	uint4 bq[4]; float4 aq[4];
-#pragma unroll
-	for (int u = 0; u < 4; ++u) { bq[u] = bp[u]; aq[u] = ap[u]; }
-	for (uint32_t t = 0; t < n_max; t += 16) {
-		uint4 bn[4]; float4 an[4];
-		const uint32_t nx = (t + 16 < n_max) ? (t + 16) / 4 : 0; /* next batch, in flight during this one */
-#pragma unroll
-		for (int u = 0; u < 4; ++u) { bn[u] = bp[nx + u]; an[u] = ap[nx + u]; }
-		float4 sq[4];
+		for (uint32_t q = 0; q < 4; ++q) { bq[q] = *(const uint4 *)(ib + chain_io_word(q, l)); aq[q] = *(const float4 *)(ia + chain_io_word(q, l)); }
 		/* the short rounding form needs |fb_s * amount| < 2^20: amounts below 2^14 and |fb_s| <= 64 (checked after) */
 		float a_max = 0.f;
 #pragma unroll
@@ -2779,17 +2968,16 @@ __global__ void __launch_bounds__(64) chain_kernel(FastParams P) {
 			a_max = fmaxf(fmaxf(a_max, fmaxf(fabsf(aq[u].x), fabsf(aq[u].y))), fmaxf(fabsf(aq[u].z), fabsf(aq[u].w)));
 		const uint32_t s_prev_phase = prev_phase; const double s_prev_Is = prev_Is;
 		const float s_prev_s = prev_s, s_fb_s = fb_s;
-		const uint32_t s_acc = acc;
 		float fb_max = fabsf(fb_s);
-		bool small = !__any(!(a_max < 0x1p14f));
-		const bool tail = !(t + 16 <= n_all);
-#define SAU_CHAIN_BATCH(L, TL, SM) chain_batch<L, TL, SM>(bq, aq, sq, t, n, acc_mode, acc, tab23, tab01, g23, g01, dscale, doff, prev_phase, prev_Is, prev_s, fb_s, fb_max)
+		bool small = !__any(n != 0 && !(a_max < 0x1p14f));
+		const bool tail = !(t + CHAIN_BATCH <= n_all);
+#define SAU_CHAIN_BATCH(L, TL, SM) chain_batch<L, TL, SM>(bq, aq, sq, t, n, tab23, tab01, g23, g01, dscale, doff, prev_phase, prev_Is, prev_s, fb_s, fb_max)
 		if (small) {
 			if (all_lds) { if (tail) SAU_CHAIN_BATCH(true, true, true); else SAU_CHAIN_BATCH(true, false, true); }
 			else { if (tail) SAU_CHAIN_BATCH(false, true, true); else SAU_CHAIN_BATCH(false, false, true); }
-			if (__any(!(fb_max <= 64.f))) { /* (never seen: feedback is an average of samples) */
+			if (__any(n != 0 && !(fb_max <= 64.f))) { /* (never seen: feedback is an average of samples) */
 				small = false;
-				prev_phase = s_prev_phase; prev_Is = s_prev_Is; prev_s = s_prev_s; fb_s = s_fb_s; acc = s_acc;
+				prev_phase = s_prev_phase; prev_Is = s_prev_Is; prev_s = s_prev_s; fb_s = s_fb_s;
 			}
 		}
 		if (!small) {
@@ -2797,12 +2985,10 @@ __global__ void __launch_bounds__(64) chain_kernel(FastParams P) {
 			else { if (tail) SAU_CHAIN_BATCH(false, true, false); else SAU_CHAIN_BATCH(false, false, false); }
 		}
 #undef SAU_CHAIN_BATCH
-		if (t < n) {
+		float *os = out_s(k & 1);
 #pragma unroll
-			for (int u = 0; u < 4; ++u) op[t / 4 + u] = sq[u];
-		}
-#pragma unroll
-		for (int u = 0; u < 4; ++u) { bq[u] = bn[u]; aq[u] = an[u]; }
+		for (uint32_t q = 0; q < 4; ++q) *(float4 *)(os + chain_io_word(q, l)) = sq[q];
+		__syncthreads();
 	}
 	if (n) { /* staged: finalize_kernel makes it the operator's state unless the voice's segment is redone */
 		o.st_prev_phase = prev_phase;
@@ -2810,10 +2996,8 @@ __global__ void __launch_bounds__(64) chain_kernel(FastParams P) {
 		o.st_prev_s = prev_s;
 		o.ras_alpha = f_bits(fb_s);
 		o.ras_level = CHAIN_MARK;
-		if (acc_mode) o.st_phase = acc;
 	}
 }
-
 
 /* Apply the closed forms to the operator state, or hand the whole segment
  * to the block loop when a chunk had to bail out. */
@@ -3264,6 +3448,7 @@ public:
 		fast_enabled_ = getenv("SAU_AMD_NO_FAST") == nullptr;
 		seq_enabled_ = getenv("SAU_AMD_NO_SEQ") == nullptr; /* running-sum phases in the time-parallel kernel */
 		chain_enabled_ = getenv("SAU_AMD_NO_CHAIN") == nullptr; /* feedback recurrences with lanes = voices */
+		chain_inline_ = getenv("SAU_AMD_CHAIN_INLINE") != nullptr;
 		two_pass_enabled_ = getenv("SAU_AMD_NO_TWO_PASS") == nullptr; /* ... in two passes where possible */
 		/* voices per segment from which feedback voices get sixteen one-wave teams per workgroup
 		 * (0: never; 1: always, also without feedback -- tests) */
@@ -3521,10 +3706,11 @@ public:
 				    !fplines_.ensure((size_t)seg.n_voices * fmax_steps * sizeof(FastLine), err)) return false;
 				fp.chain_rows = chain_rows_.p; fp.chain_stride = cstride; fp.n_chain_rows = seg.n_chain_rows;
 				fp.chain_desc = chain_desc_.p; fp.fplines = (FastLine *)fplines_.p;
+				fp.chain_inline = chain_inline_ ? 1u : 0u;
 				uint32_t ct = 0;
 				for (int wv = 0; wv < 12; ++wv) {
 					fp.ctab_of_wave[wv] = -1;
-					if (((seg.wave_mask >> wv) & 1) && (ct + 1) * tab_bytes + 1024 <= lds_limit_) {
+					if (((seg.wave_mask >> wv) & 1) && (ct + 1) * tab_bytes + CHAIN_IO_BYTES + 1024 <= lds_limit_) {
 						fp.ctab_of_wave[wv] = (int8_t)ct;
 						fp.cwave_of_tab[ct] = (uint8_t)wv;
 						++ct;
@@ -3592,7 +3778,7 @@ public:
 					}
 					if (fp.chain_rows) { /* the chains' inputs, then the chains themselves: lanes = voices */
 						launch_fast(fp.sum_levels + 2);
-						const size_t clds = (size_t)fp.n_ctabs * tab_bytes;
+						const size_t clds = (size_t)fp.n_ctabs * tab_bytes + CHAIN_IO_BYTES;
 						static size_t cconfigured[16];
 						if (clds > cconfigured[dev_ & 15]) {
 							HIP_OK(hipFuncSetAttribute((const void *)chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds));
@@ -3600,7 +3786,7 @@ public:
 						}
 						TimedPair *tc = timing_on_ ? new_pair(0) : nullptr; /* counted with the block loop it replaces */
 						if (tc) (void)hipEventRecord(tc->a, stream_);
-						hipLaunchKernelGGL(chain_kernel, dim3((seg.n_chain_rows + 63) / 64), dim3(64), clds, stream_, fp);
+						hipLaunchKernelGGL(chain_kernel, dim3((seg.n_chain_rows + 63) / 64), dim3(128), clds, stream_, fp);
 						if (tc) (void)hipEventRecord(tc->b, stream_);
 					}
 					launch_fast(fp.sum_levels + 1);
@@ -3886,7 +4072,7 @@ private:
 	std::map<void *, size_t> host_blocks_; /* alloc_host() blocks and their pool sizes */
 	uint32_t multi_min_ = 256;
 	uint32_t fast_rows_ = 8;
-	bool seq_enabled_ = true, two_pass_enabled_ = true, chain_enabled_ = true;
+	bool seq_enabled_ = true, two_pass_enabled_ = true, chain_enabled_ = true, chain_inline_ = false;
 	DevBuf<float> chain_rows_;
 	DevBuf<ChainDesc> chain_desc_;
 	DevBuf<unsigned char> fplines_;

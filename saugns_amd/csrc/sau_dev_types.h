@@ -226,13 +226,6 @@ SAU_HD uint32_t fast_slot_compact(const Step *plan, uint32_t n, FastIds *ids, bo
 SAU_HD bool step_may_chain(const Step &st) {
 	return st.kind == ST_OSC && ((st.flags & SF_SM_INLINE) || st.sm != NO_SLOT);
 }
-struct ChainDesc {
-	uint32_t n;      /* frames to run this segment (0: row pair unused) */
-	uint32_t gop;    /* the operator's state (global index) */
-	uint32_t wave;
-	uint32_t pad;
-};
-
 /* One voice of one render stream, for one segment launch. */
 struct VoiceDesc {
 	uint32_t plan_ofs, plan_len; /* into the step array */
