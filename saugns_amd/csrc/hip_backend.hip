@@ -1183,6 +1183,11 @@ struct FastParams {
 	uint32_t n_ctabs;     /* wave tables chain_kernel stages in LDS */
 	uint32_t chain_inline;/* chains fed from their own lines by chain_kernel's feeder wave (SAU_AMD_CHAIN_INLINE; off:
 	                       * measured slower) */
+	/* A segment with chains is pipelined in chunks of frames: while chain_kernel (64 CUs, a second stream) runs
+	 * chunk c, the chain-input pass prepares chunk c + 1 and the final pass finishes chunk c - 1 on the other CUs.
+	 * fast_kernel: range_mode 1 = the row groups that start in [f_lo, f_hi), 2 = those that end in (f_lo, f_hi]
+	 * (0: all). chain_kernel: frames [f_lo, f_hi) of every chain, continuing from the staged state when f_lo > 0. */
+	uint32_t range_mode, f_lo, f_hi, range_last;
 	int8_t ctab_of_wave[12];
 	uint8_t cwave_of_tab[12];
 	int8_t tab_of_wave[12];
@@ -2091,8 +2096,23 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 
 	uint32_t *const rep = P.repair + (size_t)v * FAST_REPAIR_WORDS;
 	/* REPAIR: the noted row groups instead of all, each evaluated FAST_REPAIR_SHIFT frames early */
-	const uint32_t n_iter = REPAIR ? min(uni(rep[0]), FAST_MAX_REPAIR) : ngroups;
-	for (uint32_t it = cstart; it < n_iter; it += gstride) {
+	uint32_t n_iter = REPAIR ? min(uni(rep[0]), FAST_MAX_REPAIR) : ngroups;
+	uint32_t it_lo = 0;
+	if (!REPAIR && P.range_mode != 0) {
+		if (seq) { if (!P.range_last) return; } /* one wave in order, carries in LDS: in the last chunk's launch, all of it */
+		else {
+			const uint32_t tc = (uint32_t)T * C;
+			if (P.range_mode == 1) { /* groups that start in [f_lo, f_hi) */
+				it_lo = (P.f_lo + tc - 1) / tc;
+				n_iter = min(ngroups, P.f_hi > 0xffffffffu - tc ? ngroups : (P.f_hi + tc - 1) / tc);
+			} else { /* groups that end in (f_lo, f_hi]; the last one ends with the segment */
+				it_lo = P.f_lo / tc;
+				n_iter = fast_total <= P.f_hi ? ngroups : min(ngroups, P.f_hi / tc);
+				if (P.f_lo >= fast_total) n_iter = 0;
+			}
+		}
+	}
+	for (uint32_t it = it_lo + cstart; it < n_iter; it += gstride) {
 		const uint32_t cg = REPAIR ? uni(rep[2 + 2 * it]) : it;
 		const uint32_t repair_rows = REPAIR ? uni(rep[3 + 2 * it]) : 0u;
 		const int t0 = (int)(cg * T * C) - (int)H + l - (REPAIR ? (int)FAST_REPAIR_SHIFT : 0); /* this lane's frame in row 0 */
@@ -2879,7 +2899,11 @@ __global__ void __launch_bounds__(128) chain_kernel(FastParams P) {
 	ChainDesc cd;
 	memset(&cd, 0, sizeof cd);
 	if (c < P.n_chain_rows && P.chain_desc[c].n != 0) cd = P.chain_desc[c]; /* (an unused pair has only `n` set) */
-	const uint32_t n = cd.n;
+	/* this launch's share of the chain: frames [c_lo, n) of the segment, n cut at the chunk's end */
+	const uint32_t c_lo = P.range_mode ? P.f_lo : 0u;
+	uint32_t n = cd.n;
+	if (P.range_mode && n > P.f_hi) n = P.f_hi;
+	if (n <= c_lo) n = 0;
 	if (!__any(n != 0)) return;
 	HerpC23 *t23 = (HerpC23 *)lds;
 	HerpC01 *t01 = (HerpC01 *)(lds + (size_t)P.n_ctabs * WAVE_LEN * sizeof(HerpC23));
@@ -2907,7 +2931,9 @@ __global__ void __launch_bounds__(128) chain_kernel(FastParams P) {
 	const uint4 *bp = (const uint4 *)brow;
 	const float4 *ap = (const float4 *)(brow + P.chain_stride);
 	float4 *op = (float4 *)brow;
-	uint32_t n_all = n ? (n & ~(CHAIN_BATCH - 1)) : 0xfffffff0u, n_max = n;
+	/* frames count from the chunk's start below: t = c_lo + (batch index) * 16 */
+	const uint32_t n_rel = n ? n - c_lo : 0u;
+	uint32_t n_all = n ? (n_rel & ~(CHAIN_BATCH - 1)) : 0xfffffff0u, n_max = n_rel;
 #pragma unroll
 	for (int d = 32; d >= 1; d >>= 1) {
 		n_all = min(n_all, (uint32_t)__shfl_xor((int)n_all, d));
@@ -2920,32 +2946,33 @@ __global__ void __launch_bounds__(128) chain_kernel(FastParams P) {
 	auto out_s = [&](uint32_t b) { return (float *)(io + (size_t)(4 + b) * CHAIN_IO_WORDS); };
 	const uint32_t n_batches = (n_max + CHAIN_BATCH - 1) / CHAIN_BATCH;
 	if (feeder) {
-		uint32_t acc = o.phase; /* CM_INC, CM_INLINE: the phase accumulator */
+		uint32_t acc = c_lo ? o.st_phase : o.phase; /* CM_INC, CM_INLINE: the phase accumulator (staged by the chunk before) */
 		/* step k: feed batch k while the chain wave runs batch k - 1, store the samples of batch k - 2 */
 		for (uint32_t k = 0; k <= n_batches; ++k) {
-			if (k < n_batches && k * CHAIN_BATCH < n)
-				chain_feed(cd, true, l, k * CHAIN_BATCH, &acc, bp, ap, in_base(k & 1), in_amt(k & 1));
-			if (k >= 2 && (k - 2) * CHAIN_BATCH < n) {
+			if (k < n_batches && c_lo + k * CHAIN_BATCH < n)
+				chain_feed(cd, true, l, c_lo + k * CHAIN_BATCH, &acc, bp, ap, in_base(k & 1), in_amt(k & 1));
+			if (k >= 2 && c_lo + (k - 2) * CHAIN_BATCH < n) {
 				const float *sq = out_s(k & 1);
 #pragma unroll
-				for (uint32_t q = 0; q < 4; ++q) op[(k - 2) * CHAIN_BATCH / 4 + q] = *(const float4 *)(sq + chain_io_word(q, l));
+				for (uint32_t q = 0; q < 4; ++q) op[(c_lo + (k - 2) * CHAIN_BATCH) / 4 + q] = *(const float4 *)(sq + chain_io_word(q, l));
 			}
 			__syncthreads(); /* (the first one also: tables staged) */
 		}
-		if (n_batches && (n_batches - 1) * CHAIN_BATCH < n) {
+		if (n_batches && c_lo + (n_batches - 1) * CHAIN_BATCH < n) {
 			const float *sq = out_s((n_batches - 1) & 1);
 #pragma unroll
-			for (uint32_t q = 0; q < 4; ++q) op[(n_batches - 1) * CHAIN_BATCH / 4 + q] = *(const float4 *)(sq + chain_io_word(q, l));
+			for (uint32_t q = 0; q < 4; ++q) op[(c_lo + (n_batches - 1) * CHAIN_BATCH) / 4 + q] = *(const float4 *)(sq + chain_io_word(q, l));
 		}
 		if (n && cd.mode != CM_BASE && !(cd.mode == CM_INLINE && (cd.lflags & CL_FCONST))) o.st_phase = acc;
 		return;
 	}
 	/* ---- the chain wave ---- */
-	uint32_t prev_phase = o.prev_phase;
-	double prev_Is = o.prev_Is;
-	float prev_s = o.prev_s, fb_s = o.fb_s;
+	/* the operator's state, or what the chunk before this one staged */
+	uint32_t prev_phase = c_lo ? o.st_prev_phase : o.prev_phase;
+	double prev_Is = c_lo ? o.st_prev_Is : o.prev_Is;
+	float prev_s = c_lo ? o.st_prev_s : o.prev_s, fb_s = c_lo ? bits_f(o.ras_alpha) : o.fb_s;
 	__syncthreads();
-	if (n && (o.flags & OPF_OSC_RESET)) { /* wosc.h:215-231 with the first base phase, as the block loop does */
+	if (n && c_lo == 0 && (o.flags & OPF_OSC_RESET)) { /* wosc.h:215-231 with the first base phase, as the block loop does */
 		const uint32_t phase00 = in_base(0)[chain_io_word(0, l)];
 		const uint32_t pa = phase00 - SLEN;
 		prev_Is = herp_poly(g23[pa >> SLEN_BITS], g01[pa >> SLEN_BITS], pa);
@@ -2955,7 +2982,7 @@ __global__ void __launch_bounds__(128) chain_kernel(FastParams P) {
 		prev_phase = phase00;
 	}
 	for (uint32_t k = 0; k < n_batches; ++k) {
-		const uint32_t t = k * CHAIN_BATCH;
+		const uint32_t t = c_lo + k * CHAIN_BATCH;
 		uint4 bq[4]; float4 aq[4]; float4 sq[4];
 		const uint32_t *ib = in_base(k & 1);
 		const float *ia = in_amt(k & 1);
@@ -2970,7 +2997,7 @@ __global__ void __launch_bounds__(128) chain_kernel(FastParams P) {
 		const float s_prev_s = prev_s, s_fb_s = fb_s;
 		float fb_max = fabsf(fb_s);
 		bool small = !__any(n != 0 && !(a_max < 0x1p14f));
-		const bool tail = !(t + CHAIN_BATCH <= n_all);
+		const bool tail = !((k + 1) * CHAIN_BATCH <= n_all);
 #define SAU_CHAIN_BATCH(L, TL, SM) chain_batch<L, TL, SM>(bq, aq, sq, t, n, tab23, tab01, g23, g01, dscale, doff, prev_phase, prev_Is, prev_s, fb_s, fb_max)
 		if (small) {
 			if (all_lds) { if (tail) SAU_CHAIN_BATCH(true, true, true); else SAU_CHAIN_BATCH(true, false, true); }
@@ -3414,6 +3441,8 @@ public:
 		use_device();
 		/* the buffers go back to the pool (member destructors): nothing may still be using them */
 		if (stream_) (void)hipStreamSynchronize(stream_);
+		if (chain_stream_) { (void)hipStreamSynchronize(chain_stream_); StreamPool::get().give(dev_, chain_stream_); }
+		for (hipEvent_t e : chain_ev_) (void)hipEventDestroy(e);
 		for (int i = 0; i < 2; ++i) if (fetch_ev_[i]) (void)hipEventDestroy(fetch_ev_[i]);
 		for (auto &e : events_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
 		if (stream_) StreamPool::get().give(dev_, stream_); /* drained above */
@@ -3449,6 +3478,10 @@ public:
 		seq_enabled_ = getenv("SAU_AMD_NO_SEQ") == nullptr; /* running-sum phases in the time-parallel kernel */
 		chain_enabled_ = getenv("SAU_AMD_NO_CHAIN") == nullptr; /* feedback recurrences with lanes = voices */
 		chain_inline_ = getenv("SAU_AMD_CHAIN_INLINE") != nullptr;
+		if (const char *cc = getenv("SAU_AMD_CHAIN_CHUNKS")) { /* pipeline depth of a segment with chains (1: off) */
+			const int n = atoi(cc);
+			chain_chunks_ = n >= 16 ? 16 : n >= 8 ? 8 : n >= 4 ? 4 : n >= 2 ? 2 : 1;
+		}
 		two_pass_enabled_ = getenv("SAU_AMD_NO_TWO_PASS") == nullptr; /* ... in two passes where possible */
 		/* voices per segment from which feedback voices get sixteen one-wave teams per workgroup
 		 * (0: never; 1: always, also without feedback -- tests) */
@@ -3758,16 +3791,17 @@ public:
 				if (fgrid < 1) fgrid = 1;
 				TimedPair *tf = timing_on_ ? new_pair(2) : nullptr;
 				if (tf) (void)hipEventRecord(tf->a, stream_);
-				auto launch_fast = [&](uint32_t mode) {
+				auto launch_fast = [&](uint32_t mode, uint32_t grid = 0) {
 					fp.mode = mode;
+					if (!grid) grid = fgrid;
 					if (scan_build) {
-						if (FT == 8) hipLaunchKernelGGL((fast_kernel<8, true>), dim3(fgrid), dim3(1024), flds, stream_, fp);
-						else if (FT == 4) hipLaunchKernelGGL((fast_kernel<4, true>), dim3(fgrid), dim3(1024), flds, stream_, fp);
-						else hipLaunchKernelGGL((fast_kernel<2, true>), dim3(fgrid), dim3(1024), flds, stream_, fp);
+						if (FT == 8) hipLaunchKernelGGL((fast_kernel<8, true>), dim3(grid), dim3(1024), flds, stream_, fp);
+						else if (FT == 4) hipLaunchKernelGGL((fast_kernel<4, true>), dim3(grid), dim3(1024), flds, stream_, fp);
+						else hipLaunchKernelGGL((fast_kernel<2, true>), dim3(grid), dim3(1024), flds, stream_, fp);
 					} else {
-						if (FT == 8) hipLaunchKernelGGL((fast_kernel<8, false>), dim3(fgrid), dim3(1024), flds, stream_, fp);
-						else if (FT == 4) hipLaunchKernelGGL((fast_kernel<4, false>), dim3(fgrid), dim3(1024), flds, stream_, fp);
-						else hipLaunchKernelGGL((fast_kernel<2, false>), dim3(fgrid), dim3(1024), flds, stream_, fp);
+						if (FT == 8) hipLaunchKernelGGL((fast_kernel<8, false>), dim3(grid), dim3(1024), flds, stream_, fp);
+						else if (FT == 4) hipLaunchKernelGGL((fast_kernel<4, false>), dim3(grid), dim3(1024), flds, stream_, fp);
+						else hipLaunchKernelGGL((fast_kernel<2, false>), dim3(grid), dim3(1024), flds, stream_, fp);
 					}
 				};
 				if (fp.scan) {
@@ -3776,20 +3810,66 @@ public:
 						launch_fast(pass);
 						hipLaunchKernelGGL(scan_kernel, dim3(seg.n_voices), dim3(64), 0, stream_, fp);
 					}
-					if (fp.chain_rows) { /* the chains' inputs, then the chains themselves: lanes = voices */
-						launch_fast(fp.sum_levels + 2);
+					if (fp.chain_rows) {
+						/* The chains' inputs, the chains themselves (lanes = voices), the final pass -- pipelined over
+						 * chunks of the segment: chain_kernel occupies one CU per 64 chains for frames x chain latency,
+						 * so it runs on a stream of its own while, on the other CUs, the chain-input pass prepares the
+						 * chunks after it and the final pass finishes the chunks before it. */
 						const size_t clds = (size_t)fp.n_ctabs * tab_bytes + CHAIN_IO_BYTES;
 						static size_t cconfigured[16];
 						if (clds > cconfigured[dev_ & 15]) {
 							HIP_OK(hipFuncSetAttribute((const void *)chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds));
 							cconfigured[dev_ & 15] = clds;
 						}
+						const uint32_t cgrid = (seg.n_chain_rows + 63) / 64;
+						uint32_t n_chunks = chain_chunks_;
+						while (n_chunks > 1 && seg.len / n_chunks < 4096) n_chunks /= 2;
+						if (!chain_stream_ && n_chunks > 1) {
+							chain_stream_ = StreamPool::get().take(dev_);
+							if (!chain_stream_) HIP_OK(hipStreamCreateWithFlags(&chain_stream_, hipStreamNonBlocking));
+						}
+						while (chain_ev_.size() < 2 * (size_t)n_chunks) {
+							hipEvent_t e;
+							HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+							chain_ev_.push_back(e);
+						}
+						/* chunk boundaries: multiples of the chain kernel's batch */
+						const uint32_t clen = ((seg.len + n_chunks - 1) / n_chunks + 255) & ~255u;
+						/* the time-parallel passes leave the chains' CUs alone while both run */
+						const uint32_t pgrid = n_chunks > 1 && fgrid + cgrid > FK_GRID ? (FK_GRID > cgrid + 32 ? FK_GRID - cgrid : 32) : fgrid;
 						TimedPair *tc = timing_on_ ? new_pair(0) : nullptr; /* counted with the block loop it replaces */
-						if (tc) (void)hipEventRecord(tc->a, stream_);
-						hipLaunchKernelGGL(chain_kernel, dim3((seg.n_chain_rows + 63) / 64), dim3(128), clds, stream_, fp);
-						if (tc) (void)hipEventRecord(tc->b, stream_);
+						if (n_chunks == 1) {
+							fp.range_mode = 0;
+							launch_fast(fp.sum_levels + 2);
+							if (tc) (void)hipEventRecord(tc->a, stream_);
+							hipLaunchKernelGGL(chain_kernel, dim3(cgrid), dim3(128), clds, stream_, fp);
+							if (tc) (void)hipEventRecord(tc->b, stream_);
+							launch_fast(fp.sum_levels + 1);
+						} else {
+							for (uint32_t c = 0; c < n_chunks; ++c) { /* inputs of chunk c, then its chains on the other stream */
+								fp.range_mode = 1; fp.f_lo = c * clen; fp.f_hi = c + 1 == n_chunks ? 0xffffffffu : (c + 1) * clen;
+								fp.range_last = c + 1 == n_chunks;
+								launch_fast(fp.sum_levels + 2, pgrid);
+								HIP_OK(hipEventRecord(chain_ev_[2 * c], stream_));
+								HIP_OK(hipStreamWaitEvent(chain_stream_, chain_ev_[2 * c], 0));
+								FastParams cp = fp;
+								cp.range_mode = 1; cp.f_lo = c * clen; cp.f_hi = c + 1 == n_chunks ? 0xffffffffu : (c + 1) * clen;
+								if (tc && c == 0) (void)hipEventRecord(tc->a, chain_stream_);
+								hipLaunchKernelGGL(chain_kernel, dim3(cgrid), dim3(128), clds, chain_stream_, cp);
+								if (tc && c + 1 == n_chunks) (void)hipEventRecord(tc->b, chain_stream_);
+								HIP_OK(hipEventRecord(chain_ev_[2 * c + 1], chain_stream_));
+							}
+							for (uint32_t c = 0; c < n_chunks; ++c) { /* the final pass follows the chains chunk by chunk */
+								HIP_OK(hipStreamWaitEvent(stream_, chain_ev_[2 * c + 1], 0));
+								fp.range_mode = 2; fp.f_lo = c * clen; fp.f_hi = c + 1 == n_chunks ? 0xffffffffu : (c + 1) * clen;
+								fp.range_last = c + 1 == n_chunks;
+								launch_fast(fp.sum_levels + 1, c + 1 == n_chunks ? fgrid : pgrid);
+							}
+							fp.range_mode = 0; fp.f_lo = 0; fp.f_hi = 0; fp.range_last = 0;
+						}
+					} else {
+						launch_fast(fp.sum_levels + 1);
 					}
-					launch_fast(fp.sum_levels + 1);
 				} else {
 					launch_fast(0);
 				}
@@ -4073,6 +4153,9 @@ private:
 	uint32_t multi_min_ = 256;
 	uint32_t fast_rows_ = 8;
 	bool seq_enabled_ = true, two_pass_enabled_ = true, chain_enabled_ = true, chain_inline_ = false;
+	uint32_t chain_chunks_ = 8;
+	hipStream_t chain_stream_ = nullptr;
+	std::vector<hipEvent_t> chain_ev_;
 	DevBuf<float> chain_rows_;
 	DevBuf<ChainDesc> chain_desc_;
 	DevBuf<unsigned char> fplines_;
