@@ -434,7 +434,7 @@ def main():
     ap.add_argument("--voices5", type=int, default=4096, help="config5: voices")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
-    defaults = {"config3": (20, 3), "config4": (5, 1), "config5": (5, 1)}[args.workload]
+    defaults = {"config3": (100, 3), "config4": (5, 1), "config5": (5, 1)}[args.workload]
     if args.steps is None:
         args.steps = defaults[0]
     if args.warmup is None:

@@ -140,7 +140,7 @@ bool compile_voice_plan(const std::vector<OpMirror> &ops, uint32_t carrier,
 
 /* Segments with feedback voices are at most this long: the recurrences' inputs and outputs pass
  * through per-chain rows in HBM, sized for one segment. */
-constexpr uint32_t CHAIN_SEG = 65536;
+constexpr uint32_t CHAIN_SEG = 131072;
 
 class Engine {
 public:
