@@ -26,6 +26,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <string>
@@ -4135,7 +4136,7 @@ private:
 	std::vector<VoiceDesc> voices_sent_;   /* what the device copies hold */
 	std::vector<MixStream> ms_sent_, ms_host_;
 	const void *voices_dev_ = nullptr, *ms_dev_ = nullptr;
-	std::vector<TimedPair> events_;
+	std::deque<TimedPair> events_; /* (a deque: pairs handed out stay where they are while more are added) */
 	size_t n_used_ = 0;
 	bool timing_on_ = false;
 	double acc_ms_[4] = {0, 0, 0, 0};

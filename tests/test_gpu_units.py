@@ -676,3 +676,22 @@ def test_deep_nesting(sa, oracle):
         return op
     for depth in (33, 65, 120):
         check(sa, oracle, [chain(depth)], chunk=1500)
+
+
+@pytest.mark.parametrize("chunks", ["1", "2", "16"])
+def test_feedback_chains_at_other_pipeline_depths(sa, oracle, chunks, monkeypatch):
+    """chain_kernel beside the time-parallel passes: segments with feedback voices cut into
+    1, 2 or 16 chunks instead of the default 8, and chains fed from their own lines by the feeder wave --
+    bit-exact vs the oracle, frequency / amount / amplitude ramps and a feedback modulator included."""
+    monkeypatch.setenv("SAU_AMD_CHAIN_CHUNKS", chunks)
+    if chunks == "2":
+        monkeypatch.setenv("SAU_AMD_CHAIN_INLINE", "1")
+    oracle.oracle().ora_set_fastmath_forms(1)
+    prg = vb.config5(n=96, seconds=2)
+    want = oracle.oracle_render(prg.ptr, RATE, False)
+    got = sa.Batch([prg], RATE).render(stereo=False, chunk=88200)[0]
+    assert len(got) == len(want) and (got == want).all()
+    inner = vb.Op("tri", freq=vb.Line(2.0, ratio=True), amp=0.4, pm_a=vb.Line(0.2, goal=0.6, shape="cos"))
+    voices = [vb.Op("sin", freq=vb.Line(150.0 + 7 * k, goal=300.0, shape="exp"), time_ms=900 + 10 * k, pm_a=0.3 + 0.05 * k,
+                    mods={POP_PMOD: [inner]} if k == 3 else {}) for k in range(6)]
+    check(sa, oracle, voices, chunk=50000)
