@@ -283,7 +283,7 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 	uint32_t n_main = 1, n_fpool = 0, max_ops = 1, n_pan = 0, max_steps = 1, n_fast = 1, n_fast_full = 0;
 	uint64_t wave_mask = 0;
 	bool maybe_block = false, serial = false, may_scan = false;
-	uint32_t sum_levels = 0, n_chain_rows = 0;
+	uint32_t sum_levels = 0, n_chain_rows = 0, n_inc_rows = 0;
 	for (size_t s = 0; s < streams_.size(); ++s) {
 		Stream &st = streams_[s];
 		SegmentDesc::Stream &sd = sdescs[s];
@@ -328,6 +328,7 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 			d.lat = lat;
 			d.chain_base = n_chain_rows; d.n_chain = vn.plan.n_chain;
 			n_chain_rows += vn.plan.n_chain;
+			d.inc_base = 0; d.n_inc = 0; /* (set below for voices that may have running-sum phases) */
 			if (dyn) line_begin(carr.pan, out_len, false, 0.f, lat, 0);
 			else line_skip(carr.pan, out_len, lat, 0);
 			descs.push_back(d);
@@ -356,6 +357,8 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 			if (voice_block && !vn.plan.no_fast) {
 				n_fast_full = std::max(n_fast_full, vn.plan.n_fast_full);
 				may_scan = true;
+				descs.back().inc_base = n_inc_rows; descs.back().n_inc = vn.plan.n_osc;
+				n_inc_rows += vn.plan.n_osc;
 				if (sum_levels < 3) (void)estimate_sum_levels(st, vn.carr_op, 0, false, sum_levels, 0);
 			}
 		}
@@ -379,6 +382,7 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 	seg.may_scan = may_scan;
 	seg.sum_levels = sum_levels;
 	seg.n_chain_rows = n_chain_rows;
+	seg.n_inc_rows = n_inc_rows;
 	return backend_->render(seg, err);
 }
 
@@ -459,6 +463,11 @@ bool Engine::run(int16_t *const *host_bufs, size_t buf_len, bool stereo,
 					const VoiceHost &vn = st.voices[v];
 					if (vn.duration == 0 || vn.carr_op >= st.ops.size()) continue;
 					if (vn.plan.n_chain) chains = true;
+					if (vn.plan.n_osc && !vn.plan.no_fast) { /* may it have running-sum phases? (as render_segment decides) */
+						bool vb = vn.plan.static_block;
+						for (uint32_t id : vn.plan.op_ids) if (st.ops[id].goal_seen || (st.ops[id].line_set & (1u << L_PMA))) vb = true;
+						if (vb) chains = true; /* saved increments live in rows of one segment too */
+					}
 					for (uint32_t id : vn.plan.op_ids) {
 						const OpMirror &m = st.ops[id];
 						if (id != vn.carr_op && !m.time_inf && m.time > 0 && m.time < first) first = m.time;

@@ -54,6 +54,7 @@ struct SegmentDesc {
 	bool maybe_block;         /* some voice may need the block loop (sweeps, FM, ...) */
 	bool serial;              /* some voice may run a per-sample feedback recurrence (self-modulation) */
 	uint32_t n_chain_rows = 0;/* row pairs the voices' chain_base/n_chain span */
+	uint32_t n_inc_rows = 0;  /* row pairs the voices' inc_base/n_inc span (voices that may have running-sum phases) */
 };
 
 struct BackendConfig {
@@ -129,6 +130,7 @@ struct VoicePlan {
 	bool static_block = false;     /* graph has FM / feedback / R / filtered noise: block loop */
 	bool selfmod = false;          /* a self-modulation amount has modulators of its own */
 	uint32_t n_chain = 0;          /* oscillator steps that may run a feedback recurrence (step_may_chain) */
+	uint32_t n_osc = 0;            /* W and R oscillator steps (their phase increments may be saved between passes) */
 };
 
 /* Flatten the graph under `carrier` into steps. Returns false (with err) when

@@ -1108,7 +1108,8 @@ struct FastInfo {
 	uint32_t total; /* frames this path renders (0: not eligible) */
 	uint32_t H;     /* lead-in samples per chunk */
 	uint32_t bail;  /* set when a chunk met dphase == 0 (hold-previous run) */
-	uint32_t n_fsteps; /* decoded steps of the voice (decode_kernel) */
+	uint32_t n_fsteps; /* decoded steps of the voice (decode_kernel): step list 0, the only or final pass */
+	uint32_t n_pass[4]; /* ... of step lists 1..3 (sum passes) and 4 (chain-input pass) */
 	uint32_t seq;   /* some oscillator's frequency varies (ramp, FM): phases are running sums. 1: one wave walks the
 	                 * voice in order, carrying them; 2: two passes, every wave (no sum depends on another) */
 	uint32_t n_scan; /* oscillators with running-sum phases (multi-pass voices) */
@@ -1137,6 +1138,12 @@ constexpr uint32_t FAST_REPAIR_SHIFT = 24; /* H + shift < 64 (H <= 32) */
 constexpr uint32_t FAST_MAX_REPAIR = 15;   /* noted row groups per voice and segment; more: block loop */
 constexpr uint32_t FAST_REPAIR_WORDS = 2 + 2 * FAST_MAX_REPAIR; /* count, pad, then (group, rows) pairs */
 constexpr uint32_t FAST_FLAGS = FAST_MAX_LEVELS + 2; /* pass_flags words */
+/* Decoded steps are kept once per pass that runs them ([list][voice][step]): a pass walks its own list and never
+ * loads a step only to find that another pass needs it (the per-step cost of the interpreter is most of a pass). */
+constexpr uint32_t FAST_LISTS = 5; /* 0: only / final pass, 1..3: sum passes, 4: chain-input pass */
+__device__ __forceinline__ uint32_t fast_list_of(uint32_t mode, uint32_t sum_levels) {
+	return (mode == 0 || mode == sum_levels + 1) ? 0u : (mode == sum_levels + 2 ? 4u : mode);
+}
 constexpr uint32_t FR_CHAIN_IN = 4u << FAST_MAX_LEVELS; /* FastStep.ramp: the chain-input pass runs this step */
 constexpr uint32_t FR_FINAL_SKIP = 8u << FAST_MAX_LEVELS; /* ... the final pass does not: only chains' inputs needed it */
 constexpr uint32_t FT_CHAIN = 1u << 18;     /* FastStep.type: a feedback chain (rows = bits of FastStep.pan) */
@@ -1189,6 +1196,12 @@ struct FastParams {
 	 * fast_kernel: range_mode 1 = the row groups that start in [f_lo, f_hi), 2 = those that end in (f_lo, f_hi]
 	 * (0: all). chain_kernel: frames [f_lo, f_hi) of every chain, continuing from the staged state when f_lo > 0. */
 	uint32_t range_mode, f_lo, f_hi, range_last;
+	/* Saved phase increments: a running-sum oscillator's per-frame increments, computed in the sum pass of its
+	 * level, go to a row pair in HBM (W: 32 bits in the first row; R: low and high words), and the final pass
+	 * reads them back instead of evaluating the frequency again -- whatever only produced that frequency (FM
+	 * modulators, their sub-trees) is then left out of the final pass. */
+	uint32_t *inc_rows;   /* [n_inc_rows][2][inc_stride], or NULL */
+	uint32_t inc_stride, n_inc_rows;
 	int8_t ctab_of_wave[12];
 	uint8_t cwave_of_tab[12];
 	int8_t tab_of_wave[12];
@@ -1587,7 +1600,7 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 	 * closed-form voices have repair_kernel for that case (see FAST_REPAIR_SHIFT). */
 	if (seq || has_chain) ++x_carrier;
 	fi.n_chain = has_chain && !bad ? 1u : 0u;
-	fi.H = maxd + x_carrier; fi.xlead = x_carrier; fi.bail = 0; fi.n_fsteps = 0; fi.seq = seq_kind; fi.n_scan = n_scan_out; fi.levels = levels_out; fi.lvl_bits = lvl_bits_out;
+	fi.H = maxd + x_carrier; fi.xlead = x_carrier; fi.bail = 0; fi.n_fsteps = 0; fi.n_pass[0] = fi.n_pass[1] = fi.n_pass[2] = fi.n_pass[3] = 0; fi.seq = seq_kind; fi.n_scan = n_scan_out; fi.levels = levels_out; fi.lvl_bits = lvl_bits_out;
 	fi.total = 0;
 	if ((seq || has_chain) && !P.seq_enable) bad = true;
 	if (!bad && vd.nops <= P.max_ops && vd.plan_len <= P.max_steps && maxd >= 1 && maxd + x_carrier <= P.np / 2)
@@ -1733,7 +1746,6 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 	if (P.info[v].total == 0) return;
 	const VoiceDesc vd = P.voices[v];
 	const uint32_t *ids = P.op_ids + vd.ops_ofs;
-	FastStep *fsteps = P.fsteps + (size_t)v * P.max_steps;
 	/* lane si handles step si (plan_len <= 64) */
 	bool keep = false;
 	FastStep f;
@@ -1933,6 +1945,7 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 				for (uint32_t p = 0; p < FAST_MAX_LEVELS; ++p) { want[p] = 0; mine[p] = false; }
 				unsigned long long want_c = 0; /* the chain-input pass: what the chains' inputs need */
 				bool mine_c = false;
+				bool ran_full = false; /* some sum pass evaluates this step in full (and stages its end-of-segment state) */
 				unsigned long long want_f = 0; /* the final pass: what the voice's output needs, chains read from their rows */
 				bool mine_f = false;
 				uint32_t xi = 0;
@@ -1971,9 +1984,12 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 							needed_f = true;
 							if (!rmw) want_f &= ~bit(cq.out);
 						}
+						/* a running-sum oscillator whose increments are saved (same rule as where the rows are assigned) */
+						const bool q_saved = q_fvar && seq == 2 && P.inc_rows && vd.n_inc && sq.fpm == NO_SLOT && !q_chain;
 						if (needed_f) {
 							if (sq.kind == ST_VOICE) want_f |= bit(cq.out) | bit(cq.pm);
 							else if (q_chain) want_f |= bit(cq.amp);
+							else if (q_saved) want_f |= bit(cq.pm) | bit(cq.amp) | bit(cq.aux) | bit(cq.sm);
 							else want_f |= bit(cq.pm) | bit(cq.fpm) | bit(cq.amp) | bit(cq.aux) | bit(cq.freq) | bit(cq.fmul) | bit(cq.sm);
 						}
 						if (q == (uint32_t)l) mine_f = needed_f;
@@ -1991,13 +2007,18 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 								want[p] |= bit(cq.pm) | bit(cq.fpm) | bit(cq.amp) | bit(cq.aux) | bit(cq.freq) | bit(cq.fmul);
 							}
 						}
-						if (q == (uint32_t)l) mine[p] = needed;
+						if (q == (uint32_t)l) {
+							mine[p] = needed;
+							if (needed && !(q_fvar && q_level == p + 1) && p < P.sum_levels) ran_full = true;
+						}
 					}
 				}
 				for (uint32_t p = 0; p < FAST_MAX_LEVELS; ++p) if (mine[p]) f.ramp |= 4u << p;
 				if (mine_c) f.ramp |= FR_CHAIN_IN;
 				/* what only chains' inputs needed has run (and staged its state) in the chain-input pass */
-				if (P.info[v].n_chain && !mine_f && (mine_c || st.kind == ST_LINE || st.kind == ST_SMLINE || st.kind == ST_LERP))
+				/* ... and so has what only running sums needed, in their sum passes, when the final pass reads the saved
+				 * increments; lines and range blends carry no state of their own */
+				if (!mine_f && (mine_c || ran_full || st.kind == ST_LINE || st.kind == ST_SMLINE || st.kind == ST_LERP))
 					f.ramp |= FR_FINAL_SKIP;
 				fa.pad[1] = (o.type == OT_WAVE || o.type == OT_RASEG) && !o.rt_fconst_valid && !step_is_chain_acc(st, o) ? o.rt_fblk_valid : 0u;
 				fa.pad[0] = xi;
@@ -2020,18 +2041,38 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 				}
 				f.ramp |= 2;
 				if (step_is_chain_acc(st, o)) fa.pad[2] = 1; /* increments to the chain's row, no sums */
+				else if (seq == 2 && P.inc_rows && vd.n_inc && st.fpm == NO_SLOT && !is_chain) {
+					/* its increments are saved by the sum pass of its level and read back by the final pass
+					 * (not with frequency-scaled PM: that needs the frequency itself) */
+					uint32_t k = 0;
+					for (uint32_t q = 0; q < (uint32_t)l; ++q) {
+						const Step sq = plan[q];
+						const uint32_t tq = P.ops[ids[sq.op]].type;
+						if (sq.kind == ST_OSC && (tq == OT_WAVE || tq == OT_RASEG)) ++k;
+					}
+					if (k < vd.n_inc) fa.pad[2] = 2u | ((vd.inc_base + k) << 8);
+				}
 			}
 		}
 	}
-	const unsigned long long m = __ballot(keep);
-	if (keep) {
-		const uint32_t pos = (uint32_t)__popcll(m & ((1ull << l) - 1ull));
-		fsteps[pos] = f;
-		if (f.ramp & 1) P.flines[(size_t)v * P.max_steps + pos] = fl;
-		if (f.ramp & 2) P.faux[(size_t)v * P.max_steps + pos] = fa;
-		if (chain_line) P.fplines[(size_t)v * P.max_steps + pos] = pl;
+	/* step lists: one per pass that runs the step (a multi-pass voice), else just list 0 */
+#pragma unroll
+	for (uint32_t li = 0; li < FAST_LISTS; ++li) {
+		bool in;
+		if (li == 0) in = keep && !(f.ramp & FR_FINAL_SKIP);
+		else if (li == 4) in = keep && seq == 2 && (f.ramp & FR_CHAIN_IN);
+		else in = keep && seq == 2 && (f.ramp & (2u << li));
+		const unsigned long long m = __ballot(in);
+		if (in) {
+			const uint32_t pos = (uint32_t)__popcll(m & ((1ull << l) - 1ull));
+			const size_t at = ((size_t)li * P.n_voices + v) * P.max_steps + pos;
+			P.fsteps[at] = f;
+			if (f.ramp & 1) P.flines[at] = fl;
+			if (f.ramp & 2) P.faux[at] = fa;
+			if (chain_line && P.fplines) P.fplines[at] = pl;
+		}
+		if (l == 0) { if (li == 0) P.info[v].n_fsteps = (uint32_t)__popcll(m); else P.info[v].n_pass[li - 1] = (uint32_t)__popcll(m); }
 	}
-	if (l == 0) P.info[v].n_fsteps = (uint32_t)__popcll(m);
 	/* chains the chain-input pass has to feed (the others are fed by chain_kernel's own feeder wave) */
 	const unsigned long long mc = __ballot(is_chain && keep && !chain_inline);
 	if (l == 0) P.info[v].n_chain = (uint32_t)__popcll(mc);
@@ -2074,10 +2115,14 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 	const VoiceDesc vd = P.voices[v];
 	const uint32_t H = uni(fi.H);
 
-	const uint32_t n_fsteps = uni(fi.n_fsteps);
-	const FastStep *fsteps = P.fsteps + (size_t)v * P.max_steps;
-	const FastLine *flines = P.flines + (size_t)v * P.max_steps;
-	const FastAux *faux = P.faux + (size_t)v * P.max_steps;
+	/* this pass's own list of the voice's decoded steps */
+	const uint32_t li = SCAN ? fast_list_of(P.mode, P.sum_levels) : 0u;
+	const uint32_t n_fsteps = uni(li == 0 ? fi.n_fsteps : li == 1 ? fi.n_pass[0] : li == 2 ? fi.n_pass[1] : li == 3 ? fi.n_pass[2] : fi.n_pass[3]);
+	const size_t list_at = ((size_t)li * P.n_voices + v) * P.max_steps;
+	const FastStep *fsteps = P.fsteps + list_at;
+	const FastLine *flines = P.flines + list_at;
+	const FastAux *faux = P.faux + list_at;
+	const FastLine *fplines = P.fplines ? P.fplines + list_at : nullptr;
 	/* sequential-scan voices: the one wave with cstart == 0 walks every row group in order */
 	const uint32_t seq_kind = SCAN ? uni(fi.seq) : 0u;
 	const bool seq = SCAN && seq_kind == 1;    /* one wave, in order */
@@ -2223,9 +2268,19 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 							fvar = (fa.flags & (FA_FVAR_SLOT | FA_FVAR_LINE)) != 0;
 							if (fvar) {
 								uint32_t S[T];
+								/* saved increments (FastParams.inc_rows): written by the sum pass of this oscillator's
+								 * level, read back by the final pass in place of the frequency */
+								uint32_t *irow = (fa.pad[2] & 2u) ? P.inc_rows + (size_t)2 * (fa.pad[2] >> 8) * P.inc_stride : nullptr;
+								const bool inc_read = irow && P.mode == P.sum_levels + 1;
+								const bool inc_write = irow && two && P.mode == fa.pad[1];
 #pragma unroll
 								for (int k = 0; k < T; ++k) {
 									const int t = t0 + k * (int)C;
+									uint32_t r;
+									if (inc_read) {
+										r = (t >= 0 && t < (int)fast_total) ? irow[t] : 0u;
+										fv[k] = 0.f; /* (only frequency-scaled PM reads it, and such oscillators save nothing) */
+									} else {
 									float v;
 									if (fa.flags & FA_FVAR_SLOT) {
 										v = slots[fa.freq_off + k * 64];
@@ -2239,7 +2294,9 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 									const float x = fa.coeff * v;
 									/* llrintf(x) mod 2^32 (wosc.h:145): adding 1.5 * 2^52 in f64 rounds to the nearest
 									 * integer and leaves it in the low word; exact while |x| < 2^51 */
-									const uint32_t r = fabsf(x) < 0x1p50f ? (uint32_t)__double2loint((double)x + 0x1.8p52) : rint32w(x);
+									r = fabsf(x) < 0x1p50f ? (uint32_t)__double2loint((double)x + 0x1.8p52) : rint32w(x);
+									if (inc_write && l >= (int)H && t >= 0 && t < (int)fast_total) irow[t] = r;
+									}
 									const uint32_t inc = (t >= 0 && t < (int)fast_total) ? r : 0u;
 									if (chain && fa.pad[2]) S[k] = inc; /* chain_kernel does the summing */
 									else S[k] = wave_incl_scan_dpp(inc);
@@ -2250,7 +2307,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 									float *arow = brow + P.chain_stride;
 									FastLine pl;
 									const bool from_line = f.aux_off == ~0u;
-									if (from_line) pl = load_line_uniform(P.fplines + (size_t)v * P.max_steps + si);
+									if (from_line) pl = load_line_uniform(fplines + si);
 #pragma unroll
 									for (int k = 0; k < T; ++k) {
 										const int t = t0 + k * (int)C;
@@ -2339,7 +2396,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 							float *arow = brow + P.chain_stride;
 							FastLine pl;
 							const bool from_line = f.aux_off == ~0u;
-							if (from_line) pl = load_line_uniform(P.fplines + (size_t)v * P.max_steps + si);
+							if (from_line) pl = load_line_uniform(fplines + si);
 #pragma unroll
 							for (int k = 0; k < T; ++k) {
 								const int t = t0 + k * (int)C;
@@ -2465,9 +2522,17 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 						if (fvar) {
 							const float rcoeff = rate2x ? fa.coeff * 2 : fa.coeff;
 							unsigned long long S[T], incv[T];
+							uint32_t *irow = (fa.pad[2] & 2u) ? P.inc_rows + (size_t)2 * (fa.pad[2] >> 8) * P.inc_stride : nullptr;
+							const bool inc_read = irow && P.mode == P.sum_levels + 1;
+							const bool inc_write = irow && two && P.mode == fa.pad[1];
 #pragma unroll
 							for (int k = 0; k < T; ++k) {
 								const int t = t0 + k * (int)C;
+								const bool in_seg = t >= 0 && t < (int)fast_total;
+								if (inc_read) { /* saved by the sum pass of its level: low and high words */
+									incv[k] = in_seg ? ((unsigned long long)irow[P.inc_stride + t] << 32) | irow[t] : 0ull;
+									fv[k] = 0.f;
+								} else {
 								float v;
 								if (fa.flags & FA_FVAR_SLOT) {
 									v = slots[fa.freq_off + k * 64];
@@ -2478,7 +2543,9 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 										v *= fa.fmul_off != ~0u ? slots[fa.fmul_off + k * 64] : fa.mulc;
 								}
 								fv[k] = v;
-								incv[k] = (t >= 0 && t < (int)fast_total) ? (unsigned long long)rint64(rcoeff * v) : 0ull;
+								incv[k] = in_seg ? (unsigned long long)rint64(rcoeff * v) : 0ull;
+								if (inc_write && l >= (int)H && in_seg) { irow[t] = (uint32_t)incv[k]; irow[P.inc_stride + t] = (uint32_t)(incv[k] >> 32); }
+								}
 								S[k] = wave_incl_scan64_dpp(incv[k]);
 							}
 							unsigned long long *sums = two ? scan + (size_t)fa.pad[0] * P.scan_groups : nullptr;
@@ -3479,6 +3546,7 @@ public:
 		seq_enabled_ = getenv("SAU_AMD_NO_SEQ") == nullptr; /* running-sum phases in the time-parallel kernel */
 		chain_enabled_ = getenv("SAU_AMD_NO_CHAIN") == nullptr; /* feedback recurrences with lanes = voices */
 		chain_inline_ = getenv("SAU_AMD_CHAIN_INLINE") != nullptr;
+		inc_rows_enabled_ = getenv("SAU_AMD_NO_INC_ROWS") == nullptr;
 		if (const char *cc = getenv("SAU_AMD_CHAIN_CHUNKS")) { /* pipeline depth of a segment with chains (1: off) */
 			const int n = atoi(cc);
 			chain_chunks_ = n >= 16 ? 16 : n >= 8 ? 8 : n >= 4 ? 4 : n >= 2 ? 2 : 1;
@@ -3700,9 +3768,9 @@ public:
 			const bool use_fast = fast_enabled_ && (16 * area + 1024 <= lds_limit_);
 			if (!finfo_.ensure(seg.n_voices, err) || !fdone_.ensure(seg.n_voices, err) ||
 			    !worklist_.ensure(seg.n_voices, err) || !work_count_.ensure(4, err) ||
-			    !fsteps_.ensure((size_t)seg.n_voices * fmax_steps * sizeof(FastStep), err) ||
-			    !flines_.ensure((size_t)seg.n_voices * fmax_steps * sizeof(FastLine), err) ||
-			    !faux_.ensure((size_t)seg.n_voices * fmax_steps * sizeof(FastAux), err)) return false;
+			    !fsteps_.ensure((size_t)FAST_LISTS * seg.n_voices * fmax_steps * sizeof(FastStep), err) ||
+			    !flines_.ensure((size_t)FAST_LISTS * seg.n_voices * fmax_steps * sizeof(FastLine), err) ||
+			    !faux_.ensure((size_t)FAST_LISTS * seg.n_voices * fmax_steps * sizeof(FastAux), err)) return false;
 			FastParams fp;
 			memset(&fp, 0, sizeof fp);
 			fp.voices = voices_.p; fp.steps = steps_.p; fp.fast_ids = fast_ids_.p; fp.op_ids = op_ids_.p; fp.ops = ops_.p;
@@ -3729,6 +3797,12 @@ public:
 			fp.repair_on = getenv("SAU_AMD_NO_REPAIR") ? 0u : 1u;
 			fp.max_ops = seg.max_ops; fp.max_steps = fmax_steps; fp.np = 64; fp.rows = FT;
 			fp.enable = use_fast ? 1u : 0u;
+			/* saved phase increments of running-sum oscillators (sum pass -> final pass), one segment long */
+			if (inc_rows_enabled_ && use_fast && fp.scan && seg.n_inc_rows && seg.len <= sauengine::CHAIN_SEG) {
+				const uint32_t istride = (seg.len + 63) & ~63u;
+				if (!inc_rows_.ensure((size_t)seg.n_inc_rows * 2 * istride + 64, err)) return false;
+				fp.inc_rows = inc_rows_.p; fp.inc_stride = istride; fp.n_inc_rows = seg.n_inc_rows;
+			}
 			/* feedback chains: a pair of rows per chain in HBM, one segment long (the engine keeps segments
 			 * with such voices within CHAIN_SEG frames); without them those voices take the block loop */
 			const bool chains = chain_enabled_ && use_fast && fp.scan && seg.serial && seg.n_chain_rows &&
@@ -3737,7 +3811,7 @@ public:
 				const uint32_t cstride = (seg.len + 63) & ~63u;
 				if (!chain_rows_.ensure((size_t)seg.n_chain_rows * 2 * cstride + 64, err) ||
 				    !chain_desc_.ensure(seg.n_chain_rows, err) ||
-				    !fplines_.ensure((size_t)seg.n_voices * fmax_steps * sizeof(FastLine), err)) return false;
+				    !fplines_.ensure((size_t)FAST_LISTS * seg.n_voices * fmax_steps * sizeof(FastLine), err)) return false;
 				fp.chain_rows = chain_rows_.p; fp.chain_stride = cstride; fp.n_chain_rows = seg.n_chain_rows;
 				fp.chain_desc = chain_desc_.p; fp.fplines = (FastLine *)fplines_.p;
 				fp.chain_inline = chain_inline_ ? 1u : 0u;
@@ -4155,6 +4229,8 @@ private:
 	uint32_t fast_rows_ = 8;
 	bool seq_enabled_ = true, two_pass_enabled_ = true, chain_enabled_ = true, chain_inline_ = false;
 	uint32_t chain_chunks_ = 8;
+	bool inc_rows_enabled_ = true;
+	DevBuf<uint32_t> inc_rows_;
 	hipStream_t chain_stream_ = nullptr;
 	std::vector<hipEvent_t> chain_ev_;
 	DevBuf<float> chain_rows_;

@@ -248,8 +248,13 @@ bool compile_voice_plan(const std::vector<OpMirror> &ops, uint32_t carrier,
 		if (m.type == SAU_POPT_N_noise && m.wave == SAU_NOISE_N_re) out.static_block = true;
 	}
 	out.n_chain = 0;
+	out.n_osc = 0;
 	for (const Step &st : out.steps) {
 		if (step_may_chain(st)) ++out.n_chain;
+		if (st.kind == ST_OSC && st.op < out.op_ids.size()) {
+			const uint8_t ty = ops[out.op_ids[st.op]].type;
+			if (ty == SAU_POPT_N_wave || ty == SAU_POPT_N_raseg) ++out.n_osc;
+		}
 		if (st.kind == ST_SMLINE) { out.static_block = true; out.selfmod = true; }
 		if (st.kind == ST_LINE && st.which == L_FREQ && (st.flags & SF_FORCE)) out.static_block = true;
 	}

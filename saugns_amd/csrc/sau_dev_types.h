@@ -237,6 +237,7 @@ struct VoiceDesc {
 	uint32_t flags;              /* VD_* */
 	Lattice lat;                 /* where the reference's blocks lie in this segment, for the voice's program */
 	uint32_t chain_base, n_chain;/* row pairs for its self-modulated oscillators (step_may_chain steps, in plan order) */
+	uint32_t inc_base, n_inc;    /* row pairs for saved phase increments of its oscillator steps (in plan order), or n_inc = 0 */
 };
 
 enum : uint32_t {
