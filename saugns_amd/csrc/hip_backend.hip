@@ -104,6 +104,13 @@ __device__ __forceinline__ unsigned long long wave_incl_scan64(unsigned long lon
  * moving them to scalar registers lets the compiler use scalar branches and
  * scalar arithmetic for all the per-step bookkeeping. */
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+#ifdef FK_PROF
+/* diagnostic build (saugns_amd/build.py --variant prof FK_PROF): wave-time per section of fast_voice's running-sum build */
+__device__ unsigned int g_fk_prof[16]; /* units of 64 clocks */
+#define FKP_MARK(i) do { const uint32_t fkp_now_ = uni((uint32_t)__builtin_amdgcn_s_memtime()); if (l == 0) fkp_[i] += fkp_now_ - fkp_t_; fkp_t_ = fkp_now_; } while (0)
+#else
+#define FKP_MARK(i) do {} while (0)
+#endif
 __device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float uni(float v) { return bits_f(uni(f_bits(v))); }
 __device__ __forceinline__ bool uni(bool v) { return uni((uint32_t)v) != 0; }
@@ -156,6 +163,82 @@ __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, i
 	const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane);
 	const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
 	return ((unsigned long long)hi << 32) | lo;
+}
+
+/* Decoupled look-back over a voice's row groups (FastParams.look). The calling wave owns group cg and its
+ * group total `tot`; returns the sum of all earlier groups' totals. Words carry value and status together,
+ * so one relaxed device-scope store publishes and one load observes -- no fences. A wave only ever waits
+ * for groups before its own: those belong to waves of this launch that are resident (the grid is at most
+ * one workgroup per CU) or to an earlier launch of the same segment. */
+constexpr uint32_t LOOK_AGG = 1, LOOK_PREFIX = 2;
+__device__ __forceinline__ unsigned long long look_word(uint32_t epoch, uint32_t status, uint32_t value) {
+	return ((unsigned long long)((epoch << 2) | status) << 32) | value;
+}
+__device__ __forceinline__ uint32_t lookback32(unsigned long long *ent, const uint32_t cg, const uint32_t tot,
+		const uint32_t epoch, const int l) {
+	if (cg == 0) {
+		if (l == 0) __hip_atomic_store(&ent[0], look_word(epoch, LOOK_PREFIX, tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		return 0;
+	}
+	if (l == 0) __hip_atomic_store(&ent[cg], look_word(epoch, LOOK_AGG, tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	uint32_t excl = 0;
+	int p = (int)cg - 1; /* the nearest group not yet accounted for */
+	for (;;) {
+		const int idx = p - l; /* lane l looks at the group l before it; before group 0 the prefix is 0 */
+		unsigned long long e = look_word(epoch, LOOK_PREFIX, 0);
+		if (idx >= 0) e = __hip_atomic_load(&ent[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const uint32_t hi = (uint32_t)(e >> 32);
+		const uint32_t st = (hi >> 2) == epoch ? (hi & 3u) : 0u;
+		const unsigned long long m_pref = __ballot(st == LOOK_PREFIX), m_none = __ballot(st == 0);
+		const int first_pref = m_pref ? __builtin_ctzll(m_pref) : 64;
+		const int first_none = m_none ? __builtin_ctzll(m_none) : 64;
+		const int upto = first_pref < first_none ? first_pref + 1 : first_none; /* lanes [0, upto) count */
+		uint32_t part = wave_incl_scan_dpp(l < upto ? (uint32_t)e : 0u);
+		excl += (uint32_t)__builtin_amdgcn_readlane((int)part, 63);
+		if (first_pref < first_none) break;
+		p -= upto;
+		if (upto == 0) __builtin_amdgcn_s_sleep(2);
+	}
+	if (l == 0) __hip_atomic_store(&ent[cg], look_word(epoch, LOOK_PREFIX, excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	return excl;
+}
+/* 64-bit totals (R oscillators' cycle counters): low and high halves in two arrays, a pair counts once both
+ * words show the same status */
+__device__ __forceinline__ unsigned long long lookback64(unsigned long long *ent_lo, unsigned long long *ent_hi,
+		const uint32_t cg, const unsigned long long tot, const uint32_t epoch, const int l) {
+	auto publish = [&](uint32_t at, uint32_t status, unsigned long long v) {
+		__hip_atomic_store(&ent_lo[at], look_word(epoch, status, (uint32_t)v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		__hip_atomic_store(&ent_hi[at], look_word(epoch, status, (uint32_t)(v >> 32)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	};
+	if (cg == 0) {
+		if (l == 0) publish(0, LOOK_PREFIX, tot);
+		return 0;
+	}
+	if (l == 0) publish(cg, LOOK_AGG, tot);
+	unsigned long long excl = 0;
+	int p = (int)cg - 1;
+	for (;;) {
+		const int idx = p - l;
+		unsigned long long a = look_word(epoch, LOOK_PREFIX, 0), b = a;
+		if (idx >= 0) {
+			a = __hip_atomic_load(&ent_lo[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			b = __hip_atomic_load(&ent_hi[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		const uint32_t ha = (uint32_t)(a >> 32), hb = (uint32_t)(b >> 32);
+		const uint32_t st = ((ha >> 2) == epoch && ha == hb) ? (ha & 3u) : 0u;
+		const unsigned long long m_pref = __ballot(st == LOOK_PREFIX), m_none = __ballot(st == 0);
+		const int first_pref = m_pref ? __builtin_ctzll(m_pref) : 64;
+		const int first_none = m_none ? __builtin_ctzll(m_none) : 64;
+		const int upto = first_pref < first_none ? first_pref + 1 : first_none;
+		const unsigned long long v = ((unsigned long long)(uint32_t)b << 32) | (uint32_t)a;
+		const unsigned long long part = wave_incl_scan64_dpp(l < upto ? v : 0ull);
+		excl += readlane64(part, 63);
+		if (first_pref < first_none) break;
+		p -= upto;
+		if (upto == 0) __builtin_amdgcn_s_sleep(2);
+	}
+	if (l == 0) publish(cg, LOOK_PREFIX, excl + tot);
+	return excl;
 }
 
 /* rint(p * 2^31) wrapped to 32 bits for |p| < 2^20: in f64, p + 1.5 * 2^21
@@ -1202,6 +1285,12 @@ struct FastParams {
 	 * modulators, their sub-trees) is then left out of the final pass. */
 	uint32_t *inc_rows;   /* [n_inc_rows][2][inc_stride], or NULL */
 	uint32_t inc_stride, n_inc_rows;
+	/* Single-pass running sums (seq kind 3): one word per oscillator and row group (R: two, low and high half),
+	 * {epoch:30, status:2, value:32}; a wave publishes its group's sum (status 1), adds up what its predecessors
+	 * have published back to the nearest finished prefix, and publishes its own prefix (status 2). The epoch
+	 * (one per segment) makes every older word read as empty, so nothing is cleared between segments. */
+	unsigned long long *look; /* [n_voices][FAST_MAX_SCAN][2][scan_groups], or NULL */
+	uint32_t look_epoch;
 	int8_t ctab_of_wave[12];
 	uint8_t cwave_of_tab[12];
 	int8_t tab_of_wave[12];
@@ -1580,7 +1669,9 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 				if (!(st.which & OX_VOICE)) set_level(st.out, lv, (st.flags & SF_LAYER) != 0);
 			}
 		}
-		if (multi && P.scan) {
+		if (P.look && !has_chain && n_scan <= FAST_MAX_SCAN) {
+			seq_kind = 3; /* one pass, any depth: prefixes by look-back */
+		} else if (multi && P.scan) {
 			seq_kind = 2;
 			for (uint32_t p = 0; p < levels_out && p < P.sum_levels; ++p) atomicOr(&P.pass_flags[p], 1u);
 		}
@@ -2023,6 +2114,17 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 				fa.pad[1] = (o.type == OT_WAVE || o.type == OT_RASEG) && !o.rt_fconst_valid && !step_is_chain_acc(st, o) ? o.rt_fblk_valid : 0u;
 				fa.pad[0] = xi;
 			}
+			if (seq == 3 && st.kind == ST_OSC && is_osc && !o.rt_fconst_valid) {
+				/* single-pass voice: which of its look-back arrays this oscillator has */
+				uint32_t xi = 0;
+				for (uint32_t q = 0; q < (uint32_t)l; ++q) {
+					const Step sq = plan[q];
+					const DevOp &oq = P.ops[ids[sq.op]];
+					if (oq.rt_frozen) continue;
+					if (sq.kind == ST_OSC && (oq.type == OT_WAVE || oq.type == OT_RASEG) && !oq.rt_fconst_valid) ++xi;
+				}
+				fa.pad[0] = xi; fa.pad[1] = 0;
+			}
 			if (st.kind == ST_OSC && is_osc && !o.rt_fconst_valid) {
 				/* frequency per frame: from its block, or from its own line when it has no block */
 				if (st.freq != NO_SLOT) {
@@ -2127,6 +2229,8 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 	const uint32_t seq_kind = SCAN ? uni(fi.seq) : 0u;
 	const bool seq = SCAN && seq_kind == 1;    /* one wave, in order */
 	const bool two = SCAN && seq_kind == 2;    /* two passes, every wave */
+	const bool look = SCAN && seq_kind == 3;   /* one pass, every wave, prefixes by look-back */
+	unsigned long long *lookv = look ? P.look + (size_t)v * FAST_MAX_SCAN * 2 * P.scan_groups : nullptr;
 	if (seq && cstart != 0) return;
 	const uint32_t gstride = seq ? 1u : wpv;
 	unsigned long long *scan = two ? P.scan + (size_t)v * FAST_MAX_SCAN * P.scan_groups : nullptr;
@@ -2158,6 +2262,11 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 			}
 		}
 	}
+#ifdef FK_PROF
+	uint32_t *fkp_ = (uint32_t *)carry; /* (unused by multi-pass voices) */
+	if (l == 0) for (int i = 0; i < 8; ++i) fkp_[i] = 0;
+	uint32_t fkp_t_ = uni((uint32_t)__builtin_amdgcn_s_memtime());
+#endif
 	for (uint32_t it = it_lo + cstart; it < n_iter; it += gstride) {
 		const uint32_t cg = REPAIR ? uni(rep[2 + 2 * it]) : it;
 		const uint32_t repair_rows = REPAIR ? uni(rep[3 + 2 * it]) : 0u;
@@ -2183,6 +2292,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 			const bool chain_in = SCAN && P.mode == P.sum_levels + 2; /* the pass that writes the chains' inputs */
 			if (chain_in && !(f.ramp & FR_CHAIN_IN)) continue;
 			if (SCAN && P.mode == P.sum_levels + 1 && (f.ramp & FR_FINAL_SKIP)) continue;
+			if (SCAN) FKP_MARK(0);
 			if (kind == ST_OSC) {
 				const uint32_t type = f.type & 0xff;
 				const bool wave_env = (flags & SF_WAVE_ENV) != 0;
@@ -2255,6 +2365,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 							}
 						}
 					}
+					if (SCAN) FKP_MARK(1);
 					if (!done) {
 						uint32_t ph[T];
 						double Is[T];
@@ -2323,8 +2434,17 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 								 * this wave (in-order voices), or the prefix of all earlier groups' sums */
 								unsigned long long *sums = two ? scan + (size_t)fa.pad[0] * P.scan_groups : nullptr;
 								const bool sum_me = two && P.mode == fa.pad[1]; /* this pass computes this oscillator's sums */
-								uint32_t acc = two ? (sum_me ? 0u : f.phase0 + (uint32_t)sums[cg])
-								                   : (first_group ? f.phase0 : (uint32_t)carry[si]);
+								uint32_t acc;
+								if (look) {
+									uint32_t tot = 0;
+#pragma unroll
+									for (int k = 0; k < T; ++k)
+										tot += (uint32_t)__builtin_amdgcn_readlane((int)S[k], 63) - (uint32_t)__builtin_amdgcn_readlane((int)S[k], (int)H - 1);
+									acc = f.phase0 + lookback32(lookv + (size_t)fa.pad[0] * 2 * P.scan_groups, cg, tot, P.look_epoch, l);
+								} else {
+									acc = two ? (sum_me ? 0u : f.phase0 + (uint32_t)sums[cg])
+									          : (first_group ? f.phase0 : (uint32_t)carry[si]);
+								}
 #pragma unroll
 								for (int k = 0; k < T; ++k) {
 									const uint32_t lead = (uint32_t)__builtin_amdgcn_readlane((int)S[k], (int)H - 1);
@@ -2335,13 +2455,15 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 								if (two) {
 									if (sum_me) { /* this pass ends here for this oscillator */
 										if (l == 0) sums[cg] = (unsigned long long)acc;
+										FKP_MARK(2);
 										continue;
 									}
-								} else if (l == 0) {
+								} else if (!look && l == 0) {
 									carry[si] = (unsigned long long)acc;
 								}
 							}
 						}
+						if (SCAN) FKP_MARK(2);
 						if (!fvar) {
 							/* phase0 + inc*(t+1): one multiply per lane, then adds */
 							uint32_t acc = f.phase0 + f.inc * (uint32_t)(t0 + 1);
@@ -2550,8 +2672,17 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 							}
 							unsigned long long *sums = two ? scan + (size_t)fa.pad[0] * P.scan_groups : nullptr;
 							const bool sum_me = two && P.mode == fa.pad[1];
-							unsigned long long acc = two ? (sum_me ? 0ull : cp0 + sums[cg])
-							                             : (first_group ? cp0 : carry[si]);
+							unsigned long long acc;
+							if (look) {
+								unsigned long long tot = 0;
+#pragma unroll
+								for (int k = 0; k < T; ++k) tot += readlane64(S[k], 63) - readlane64(S[k], (int)H - 1);
+								unsigned long long *e_lo = lookv + (size_t)fa.pad[0] * 2 * P.scan_groups;
+								acc = cp0 + lookback64(e_lo, e_lo + P.scan_groups, cg, tot, P.look_epoch, l);
+							} else {
+								acc = two ? (sum_me ? 0ull : cp0 + sums[cg])
+								          : (first_group ? cp0 : carry[si]);
+							}
 #pragma unroll
 							for (int k = 0; k < T; ++k) {
 								const unsigned long long lead = readlane64(S[k], (int)H - 1);
@@ -2564,7 +2695,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 									if (l == 0) sums[cg] = acc;
 									continue;
 								}
-							} else if (l == 0) {
+							} else if (!look && l == 0) {
 								carry[si] = acc;
 							}
 							if (is_last_group) { /* the counter after the segment's last frame */
@@ -2620,6 +2751,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 #pragma unroll
 					for (int k = 0; k < T; ++k) s[k] = f.fc;
 				}
+				if (SCAN) FKP_MARK(3);
 				/* amplitude and combine: generator.c:384-440 */
 				float r[T];
 				if (f.amp_off != ~0u) {
@@ -2655,6 +2787,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 #pragma unroll
 					for (int k = 0; k < T; ++k) slots[f.out_off + k * 64] = r[k];
 				}
+				if (SCAN) FKP_MARK(4);
 			} else if (kind == ST_LINE) {
 				/* held line: v0 (sau/line.c:435-442); ratio lines only exist for freq */
 				if (f.ramp) {
@@ -2700,6 +2833,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 				}
 			}
 		}
+		if (SCAN) FKP_MARK(5);
 		if (held_rows) {
 			/* to the repair pass -- unless this is it, the group touches an end of the segment
 			 * (carried state sits at fixed lanes there) or the voice has running sums */
@@ -2722,6 +2856,12 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 		}
 	}
 	if (__any(zero_acc) && l == 0) atomicOr(&P.info[v].bail, 1u);
+#ifdef FK_PROF
+	if (SCAN && l == 0) {
+		const uint32_t base = P.mode != 0 && P.mode <= P.sum_levels ? 0u : 8u;
+		for (int i = 0; i < 6; ++i) atomicAdd(&g_fk_prof[base + i], fkp_[i] >> 6);
+	}
+#endif
 
 }
 
@@ -3527,15 +3667,18 @@ public:
 		if (!stream_) HIP_OK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
 		static std::mutex prop_mu;
 		static size_t dev_lds[16]; /* per device: hipGetDeviceProperties costs a millisecond */
+		static int dev_cus[16];
 		{
 			std::lock_guard<std::mutex> lk(prop_mu);
 			if (!dev_lds[dev & 15]) {
 				hipDeviceProp_t prop;
 				HIP_OK(hipGetDeviceProperties(&prop, dev));
+				dev_cus[dev & 15] = prop.multiProcessorCount;
 				dev_lds[dev & 15] = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor
 				                                                          : prop.sharedMemPerBlock;
 			}
 			lds_limit_ = dev_lds[dev & 15];
+			n_cus_ = dev_cus[dev & 15];
 		}
 		if (lds_limit_ > 160 * 1024) lds_limit_ = 160 * 1024;
 		if (const char *ll = getenv("SAU_AMD_LDS_LIMIT")) lds_limit_ = (size_t)atol(ll);
@@ -3547,6 +3690,7 @@ public:
 		chain_enabled_ = getenv("SAU_AMD_NO_CHAIN") == nullptr; /* feedback recurrences with lanes = voices */
 		chain_inline_ = getenv("SAU_AMD_CHAIN_INLINE") != nullptr;
 		inc_rows_enabled_ = getenv("SAU_AMD_NO_INC_ROWS") == nullptr;
+		lookback_enabled_ = getenv("SAU_AMD_NO_LOOKBACK") == nullptr; /* single-pass running sums */
 		if (const char *cc = getenv("SAU_AMD_CHAIN_CHUNKS")) { /* pipeline depth of a segment with chains (1: off) */
 			const int n = atoi(cc);
 			chain_chunks_ = n >= 16 ? 16 : n >= 8 ? 8 : n >= 4 ? 4 : n >= 2 ? 2 : 1;
@@ -3785,6 +3929,16 @@ public:
 				fp.scan_groups = seg.len / (32 * FT) + 2;
 				if (!scan_.ensure((size_t)seg.n_voices * FAST_MAX_SCAN * fp.scan_groups, err)) return false;
 				fp.scan = scan_.p;
+				if (lookback_enabled_) {
+					/* look-back words: valid for this segment's epoch only, so a fresh block starts out zeroed */
+					const unsigned long long *before = look_.p;
+					if (!look_.ensure((size_t)seg.n_voices * FAST_MAX_SCAN * 2 * fp.scan_groups, err)) return false;
+					if (look_.p != before || look_epoch_ >= (1u << 30) - 1) {
+						HIP_OK(hipMemsetAsync(look_.p, 0, look_.cap * sizeof(unsigned long long), stream_));
+						look_epoch_ = 0;
+					}
+					fp.look = look_.p; fp.look_epoch = ++look_epoch_;
+				}
 			}
 			if (!pass_flags_.p) {
 				if (!pass_flags_.ensure(FAST_FLAGS, err)) return false;
@@ -3863,6 +4017,8 @@ public:
 				const unsigned long long want = (unsigned long long)seg.n_voices * (groups < 64 ? groups : 64);
 				uint32_t fgrid = (uint32_t)((want + 15) / 16 > FK_GRID ? FK_GRID : (want + 15) / 16);
 				if (fgrid > FK_GRID) fgrid = FK_GRID;
+				/* look-back waits on other workgroups of the launch: all of them must be resident */
+				if (fp.look && n_cus_ > 0 && fgrid > (uint32_t)n_cus_) fgrid = (uint32_t)n_cus_;
 				if (fgrid < 1) fgrid = 1;
 				TimedPair *tf = timing_on_ ? new_pair(2) : nullptr;
 				if (tf) (void)hipEventRecord(tf->a, stream_);
@@ -3881,7 +4037,8 @@ public:
 				};
 				if (fp.scan) {
 					/* some voice may have running-sum phases: sums per row group, their prefixes, final pass */
-					for (uint32_t pass = 1; pass <= fp.sum_levels; ++pass) {
+					/* (with look-back only voices with feedback chains still take sum passes) */
+					for (uint32_t pass = 1; pass <= fp.sum_levels && !(fp.look && !fp.chain_rows); ++pass) {
 						launch_fast(pass);
 						hipLaunchKernelGGL(scan_kernel, dim3(seg.n_voices), dim3(64), 0, stream_, fp);
 					}
@@ -4230,6 +4387,10 @@ private:
 	bool seq_enabled_ = true, two_pass_enabled_ = true, chain_enabled_ = true, chain_inline_ = false;
 	uint32_t chain_chunks_ = 8;
 	bool inc_rows_enabled_ = true;
+	bool lookback_enabled_ = true;
+	DevBuf<unsigned long long> look_;
+	uint32_t look_epoch_ = 0;
+	int n_cus_ = 0;
 	DevBuf<uint32_t> inc_rows_;
 	hipStream_t chain_stream_ = nullptr;
 	std::vector<hipEvent_t> chain_ev_;
@@ -4312,3 +4473,12 @@ HipBackend *create_hip_backend(std::string &err) {
 }
 
 } /* namespace sauhip */
+
+#ifdef FK_PROF
+extern "C" __attribute__((visibility("default"))) int sauAmd_prof_read(unsigned int *out16, int reset) {
+	unsigned int z[16] = {0};
+	if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(sauhip::g_fk_prof), sizeof z) != hipSuccess) return -1;
+	if (reset && hipMemcpyToSymbol(HIP_SYMBOL(sauhip::g_fk_prof), z, sizeof z) != hipSuccess) return -1;
+	return 0;
+}
+#endif

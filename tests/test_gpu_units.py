@@ -618,11 +618,13 @@ def test_ratio_chains_below_modulated_frequencies(sa, oracle):
 
 
 @pytest.mark.parametrize("env", [{"SAU_AMD_FAST_ROWS": "2"}, {"SAU_AMD_NO_TWO_PASS": "1"}, {"SAU_AMD_NO_SEQ": "1"},
-                                 {"SAU_AMD_LDS_LIMIT": "65536"}, {"SAU_AMD_MULTI_MIN": "1"}])
+                                 {"SAU_AMD_LDS_LIMIT": "65536"}, {"SAU_AMD_MULTI_MIN": "1"},
+                                 {"SAU_AMD_NO_LOOKBACK": "1"}, {"SAU_AMD_NO_LOOKBACK": "1", "SAU_AMD_NO_INC_ROWS": "1"}])
 def test_random_graphs_in_other_kernel_configurations(sa, oracle, env):
     """The random programs with events through the other builds and modes of the kernels: two rows per
     pass, running sums by one wave in order, no running sums in the time-parallel path at all, a
-    tight LDS budget, single-wave teams in the block loop."""
+    tight LDS budget, single-wave teams in the block loop, running sums in several passes instead of
+    one pass with look-back (with and without the saved increments)."""
     oracle.oracle().ora_set_fastmath_forms(1)
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
@@ -695,3 +697,42 @@ def test_feedback_chains_at_other_pipeline_depths(sa, oracle, chunks, monkeypatc
     voices = [vb.Op("sin", freq=vb.Line(150.0 + 7 * k, goal=300.0, shape="exp"), time_ms=900 + 10 * k, pm_a=0.3 + 0.05 * k,
                     mods={POP_PMOD: [inner]} if k == 3 else {}) for k in range(6)]
     check(sa, oracle, voices, chunk=50000)
+
+
+@pytest.mark.parametrize("lookback", ["on", "off"])
+def test_running_sums_by_look_back(sa, oracle, lookback, monkeypatch):
+    """Running-sum phases in one pass (every wave publishes its row group's sum and looks back
+    for its prefix) against the several-pass form of the same voices: FM nested deeper than the sum
+    passes reach, nine running-sum oscillators in one voice (one more than the look-back arrays hold:
+    that voice goes to one wave in order), R oscillators with swept and modulated frequencies (64-bit
+    counters), a single long voice whose waves sit in different workgroups, and many short voices."""
+    from saugns_amd.api import POPT_RASEG
+    if lookback == "off":
+        monkeypatch.setenv("SAU_AMD_NO_LOOKBACK", "1")
+    def nest(depth, f0=3.0):
+        m = vb.Op("sin", freq=f0, amp=9.0)
+        for d in range(depth - 1):
+            m = vb.Op(("tri", "sin", "saw")[d % 3], freq=f0 * (d + 2) * 1.7, amp=14.0 + 5 * d, mods={POP_FMOD: [m]})
+        return m
+    check(sa, oracle, [vb.Op("sin", freq=330.0, time_ms=700, mods={POP_FMOD: [nest(5)]})], chunk=1000000)
+    wide = lambda n: [vb.Op("sin", freq=vb.Line(2.0 + k, goal=5.0 + 2 * k, shape=("lin", "exp", "cos")[k % 3]), amp=6.0 + k)
+                      for k in range(n)]
+    check(sa, oracle, [vb.Op("sin", freq=vb.Line(200.0, goal=260.0, shape="lin"), time_ms=500, mods={POP_FMOD: wide(7)}),
+                       vb.Op("sin", freq=vb.Line(300.0, goal=150.0, shape="exp"), time_ms=400, mods={POP_FMOD: wide(8)})],
+          stereo=True, chunk=30000)
+    r_voices = [vb.Op(freq=vb.Line(120.0 + 40 * k, goal=480.0 - 30 * k, shape="exp"), amp=0.7, time_ms=350 + 20 * k,
+                      op_type=POPT_RASEG, seed=77 + k, ras=(("lin", "cos", "sah")[k % 3], k % 6, (0, 9, 25, 31)[k % 4]),
+                      mods={POP_FMOD: [vb.Op("sin", freq=6.0, amp=25.0)]} if k & 1 else {}) for k in range(6)]
+    check(sa, oracle, r_voices, chunk=100000)
+    r_mod = vb.Op(freq=vb.Line(3.0, goal=11.0, shape="lin"), amp=30.0, op_type=POPT_RASEG, seed=5, ras=("cos", 1, 9))
+    check(sa, oracle, [vb.Op("sin", freq=440.0, time_ms=600, mods={POP_FMOD: [r_mod]})], chunk=1000000)
+    long_one = vb.Op("sin", freq=vb.Line(55.0, goal=1760.0, shape="exp"), time_ms=6000,
+                     mods={POP_FMOD: [vb.Op("sin", freq=4.0, amp=8.0, mods={POP_FMOD: [vb.Op("sin", freq=0.7, amp=2.0)]})]})
+    check(sa, oracle, [long_one], chunk=1000000)
+    many = [vb.Op("sin", freq=vb.Line(100.0 + 3 * k, goal=200.0 + k, shape="lin"), time_ms=40 + k % 17,
+                  mods={POP_FMOD: [vb.Op("sin", freq=5.0 + k % 5, amp=10.0)]}) for k in range(300)]
+    check(sa, oracle, many, chunk=1000000)
+    b = sa.Batch([vb.build_program([vb.Op("sin", freq=330.0, time_ms=700, mods={POP_FMOD: [nest(5)]}), long_one])], RATE)
+    b.set_timing(2)
+    b.render(stereo=False, chunk=4000000)
+    assert b.timing_ex()["block_ms"] < 1.0  # the time-parallel kernel took them, not the block loop
