@@ -104,13 +104,6 @@ __device__ __forceinline__ unsigned long long wave_incl_scan64(unsigned long lon
  * moving them to scalar registers lets the compiler use scalar branches and
  * scalar arithmetic for all the per-step bookkeeping. */
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-#ifdef FK_PROF
-/* diagnostic build (saugns_amd/build.py --variant prof FK_PROF): wave-time per section of fast_voice's running-sum build */
-__device__ unsigned int g_fk_prof[16]; /* units of 64 clocks */
-#define FKP_MARK(i) do { const uint32_t fkp_now_ = uni((uint32_t)__builtin_amdgcn_s_memtime()); if (l == 0) fkp_[i] += fkp_now_ - fkp_t_; fkp_t_ = fkp_now_; } while (0)
-#else
-#define FKP_MARK(i) do {} while (0)
-#endif
 __device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float uni(float v) { return bits_f(uni(f_bits(v))); }
 __device__ __forceinline__ bool uni(bool v) { return uni((uint32_t)v) != 0; }
@@ -1220,7 +1213,7 @@ constexpr uint32_t FAST_MAX_LEVELS = 3; /* running sums that depend on running s
 constexpr uint32_t FAST_REPAIR_SHIFT = 24; /* H + shift < 64 (H <= 32) */
 constexpr uint32_t FAST_MAX_REPAIR = 15;   /* noted row groups per voice and segment; more: block loop */
 constexpr uint32_t FAST_REPAIR_WORDS = 2 + 2 * FAST_MAX_REPAIR; /* count, pad, then (group, rows) pairs */
-constexpr uint32_t FAST_FLAGS = FAST_MAX_LEVELS + 2; /* pass_flags words */
+constexpr uint32_t FAST_FLAGS = FAST_MAX_LEVELS + 3; /* pass_flags words */
 /* Decoded steps are kept once per pass that runs them ([list][voice][step]): a pass walks its own list and never
  * loads a step only to find that another pass needs it (the per-step cost of the interpreter is most of a pass). */
 constexpr uint32_t FAST_LISTS = 5; /* 0: only / final pass, 1..3: sum passes, 4: chain-input pass */
@@ -1291,6 +1284,8 @@ struct FastParams {
 	 * (one per segment) makes every older word read as empty, so nothing is cleared between segments. */
 	unsigned long long *look; /* [n_voices][FAST_MAX_SCAN][2][scan_groups], or NULL */
 	uint32_t look_epoch;
+	uint32_t rows_multi; /* rows per pass in the launches of the full running-sum build (kinds 1 and 2) */
+	uint32_t only_multi; /* this launch: only the voices fast_kernel<T, 2> leaves out (one wave in order, several passes) */
 	int8_t ctab_of_wave[12];
 	uint8_t cwave_of_tab[12];
 	int8_t tab_of_wave[12];
@@ -1697,6 +1692,7 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 	if (!bad && vd.nops <= P.max_ops && vd.plan_len <= P.max_steps && maxd >= 1 && maxd + x_carrier <= P.np / 2)
 		fi.total = min(min_time, vd.run_len);
 	P.info[v] = fi;
+	if (fi.total && (seq_kind == 1 || seq_kind == 2)) atomicOr(&P.pass_flags[FAST_MAX_LEVELS + 2], 1u);
 	P.fast_done[v] = 0;
 	P.repair[(size_t)v * FAST_REPAIR_WORDS] = 0;
 }
@@ -1812,7 +1808,7 @@ __global__ void __launch_bounds__(64) scan_kernel(FastParams P) {
 	if (fi.seq != 2 || fi.total == 0) return;
 	const uint32_t C = 64u - fi.H;
 	const uint32_t nrows = (fi.total + C - 1) / C;
-	const uint32_t ngroups = (nrows + P.rows - 1) / P.rows;
+	const uint32_t ngroups = (nrows + P.rows_multi - 1) / P.rows_multi;
 	for (uint32_t x = 0; x < fi.n_scan && x < FAST_MAX_SCAN; ++x) {
 		if (((fi.lvl_bits >> (2 * x)) & 3u) != P.mode) continue; /* sums of this pass only */
 		unsigned long long *a = P.scan + ((size_t)v * FAST_MAX_SCAN + x) * P.scan_groups;
@@ -1831,10 +1827,11 @@ __global__ void __launch_bounds__(64) scan_kernel(FastParams P) {
  * that a row touches no operator records: lazily-constant frequency lines
  * vanish, everything a step needs is 20 dwords in scalar registers. */
 __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
-	const uint32_t NP = 64 * P.rows; /* frames per block buffer */
 	const uint32_t v = blockIdx.x;
 	const int l = threadIdx.x;
 	if (P.info[v].total == 0) return;
+	/* frames per block buffer: the launch that takes this kind of voice has its own rows per pass */
+	const uint32_t NP = 64 * ((P.info[v].seq == 1 || P.info[v].seq == 2) ? P.rows_multi : P.rows);
 	const VoiceDesc vd = P.voices[v];
 	const uint32_t *ids = P.op_ids + vd.ops_ofs;
 	/* lane si handles step si (plan_len <= 64) */
@@ -2206,7 +2203,7 @@ __device__ __forceinline__ FastStep load_step_uniform(const FastStep *p) {
  * (frequency ramps, FM); the plain build stays as lean as closed-form voices
  * need it (the same code with the running-sum branches compiled in was 27 %
  * slower on them), and a kernel that may meet both kinds holds both copies. */
-template <int T, bool SCAN, bool REPAIR = false>
+template <int T, int SCAN, bool REPAIR = false>
 __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v, const FastInfo &fi,
 		float *slots, unsigned long long *carry, const HerpC23 *t23, const HerpC01 *t01, const int l,
 		const uint32_t wpv, const uint32_t cstart) {
@@ -2218,7 +2215,10 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 	const uint32_t H = uni(fi.H);
 
 	/* this pass's own list of the voice's decoded steps */
-	const uint32_t li = SCAN ? fast_list_of(P.mode, P.sum_levels) : 0u;
+	/* SCAN: 0 closed-form phases only; 1 every kind of running-sum voice; 2 single-pass (look-back) voices only,
+	 * without the code of the several-pass forms and the feedback chains */
+	constexpr bool FULL = SCAN == 1;
+	const uint32_t li = FULL ? fast_list_of(P.mode, P.sum_levels) : 0u;
 	const uint32_t n_fsteps = uni(li == 0 ? fi.n_fsteps : li == 1 ? fi.n_pass[0] : li == 2 ? fi.n_pass[1] : li == 3 ? fi.n_pass[2] : fi.n_pass[3]);
 	const size_t list_at = ((size_t)li * P.n_voices + v) * P.max_steps;
 	const FastStep *fsteps = P.fsteps + list_at;
@@ -2227,9 +2227,9 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 	const FastLine *fplines = P.fplines ? P.fplines + list_at : nullptr;
 	/* sequential-scan voices: the one wave with cstart == 0 walks every row group in order */
 	const uint32_t seq_kind = SCAN ? uni(fi.seq) : 0u;
-	const bool seq = SCAN && seq_kind == 1;    /* one wave, in order */
-	const bool two = SCAN && seq_kind == 2;    /* two passes, every wave */
-	const bool look = SCAN && seq_kind == 3;   /* one pass, every wave, prefixes by look-back */
+	const bool seq = FULL && seq_kind == 1;    /* one wave, in order */
+	const bool two = FULL && seq_kind == 2;    /* two passes, every wave */
+	const bool look = SCAN == 2 || (FULL && seq_kind == 3); /* one pass, every wave, prefixes by look-back */
 	unsigned long long *lookv = look ? P.look + (size_t)v * FAST_MAX_SCAN * 2 * P.scan_groups : nullptr;
 	if (seq && cstart != 0) return;
 	const uint32_t gstride = seq ? 1u : wpv;
@@ -2262,11 +2262,6 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 			}
 		}
 	}
-#ifdef FK_PROF
-	uint32_t *fkp_ = (uint32_t *)carry; /* (unused by multi-pass voices) */
-	if (l == 0) for (int i = 0; i < 8; ++i) fkp_[i] = 0;
-	uint32_t fkp_t_ = uni((uint32_t)__builtin_amdgcn_s_memtime());
-#endif
 	for (uint32_t it = it_lo + cstart; it < n_iter; it += gstride) {
 		const uint32_t cg = REPAIR ? uni(rep[2 + 2 * it]) : it;
 		const uint32_t repair_rows = REPAIR ? uni(rep[3 + 2 * it]) : 0u;
@@ -2287,19 +2282,18 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 #endif
 			const uint32_t kind = f.kind & 0xff;
 			const uint32_t flags = (f.kind >> 8) & 0xff;
-			const bool sum_pass = SCAN && P.mode != 0 && P.mode <= P.sum_levels;
+			const bool sum_pass = FULL && P.mode != 0 && P.mode <= P.sum_levels;
 			if (sum_pass && !(f.ramp & (2u << P.mode))) continue; /* not needed for this pass's phase increments */
-			const bool chain_in = SCAN && P.mode == P.sum_levels + 2; /* the pass that writes the chains' inputs */
+			const bool chain_in = FULL && P.mode == P.sum_levels + 2; /* the pass that writes the chains' inputs */
 			if (chain_in && !(f.ramp & FR_CHAIN_IN)) continue;
-			if (SCAN && P.mode == P.sum_levels + 1 && (f.ramp & FR_FINAL_SKIP)) continue;
-			if (SCAN) FKP_MARK(0);
+			if (FULL && P.mode == P.sum_levels + 1 && (f.ramp & FR_FINAL_SKIP)) continue;
 			if (kind == ST_OSC) {
 				const uint32_t type = f.type & 0xff;
 				const bool wave_env = (flags & SF_WAVE_ENV) != 0;
 				const bool layer = (flags & SF_LAYER) != 0;
 				const bool to_voice = ((f.kind >> 16) & OX_VOICE) != 0;
 				float s[T];
-				const bool chain = SCAN && (f.type & FT_CHAIN) != 0;
+				const bool chain = FULL && (f.type & FT_CHAIN) != 0;
 				if (type == OT_WAVE && chain && P.mode == P.sum_levels + 1) { /* (the final pass) */
 					/* a feedback chain: chain_kernel has run it; its samples are in the row */
 					const float *crow = P.chain_rows + (size_t)2 * f_bits(f.pan) * P.chain_stride;
@@ -2365,7 +2359,6 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 							}
 						}
 					}
-					if (SCAN) FKP_MARK(1);
 					if (!done) {
 						uint32_t ph[T];
 						double Is[T];
@@ -2381,7 +2374,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 								uint32_t S[T];
 								/* saved increments (FastParams.inc_rows): written by the sum pass of this oscillator's
 								 * level, read back by the final pass in place of the frequency */
-								uint32_t *irow = (fa.pad[2] & 2u) ? P.inc_rows + (size_t)2 * (fa.pad[2] >> 8) * P.inc_stride : nullptr;
+								uint32_t *irow = (FULL && (fa.pad[2] & 2u)) ? P.inc_rows + (size_t)2 * (fa.pad[2] >> 8) * P.inc_stride : nullptr;
 								const bool inc_read = irow && P.mode == P.sum_levels + 1;
 								const bool inc_write = irow && two && P.mode == fa.pad[1];
 #pragma unroll
@@ -2455,7 +2448,6 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 								if (two) {
 									if (sum_me) { /* this pass ends here for this oscillator */
 										if (l == 0) sums[cg] = (unsigned long long)acc;
-										FKP_MARK(2);
 										continue;
 									}
 								} else if (!look && l == 0) {
@@ -2463,7 +2455,6 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 								}
 							}
 						}
-						if (SCAN) FKP_MARK(2);
 						if (!fvar) {
 							/* phase0 + inc*(t+1): one multiply per lane, then adds */
 							uint32_t acc = f.phase0 + f.inc * (uint32_t)(t0 + 1);
@@ -2644,7 +2635,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 						if (fvar) {
 							const float rcoeff = rate2x ? fa.coeff * 2 : fa.coeff;
 							unsigned long long S[T], incv[T];
-							uint32_t *irow = (fa.pad[2] & 2u) ? P.inc_rows + (size_t)2 * (fa.pad[2] >> 8) * P.inc_stride : nullptr;
+							uint32_t *irow = (FULL && (fa.pad[2] & 2u)) ? P.inc_rows + (size_t)2 * (fa.pad[2] >> 8) * P.inc_stride : nullptr;
 							const bool inc_read = irow && P.mode == P.sum_levels + 1;
 							const bool inc_write = irow && two && P.mode == fa.pad[1];
 #pragma unroll
@@ -2751,7 +2742,6 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 #pragma unroll
 					for (int k = 0; k < T; ++k) s[k] = f.fc;
 				}
-				if (SCAN) FKP_MARK(3);
 				/* amplitude and combine: generator.c:384-440 */
 				float r[T];
 				if (f.amp_off != ~0u) {
@@ -2787,7 +2777,6 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 #pragma unroll
 					for (int k = 0; k < T; ++k) slots[f.out_off + k * 64] = r[k];
 				}
-				if (SCAN) FKP_MARK(4);
 			} else if (kind == ST_LINE) {
 				/* held line: v0 (sau/line.c:435-442); ratio lines only exist for freq */
 				if (f.ramp) {
@@ -2833,7 +2822,6 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 				}
 			}
 		}
-		if (SCAN) FKP_MARK(5);
 		if (held_rows) {
 			/* to the repair pass -- unless this is it, the group touches an end of the segment
 			 * (carried state sits at fixed lanes there) or the voice has running sums */
@@ -2856,12 +2844,6 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 		}
 	}
 	if (__any(zero_acc) && l == 0) atomicOr(&P.info[v].bail, 1u);
-#ifdef FK_PROF
-	if (SCAN && l == 0) {
-		const uint32_t base = P.mode != 0 && P.mode <= P.sum_levels ? 0u : 8u;
-		for (int i = 0; i < 6; ++i) atomicAdd(&g_fk_prof[base + i], fkp_[i] >> 6);
-	}
-#endif
 
 }
 
@@ -2869,7 +2851,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 #ifndef FK_MINB
 #define FK_MINB 1
 #endif
-template <int T, bool SCAN>
+template <int T, int SCAN>
 __global__ void __launch_bounds__(1024, FK_MINB) fast_kernel(FastParams P) {
 	constexpr int NP = 64 * T;
 	constexpr int W = 16;
@@ -2878,8 +2860,9 @@ __global__ void __launch_bounds__(1024, FK_MINB) fast_kernel(FastParams P) {
 	const int w = (int)uni((uint32_t)tid >> 6);
 	const int l = tid & 63;
 	/* a sum pass nobody needs costs a launch, not a table staging */
-	if (SCAN && P.mode != 0 && P.mode <= P.sum_levels && P.pass_flags[P.mode - 1] == 0) return;
-	if (SCAN && P.mode == P.sum_levels + 2 && P.pass_flags[FAST_MAX_LEVELS + 1] == 0) return; /* no chains */
+	if (SCAN == 1 && P.mode != 0 && P.mode <= P.sum_levels && P.pass_flags[P.mode - 1] == 0) return;
+	if (SCAN == 1 && P.mode == P.sum_levels + 2 && P.pass_flags[FAST_MAX_LEVELS + 1] == 0) return; /* no chains */
+	if (SCAN == 1 && P.only_multi && P.pass_flags[FAST_MAX_LEVELS + 2] == 0) return; /* no voice the single-pass build left out */
 
 	HerpC23 *t23 = (HerpC23 *)lds;
 	HerpC01 *t01 = (HerpC01 *)(lds + (size_t)P.n_tabs * WAVE_LEN * sizeof(HerpC23));
@@ -2910,12 +2893,19 @@ __global__ void __launch_bounds__(1024, FK_MINB) fast_kernel(FastParams P) {
 	for (; v < NV; v += vstride) {
 		const FastInfo fi = P.info[v];
 		const uint32_t seq_kind = SCAN ? uni(fi.seq) : 0u;
-		if (SCAN && P.mode != 0 && P.mode <= P.sum_levels && (seq_kind != 2 || uni(fi.levels) < P.mode))
+		if (SCAN == 1 && P.mode != 0 && P.mode <= P.sum_levels && (seq_kind != 2 || uni(fi.levels) < P.mode))
 			continue; /* a sum pass only concerns multi-pass voices that deep */
-		if (SCAN && P.mode == P.sum_levels + 2 && (seq_kind != 2 || uni(fi.n_chain) == 0))
+		if (SCAN == 1 && P.mode == P.sum_levels + 2 && (seq_kind != 2 || uni(fi.n_chain) == 0))
 			continue; /* the chain-input pass only concerns voices with feedback chains */
-		if (SCAN && seq_kind != 0) fast_voice<T, true>(P, v, fi, slots, carry, t23, t01, l, wpv, cstart);
-		else fast_voice<T, false>(P, v, fi, slots, carry, t23, t01, l, wpv, cstart);
+		if (SCAN == 2) { /* the other kinds of running-sum voice have a launch of the full build to themselves */
+			if (seq_kind == 1 || seq_kind == 2) continue;
+			if (seq_kind == 3) fast_voice<T, 2>(P, v, fi, slots, carry, t23, t01, l, wpv, cstart);
+			else fast_voice<T, 0>(P, v, fi, slots, carry, t23, t01, l, wpv, cstart);
+			continue;
+		}
+		if (SCAN == 1 && P.only_multi && seq_kind != 1 && seq_kind != 2) continue;
+		if (SCAN && seq_kind != 0) fast_voice<T, 1>(P, v, fi, slots, carry, t23, t01, l, wpv, cstart);
+		else fast_voice<T, 0>(P, v, fi, slots, carry, t23, t01, l, wpv, cstart);
 	}
 }
 
@@ -2950,7 +2940,7 @@ __global__ void __launch_bounds__(1024) repair_kernel(FastParams P) {
 		if (uni(P.repair[(size_t)v * FAST_REPAIR_WORDS]) == 0) continue;
 		const FastInfo fi = P.info[v];
 		if (uni(fi.total) == 0 || uni(fi.seq) != 0) continue;
-		fast_voice<T, false, true>(P, v, fi, slots, carry, t23, t01, l, 1u, 0u);
+		fast_voice<T, 0, true>(P, v, fi, slots, carry, t23, t01, l, 1u, 0u);
 	}
 }
 
@@ -3691,6 +3681,7 @@ public:
 		chain_inline_ = getenv("SAU_AMD_CHAIN_INLINE") != nullptr;
 		inc_rows_enabled_ = getenv("SAU_AMD_NO_INC_ROWS") == nullptr;
 		lookback_enabled_ = getenv("SAU_AMD_NO_LOOKBACK") == nullptr; /* single-pass running sums */
+		if (const char *lr = getenv("SAU_AMD_LOOK_ROWS")) look_rows_ = (uint32_t)atoi(lr);
 		if (const char *cc = getenv("SAU_AMD_CHAIN_CHUNKS")) { /* pipeline depth of a segment with chains (1: off) */
 			const int n = atoi(cc);
 			chain_chunks_ = n >= 16 ? 16 : n >= 8 ? 8 : n >= 4 ? 4 : n >= 2 ? 2 : 1;
@@ -3897,8 +3888,14 @@ public:
 			 * (more rows amortise the per-step work: 8 rows measured 8 % faster
 			 * than 4, 4 rows 28 % faster than 2) */
 			uint32_t FT = fast_rows_;
-			/* the build with the running-sum code needs more registers: 8 rows per pass would spill */
-			if (seq_enabled_ && seg.may_scan && FT > 4) FT = 4;
+			/* The build with all the running-sum code needs more registers: 8 rows per pass would spill. Where the
+			 * single-pass (look-back) build serves, it takes those voices and the closed-form ones at the full rows
+			 * per pass, and the full build gets a launch for what is left (voices one wave walks in order);
+			 * segments with feedback chains go through the full build alone. */
+			const bool look_split = seq_enabled_ && seg.may_scan && two_pass_enabled_ && lookback_enabled_ && look_rows_ != 0 &&
+				!(chain_enabled_ && seg.serial && seg.n_chain_rows && seg.len <= sauengine::CHAIN_SEG);
+			if (seq_enabled_ && seg.may_scan && FT > 4 && !look_split) FT = 4;
+			if (look_split && FT > look_rows_) FT = look_rows_ >= 8 ? 8 : look_rows_ >= 4 ? 4 : 2;
 			/* block buffers: without frequency blocks, or with them when some voice may need
 			 * the sequential scan (ramped or modulated frequencies) */
 			const bool seq_ok = seq_enabled_ && seg.may_scan;
@@ -3910,6 +3907,7 @@ public:
 			while (FT > 2 && 16 * area_of(FT) + one_tab + 1024 > lds_limit_) FT /= 2;
 			const size_t area = area_of(FT);
 			const bool use_fast = fast_enabled_ && (16 * area + 1024 <= lds_limit_);
+			const uint32_t FTM = FT > 4 && seq_enabled_ && seg.may_scan ? 4 : FT; /* rows per pass of the full build */
 			if (!finfo_.ensure(seg.n_voices, err) || !fdone_.ensure(seg.n_voices, err) ||
 			    !worklist_.ensure(seg.n_voices, err) || !work_count_.ensure(4, err) ||
 			    !fsteps_.ensure((size_t)FAST_LISTS * seg.n_voices * fmax_steps * sizeof(FastStep), err) ||
@@ -3926,7 +3924,7 @@ public:
 			fp.scan = nullptr; fp.scan_groups = 0; fp.mode = 0;
 			if (seq_ok && two_pass_enabled_) {
 				/* row groups per voice at most: rows hold at least 32 new frames (H <= 32) */
-				fp.scan_groups = seg.len / (32 * FT) + 2;
+				fp.scan_groups = seg.len / (32 * FTM) + 2;
 				if (!scan_.ensure((size_t)seg.n_voices * FAST_MAX_SCAN * fp.scan_groups, err)) return false;
 				fp.scan = scan_.p;
 				if (lookback_enabled_) {
@@ -3949,7 +3947,7 @@ public:
 			if (!repair_.ensure((size_t)seg.n_voices * FAST_REPAIR_WORDS, err)) return false;
 			fp.repair = repair_.p;
 			fp.repair_on = getenv("SAU_AMD_NO_REPAIR") ? 0u : 1u;
-			fp.max_ops = seg.max_ops; fp.max_steps = fmax_steps; fp.np = 64; fp.rows = FT;
+			fp.max_ops = seg.max_ops; fp.max_steps = fmax_steps; fp.np = 64; fp.rows = FT; fp.rows_multi = FTM;
 			fp.enable = use_fast ? 1u : 0u;
 			/* saved phase increments of running-sum oscillators (sum pass -> final pass), one segment long */
 			if (inc_rows_enabled_ && use_fast && fp.scan && seg.n_inc_rows && seg.len <= sauengine::CHAIN_SEG) {
@@ -3999,18 +3997,25 @@ public:
 			if (use_fast) {
 				hipLaunchKernelGGL(decode_kernel, dim3(seg.n_voices), dim3(64), 0, stream_, fp);
 				const size_t flds = ft * tab_bytes + 16 * area;
-				const bool scan_build = seq_ok; /* some voice may need running-sum phases */
-				const void *fk = scan_build
-					? (FT == 8 ? (const void *)fast_kernel<8, true> : FT == 4 ? (const void *)fast_kernel<4, true>
-					                                                          : (const void *)fast_kernel<2, true>)
-					: (FT == 8 ? (const void *)fast_kernel<8, false> : FT == 4 ? (const void *)fast_kernel<4, false>
-					                                                           : (const void *)fast_kernel<2, false>);
-				static size_t fconfigured[16][6];
-				size_t &conf = fconfigured[dev_ & 15][(FT == 8 ? 2 : FT == 4 ? 1 : 0) + (scan_build ? 3 : 0)];
-				if (flds > conf) {
-					HIP_OK(hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
-					conf = flds;
-				}
+				/* build 0: closed-form phases only; 1: every kind of running-sum voice; 2: single-pass voices and closed-form ones */
+				const int main_build = !seq_ok ? 0 : look_split ? 2 : 1;
+				static const void *const fkernels[3][3] = {
+					{(const void *)fast_kernel<2, 0>, (const void *)fast_kernel<4, 0>, (const void *)fast_kernel<8, 0>},
+					{(const void *)fast_kernel<2, 1>, (const void *)fast_kernel<4, 1>, (const void *)fast_kernel<8, 1>},
+					{(const void *)fast_kernel<2, 2>, (const void *)fast_kernel<4, 2>, (const void *)fast_kernel<8, 2>}};
+				static size_t fconfigured[16][3][3];
+				auto launch_build = [&](int build, uint32_t rows, uint32_t grid) -> bool {
+					const int ri = rows == 8 ? 2 : rows == 4 ? 1 : 0;
+					const size_t lds = ft * tab_bytes + 16 * area_of(rows);
+					size_t &conf = fconfigured[dev_ & 15][build][ri];
+					if (lds > conf) {
+						HIP_OK(hipFuncSetAttribute(fkernels[build][ri], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+						conf = lds;
+					}
+					void *args[] = {(void *)&fp};
+					HIP_OK(hipLaunchKernel(fkernels[build][ri], dim3(grid), dim3(1024), args, lds, stream_));
+					return true;
+				};
 				/* as many waves per voice as it has row groups (up to 64) when voices are
 				 * few, one CU-filling grid at most */
 				const uint32_t groups = (seg.len + (60 * FT) - 1) / (60 * FT);
@@ -4022,17 +4027,14 @@ public:
 				if (fgrid < 1) fgrid = 1;
 				TimedPair *tf = timing_on_ ? new_pair(2) : nullptr;
 				if (tf) (void)hipEventRecord(tf->a, stream_);
+				bool launched = true;
 				auto launch_fast = [&](uint32_t mode, uint32_t grid = 0) {
-					fp.mode = mode;
-					if (!grid) grid = fgrid;
-					if (scan_build) {
-						if (FT == 8) hipLaunchKernelGGL((fast_kernel<8, true>), dim3(grid), dim3(1024), flds, stream_, fp);
-						else if (FT == 4) hipLaunchKernelGGL((fast_kernel<4, true>), dim3(grid), dim3(1024), flds, stream_, fp);
-						else hipLaunchKernelGGL((fast_kernel<2, true>), dim3(grid), dim3(1024), flds, stream_, fp);
-					} else {
-						if (FT == 8) hipLaunchKernelGGL((fast_kernel<8, false>), dim3(grid), dim3(1024), flds, stream_, fp);
-						else if (FT == 4) hipLaunchKernelGGL((fast_kernel<4, false>), dim3(grid), dim3(1024), flds, stream_, fp);
-						else hipLaunchKernelGGL((fast_kernel<2, false>), dim3(grid), dim3(1024), flds, stream_, fp);
+					fp.mode = mode; fp.only_multi = 0;
+					if (!launch_build(main_build, FT, grid ? grid : fgrid)) launched = false;
+					if (main_build == 2) { /* what the single-pass build leaves out: returns at once when there is none */
+						fp.only_multi = 1;
+						if (!launch_build(1, FTM, grid ? grid : fgrid)) launched = false;
+						fp.only_multi = 0;
 					}
 				};
 				if (fp.scan) {
@@ -4105,6 +4107,7 @@ public:
 				} else {
 					launch_fast(0);
 				}
+				if (!launched) return false;
 				{ /* row groups noted for a second evaluation: returns at once when there are none */
 					const void *rk = FT == 8 ? (const void *)repair_kernel<8> : FT == 4 ? (const void *)repair_kernel<4>
 					                                                                    : (const void *)repair_kernel<2>;
@@ -4388,6 +4391,7 @@ private:
 	uint32_t chain_chunks_ = 8;
 	bool inc_rows_enabled_ = true;
 	bool lookback_enabled_ = true;
+	uint32_t look_rows_ = 8; /* rows per pass of the single-pass build (SAU_AMD_LOOK_ROWS; 0: no such build, the full one takes every voice) */
 	DevBuf<unsigned long long> look_;
 	uint32_t look_epoch_ = 0;
 	int n_cus_ = 0;
@@ -4474,11 +4478,3 @@ HipBackend *create_hip_backend(std::string &err) {
 
 } /* namespace sauhip */
 
-#ifdef FK_PROF
-extern "C" __attribute__((visibility("default"))) int sauAmd_prof_read(unsigned int *out16, int reset) {
-	unsigned int z[16] = {0};
-	if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(sauhip::g_fk_prof), sizeof z) != hipSuccess) return -1;
-	if (reset && hipMemcpyToSymbol(HIP_SYMBOL(sauhip::g_fk_prof), z, sizeof z) != hipSuccess) return -1;
-	return 0;
-}
-#endif

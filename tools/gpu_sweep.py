@@ -124,6 +124,18 @@ if "c3f" in which:
         voices.append(Op("sin", freq=Line(_num(".4f", 110.0 + i * 0.731), goal=_num(".3f", 220.0 + i * 0.5), shape="exp"),
                          time_ms=30000, mods={POP_PMOD: [m1]}))
     run("1024 x 2 ops, carrier glide", build_program(voices), frames=44100, steps=4)
+if "fmstack" in which:
+    # FM (vibrato) on the carrier and a 3-deep ratio PM stack under it: 5 operators, long steps
+    from saugns_amd.voicebank import Op, Line, build_program, _f32, _num
+    from saugns_amd.api import POP_PMOD, POP_FMOD
+    voices = []
+    for i in range(1024):
+        m3 = Op("sin", freq=Line(float(3 + i % 4), ratio=True), amp=_f32(0.4))
+        m2 = Op("tri", freq=Line(float(2 + i % 3), ratio=True), amp=_f32(0.7), mods={POP_PMOD: [m3]})
+        m1 = Op("sin", freq=Line(float(1 + i % 5), ratio=True), amp=_num(".2f", 0.5 + (i % 7) * 0.1), mods={POP_PMOD: [m2]})
+        vib = Op("sin", freq=_num(".2f", 4.0 + (i % 9) * 0.5), amp=_num(".1f", 10.0 + i % 30))
+        voices.append(Op("sin", freq=_num(".4f", 110.0 + i * 0.731), time_ms=60000, mods={POP_PMOD: [m1], POP_FMOD: [vib]}))
+    run("1024 x 5 ops, FM + ratio PM stack", build_program(voices), frames=441000, steps=2)
 if "mixed" in which:
     from saugns_amd.voicebank import Op, Line, build_program, _f32, _num
     from saugns_amd.api import POP_PMOD, POP_FMOD
