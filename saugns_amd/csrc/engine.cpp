@@ -283,7 +283,7 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 	uint32_t n_main = 1, n_fpool = 0, max_ops = 1, n_pan = 0, max_steps = 1, n_fast = 1, n_fast_full = 0;
 	uint64_t wave_mask = 0;
 	bool maybe_block = false, serial = false, may_scan = false;
-	uint32_t sum_levels = 0, n_chain_rows = 0, n_inc_rows = 0;
+	uint32_t sum_levels = 0, n_chain_rows = 0, n_inc_rows = 0, n_look_rows = 0;
 	for (size_t s = 0; s < streams_.size(); ++s) {
 		Stream &st = streams_[s];
 		SegmentDesc::Stream &sd = sdescs[s];
@@ -329,6 +329,7 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 			d.chain_base = n_chain_rows; d.n_chain = vn.plan.n_chain;
 			n_chain_rows += vn.plan.n_chain;
 			d.inc_base = 0; d.n_inc = 0; /* (set below for voices that may have running-sum phases) */
+			d.look_base = 0; d.n_look = 0;
 			if (dyn) line_begin(carr.pan, out_len, false, 0.f, lat, 0);
 			else line_skip(carr.pan, out_len, lat, 0);
 			descs.push_back(d);
@@ -359,6 +360,10 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 				may_scan = true;
 				descs.back().inc_base = n_inc_rows; descs.back().n_inc = vn.plan.n_osc;
 				n_inc_rows += vn.plan.n_osc;
+				if (vn.plan.n_chain == 0) { /* single-pass running sums: one look-back row per oscillator, eight at most */
+					descs.back().look_base = n_look_rows; descs.back().n_look = std::min<uint32_t>(vn.plan.n_osc, 8);
+					n_look_rows += descs.back().n_look;
+				}
 				if (sum_levels < 3) (void)estimate_sum_levels(st, vn.carr_op, 0, false, sum_levels, 0);
 			}
 		}
@@ -383,6 +388,7 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 	seg.sum_levels = sum_levels;
 	seg.n_chain_rows = n_chain_rows;
 	seg.n_inc_rows = n_inc_rows;
+	seg.n_look_rows = n_look_rows;
 	return backend_->render(seg, err);
 }
 

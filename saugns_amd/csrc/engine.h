@@ -55,6 +55,7 @@ struct SegmentDesc {
 	bool serial;              /* some voice may run a per-sample feedback recurrence (self-modulation) */
 	uint32_t n_chain_rows = 0;/* row pairs the voices' chain_base/n_chain span */
 	uint32_t n_inc_rows = 0;  /* row pairs the voices' inc_base/n_inc span (voices that may have running-sum phases) */
+	uint32_t n_look_rows = 0; /* rows the voices' look_base/n_look span (those of them without feedback chains) */
 };
 
 struct BackendConfig {

@@ -164,44 +164,62 @@ __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, i
  * for groups before its own: those belong to waves of this launch that are resident (the grid is at most
  * one workgroup per CU) or to an earlier launch of the same segment. */
 constexpr uint32_t LOOK_AGG = 1, LOOK_PREFIX = 2;
-__device__ __forceinline__ unsigned long long look_word(uint32_t epoch, uint32_t status, uint32_t value) {
-	return ((unsigned long long)((epoch << 2) | status) << 32) | value;
+/* The same words in LDS, for a voice whose waves all sit in one workgroup (2, 4, 8 or 16 of them): a ring of
+ * 4 x waves entries per oscillator, tagged with the group's number + 1 (LDS starts out zeroed). A wave that
+ * writes group g has finished group g - waves, so every wave of the voice has published at least up to round
+ * r - 2 and reads no further back than its own prefix of round r - 3: the entry of g - 4 x waves is dead. */
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+__device__ __forceinline__ unsigned long long look_word(uint32_t tag, uint32_t status, uint32_t value) {
+	return ((unsigned long long)((tag << 2) | status) << 32) | value;
 }
-__device__ __forceinline__ uint32_t lookback32(unsigned long long *ent, const uint32_t cg, const uint32_t tot,
-		const uint32_t epoch, const int l) {
+template <bool LDS> __device__ __forceinline__ void look_store(unsigned long long *p, unsigned long long w) {
+	if (LDS) __hip_atomic_store((lds_u64 *)p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	else __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool LDS> __device__ __forceinline__ unsigned long long look_load(unsigned long long *p) {
+	if (LDS) return __hip_atomic_load((lds_u64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+/* LDS: entry of group i at ent[i & (ring - 1)], tag i + 1; HBM: at ent[i], tag = the segment's epoch */
+template <bool LDS> __device__ __forceinline__ uint32_t lookback32(unsigned long long *ent, const uint32_t cg, const uint32_t tot,
+		const uint32_t epoch, const uint32_t ring, const int l) {
+	auto at = [&](uint32_t i) { return LDS ? (i & (ring - 1)) : i; };
+	auto tag = [&](uint32_t i) { return LDS ? i + 1 : epoch; };
 	if (cg == 0) {
-		if (l == 0) __hip_atomic_store(&ent[0], look_word(epoch, LOOK_PREFIX, tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (l == 0) look_store<LDS>(&ent[0], look_word(tag(0), LOOK_PREFIX, tot));
 		return 0;
 	}
-	if (l == 0) __hip_atomic_store(&ent[cg], look_word(epoch, LOOK_AGG, tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	if (l == 0) look_store<LDS>(&ent[at(cg)], look_word(tag(cg), LOOK_AGG, tot));
 	uint32_t excl = 0;
 	int p = (int)cg - 1; /* the nearest group not yet accounted for */
 	for (;;) {
 		const int idx = p - l; /* lane l looks at the group l before it; before group 0 the prefix is 0 */
-		unsigned long long e = look_word(epoch, LOOK_PREFIX, 0);
-		if (idx >= 0) e = __hip_atomic_load(&ent[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		unsigned long long e = 0;
+		if (idx >= 0) e = look_load<LDS>(&ent[at((uint32_t)idx)]);
 		const uint32_t hi = (uint32_t)(e >> 32);
-		const uint32_t st = (hi >> 2) == epoch ? (hi & 3u) : 0u;
+		const uint32_t st = idx < 0 ? LOOK_PREFIX : (hi >> 2) == tag((uint32_t)idx) ? (hi & 3u) : 0u;
 		const unsigned long long m_pref = __ballot(st == LOOK_PREFIX), m_none = __ballot(st == 0);
 		const int first_pref = m_pref ? __builtin_ctzll(m_pref) : 64;
 		const int first_none = m_none ? __builtin_ctzll(m_none) : 64;
 		const int upto = first_pref < first_none ? first_pref + 1 : first_none; /* lanes [0, upto) count */
-		uint32_t part = wave_incl_scan_dpp(l < upto ? (uint32_t)e : 0u);
+		const uint32_t part = wave_incl_scan_dpp(l < upto && idx >= 0 ? (uint32_t)e : 0u);
 		excl += (uint32_t)__builtin_amdgcn_readlane((int)part, 63);
 		if (first_pref < first_none) break;
 		p -= upto;
-		if (upto == 0) __builtin_amdgcn_s_sleep(2);
+		if (upto == 0) __builtin_amdgcn_s_sleep(LDS ? 1 : 2);
 	}
-	if (l == 0) __hip_atomic_store(&ent[cg], look_word(epoch, LOOK_PREFIX, excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	if (l == 0) look_store<LDS>(&ent[at(cg)], look_word(tag(cg), LOOK_PREFIX, excl + tot));
 	return excl;
 }
 /* 64-bit totals (R oscillators' cycle counters): low and high halves in two arrays, a pair counts once both
  * words show the same status */
-__device__ __forceinline__ unsigned long long lookback64(unsigned long long *ent_lo, unsigned long long *ent_hi,
-		const uint32_t cg, const unsigned long long tot, const uint32_t epoch, const int l) {
-	auto publish = [&](uint32_t at, uint32_t status, unsigned long long v) {
-		__hip_atomic_store(&ent_lo[at], look_word(epoch, status, (uint32_t)v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		__hip_atomic_store(&ent_hi[at], look_word(epoch, status, (uint32_t)(v >> 32)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+template <bool LDS> __device__ __forceinline__ unsigned long long lookback64(unsigned long long *ent_lo, unsigned long long *ent_hi,
+		const uint32_t cg, const unsigned long long tot, const uint32_t epoch, const uint32_t ring, const int l) {
+	auto at = [&](uint32_t i) { return LDS ? (i & (ring - 1)) : i; };
+	auto tag = [&](uint32_t i) { return LDS ? i + 1 : epoch; };
+	auto publish = [&](uint32_t i, uint32_t status, unsigned long long v) {
+		look_store<LDS>(&ent_lo[at(i)], look_word(tag(i), status, (uint32_t)v));
+		look_store<LDS>(&ent_hi[at(i)], look_word(tag(i), status, (uint32_t)(v >> 32)));
 	};
 	if (cg == 0) {
 		if (l == 0) publish(0, LOOK_PREFIX, tot);
@@ -212,23 +230,23 @@ __device__ __forceinline__ unsigned long long lookback64(unsigned long long *ent
 	int p = (int)cg - 1;
 	for (;;) {
 		const int idx = p - l;
-		unsigned long long a = look_word(epoch, LOOK_PREFIX, 0), b = a;
+		unsigned long long a = 0, b = 0;
 		if (idx >= 0) {
-			a = __hip_atomic_load(&ent_lo[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			b = __hip_atomic_load(&ent_hi[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			a = look_load<LDS>(&ent_lo[at((uint32_t)idx)]);
+			b = look_load<LDS>(&ent_hi[at((uint32_t)idx)]);
 		}
 		const uint32_t ha = (uint32_t)(a >> 32), hb = (uint32_t)(b >> 32);
-		const uint32_t st = ((ha >> 2) == epoch && ha == hb) ? (ha & 3u) : 0u;
+		const uint32_t st = idx < 0 ? LOOK_PREFIX : ((ha >> 2) == tag((uint32_t)idx) && ha == hb) ? (ha & 3u) : 0u;
 		const unsigned long long m_pref = __ballot(st == LOOK_PREFIX), m_none = __ballot(st == 0);
 		const int first_pref = m_pref ? __builtin_ctzll(m_pref) : 64;
 		const int first_none = m_none ? __builtin_ctzll(m_none) : 64;
 		const int upto = first_pref < first_none ? first_pref + 1 : first_none;
 		const unsigned long long v = ((unsigned long long)(uint32_t)b << 32) | (uint32_t)a;
-		const unsigned long long part = wave_incl_scan64_dpp(l < upto ? v : 0ull);
+		const unsigned long long part = wave_incl_scan64_dpp(l < upto && idx >= 0 ? v : 0ull);
 		excl += readlane64(part, 63);
 		if (first_pref < first_none) break;
 		p -= upto;
-		if (upto == 0) __builtin_amdgcn_s_sleep(2);
+		if (upto == 0) __builtin_amdgcn_s_sleep(LDS ? 1 : 2);
 	}
 	if (l == 0) publish(cg, LOOK_PREFIX, excl + tot);
 	return excl;
@@ -1201,6 +1219,7 @@ struct FastAux;
 struct ChainDesc;
 constexpr uint32_t CHAIN_DESC_WORDS = 32;
 constexpr uint32_t FAST_MAX_SCAN = 8;   /* oscillators with running-sum phases per multi-pass voice */
+constexpr uint32_t LOOK_LDS_BYTES = FAST_MAX_SCAN * 2 * 64 * sizeof(unsigned long long); /* the look-back rings of a workgroup */
 constexpr uint32_t FAST_MAX_LEVELS = 3; /* running sums that depend on running sums: at most that many sum passes
                                          * (FastParams.sum_levels of them are launched for a segment) */
 /* A repeated phase (the output holds, wosc.h:251-252) on the first lane an operator's values are
@@ -1282,7 +1301,7 @@ struct FastParams {
 	 * {epoch:30, status:2, value:32}; a wave publishes its group's sum (status 1), adds up what its predecessors
 	 * have published back to the nearest finished prefix, and publishes its own prefix (status 2). The epoch
 	 * (one per segment) makes every older word read as empty, so nothing is cleared between segments. */
-	unsigned long long *look; /* [n_voices][FAST_MAX_SCAN][2][scan_groups], or NULL */
+	unsigned long long *look; /* [n_look_rows][2][scan_groups] (VoiceDesc.look_base/n_look), or NULL */
 	uint32_t look_epoch;
 	uint32_t rows_multi; /* rows per pass in the launches of the full running-sum build (kinds 1 and 2) */
 	uint32_t only_multi; /* this launch: only the voices fast_kernel<T, 2> leaves out (one wave in order, several passes) */
@@ -1664,7 +1683,7 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 				if (!(st.which & OX_VOICE)) set_level(st.out, lv, (st.flags & SF_LAYER) != 0);
 			}
 		}
-		if (P.look && !has_chain && n_scan <= FAST_MAX_SCAN) {
+		if (P.look && !has_chain && n_scan <= FAST_MAX_SCAN && n_scan <= vd.n_look) {
 			seq_kind = 3; /* one pass, any depth: prefixes by look-back */
 		} else if (multi && P.scan) {
 			seq_kind = 2;
@@ -2206,7 +2225,7 @@ __device__ __forceinline__ FastStep load_step_uniform(const FastStep *p) {
 template <int T, int SCAN, bool REPAIR = false>
 __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v, const FastInfo &fi,
 		float *slots, unsigned long long *carry, const HerpC23 *t23, const HerpC01 *t01, const int l,
-		const uint32_t wpv, const uint32_t cstart) {
+		const uint32_t wpv, const uint32_t cstart, unsigned long long *lring = nullptr) {
 	constexpr int NP = 64 * T;
 	(void)NP;
 	const uint32_t fast_total = uni(fi.total);
@@ -2229,8 +2248,14 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 	const uint32_t seq_kind = SCAN ? uni(fi.seq) : 0u;
 	const bool seq = FULL && seq_kind == 1;    /* one wave, in order */
 	const bool two = FULL && seq_kind == 2;    /* two passes, every wave */
-	const bool look = SCAN == 2 || (FULL && seq_kind == 3); /* one pass, every wave, prefixes by look-back */
-	unsigned long long *lookv = look ? P.look + (size_t)v * FAST_MAX_SCAN * 2 * P.scan_groups : nullptr;
+	const bool look = SCAN == 2;               /* one pass, every wave, prefixes by look-back (a build of its own) */
+	unsigned long long *lookv = look ? P.look + (size_t)vd.look_base * 2 * P.scan_groups : nullptr;
+	/* the single-pass build: a voice with one wave carries its sums in LDS like an in-order voice; the waves of
+	 * one workgroup look back through rings in LDS; voices spread wider go through HBM */
+	const bool look_own = SCAN == 2 && wpv == 1;
+	const bool look_lds = SCAN == 2 && lring && wpv >= 2 && wpv <= 16 && (16 % wpv) == 0;
+	const uint32_t lk_ring = 4 * wpv;
+	unsigned long long *lk_base = look_lds ? lring + (uni((uint32_t)threadIdx.x >> 6) / wpv) * lk_ring : nullptr;
 	if (seq && cstart != 0) return;
 	const uint32_t gstride = seq ? 1u : wpv;
 	unsigned long long *scan = two ? P.scan + (size_t)v * FAST_MAX_SCAN * P.scan_groups : nullptr;
@@ -2248,7 +2273,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 	/* REPAIR: the noted row groups instead of all, each evaluated FAST_REPAIR_SHIFT frames early */
 	uint32_t n_iter = REPAIR ? min(uni(rep[0]), FAST_MAX_REPAIR) : ngroups;
 	uint32_t it_lo = 0;
-	if (!REPAIR && P.range_mode != 0) {
+	if (!REPAIR && SCAN != 2 && P.range_mode != 0) { /* (the single-pass build never runs in chunks) */
 		if (seq) { if (!P.range_last) return; } /* one wave in order, carries in LDS: in the last chunk's launch, all of it */
 		else {
 			const uint32_t tc = (uint32_t)T * C;
@@ -2428,12 +2453,15 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 								unsigned long long *sums = two ? scan + (size_t)fa.pad[0] * P.scan_groups : nullptr;
 								const bool sum_me = two && P.mode == fa.pad[1]; /* this pass computes this oscillator's sums */
 								uint32_t acc;
-								if (look) {
+								if (look_own) {
+									acc = first_group ? f.phase0 : (uint32_t)carry[si];
+								} else if (look) {
 									uint32_t tot = 0;
 #pragma unroll
 									for (int k = 0; k < T; ++k)
 										tot += (uint32_t)__builtin_amdgcn_readlane((int)S[k], 63) - (uint32_t)__builtin_amdgcn_readlane((int)S[k], (int)H - 1);
-									acc = f.phase0 + lookback32(lookv + (size_t)fa.pad[0] * 2 * P.scan_groups, cg, tot, P.look_epoch, l);
+									acc = f.phase0 + (look_lds ? lookback32<true>(lk_base + (size_t)fa.pad[0] * 2 * 64, cg, tot, 0, lk_ring, l)
+									                           : lookback32<false>(lookv + (size_t)fa.pad[0] * 2 * P.scan_groups, cg, tot, P.look_epoch, 0, l));
 								} else {
 									acc = two ? (sum_me ? 0u : f.phase0 + (uint32_t)sums[cg])
 									          : (first_group ? f.phase0 : (uint32_t)carry[si]);
@@ -2450,7 +2478,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 										if (l == 0) sums[cg] = (unsigned long long)acc;
 										continue;
 									}
-								} else if (!look && l == 0) {
+								} else if ((!look || look_own) && l == 0) {
 									carry[si] = (unsigned long long)acc;
 								}
 							}
@@ -2462,10 +2490,12 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 #pragma unroll
 							for (int k = 0; k < T; ++k) { ph[k] = acc; acc += row_inc; fv[k] = f.fc; }
 						}
-						uint32_t phu[SCAN ? T : 1]; /* accumulator values, before modulation */
-						if (SCAN) {
+						if (SCAN && is_last_group) { /* the accumulator after the segment's last frame, before modulation */
 #pragma unroll
-							for (int k = 0; k < T; ++k) phu[SCAN ? k : 0] = ph[k];
+							for (int k = 0; k < T; ++k) {
+								const int t = t0 + k * (int)C;
+								if (t == (int)fast_total - 1 && l >= (int)H) P.ops[f.gop].st_phase = ph[k];
+							}
 						}
 						if (has_pm && !has_fpm) {
 							float pm[T];
@@ -2517,7 +2547,6 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 								if (l >= (int)H && t >= 0 && t < (int)fast_total) {
 									((u32_alias *)brow)[t] = ph[k];
 									arow[t] = a;
-									if (t == (int)fast_total - 1) P.ops[f.gop].st_phase = phu[SCAN ? k : 0];
 								}
 							}
 							continue;
@@ -2608,7 +2637,6 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 								const int t = t0 + k * (int)C;
 								if (t == (int)fast_total - 1 && l >= (int)H) {
 									DevOp &o = P.ops[f.gop];
-									if (SCAN) o.st_phase = phu[SCAN ? k : 0];
 									o.st_prev_phase = ph[k];
 									o.st_prev_Is = Is[k];
 									o.st_prev_s = s[k];
@@ -2664,12 +2692,19 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 							unsigned long long *sums = two ? scan + (size_t)fa.pad[0] * P.scan_groups : nullptr;
 							const bool sum_me = two && P.mode == fa.pad[1];
 							unsigned long long acc;
-							if (look) {
+							if (look_own) {
+								acc = first_group ? cp0 : carry[si];
+							} else if (look) {
 								unsigned long long tot = 0;
 #pragma unroll
 								for (int k = 0; k < T; ++k) tot += readlane64(S[k], 63) - readlane64(S[k], (int)H - 1);
-								unsigned long long *e_lo = lookv + (size_t)fa.pad[0] * 2 * P.scan_groups;
-								acc = cp0 + lookback64(e_lo, e_lo + P.scan_groups, cg, tot, P.look_epoch, l);
+								if (look_lds) {
+									unsigned long long *e_lo = lk_base + (size_t)fa.pad[0] * 2 * 64;
+									acc = cp0 + lookback64<true>(e_lo, e_lo + 64, cg, tot, 0, lk_ring, l);
+								} else {
+									unsigned long long *e_lo = lookv + (size_t)fa.pad[0] * 2 * P.scan_groups;
+									acc = cp0 + lookback64<false>(e_lo, e_lo + P.scan_groups, cg, tot, P.look_epoch, 0, l);
+								}
 							} else {
 								acc = two ? (sum_me ? 0ull : cp0 + sums[cg])
 								          : (first_group ? cp0 : carry[si]);
@@ -2686,7 +2721,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 									if (l == 0) sums[cg] = acc;
 									continue;
 								}
-							} else if (!look && l == 0) {
+							} else if ((!look || look_own) && l == 0) {
 								carry[si] = acc;
 							}
 							if (is_last_group) { /* the counter after the segment's last frame */
@@ -2870,6 +2905,12 @@ __global__ void __launch_bounds__(1024, FK_MINB) fast_kernel(FastParams P) {
 	const size_t area_bytes = (size_t)P.n_fast * NP * sizeof(float) + (size_t)P.max_steps * sizeof(unsigned long long);
 	float *slots = (float *)(areas + (size_t)w * area_bytes) + l; /* lane's column of every row */
 	unsigned long long *carry = (unsigned long long *)(areas + (size_t)w * area_bytes + (size_t)P.n_fast * NP * sizeof(float)); /* per step */
+	unsigned long long *lring = nullptr; /* the single-pass build: look-back rings after the waves' areas, zeroed */
+	if (SCAN == 2) {
+		lring = (unsigned long long *)(areas + (size_t)W * area_bytes);
+		lring[tid] = 0;
+		static_assert(LOOK_LDS_BYTES == 1024 * sizeof(unsigned long long), "one word per thread");
+	}
 
 	for (uint32_t t = 0; t < P.n_tabs; ++t) {
 		const uint32_t wave = P.wave_of_tab[t];
@@ -2899,11 +2940,11 @@ __global__ void __launch_bounds__(1024, FK_MINB) fast_kernel(FastParams P) {
 			continue; /* the chain-input pass only concerns voices with feedback chains */
 		if (SCAN == 2) { /* the other kinds of running-sum voice have a launch of the full build to themselves */
 			if (seq_kind == 1 || seq_kind == 2) continue;
-			if (seq_kind == 3) fast_voice<T, 2>(P, v, fi, slots, carry, t23, t01, l, wpv, cstart);
+			if (seq_kind == 3) fast_voice<T, 2>(P, v, fi, slots, carry, t23, t01, l, wpv, cstart, total_waves >= NV ? lring : nullptr);
 			else fast_voice<T, 0>(P, v, fi, slots, carry, t23, t01, l, wpv, cstart);
 			continue;
 		}
-		if (SCAN == 1 && P.only_multi && seq_kind != 1 && seq_kind != 2) continue;
+		if (SCAN == 1 && (P.only_multi ? (seq_kind != 1 && seq_kind != 2) : seq_kind == 3)) continue;
 		if (SCAN && seq_kind != 0) fast_voice<T, 1>(P, v, fi, slots, carry, t23, t01, l, wpv, cstart);
 		else fast_voice<T, 0>(P, v, fi, slots, carry, t23, t01, l, wpv, cstart);
 	}
@@ -3890,10 +3931,9 @@ public:
 			uint32_t FT = fast_rows_;
 			/* The build with all the running-sum code needs more registers: 8 rows per pass would spill. Where the
 			 * single-pass (look-back) build serves, it takes those voices and the closed-form ones at the full rows
-			 * per pass, and the full build gets a launch for what is left (voices one wave walks in order);
-			 * segments with feedback chains go through the full build alone. */
-			const bool look_split = seq_enabled_ && seg.may_scan && two_pass_enabled_ && lookback_enabled_ && look_rows_ != 0 &&
-				!(chain_enabled_ && seg.serial && seg.n_chain_rows && seg.len <= sauengine::CHAIN_SEG);
+			 * per pass, and the full build's launches only see what is left (voices with feedback chains, voices
+			 * one wave walks in order). */
+			const bool look_split = seq_enabled_ && seg.may_scan && two_pass_enabled_ && lookback_enabled_ && look_rows_ != 0;
 			if (seq_enabled_ && seg.may_scan && FT > 4 && !look_split) FT = 4;
 			if (look_split && FT > look_rows_) FT = look_rows_ >= 8 ? 8 : look_rows_ >= 4 ? 4 : 2;
 			/* block buffers: without frequency blocks, or with them when some voice may need
@@ -3904,9 +3944,17 @@ public:
 				return (size_t)n_fast * 64 * t * sizeof(float) + (size_t)fmax_steps * sizeof(unsigned long long);
 			};
 			const size_t one_tab = seg.wave_mask ? tab_bytes : 0;
-			while (FT > 2 && 16 * area_of(FT) + one_tab + 1024 > lds_limit_) FT /= 2;
+			const size_t look_lds = look_split ? LOOK_LDS_BYTES : 0;
+			while (FT > 2 && 16 * area_of(FT) + one_tab + look_lds + 1024 > lds_limit_) FT /= 2;
+			{ /* every wave table the segment uses in LDS is worth more than rows per pass (an oscillator whose table
+			   * is left out reads it from L2 per sample): fewer rows where that makes them all fit */
+				const size_t need = (size_t)__builtin_popcount(seg.wave_mask) * tab_bytes + look_lds + 1024;
+				uint32_t t = FT;
+				while (t > 4 && 16 * area_of(t) + need > lds_limit_) t /= 2; /* (but not below 4 rows: that costs more) */
+				if (16 * area_of(t) + need <= lds_limit_) FT = t;
+			}
 			const size_t area = area_of(FT);
-			const bool use_fast = fast_enabled_ && (16 * area + 1024 <= lds_limit_);
+			const bool use_fast = fast_enabled_ && (16 * area + look_lds + 1024 <= lds_limit_);
 			const uint32_t FTM = FT > 4 && seq_enabled_ && seg.may_scan ? 4 : FT; /* rows per pass of the full build */
 			if (!finfo_.ensure(seg.n_voices, err) || !fdone_.ensure(seg.n_voices, err) ||
 			    !worklist_.ensure(seg.n_voices, err) || !work_count_.ensure(4, err) ||
@@ -3927,10 +3975,10 @@ public:
 				fp.scan_groups = seg.len / (32 * FTM) + 2;
 				if (!scan_.ensure((size_t)seg.n_voices * FAST_MAX_SCAN * fp.scan_groups, err)) return false;
 				fp.scan = scan_.p;
-				if (lookback_enabled_) {
+				if (look_split && seg.n_look_rows) {
 					/* look-back words: valid for this segment's epoch only, so a fresh block starts out zeroed */
 					const unsigned long long *before = look_.p;
-					if (!look_.ensure((size_t)seg.n_voices * FAST_MAX_SCAN * 2 * fp.scan_groups, err)) return false;
+					if (!look_.ensure((size_t)seg.n_look_rows * 2 * fp.scan_groups, err)) return false;
 					if (look_.p != before || look_epoch_ >= (1u << 30) - 1) {
 						HIP_OK(hipMemsetAsync(look_.p, 0, look_.cap * sizeof(unsigned long long), stream_));
 						look_epoch_ = 0;
@@ -3950,7 +3998,10 @@ public:
 			fp.max_ops = seg.max_ops; fp.max_steps = fmax_steps; fp.np = 64; fp.rows = FT; fp.rows_multi = FTM;
 			fp.enable = use_fast ? 1u : 0u;
 			/* saved phase increments of running-sum oscillators (sum pass -> final pass), one segment long */
-			if (inc_rows_enabled_ && use_fast && fp.scan && seg.n_inc_rows && seg.len <= sauengine::CHAIN_SEG) {
+			/* (only voices that take several passes use them -- with look-back those with feedback chains -- and a
+			 * bank of thousands of those would ask for gigabytes: beyond 1 GiB the final pass recomputes instead) */
+			if (inc_rows_enabled_ && use_fast && fp.scan && seg.n_inc_rows && seg.len <= sauengine::CHAIN_SEG &&
+			    (size_t)seg.n_inc_rows * 2 * ((seg.len + 63) & ~63u) * sizeof(uint32_t) <= ((size_t)1 << 30)) {
 				const uint32_t istride = (seg.len + 63) & ~63u;
 				if (!inc_rows_.ensure((size_t)seg.n_inc_rows * 2 * istride + 64, err)) return false;
 				fp.inc_rows = inc_rows_.p; fp.inc_stride = istride; fp.n_inc_rows = seg.n_inc_rows;
@@ -3983,7 +4034,7 @@ public:
 			for (int wv = 0; wv < 12; ++wv) {
 				fp.tab_of_wave[wv] = -1;
 				if (use_fast && ((seg.wave_mask >> wv) & 1) &&
-				    16 * area + (ft + 1) * tab_bytes + 1024 <= lds_limit_) {
+				    16 * area + look_lds + (ft + 1) * tab_bytes + 1024 <= lds_limit_) {
 					fp.tab_of_wave[wv] = (int8_t)ft;
 					fp.wave_of_tab[ft] = (uint8_t)wv;
 					++ft;
@@ -4006,7 +4057,7 @@ public:
 				static size_t fconfigured[16][3][3];
 				auto launch_build = [&](int build, uint32_t rows, uint32_t grid) -> bool {
 					const int ri = rows == 8 ? 2 : rows == 4 ? 1 : 0;
-					const size_t lds = ft * tab_bytes + 16 * area_of(rows);
+					const size_t lds = ft * tab_bytes + 16 * area_of(rows) + (build == 2 ? LOOK_LDS_BYTES : 0);
 					size_t &conf = fconfigured[dev_ & 15][build][ri];
 					if (lds > conf) {
 						HIP_OK(hipFuncSetAttribute(fkernels[build][ri], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -4029,18 +4080,23 @@ public:
 				if (tf) (void)hipEventRecord(tf->a, stream_);
 				bool launched = true;
 				auto launch_fast = [&](uint32_t mode, uint32_t grid = 0) {
-					fp.mode = mode; fp.only_multi = 0;
-					if (!launch_build(main_build, FT, grid ? grid : fgrid)) launched = false;
+					fp.mode = mode;
 					if (main_build == 2) { /* what the single-pass build leaves out: returns at once when there is none */
 						fp.only_multi = 1;
 						if (!launch_build(1, FTM, grid ? grid : fgrid)) launched = false;
 						fp.only_multi = 0;
+					} else if (!launch_build(main_build, FT, grid ? grid : fgrid)) {
+						launched = false;
 					}
 				};
+				if (main_build == 2) { /* closed-form and single-pass voices: one launch, whole segment */
+					fp.mode = fp.sum_levels + 1; fp.only_multi = 0;
+					if (!launch_build(2, FT, fgrid)) launched = false;
+				}
 				if (fp.scan) {
 					/* some voice may have running-sum phases: sums per row group, their prefixes, final pass */
-					/* (with look-back only voices with feedback chains still take sum passes) */
-					for (uint32_t pass = 1; pass <= fp.sum_levels && !(fp.look && !fp.chain_rows); ++pass) {
+					/* (with look-back only voices that have, or may get, feedback chains still take sum passes) */
+					for (uint32_t pass = 1; pass <= fp.sum_levels && (!fp.look || seg.n_chain_rows); ++pass) {
 						launch_fast(pass);
 						hipLaunchKernelGGL(scan_kernel, dim3(seg.n_voices), dim3(64), 0, stream_, fp);
 					}

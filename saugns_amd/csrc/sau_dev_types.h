@@ -238,6 +238,7 @@ struct VoiceDesc {
 	Lattice lat;                 /* where the reference's blocks lie in this segment, for the voice's program */
 	uint32_t chain_base, n_chain;/* row pairs for its self-modulated oscillators (step_may_chain steps, in plan order) */
 	uint32_t inc_base, n_inc;    /* row pairs for saved phase increments of its oscillator steps (in plan order), or n_inc = 0 */
+	uint32_t look_base, n_look;  /* look-back rows for its running-sum oscillators (a voice without feedback chains), or n_look = 0 */
 };
 
 enum : uint32_t {
