@@ -2397,38 +2397,62 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 							fvar = (fa.flags & (FA_FVAR_SLOT | FA_FVAR_LINE)) != 0;
 							if (fvar) {
 								uint32_t S[T];
+								auto freq_at = [&](int k, int t) -> float { /* the frequency at row k's frame t */
+									if (fa.flags & FA_FVAR_SLOT) return slots[fa.freq_off + k * 64];
+									float v = fast_line_value(fa.fl, t);
+									const bool in_goal = (uint32_t)t < fa.fl.goal_len;
+									if (fa.flags & (in_goal ? FA_MUL_GOAL : FA_MUL_HOLD))
+										v *= fa.fmul_off != ~0u ? slots[fa.fmul_off + k * 64] : fa.mulc;
+									return v;
+								};
 								/* saved increments (FastParams.inc_rows): written by the sum pass of this oscillator's
 								 * level, read back by the final pass in place of the frequency */
 								uint32_t *irow = (FULL && (fa.pad[2] & 2u)) ? P.inc_rows + (size_t)2 * (fa.pad[2] >> 8) * P.inc_stride : nullptr;
 								const bool inc_read = irow && P.mode == P.sum_levels + 1;
 								const bool inc_write = irow && two && P.mode == fa.pad[1];
+								if (FULL) {
 #pragma unroll
-								for (int k = 0; k < T; ++k) {
-									const int t = t0 + k * (int)C;
-									uint32_t r;
-									if (inc_read) {
-										r = (t >= 0 && t < (int)fast_total) ? irow[t] : 0u;
-										fv[k] = 0.f; /* (only frequency-scaled PM reads it, and such oscillators save nothing) */
-									} else {
-									float v;
-									if (fa.flags & FA_FVAR_SLOT) {
-										v = slots[fa.freq_off + k * 64];
-									} else {
-										v = fast_line_value(fa.fl, t);
-										const bool in_goal = (uint32_t)t < fa.fl.goal_len;
-										if (fa.flags & (in_goal ? FA_MUL_GOAL : FA_MUL_HOLD))
-											v *= fa.fmul_off != ~0u ? slots[fa.fmul_off + k * 64] : fa.mulc;
+									for (int k = 0; k < T; ++k) {
+										const int t = t0 + k * (int)C;
+										uint32_t r;
+										if (inc_read) {
+											r = (t >= 0 && t < (int)fast_total) ? irow[t] : 0u;
+											fv[k] = 0.f; /* (only frequency-scaled PM reads it, and such oscillators save nothing) */
+										} else {
+											const float v = freq_at(k, t);
+											fv[k] = v;
+											const float x = fa.coeff * v;
+											/* llrintf(x) mod 2^32 (wosc.h:145): adding 1.5 * 2^52 in f64 rounds to the nearest
+											 * integer and leaves it in the low word; exact while |x| < 2^51 */
+											r = fabsf(x) < 0x1p50f ? (uint32_t)__double2loint((double)x + 0x1.8p52) : rint32w(x);
+											if (inc_write && l >= (int)H && t >= 0 && t < (int)fast_total) irow[t] = r;
+										}
+										const uint32_t inc = (t >= 0 && t < (int)fast_total) ? r : 0u;
+										if (chain && fa.pad[2]) S[k] = inc; /* chain_kernel does the summing */
+										else S[k] = wave_incl_scan_dpp(inc);
 									}
-									fv[k] = v;
-									const float x = fa.coeff * v;
-									/* llrintf(x) mod 2^32 (wosc.h:145): adding 1.5 * 2^52 in f64 rounds to the nearest
-									 * integer and leaves it in the low word; exact while |x| < 2^51 */
-									r = fabsf(x) < 0x1p50f ? (uint32_t)__double2loint((double)x + 0x1.8p52) : rint32w(x);
-									if (inc_write && l >= (int)H && t >= 0 && t < (int)fast_total) irow[t] = r;
+								} else { /* the single-pass build: one test per group for the rounding form */
+									float x[T];
+									bool big = false;
+#pragma unroll
+									for (int k = 0; k < T; ++k) {
+										fv[k] = freq_at(k, t0 + k * (int)C);
+										x[k] = fa.coeff * fv[k];
+										big |= !(fabsf(x[k]) < 0x1p50f);
 									}
-									const uint32_t inc = (t >= 0 && t < (int)fast_total) ? r : 0u;
-									if (chain && fa.pad[2]) S[k] = inc; /* chain_kernel does the summing */
-									else S[k] = wave_incl_scan_dpp(inc);
+									uint32_t r[T];
+									if (!__any(big)) {
+#pragma unroll
+										for (int k = 0; k < T; ++k) r[k] = (uint32_t)__double2loint((double)x[k] + 0x1.8p52);
+									} else {
+#pragma unroll
+										for (int k = 0; k < T; ++k) r[k] = rint32w(x[k]);
+									}
+#pragma unroll
+									for (int k = 0; k < T; ++k) {
+										const int t = t0 + k * (int)C;
+										S[k] = wave_incl_scan_dpp((t >= 0 && t < (int)fast_total) ? r[k] : 0u);
+									}
 								}
 								if (chain && fa.pad[2]) {
 									/* chain-input pass of a chain that accumulates its own phase: increments and amounts */
