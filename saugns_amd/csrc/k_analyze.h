@@ -1,0 +1,406 @@
+/* k_analyze.h -- part of hip_backend.hip (included there, inside namespace sauhip; not a header of its own).
+ * analyze_kernel: which voices the time-parallel path takes this segment, and in which form. */
+
+/* a W oscillator step whose self-modulation is on (generator.c:479-498, wosc.h:273-310): chain_kernel's */
+__device__ __forceinline__ bool step_is_chain(const Step &st, const DevOp &o) {
+	return !o.rt_frozen && step_may_chain(st) && o.type == OT_WAVE &&
+		(st.sm != NO_SLOT || o.line[L_PMA].v0 != 0.f || (o.line[L_PMA].flags & LP_GOAL));
+}
+/* ... and whose varying frequency is its only phase input: chain_kernel sums the phase increments itself
+ * (a sum pass and a scan less), the chain-input pass hands it increments instead of base phases */
+__device__ __forceinline__ bool step_is_chain_acc(const Step &st, const DevOp &o) {
+	return step_is_chain(st, o) && !o.rt_fconst_valid && st.pm == NO_SLOT && st.fpm == NO_SLOT;
+}
+
+/* ... and all of whose inputs are its own lines: a frequency that is one value, or its frequency line alone
+ * (times a parent frequency that is one value) with nothing added into its block, amounts from its pm_a line.
+ * chain_kernel's feeder wave evaluates those itself; the chain-input pass has nothing to do for it.
+ * line_step: the plan index of the ST_LINE step that fills its frequency block, or ~0u. */
+__device__ __forceinline__ bool step_is_chain_inline(bool enabled, const Step *plan, uint32_t si, const uint32_t *ids, const DevOp *ops,
+		uint32_t *line_step) {
+	if (!enabled) { *line_step = ~0u; return false; }
+	const Step st = plan[si];
+	const DevOp &o = ops[ids[st.op]];
+	*line_step = ~0u;
+	if (!step_is_chain(st, o) || st.pm != NO_SLOT || st.fpm != NO_SLOT || st.sm != NO_SLOT) return false;
+	if (o.rt_fconst_valid) return true;
+	uint32_t fmul = st.fmul, prov = st.prov;
+	if (st.freq != NO_SLOT) {
+		uint32_t q = si;
+		bool found = false;
+		while (q-- > 0) { /* its block: written by its own line step and by nothing since */
+			const Step sq = plan[q];
+			if (sq.kind == ST_LINE && sq.which == L_FREQ && sq.op == st.op && sq.out == st.freq) { found = true; break; }
+			if ((sq.kind == ST_OSC || sq.kind == ST_LERP || sq.kind == ST_LINE || sq.kind == ST_SMLINE) && sq.out == st.freq) return false;
+		}
+		if (!found) return false;
+		*line_step = q;
+		fmul = plan[q].fmul; prov = plan[q].prov;
+	}
+	if (fmul != NO_SLOT) { /* a ratio of the parent's frequency: only when that is one value */
+		const LineState &fl = o.line[L_FREQ];
+		const bool ratio = (fl.flags & LP_STATE_RATIO) || ((fl.flags & LP_GOAL) && (fl.flags & LP_GOAL_RATIO));
+		if (ratio && !(prov != NO_SLOT && ops[ids[prov]].rt_fconst_valid)) return false;
+	}
+	return true;
+}
+
+/* the operator whose frequency line most recently filled block `slot` before step si (0xff: none) */
+__device__ __forceinline__ uint32_t block_owner(const Step *plan, uint32_t si, uint32_t slot) {
+	for (uint32_t q = si; q-- > 0;) {
+		const Step sq = plan[q];
+		if (sq.kind == ST_LINE && sq.which == L_FREQ && sq.out == slot) return sq.op;
+	}
+	return 0xff;
+}
+
+/* does voice-local operator `op` take frequency-scaled phase modulation? */
+__device__ __forceinline__ bool op_has_fpm(const Step *plan, uint32_t n, uint32_t op) {
+	for (uint32_t q = 0; q < n; ++q) {
+		const Step sq = plan[q];
+		if (sq.kind == ST_OSC && sq.op == op) return sq.fpm != NO_SLOT;
+	}
+	return false;
+}
+
+__global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
+	const uint32_t v = blockIdx.x * 64 + threadIdx.x;
+	if (v == 0) *P.work_count = 0; /* finalize_kernel (a later launch) builds the block loop's work list */
+	if (v >= P.n_voices) return;
+	const VoiceDesc vd = P.voices[v];
+	const uint32_t *ids = P.op_ids + vd.ops_ofs;
+	bool bad = (vd.flags & VD_NO_FAST) != 0 || !P.enable;
+	bool seq = false;
+	uint32_t min_time = 0xFFFFFFFFu;
+	const Step *plan = P.steps + vd.plan_ofs;
+	/* An operator that has run out of time yields nothing, and neither it nor
+	 * anything nested in it advances (run_block gives its subtree zero
+	 * length, generator.c:686-700): such subtrees are left out below. */
+	for (uint32_t i = 0; i < vd.nops; ++i) P.ops[ids[i]].rt_frozen = 0;
+	if (P.chain_desc)
+		for (uint32_t k = 0; k < vd.n_chain; ++k) /* ChainDesc.n (its first word; the type is defined further down) */
+			((uint32_t *)P.chain_desc)[(size_t)(vd.chain_base + k) * CHAIN_DESC_WORDS] = 0;
+	const bool chain_ok = P.chain_rows != nullptr && P.scan != nullptr;
+	bool has_chain = false;
+	{
+		uint32_t dep = 0, frozen_at = 0;
+		for (uint32_t si = 0; si < vd.plan_len; ++si) {
+			const Step st = plan[si];
+			DevOp &o = P.ops[ids[st.op]];
+			if (st.flags & SF_BEGIN) {
+				++dep;
+				if (!frozen_at && !(o.flags & OPF_TIME_INF) && o.time == 0) frozen_at = dep;
+			}
+			if (frozen_at) o.rt_frozen = 1;
+			if (st.flags & SF_END) {
+				if (dep == frozen_at) frozen_at = 0;
+				--dep;
+			}
+		}
+	}
+	if (P.ops[ids[vd.carr_local]].rt_frozen) bad = true; /* the voice is over (generator.c:839) */
+	for (uint32_t i = 0; i < vd.nops; ++i) {
+		DevOp &o = P.ops[ids[i]];
+		if (o.rt_frozen) continue;
+		/* ramps in progress: amplitude lines are closed-form per frame (sau/line.c
+		 * fills depend on the position only); frequency ramps need a phase scan,
+		 * self-modulation and pan ramps stay with the block loop */
+		for (uint32_t ln = 0; ln < L_COUNT; ++ln) {
+			if (!(o.line[ln].flags & LP_GOAL)) continue;
+			if (ln == L_FREQ || ln == L_FREQ2) seq = true; /* phase becomes a running sum */
+			else if (ln == L_PAN) { /* fine when the plan gives the pan line a step of its own */
+				if (!(vd.plan_len && plan[vd.plan_len - 1].kind == ST_VOICE)) bad = true;
+			} else if (ln == L_PMA) { if (!(chain_ok && o.type == OT_WAVE)) bad = true; }
+			else if (ln != L_AMP && ln != L_AMP2) bad = true;
+		}
+		if (o.type == OT_NOISE && o.wave == NZ_re) bad = true;
+		/* self-modulation is a recurrence: W oscillators' go to chain_kernel, R's to the block loop */
+		if (o.line[L_PMA].v0 != 0.f && !(chain_ok && o.type == OT_WAVE)) bad = true;
+		if (o.type == OT_WAVE) o.ras_level = 0; /* (CHAIN_MARK of an earlier segment) */
+		o.rt_fconst_valid = 0;
+		o.rt_fblk_valid = 0;
+		o.st_phase = 0; /* until the kernels stage into it: see "modulated blocks" below */
+		o.st_prev_phase = 0; /* likewise: extra lead-in of the operator while this kernel and decode_kernel run */
+		if (!(o.flags & OPF_TIME_INF) && o.time < min_time) min_time = o.time;
+	}
+	uint32_t depth = 0, maxd = 0;
+	/* Extra lead-in per block buffer, over what its writer's nesting depth gives: contents exact
+	 * from lane H - depth + 1 + extra. 0..7 in three bit planes over the 256 buffer ids. It
+	 * arises where a ratio frequency multiplies by a modulated frequency block written at a
+	 * smaller depth than the reader's (see "modulated block" below) and travels up the
+	 * operator tree with the data. */
+	unsigned long long x0[4] = {0, 0, 0, 0}, x1[4] = {0, 0, 0, 0}, x2[4] = {0, 0, 0, 0};
+	auto extra_of = [&](uint32_t sl) -> uint32_t {
+		if (sl == NO_SLOT) return 0;
+		const uint32_t q = sl >> 6, sh = sl & 63;
+		const unsigned long long a = q == 0 ? x0[0] : q == 1 ? x0[1] : q == 2 ? x0[2] : x0[3];
+		const unsigned long long b = q == 0 ? x1[0] : q == 1 ? x1[1] : q == 2 ? x1[2] : x1[3];
+		const unsigned long long c = q == 0 ? x2[0] : q == 1 ? x2[1] : q == 2 ? x2[2] : x2[3];
+		return (uint32_t)((a >> sh) & 1ull) | ((uint32_t)((b >> sh) & 1ull) << 1) | ((uint32_t)((c >> sh) & 1ull) << 2);
+	};
+	auto set_extra = [&](uint32_t sl, uint32_t x, bool keep_max) {
+		if (sl == NO_SLOT) return;
+		if (keep_max) { const uint32_t old = extra_of(sl); if (old > x) x = old; }
+		const unsigned long long bit = 1ull << (sl & 63);
+#pragma unroll
+		for (int q = 0; q < 4; ++q)
+			if ((int)(sl >> 6) == q) {
+				x0[q] = (x0[q] & ~bit) | ((x & 1) ? bit : 0ull);
+				x1[q] = (x1[q] & ~bit) | ((x & 2) ? bit : 0ull);
+				x2[q] = (x2[q] & ~bit) | ((x & 4) ? bit : 0ull);
+			}
+	};
+	uint32_t x_carrier = 0;
+	for (uint32_t si = 0; si < vd.plan_len && !bad; ++si) {
+		const Step st = plan[si];
+		DevOp &o = P.ops[ids[st.op]];
+		if (o.rt_frozen) { /* nesting still counts: depths of live steps stay what they are */
+			if (st.flags & SF_BEGIN) ++depth;
+			if (st.flags & SF_END) --depth;
+			continue;
+		}
+		if (st.flags & SF_BEGIN) { ++depth; if (depth > maxd) maxd = depth; }
+		const bool is_osc = o.type == OT_WAVE || o.type == OT_RASEG;
+		const bool freq_here = (st.kind == ST_LINE && st.which == L_FREQ) ||
+			(st.kind == ST_OSC && st.freq == NO_SLOT && is_osc);
+		if (st.kind == ST_ZERO) bad = true;
+		if (st.kind == ST_SMLINE && !(chain_ok && o.type == OT_WAVE)) bad = true;
+		if (st.kind == ST_OSC && st.sm != NO_SLOT && !(chain_ok && o.type == OT_WAVE)) bad = true;
+		if (step_may_chain(st) && o.type == OT_WAVE &&
+		    (st.sm != NO_SLOT || o.line[L_PMA].v0 != 0.f || (o.line[L_PMA].flags & LP_GOAL)))
+			has_chain = true;
+		/* a ratio line (sau/line.c:72) multiplies by the parent's frequency: one value, or a block */
+		bool pconst = false; float pf = 0.f;
+		if (st.fmul != NO_SLOT && st.fmul >= FSLOT_BASE) {
+			/* the parent's frequency block as it stands when this step reads it: one value if
+			 * the parent's line is held and nothing has been added into the block yet (the
+			 * first FM modulator of a plain carrier sees exactly that, generator.c:448-477) */
+			const uint32_t ow = block_owner(plan, si, st.fmul);
+			if (ow != 0xff) {
+				const DevOp &po = P.ops[ids[ow]];
+				pconst = po.rt_fblk_valid != 0; pf = po.rt_fconst;
+			} else if (st.prov != NO_SLOT) {
+				const DevOp &po = P.ops[ids[st.prov]];
+				pconst = po.rt_fconst_valid != 0; pf = po.rt_fconst;
+			}
+		}
+		/* Anything added into a frequency block makes it per-frame: a modulated block. Its
+		 * contents are exact only from the lane its writers are (nesting depth wd: lane
+		 * H - wd + 1). Whoever multiplies by it -- ratio lines of operators nested in its
+		 * owner, directly or through blocks derived from it -- must not need it earlier:
+		 * a reader at depth d sums increments from lane H - d + 1 on (one earlier when it
+		 * scales a phase modulator by its frequency). A deeper reader gets that many lanes of
+		 * extra lead-in (and so does everything that consumes its output, up to the carrier:
+		 * the voice's rows get H + extra lead-in lanes).
+		 * (st_phase holds wd while this kernel runs; 0: not a modulated block.) */
+		uint32_t x_step = 0; /* this step's output: extra lead-in of what it reads */
+		if (st.kind == ST_LERP) x_step = extra_of(st.freq) > extra_of(st.pm) ? extra_of(st.freq) : extra_of(st.pm);
+		if ((st.kind == ST_OSC || st.kind == ST_LERP) && st.out != NO_SLOT && st.out >= FSLOT_BASE) {
+			const uint32_t ow = block_owner(plan, si, st.out);
+			if (ow != 0xff) {
+				DevOp &oo = P.ops[ids[ow]];
+				oo.rt_fblk_valid = 0;
+				const uint32_t wd = st.kind == ST_OSC ? depth : depth + 1;
+				if (oo.st_phase == 0 || wd < oo.st_phase) oo.st_phase = wd;
+			}
+		}
+		if (st.kind == ST_LINE || freq_here) {
+			const LineState &ls = o.line[st.kind == ST_LINE ? st.which : L_FREQ];
+			const bool g_ratio = (ls.flags & LP_GOAL_RATIO) != 0, s_ratio = (ls.flags & LP_STATE_RATIO) != 0;
+			if (st.fmul != NO_SLOT) {
+				/* a ramp whose goal and state disagree about being ratios rescales its
+				 * state by the parent's first sample (sau/line.c:358-370): block loop */
+				if ((ls.flags & LP_GOAL) && g_ratio != s_ratio) {
+					/* fine when the parent's frequency is one value for the segment: decode_kernel and
+					 * finalize_kernel then apply the rescaling with it */
+					const bool parent_const = st.prov != NO_SLOT && P.ops[ids[st.prov]].rt_fconst_valid != 0;
+					if (!parent_const) bad = true;
+				}
+				if ((s_ratio || ((ls.flags & LP_GOAL) && g_ratio)) && !pconst) {
+					seq = true;
+					if (st.fmul >= FSLOT_BASE) {
+						const uint32_t ow = block_owner(plan, si, st.fmul);
+						const uint32_t wd = ow != 0xff ? P.ops[ids[ow]].st_phase : 0u;
+						if (wd) {
+							const uint32_t need = depth + (op_has_fpm(plan, vd.plan_len, st.op) ? 1u : 0u);
+							/* the block is exact from lane H - wd + 1 + its own extra; this reader
+							 * would sum from lane H - need + 1 */
+							x_step = (need > wd ? need - wd : 0u) + extra_of(st.fmul);
+							/* this operator's own block derives from the modulated one */
+							if (st.kind == ST_LINE && st.which == L_FREQ && (o.st_phase == 0 || wd < o.st_phase))
+								o.st_phase = wd;
+						}
+					}
+				}
+			}
+		}
+		if (freq_here && !bad) {
+			const LineState &fl = o.line[L_FREQ];
+			/* one value for the segment? (the block loop's const_freq) */
+			bool isconst = !(fl.flags & LP_GOAL) && !(st.kind == ST_LINE && (st.flags & SF_FORCE));
+			float fc = fl.v0;
+			if (st.fmul != NO_SLOT && (fl.flags & LP_STATE_RATIO)) {
+				if (pconst) fc = fl.v0 * pf; /* sau/line.c:72 */
+				else isconst = false;
+			}
+			o.rt_fconst = fc;
+			o.rt_fconst_valid = isconst ? 1u : 0u;
+			/* the block itself (before modulators are added) holds one value? */
+			o.rt_fblk_valid = (isconst || (st.kind == ST_LINE && (st.flags & SF_FORCE) && !(fl.flags & LP_GOAL) &&
+					!((fl.flags & LP_STATE_RATIO) && st.fmul != NO_SLOT && !pconst))) ? 1u : 0u;
+			if (!isconst) seq = true;
+		}
+		if (st.kind == ST_OSC && is_osc && st.freq != NO_SLOT && !o.rt_fconst_valid) seq = true;
+		/* extra lead-in: what this step reads, what its own ratio frequency needs, to what it writes */
+		if (st.kind == ST_LINE) {
+			/* the block made here is as exact as the one it multiplies by; what the operator itself
+			 * needs on top waits in st_prev_phase for its oscillator step */
+			if (x_step > 7) bad = true;
+			set_extra(st.out, extra_of(st.fmul), false);
+			if (st.which == L_FREQ) o.st_prev_phase = x_step;
+		} else if (st.kind == ST_LERP) {
+			if (x_step > 7) bad = true;
+			set_extra(st.out, x_step, true);
+		} else if (st.kind == ST_OSC) {
+			uint32_t x = x_step > o.st_prev_phase ? x_step : o.st_prev_phase; /* its own frequency's need */
+			const uint32_t in[5] = {extra_of(st.freq), extra_of(st.pm), extra_of(st.fpm), extra_of(st.amp), extra_of(st.sm)};
+#pragma unroll
+			for (int k = 0; k < 5; ++k) if (in[k] > x) x = in[k];
+			if (x > 7) bad = true;
+			o.st_prev_phase = x; /* for decode_kernel (the kernels stage into this field only later) */
+			if (st.op == vd.carr_local) x_carrier = x;
+			if (!(st.which & OX_VOICE)) set_extra(st.out, x, (st.flags & SF_LAYER) != 0 || st.out >= FSLOT_BASE);
+		} else if (st.kind == ST_VOICE) {
+			const uint32_t x = extra_of(st.out) > extra_of(st.pm) ? extra_of(st.out) : extra_of(st.pm);
+			if (x > x_carrier) x_carrier = x;
+		}
+		if (st.flags & SF_END) --depth;
+	}
+	/* Two passes suffice when no running sum depends on another one: the per-frame
+	 * increments of every such oscillator (its frequency inputs) must not depend on
+	 * the output of an oscillator whose phase is itself a running sum. Forward
+	 * data-flow over the block buffers ("tainted" = depends on such an output). */
+	/* Several passes instead of one wave in order: a running sum can be computed by all
+	 * waves once the sums it depends on are known. Level 1: its per-frame increments (its
+	 * frequency inputs) depend on no other running-sum oscillator's output; level n + 1:
+	 * they depend on level-n outputs. Forward data-flow over the block buffers, two bits
+	 * per buffer: the deepest level its contents depend on. */
+	/* Feedback chains: the recurrence's inputs (frequency, phase modulators, amounts) must not depend on any
+	 * chain's output, and no running sum may either -- the sum passes and the chain-input pass run before
+	 * chain_kernel. Forward data-flow, one bit per block buffer ("depends on a chain's output"). */
+	if (has_chain && !bad) {
+		unsigned long long c0[4] = {0, 0, 0, 0};
+		auto dep = [&](uint32_t sl) -> bool {
+			if (sl == NO_SLOT) return false;
+			const uint32_t q = sl >> 6;
+			const unsigned long long a = q == 0 ? c0[0] : q == 1 ? c0[1] : q == 2 ? c0[2] : c0[3];
+			return ((a >> (sl & 63)) & 1ull) != 0;
+		};
+		auto set_dep = [&](uint32_t sl, bool v, bool keep) {
+			if (sl == NO_SLOT) return;
+			const unsigned long long bit = 1ull << (sl & 63);
+#pragma unroll
+			for (int q = 0; q < 4; ++q)
+				if ((int)(sl >> 6) == q) c0[q] = v ? (c0[q] | bit) : (keep ? c0[q] : (c0[q] & ~bit));
+		};
+		for (uint32_t si = 0; si < vd.plan_len && !bad; ++si) {
+			const Step st = plan[si];
+			const DevOp &o = P.ops[ids[st.op]];
+			if (o.rt_frozen) continue;
+			if (st.kind == ST_LINE) set_dep(st.out, dep(st.fmul), false);
+			else if (st.kind == ST_SMLINE) set_dep(st.out, false, false);
+			else if (st.kind == ST_LERP) set_dep(st.out, dep(st.freq) || dep(st.pm), true);
+			else if (st.kind == ST_OSC) {
+				const bool in_dep = dep(st.pm) || dep(st.fpm) || dep(st.freq) || dep(st.fmul) || dep(st.sm);
+				const bool chain = step_may_chain(st) && o.type == OT_WAVE &&
+					(st.sm != NO_SLOT || o.line[L_PMA].v0 != 0.f || (o.line[L_PMA].flags & LP_GOAL));
+				const bool fvar = (o.type == OT_WAVE || o.type == OT_RASEG) && !o.rt_fconst_valid;
+				if (chain && in_dep) bad = true;
+				if (fvar && (dep(st.freq) || dep(st.fmul))) bad = true;
+				if (!(st.which & OX_VOICE)) set_dep(st.out, chain || in_dep || dep(st.amp), (st.flags & SF_LAYER) != 0);
+			}
+		}
+	}
+	uint32_t seq_kind = seq ? 1u : 0u, n_scan_out = 0, levels_out = 0, lvl_bits_out = 0;
+	if (seq && !bad) {
+		unsigned long long t0[4] = {0, 0, 0, 0}, t1[4] = {0, 0, 0, 0};
+		auto level_of = [&](uint32_t sl) -> uint32_t {
+			if (sl == NO_SLOT) return 0;
+			const uint32_t q = sl >> 6;
+			const unsigned long long a = q == 0 ? t0[0] : q == 1 ? t0[1] : q == 2 ? t0[2] : t0[3];
+			const unsigned long long b = q == 0 ? t1[0] : q == 1 ? t1[1] : q == 2 ? t1[2] : t1[3];
+			return (uint32_t)((a >> (sl & 63)) & 1ull) | ((uint32_t)((b >> (sl & 63)) & 1ull) << 1);
+		};
+		auto set_level = [&](uint32_t sl, uint32_t lv, bool keep_max) {
+			if (sl == NO_SLOT) return;
+			if (keep_max) { const uint32_t old = level_of(sl); if (old > lv) lv = old; }
+			const unsigned long long bit = 1ull << (sl & 63);
+#pragma unroll
+			for (int q = 0; q < 4; ++q)
+				if ((int)(sl >> 6) == q) {
+					t0[q] = (t0[q] & ~bit) | ((lv & 1) ? bit : 0ull);
+					t1[q] = (t1[q] & ~bit) | ((lv & 2) ? bit : 0ull);
+				}
+		};
+		auto max2 = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+		bool multi = true;
+		uint32_t n_scan = 0;
+		for (uint32_t si = 0; si < vd.plan_len; ++si) {
+			const Step st = plan[si];
+			DevOp &o = P.ops[ids[st.op]];
+			if (o.rt_frozen) continue;
+			if (st.kind == ST_LINE) {
+				set_level(st.out, level_of(st.fmul), false);
+			} else if (st.kind == ST_LERP) {
+				set_level(st.out, max2(level_of(st.freq), level_of(st.pm)), true);
+			} else if (st.kind == ST_OSC) {
+				const bool fvar = (o.type == OT_WAVE || o.type == OT_RASEG) && !o.rt_fconst_valid &&
+					!(chain_ok && step_is_chain_acc(st, o));
+				uint32_t lv = max2(max2(level_of(st.pm), level_of(st.fpm)), max2(level_of(st.amp),
+						max2(level_of(st.freq), level_of(st.fmul))));
+				if (fvar) {
+					const uint32_t mine = 1 + max2(level_of(st.freq), level_of(st.fmul));
+					if (mine > P.sum_levels || n_scan >= FAST_MAX_SCAN) multi = false; /* deeper: one wave, in order */
+					else {
+						lvl_bits_out |= mine << (2 * n_scan);
+						if (mine > levels_out) levels_out = mine;
+						o.rt_fblk_valid = mine; /* (its first meaning is over: from here on the operator's level) */
+					}
+					++n_scan;
+					lv = max2(lv, mine > 3 ? 3u : mine);
+				}
+				if (!(st.which & OX_VOICE)) set_level(st.out, lv, (st.flags & SF_LAYER) != 0);
+			}
+		}
+		if (P.look && !has_chain && n_scan <= FAST_MAX_SCAN && n_scan <= vd.n_look) {
+			seq_kind = 3; /* one pass, any depth: prefixes by look-back */
+		} else if (multi && P.scan) {
+			seq_kind = 2;
+			for (uint32_t p = 0; p < levels_out && p < P.sum_levels; ++p) atomicOr(&P.pass_flags[p], 1u);
+		}
+		n_scan_out = n_scan;
+	}
+	if (has_chain && !bad) {
+		if (seq_kind == 1) bad = true; /* (one wave in order: not with chains) */
+		else {
+			seq_kind = 2; /* multi-pass voice, possibly without sums */
+			atomicOr(&P.pass_flags[FAST_MAX_LEVELS + 1], 1u);
+		}
+	}
+	FastInfo fi;
+	/* Running-sum voices get one more lead-in lane than their data flow needs: a repeated phase on
+	 * the first lane an operator is defined in then spoils nothing that is stored (what it spoils
+	 * climbs one lane per nesting level and ends on the lane before the first stored one), where
+	 * closed-form voices have repair_kernel for that case (see FAST_REPAIR_SHIFT). */
+	if (seq || has_chain) ++x_carrier;
+	fi.n_chain = has_chain && !bad ? 1u : 0u;
+	fi.H = maxd + x_carrier; fi.xlead = x_carrier; fi.bail = 0; fi.n_fsteps = 0; fi.n_pass[0] = fi.n_pass[1] = fi.n_pass[2] = fi.n_pass[3] = 0; fi.seq = seq_kind; fi.n_scan = n_scan_out; fi.levels = levels_out; fi.lvl_bits = lvl_bits_out;
+	fi.total = 0;
+	if ((seq || has_chain) && !P.seq_enable) bad = true;
+	if (!bad && vd.nops <= P.max_ops && vd.plan_len <= P.max_steps && maxd >= 1 && maxd + x_carrier <= P.np / 2)
+		fi.total = min(min_time, vd.run_len);
+	P.info[v] = fi;
+	if (fi.total && (seq_kind == 1 || seq_kind == 2)) atomicOr(&P.pass_flags[FAST_MAX_LEVELS + 2], 1u);
+	P.fast_done[v] = 0;
+	P.repair[(size_t)v * FAST_REPAIR_WORDS] = 0;
+}

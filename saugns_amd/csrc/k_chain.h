@@ -1,0 +1,281 @@
+/* k_chain.h -- part of hip_backend.hip (included there, inside namespace sauhip; not a header of its own).
+ * chain_kernel: feedback recurrences with lanes = voices. */
+/* ======================================================================== */
+/* feedback chains: lanes = voices                                          */
+/* ======================================================================== */
+/* The self-modulation recurrence (wosc.h:273-310: feedback -> phase -> table -> sample -> feedback) is one
+ * dependent chain per operator, about a hundred nanoseconds per sample whatever the width of the machine.
+ * The block loop ran one such chain on one lane of a wave; here a wave runs sixty-four, one per lane, and
+ * nothing but the chain. A workgroup is two waves. The CHAIN wave reads its inputs -- base phases and
+ * self-modulation amounts, sixteen frames per lane at a time -- from LDS, runs the recurrence and leaves the
+ * samples in LDS. The FEEDER wave moves everything else: it fetches the next batch of inputs from the chains'
+ * row pairs in HBM (written by the time-parallel passes: fast_voice, chain-input pass), sums phase increments
+ * for chains that get those instead of base phases, or -- for chains whose inputs are just their own
+ * frequency and amount lines -- evaluates the lines itself, so that such voices need no chain-input pass at
+ * all; and it stores the previous batch of samples to the chain's first row, where the final pass takes them
+ * (amplitude, mixing into the parent, voice output). One barrier per batch. 4096 chains are 64 workgroups on
+ * 64 CUs, and the render takes frames x chain latency. */
+constexpr uint32_t CHAIN_BATCH = 16;               /* frames per lane and batch */
+constexpr uint32_t CHAIN_IO_WORDS = CHAIN_BATCH * 64; /* one array of one batch */
+constexpr size_t CHAIN_IO_BYTES = (size_t)(2 * 2 + 2) * CHAIN_IO_WORDS * 4; /* in[2][2] + out[2] */
+
+/* LDS layout of a batch array: frame 4q + r of lane l at word (q * 64 + l) * 4 + r -- a lane's four 16-byte
+ * accesses are conflict-free */
+__device__ __forceinline__ uint32_t chain_io_word(uint32_t q, int l) { return (q * 64u + (uint32_t)l) * 4u; }
+
+/* SMALL: every feedback offset of the batch is known to stay below 2^20 cycles in magnitude, where the short
+ * rounding form is exact (rint32w_p31_small) -- no per-sample test on the chain; the caller verifies the bound
+ * it assumed for |fb_s| afterwards (fb_max) and redoes the batch without SMALL if it was exceeded. */
+template <bool LDS_TAB, bool TAIL, bool SMALL>
+__device__ __forceinline__ void chain_batch(const uint4 *bq, const float4 *aq, float4 *sq, uint32_t t, uint32_t n,
+		uint32_t tab23, uint32_t tab01, const HerpC23 *g23, const HerpC01 *g01, float dscale, float doff,
+		uint32_t &prev_phase, double &prev_Is, float &prev_s, float &fb_s, float &fb_max) {
+	/* one 16-byte and one 8-byte LDS read per sample (ds_read_b128 / ds_read_b64): the entries are that aligned */
+	typedef double __attribute__((ext_vector_type(2))) f64x2;
+	typedef float __attribute__((ext_vector_type(2))) f32x2;
+	typedef const f64x2 __attribute__((address_space(3))) *lds_f64x2;
+	typedef const f32x2 __attribute__((address_space(3))) *lds_f32x2;
+#pragma unroll
+	for (int u = 0; u < 4; ++u) {
+		const uint32_t b4[4] = {bq[u].x, bq[u].y, bq[u].z, bq[u].w};
+		const float a4[4] = {aq[u].x, aq[u].y, aq[u].z, aq[u].w};
+		float s4[4];
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			const float p = fb_s * a4[j];
+			uint32_t ofs = rint32w_p31_small(p);
+			if (!SMALL) { if (__builtin_expect(!(fabsf(p) < 0x1p20f), 0)) ofs = rint32w(p * 0x1p31f); }
+			const uint32_t phase = b4[j] + ofs;
+			const int32_t d = (int32_t)(phase - prev_phase);
+			const uint32_t ind = phase >> SLEN_BITS;
+			HerpC23 hi; HerpC01 lo;
+			if (LDS_TAB) {
+				const f64x2 c23 = *(lds_f64x2)(uintptr_t)(tab23 + ind * (uint32_t)sizeof(HerpC23));
+				const f32x2 c01 = *(lds_f32x2)(uintptr_t)(tab01 + ind * (uint32_t)sizeof(HerpC01));
+				hi.c3 = c23.x; hi.c2 = c23.y; lo.c1 = c01.x; lo.c0 = c01.y;
+			} else {
+				hi = g23[ind]; lo = g01[ind];
+			}
+			const double Isv = herp_poly(hi, lo, phase);
+			const float sv_new = wosc_diff(Isv, prev_Is, d, dscale, doff);
+			bool hold = d == 0; /* wosc.h:292-293: a repeated phase holds the previous sample */
+			const bool act = !TAIL || t + (uint32_t)(4 * u + j) < n;
+			if (TAIL) hold = hold || !act;
+			const float sv = hold ? prev_s : sv_new;
+			prev_Is = hold ? prev_Is : Isv;
+			prev_phase = (TAIL && !act) ? prev_phase : phase; /* (equal to the old one when held) */
+			prev_s = sv;
+			s4[j] = sv;
+			const float fb_n = (fb_s + sv) * 0.5f;
+			fb_s = (TAIL && !act) ? fb_s : fb_n;
+			if (SMALL) fb_max = fmaxf(fb_max, fabsf(fb_n)) + fb_n * 0.f; /* (beside the chain, not on it; NaN and Inf stick) */
+		}
+		sq[u] = make_float4(s4[0], s4[1], s4[2], s4[3]);
+	}
+}
+
+/* Sixteen consecutive values of a line, frames [t, t + 16) of the segment. Lanes hold different lines: the shape
+ * is tested once per batch and shape (not once per value), each shape's loop compiled with its type known. */
+template <uint32_t TYPE>
+__device__ __forceinline__ void line_batch_shape(const FastLine &fl, uint32_t t, float *out) {
+	if (fl.sw.type != TYPE) return;
+	Sweep sw = fl.sw;
+	sw.type = TYPE;
+#pragma unroll
+	for (uint32_t j = 0; j < CHAIN_BATCH; ++j)
+		if (t + j < fl.goal_len) out[j] = sweep_value_inl<true>(sw, t + j);
+}
+__device__ __forceinline__ void line_batch(const FastLine &fl, uint32_t t, float *out) {
+#pragma unroll
+	for (uint32_t j = 0; j < CHAIN_BATCH; ++j) out[j] = fl.hold;
+	if (t >= fl.goal_len) return;
+	line_batch_shape<LN_cos>(fl, t, out); line_batch_shape<LN_lin>(fl, t, out); line_batch_shape<LN_sah>(fl, t, out);
+	line_batch_shape<LN_xpe>(fl, t, out); line_batch_shape<LN_lge>(fl, t, out); line_batch_shape<LN_sqe>(fl, t, out);
+	line_batch_shape<LN_cub>(fl, t, out); line_batch_shape<LN_smo>(fl, t, out); line_batch_shape<LN_ncl>(fl, t, out);
+	line_batch_shape<LN_nhl>(fl, t, out); line_batch_shape<LN_uwh>(fl, t, out);
+	/* (LN_exp / LN_log were resolved to xpe / lge when the sweep was set up: sau/line.c:125-148) */
+}
+
+/* the feeder's share of one batch: inputs of frames [t, t + 16) into the LDS arrays */
+__device__ __forceinline__ void chain_feed(const ChainDesc &cd, bool live, int l, uint32_t t, uint32_t *acc,
+		const uint4 *bp, const float4 *ap, uint32_t *in_base, float *in_amt) {
+	if (!live) return;
+	uint32_t a = *acc, a_end = *acc; /* a_end: the accumulator after the segment's last frame, should it fall in this batch */
+	if (cd.mode == CM_INLINE) {
+		/* frequency and amounts from the operator's own lines (sau/line.c fills are functions of the position) */
+		float fv[CHAIN_BATCH], m[CHAIN_BATCH];
+		uint32_t b[CHAIN_BATCH];
+		line_batch(cd.pl, t, m);
+		if (!(cd.lflags & CL_FCONST)) line_batch(cd.fl, t, fv);
+#pragma unroll
+		for (uint32_t j = 0; j < CHAIN_BATCH; ++j) {
+			const uint32_t i = t + j;
+			uint32_t inc = cd.inc_const;
+			if (!(cd.lflags & CL_FCONST)) {
+				float v = fv[j];
+				if (cd.lflags & (i < cd.fl.goal_len ? CL_MUL_GOAL : CL_MUL_HOLD)) v *= cd.mulc;
+				const float x = cd.coeff * v;
+				inc = fabsf(x) < 0x1p50f ? (uint32_t)__double2loint((double)x + 0x1.8p52) : rint32w(x);
+			}
+			a += inc; /* wosc.h:145: pre-increment */
+			if (i < cd.n) a_end = a;
+			b[j] = a;
+		}
+#pragma unroll
+		for (uint32_t q = 0; q < 4; ++q) {
+			*(uint4 *)(in_base + chain_io_word(q, l)) = make_uint4(b[4 * q], b[4 * q + 1], b[4 * q + 2], b[4 * q + 3]);
+			*(float4 *)(in_amt + chain_io_word(q, l)) = make_float4(m[4 * q], m[4 * q + 1], m[4 * q + 2], m[4 * q + 3]);
+		}
+		*acc = a_end;
+		return;
+	}
+#pragma unroll
+	for (uint32_t q = 0; q < 4; ++q) {
+		uint4 b = bp[t / 4 + q];
+		if (cd.mode == CM_INC) { /* phase increments: summed here */
+			const uint32_t i = t + 4 * q;
+			b.x += a; b.y += b.x; b.z += b.y; b.w += b.z;
+			a = b.w;
+			a_end = i + 3 < cd.n ? b.w : i + 2 < cd.n ? b.z : i + 1 < cd.n ? b.y : i < cd.n ? b.x : a_end;
+		}
+		*(uint4 *)(in_base + chain_io_word(q, l)) = b;
+		*(float4 *)(in_amt + chain_io_word(q, l)) = ap[t / 4 + q];
+	}
+	*acc = a_end;
+}
+
+__global__ void __launch_bounds__(128) chain_kernel(FastParams P) {
+	extern __shared__ __align__(16) unsigned char lds[];
+	if (P.pass_flags[FAST_MAX_LEVELS + 1] == 0) return; /* no voice of the segment has a chain */
+	const int l = threadIdx.x & 63;
+	const bool feeder = uni((uint32_t)threadIdx.x >> 6) != 0;
+	const uint32_t c = blockIdx.x * 64 + (uint32_t)l;
+	ChainDesc cd;
+	memset(&cd, 0, sizeof cd);
+	if (c < P.n_chain_rows && P.chain_desc[c].n != 0) cd = P.chain_desc[c]; /* (an unused pair has only `n` set) */
+	/* this launch's share of the chain: frames [c_lo, n) of the segment, n cut at the chunk's end */
+	const uint32_t c_lo = P.range_mode ? P.f_lo : 0u;
+	uint32_t n = cd.n;
+	if (P.range_mode && n > P.f_hi) n = P.f_hi;
+	if (n <= c_lo) n = 0;
+	if (!__any(n != 0)) return;
+	HerpC23 *t23 = (HerpC23 *)lds;
+	HerpC01 *t01 = (HerpC01 *)(lds + (size_t)P.n_ctabs * WAVE_LEN * sizeof(HerpC23));
+	uint32_t *io = (uint32_t *)(lds + (size_t)P.n_ctabs * WAVE_LEN * (sizeof(HerpC23) + sizeof(HerpC01)));
+	for (uint32_t t = 0; t < P.n_ctabs; ++t) {
+		const uint32_t wave = P.cwave_of_tab[t];
+		const uint4 *s23 = (const uint4 *)(P.g_c23 + (size_t)wave * WAVE_LEN);
+		uint4 *d23 = (uint4 *)(t23 + (size_t)t * WAVE_LEN);
+		for (uint32_t i = threadIdx.x; i < WAVE_LEN; i += 128) d23[i] = s23[i];
+		const uint2 *s01 = (const uint2 *)(P.g_c01 + (size_t)wave * WAVE_LEN);
+		uint2 *d01 = (uint2 *)(t01 + (size_t)t * WAVE_LEN);
+		for (uint32_t i = threadIdx.x; i < WAVE_LEN; i += 128) d01[i] = s01[i];
+	}
+	const uint32_t wave = cd.wave < 12 ? cd.wave : 0;
+	const int ti = P.ctab_of_wave[wave];
+	const bool all_lds = __all(n == 0 || ti >= 0) != 0;
+	const uint32_t tab23 = (uint32_t)(uintptr_t)(t23 + (size_t)(ti >= 0 ? ti : 0) * WAVE_LEN);
+	const uint32_t tab01 = (uint32_t)(uintptr_t)(t01 + (size_t)(ti >= 0 ? ti : 0) * WAVE_LEN);
+	const HerpC23 *g23 = P.g_c23 + (size_t)wave * WAVE_LEN;
+	const HerpC01 *g01 = P.g_c01 + (size_t)wave * WAVE_LEN;
+	const float dscale = P.wc[wave].diff_scale, doff = P.wc[wave].diff_offset;
+	DevOp &o = P.ops[cd.gop];
+	/* row pair of the chain (idle lanes: pair 0, reads only) */
+	float *brow = P.chain_rows + (size_t)2 * (n ? c : 0u) * P.chain_stride;
+	const uint4 *bp = (const uint4 *)brow;
+	const float4 *ap = (const float4 *)(brow + P.chain_stride);
+	float4 *op = (float4 *)brow;
+	/* frames count from the chunk's start below: t = c_lo + (batch index) * 16 */
+	const uint32_t n_rel = n ? n - c_lo : 0u;
+	uint32_t n_all = n ? (n_rel & ~(CHAIN_BATCH - 1)) : 0xfffffff0u, n_max = n_rel;
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) {
+		n_all = min(n_all, (uint32_t)__shfl_xor((int)n_all, d));
+		n_max = max(n_max, (uint32_t)__shfl_xor((int)n_max, d));
+	}
+	n_all = uni(n_all); n_max = uni(n_max);
+	/* in[b][0]: base phases, in[b][1]: amounts, then out[b]: samples; b = batch & 1 */
+	auto in_base = [&](uint32_t b) { return io + (size_t)(2 * b) * CHAIN_IO_WORDS; };
+	auto in_amt = [&](uint32_t b) { return (float *)(io + (size_t)(2 * b + 1) * CHAIN_IO_WORDS); };
+	auto out_s = [&](uint32_t b) { return (float *)(io + (size_t)(4 + b) * CHAIN_IO_WORDS); };
+	const uint32_t n_batches = (n_max + CHAIN_BATCH - 1) / CHAIN_BATCH;
+	if (feeder) {
+		uint32_t acc = c_lo ? o.st_phase : o.phase; /* CM_INC, CM_INLINE: the phase accumulator (staged by the chunk before) */
+		/* step k: feed batch k while the chain wave runs batch k - 1, store the samples of batch k - 2 */
+		for (uint32_t k = 0; k <= n_batches; ++k) {
+			if (k < n_batches && c_lo + k * CHAIN_BATCH < n)
+				chain_feed(cd, true, l, c_lo + k * CHAIN_BATCH, &acc, bp, ap, in_base(k & 1), in_amt(k & 1));
+			if (k >= 2 && c_lo + (k - 2) * CHAIN_BATCH < n) {
+				const float *sq = out_s(k & 1);
+#pragma unroll
+				for (uint32_t q = 0; q < 4; ++q) op[(c_lo + (k - 2) * CHAIN_BATCH) / 4 + q] = *(const float4 *)(sq + chain_io_word(q, l));
+			}
+			__syncthreads(); /* (the first one also: tables staged) */
+		}
+		if (n_batches && c_lo + (n_batches - 1) * CHAIN_BATCH < n) {
+			const float *sq = out_s((n_batches - 1) & 1);
+#pragma unroll
+			for (uint32_t q = 0; q < 4; ++q) op[(c_lo + (n_batches - 1) * CHAIN_BATCH) / 4 + q] = *(const float4 *)(sq + chain_io_word(q, l));
+		}
+		if (n && cd.mode != CM_BASE && !(cd.mode == CM_INLINE && (cd.lflags & CL_FCONST))) o.st_phase = acc;
+		return;
+	}
+	/* ---- the chain wave ---- */
+	/* the operator's state, or what the chunk before this one staged */
+	uint32_t prev_phase = c_lo ? o.st_prev_phase : o.prev_phase;
+	double prev_Is = c_lo ? o.st_prev_Is : o.prev_Is;
+	float prev_s = c_lo ? o.st_prev_s : o.prev_s, fb_s = c_lo ? bits_f(o.ras_alpha) : o.fb_s;
+	__syncthreads();
+	if (n && c_lo == 0 && (o.flags & OPF_OSC_RESET)) { /* wosc.h:215-231 with the first base phase, as the block loop does */
+		const uint32_t phase00 = in_base(0)[chain_io_word(0, l)];
+		const uint32_t pa = phase00 - SLEN;
+		prev_Is = herp_poly(g23[pa >> SLEN_BITS], g01[pa >> SLEN_BITS], pa);
+		const double Is0 = herp_poly(g23[phase00 >> SLEN_BITS], g01[phase00 >> SLEN_BITS], phase00);
+		prev_s = wosc_diff(Is0, prev_Is, (int32_t)SLEN, dscale, doff);
+		prev_Is = Is0;
+		prev_phase = phase00;
+	}
+	for (uint32_t k = 0; k < n_batches; ++k) {
+		const uint32_t t = c_lo + k * CHAIN_BATCH;
+		uint4 bq[4]; float4 aq[4]; float4 sq[4];
+		const uint32_t *ib = in_base(k & 1);
+		const float *ia = in_amt(k & 1);
+#pragma unroll
+		for (uint32_t q = 0; q < 4; ++q) { bq[q] = *(const uint4 *)(ib + chain_io_word(q, l)); aq[q] = *(const float4 *)(ia + chain_io_word(q, l)); }
+		/* the short rounding form needs |fb_s * amount| < 2^20: amounts below 2^14 and |fb_s| <= 64 (checked after) */
+		float a_max = 0.f;
+#pragma unroll
+		for (int u = 0; u < 4; ++u)
+			a_max = fmaxf(fmaxf(a_max, fmaxf(fabsf(aq[u].x), fabsf(aq[u].y))), fmaxf(fabsf(aq[u].z), fabsf(aq[u].w)));
+		const uint32_t s_prev_phase = prev_phase; const double s_prev_Is = prev_Is;
+		const float s_prev_s = prev_s, s_fb_s = fb_s;
+		float fb_max = fabsf(fb_s);
+		bool small = !__any(n != 0 && !(a_max < 0x1p14f));
+		const bool tail = !((k + 1) * CHAIN_BATCH <= n_all);
+#define SAU_CHAIN_BATCH(L, TL, SM) chain_batch<L, TL, SM>(bq, aq, sq, t, n, tab23, tab01, g23, g01, dscale, doff, prev_phase, prev_Is, prev_s, fb_s, fb_max)
+		if (small) {
+			if (all_lds) { if (tail) SAU_CHAIN_BATCH(true, true, true); else SAU_CHAIN_BATCH(true, false, true); }
+			else { if (tail) SAU_CHAIN_BATCH(false, true, true); else SAU_CHAIN_BATCH(false, false, true); }
+			if (__any(n != 0 && !(fb_max <= 64.f))) { /* (never seen: feedback is an average of samples) */
+				small = false;
+				prev_phase = s_prev_phase; prev_Is = s_prev_Is; prev_s = s_prev_s; fb_s = s_fb_s;
+			}
+		}
+		if (!small) {
+			if (all_lds) { if (tail) SAU_CHAIN_BATCH(true, true, false); else SAU_CHAIN_BATCH(true, false, false); }
+			else { if (tail) SAU_CHAIN_BATCH(false, true, false); else SAU_CHAIN_BATCH(false, false, false); }
+		}
+#undef SAU_CHAIN_BATCH
+		float *os = out_s(k & 1);
+#pragma unroll
+		for (uint32_t q = 0; q < 4; ++q) *(float4 *)(os + chain_io_word(q, l)) = sq[q];
+		__syncthreads();
+	}
+	if (n) { /* staged: finalize_kernel makes it the operator's state unless the voice's segment is redone */
+		o.st_prev_phase = prev_phase;
+		o.st_prev_Is = prev_Is;
+		o.st_prev_s = prev_s;
+		o.ras_alpha = f_bits(fb_s);
+		o.ras_level = CHAIN_MARK;
+	}
+}

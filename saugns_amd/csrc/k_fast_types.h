@@ -1,0 +1,130 @@
+/* k_fast_types.h -- part of hip_backend.hip (included there, inside namespace sauhip; not a header of its own).
+ * The time-parallel path's parameter block, per-voice analysis record and constants. */
+/* ======================================================================== */
+/* time-parallel path: analyze -> fast -> finalize                          */
+/* ======================================================================== */
+/* While every line of a voice is held (no sweep pending), every oscillator
+ * frequency is one value, nothing feeds back and no operator runs out of
+ * time, sample t of the segment depends on the segment-start state only
+ * through closed forms: phase(t) = phase0 + inc*(t+1) (the wrapping sum of
+ * equal increments, wosc.h:129,145), noise counter n0 + t (noise.h:45).  Waves
+ * then take chunks of the time axis independently: no barriers, no carried
+ * state, block buffers private to the wave.  Each chunk recomputes H =
+ * nesting-depth samples of lead-in so that the differentiators
+ * (wosc.h:250-256) have their previous sample.  Everything else (sweeps, FM,
+ * feedback, operators that expire) is left to render_kernel's block loop,
+ * which continues where this path stops (fast_done). */
+
+struct FastInfo {
+	uint32_t total; /* frames this path renders (0: not eligible) */
+	uint32_t H;     /* lead-in samples per chunk */
+	uint32_t bail;  /* set when a chunk met dphase == 0 (hold-previous run) */
+	uint32_t n_fsteps; /* decoded steps of the voice (decode_kernel): step list 0, the only or final pass */
+	uint32_t n_pass[4]; /* ... of step lists 1..3 (sum passes) and 4 (chain-input pass) */
+	uint32_t seq;   /* some oscillator's frequency varies (ramp, FM): phases are running sums. 1: one wave walks the
+	                 * voice in order, carrying them; 2: two passes, every wave (no sum depends on another) */
+	uint32_t n_scan; /* oscillators with running-sum phases (multi-pass voices) */
+	uint32_t levels; /* deepest level among them (1: no sum depends on another) */
+	uint32_t lvl_bits; /* 2 bits per such oscillator, in plan order: its level */
+	uint32_t xlead;  /* lead-in lanes beyond the nesting depth (ratio frequencies below modulated blocks); in H */
+	uint32_t n_chain; /* self-modulated oscillators handed to chain_kernel this segment */
+};
+
+struct FastStep;
+struct FastLine;
+struct FastAux;
+struct ChainDesc;
+constexpr uint32_t CHAIN_DESC_WORDS = 32;
+constexpr uint32_t FAST_MAX_SCAN = 8;   /* oscillators with running-sum phases per multi-pass voice */
+constexpr uint32_t LOOK_LDS_BYTES = FAST_MAX_SCAN * 2 * 64 * sizeof(unsigned long long); /* the look-back rings of a workgroup */
+constexpr uint32_t FAST_MAX_LEVELS = 3; /* running sums that depend on running sums: at most that many sum passes
+                                         * (FastParams.sum_levels of them are launched for a segment) */
+/* A repeated phase (the output holds, wosc.h:251-252) on the first lane an operator's values are
+ * defined in cannot take the held output from the lane before. What that spoils is exactly the
+ * first owned frame of the row (one lane per nesting level upwards). fast_kernel notes such row
+ * groups per voice and repair_kernel evaluates them once more FAST_REPAIR_SHIFT frames earlier,
+ * where that frame lies in the middle of a row, storing only that frame. Through-zero PM makes
+ * exact repeats a several-per-10-s event for a 1024-voice bank and one in 64 of them falls on
+ * such a lane; each used to send its voice's whole segment to the block loop (8.5 ms for 10 s). */
+constexpr uint32_t FAST_REPAIR_SHIFT = 24; /* H + shift < 64 (H <= 32) */
+constexpr uint32_t FAST_MAX_REPAIR = 15;   /* noted row groups per voice and segment; more: block loop */
+constexpr uint32_t FAST_REPAIR_WORDS = 2 + 2 * FAST_MAX_REPAIR; /* count, pad, then (group, rows) pairs */
+constexpr uint32_t FAST_FLAGS = FAST_MAX_LEVELS + 3; /* pass_flags words */
+/* Decoded steps are kept once per pass that runs them ([list][voice][step]): a pass walks its own list and never
+ * loads a step only to find that another pass needs it (the per-step cost of the interpreter is most of a pass). */
+constexpr uint32_t FAST_LISTS = 5; /* 0: only / final pass, 1..3: sum passes, 4: chain-input pass */
+__device__ __forceinline__ uint32_t fast_list_of(uint32_t mode, uint32_t sum_levels) {
+	return (mode == 0 || mode == sum_levels + 1) ? 0u : (mode == sum_levels + 2 ? 4u : mode);
+}
+constexpr uint32_t FR_CHAIN_IN = 4u << FAST_MAX_LEVELS; /* FastStep.ramp: the chain-input pass runs this step */
+constexpr uint32_t FR_FINAL_SKIP = 8u << FAST_MAX_LEVELS; /* ... the final pass does not: only chains' inputs needed it */
+constexpr uint32_t FT_CHAIN = 1u << 18;     /* FastStep.type: a feedback chain (rows = bits of FastStep.pan) */
+constexpr uint32_t CHAIN_MARK = 0xC4A10001u; /* DevOp.ras_level of a W operator: chain_kernel staged its state */
+struct FastParams {
+	const VoiceDesc *voices;
+	const Step *steps;
+	const FastIds *fast_ids; /* parallel to steps */
+	const uint32_t *op_ids;
+	DevOp *ops;
+	float *vout;
+	float *pan;
+	FastInfo *info;
+	uint32_t *fast_done;
+	uint32_t *worklist;   /* out: voices the block loop still has to run */
+	uint32_t *work_count;
+	VoiceOut *vinfo;
+	const HerpC23 *g_c23;
+	const HerpC01 *g_c01;
+	FastStep *fsteps;     /* [n_voices][max_steps], written by decode_kernel */
+	FastLine *flines;     /* same indexing: the ramp of a step whose line is in progress */
+	FastAux *faux;        /* same indexing: sequential-scan extras */
+	uint32_t row_stride, n_voices, n_fast, max_ops, max_steps, n_tabs, np;
+	uint32_t rows;        /* T of the fast_kernel<T> that will run: block buffers hold 64 * rows frames */
+	uint32_t enable;      /* 0: leave every voice to the block loop */
+	uint32_t seq_enable;  /* block buffers are sized for frequency blocks: sequential-scan voices allowed */
+	uint32_t ids_full_ofs;/* offset of the with-frequency numbering in fast_ids */
+	uint32_t mode;        /* fast_kernel: 0 the only pass; 1..sum_levels: sums of phase increments of that level;
+	                       * sum_levels + 1: final pass. scan_kernel: the level whose sums to prefix */
+	uint32_t sum_levels;  /* sum passes this segment's launch sequence has (2, or 3 when the host expects that depth) */
+	unsigned long long *scan; /* [n_voices][FAST_MAX_SCAN][scan_groups]: those sums (W: mod 2^32; R: 64 bits), then
+	                           * (scan_kernel) their prefixes */
+	uint32_t scan_groups;
+	uint32_t *pass_flags; /* [FAST_MAX_LEVELS]: some voice of the segment needs that sum pass (set by analyze_kernel);
+	                       * [FAST_MAX_LEVELS]: some voice has row groups noted for repair_kernel;
+	                       * [FAST_MAX_LEVELS + 1]: some voice has feedback chains */
+	uint32_t *repair;     /* [voice][FAST_REPAIR_WORDS] */
+	uint32_t repair_on;   /* 0: such voices go to the block loop (SAU_AMD_NO_REPAIR, tests) */
+	/* feedback recurrences (wosc.h:273-310) out of the time-parallel passes: a pair of rows per chain in HBM --
+	 * base phases, then (in place) the samples; self-modulation amounts -- and what chain_kernel needs to run it */
+	float *chain_rows;    /* [n_chain_rows][2][chain_stride], or NULL: such voices go to the block loop */
+	uint32_t chain_stride, n_chain_rows;
+	ChainDesc *chain_desc;
+	FastLine *fplines;    /* [voice][max_steps]: the self-modulation amount line of a chain step without a block for it */
+	uint32_t n_ctabs;     /* wave tables chain_kernel stages in LDS */
+	uint32_t chain_inline;/* chains fed from their own lines by chain_kernel's feeder wave (SAU_AMD_CHAIN_INLINE; off:
+	                       * measured slower) */
+	/* A segment with chains is pipelined in chunks of frames: while chain_kernel (64 CUs, a second stream) runs
+	 * chunk c, the chain-input pass prepares chunk c + 1 and the final pass finishes chunk c - 1 on the other CUs.
+	 * fast_kernel: range_mode 1 = the row groups that start in [f_lo, f_hi), 2 = those that end in (f_lo, f_hi]
+	 * (0: all). chain_kernel: frames [f_lo, f_hi) of every chain, continuing from the staged state when f_lo > 0. */
+	uint32_t range_mode, f_lo, f_hi, range_last;
+	/* Saved phase increments: a running-sum oscillator's per-frame increments, computed in the sum pass of its
+	 * level, go to a row pair in HBM (W: 32 bits in the first row; R: low and high words), and the final pass
+	 * reads them back instead of evaluating the frequency again -- whatever only produced that frequency (FM
+	 * modulators, their sub-trees) is then left out of the final pass. */
+	uint32_t *inc_rows;   /* [n_inc_rows][2][inc_stride], or NULL */
+	uint32_t inc_stride, n_inc_rows;
+	/* Single-pass running sums (seq kind 3): one word per oscillator and row group (R: two, low and high half),
+	 * {epoch:30, status:2, value:32}; a wave publishes its group's sum (status 1), adds up what its predecessors
+	 * have published back to the nearest finished prefix, and publishes its own prefix (status 2). The epoch
+	 * (one per segment) makes every older word read as empty, so nothing is cleared between segments. */
+	unsigned long long *look; /* [n_look_rows][2][scan_groups] (VoiceDesc.look_base/n_look), or NULL */
+	uint32_t look_epoch;
+	uint32_t rows_multi; /* rows per pass in the launches of the full running-sum build (kinds 1 and 2) */
+	uint32_t only_multi; /* this launch: only the voices fast_kernel<T, 2> leaves out (one wave in order, several passes) */
+	int8_t ctab_of_wave[12];
+	uint8_t cwave_of_tab[12];
+	int8_t tab_of_wave[12];
+	uint8_t wave_of_tab[12];
+	WaveConst wc[12];
+};

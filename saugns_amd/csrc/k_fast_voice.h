@@ -1,0 +1,814 @@
+/* k_fast_voice.h -- part of hip_backend.hip (included there, inside namespace sauhip; not a header of its own).
+ * fast_voice / fast_kernel / repair_kernel: rows of 64 frames per wave, closed-form and running-sum phases. */
+/* lane l receives lane l-1's value (lane 0: zero; it is lead-in) */
+__device__ __forceinline__ uint32_t lane_prev(uint32_t x) {
+	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+}
+__device__ __forceinline__ double lane_prev(double x) {
+	const uint32_t lo = lane_prev((uint32_t)__double2loint(x));
+	const uint32_t hi = lane_prev((uint32_t)__double2hiint(x));
+	return __hiloint2double((int)hi, (int)lo);
+}
+
+/* Uniform (scalar-cache) load of one decoded step: the address is the same
+ * for the whole wave and the memory was written by an earlier kernel. */
+__device__ __forceinline__ FastStep load_step_uniform(const FastStep *p) {
+	const_u32_ptr q = (const_u32_ptr)(uintptr_t)p;
+	union { FastStep s; uint32_t u[20]; } c;
+#pragma unroll
+	for (int i = 0; i < 20; ++i) c.u[i] = q[i];
+	return c.s;
+}
+
+/* (A 24-byte interleaved LDS entry read with ds_read2_b64 + ds_read_b64 was
+ * measured 60 % worse in bank conflicts than this split 16 + 8 byte layout.) */
+/* One voice's share of this wave's work. SCAN: built with the running-sum code
+ * (frequency ramps, FM); the plain build stays as lean as closed-form voices
+ * need it (the same code with the running-sum branches compiled in was 27 %
+ * slower on them), and a kernel that may meet both kinds holds both copies. */
+template <int T, int SCAN, bool REPAIR = false>
+__device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v, const FastInfo &fi,
+		float *slots, unsigned long long *carry, const HerpC23 *t23, const HerpC01 *t01, const int l,
+		const uint32_t wpv, const uint32_t cstart, unsigned long long *lring = nullptr) {
+	constexpr int NP = 64 * T;
+	(void)NP;
+	const uint32_t fast_total = uni(fi.total);
+	if (fast_total == 0) return;
+	const VoiceDesc vd = P.voices[v];
+	const uint32_t H = uni(fi.H);
+
+	/* this pass's own list of the voice's decoded steps */
+	/* SCAN: 0 closed-form phases only; 1 every kind of running-sum voice; 2 single-pass (look-back) voices only,
+	 * without the code of the several-pass forms and the feedback chains */
+	constexpr bool FULL = SCAN == 1;
+	const uint32_t li = FULL ? fast_list_of(P.mode, P.sum_levels) : 0u;
+	const uint32_t n_fsteps = uni(li == 0 ? fi.n_fsteps : li == 1 ? fi.n_pass[0] : li == 2 ? fi.n_pass[1] : li == 3 ? fi.n_pass[2] : fi.n_pass[3]);
+	const size_t list_at = ((size_t)li * P.n_voices + v) * P.max_steps;
+	const FastStep *fsteps = P.fsteps + list_at;
+	const FastLine *flines = P.flines + list_at;
+	const FastAux *faux = P.faux + list_at;
+	const FastLine *fplines = P.fplines ? P.fplines + list_at : nullptr;
+	/* sequential-scan voices: the one wave with cstart == 0 walks every row group in order */
+	const uint32_t seq_kind = SCAN ? uni(fi.seq) : 0u;
+	const bool seq = FULL && seq_kind == 1;    /* one wave, in order */
+	const bool two = FULL && seq_kind == 2;    /* two passes, every wave */
+	const bool look = SCAN == 2;               /* one pass, every wave, prefixes by look-back (a build of its own) */
+	unsigned long long *lookv = look ? P.look + (size_t)vd.look_base * 2 * P.scan_groups : nullptr;
+	/* the single-pass build: a voice with one wave carries its sums in LDS like an in-order voice; the waves of
+	 * one workgroup look back through rings in LDS; voices spread wider go through HBM */
+	const bool look_own = SCAN == 2 && wpv == 1;
+	const bool look_lds = SCAN == 2 && lring && wpv >= 2 && wpv <= 16 && (16 % wpv) == 0;
+	const uint32_t lk_ring = 4 * wpv;
+	unsigned long long *lk_base = look_lds ? lring + (uni((uint32_t)threadIdx.x >> 6) / wpv) * lk_ring : nullptr;
+	if (seq && cstart != 0) return;
+	const uint32_t gstride = seq ? 1u : wpv;
+	unsigned long long *scan = two ? P.scan + (size_t)v * FAST_MAX_SCAN * P.scan_groups : nullptr;
+	float *vrow = P.vout + (size_t)vd.out_row * P.row_stride;
+	float *prow = (vd.pan_dynamic_row != ~0u) ? P.pan + (size_t)vd.pan_dynamic_row * P.row_stride : nullptr;
+	/* A wave renders T rows at a time; a row is 64 consecutive frames, one per
+	 * lane, of which the first H are lead-in (recomputed, not stored). */
+	const uint32_t C = 64u - H;                       /* new frames per row */
+	const uint32_t nrows = (fast_total + C - 1) / C;
+	const uint32_t ngroups = (nrows + T - 1) / T;
+	const uint32_t last_group = ((fast_total - 1) / C) / T; /* holds the segment's last frame */
+	uint32_t zero_acc = 0; /* nonzero: some hold-previous run could not be resolved here */
+
+	uint32_t *const rep = P.repair + (size_t)v * FAST_REPAIR_WORDS;
+	/* REPAIR: the noted row groups instead of all, each evaluated FAST_REPAIR_SHIFT frames early */
+	uint32_t n_iter = REPAIR ? min(uni(rep[0]), FAST_MAX_REPAIR) : ngroups;
+	uint32_t it_lo = 0;
+	if (!REPAIR && SCAN != 2 && P.range_mode != 0) { /* (the single-pass build never runs in chunks) */
+		if (seq) { if (!P.range_last) return; } /* one wave in order, carries in LDS: in the last chunk's launch, all of it */
+		else {
+			const uint32_t tc = (uint32_t)T * C;
+			if (P.range_mode == 1) { /* groups that start in [f_lo, f_hi) */
+				it_lo = (P.f_lo + tc - 1) / tc;
+				n_iter = min(ngroups, P.f_hi > 0xffffffffu - tc ? ngroups : (P.f_hi + tc - 1) / tc);
+			} else { /* groups that end in (f_lo, f_hi]; the last one ends with the segment */
+				it_lo = P.f_lo / tc;
+				n_iter = fast_total <= P.f_hi ? ngroups : min(ngroups, P.f_hi / tc);
+				if (P.f_lo >= fast_total) n_iter = 0;
+			}
+		}
+	}
+	for (uint32_t it = it_lo + cstart; it < n_iter; it += gstride) {
+		const uint32_t cg = REPAIR ? uni(rep[2 + 2 * it]) : it;
+		const uint32_t repair_rows = REPAIR ? uni(rep[3 + 2 * it]) : 0u;
+		const int t0 = (int)(cg * T * C) - (int)H + l - (REPAIR ? (int)FAST_REPAIR_SHIFT : 0); /* this lane's frame in row 0 */
+		const bool first_group = (cg == 0);
+		const bool is_last_group = (cg == last_group);
+		uint32_t held_rows = 0; /* rows with a hold this evaluation could not resolve */
+		(void)repair_rows;
+#if FK_PREFETCH
+		FastStep fnext = load_step_uniform(fsteps);
+#endif
+		for (uint32_t si = 0; si < n_fsteps; ++si) {
+#if FK_PREFETCH
+			const FastStep f = fnext;
+			fnext = load_step_uniform(fsteps + (si + 1 < n_fsteps ? si + 1 : si)); /* in flight during this step */
+#else
+			const FastStep f = load_step_uniform(fsteps + si);
+#endif
+			const uint32_t kind = f.kind & 0xff;
+			const uint32_t flags = (f.kind >> 8) & 0xff;
+			const bool sum_pass = FULL && P.mode != 0 && P.mode <= P.sum_levels;
+			if (sum_pass && !(f.ramp & (2u << P.mode))) continue; /* not needed for this pass's phase increments */
+			const bool chain_in = FULL && P.mode == P.sum_levels + 2; /* the pass that writes the chains' inputs */
+			if (chain_in && !(f.ramp & FR_CHAIN_IN)) continue;
+			if (FULL && P.mode == P.sum_levels + 1 && (f.ramp & FR_FINAL_SKIP)) continue;
+			if (kind == ST_OSC) {
+				const uint32_t type = f.type & 0xff;
+				const bool wave_env = (flags & SF_WAVE_ENV) != 0;
+				const bool layer = (flags & SF_LAYER) != 0;
+				const bool to_voice = ((f.kind >> 16) & OX_VOICE) != 0;
+				float s[T];
+				const bool chain = FULL && (f.type & FT_CHAIN) != 0;
+				if (type == OT_WAVE && chain && P.mode == P.sum_levels + 1) { /* (the final pass) */
+					/* a feedback chain: chain_kernel has run it; its samples are in the row */
+					const float *crow = P.chain_rows + (size_t)2 * f_bits(f.pan) * P.chain_stride;
+#pragma unroll
+					for (int k = 0; k < T; ++k) {
+						const int t = t0 + k * (int)C;
+						s[k] = (t >= 0 && t < (int)fast_total) ? crow[t] : 0.f;
+					}
+				} else if (type == OT_WAVE) {
+					const bool has_pm = f.pm_off != ~0u, has_fpm = f.fpm_off != ~0u;
+					/* this operator's values are defined from lane p_min on
+					 * (one more lead-in sample per nesting level below it) */
+					const int p_min = (int)H - (int)(f.kind >> 24) + 1;
+					bool done = false;
+					if (FK_COMMON && f.tab >= 0 && !has_fpm && !first_group && !is_last_group && !(f.ramp & 2) && !chain) {
+						/* the common case, straight-line: table in LDS, plain PM or
+						 * none, no segment edge in this group */
+						uint32_t ph[T];
+						{
+							uint32_t acc = f.phase0 + f.inc * (uint32_t)(t0 + 1);
+							const uint32_t row_inc = f.inc * C;
+#pragma unroll
+							for (int k = 0; k < T; ++k) { ph[k] = acc; acc += row_inc; }
+						}
+						bool ok = true;
+						if (has_pm) {
+							float pm[T];
+							bool big = false;
+#pragma unroll
+							for (int k = 0; k < T; ++k) {
+								pm[k] = slots[f.pm_off + k * 64];
+								big |= !(fabsf(pm[k]) < 0x1p20f);
+							}
+							ok = !__any(big);
+#pragma unroll
+							for (int k = 0; k < T; ++k) ph[k] += rint32w_p31_small(pm[k]);
+						}
+						if (ok) {
+							const HerpC23 *l23 = t23 + (size_t)f.tab * WAVE_LEN;
+							const HerpC01 *l01 = t01 + (size_t)f.tab * WAVE_LEN;
+							double Is[T];
+#pragma unroll
+							for (int k = 0; k < T; ++k) {
+								const uint32_t ind = ph[k] >> SLEN_BITS;
+								Is[k] = herp_poly(l23[ind], l01[ind], ph[k]);
+							}
+							if (FK_CONSTD && !has_pm && f.inc != 0) {
+								/* unmodulated: every phase step is inc, one division serves all */
+								const double x = (double)div_f32_normal(f.diff_scale, (float)(int32_t)f.inc);
+#pragma unroll
+								for (int k = 0; k < T; ++k)
+									s[k] = (float)((Is[k] - lane_prev(Is[k])) * x + (double)f.diff_offset);
+								done = true;
+							} else {
+								bool zero = false;
+#pragma unroll
+								for (int k = 0; k < T; ++k) {
+									const int32_t d = (int32_t)(ph[k] - lane_prev(ph[k]));
+									zero |= (d == 0);
+									s[k] = wosc_diff(Is[k], lane_prev(Is[k]), d, f.diff_scale, f.diff_offset);
+								}
+								done = !__any(zero && l >= p_min);
+							}
+						}
+					}
+					if (!done) {
+						uint32_t ph[T];
+						double Is[T];
+						float fv[T]; /* frequency per frame (freq-scaled PM reads it) */
+						bool fvar = false;
+						if (SCAN && (f.ramp & 2)) {
+							/* the frequency varies (ramp, FM): phase is a running sum of per-frame
+							 * increments (wosc.h:135-169). This wave walks the voice's rows in order;
+							 * `carry` holds the accumulator at the frame before each row's new frames. */
+							const FastAux fa = load_aux_uniform(faux + si);
+							fvar = (fa.flags & (FA_FVAR_SLOT | FA_FVAR_LINE)) != 0;
+							if (fvar) {
+								uint32_t S[T];
+								auto freq_at = [&](int k, int t) -> float { /* the frequency at row k's frame t */
+									if (fa.flags & FA_FVAR_SLOT) return slots[fa.freq_off + k * 64];
+									float v = fast_line_value(fa.fl, t);
+									const bool in_goal = (uint32_t)t < fa.fl.goal_len;
+									if (fa.flags & (in_goal ? FA_MUL_GOAL : FA_MUL_HOLD))
+										v *= fa.fmul_off != ~0u ? slots[fa.fmul_off + k * 64] : fa.mulc;
+									return v;
+								};
+								/* saved increments (FastParams.inc_rows): written by the sum pass of this oscillator's
+								 * level, read back by the final pass in place of the frequency */
+								uint32_t *irow = (FULL && (fa.pad[2] & 2u)) ? P.inc_rows + (size_t)2 * (fa.pad[2] >> 8) * P.inc_stride : nullptr;
+								const bool inc_read = irow && P.mode == P.sum_levels + 1;
+								const bool inc_write = irow && two && P.mode == fa.pad[1];
+								if (FULL) {
+#pragma unroll
+									for (int k = 0; k < T; ++k) {
+										const int t = t0 + k * (int)C;
+										uint32_t r;
+										if (inc_read) {
+											r = (t >= 0 && t < (int)fast_total) ? irow[t] : 0u;
+											fv[k] = 0.f; /* (only frequency-scaled PM reads it, and such oscillators save nothing) */
+										} else {
+											const float v = freq_at(k, t);
+											fv[k] = v;
+											const float x = fa.coeff * v;
+											/* llrintf(x) mod 2^32 (wosc.h:145): adding 1.5 * 2^52 in f64 rounds to the nearest
+											 * integer and leaves it in the low word; exact while |x| < 2^51 */
+											r = fabsf(x) < 0x1p50f ? (uint32_t)__double2loint((double)x + 0x1.8p52) : rint32w(x);
+											if (inc_write && l >= (int)H && t >= 0 && t < (int)fast_total) irow[t] = r;
+										}
+										const uint32_t inc = (t >= 0 && t < (int)fast_total) ? r : 0u;
+										if (chain && fa.pad[2]) S[k] = inc; /* chain_kernel does the summing */
+										else S[k] = wave_incl_scan_dpp(inc);
+									}
+								} else { /* the single-pass build: one test per group for the rounding form */
+									float x[T];
+									bool big = false;
+#pragma unroll
+									for (int k = 0; k < T; ++k) {
+										fv[k] = freq_at(k, t0 + k * (int)C);
+										x[k] = fa.coeff * fv[k];
+										big |= !(fabsf(x[k]) < 0x1p50f);
+									}
+									uint32_t r[T];
+									if (!__any(big)) {
+#pragma unroll
+										for (int k = 0; k < T; ++k) r[k] = (uint32_t)__double2loint((double)x[k] + 0x1.8p52);
+									} else {
+#pragma unroll
+										for (int k = 0; k < T; ++k) r[k] = rint32w(x[k]);
+									}
+#pragma unroll
+									for (int k = 0; k < T; ++k) {
+										const int t = t0 + k * (int)C;
+										S[k] = wave_incl_scan_dpp((t >= 0 && t < (int)fast_total) ? r[k] : 0u);
+									}
+								}
+								if (chain && fa.pad[2]) {
+									/* chain-input pass of a chain that accumulates its own phase: increments and amounts */
+									float *brow = P.chain_rows + (size_t)2 * f_bits(f.pan) * P.chain_stride;
+									float *arow = brow + P.chain_stride;
+									FastLine pl;
+									const bool from_line = f.aux_off == ~0u;
+									if (from_line) pl = load_line_uniform(fplines + si);
+#pragma unroll
+									for (int k = 0; k < T; ++k) {
+										const int t = t0 + k * (int)C;
+										const float a = from_line ? fast_line_value(pl, t) : slots[f.aux_off + k * 64];
+										if (l >= (int)H && t >= 0 && t < (int)fast_total) {
+											((u32_alias *)brow)[t] = S[k];
+											arow[t] = a;
+										}
+									}
+									continue;
+								}
+								/* the accumulator at the frame before this group's first new frame: carried by
+								 * this wave (in-order voices), or the prefix of all earlier groups' sums */
+								unsigned long long *sums = two ? scan + (size_t)fa.pad[0] * P.scan_groups : nullptr;
+								const bool sum_me = two && P.mode == fa.pad[1]; /* this pass computes this oscillator's sums */
+								uint32_t acc;
+								if (look_own) {
+									acc = first_group ? f.phase0 : (uint32_t)carry[si];
+								} else if (look) {
+									uint32_t tot = 0;
+#pragma unroll
+									for (int k = 0; k < T; ++k)
+										tot += (uint32_t)__builtin_amdgcn_readlane((int)S[k], 63) - (uint32_t)__builtin_amdgcn_readlane((int)S[k], (int)H - 1);
+									acc = f.phase0 + (look_lds ? lookback32<true>(lk_base + (size_t)fa.pad[0] * 2 * 64, cg, tot, 0, lk_ring, l)
+									                           : lookback32<false>(lookv + (size_t)fa.pad[0] * 2 * P.scan_groups, cg, tot, P.look_epoch, 0, l));
+								} else {
+									acc = two ? (sum_me ? 0u : f.phase0 + (uint32_t)sums[cg])
+									          : (first_group ? f.phase0 : (uint32_t)carry[si]);
+								}
+#pragma unroll
+								for (int k = 0; k < T; ++k) {
+									const uint32_t lead = (uint32_t)__builtin_amdgcn_readlane((int)S[k], (int)H - 1);
+									const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)S[k], 63);
+									ph[k] = acc + (S[k] - lead);
+									acc += last - lead;
+								}
+								if (two) {
+									if (sum_me) { /* this pass ends here for this oscillator */
+										if (l == 0) sums[cg] = (unsigned long long)acc;
+										continue;
+									}
+								} else if ((!look || look_own) && l == 0) {
+									carry[si] = (unsigned long long)acc;
+								}
+							}
+						}
+						if (!fvar) {
+							/* phase0 + inc*(t+1): one multiply per lane, then adds */
+							uint32_t acc = f.phase0 + f.inc * (uint32_t)(t0 + 1);
+							const uint32_t row_inc = f.inc * C;
+#pragma unroll
+							for (int k = 0; k < T; ++k) { ph[k] = acc; acc += row_inc; fv[k] = f.fc; }
+						}
+						if (SCAN && is_last_group) { /* the accumulator after the segment's last frame, before modulation */
+#pragma unroll
+							for (int k = 0; k < T; ++k) {
+								const int t = t0 + k * (int)C;
+								if (t == (int)fast_total - 1 && l >= (int)H) P.ops[f.gop].st_phase = ph[k];
+							}
+						}
+						if (has_pm && !has_fpm) {
+							float pm[T];
+							bool big = false;
+#pragma unroll
+							for (int k = 0; k < T; ++k) {
+								pm[k] = slots[f.pm_off + k * 64];
+								big |= !(fabsf(pm[k]) < 0x1p20f);
+							}
+							if (!__any(big)) {
+#pragma unroll
+								for (int k = 0; k < T; ++k) ph[k] += rint32w_p31_small(pm[k]);
+							} else {
+#pragma unroll
+								for (int k = 0; k < T; ++k) ph[k] += rint32w_p31(pm[k]);
+							}
+						} else if (has_pm || has_fpm) {
+							float pm[T], fpm[T];
+#pragma unroll
+							for (int k = 0; k < T; ++k) { pm[k] = 0.f; fpm[k] = 0.f; }
+							if (has_pm) {
+#pragma unroll
+								for (int k = 0; k < T; ++k) pm[k] = slots[f.pm_off + k * 64];
+							}
+							if (has_fpm) {
+#pragma unroll
+								for (int k = 0; k < T; ++k) fpm[k] = slots[f.fpm_off + k * 64];
+							}
+							if (has_pm) {
+#pragma unroll
+								for (int k = 0; k < T; ++k) ph[k] += pm_offset32(true, true, pm[k], fpm[k], fv[k]);
+							} else {
+#pragma unroll
+								for (int k = 0; k < T; ++k) ph[k] += pm_offset32(false, true, 0.f, fpm[k], fv[k]);
+							}
+						}
+						if (chain) {
+							/* chain-input pass: base phases (accumulator + phase modulation; the feedback term is
+							 * chain_kernel's) and self-modulation amounts to the chain's rows, nothing else */
+							float *brow = P.chain_rows + (size_t)2 * f_bits(f.pan) * P.chain_stride;
+							float *arow = brow + P.chain_stride;
+							FastLine pl;
+							const bool from_line = f.aux_off == ~0u;
+							if (from_line) pl = load_line_uniform(fplines + si);
+#pragma unroll
+							for (int k = 0; k < T; ++k) {
+								const int t = t0 + k * (int)C;
+								const float a = from_line ? fast_line_value(pl, t) : slots[f.aux_off + k * 64];
+								if (l >= (int)H && t >= 0 && t < (int)fast_total) {
+									((u32_alias *)brow)[t] = ph[k];
+									arow[t] = a;
+								}
+							}
+							continue;
+						}
+						const bool reset = (f.type >> 16) & 1;
+						if (first_group) {
+							/* t = -1: the sample before the segment (wosc.h:215-231 on restart) */
+							const uint32_t nxt = __shfl_down(ph[0], 1);
+							if (l == (int)H - 1) ph[0] = reset ? nxt - SLEN : f.prev_phase;
+						}
+						if (f.tab >= 0) {
+							const HerpC23 *l23 = t23 + (size_t)f.tab * WAVE_LEN;
+							const HerpC01 *l01 = t01 + (size_t)f.tab * WAVE_LEN;
+#pragma unroll
+							for (int k = 0; k < T; ++k) {
+								const uint32_t ind = ph[k] >> SLEN_BITS;
+								Is[k] = herp_poly(l23[ind], l01[ind], ph[k]);
+							}
+						} else {
+							const uint32_t wave = (f.type >> 8) & 0xff;
+							const HerpC23 *g23 = P.g_c23 + (size_t)wave * WAVE_LEN;
+							const HerpC01 *g01 = P.g_c01 + (size_t)wave * WAVE_LEN;
+#pragma unroll
+							for (int k = 0; k < T; ++k) {
+								const uint32_t ind = ph[k] >> SLEN_BITS;
+								Is[k] = herp_poly(g23[ind], g01[ind], ph[k]);
+							}
+						}
+						if (first_group && !reset) {
+							if (l == (int)H - 1) Is[0] = f.prev_Is;
+						}
+						uint32_t pph[T];
+						bool zero = false;
+						if (FK_CONSTD && !has_pm && !has_fpm && !first_group && f.inc != 0 && !fvar) {
+							/* unmodulated: every phase step is inc, one division serves all */
+							const double x = (double)div_f32_normal(f.diff_scale, (float)(int32_t)f.inc);
+#pragma unroll
+							for (int k = 0; k < T; ++k) {
+								pph[k] = ph[k] - f.inc;
+								const double pIs = lane_prev(Is[k]);
+								s[k] = (float)((Is[k] - pIs) * x + (double)f.diff_offset);
+							}
+						} else {
+#pragma unroll
+							for (int k = 0; k < T; ++k) {
+								pph[k] = lane_prev(ph[k]);
+								const double pIs = lane_prev(Is[k]);
+								const int32_t d = (int32_t)(ph[k] - pph[k]);
+								zero |= (d == 0);
+								s[k] = wosc_diff(Is[k], pIs, d, f.diff_scale, f.diff_offset);
+							}
+						}
+						if (__any(zero && l >= p_min)) {
+							/* dphase == 0: the differentiator holds its previous output
+							 * (wosc.h:251-252). Isolated cases resolve inside the row; a
+							 * run that reaches back past the lead-in goes to the block loop. */
+							bool held[T], src[T]; /* src: holds a defined output to copy from */
+#pragma unroll
+							for (int k = 0; k < T; ++k) {
+								const int t = t0 + k * (int)C;
+								const bool defined = l >= p_min && t >= 0;
+								held[k] = (ph[k] == pph[k]) && defined && t < (int)fast_total;
+								src[k] = defined && !held[k];
+							}
+							for (int it = 0; it < 64; ++it) {
+								bool changed = false;
+#pragma unroll
+								for (int k = 0; k < T; ++k) {
+									const float sp = __shfl_up(s[k], 1);
+									const bool okp = __shfl_up(src[k], 1);
+									if (held[k] && okp && l > 0) { s[k] = sp; held[k] = false; src[k] = true; changed = true; }
+								}
+								if (!__any(changed)) break;
+							}
+#pragma unroll
+							for (int k = 0; k < T; ++k) {
+								/* running-sum voices have a lane of slack (analyze_kernel): a hold left on the
+								 * operator's first defined lane is harmless there */
+								if (SCAN && l == p_min) held[k] = false;
+								if (held[k]) rep[1] = ((uint32_t)(l - p_min) << 24) | ((uint32_t)k << 20) | (si << 12) | (cg & 0xfff); /* debug */
+								held_rows |= __any(held[k]) ? (1u << k) : 0u;
+							}
+						}
+						if (is_last_group) {
+							/* the row that holds the segment's last frame stages the state */
+#pragma unroll
+							for (int k = 0; k < T; ++k) {
+								const int t = t0 + k * (int)C;
+								if (t == (int)fast_total - 1 && l >= (int)H) {
+									DevOp &o = P.ops[f.gop];
+									o.st_prev_phase = ph[k];
+									o.st_prev_Is = Is[k];
+									o.st_prev_s = s[k];
+								}
+							}
+						}
+					}
+				} else if (type == OT_RASEG) {
+					/* rasg.h:165-222 + 692-743: frame t reads the counter cp0 + inc * t (+ PM) */
+					const bool rate2x = (f.type >> 17) & 1;
+					const float phase_scale = rate2x ? 0x1p31f * 2 : 0x1p31f;
+					const RasParams rp = ras_params((uint32_t)f.tab & 0xff, ((uint32_t)f.tab >> 8) & 0xffff,
+							f_bits(f.diff_scale), f_bits(f.diff_offset), ((uint32_t)f.tab >> 24) & 0x7f);
+					const unsigned long long inc64 = ((unsigned long long)f.prev_phase << 32) | f.inc;
+					const unsigned long long cp0 = (unsigned long long)__double_as_longlong(f.prev_Is);
+					const bool has_pm = f.pm_off != ~0u, has_fpm = f.fpm_off != ~0u;
+					unsigned long long cpv[T]; /* the counter each frame reads (post-increment), before PM */
+					float fv[T];
+					bool fvar = false;
+					if (SCAN && (f.ramp & 2)) {
+						/* the frequency varies: the counter is a running sum of 64-bit increments */
+						const FastAux fa = load_aux_uniform(faux + si);
+						fvar = (fa.flags & (FA_FVAR_SLOT | FA_FVAR_LINE)) != 0;
+						if (fvar) {
+							const float rcoeff = rate2x ? fa.coeff * 2 : fa.coeff;
+							unsigned long long S[T], incv[T];
+							uint32_t *irow = (FULL && (fa.pad[2] & 2u)) ? P.inc_rows + (size_t)2 * (fa.pad[2] >> 8) * P.inc_stride : nullptr;
+							const bool inc_read = irow && P.mode == P.sum_levels + 1;
+							const bool inc_write = irow && two && P.mode == fa.pad[1];
+#pragma unroll
+							for (int k = 0; k < T; ++k) {
+								const int t = t0 + k * (int)C;
+								const bool in_seg = t >= 0 && t < (int)fast_total;
+								if (inc_read) { /* saved by the sum pass of its level: low and high words */
+									incv[k] = in_seg ? ((unsigned long long)irow[P.inc_stride + t] << 32) | irow[t] : 0ull;
+									fv[k] = 0.f;
+								} else {
+								float v;
+								if (fa.flags & FA_FVAR_SLOT) {
+									v = slots[fa.freq_off + k * 64];
+								} else {
+									v = fast_line_value(fa.fl, t);
+									const bool in_goal = (uint32_t)t < fa.fl.goal_len;
+									if (fa.flags & (in_goal ? FA_MUL_GOAL : FA_MUL_HOLD))
+										v *= fa.fmul_off != ~0u ? slots[fa.fmul_off + k * 64] : fa.mulc;
+								}
+								fv[k] = v;
+								incv[k] = in_seg ? (unsigned long long)rint64(rcoeff * v) : 0ull;
+								if (inc_write && l >= (int)H && in_seg) { irow[t] = (uint32_t)incv[k]; irow[P.inc_stride + t] = (uint32_t)(incv[k] >> 32); }
+								}
+								S[k] = wave_incl_scan64_dpp(incv[k]);
+							}
+							unsigned long long *sums = two ? scan + (size_t)fa.pad[0] * P.scan_groups : nullptr;
+							const bool sum_me = two && P.mode == fa.pad[1];
+							unsigned long long acc;
+							if (look_own) {
+								acc = first_group ? cp0 : carry[si];
+							} else if (look) {
+								unsigned long long tot = 0;
+#pragma unroll
+								for (int k = 0; k < T; ++k) tot += readlane64(S[k], 63) - readlane64(S[k], (int)H - 1);
+								if (look_lds) {
+									unsigned long long *e_lo = lk_base + (size_t)fa.pad[0] * 2 * 64;
+									acc = cp0 + lookback64<true>(e_lo, e_lo + 64, cg, tot, 0, lk_ring, l);
+								} else {
+									unsigned long long *e_lo = lookv + (size_t)fa.pad[0] * 2 * P.scan_groups;
+									acc = cp0 + lookback64<false>(e_lo, e_lo + P.scan_groups, cg, tot, P.look_epoch, 0, l);
+								}
+							} else {
+								acc = two ? (sum_me ? 0ull : cp0 + sums[cg])
+								          : (first_group ? cp0 : carry[si]);
+							}
+#pragma unroll
+							for (int k = 0; k < T; ++k) {
+								const unsigned long long lead = readlane64(S[k], (int)H - 1);
+								const unsigned long long last = readlane64(S[k], 63);
+								cpv[k] = acc + (S[k] - lead) - incv[k];
+								acc += last - lead;
+							}
+							if (two) {
+								if (sum_me) {
+									if (l == 0) sums[cg] = acc;
+									continue;
+								}
+							} else if ((!look || look_own) && l == 0) {
+								carry[si] = acc;
+							}
+							if (is_last_group) { /* the counter after the segment's last frame */
+#pragma unroll
+								for (int k = 0; k < T; ++k) {
+									const int t = t0 + k * (int)C;
+									if (t == (int)fast_total - 1 && l >= (int)H)
+										P.ops[f.gop].st_prev_Is = __longlong_as_double((long long)(cpv[k] + incv[k]));
+								}
+							}
+						}
+					}
+					if (!fvar) {
+#pragma unroll
+						for (int k = 0; k < T; ++k) {
+							const int t = t0 + k * (int)C;
+							cpv[k] = cp0 + inc64 * (unsigned long long)(long long)t;
+							fv[k] = f.fc;
+						}
+					}
+#pragma unroll
+					for (int k = 0; k < T; ++k) {
+						unsigned long long cp = cpv[k];
+						if (has_pm || has_fpm)
+							cp += (unsigned long long)pm_offset(has_pm, has_fpm,
+									has_pm ? slots[f.pm_off + k * 64] : 0.f,
+									has_fpm ? slots[f.fpm_off + k * 64] : 0.f, fv[k], phase_scale);
+						uint32_t cyc;
+						float phf;
+						ras_split(cp, cyc, phf);
+						s[k] = ras_sample(rp, cyc, phf, true);
+					}
+				} else if (type == OT_NOISE) {
+					const uint32_t nz = (f.type >> 8) & 0xff;
+					const uint32_t n0 = f.phase0, nprev = f.prev_phase;
+#pragma unroll
+					for (int k = 0; k < T; ++k) {
+						const int t = t0 + k * (int)C;
+						const uint32_t n = n0 + (uint32_t)t;
+						if (nz == NZ_vi) {
+							uint32_t s1 = ranfast32(n);
+							uint32_t s0 = t == 0 ? nprev : ranfast32(n - 1);
+							s[k] = fscalei((s1 / 2) - (s0 / 2), 0x1p-31f);
+						} else if (nz == NZ_bv) {
+							int32_t s1 = noise_bv_term(n);
+							int32_t s0 = t == 0 ? (int32_t)nprev : noise_bv_term(n - 1);
+							s[k] = (float)(s1 - s0);
+						} else {
+							s[k] = noise_stateless(nz, n);
+						}
+					}
+				} else { /* OT_AMP (generator.c:517-518: 1), or an oscillator whose output stands still */
+#pragma unroll
+					for (int k = 0; k < T; ++k) s[k] = f.fc;
+				}
+				/* amplitude and combine: generator.c:384-440 */
+				float r[T];
+				if (f.amp_off != ~0u) {
+#pragma unroll
+					for (int k = 0; k < T; ++k) r[k] = slots[f.amp_off + k * 64];
+				} else if (f.ramp & 1) { /* amplitude ramp in progress, sau/line.c:65-281 */
+					const FastLine fl = load_line_uniform(flines + si);
+#pragma unroll
+					for (int k = 0; k < T; ++k) r[k] = fast_line_value(fl, t0 + k * (int)C);
+				} else {
+#pragma unroll
+					for (int k = 0; k < T; ++k) r[k] = f.ac;
+				}
+				if (layer) {
+#pragma unroll
+					for (int k = 0; k < T; ++k)
+						r[k] = mix_combine(slots[f.out_off + k * 64], s[k], r[k], wave_env, true);
+				} else if (wave_env) {
+#pragma unroll
+					for (int k = 0; k < T; ++k) r[k] = mix_combine(0.f, s[k], r[k], true, false);
+				} else {
+#pragma unroll
+					for (int k = 0; k < T; ++k) r[k] = s[k] * r[k];
+				}
+				if (to_voice) {
+#pragma unroll
+					for (int k = 0; k < T; ++k) {
+						const int t = t0 + k * (int)C;
+						const bool mine = REPAIR ? (l == (int)(H + FAST_REPAIR_SHIFT) && ((repair_rows >> k) & 1u)) : (l >= (int)H);
+						if (mine && t < (int)fast_total) vrow[t] = r[k];
+					}
+				} else {
+#pragma unroll
+					for (int k = 0; k < T; ++k) slots[f.out_off + k * 64] = r[k];
+				}
+			} else if (kind == ST_LINE) {
+				/* held line: v0 (sau/line.c:435-442); ratio lines only exist for freq */
+				if (f.ramp) {
+					FastLine fl;
+					fl.goal_len = 0; fl.hold = f.ac; fl.pad = 0;
+					fl.sw = sweep_setup(LN_sah, 0.f, 0.f, 0, 1);
+					if (f.ramp & 1) fl = load_line_uniform(flines + si);
+					uint32_t mflags = 0, fmul_off = ~0u;
+					float mulc = 1.f;
+					if (SCAN && (f.ramp & 2)) { /* ratio line: x the parent's frequency (sau/line.c:72) */
+						const FastAux fa = load_aux_uniform(faux + si);
+						mflags = fa.flags; fmul_off = fa.fmul_off; mulc = fa.mulc;
+					}
+#pragma unroll
+					for (int k = 0; k < T; ++k) {
+						const int t = t0 + k * (int)C;
+						float v = fast_line_value(fl, t);
+						const bool in_goal = (uint32_t)t < fl.goal_len;
+						if (mflags & (in_goal ? FA_MUL_GOAL : FA_MUL_HOLD))
+							v *= fmul_off != ~0u ? slots[fmul_off + k * 64] : mulc;
+						slots[f.out_off + k * 64] = v;
+					}
+				} else {
+#pragma unroll
+					for (int k = 0; k < T; ++k) slots[f.out_off + k * 64] = f.ac;
+				}
+			} else if (kind == ST_LERP) { /* generator.c:466-467 */
+#pragma unroll
+				for (int k = 0; k < T; ++k) {
+					float pv = slots[f.out_off + k * 64];
+					pv += (slots[f.aux_off + k * 64] - pv) * slots[f.pm_off + k * 64];
+					slots[f.out_off + k * 64] = pv;
+				}
+			} else if (kind == ST_VOICE) { /* generator.c:749-788 with pan modulators */
+#pragma unroll
+				for (int k = 0; k < T; ++k) {
+					const int t = t0 + k * (int)C;
+					const bool mine = REPAIR ? (l == (int)(H + FAST_REPAIR_SHIFT) && ((repair_rows >> k) & 1u)) : (l >= (int)H);
+					if (mine && t < (int)fast_total) {
+						vrow[t] = slots[f.out_off + k * 64];
+						if (prow) prow[t] = f.pm_off != ~0u ? slots[f.pm_off + k * 64] : f.pan;
+					}
+				}
+			}
+		}
+		if (held_rows) {
+			/* to the repair pass -- unless this is it, the group touches an end of the segment
+			 * (carried state sits at fixed lanes there) or the voice has running sums */
+			bool noted = false;
+			if (!REPAIR && !SCAN && P.repair_on && !first_group && !is_last_group &&
+			    (int)(cg * T * C) - (int)H >= (int)FAST_REPAIR_SHIFT) {
+				uint32_t at = 0;
+				if (l == 0) at = atomicAdd(&rep[0], 1u);
+				at = uni(at);
+				if (at < FAST_MAX_REPAIR) {
+					if (l == 0) {
+						rep[2 + 2 * at] = cg;
+						rep[3 + 2 * at] = held_rows;
+						atomicOr(&P.pass_flags[FAST_MAX_LEVELS], 1u);
+					}
+					noted = true;
+				}
+			}
+			if (!noted) zero_acc = 1;
+		}
+	}
+	if (__any(zero_acc) && l == 0) atomicOr(&P.info[v].bail, 1u);
+
+}
+
+/* SCAN: the kernel may meet voices with running-sum phases (it then holds both builds of fast_voice). */
+#ifndef FK_MINB
+#define FK_MINB 1
+#endif
+template <int T, int SCAN>
+__global__ void __launch_bounds__(1024, FK_MINB) fast_kernel(FastParams P) {
+	constexpr int NP = 64 * T;
+	constexpr int W = 16;
+	extern __shared__ __align__(16) unsigned char lds[];
+	const int tid = threadIdx.x;
+	const int w = (int)uni((uint32_t)tid >> 6);
+	const int l = tid & 63;
+	/* a sum pass nobody needs costs a launch, not a table staging */
+	if (SCAN == 1 && P.mode != 0 && P.mode <= P.sum_levels && P.pass_flags[P.mode - 1] == 0) return;
+	if (SCAN == 1 && P.mode == P.sum_levels + 2 && P.pass_flags[FAST_MAX_LEVELS + 1] == 0) return; /* no chains */
+	if (SCAN == 1 && P.only_multi && P.pass_flags[FAST_MAX_LEVELS + 2] == 0) return; /* no voice the single-pass build left out */
+
+	HerpC23 *t23 = (HerpC23 *)lds;
+	HerpC01 *t01 = (HerpC01 *)(lds + (size_t)P.n_tabs * WAVE_LEN * sizeof(HerpC23));
+	unsigned char *areas = lds + (size_t)P.n_tabs * WAVE_LEN * (sizeof(HerpC23) + sizeof(HerpC01));
+	const size_t area_bytes = (size_t)P.n_fast * NP * sizeof(float) + (size_t)P.max_steps * sizeof(unsigned long long);
+	float *slots = (float *)(areas + (size_t)w * area_bytes) + l; /* lane's column of every row */
+	unsigned long long *carry = (unsigned long long *)(areas + (size_t)w * area_bytes + (size_t)P.n_fast * NP * sizeof(float)); /* per step */
+	unsigned long long *lring = nullptr; /* the single-pass build: look-back rings after the waves' areas, zeroed */
+	if (SCAN == 2) {
+		lring = (unsigned long long *)(areas + (size_t)W * area_bytes);
+		lring[tid] = 0;
+		static_assert(LOOK_LDS_BYTES == 1024 * sizeof(unsigned long long), "one word per thread");
+	}
+
+	for (uint32_t t = 0; t < P.n_tabs; ++t) {
+		const uint32_t wave = P.wave_of_tab[t];
+		const uint4 *s23 = (const uint4 *)(P.g_c23 + (size_t)wave * WAVE_LEN);
+		uint4 *d23 = (uint4 *)(t23 + (size_t)t * WAVE_LEN);
+		for (uint32_t i = tid; i < WAVE_LEN; i += 64 * W) d23[i] = s23[i];
+		const uint2 *s01 = (const uint2 *)(P.g_c01 + (size_t)wave * WAVE_LEN);
+		uint2 *d01 = (uint2 *)(t01 + (size_t)t * WAVE_LEN);
+		for (uint32_t i = tid; i < WAVE_LEN; i += 64 * W) d01[i] = s01[i];
+	}
+	__syncthreads(); /* the only barrier: tables are shared, all else is per wave */
+
+	const uint32_t g = blockIdx.x * W + (uint32_t)w;
+	const uint32_t total_waves = gridDim.x * W;
+	const uint32_t NV = P.n_voices;
+	const uint32_t wpv = total_waves >= NV ? total_waves / NV : 1; /* waves per voice */
+	uint32_t v = total_waves >= NV ? g / wpv : g;
+	const uint32_t vstride = total_waves >= NV ? NV : total_waves;
+	const uint32_t cstart = total_waves >= NV ? g % wpv : 0;
+
+	for (; v < NV; v += vstride) {
+		const FastInfo fi = P.info[v];
+		const uint32_t seq_kind = SCAN ? uni(fi.seq) : 0u;
+		if (SCAN == 1 && P.mode != 0 && P.mode <= P.sum_levels && (seq_kind != 2 || uni(fi.levels) < P.mode))
+			continue; /* a sum pass only concerns multi-pass voices that deep */
+		if (SCAN == 1 && P.mode == P.sum_levels + 2 && (seq_kind != 2 || uni(fi.n_chain) == 0))
+			continue; /* the chain-input pass only concerns voices with feedback chains */
+		if (SCAN == 2) { /* the other kinds of running-sum voice have a launch of the full build to themselves */
+			if (seq_kind == 1 || seq_kind == 2) continue;
+			if (seq_kind == 3) fast_voice<T, 2>(P, v, fi, slots, carry, t23, t01, l, wpv, cstart, total_waves >= NV ? lring : nullptr);
+			else fast_voice<T, 0>(P, v, fi, slots, carry, t23, t01, l, wpv, cstart);
+			continue;
+		}
+		if (SCAN == 1 && (P.only_multi ? (seq_kind != 1 && seq_kind != 2) : seq_kind == 3)) continue;
+		if (SCAN && seq_kind != 0) fast_voice<T, 1>(P, v, fi, slots, carry, t23, t01, l, wpv, cstart);
+		else fast_voice<T, 0>(P, v, fi, slots, carry, t23, t01, l, wpv, cstart);
+	}
+}
+
+/* The row groups fast_kernel noted (see FAST_REPAIR_SHIFT): same workgroup shape and LDS layout. */
+template <int T>
+__global__ void __launch_bounds__(1024) repair_kernel(FastParams P) {
+	constexpr int NP = 64 * T;
+	constexpr int W = 16;
+	extern __shared__ __align__(16) unsigned char lds[];
+	if (P.pass_flags[FAST_MAX_LEVELS] == 0) return; /* the usual case */
+	const int tid = threadIdx.x;
+	const int w = (int)uni((uint32_t)tid >> 6);
+	const int l = tid & 63;
+	HerpC23 *t23 = (HerpC23 *)lds;
+	HerpC01 *t01 = (HerpC01 *)(lds + (size_t)P.n_tabs * WAVE_LEN * sizeof(HerpC23));
+	unsigned char *areas = lds + (size_t)P.n_tabs * WAVE_LEN * (sizeof(HerpC23) + sizeof(HerpC01));
+	const size_t area_bytes = (size_t)P.n_fast * NP * sizeof(float) + (size_t)P.max_steps * sizeof(unsigned long long);
+	float *slots = (float *)(areas + (size_t)w * area_bytes) + l;
+	unsigned long long *carry = (unsigned long long *)(areas + (size_t)w * area_bytes + (size_t)P.n_fast * NP * sizeof(float));
+	for (uint32_t t = 0; t < P.n_tabs; ++t) {
+		const uint32_t wave = P.wave_of_tab[t];
+		const uint4 *s23 = (const uint4 *)(P.g_c23 + (size_t)wave * WAVE_LEN);
+		uint4 *d23 = (uint4 *)(t23 + (size_t)t * WAVE_LEN);
+		for (uint32_t i = tid; i < WAVE_LEN; i += 64 * W) d23[i] = s23[i];
+		const uint2 *s01 = (const uint2 *)(P.g_c01 + (size_t)wave * WAVE_LEN);
+		uint2 *d01 = (uint2 *)(t01 + (size_t)t * WAVE_LEN);
+		for (uint32_t i = tid; i < WAVE_LEN; i += 64 * W) d01[i] = s01[i];
+	}
+	__syncthreads();
+	/* one wave per voice with noted groups */
+	for (uint32_t v = blockIdx.x * W + (uint32_t)w; v < P.n_voices; v += gridDim.x * W) {
+		if (uni(P.repair[(size_t)v * FAST_REPAIR_WORDS]) == 0) continue;
+		const FastInfo fi = P.info[v];
+		if (uni(fi.total) == 0 || uni(fi.seq) != 0) continue;
+		fast_voice<T, 0, true>(P, v, fi, slots, carry, t23, t01, l, 1u, 0u);
+	}
+}

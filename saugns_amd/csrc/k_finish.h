@@ -1,0 +1,228 @@
+/* k_finish.h -- part of hip_backend.hip (included there, inside namespace sauhip; not a header of its own).
+ * finalize_kernel, mix_kernel, event_kernel and the line known-answer kernel. */
+/* Apply the closed forms to the operator state, or hand the whole segment
+ * to the block loop when a chunk had to bail out. */
+__global__ void __launch_bounds__(64) finalize_kernel(FastParams P) {
+	/* one thread per (voice, operator); the voice's own bookkeeping goes to its operator 0 */
+	const uint32_t gid = blockIdx.x * 64 + threadIdx.x;
+	const uint32_t v = gid / P.max_ops, i = gid % P.max_ops;
+	if (gid < FAST_FLAGS && P.pass_flags) P.pass_flags[gid] = 0; /* for the next segment's kernels */
+	if (v >= P.n_voices) return;
+	const FastInfo fi = P.info[v];
+	const VoiceDesc vd = P.voices[v];
+	if (fi.total == 0 || fi.bail) {
+		if (i == 0) {
+			P.fast_done[v] = 0;
+			P.worklist[atomicAdd(P.work_count, 1u)] = v;
+		}
+		return;
+	}
+	const uint32_t *ids = P.op_ids + vd.ops_ofs;
+	const uint32_t total = fi.total;
+	if (i < vd.nops) {
+		DevOp &o = P.ops[ids[i]];
+		if (!o.rt_frozen) { /* (out of time: state stands still) */
+		if (!(o.flags & OPF_TIME_INF)) o.time -= total;
+		const bool o_osc = o.type == OT_WAVE || o.type == OT_RASEG;
+		const Step *plan = P.steps + vd.plan_ofs;
+		for (uint32_t ln = 0; ln < L_COUNT; ++ln) {
+			/* the lines the reference runs or skips for this operator (generator.c:505-664, 756-762) */
+			if (ln == L_PAN && i != vd.carr_local) continue;
+			if (!o_osc && (ln == L_FREQ || ln == L_FREQ2 || ln == L_PMA)) continue;
+			LineState ls = o.line[ln];
+			if (ls.flags & LP_GOAL) {
+				/* a range partner without range modulators is skipped, not run (generator.c:468-470) */
+				bool skipped = false;
+				if (ln == L_FREQ2 || ln == L_AMP2) {
+					skipped = true;
+					for (uint32_t si = 0; si < vd.plan_len; ++si)
+						if (plan[si].op == i && plan[si].kind == ST_LINE && plan[si].which == ln) { skipped = false; break; }
+				}
+				/* a frequency ramp whose goal and state disagree about being ratios rescales its
+				 * state by the parent's frequency (sau/line.c:358-370); such a voice only comes
+				 * this way when that frequency is one value (analyze_kernel) */
+				bool have_mul = false; float mul0 = 0.f;
+				const bool g_ratio = (ls.flags & LP_GOAL_RATIO) != 0, s_ratio = (ls.flags & LP_STATE_RATIO) != 0;
+				if (!skipped && (ln == L_FREQ || ln == L_FREQ2) && g_ratio != s_ratio) {
+					for (uint32_t si = 0; si < vd.plan_len; ++si) {
+						const Step st = plan[si];
+						if (st.op != i || st.fmul == NO_SLOT || st.prov == NO_SLOT) continue;
+						if ((st.kind == ST_LINE && st.which == ln) || (st.kind == ST_OSC && ln == L_FREQ)) {
+							have_mul = true; mul0 = P.ops[ids[st.prov]].rt_fconst;
+							break;
+						}
+					}
+				}
+				if (skipped) line_skip(ls, total, vd.lat, 0);
+				else (void)line_begin(ls, total, have_mul, mul0, vd.lat, 0);
+			} else {
+				line_advance_hold(ls, total, vd.lat, 0);
+			}
+			o.line[ln] = ls;
+		}
+		if (o.type == OT_WAVE) {
+			if (o.rt_fconst_valid) o.phase += rint32w(o.coeff * o.rt_fconst) * total;
+			else o.phase = o.st_phase; /* running sum, staged by the sequential scan */
+			o.prev_phase = o.st_prev_phase;
+			o.prev_Is = o.st_prev_Is;
+			o.prev_s = o.st_prev_s;
+			o.flags &= ~OPF_OSC_RESET;
+			if (o.ras_level == CHAIN_MARK) { /* a feedback chain: chain_kernel staged the rest of its state */
+				o.fb_s = bits_f(o.ras_alpha);
+				o.ras_level = 0;
+			}
+		} else if (o.type == OT_RASEG) {
+			const bool rate2x = (o.flags & OPF_RATE2X) != 0;
+			const unsigned long long inc64 = (unsigned long long)rint64((rate2x ? o.coeff * 2 : o.coeff) * o.rt_fconst);
+			if (o.rt_fconst_valid) o.cycle_phase += inc64 * total;
+			else o.cycle_phase = (unsigned long long)__double_as_longlong(o.st_prev_Is); /* running sum, staged */
+		} else if (o.type == OT_NOISE) {
+			const uint32_t n0 = o.noise_n;
+			if (o.wave == NZ_vi) o.noise_prev = ranfast32(n0 + total - 1);
+			else if (o.wave == NZ_bv) o.noise_prev = (uint32_t)noise_bv_term(n0 + total - 1);
+			o.noise_n = n0 + total;
+		}
+		}
+	}
+	if (i != 0) return;
+	P.fast_done[v] = total;
+	if (total < vd.run_len) {
+		P.worklist[atomicAdd(P.work_count, 1u)] = v;
+	} else { /* whole segment done here: tell the mixer */
+		VoiceOut vo;
+		vo.pan_const = P.ops[ids[vd.carr_local]].line[L_PAN].v0;
+		vo.has_pan = vd.pan_dynamic_row != ~0u ? 1u : 0u;
+		vo.valid_len = total;
+		vo.pan_row = vd.pan_dynamic_row;
+		P.vinfo[vd.out_row] = vo;
+	}
+}
+
+struct MixStream {
+	uint32_t first_row, n_rows;
+	float amp_scale;
+	uint32_t write_len;
+	int16_t *pcm; /* stream's PCM row */
+};
+
+struct MixParams {
+	const MixStream *streams;
+	const float *vout;
+	const float *pan;
+	const VoiceOut *vinfo;
+	uint32_t row_stride;
+	uint32_t pcm_offset;
+	uint32_t stereo;
+	uint32_t swap_bytes; /* big-endian PCM for AU files (player/sndfile.c:160-168) */
+};
+
+/* generator.c:749-825: ordered voice sum (ref-build association) and PCM.
+ * One thread per output frame walks the stream's voices in ascending id --
+ * the reference's f32 accumulation order -- so the sum is bit-identical to
+ * the CPU's and independent of scheduling.  Loads are issued eight voices
+ * ahead of the (serially dependent) adds. */
+constexpr int MIX_TILE = 256; /* voices whose constants are staged at a time */
+constexpr int MIX_AHEAD = 16; /* loads in flight per thread */
+__global__ void __launch_bounds__(256) mix_kernel(MixParams P) {
+	__shared__ float s_pan[MIX_TILE];
+	__shared__ uint32_t s_valid[MIX_TILE];
+	__shared__ uint32_t s_prow[MIX_TILE]; /* pan row, or ~0u */
+	__shared__ uint32_t s_special;        /* tile has a short row or a pan row */
+	const MixStream ms = P.streams[blockIdx.y];
+	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+	if (blockIdx.x * 256 >= ms.write_len) return;
+	const bool act = i < ms.write_len;
+	float L = 0.f, R = 0.f;
+	for (uint32_t r0 = 0; r0 < ms.n_rows; r0 += MIX_TILE) {
+		const uint32_t nt = min((uint32_t)MIX_TILE, ms.n_rows - r0);
+		__syncthreads();
+		if (threadIdx.x == 0) s_special = 0;
+		__syncthreads();
+		if (threadIdx.x < nt) {
+			const VoiceOut vo = P.vinfo[ms.first_row + r0 + threadIdx.x];
+			s_pan[threadIdx.x] = vo.pan_const;
+			s_valid[threadIdx.x] = vo.valid_len;
+			s_prow[threadIdx.x] = vo.has_pan ? vo.pan_row : ~0u;
+			if (vo.has_pan || vo.valid_len < ms.write_len) s_special = 1;
+		}
+		__syncthreads();
+		if (!act) continue;
+		const float *base = P.vout + (size_t)(ms.first_row + r0) * P.row_stride + i;
+		if (s_special == 0) {
+			/* every row of the tile covers the whole segment with a constant pan */
+			uint32_t r = 0;
+			for (; r + MIX_AHEAD <= nt; r += MIX_AHEAD) {
+				float sv[MIX_AHEAD];
+#pragma unroll
+				for (int u = 0; u < MIX_AHEAD; ++u) sv[u] = base[(size_t)(r + u) * P.row_stride];
+#pragma unroll
+				for (int u = 0; u < MIX_AHEAD; ++u) {
+					const float v = sv[u] * ms.amp_scale;
+					const float s_r = v * s_pan[r + u];
+					L = (L + v) - s_r;
+					R = (R + v) + s_r;
+				}
+			}
+			for (; r < nt; ++r) {
+				const float v = base[(size_t)r * P.row_stride] * ms.amp_scale;
+				const float s_r = v * s_pan[r];
+				L = (L + v) - s_r;
+				R = (R + v) + s_r;
+			}
+			continue;
+		}
+		for (uint32_t r = 0; r < nt; r += 8) {
+			float sv[8], pn[8];
+			bool okv[8];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) {
+				const uint32_t rr = r + u;
+				const bool ok = rr < nt && i < s_valid[rr < nt ? rr : 0];
+				okv[u] = ok;
+				sv[u] = ok ? base[(size_t)rr * P.row_stride] : 0.f;
+				const uint32_t pr = rr < nt ? s_prow[rr] : ~0u;
+				pn[u] = rr < nt ? s_pan[rr] : 0.f;
+				if (ok && pr != ~0u) pn[u] = P.pan[(size_t)pr * P.row_stride + i];
+			}
+#pragma unroll
+			for (int u = 0; u < 8; ++u) {
+				if (okv[u]) { /* generator.c:842-843: a voice adds only the frames it produced */
+					const float v = sv[u] * ms.amp_scale;
+					const float s_r = v * pn[u];
+					L = (L + v) - s_r;
+					R = (R + v) + s_r;
+				}
+			}
+		}
+	}
+	if (!act) return;
+	if (P.stereo) {
+		int16_t *d = ms.pcm + 2 * (size_t)(P.pcm_offset + i);
+		const int16_t l16 = pcm16(L), r16 = pcm16(R);
+		d[0] = P.swap_bytes ? pcm_swap(l16) : l16;
+		d[1] = P.swap_bytes ? pcm_swap(r16) : r16;
+	} else {
+		const int16_t m16 = pcm16((L + R) * 0.5f);
+		ms.pcm[P.pcm_offset + i] = P.swap_bytes ? pcm_swap(m16) : m16;
+	}
+}
+
+__global__ void event_kernel(DevOp *ops, const OpUpdate *recs, uint32_t n, const WaveConst *wc) {
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	OpUpdate u = recs[i];
+	DevOp o = ops[u.op];
+	apply_update(o, u, wc);
+	ops[u.op] = o;
+}
+
+/* Known-answer probe of the shared arithmetic as compiled for the device:
+ * one block evaluates a line for `len` samples exactly as ST_LINE does. */
+__global__ void kat_line_kernel(LineState st, uint32_t len, const float *mul, float *out,
+		LineState *st_out) {
+	LineState ls = st;
+	LineBlock lb = line_begin(ls, len, mul != nullptr, mul ? mul[0] : 0.f, lattice_none(), 0);
+	for (uint32_t j = threadIdx.x; j < len; j += blockDim.x)
+		out[j] = line_value(lb, j, mul ? mul[j] : 1.f);
+	if (threadIdx.x == 0) *st_out = ls;
+}

@@ -74,6 +74,23 @@ if c5:
                "note": "averages per launch over the run (segments of 65536 frames, the last one shorter); "
                        "zero-work launches of a pass nobody needs are included in that pass's average",
                "kernels": c5}, open(f"profiles/{name}_c5_pmc_summary.json", "w"), indent=1)
+# running-sum workloads: the sweep's lines, kernel statistics, instruction counts per launch of the single-pass build
+if os.path.exists(f"gpurun_out/sweep_{tag}_fm.txt"):
+    shutil.copy(f"gpurun_out/sweep_{tag}_fm.txt", f"profiles/{name}_fm_sweep.txt")
+if os.path.exists(f"gpurun_out/prof_{tag}_fm/{tag}_fm_kernel_stats.csv"):
+    shutil.copy(f"gpurun_out/prof_{tag}_fm/{tag}_fm_kernel_stats.csv", f"profiles/{name}_fm_kernel_stats.csv")
+src = f"gpurun_out/pmc_{tag}_fm_inst/i_counter_collection.csv"
+if os.path.exists(src):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(src)):
+        if "sauhip" in r["Kernel_Name"]:
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    fm = {k: dict({c: sum(x) / len(x) for c, x in v.items()}, launches=len(next(iter(v.values())))) for k, v in agg.items()}
+    json.dump({"command": "rocprofv3 --pmc <C> --kernel-trace -- python3 tools/gpu_sweep.py c3f",
+               "note": "1024 voices x 4 operators with carrier FM, then 1024 x 2 with a carrier glide; 44100-frame steps; "
+                       "averages per launch over both", "kernels": fm},
+              open(f"profiles/{name}_fm_pmc_summary.json", "w"), indent=1)
 fk = [v for n, v in out["kernels"].items() if "fast_kernel" in n][0]
 rows = bench["config"]["operators"] * frames_per_step / 60  # 64-lane rows incl. lead-in, per launch
 print({a: (round(b / rows, 2) if isinstance(b, float) and b > 1e6 else b) for a, b in fk.items()})
