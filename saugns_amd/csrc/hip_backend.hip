@@ -140,6 +140,32 @@ private:
 	std::vector<hipStream_t> free_[16];
 };
 
+/* Launches of the single-pass running-sum build whose voices have waves in more than one workgroup wait for each
+ * other's sums across workgroups. One such launch alone always finishes (its workgroups are dispatched in order and
+ * a voice's lie next to each other, so what a blocked workgroup waits for is the next to get a CU), two at once
+ * from different generators could hold each other's CUs: within the process they take turns, through an event
+ * chain per device. (Launches whose voices each sit inside one workgroup need none of this.) */
+class SpreadLaunchOrder {
+public:
+	static SpreadLaunchOrder &get() { static SpreadLaunchOrder *g = new SpreadLaunchOrder; return *g; }
+	/* `launch` enqueues the kernel on `stream`; it runs after the device's previous such launch has finished */
+	template <typename F> bool ordered(int dev, hipStream_t stream, F launch) {
+		std::lock_guard<std::mutex> lk(mu_);
+		Dev &d = dev_[dev & 15];
+		if (d.last && hipStreamWaitEvent(stream, d.last, 0) != hipSuccess) return false;
+		if (!launch()) return false;
+		hipEvent_t &e = d.ring[d.next++ & 63];
+		if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+		if (hipEventRecord(e, stream) != hipSuccess) return false;
+		d.last = e; /* (a wait captures the event's state when it is enqueued: re-recording it 64 launches on is harmless) */
+		return true;
+	}
+private:
+	struct Dev { hipEvent_t ring[64] = {}; hipEvent_t last = nullptr; unsigned next = 0; };
+	std::mutex mu_;
+	Dev dev_[16];
+};
+
 static void *pool_alloc(bool pinned, size_t &bytes, std::string &err) {
 	bytes = BufPool::bucket(bytes);
 	void *q = BufPool::get().take(pinned, bytes);
@@ -292,6 +318,7 @@ public:
 		inc_rows_enabled_ = getenv("SAU_AMD_NO_INC_ROWS") == nullptr;
 		lookback_enabled_ = getenv("SAU_AMD_NO_LOOKBACK") == nullptr; /* single-pass running sums */
 		if (const char *lr = getenv("SAU_AMD_LOOK_ROWS")) look_rows_ = (uint32_t)atoi(lr);
+		if (const char *lm = getenv("SAU_AMD_LOOK_MIN_VOICES")) look_min_voices_ = (uint32_t)atoi(lm);
 		if (const char *cc = getenv("SAU_AMD_CHAIN_CHUNKS")) { /* pipeline depth of a segment with chains (1: off) */
 			const int n = atoi(cc);
 			chain_chunks_ = n >= 16 ? 16 : n >= 8 ? 8 : n >= 4 ? 4 : n >= 2 ? 2 : 1;
@@ -502,7 +529,8 @@ public:
 			 * single-pass (look-back) build serves, it takes those voices and the closed-form ones at the full rows
 			 * per pass, and the full build's launches only see what is left (voices with feedback chains, voices
 			 * one wave walks in order). */
-			const bool look_split = seq_enabled_ && seg.may_scan && two_pass_enabled_ && lookback_enabled_ && look_rows_ != 0;
+			const bool look_split = seq_enabled_ && seg.may_scan && two_pass_enabled_ && lookback_enabled_ && look_rows_ != 0 &&
+				seg.n_voices >= look_min_voices_;
 			if (seq_enabled_ && seg.may_scan && FT > 4 && !look_split) FT = 4;
 			if (look_split && FT > look_rows_) FT = look_rows_ >= 8 ? 8 : look_rows_ >= 4 ? 4 : 2;
 			/* block buffers: without frequency blocks, or with them when some voice may need
@@ -642,8 +670,6 @@ public:
 				const unsigned long long want = (unsigned long long)seg.n_voices * (groups < 64 ? groups : 64);
 				uint32_t fgrid = (uint32_t)((want + 15) / 16 > FK_GRID ? FK_GRID : (want + 15) / 16);
 				if (fgrid > FK_GRID) fgrid = FK_GRID;
-				/* look-back waits on other workgroups of the launch: all of them must be resident */
-				if (fp.look && n_cus_ > 0 && fgrid > (uint32_t)n_cus_) fgrid = (uint32_t)n_cus_;
 				if (fgrid < 1) fgrid = 1;
 				TimedPair *tf = timing_on_ ? new_pair(2) : nullptr;
 				if (tf) (void)hipEventRecord(tf->a, stream_);
@@ -658,9 +684,23 @@ public:
 						launched = false;
 					}
 				};
-				if (main_build == 2) { /* closed-form and single-pass voices: one launch, whole segment */
-					fp.mode = fp.sum_levels + 1; fp.only_multi = 0;
-					if (!launch_build(2, FT, fgrid)) launched = false;
+				if (main_build == 2) {
+					/* closed-form and single-pass voices: one launch, whole segment; as many waves per voice as it has row
+					 * groups (up to 64) when voices are few */
+					unsigned long long wpv = ((unsigned long long)FK_GRID * 16) / seg.n_voices;
+					if (wpv > 64) wpv = 64;
+					if (wpv > groups) wpv = groups;
+					if (wpv < 1) wpv = 1;
+					const unsigned long long waves = (unsigned long long)seg.n_voices * wpv;
+					const uint32_t grid2 = waves > (unsigned long long)FK_GRID * 16 ? FK_GRID : (uint32_t)((waves + 15) / 16);
+					fp.mode = fp.sum_levels + 1; fp.only_multi = 0; fp.look_wpv = (uint32_t)wpv;
+					fp.look_wpv_flags = getenv("SAU_AMD_LOOK_NO_LDS") ? 1u : 0u;
+					const bool inside = wpv <= 16 && (16 % wpv) == 0 && !fp.look_wpv_flags; /* every voice within one workgroup */
+					if (inside || !fp.look) {
+						if (!launch_build(2, FT, grid2 ? grid2 : 1)) launched = false;
+					} else if (!SpreadLaunchOrder::get().ordered(dev_, stream_, [&]() { return launch_build(2, FT, grid2 ? grid2 : 1); })) {
+						launched = false;
+					}
 				}
 				if (fp.scan) {
 					/* some voice may have running-sum phases: sums per row group, their prefixes, final pass */
@@ -1016,6 +1056,7 @@ private:
 	uint32_t chain_chunks_ = 8;
 	bool inc_rows_enabled_ = true;
 	bool lookback_enabled_ = true;
+	uint32_t look_min_voices_ = 1; /* SAU_AMD_LOOK_MIN_VOICES: segments with fewer voices keep the several-pass form */
 	uint32_t look_rows_ = 8; /* rows per pass of the single-pass build (SAU_AMD_LOOK_ROWS; 0: no such build, the full one takes every voice) */
 	DevBuf<unsigned long long> look_;
 	uint32_t look_epoch_ = 0;

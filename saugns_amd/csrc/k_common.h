@@ -140,10 +140,11 @@ template <bool LDS> __device__ __forceinline__ unsigned long long look_load(unsi
 	if (LDS) return __hip_atomic_load((lds_u64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-/* LDS: entry of group i at ent[i & (ring - 1)], tag i + 1; HBM: at ent[i], tag = the segment's epoch */
+/* LDS: entry of group i at ent[i % ring] (the caller keeps cg % ring), tag i + 1; HBM: at ent[i], tag = the segment's epoch */
 template <bool LDS> __device__ __forceinline__ uint32_t lookback32(unsigned long long *ent, const uint32_t cg, const uint32_t tot,
-		const uint32_t epoch, const uint32_t ring, const int l) {
-	auto at = [&](uint32_t i) { return LDS ? (i & (ring - 1)) : i; };
+		const uint32_t epoch, const uint32_t ring, const uint32_t cgm /* LDS: cg % ring */, const int l) {
+	/* (LDS: groups up to `ring` back have their entries; what lies further back is dead and reads as empty) */
+	auto at = [&](uint32_t i) { const int s_ = (int)cgm - (int)(cg - i); return LDS ? (uint32_t)(s_ < 0 ? s_ + (int)ring : s_) : i; };
 	auto tag = [&](uint32_t i) { return LDS ? i + 1 : epoch; };
 	if (cg == 0) {
 		if (l == 0) look_store<LDS>(&ent[0], look_word(tag(0), LOOK_PREFIX, tot));
@@ -155,7 +156,7 @@ template <bool LDS> __device__ __forceinline__ uint32_t lookback32(unsigned long
 	for (;;) {
 		const int idx = p - l; /* lane l looks at the group l before it; before group 0 the prefix is 0 */
 		unsigned long long e = 0;
-		if (idx >= 0) e = look_load<LDS>(&ent[at((uint32_t)idx)]);
+		if (idx >= 0 && (!LDS || cg - (uint32_t)idx <= ring)) e = look_load<LDS>(&ent[at((uint32_t)idx)]);
 		const uint32_t hi = (uint32_t)(e >> 32);
 		const uint32_t st = idx < 0 ? LOOK_PREFIX : (hi >> 2) == tag((uint32_t)idx) ? (hi & 3u) : 0u;
 		const unsigned long long m_pref = __ballot(st == LOOK_PREFIX), m_none = __ballot(st == 0);
@@ -174,8 +175,8 @@ template <bool LDS> __device__ __forceinline__ uint32_t lookback32(unsigned long
 /* 64-bit totals (R oscillators' cycle counters): low and high halves in two arrays, a pair counts once both
  * words show the same status */
 template <bool LDS> __device__ __forceinline__ unsigned long long lookback64(unsigned long long *ent_lo, unsigned long long *ent_hi,
-		const uint32_t cg, const unsigned long long tot, const uint32_t epoch, const uint32_t ring, const int l) {
-	auto at = [&](uint32_t i) { return LDS ? (i & (ring - 1)) : i; };
+		const uint32_t cg, const unsigned long long tot, const uint32_t epoch, const uint32_t ring, const uint32_t cgm, const int l) {
+	auto at = [&](uint32_t i) { const int s_ = (int)cgm - (int)(cg - i); return LDS ? (uint32_t)(s_ < 0 ? s_ + (int)ring : s_) : i; };
 	auto tag = [&](uint32_t i) { return LDS ? i + 1 : epoch; };
 	auto publish = [&](uint32_t i, uint32_t status, unsigned long long v) {
 		look_store<LDS>(&ent_lo[at(i)], look_word(tag(i), status, (uint32_t)v));
@@ -191,7 +192,7 @@ template <bool LDS> __device__ __forceinline__ unsigned long long lookback64(uns
 	for (;;) {
 		const int idx = p - l;
 		unsigned long long a = 0, b = 0;
-		if (idx >= 0) {
+		if (idx >= 0 && (!LDS || cg - (uint32_t)idx <= ring)) {
 			a = look_load<LDS>(&ent_lo[at((uint32_t)idx)]);
 			b = look_load<LDS>(&ent_hi[at((uint32_t)idx)]);
 		}

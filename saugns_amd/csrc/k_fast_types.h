@@ -120,6 +120,9 @@ struct FastParams {
 	 * (one per segment) makes every older word read as empty, so nothing is cleared between segments. */
 	unsigned long long *look; /* [n_look_rows][2][scan_groups] (VoiceDesc.look_base/n_look), or NULL */
 	uint32_t look_epoch;
+	uint32_t look_wpv_flags; /* 1: no rings in LDS (tuning aid) */
+	uint32_t look_wpv;  /* waves per voice in fast_kernel<T, 2>'s launches (1..64): a voice whose waves sit in one workgroup
+	                     * looks back through rings in LDS, one spread over neighbouring workgroups through words in HBM */
 	uint32_t rows_multi; /* rows per pass in the launches of the full running-sum build (kinds 1 and 2) */
 	uint32_t only_multi; /* this launch: only the voices fast_kernel<T, 2> leaves out (one wave in order, several passes) */
 	int8_t ctab_of_wave[12];

@@ -57,9 +57,10 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 	/* the single-pass build: a voice with one wave carries its sums in LDS like an in-order voice; the waves of
 	 * one workgroup look back through rings in LDS; voices spread wider go through HBM */
 	const bool look_own = SCAN == 2 && wpv == 1;
-	const bool look_lds = SCAN == 2 && lring && wpv >= 2 && wpv <= 16 && (16 % wpv) == 0;
+	const uint32_t w0 = (v * wpv) & 15u; /* the voice's first wave within its workgroup (fast_kernel: waves v * wpv ...) */
+	const bool look_lds = SCAN == 2 && lring && wpv >= 2 && w0 + wpv <= 16 && !(P.look_wpv_flags & 1u);
 	const uint32_t lk_ring = 4 * wpv;
-	unsigned long long *lk_base = look_lds ? lring + (uni((uint32_t)threadIdx.x >> 6) / wpv) * lk_ring : nullptr;
+	unsigned long long *lk_base = look_lds ? lring + w0 * 4 : nullptr;
 	if (seq && cstart != 0) return;
 	const uint32_t gstride = seq ? 1u : wpv;
 	unsigned long long *scan = two ? P.scan + (size_t)v * FAST_MAX_SCAN * P.scan_groups : nullptr;
@@ -91,7 +92,8 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 			}
 		}
 	}
-	for (uint32_t it = it_lo + cstart; it < n_iter; it += gstride) {
+	uint32_t cgm = cstart; /* the group number mod the look-back ring (groups cstart, cstart + waves, ...) */
+	for (uint32_t it = it_lo + cstart; it < n_iter; it += gstride, cgm = cgm + wpv >= lk_ring ? cgm + wpv - lk_ring : cgm + wpv) {
 		const uint32_t cg = REPAIR ? uni(rep[2 + 2 * it]) : it;
 		const uint32_t repair_rows = REPAIR ? uni(rep[3 + 2 * it]) : 0u;
 		const int t0 = (int)(cg * T * C) - (int)H + l - (REPAIR ? (int)FAST_REPAIR_SHIFT : 0); /* this lane's frame in row 0 */
@@ -288,8 +290,8 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 #pragma unroll
 									for (int k = 0; k < T; ++k)
 										tot += (uint32_t)__builtin_amdgcn_readlane((int)S[k], 63) - (uint32_t)__builtin_amdgcn_readlane((int)S[k], (int)H - 1);
-									acc = f.phase0 + (look_lds ? lookback32<true>(lk_base + (size_t)fa.pad[0] * 2 * 64, cg, tot, 0, lk_ring, l)
-									                           : lookback32<false>(lookv + (size_t)fa.pad[0] * 2 * P.scan_groups, cg, tot, P.look_epoch, 0, l));
+									acc = f.phase0 + (look_lds ? lookback32<true>(lk_base + (size_t)fa.pad[0] * 2 * 64, cg, tot, 0, lk_ring, cgm, l)
+									                           : lookback32<false>(lookv + (size_t)fa.pad[0] * 2 * P.scan_groups, cg, tot, P.look_epoch, 0, 0, l));
 								} else {
 									acc = two ? (sum_me ? 0u : f.phase0 + (uint32_t)sums[cg])
 									          : (first_group ? f.phase0 : (uint32_t)carry[si]);
@@ -528,10 +530,10 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 								for (int k = 0; k < T; ++k) tot += readlane64(S[k], 63) - readlane64(S[k], (int)H - 1);
 								if (look_lds) {
 									unsigned long long *e_lo = lk_base + (size_t)fa.pad[0] * 2 * 64;
-									acc = cp0 + lookback64<true>(e_lo, e_lo + 64, cg, tot, 0, lk_ring, l);
+									acc = cp0 + lookback64<true>(e_lo, e_lo + 64, cg, tot, 0, lk_ring, cgm, l);
 								} else {
 									unsigned long long *e_lo = lookv + (size_t)fa.pad[0] * 2 * P.scan_groups;
-									acc = cp0 + lookback64<false>(e_lo, e_lo + P.scan_groups, cg, tot, P.look_epoch, 0, l);
+									acc = cp0 + lookback64<false>(e_lo, e_lo + P.scan_groups, cg, tot, P.look_epoch, 0, 0, l);
 								}
 							} else {
 								acc = two ? (sum_me ? 0ull : cp0 + sums[cg])
@@ -754,7 +756,8 @@ __global__ void __launch_bounds__(1024, FK_MINB) fast_kernel(FastParams P) {
 	const uint32_t g = blockIdx.x * W + (uint32_t)w;
 	const uint32_t total_waves = gridDim.x * W;
 	const uint32_t NV = P.n_voices;
-	const uint32_t wpv = total_waves >= NV ? total_waves / NV : 1; /* waves per voice */
+	uint32_t wpv = total_waves >= NV ? total_waves / NV : 1; /* waves per voice */
+	if (SCAN == 2 && total_waves >= NV) wpv = P.look_wpv; /* (voices x waves <= the launch's waves: the host's choice) */
 	uint32_t v = total_waves >= NV ? g / wpv : g;
 	const uint32_t vstride = total_waves >= NV ? NV : total_waves;
 	const uint32_t cstart = total_waves >= NV ? g % wpv : 0;

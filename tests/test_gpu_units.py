@@ -619,12 +619,14 @@ def test_ratio_chains_below_modulated_frequencies(sa, oracle):
 
 @pytest.mark.parametrize("env", [{"SAU_AMD_FAST_ROWS": "2"}, {"SAU_AMD_NO_TWO_PASS": "1"}, {"SAU_AMD_NO_SEQ": "1"},
                                  {"SAU_AMD_LDS_LIMIT": "65536"}, {"SAU_AMD_MULTI_MIN": "1"},
-                                 {"SAU_AMD_NO_LOOKBACK": "1"}, {"SAU_AMD_NO_LOOKBACK": "1", "SAU_AMD_NO_INC_ROWS": "1"}])
+                                 {"SAU_AMD_NO_LOOKBACK": "1"}, {"SAU_AMD_NO_LOOKBACK": "1", "SAU_AMD_NO_INC_ROWS": "1"},
+                                 {"SAU_AMD_LOOK_MIN_VOICES": "1"}, {"SAU_AMD_LOOK_MIN_VOICES": "1", "SAU_AMD_LOOK_ROWS": "4"}])
 def test_random_graphs_in_other_kernel_configurations(sa, oracle, env):
     """The random programs with events through the other builds and modes of the kernels: two rows per
     pass, running sums by one wave in order, no running sums in the time-parallel path at all, a
     tight LDS budget, single-wave teams in the block loop, running sums in several passes instead of
-    one pass with look-back (with and without the saved increments)."""
+    one pass with look-back (with and without the saved increments), and -- few voices as these programs
+    have -- one pass with look-back where the default keeps several passes (8 and 4 rows per pass)."""
     oracle.oracle().ora_set_fastmath_forms(1)
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
@@ -709,6 +711,8 @@ def test_running_sums_by_look_back(sa, oracle, lookback, monkeypatch):
     from saugns_amd.api import POPT_RASEG
     if lookback == "off":
         monkeypatch.setenv("SAU_AMD_NO_LOOKBACK", "1")
+    else:
+        monkeypatch.setenv("SAU_AMD_LOOK_MIN_VOICES", "1")  # (by default segments with few voices keep the several-pass form)
     def nest(depth, f0=3.0):
         m = vb.Op("sin", freq=f0, amp=9.0)
         for d in range(depth - 1):
@@ -732,7 +736,42 @@ def test_running_sums_by_look_back(sa, oracle, lookback, monkeypatch):
     many = [vb.Op("sin", freq=vb.Line(100.0 + 3 * k, goal=200.0 + k, shape="lin"), time_ms=40 + k % 17,
                   mods={POP_FMOD: [vb.Op("sin", freq=5.0 + k % 5, amp=10.0)]}) for k in range(300)]
     check(sa, oracle, many, chunk=1000000)
+    # 300 voices long enough for 13 waves each: most of them sit across two workgroups (words in HBM, not rings in LDS)
+    across = [vb.Op(("sin", "tri")[k & 1], freq=vb.Line(90.0 + 2 * k, goal=400.0 - k, shape=("exp", "lin")[k % 2]), time_ms=190 + k % 23,
+                    mods={POP_FMOD: [vb.Op("sin", freq=4.0 + k % 7, amp=12.0)]} if k % 3 else {}) for k in range(300)]
+    check(sa, oracle, across, chunk=1000000)
     b = sa.Batch([vb.build_program([vb.Op("sin", freq=330.0, time_ms=700, mods={POP_FMOD: [nest(5)]}), long_one])], RATE)
     b.set_timing(2)
     b.render(stereo=False, chunk=4000000)
     assert b.timing_ex()["block_ms"] < 1.0  # the time-parallel kernel took them, not the block loop
+
+
+@pytest.mark.timeout(180)
+def test_two_generators_at_once_with_running_sums(sa, oracle):
+    """Two host threads, a generator each, rendering banks of FM voices at the same time: their single-pass
+    launches have voices spread over several workgroups (up to 64 waves per voice), which wait for each other
+    across workgroups -- the process lets such launches take turns on a device (SpreadLaunchOrder), everything
+    else of the two generators overlaps. Both renders equal the oracle's."""
+    import threading
+    oracle.oracle().ora_set_fastmath_forms(1)
+    def bank(seed):
+        return [vb.Op("sin", freq=vb.Line(100.0 + 7 * k + seed, goal=300.0 + 3 * k, shape="exp"), time_ms=1500 + 10 * k,
+                      mods={POP_FMOD: [vb.Op("sin", freq=3.0 + k % 5, amp=15.0 + seed,
+                                             mods={POP_FMOD: [vb.Op("tri", freq=0.5 + 0.1 * k, amp=1.5)]})]})
+                for k in range(40)]
+    prgs = [vb.build_program(bank(s)) for s in (0, 11)]
+    want = [oracle.oracle_render(p.ptr, RATE, False) for p in prgs]
+    got = [None, None]
+    def work(i):
+        out = []
+        for rep in range(3):
+            out.append(sa.Batch([prgs[i]], RATE).render(stereo=False, chunk=20000 + 7000 * i)[0])
+        got[i] = out
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for i in range(2):
+        for pcm in got[i]:
+            assert len(pcm) == len(want[i]) and (pcm == want[i]).all()
