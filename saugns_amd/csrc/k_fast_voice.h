@@ -320,7 +320,13 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 #pragma unroll
 							for (int k = 0; k < T; ++k) { ph[k] = acc; acc += row_inc; fv[k] = f.fc; }
 						}
-						if (SCAN && is_last_group) { /* the accumulator after the segment's last frame, before modulation */
+						/* the accumulator after the segment's last frame, before modulation: the single-pass build stages it here;
+						 * the full build keeps the values and stages them with the rest (its register allocation fares better) */
+						uint32_t phu[FULL ? T : 1];
+						if (FULL) {
+#pragma unroll
+							for (int k = 0; k < T; ++k) phu[FULL ? k : 0] = ph[k];
+						} else if (SCAN && is_last_group) {
 #pragma unroll
 							for (int k = 0; k < T; ++k) {
 								const int t = t0 + k * (int)C;
@@ -377,6 +383,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 								if (l >= (int)H && t >= 0 && t < (int)fast_total) {
 									((u32_alias *)brow)[t] = ph[k];
 									arow[t] = a;
+									if (FULL && t == (int)fast_total - 1) P.ops[f.gop].st_phase = phu[FULL ? k : 0];
 								}
 							}
 							continue;
@@ -467,6 +474,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 								const int t = t0 + k * (int)C;
 								if (t == (int)fast_total - 1 && l >= (int)H) {
 									DevOp &o = P.ops[f.gop];
+									if (FULL) o.st_phase = phu[FULL ? k : 0];
 									o.st_prev_phase = ph[k];
 									o.st_prev_Is = Is[k];
 									o.st_prev_s = s[k];
