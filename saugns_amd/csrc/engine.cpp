@@ -469,11 +469,9 @@ bool Engine::run(int16_t *const *host_bufs, size_t buf_len, bool stereo,
 					const VoiceHost &vn = st.voices[v];
 					if (vn.duration == 0 || vn.carr_op >= st.ops.size()) continue;
 					if (vn.plan.n_chain) chains = true;
-					if (vn.plan.n_osc && !vn.plan.no_fast) { /* may it have running-sum phases? (as render_segment decides) */
-						bool vb = vn.plan.static_block;
-						for (uint32_t id : vn.plan.op_ids) if (st.ops[id].goal_seen || (st.ops[id].line_set & (1u << L_PMA))) vb = true;
-						if (vb) chains = true; /* saved increments live in rows of one segment too */
-					}
+					/* (voices that merely have running-sum phases need no cap: they take one pass with look-back, whose
+					 * state is per row group; where they take several passes instead, the backend saves increments only
+					 * for segments within CHAIN_SEG and recomputes them beyond) */
 					for (uint32_t id : vn.plan.op_ids) {
 						const OpMirror &m = st.ops[id];
 						if (id != vn.carr_op && !m.time_inf && m.time > 0 && m.time < first) first = m.time;

@@ -570,8 +570,11 @@ public:
 			if (seq_ok && two_pass_enabled_) {
 				/* row groups per voice at most: rows hold at least 32 new frames (H <= 32) */
 				fp.scan_groups = seg.len / (32 * FTM) + 2;
-				if (!scan_.ensure((size_t)seg.n_voices * FAST_MAX_SCAN * fp.scan_groups, err)) return false;
-				fp.scan = scan_.p;
+				/* (the several-pass form's sums: with look-back only voices that have, or may get, feedback chains take it) */
+				if (!look_split || seg.n_chain_rows) {
+					if (!scan_.ensure((size_t)seg.n_voices * FAST_MAX_SCAN * fp.scan_groups, err)) return false;
+					fp.scan = scan_.p;
+				}
 				if (look_split && seg.n_look_rows) {
 					/* look-back words: valid for this segment's epoch only, so a fresh block starts out zeroed */
 					const unsigned long long *before = look_.p;
