@@ -795,7 +795,7 @@ public:
 			}
 			TimedPair *tz = timing_on_ ? new_pair(3) : nullptr;
 			if (tz) (void)hipEventRecord(tz->a, stream_);
-			hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)(((size_t)seg.n_voices * fp.max_ops + 63) / 64)), dim3(64), 0,
+			hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)(((size_t)seg.n_voices * fp.max_ops * 8 + 63) / 64)), dim3(64), 0,
 					stream_, fp);
 			if (tz) (void)hipEventRecord(tz->b, stream_);
 			HIP_OK(hipGetLastError());

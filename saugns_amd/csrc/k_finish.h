@@ -3,15 +3,19 @@
 /* Apply the closed forms to the operator state, or hand the whole segment
  * to the block loop when a chunk had to bail out. */
 __global__ void __launch_bounds__(64) finalize_kernel(FastParams P) {
-	/* one thread per (voice, operator); the voice's own bookkeeping goes to its operator 0 */
+	/* eight threads per (voice, operator): one per line (a held line's walk over the reference's block lattice
+	 * is a loop over the host's calls inside the segment -- the long pole of this kernel), one for the rest of the
+	 * operator's state; the voice's own bookkeeping goes to that thread of its operator 0 */
 	const uint32_t gid = blockIdx.x * 64 + threadIdx.x;
-	const uint32_t v = gid / P.max_ops, i = gid % P.max_ops;
+	const uint32_t sub = gid & 7u, vo_ = gid >> 3;
+	static_assert(L_COUNT <= 6, "threads 0..5 of an operator's eight take its lines, thread 6 the rest");
+	const uint32_t v = vo_ / P.max_ops, i = vo_ % P.max_ops;
 	if (gid < FAST_FLAGS && P.pass_flags) P.pass_flags[gid] = 0; /* for the next segment's kernels */
 	if (v >= P.n_voices) return;
 	const FastInfo fi = P.info[v];
 	const VoiceDesc vd = P.voices[v];
 	if (fi.total == 0 || fi.bail) {
-		if (i == 0) {
+		if (i == 0 && sub == 6) {
 			P.fast_done[v] = 0;
 			P.worklist[atomicAdd(P.work_count, 1u)] = v;
 		}
@@ -22,10 +26,9 @@ __global__ void __launch_bounds__(64) finalize_kernel(FastParams P) {
 	if (i < vd.nops) {
 		DevOp &o = P.ops[ids[i]];
 		if (!o.rt_frozen) { /* (out of time: state stands still) */
-		if (!(o.flags & OPF_TIME_INF)) o.time -= total;
 		const bool o_osc = o.type == OT_WAVE || o.type == OT_RASEG;
 		const Step *plan = P.steps + vd.plan_ofs;
-		for (uint32_t ln = 0; ln < L_COUNT; ++ln) {
+		for (uint32_t ln = sub; ln < L_COUNT; ln += 8) { /* (this thread's line, if it has one) */
 			/* the lines the reference runs or skips for this operator (generator.c:505-664, 756-762) */
 			if (ln == L_PAN && i != vd.carr_local) continue;
 			if (!o_osc && (ln == L_FREQ || ln == L_FREQ2 || ln == L_PMA)) continue;
@@ -60,6 +63,8 @@ __global__ void __launch_bounds__(64) finalize_kernel(FastParams P) {
 			}
 			o.line[ln] = ls;
 		}
+		if (sub == 6) {
+		if (!(o.flags & OPF_TIME_INF)) o.time -= total;
 		if (o.type == OT_WAVE) {
 			if (o.rt_fconst_valid) o.phase += rint32w(o.coeff * o.rt_fconst) * total;
 			else o.phase = o.st_phase; /* running sum, staged by the sequential scan */
@@ -83,8 +88,9 @@ __global__ void __launch_bounds__(64) finalize_kernel(FastParams P) {
 			o.noise_n = n0 + total;
 		}
 		}
+		}
 	}
-	if (i != 0) return;
+	if (i != 0 || sub != 6) return;
 	P.fast_done[v] = total;
 	if (total < vd.run_len) {
 		P.worklist[atomicAdd(P.work_count, 1u)] = v;
