@@ -1,5 +1,15 @@
 /* k_fast_voice.h -- part of hip_backend.hip (included there, inside namespace sauhip; not a header of its own).
  * fast_voice / fast_kernel / repair_kernel: rows of 64 frames per wave, closed-form and running-sum phases. */
+/* Where entry i of a wave table sits in LDS. Identity: XOR swizzles of the low index bits with the next ones
+ * (-DFK_SWZ_BITS=2, 4, 5, tried in r02 against the 58 % bank-conflict cycles of the table gather) left
+ * SQ_LDS_BANK_CONFLICT where it was or raised it by 3-5 % and cost 1-5 % in time for the two extra VALU
+ * instructions per lookup (profiles/r02_b_lds_swizzle.json): the conflicts are the gather's own. */
+#ifndef FK_SWZ_BITS
+#define FK_SWZ(i) (i)
+#else
+#define FK_SWZ(i) ((i) ^ (((i) >> FK_SWZ_BITS) & ((1u << FK_SWZ_BITS) - 1u)))
+#endif
+
 /* lane l receives lane l-1's value (lane 0: zero; it is lead-in) */
 __device__ __forceinline__ uint32_t lane_prev(uint32_t x) {
 	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
@@ -169,7 +179,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 #pragma unroll
 							for (int k = 0; k < T; ++k) {
 								const uint32_t ind = ph[k] >> SLEN_BITS;
-								Is[k] = herp_poly(l23[ind], l01[ind], ph[k]);
+								Is[k] = herp_poly(l23[FK_SWZ(ind)], l01[FK_SWZ(ind)], ph[k]);
 							}
 							if (FK_CONSTD && !has_pm && f.inc != 0) {
 								/* unmodulated: every phase step is inc, one division serves all */
@@ -400,7 +410,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 #pragma unroll
 							for (int k = 0; k < T; ++k) {
 								const uint32_t ind = ph[k] >> SLEN_BITS;
-								Is[k] = herp_poly(l23[ind], l01[ind], ph[k]);
+								Is[k] = herp_poly(l23[FK_SWZ(ind)], l01[FK_SWZ(ind)], ph[k]);
 							}
 						} else {
 							const uint32_t wave = (f.type >> 8) & 0xff;
@@ -754,10 +764,10 @@ __global__ void __launch_bounds__(1024, FK_MINB) fast_kernel(FastParams P) {
 		const uint32_t wave = P.wave_of_tab[t];
 		const uint4 *s23 = (const uint4 *)(P.g_c23 + (size_t)wave * WAVE_LEN);
 		uint4 *d23 = (uint4 *)(t23 + (size_t)t * WAVE_LEN);
-		for (uint32_t i = tid; i < WAVE_LEN; i += 64 * W) d23[i] = s23[i];
+		for (uint32_t i = tid; i < WAVE_LEN; i += 64 * W) d23[FK_SWZ(i)] = s23[i];
 		const uint2 *s01 = (const uint2 *)(P.g_c01 + (size_t)wave * WAVE_LEN);
 		uint2 *d01 = (uint2 *)(t01 + (size_t)t * WAVE_LEN);
-		for (uint32_t i = tid; i < WAVE_LEN; i += 64 * W) d01[i] = s01[i];
+		for (uint32_t i = tid; i < WAVE_LEN; i += 64 * W) d01[FK_SWZ(i)] = s01[i];
 	}
 	__syncthreads(); /* the only barrier: tables are shared, all else is per wave */
 
@@ -809,10 +819,10 @@ __global__ void __launch_bounds__(1024) repair_kernel(FastParams P) {
 		const uint32_t wave = P.wave_of_tab[t];
 		const uint4 *s23 = (const uint4 *)(P.g_c23 + (size_t)wave * WAVE_LEN);
 		uint4 *d23 = (uint4 *)(t23 + (size_t)t * WAVE_LEN);
-		for (uint32_t i = tid; i < WAVE_LEN; i += 64 * W) d23[i] = s23[i];
+		for (uint32_t i = tid; i < WAVE_LEN; i += 64 * W) d23[FK_SWZ(i)] = s23[i];
 		const uint2 *s01 = (const uint2 *)(P.g_c01 + (size_t)wave * WAVE_LEN);
 		uint2 *d01 = (uint2 *)(t01 + (size_t)t * WAVE_LEN);
-		for (uint32_t i = tid; i < WAVE_LEN; i += 64 * W) d01[i] = s01[i];
+		for (uint32_t i = tid; i < WAVE_LEN; i += 64 * W) d01[FK_SWZ(i)] = s01[i];
 	}
 	__syncthreads();
 	/* one wave per voice with noted groups */
