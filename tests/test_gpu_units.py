@@ -620,7 +620,8 @@ def test_ratio_chains_below_modulated_frequencies(sa, oracle):
 @pytest.mark.parametrize("env", [{"SAU_AMD_FAST_ROWS": "2"}, {"SAU_AMD_NO_TWO_PASS": "1"}, {"SAU_AMD_NO_SEQ": "1"},
                                  {"SAU_AMD_LDS_LIMIT": "65536"}, {"SAU_AMD_MULTI_MIN": "1"},
                                  {"SAU_AMD_NO_LOOKBACK": "1"}, {"SAU_AMD_NO_LOOKBACK": "1", "SAU_AMD_NO_INC_ROWS": "1"},
-                                 {"SAU_AMD_LOOK_MIN_VOICES": "1"}, {"SAU_AMD_LOOK_MIN_VOICES": "1", "SAU_AMD_LOOK_ROWS": "4"}])
+                                 {"SAU_AMD_LOOK_MIN_VOICES": "1"}, {"SAU_AMD_LOOK_MIN_VOICES": "1", "SAU_AMD_LOOK_ROWS": "4"},
+                                 {"SAU_AMD_LOOK_NO_LDS": "1"}])
 def test_random_graphs_in_other_kernel_configurations(sa, oracle, env):
     """The random programs with events through the other builds and modes of the kernels: two rows per
     pass, running sums by one wave in order, no running sums in the time-parallel path at all, a
@@ -740,6 +741,12 @@ def test_running_sums_by_look_back(sa, oracle, lookback, monkeypatch):
     across = [vb.Op(("sin", "tri")[k & 1], freq=vb.Line(90.0 + 2 * k, goal=400.0 - k, shape=("exp", "lin")[k % 2]), time_ms=190 + k % 23,
                     mods={POP_FMOD: [vb.Op("sin", freq=4.0 + k % 7, amp=12.0)]} if k % 3 else {}) for k in range(300)]
     check(sa, oracle, across, chunk=1000000)
+    # banks too big for more than one wave per voice (2500 voices: a wave each, sums carried in LDS; 4200: waves
+    # take several voices in turn)
+    for n in (2500, 4200):
+        bank = [vb.Op("sin", freq=vb.Line(80.0 + 0.1 * k, goal=160.0 + 0.05 * k, shape="lin"), time_ms=30 + k % 11,
+                      mods={POP_FMOD: [vb.Op("sin", freq=6.0 + k % 3, amp=9.0)]} if k % 2 else {}) for k in range(n)]
+        check(sa, oracle, bank, chunk=1000000)
     b = sa.Batch([vb.build_program([vb.Op("sin", freq=330.0, time_ms=700, mods={POP_FMOD: [nest(5)]}), long_one])], RATE)
     b.set_timing(2)
     b.render(stereo=False, chunk=4000000)
