@@ -293,18 +293,15 @@ public:
 		if (!stream_) HIP_OK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
 		static std::mutex prop_mu;
 		static size_t dev_lds[16]; /* per device: hipGetDeviceProperties costs a millisecond */
-		static int dev_cus[16];
 		{
 			std::lock_guard<std::mutex> lk(prop_mu);
 			if (!dev_lds[dev & 15]) {
 				hipDeviceProp_t prop;
 				HIP_OK(hipGetDeviceProperties(&prop, dev));
-				dev_cus[dev & 15] = prop.multiProcessorCount;
 				dev_lds[dev & 15] = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor
 				                                                          : prop.sharedMemPerBlock;
 			}
 			lds_limit_ = dev_lds[dev & 15];
-			n_cus_ = dev_cus[dev & 15];
 		}
 		if (lds_limit_ > 160 * 1024) lds_limit_ = 160 * 1024;
 		if (const char *ll = getenv("SAU_AMD_LDS_LIMIT")) lds_limit_ = (size_t)atol(ll);
@@ -1063,7 +1060,6 @@ private:
 	uint32_t look_rows_ = 8; /* rows per pass of the single-pass build (SAU_AMD_LOOK_ROWS; 0: no such build, the full one takes every voice) */
 	DevBuf<unsigned long long> look_;
 	uint32_t look_epoch_ = 0;
-	int n_cus_ = 0;
 	DevBuf<uint32_t> inc_rows_;
 	hipStream_t chain_stream_ = nullptr;
 	std::vector<hipEvent_t> chain_ev_;
