@@ -82,11 +82,13 @@ def cpu_reference(make_prg, what, voices, ops_per_voice, tabs, all_cores=False):
 
         def render(frames):
             return po.oracle_render(prg.ptr, 44100, False, max_frames=frames, chunk=11289)
-    frames = 2205  # calibrate, then run ~15 s of CPU work
+    frames = 2205  # calibrate (the first call also pays for one-time set-up), then run ~12 s of CPU work
+    render(frames)
+    frames = 8820
     t0 = time.perf_counter()
     render(frames)
     dt = time.perf_counter() - t0
-    frames = int(min(44100 * 20, max(frames, frames * 15.0 / max(dt, 1e-3))))
+    frames = int(min(44100 * 30, max(frames, frames * 12.0 / max(dt, 1e-3))))
     t0 = time.perf_counter()
     render(frames)
     dt = time.perf_counter() - t0
