@@ -640,7 +640,13 @@ public:
 			fp.n_tabs = ft;
 			TimedPair *ta = timing_on_ ? new_pair(3) : nullptr;
 			if (ta) (void)hipEventRecord(ta->a, stream_);
-			hipLaunchKernelGGL(analyze_kernel, dim3((seg.n_voices + 63) / 64), dim3(64), 0, stream_, fp);
+			{
+				/* a thread per voice, a chain of dependent loads each: few voices per wave shorten it a little (their
+				 * loads diverge; measured per launch, 1024 FM voices / config 4 / config 3: 64 per wave 34 us, 16: 30, 4: 28.5) */
+				static const uint32_t lanes = getenv("SAU_AMD_ANALYZE_LANES") ? (uint32_t)atoi(getenv("SAU_AMD_ANALYZE_LANES")) : 4u;
+				const uint32_t al = lanes >= 1 && lanes <= 64 ? lanes : 4u;
+				hipLaunchKernelGGL(analyze_kernel, dim3((seg.n_voices + al - 1) / al), dim3(al), 0, stream_, fp);
+			}
 			if (ta) (void)hipEventRecord(ta->b, stream_);
 			if (use_fast) {
 				hipLaunchKernelGGL(decode_kernel, dim3(seg.n_voices), dim3(64), 0, stream_, fp);

@@ -64,7 +64,7 @@ __device__ __forceinline__ bool op_has_fpm(const Step *plan, uint32_t n, uint32_
 }
 
 __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
-	const uint32_t v = blockIdx.x * 64 + threadIdx.x;
+	const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; /* (the host picks the voices per wave) */
 	if (v == 0) *P.work_count = 0; /* finalize_kernel (a later launch) builds the block loop's work list */
 	if (v >= P.n_voices) return;
 	const VoiceDesc vd = P.voices[v];
