@@ -128,7 +128,7 @@ struct MixParams {
  * the CPU's and independent of scheduling.  Loads are issued eight voices
  * ahead of the (serially dependent) adds. */
 constexpr int MIX_TILE = 256; /* voices whose constants are staged at a time */
-constexpr int MIX_AHEAD = 16; /* loads in flight per thread */
+constexpr int MIX_AHEAD = 32; /* loads per batch and thread */
 __global__ void __launch_bounds__(256) mix_kernel(MixParams P) {
 	__shared__ float s_pan[MIX_TILE];
 	__shared__ uint32_t s_valid[MIX_TILE];
@@ -156,18 +156,34 @@ __global__ void __launch_bounds__(256) mix_kernel(MixParams P) {
 		const float *base = P.vout + (size_t)(ms.first_row + r0) * P.row_stride + i;
 		if (s_special == 0) {
 			/* every row of the tile covers the whole segment with a constant pan */
+			/* two batches of row loads in flight: the next batch is issued before the adds of this one (which are one
+			 * dependent chain per channel, the reference's voice order) -- a segment of 44100 frames is only 689 waves,
+			 * and what they keep in flight is what the HBM pipe sees */
 			uint32_t r = 0;
-			for (; r + MIX_AHEAD <= nt; r += MIX_AHEAD) {
-				float sv[MIX_AHEAD];
+			auto load = [&](float *sv, uint32_t at) {
 #pragma unroll
-				for (int u = 0; u < MIX_AHEAD; ++u) sv[u] = base[(size_t)(r + u) * P.row_stride];
+				for (int u = 0; u < MIX_AHEAD; ++u) sv[u] = base[(size_t)(at + u) * P.row_stride];
+			};
+			auto add = [&](const float *sv, uint32_t at) {
 #pragma unroll
 				for (int u = 0; u < MIX_AHEAD; ++u) {
 					const float v = sv[u] * ms.amp_scale;
-					const float s_r = v * s_pan[r + u];
+					const float s_r = v * s_pan[at + u];
 					L = (L + v) - s_r;
 					R = (R + v) + s_r;
 				}
+			};
+			float sa[MIX_AHEAD], sb[MIX_AHEAD];
+			if (r + MIX_AHEAD <= nt) load(sa, r);
+			while (r + MIX_AHEAD <= nt) {
+				const bool more_b = r + 2 * MIX_AHEAD <= nt;
+				if (more_b) load(sb, r + MIX_AHEAD);
+				add(sa, r);
+				r += MIX_AHEAD;
+				if (!more_b) break;
+				if (r + 2 * MIX_AHEAD <= nt) load(sa, r + MIX_AHEAD);
+				add(sb, r);
+				r += MIX_AHEAD;
 			}
 			for (; r < nt; ++r) {
 				const float v = base[(size_t)r * P.row_stride] * ms.amp_scale;
