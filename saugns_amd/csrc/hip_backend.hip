@@ -326,7 +326,7 @@ public:
 		multi_min_ = 256;
 		if (const char *fr = getenv("SAU_AMD_FAST_ROWS")) { /* 8 (default), 4 or 2 */
 			const int r = atoi(fr);
-			fast_rows_ = r >= 8 ? 8 : r >= 4 ? 4 : 2;
+			fast_rows_ = r >= 8 ? 8 : r >= 6 ? 6 : r >= 4 ? 4 : 2;
 		}
 		if (const char *mm = getenv("SAU_AMD_MULTI_MIN")) multi_min_ = (uint32_t)atol(mm);
 		if (!ops_.ensure(cfg.op_count ? cfg.op_count : 1, err)) return false;
@@ -522,6 +522,7 @@ public:
 			 * (more rows amortise the per-step work: 8 rows measured 8 % faster
 			 * than 4, 4 rows 28 % faster than 2) */
 			uint32_t FT = fast_rows_;
+			auto fewer = [](uint32_t t) { return t > 6 ? 6u : t > 4 ? 4u : 2u; }; /* 8, 6, 4 or 2 rows per pass */
 			/* The build with all the running-sum code needs more registers: 8 rows per pass would spill. Where the
 			 * single-pass (look-back) build serves, it takes those voices and the closed-form ones at the full rows
 			 * per pass, and the full build's launches only see what is left (voices with feedback chains, voices
@@ -529,7 +530,7 @@ public:
 			const bool look_split = seq_enabled_ && seg.may_scan && two_pass_enabled_ && lookback_enabled_ && look_rows_ != 0 &&
 				seg.n_voices >= look_min_voices_;
 			if (seq_enabled_ && seg.may_scan && FT > 4 && !look_split) FT = 4;
-			if (look_split && FT > look_rows_) FT = look_rows_ >= 8 ? 8 : look_rows_ >= 4 ? 4 : 2;
+			if (look_split && FT > look_rows_) FT = look_rows_ >= 8 ? 8 : look_rows_ >= 6 ? 6 : look_rows_ >= 4 ? 4 : 2;
 			/* block buffers: without frequency blocks, or with them when some voice may need
 			 * the sequential scan (ramped or modulated frequencies) */
 			const bool seq_ok = seq_enabled_ && seg.may_scan;
@@ -539,12 +540,12 @@ public:
 			};
 			const size_t one_tab = seg.wave_mask ? tab_bytes : 0;
 			const size_t look_lds = look_split ? LOOK_LDS_BYTES : 0;
-			while (FT > 2 && 16 * area_of(FT) + one_tab + look_lds + 1024 > lds_limit_) FT /= 2;
+			while (FT > 2 && 16 * area_of(FT) + one_tab + look_lds + 1024 > lds_limit_) FT = fewer(FT);
 			{ /* every wave table the segment uses in LDS is worth more than rows per pass (an oscillator whose table
 			   * is left out reads it from L2 per sample): fewer rows where that makes them all fit */
 				const size_t need = (size_t)__builtin_popcount(seg.wave_mask) * tab_bytes + look_lds + 1024;
 				uint32_t t = FT;
-				while (t > 4 && 16 * area_of(t) + need > lds_limit_) t /= 2; /* (but not below 4 rows: that costs more) */
+				while (t > 4 && 16 * area_of(t) + need > lds_limit_) t = fewer(t); /* (but not below 4 rows: that costs more) */
 				if (16 * area_of(t) + need <= lds_limit_) FT = t;
 			}
 			const size_t area = area_of(FT);
@@ -653,13 +654,15 @@ public:
 				const size_t flds = ft * tab_bytes + 16 * area;
 				/* build 0: closed-form phases only; 1: every kind of running-sum voice; 2: single-pass voices and closed-form ones */
 				const int main_build = !seq_ok ? 0 : look_split ? 2 : 1;
-				static const void *const fkernels[3][3] = {
-					{(const void *)fast_kernel<2, 0>, (const void *)fast_kernel<4, 0>, (const void *)fast_kernel<8, 0>},
-					{(const void *)fast_kernel<2, 1>, (const void *)fast_kernel<4, 1>, (const void *)fast_kernel<8, 1>},
-					{(const void *)fast_kernel<2, 2>, (const void *)fast_kernel<4, 2>, (const void *)fast_kernel<8, 2>}};
-				static size_t fconfigured[16][3][3];
+				/* (rows per pass 2, 4, 6, 8; the full build never runs at more than 4: its 6-row slot stands in with 4's) */
+				static const void *const fkernels[3][4] = {
+					{(const void *)fast_kernel<2, 0>, (const void *)fast_kernel<4, 0>, (const void *)fast_kernel<6, 0>, (const void *)fast_kernel<8, 0>},
+					{(const void *)fast_kernel<2, 1>, (const void *)fast_kernel<4, 1>, (const void *)fast_kernel<4, 1>, (const void *)fast_kernel<8, 1>},
+					{(const void *)fast_kernel<2, 2>, (const void *)fast_kernel<4, 2>, (const void *)fast_kernel<6, 2>, (const void *)fast_kernel<8, 2>}};
+				static size_t fconfigured[16][3][4];
 				auto launch_build = [&](int build, uint32_t rows, uint32_t grid) -> bool {
-					const int ri = rows == 8 ? 2 : rows == 4 ? 1 : 0;
+					if (build == 1 && rows == 6) rows = 4;
+					const int ri = rows == 8 ? 3 : rows == 6 ? 2 : rows == 4 ? 1 : 0;
 					const size_t lds = ft * tab_bytes + 16 * area_of(rows) + (build == 2 ? LOOK_LDS_BYTES : 0);
 					size_t &conf = fconfigured[dev_ & 15][build][ri];
 					if (lds > conf) {
@@ -780,10 +783,10 @@ public:
 				}
 				if (!launched) return false;
 				{ /* row groups noted for a second evaluation: returns at once when there are none */
-					const void *rk = FT == 8 ? (const void *)repair_kernel<8> : FT == 4 ? (const void *)repair_kernel<4>
-					                                                                    : (const void *)repair_kernel<2>;
-					static size_t rconfigured[16][3];
-					size_t &rconf = rconfigured[dev_ & 15][FT == 8 ? 2 : FT == 4 ? 1 : 0];
+					const void *rk = FT == 8 ? (const void *)repair_kernel<8> : FT == 6 ? (const void *)repair_kernel<6>
+					               : FT == 4 ? (const void *)repair_kernel<4> : (const void *)repair_kernel<2>;
+					static size_t rconfigured[16][4];
+					size_t &rconf = rconfigured[dev_ & 15][FT == 8 ? 3 : FT == 6 ? 2 : FT == 4 ? 1 : 0];
 					if (flds > rconf) {
 						HIP_OK(hipFuncSetAttribute(rk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
 						rconf = flds;
@@ -791,6 +794,7 @@ public:
 					const uint32_t rgrid = (seg.n_voices + 15) / 16 < 64 ? (seg.n_voices + 15) / 16 : 64;
 					fp.mode = 0;
 					if (FT == 8) hipLaunchKernelGGL((repair_kernel<8>), dim3(rgrid), dim3(1024), flds, stream_, fp);
+					else if (FT == 6) hipLaunchKernelGGL((repair_kernel<6>), dim3(rgrid), dim3(1024), flds, stream_, fp);
 					else if (FT == 4) hipLaunchKernelGGL((repair_kernel<4>), dim3(rgrid), dim3(1024), flds, stream_, fp);
 					else hipLaunchKernelGGL((repair_kernel<2>), dim3(rgrid), dim3(1024), flds, stream_, fp);
 				}
