@@ -326,7 +326,7 @@ public:
 		multi_min_ = 256;
 		if (const char *fr = getenv("SAU_AMD_FAST_ROWS")) { /* 8 (default), 4 or 2 */
 			const int r = atoi(fr);
-			fast_rows_ = r >= 8 ? 8 : r >= 6 ? 6 : r >= 4 ? 4 : 2;
+			fast_rows_ = r >= 8 ? 8 : r >= 6 ? 6 : r >= 5 ? 5 : r >= 4 ? 4 : 2;
 		}
 		if (const char *mm = getenv("SAU_AMD_MULTI_MIN")) multi_min_ = (uint32_t)atol(mm);
 		if (!ops_.ensure(cfg.op_count ? cfg.op_count : 1, err)) return false;
@@ -522,7 +522,7 @@ public:
 			 * (more rows amortise the per-step work: 8 rows measured 8 % faster
 			 * than 4, 4 rows 28 % faster than 2) */
 			uint32_t FT = fast_rows_;
-			auto fewer = [](uint32_t t) { return t > 6 ? 6u : t > 4 ? 4u : 2u; }; /* 8, 6, 4 or 2 rows per pass */
+			auto fewer = [](uint32_t t) { return t > 6 ? 6u : t > 5 ? 5u : t > 4 ? 4u : 2u; }; /* 8, 6, 5, 4 or 2 rows per pass */
 			/* The build with all the running-sum code needs more registers: 8 rows per pass would spill. Where the
 			 * single-pass (look-back) build serves, it takes those voices and the closed-form ones at the full rows
 			 * per pass, and the full build's launches only see what is left (voices with feedback chains, voices
@@ -530,7 +530,7 @@ public:
 			const bool look_split = seq_enabled_ && seg.may_scan && two_pass_enabled_ && lookback_enabled_ && look_rows_ != 0 &&
 				seg.n_voices >= look_min_voices_;
 			if (seq_enabled_ && seg.may_scan && FT > 4 && !look_split) FT = 4;
-			if (look_split && FT > look_rows_) FT = look_rows_ >= 8 ? 8 : look_rows_ >= 6 ? 6 : look_rows_ >= 4 ? 4 : 2;
+			if (look_split && FT > look_rows_) FT = look_rows_ >= 8 ? 8 : look_rows_ >= 6 ? 6 : look_rows_ >= 5 ? 5 : look_rows_ >= 4 ? 4 : 2;
 			/* block buffers: without frequency blocks, or with them when some voice may need
 			 * the sequential scan (ramped or modulated frequencies) */
 			const bool seq_ok = seq_enabled_ && seg.may_scan;
@@ -654,15 +654,15 @@ public:
 				const size_t flds = ft * tab_bytes + 16 * area;
 				/* build 0: closed-form phases only; 1: every kind of running-sum voice; 2: single-pass voices and closed-form ones */
 				const int main_build = !seq_ok ? 0 : look_split ? 2 : 1;
-				/* (rows per pass 2, 4, 6, 8; the full build never runs at more than 4: its 6-row slot stands in with 4's) */
-				static const void *const fkernels[3][4] = {
-					{(const void *)fast_kernel<2, 0>, (const void *)fast_kernel<4, 0>, (const void *)fast_kernel<6, 0>, (const void *)fast_kernel<8, 0>},
-					{(const void *)fast_kernel<2, 1>, (const void *)fast_kernel<4, 1>, (const void *)fast_kernel<4, 1>, (const void *)fast_kernel<8, 1>},
-					{(const void *)fast_kernel<2, 2>, (const void *)fast_kernel<4, 2>, (const void *)fast_kernel<6, 2>, (const void *)fast_kernel<8, 2>}};
-				static size_t fconfigured[16][3][4];
+				/* (rows per pass 2, 4, 5, 6, 8; the full build never runs at more than 4: its 5- and 6-row slots stand in with 4's) */
+				static const void *const fkernels[3][5] = {
+					{(const void *)fast_kernel<2, 0>, (const void *)fast_kernel<4, 0>, (const void *)fast_kernel<5, 0>, (const void *)fast_kernel<6, 0>, (const void *)fast_kernel<8, 0>},
+					{(const void *)fast_kernel<2, 1>, (const void *)fast_kernel<4, 1>, (const void *)fast_kernel<4, 1>, (const void *)fast_kernel<4, 1>, (const void *)fast_kernel<8, 1>},
+					{(const void *)fast_kernel<2, 2>, (const void *)fast_kernel<4, 2>, (const void *)fast_kernel<5, 2>, (const void *)fast_kernel<6, 2>, (const void *)fast_kernel<8, 2>}};
+				static size_t fconfigured[16][3][5];
 				auto launch_build = [&](int build, uint32_t rows, uint32_t grid) -> bool {
-					if (build == 1 && rows == 6) rows = 4;
-					const int ri = rows == 8 ? 3 : rows == 6 ? 2 : rows == 4 ? 1 : 0;
+					if (build == 1 && (rows == 6 || rows == 5)) rows = 4;
+					const int ri = rows == 8 ? 4 : rows == 6 ? 3 : rows == 5 ? 2 : rows == 4 ? 1 : 0;
 					const size_t lds = ft * tab_bytes + 16 * area_of(rows) + (build == 2 ? LOOK_LDS_BYTES : 0);
 					size_t &conf = fconfigured[dev_ & 15][build][ri];
 					if (lds > conf) {
@@ -784,9 +784,10 @@ public:
 				if (!launched) return false;
 				{ /* row groups noted for a second evaluation: returns at once when there are none */
 					const void *rk = FT == 8 ? (const void *)repair_kernel<8> : FT == 6 ? (const void *)repair_kernel<6>
-					               : FT == 4 ? (const void *)repair_kernel<4> : (const void *)repair_kernel<2>;
-					static size_t rconfigured[16][4];
-					size_t &rconf = rconfigured[dev_ & 15][FT == 8 ? 3 : FT == 6 ? 2 : FT == 4 ? 1 : 0];
+					               : FT == 5 ? (const void *)repair_kernel<5> : FT == 4 ? (const void *)repair_kernel<4>
+					               : (const void *)repair_kernel<2>;
+					static size_t rconfigured[16][5];
+					size_t &rconf = rconfigured[dev_ & 15][FT == 8 ? 4 : FT == 6 ? 3 : FT == 5 ? 2 : FT == 4 ? 1 : 0];
 					if (flds > rconf) {
 						HIP_OK(hipFuncSetAttribute(rk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
 						rconf = flds;
@@ -795,6 +796,7 @@ public:
 					fp.mode = 0;
 					if (FT == 8) hipLaunchKernelGGL((repair_kernel<8>), dim3(rgrid), dim3(1024), flds, stream_, fp);
 					else if (FT == 6) hipLaunchKernelGGL((repair_kernel<6>), dim3(rgrid), dim3(1024), flds, stream_, fp);
+					else if (FT == 5) hipLaunchKernelGGL((repair_kernel<5>), dim3(rgrid), dim3(1024), flds, stream_, fp);
 					else if (FT == 4) hipLaunchKernelGGL((repair_kernel<4>), dim3(rgrid), dim3(1024), flds, stream_, fp);
 					else hipLaunchKernelGGL((repair_kernel<2>), dim3(rgrid), dim3(1024), flds, stream_, fp);
 				}
