@@ -423,10 +423,13 @@ def _through_zero_bank(n, seconds):
 
 
 @pytest.mark.gpu
-def test_repeated_phases_at_row_starts_stay_on_the_fast_path(sa, oracle):
+@pytest.mark.parametrize("rows", ["8", "6", "5", "4"])
+def test_repeated_phases_at_row_starts_stay_on_the_fast_path(sa, oracle, rows, monkeypatch):
     """Hundreds of exactly repeated phases, some of them on the first lane an operator is defined
     in: bit-exact, and made good by repair_kernel (the row group once more, shifted) -- no voice
-    is handed to the block loop (which would take milliseconds per voice here)."""
+    is handed to the block loop (which would take milliseconds per voice here). At every number of
+    rows per pass that has a build of its own."""
+    monkeypatch.setenv("SAU_AMD_FAST_ROWS", rows)
     oracle.oracle().ora_set_fastmath_forms(1)
     prg = _through_zero_bank(256, 20)
     want = oracle.oracle_render(prg.ptr, RATE, False)
@@ -436,6 +439,8 @@ def test_repeated_phases_at_row_starts_stay_on_the_fast_path(sa, oracle):
     t = b.timing_ex()
     assert len(got) == len(want) and (got == want).all()
     assert t["block_ms"] < 1.0, t
+    if rows != "8":
+        return
     # the case is real: without the repair pass some voices do go to the block loop (still bit-exact)
     os.environ["SAU_AMD_NO_REPAIR"] = "1"
     try:
@@ -617,7 +622,7 @@ def test_ratio_chains_below_modulated_frequencies(sa, oracle):
     assert b.timing_ex()["block_ms"] < 1.0  # none of them needed the block loop
 
 
-@pytest.mark.parametrize("env", [{"SAU_AMD_FAST_ROWS": "2"}, {"SAU_AMD_FAST_ROWS": "6"}, {"SAU_AMD_NO_TWO_PASS": "1"}, {"SAU_AMD_NO_SEQ": "1"},
+@pytest.mark.parametrize("env", [{"SAU_AMD_FAST_ROWS": "2"}, {"SAU_AMD_FAST_ROWS": "6"}, {"SAU_AMD_FAST_ROWS": "5"}, {"SAU_AMD_NO_TWO_PASS": "1"}, {"SAU_AMD_NO_SEQ": "1"},
                                  {"SAU_AMD_LDS_LIMIT": "65536"}, {"SAU_AMD_MULTI_MIN": "1"},
                                  {"SAU_AMD_NO_LOOKBACK": "1"}, {"SAU_AMD_NO_LOOKBACK": "1", "SAU_AMD_NO_INC_ROWS": "1"},
                                  {"SAU_AMD_LOOK_MIN_VOICES": "1"}, {"SAU_AMD_LOOK_MIN_VOICES": "1", "SAU_AMD_LOOK_ROWS": "4"},
