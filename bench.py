@@ -3,6 +3,15 @@
 
     python bench.py --gpus N --steps K --warmup W [--workload config3|config4|config5]
 
+`--gpus N` with N > 1 and no launcher around it (no WORLD_SIZE in the environment) starts the N ranks
+itself: N fresh child processes of this script, one per GPU, before this process has touched the GPU;
+rank 0's JSON line is relayed. Under `python -m torch.distributed.run --nproc-per-node N` the ranks
+are the launcher's. Every rank checks that the world it finds is the `--gpus` it was given.
+
+The default (config 3) line also carries `other_workloads`: short runs of config 5 and config 4 in
+the same process, outside config 3's timed region, each with its own value / ms_per_step / roofline /
+cpu_baseline and the same SHA-256 checks (`--no-others` leaves them out, e.g. under rocprofv3).
+
 One step = one pass of the generator hot path over one batch, program state, block buffers and PCM
 resident in HBM:
 
@@ -58,10 +67,10 @@ def profile_traffic(workload, kernel_prefix):
             if pmc.get("workload", {}).get("name") != workload:
                 continue
             k = [v for n, v in pmc["kernels"].items() if kernel_prefix in n]
-            best = (k[0]["hbm_bytes_per_launch_corrected"], "profiles/" + f)
+            best = (k[0]["hbm_bytes_per_launch_corrected"], "profiles/" + f, k[0].get("valu"))
         except (OSError, KeyError, ValueError, IndexError):
             pass
-    return best if best else (None, None)
+    return best if best else (None, None, None)
 
 
 def cpu_reference(make_prg, what, voices, ops_per_voice, tabs, all_cores=False):
@@ -147,6 +156,24 @@ def sha256(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
+def test_backend():
+    """tests/test_dist.py only (SAU_BENCH_TEST_BACKEND = tests/seqexec/libseqexec.so): the host control plane over the
+    sequential plan executor, so that the N-rank logic of this script -- launcher, sharding, barriers, reductions --
+    runs on a box without GPUs. Lines produced this way say so in `data` and measure nothing."""
+    path = os.environ.get("SAU_BENCH_TEST_BACKEND")
+    if not path:
+        return None
+    import ctypes as C
+    seq = C.CDLL(path)
+    seq.seq_backend_create.restype = C.c_void_p
+    seq.seq_backend_create.argtypes = [C.c_uint32]
+    return seq.seq_backend_create(1016)
+
+
+def new_batch(sa, prgs):
+    return sa.Batch(prgs, 44100, backend=test_backend())
+
+
 class Ranks:
     """One process per GPU; torch.distributed (backend "nccl" = RCCL) only for the barrier, the
     max-over-ranks clock and the after-the-fact report."""
@@ -161,9 +188,11 @@ class Ranks:
         # SAU_BENCH_BACKEND=gloo lets the N>1 logic be exercised on a box with fewer GPUs than
         # ranks (ranks then share devices; rendezvous and reductions on the CPU)
         self.backend = os.environ.get("SAU_BENCH_BACKEND", "nccl")
+        self.cuda = not os.environ.get("SAU_BENCH_TEST_BACKEND")
         dev = local_rank % max(1, torch.cuda.device_count())
         os.environ.setdefault("SAU_AMD_DEVICE", str(dev))
-        torch.cuda.set_device(dev)
+        if self.cuda:
+            torch.cuda.set_device(dev)
         if self.world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             if self.backend == "nccl":
@@ -175,7 +204,8 @@ class Ranks:
     def barrier(self, batches=()):
         if self.world > 1:
             self.dist.barrier()
-        self.torch.cuda.synchronize()
+        if self.cuda:
+            self.torch.cuda.synchronize()
         for b in batches:
             b.sync()
 
@@ -204,7 +234,7 @@ def run_config3(args, R, sa, tabs):
     index = json.load(open(os.path.join(GOLDEN, "index.json")))
     seconds = max(1, (args.frames * (args.steps + args.warmup + 2)) // 44100 + 2)
     prg = voicebank.config3(n=args.voices, seconds=seconds)
-    batch = sa.Batch([prg], 44100)
+    batch = new_batch(sa, [prg])
     # what is about to be timed is the reference's render: the first step (the script's first 10 s)
     verified = None
     pcm = batch.run(args.frames, stereo=False)[0]
@@ -240,7 +270,7 @@ def run_config3(args, R, sa, tabs):
     alg_bytes = (n_ops * 8 + 2) * args.frames
     launch_s = (tm["fast_ms"] / 1e3) / max(1, tm["segments"])
     achieved = alg_bytes / launch_s / 1e9 if launch_s > 0 else 0.0
-    traffic, source = profile_traffic("config3", "fast_kernel<") if verified else (None, None)
+    traffic, source, valu = profile_traffic("config3", "fast_kernel<") if verified else (None, None, None)
     out = {
         "metric": "mono samples/sec/GPU @ N voices (depth-3 FM)",
         "value": frames_total / dt, "unit": "mixed mono int16 frames/s",
@@ -258,6 +288,9 @@ def run_config3(args, R, sa, tabs):
                    "operator_samples_per_s": frames_total / dt * n_ops},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                      "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": source,
+                     # the kernel is VALU-bound in fact -- issued VALU instructions x 4 cycles over
+                     # SIMDs x launch cycles, from the same hash-matched PMC summary (tools/collect_profile.py)
+                     "valu": valu,
                      "kernel": "fast_kernel<8, 0>", "avg_launch_ms": launch_s * 1e3,
                      "launches": tm["segments"], "algorithmic_bytes_per_launch": alg_bytes},
     }
@@ -268,8 +301,45 @@ def run_config3(args, R, sa, tabs):
     return out
 
 
-def run_config4(args, R, sa, tabs):
+def cpu_reference_config4(fx, tabs, budget_s=10.0):
+    """Config 4 on one host core: whole 60 s renders of seeds 0, 1, 2, ... through the compiled reference (or the
+    oracle port), as many as fit the time budget (at least 2, at most 64)."""
     import numpy as np
+    from oracle import pyoracle as po
+    import saugns_amd as sa
+    frames_each = int(fx["frames"][0])
+    if po.have_ref():
+        kind = "reference"
+        po.ref()
+
+        def render(prg):
+            return po.ref_render(prg.ptr, 44100, False, chunk=11289)
+    else:
+        kind = "port"
+        po.oracle_use_tables(tabs)
+        po.oracle().ora_set_fastmath_forms(1)
+
+        def render(prg):
+            return po.oracle_render(prg.ptr, 44100, False, chunk=11289)
+    render(sa.Program.from_image(fx["images"][0].tobytes()))  # one-time set-up
+    n, frames, ok = 0, 0, True
+    t0 = time.perf_counter()
+    while n < 64 and (n < 2 or time.perf_counter() - t0 < budget_s):
+        pcm = render(sa.Program.from_image(fx["images"][n].tobytes()))
+        frames += len(pcm)
+        ok = ok and (kind != "reference" or sha256(np.asarray(pcm)) == str(fx["sha256"][n]))
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": frames / dt, "unit": "mixed mono int16 frames/s summed over renders", "cores": 1, "kind": kind,
+            "sample": f"config 4, seeds 0..{n - 1} of rainy_thunder.sau, whole {frames_each}-frame renders one after "
+                      f"another, {dt:.1f} s on 1 host thread (hash of each hashed-render equals the fixture's: {ok})",
+            "operator_samples_per_s": frames * 7 / dt}
+
+
+def run_config4(args, R, sa, tabs, steps=None, warmup=None):
+    import numpy as np
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
     from saugns_amd.shard import shard_range
     fx = np.load(os.path.join(GOLDEN, "config4_seeds.npz"))
     per_gpu = args.renders
@@ -278,9 +348,11 @@ def run_config4(args, R, sa, tabs):
     prgs = [sa.Program.from_image(fx["images"][k].tobytes()) for k in range(a, b)]
     frames_each = int(fx["frames"][0])
     run_len = 441000
+    if args.c4_frames:  # tests: the head of every render only (then compared with the fixtures' PCM heads)
+        frames_each = run_len = min(frames_each, args.c4_frames)
 
     def step(fetch, timing=None):
-        batch = sa.Batch(prgs, 44100)
+        batch = new_batch(sa, prgs)
         batch.set_call_len(11289)  # the reference host's call size (saugns.c:471,526)
         if timing is not None:
             batch.set_timing(2)
@@ -292,7 +364,7 @@ def run_config4(args, R, sa, tabs):
                 for i in range(len(prgs)):
                     outs[i].append(pcm[i, :lens[i]].copy())
             n += sum(lens)
-            alive = any(more)
+            alive = any(more) and not args.c4_frames
         batch.sync()
         if timing is not None:
             t = batch.timing_ex()
@@ -301,65 +373,76 @@ def run_config4(args, R, sa, tabs):
         batch.close()
         return n, outs
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step(False)
     R.barrier()
     tm = {"fast_ms": 0.0, "block_ms": 0.0, "mix_ms": 0.0, "aux_ms": 0.0, "segments": 0}
     t0 = time.perf_counter()
     frames_mine = 0
-    for _ in range(args.steps):
+    for _ in range(steps):
         frames_mine += step(False, tm)[0]
     R.barrier()
     dt = R.max(time.perf_counter() - t0)
     # after the timed region: every render against the reference's SHA-256, then the ranks' report
     n, outs = step(True)
-    bad = [a + i for i, o in enumerate(outs) if sha256(np.concatenate(o)) != str(fx["sha256"][a + i])]
+    if args.c4_frames:
+        heads = np.load(os.path.join(GOLDEN, "pcm_heads.npz"))
+        bad = [a + i for i, o in enumerate(outs) if f"config4_seed{a + i}" in heads and
+               np.abs(np.concatenate(o).astype(int) - heads[f"config4_seed{a + i}"][:frames_each].astype(int)).max() > 1]
+    else:
+        bad = [a + i for i, o in enumerate(outs) if sha256(np.concatenate(o)) != str(fx["sha256"][a + i])]
     if bad:
         raise SystemExit(f"rank {R.rank}: renders {bad[:8]} differ from the reference's SHA-256")
     checksum = sum(int(np.concatenate(o).astype(np.int64).sum()) for o in outs) & 0x7FFFFFFFFFFF
     tally = R.sum([frames_mine, n, checksum, len(prgs)])
-    if tally[0] != args.steps * frames_each * total or tally[3] != total:
+    if tally[0] != steps * frames_each * total or tally[3] != total:
         raise SystemExit(f"rank {R.rank}: frame count {tally} does not add up to {total} renders")
     if R.rank != 0:
         return None
     # 7 operators per render (2 voices): 8 B per operator-sample + 2 B per output frame
     alg = (7 * 8 + 2) * frames_each * len(prgs)
-    kern_s = tm["fast_ms"] / 1e3 / args.steps
+    kern_s = tm["fast_ms"] / 1e3 / steps
     achieved = alg / kern_s / 1e9 if kern_s > 0 else 0.0
-    return {
+    out = {
         "metric": "mono samples/sec, examples/rainy_thunder.sau x 512 renders sharded over GPUs",
         "value": tally[0] / dt, "unit": "mixed mono int16 frames/s summed over renders",
-        "n_gpus": R.world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "n_gpus": R.world, "steps": steps, "warmup": warmup,
+        "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32 (u64 cycle counters, u32 phase)", "data": "synthetic",
         "config": {"workload": f"BASELINE config 4: rainy_thunder.sau with seed=k, {len(prgs)} renders per GPU "
                                f"(seeds shard_range({total}, rank, {R.world})), 60 s at 44.1 kHz mono each; one step = "
                                f"the rank's renders from generator creation to the last frame",
                    "renders_all_ranks": tally[3], "frames_all_ranks": tally[0],
                    "pcm_checksum_all_ranks": tally[2],
-                   "verified": f"SHA-256 of every one of the {total} renders equals the compiled reference's "
-                               "(tests/golden/config4_seeds.npz)"},
+                   "verified": (f"SHA-256 of every one of the {total} renders equals the compiled reference's "
+                                "(tests/golden/config4_seeds.npz)") if not args.c4_frames else
+                               f"first {frames_each} frames of seeds 0..3 within 1 LSB of tests/golden/pcm_heads.npz"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                      "frac": achieved / 8000.0, "traffic": None, "traffic_source": None,
                      "kernel": "fast_kernel<4, 2> (running sums in one pass with look-back; one launch per segment)",
                      "kernel_ms_per_step": kern_s * 1e3, "other_kernels_ms_per_step":
-                     {k: tm[k] / args.steps for k in ("block_ms", "mix_ms", "aux_ms")},
-                     "segments_per_step": tm["segments"] / args.steps,
+                     {k: tm[k] / steps for k in ("block_ms", "mix_ms", "aux_ms")},
+                     "segments_per_step": tm["segments"] / steps,
                      "algorithmic_bytes_per_step": alg,
                      "note": "64 renders per GPU are a few hundred voices: below the voice count that fills 256 CUs, and "
                              "a quarter of the step is the per-segment launch sequence around the kernel"},
     }
+    if not args.no_cpu and R.world == 1:
+        out["cpu_baseline"] = cpu_reference_config4(fx, tabs)
+    return out
 
 
-def run_config5(args, R, sa, tabs):
+def run_config5(args, R, sa, tabs, steps=None, warmup=None):
     import numpy as np
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
     from saugns_amd import voicebank
     index = json.load(open(os.path.join(GOLDEN, "index.json")))
     prg = voicebank.config5(n=args.voices5, seconds=10)
     frames = 441000
 
     def step(fetch, timing=None):
-        batch = sa.Batch([prg], 44100)
+        batch = new_batch(sa, [prg])
         if timing is not None:
             batch.set_timing(2)
         pcm = batch.run(frames, stereo=False, fetch=fetch)[0]
@@ -378,31 +461,31 @@ def run_config5(args, R, sa, tabs):
         if got != want:
             raise SystemExit(f"rank {R.rank}: config 5 PCM {got[:16]} is not the reference's {want[:16]}")
         verified = {"sha256": got, "equals": "tests/golden/index.json configs.config5.sha256 (compiled reference)"}
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step(False)
     R.barrier()
     tm = {"fast_ms": 0.0, "block_ms": 0.0, "mix_ms": 0.0, "aux_ms": 0.0, "segments": 0}
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step(False, tm)
     R.barrier()
     dt = R.max(time.perf_counter() - t0)
-    mine = [frames * args.steps, int(np.asarray(pcm, dtype=np.int64).sum() & 0x7FFFFFFF)]
+    mine = [frames * steps, int(np.asarray(pcm, dtype=np.int64).sum() & 0x7FFFFFFF)]
     tally = R.sum(mine)
-    if tally[0] != frames * args.steps * R.world or tally[1] != mine[1] * R.world:
+    if tally[0] != frames * steps * R.world or tally[1] != mine[1] * R.world:
         raise SystemExit(f"rank {R.rank}: ranks disagree ({tally} vs {mine} x {R.world})")
     if R.rank != 0:
         return None
     n_ops = args.voices5 * 2
     alg = (n_ops * 8 + 2) * frames
     dom = max(("block_ms", "fast_ms"), key=lambda k: tm[k])
-    kern_s = tm[dom] / 1e3 / args.steps
+    kern_s = tm[dom] / 1e3 / steps
     achieved = alg / kern_s / 1e9 if kern_s > 0 else 0.0
     out = {
         "metric": "mono samples/sec/GPU @ N voices (self-feedback FM + AM + ramps)",
         "value": tally[0] / dt, "unit": "mixed mono int16 frames/s",
-        "n_gpus": R.world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "n_gpus": R.world, "steps": steps, "warmup": warmup,
+        "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32 (f64 table interpolation, u32 phase)", "data": "synthetic",
         "config": {"workload": f"BASELINE config 5: {args.voices5} voices x (self-modulated carrier with frequency, "
                                f"amplitude and feedback ramps + range-AM modulator) = {n_ops} operators, 44.1 kHz mono; "
@@ -414,14 +497,56 @@ def run_config5(args, R, sa, tabs):
                      "frac": achieved / 8000.0, "traffic": None, "traffic_source": None,
                      "kernel": "feedback recurrence + block loop (" + dom + ")",
                      "kernel_ms_per_step": kern_s * 1e3,
-                     "all_kernels_ms_per_step": {k: tm[k] / args.steps for k in ("fast_ms", "block_ms", "mix_ms", "aux_ms")},
-                     "segments_per_step": tm["segments"] / args.steps,
+                     "all_kernels_ms_per_step": {k: tm[k] / steps for k in ("fast_ms", "block_ms", "mix_ms", "aux_ms")},
+                     "segments_per_step": tm["segments"] / steps,
                      "algorithmic_bytes_per_step": alg},
     }
     if not args.no_cpu and R.world == 1:
         out["cpu_baseline"] = cpu_reference(lambda: voicebank.config5(n=args.voices5, seconds=10),
                                             f"config 5 ({args.voices5} feedback voices)", args.voices5, 2, tabs)
     return out
+
+
+def launch_ranks(n):
+    """`bench.py --gpus N` without a launcher: start the N ranks as fresh child processes of this script, one per
+    GPU (LOCAL_RANK selects it), and relay rank 0's JSON line. This process never initialises the GPU (nothing
+    below imports torch or the library), so no process that has is ever replaced or forked."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    import threading
+    got = []
+    reader = threading.Thread(target=lambda: got.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rcs = [None] * n
+    while any(rc is None for rc in rcs):  # a rank that dies takes the others with it (they would wait at a barrier)
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+        if any(rc not in (None, 0) for rc in rcs):
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    p.terminate()  # exactly the children started above
+                    rcs[r] = p.wait()
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    line = got[0] if got else ""
+    sys.stdout.write(line)
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        raise SystemExit(f"bench.py: rank(s) failed (rank, exit code): {bad}")
+    if not line.strip():
+        raise SystemExit("bench.py: rank 0 printed no result line")
 
 
 def main():
@@ -434,8 +559,12 @@ def main():
     ap.add_argument("--voices", type=int, default=1024, help="config3: voices")
     ap.add_argument("--renders", type=int, default=64, help="config4: renders per GPU")
     ap.add_argument("--voices5", type=int, default=4096, help="config5: voices")
+    ap.add_argument("--c4-frames", type=int, default=0, help="config4 (tests): render only the first frames of each script")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-others", action="store_true", help="config3: no short config 5 / config 4 runs after it")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus)  # before anything touches the GPU
     defaults = {"config3": (100, 3), "config4": (5, 1), "config5": (5, 1)}[args.workload]
     if args.steps is None:
         args.steps = defaults[0]
@@ -444,12 +573,26 @@ def main():
 
     import numpy as np
     R = Ranks()
+    if R.world != args.gpus:
+        raise SystemExit(f"rank {R.rank}: --gpus {args.gpus} but the launcher's world has {R.world} ranks")
     import saugns_amd as sa
     tabs = np.fromfile(os.path.join(GOLDEN, "piluts_ref.f32"), dtype="<f4").reshape(12, 2048)
     sa.set_piluts(tabs)
     out = {"config3": run_config3, "config4": run_config4, "config5": run_config5}[args.workload](args, R, sa, tabs)
+    others = {}
+    if args.workload == "config3" and not args.no_others and args.voices == 1024 and args.frames == 441000:
+        # the other two BASELINE workloads, every rank alike (their barriers are collective), short runs
+        for name, fn in (("config5", run_config5), ("config4", run_config4)):
+            o = fn(args, R, sa, tabs, steps=3, warmup=1)
+            if o is not None:
+                o["roofline"]["kernel_source_sha"] = kernel_source_hash()
+                others[name] = o
     if out is not None:
         out["roofline"]["kernel_source_sha"] = kernel_source_hash()
+        if os.environ.get("SAU_BENCH_TEST_BACKEND"):
+            out["data"] = "TEST BACKEND (CPU plan executor of tests/seqexec): rank logic only, not a measurement"
+        if others:
+            out["other_workloads"] = others
         print(json.dumps(out))
     R.close()
 

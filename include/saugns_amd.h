@@ -135,7 +135,9 @@ typedef struct sauAmdOpDesc {
 	uint32_t seed;
 	sauAmdLineDesc pan, amp, amp2, freq, freq2, pm_a;
 } sauAmdOpDesc;
-/* NULL on a malformed description (parent out of range, cycles, voices out of time order). */
+/* NULL on a malformed description: parent out of range, cycles, voices out of time order, an operator type,
+ * wave / noise id, R line or function or a ramp shape outside its enum, a carrier with time_ms == 0 (a voice's
+ * length is its carrier's), nesting deeper than 255, a duration beyond 32 bits of milliseconds. */
 SAU_AMD_API sauProgram *sauAmd_build_bank(const sauAmdOpDesc *ops, size_t n_ops, float ampmult,
 		uint32_t default_mod_ms);
 SAU_AMD_API void sauAmd_free_bank(sauProgram *prg);

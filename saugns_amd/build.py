@@ -51,21 +51,27 @@ def build(force=False, verbose=False):
         try:
             if not force and not _stale():
                 return LIB
-            return _build(verbose)
+            return _build(verbose, force)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
-def _build(verbose):
+def _build(verbose, force=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.rsplit(".", 1)[0] + ".o")
+        objs.append(obj)
+        # the kernel parts (k_*.h) are included by hip_backend.hip only
+        deps = [src] + [h for h in HEADERS if src.endswith(".hip") or not h.startswith("k_")]
+        if not force and os.path.exists(obj) and all(
+                os.path.getmtime(os.path.join(CSRC, d)) <= os.path.getmtime(obj) for d in deps) and \
+                os.path.getmtime(__file__) <= os.path.getmtime(obj):
+            continue
         cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
-        objs.append(obj)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
     subprocess.check_call(cmd)
     return LIB

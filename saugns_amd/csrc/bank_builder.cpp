@@ -48,8 +48,20 @@ extern "C" sauProgram *sauAmd_build_bank(const sauAmdOpDesc *ops, size_t n_ops, 
 	/* children per operator and use type, in the order given */
 	std::vector<std::vector<uint32_t>> kids(n_ops);
 	std::vector<uint32_t> carriers;
+	auto line_ok = [](const sauAmdLineDesc &d) { return !d.present || d.shape < SAU_LINE_NAMED; };
 	for (size_t i = 0; i < n_ops; ++i) {
 		const sauAmdOpDesc &o = ops[i];
+		/* ids the generator would index tables with: operator type, wave / noise id, R line and function, ramp shapes */
+		if (o.type >= SAU_POPT_TYPES) return nullptr;
+		if (o.type == SAU_POPT_N_wave && (o.mode & 0xff) >= SAU_WAVE_NAMED) return nullptr;
+		if (o.type == SAU_POPT_N_wave && o.mode > 0xff) return nullptr;
+		if (o.type == SAU_POPT_N_noise && o.mode >= SAU_NOISE_NAMED) return nullptr;
+		if (o.type == SAU_POPT_N_raseg && ((o.mode & 0xff) >= SAU_LINE_NAMED || ((o.mode >> 16) & 0x3f) >= SAU_RAS_FUNCTIONS ||
+		                                  (o.mode >> 22) != 0)) return nullptr;
+		if (!line_ok(o.pan) || !line_ok(o.amp) || !line_ok(o.amp2) || !line_ok(o.freq) || !line_ok(o.freq2) || !line_ok(o.pm_a))
+			return nullptr;
+		/* a voice's length is its carrier's: it has to state one (the parser gives carriers a set time too) */
+		if (o.use == SAU_POP_N_carr && o.time_ms == 0) return nullptr;
 		if (o.use == SAU_POP_N_carr) carriers.push_back((uint32_t)i);
 		else {
 			if (o.parent >= n_ops || o.parent == i || o.use >= SAU_POP_NAMED) return nullptr;
@@ -64,7 +76,8 @@ extern "C" sauProgram *sauAmd_build_bank(const sauAmdOpDesc *ops, size_t n_ops, 
 	b->lines.reserve(n_ops * 6);
 	b->idarrs.reserve(n_ops * 2 + 16);
 	std::vector<uint32_t> id_of(n_ops, 0xFFFFFFFFu);
-	uint32_t next_id = 0, depth_max = 0, dur = 0;
+	uint32_t next_id = 0, depth_max = 0;
+	uint64_t dur = 0;
 	/* ids in pre-order, use types ascending, as the parser numbers nested objects */
 	struct Frame { uint32_t op, depth; };
 	std::vector<Frame> stack;
@@ -82,6 +95,7 @@ extern "C" sauProgram *sauAmd_build_bank(const sauAmdOpDesc *ops, size_t n_ops, 
 		}
 	}
 	if (next_id != n_ops) { delete b; return nullptr; } /* operators not under any carrier */
+	if (depth_max > 255) { delete b; return nullptr; } /* op_nest_depth is a uint8_t (sau/program.h:259) */
 	/* operator data in post-order per voice */
 	auto add_line = [&](const sauAmdLineDesc &d, uint32_t t_ms, bool rp) -> sauLine * {
 		if (!d.present) return nullptr;
@@ -167,7 +181,7 @@ extern "C" sauProgram *sauAmd_build_bank(const sauAmdOpDesc *ops, size_t n_ops, 
 		ev.op_data_count = (uint32_t)(b->ods.size() - first_od);
 		ev.op_data = (const sauProgramOpData *)(uintptr_t)(first_od + 1);
 		const uint32_t ct = ops[carriers[v]].time_ms ? ops[carriers[v]].time_ms : default_mod_ms;
-		if (start + ct > dur) dur = start + ct;
+		if ((uint64_t)start + ct > dur) dur = (uint64_t)start + ct;
 	}
 	/* the vectors no longer move: indices become pointers */
 	auto fix = [&](const sauProgramIDArr *&p) { if (p) p = (const sauProgramIDArr *)&b->idarrs[(uintptr_t)p - 1]; };
@@ -183,7 +197,8 @@ extern "C" sauProgram *sauAmd_build_bank(const sauAmdOpDesc *ops, size_t n_ops, 
 	b->prg.vo_count = (uint16_t)carriers.size();
 	b->prg.op_count = (uint32_t)n_ops;
 	b->prg.op_nest_depth = (uint8_t)(depth_max > 255 ? 255 : depth_max);
-	b->prg.duration_ms = dur;
+	if (dur > 0xFFFFFFFFull) { delete b; return nullptr; } /* duration_ms is 32 bits */
+	b->prg.duration_ms = (uint32_t)dur;
 	b->prg.ampmult = ampmult;
 	b->prg.name = "bank";
 	return &b->prg; /* (first member of Built) */

@@ -179,6 +179,19 @@ static void pool_free(bool pinned, void *q, size_t bytes) {
 	if (!BufPool::get().give(pinned, q, bytes)) { if (pinned) (void)hipHostFree(q); else (void)hipFree(q); }
 }
 
+/* hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device and kernel, remembered in static tables: generators
+ * driven from different host threads share them, so check-then-raise runs under one lock (values only ever grow) */
+static std::mutex &attr_mutex() { static std::mutex *m = new std::mutex; return *m; }
+static bool raise_lds_attr(const void *fn, size_t lds, size_t &configured, std::string &err) {
+	std::lock_guard<std::mutex> lk(attr_mutex());
+	if (lds > configured) {
+		hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		if (e != hipSuccess) { err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(e); return false; }
+		configured = lds;
+	}
+	return true;
+}
+
 template <typename T, bool PINNED> struct PoolBuf {
 	T *p = nullptr;
 	size_t cap = 0, bytes = 0;
@@ -293,6 +306,7 @@ public:
 		if (!stream_) HIP_OK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
 		static std::mutex prop_mu;
 		static size_t dev_lds[16]; /* per device: hipGetDeviceProperties costs a millisecond */
+		static uint32_t dev_cus[16];
 		{
 			std::lock_guard<std::mutex> lk(prop_mu);
 			if (!dev_lds[dev & 15]) {
@@ -300,8 +314,14 @@ public:
 				HIP_OK(hipGetDeviceProperties(&prop, dev));
 				dev_lds[dev & 15] = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor
 				                                                          : prop.sharedMemPerBlock;
+				dev_cus[dev & 15] = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : FK_GRID;
 			}
 			lds_limit_ = dev_lds[dev & 15];
+			/* the time-parallel kernels' grids are one 1024-thread workgroup per CU at most: waves that wait for other
+			 * workgroups' sums (spread look-back launches) need the whole grid resident, so the grid follows the CUs
+			 * this device really has (a partitioned or CU-masked device has fewer than 256) */
+			fk_grid_ = dev_cus[dev & 15] < FK_GRID ? dev_cus[dev & 15] : FK_GRID;
+			if (const char *fg = getenv("SAU_AMD_FK_GRID")) { const int n = atoi(fg); if (n >= 1 && n <= (int)FK_GRID) fk_grid_ = (uint32_t)n; }
 		}
 		if (lds_limit_ > 160 * 1024) lds_limit_ = 160 * 1024;
 		if (const char *ll = getenv("SAU_AMD_LDS_LIMIT")) lds_limit_ = (size_t)atol(ll);
@@ -408,11 +428,7 @@ public:
 	template <int W, int T, int V>
 	bool launch_render(const RenderParams &rp, uint32_t grid, size_t lds, std::string &err) {
 		static size_t configured[16]; /* per device (function attributes are per device) */
-		if (lds > configured[dev_ & 15]) {
-			HIP_OK(hipFuncSetAttribute((const void *)render_kernel<W, T, V>,
-					hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-			configured[dev_ & 15] = lds;
-		}
+		if (!raise_lds_attr((const void *)render_kernel<W, T, V>, lds, configured[dev_ & 15], err)) return false;
 		hipLaunchKernelGGL((render_kernel<W, T, V>), dim3(grid), dim3(64 * W * V), lds, stream_, rp);
 		HIP_OK(hipGetLastError());
 		return true;
@@ -574,14 +590,36 @@ public:
 					fp.scan = scan_.p;
 				}
 				if (look_split && seg.n_look_rows) {
-					/* look-back words: valid for this segment's epoch only, so a fresh block starts out zeroed */
-					const unsigned long long *before = look_.p;
-					if (!look_.ensure((size_t)seg.n_look_rows * 2 * fp.scan_groups, err)) return false;
-					if (look_.p != before || look_epoch_ >= (1u << 30) - 1) {
-						HIP_OK(hipMemsetAsync(look_.p, 0, look_.cap * sizeof(unsigned long long), stream_));
-						look_epoch_ = 0;
+					/* Waves per voice of the single-pass build's launch (as many as the voice has row groups, up to 64,
+					 * when voices are few). Voices whose waves sit in one workgroup (1, 2, 4, 8 or 16 of them) look back
+					 * through rings in LDS and need no words in HBM; only a launch that spreads voices over
+					 * neighbouring workgroups does. Those words (8 B x 2 x row groups per running-sum oscillator) are
+					 * capped at 1 GiB: beyond that the launch keeps every voice inside a workgroup instead. */
+					const uint32_t groups = (seg.len + (60 * FT) - 1) / (60 * FT);
+					unsigned long long wpv = ((unsigned long long)fk_grid_ * 16) / seg.n_voices;
+					if (wpv > 64) wpv = 64;
+					if (wpv > groups) wpv = groups;
+					if (wpv < 1) wpv = 1;
+					const bool no_lds = getenv("SAU_AMD_LOOK_NO_LDS") != nullptr;
+					auto is_inside = [&](unsigned long long w) { return w <= 16 && (16 % w) == 0 && !no_lds; };
+					const size_t look_words = (size_t)seg.n_look_rows * 2 * fp.scan_groups;
+					if (!is_inside(wpv) && !no_lds && look_words * sizeof(unsigned long long) > ((size_t)1 << 30))
+						wpv = wpv > 16 ? 16 : wpv > 8 ? 8 : wpv > 4 ? 4 : 2;
+					look_wpv_ = (uint32_t)wpv;
+					look_inside_ = is_inside(wpv);
+					if (!look_inside_) {
+						/* look-back words: valid for this segment's epoch only, so a fresh block starts out zeroed */
+						const unsigned long long *before = look_.p;
+						if (!look_.ensure(look_words, err)) return false;
+						if (look_.p != before || look_epoch_ >= (1u << 30) - 1) {
+							HIP_OK(hipMemsetAsync(look_.p, 0, look_.cap * sizeof(unsigned long long), stream_));
+							look_epoch_ = 0;
+						}
+						fp.look_epoch = ++look_epoch_;
+					} else if (!look_.p && !look_.ensure(64, err)) {
+						return false; /* (a token block: the kernel forms row addresses from it and never reads them) */
 					}
-					fp.look = look_.p; fp.look_epoch = ++look_epoch_;
+					fp.look = look_.p;
 				}
 			}
 			if (!pass_flags_.p) {
@@ -664,11 +702,7 @@ public:
 					if (build == 1 && (rows == 6 || rows == 5)) rows = 4;
 					const int ri = rows == 8 ? 4 : rows == 6 ? 3 : rows == 5 ? 2 : rows == 4 ? 1 : 0;
 					const size_t lds = ft * tab_bytes + 16 * area_of(rows) + (build == 2 ? LOOK_LDS_BYTES : 0);
-					size_t &conf = fconfigured[dev_ & 15][build][ri];
-					if (lds > conf) {
-						HIP_OK(hipFuncSetAttribute(fkernels[build][ri], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-						conf = lds;
-					}
+					if (!raise_lds_attr(fkernels[build][ri], lds, fconfigured[dev_ & 15][build][ri], err)) return false;
 					void *args[] = {(void *)&fp};
 					HIP_OK(hipLaunchKernel(fkernels[build][ri], dim3(grid), dim3(1024), args, lds, stream_));
 					return true;
@@ -677,8 +711,8 @@ public:
 				 * few, one CU-filling grid at most */
 				const uint32_t groups = (seg.len + (60 * FT) - 1) / (60 * FT);
 				const unsigned long long want = (unsigned long long)seg.n_voices * (groups < 64 ? groups : 64);
-				uint32_t fgrid = (uint32_t)((want + 15) / 16 > FK_GRID ? FK_GRID : (want + 15) / 16);
-				if (fgrid > FK_GRID) fgrid = FK_GRID;
+				uint32_t fgrid = (uint32_t)((want + 15) / 16 > fk_grid_ ? fk_grid_ : (want + 15) / 16);
+				if (fgrid > fk_grid_) fgrid = fk_grid_;
 				if (fgrid < 1) fgrid = 1;
 				TimedPair *tf = timing_on_ ? new_pair(2) : nullptr;
 				if (tf) (void)hipEventRecord(tf->a, stream_);
@@ -696,15 +730,18 @@ public:
 				if (main_build == 2) {
 					/* closed-form and single-pass voices: one launch, whole segment; as many waves per voice as it has row
 					 * groups (up to 64) when voices are few */
-					unsigned long long wpv = ((unsigned long long)FK_GRID * 16) / seg.n_voices;
-					if (wpv > 64) wpv = 64;
-					if (wpv > groups) wpv = groups;
-					if (wpv < 1) wpv = 1;
+					unsigned long long wpv = look_wpv_;
+					if (!fp.look) { /* (no running-sum oscillator in any voice: closed-form voices only) */
+						wpv = ((unsigned long long)fk_grid_ * 16) / seg.n_voices;
+						if (wpv > 64) wpv = 64;
+						if (wpv > groups) wpv = groups;
+						if (wpv < 1) wpv = 1;
+					}
 					const unsigned long long waves = (unsigned long long)seg.n_voices * wpv;
-					const uint32_t grid2 = waves > (unsigned long long)FK_GRID * 16 ? FK_GRID : (uint32_t)((waves + 15) / 16);
+					const uint32_t grid2 = waves > (unsigned long long)fk_grid_ * 16 ? fk_grid_ : (uint32_t)((waves + 15) / 16);
 					fp.mode = fp.sum_levels + 1; fp.only_multi = 0; fp.look_wpv = (uint32_t)wpv;
 					fp.look_wpv_flags = getenv("SAU_AMD_LOOK_NO_LDS") ? 1u : 0u;
-					const bool inside = wpv <= 16 && (16 % wpv) == 0 && !fp.look_wpv_flags; /* every voice within one workgroup */
+					const bool inside = !fp.look || look_inside_; /* every voice within one workgroup */
 					if (inside || !fp.look) {
 						if (!launch_build(2, FT, grid2 ? grid2 : 1)) launched = false;
 					} else if (!SpreadLaunchOrder::get().ordered(dev_, stream_, [&]() { return launch_build(2, FT, grid2 ? grid2 : 1); })) {
@@ -725,10 +762,7 @@ public:
 						 * chunks after it and the final pass finishes the chunks before it. */
 						const size_t clds = (size_t)fp.n_ctabs * tab_bytes + CHAIN_IO_BYTES;
 						static size_t cconfigured[16];
-						if (clds > cconfigured[dev_ & 15]) {
-							HIP_OK(hipFuncSetAttribute((const void *)chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds));
-							cconfigured[dev_ & 15] = clds;
-						}
+						if (!raise_lds_attr((const void *)chain_kernel, clds, cconfigured[dev_ & 15], err)) return false;
 						const uint32_t cgrid = (seg.n_chain_rows + 63) / 64;
 						uint32_t n_chunks = chain_chunks_;
 						while (n_chunks > 1 && seg.len / n_chunks < 4096) n_chunks /= 2;
@@ -744,7 +778,7 @@ public:
 						/* chunk boundaries: multiples of the chain kernel's batch */
 						const uint32_t clen = ((seg.len + n_chunks - 1) / n_chunks + 255) & ~255u;
 						/* the time-parallel passes leave the chains' CUs alone while both run */
-						const uint32_t pgrid = n_chunks > 1 && fgrid + cgrid > FK_GRID ? (FK_GRID > cgrid + 32 ? FK_GRID - cgrid : 32) : fgrid;
+						const uint32_t pgrid = n_chunks > 1 && fgrid + cgrid > fk_grid_ ? (fk_grid_ > cgrid + 32 ? fk_grid_ - cgrid : 32) : fgrid;
 						TimedPair *tc = timing_on_ ? new_pair(0) : nullptr; /* counted with the block loop it replaces */
 						if (n_chunks == 1) {
 							fp.range_mode = 0;
@@ -787,11 +821,7 @@ public:
 					               : FT == 5 ? (const void *)repair_kernel<5> : FT == 4 ? (const void *)repair_kernel<4>
 					               : (const void *)repair_kernel<2>;
 					static size_t rconfigured[16][5];
-					size_t &rconf = rconfigured[dev_ & 15][FT == 8 ? 4 : FT == 6 ? 3 : FT == 5 ? 2 : FT == 4 ? 1 : 0];
-					if (flds > rconf) {
-						HIP_OK(hipFuncSetAttribute(rk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
-						rconf = flds;
-					}
+					if (!raise_lds_attr(rk, flds, rconfigured[dev_ & 15][FT == 8 ? 4 : FT == 6 ? 3 : FT == 5 ? 2 : FT == 4 ? 1 : 0], err)) return false;
 					const uint32_t rgrid = (seg.n_voices + 15) / 16 < 64 ? (seg.n_voices + 15) / 16 : 64;
 					fp.mode = 0;
 					if (FT == 8) hipLaunchKernelGGL((repair_kernel<8>), dim3(rgrid), dim3(1024), flds, stream_, fp);
@@ -1079,6 +1109,9 @@ private:
 	DevBuf<ChainDesc> chain_desc_;
 	DevBuf<unsigned char> fplines_;
 	uint32_t block_grid_ = 1;
+	uint32_t fk_grid_ = FK_GRID;
+	uint32_t look_wpv_ = 1;     /* this segment's single-pass launch: waves per voice, and whether every voice sits */
+	bool look_inside_ = true;   /* inside one workgroup (LDS rings, no waits across workgroups) */
 };
 
 /* Known-answer probe: div_diff_scale(a, b) against IEEE a / b for every f32 b

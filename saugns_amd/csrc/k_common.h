@@ -124,6 +124,12 @@ __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, i
  * for groups before its own: those belong to waves of this launch that are resident (the grid is at most
  * one workgroup per CU) or to an earlier launch of the same segment. */
 constexpr uint32_t LOOK_AGG = 1, LOOK_PREFIX = 2;
+/* Waiting across workgroups (words in HBM) assumes that the workgroups a wave waits for are resident or next in
+ * line for a CU. That holds for one such launch at a time on a device this process has to itself; a second
+ * process on the same device (or a CU-masked one) can break it. The wait is therefore bounded: after
+ * LOOK_SPIN_MAX empty polls (tens of milliseconds; a normal wait is microseconds) the wave gives up, says so
+ * through `stuck`, and the voice's segment is redone by the block loop (FastInfo.bail) -- slow, never hung. */
+constexpr uint32_t LOOK_SPIN_MAX = 1u << 15;
 /* The same words in LDS, for a voice whose waves all sit in one workgroup (2, 4, 8 or 16 of them): a ring of
  * 4 x waves entries per oscillator, tagged with the group's number + 1 (LDS starts out zeroed). A wave that
  * writes group g has finished group g - waves, so every wave of the voice has published at least up to round
@@ -142,7 +148,7 @@ template <bool LDS> __device__ __forceinline__ unsigned long long look_load(unsi
 }
 /* LDS: entry of group i at ent[i % ring] (the caller keeps cg % ring), tag i + 1; HBM: at ent[i], tag = the segment's epoch */
 template <bool LDS> __device__ __forceinline__ uint32_t lookback32(unsigned long long *ent, const uint32_t cg, const uint32_t tot,
-		const uint32_t epoch, const uint32_t ring, const uint32_t cgm /* LDS: cg % ring */, const int l) {
+		const uint32_t epoch, const uint32_t ring, const uint32_t cgm /* LDS: cg % ring */, const int l, uint32_t &stuck) {
 	/* (LDS: groups up to `ring` back have their entries; what lies further back is dead and reads as empty) */
 	auto at = [&](uint32_t i) { const int s_ = (int)cgm - (int)(cg - i); return LDS ? (uint32_t)(s_ < 0 ? s_ + (int)ring : s_) : i; };
 	auto tag = [&](uint32_t i) { return LDS ? i + 1 : epoch; };
@@ -175,7 +181,8 @@ template <bool LDS> __device__ __forceinline__ uint32_t lookback32(unsigned long
 /* 64-bit totals (R oscillators' cycle counters): low and high halves in two arrays, a pair counts once both
  * words show the same status */
 template <bool LDS> __device__ __forceinline__ unsigned long long lookback64(unsigned long long *ent_lo, unsigned long long *ent_hi,
-		const uint32_t cg, const unsigned long long tot, const uint32_t epoch, const uint32_t ring, const uint32_t cgm, const int l) {
+		const uint32_t cg, const unsigned long long tot, const uint32_t epoch, const uint32_t ring, const uint32_t cgm, const int l,
+		uint32_t &stuck) {
 	auto at = [&](uint32_t i) { const int s_ = (int)cgm - (int)(cg - i); return LDS ? (uint32_t)(s_ < 0 ? s_ + (int)ring : s_) : i; };
 	auto tag = [&](uint32_t i) { return LDS ? i + 1 : epoch; };
 	auto publish = [&](uint32_t i, uint32_t status, unsigned long long v) {

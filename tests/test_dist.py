@@ -65,3 +65,64 @@ def test_two_rank_gloo_batch(tmp_path, seqexec):  # (the fixture rebuilds libseq
                           "29533", str(f)], capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "OK 44100" in out.stdout
+
+
+def _bench(argv, seqexec, launcher=False, env_extra=None, timeout=600):
+    """bench.py's N-rank logic on a box without GPUs: the host control plane over the sequential executor, gloo."""
+    env = dict(os.environ, SAU_BENCH_TEST_BACKEND=os.path.join(ROOT, "tests", "seqexec", "libseqexec.so"),
+               SAU_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    cmd = [sys.executable]
+    if launcher:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                "--master-port", "29541"]
+    return subprocess.run(cmd + [os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, env=env,
+                          timeout=timeout)
+
+
+def _line(out):
+    import json
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [x for x in out.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_starts_two_ranks_config4(seqexec):
+    """`python bench.py --gpus 2 --workload config4` -- the driver's command shape, no launcher around it -- runs two
+    ranks that render shard_range(2 * 2, r, 2) of BASELINE config 4's seeds and reduce {frames, checksum}."""
+    j = _line(_bench(["--gpus", "2", "--workload", "config4", "--renders", "2", "--c4-frames", "11025",
+                      "--steps", "1", "--warmup", "0", "--no-cpu"], seqexec))
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak"
+    assert j["config"]["renders_all_ranks"] == 4 and j["config"]["frames_all_ranks"] == 4 * 11025
+    assert "TEST BACKEND" in j["data"]  # a line made this way never passes for a measurement
+
+
+def test_bench_gpus_2_starts_two_ranks_config3(seqexec):
+    j = _line(_bench(["--gpus", "2", "--voices", "8", "--frames", "4410", "--steps", "2", "--warmup", "1",
+                      "--no-cpu"], seqexec))
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["config"]["frames_all_ranks"] == 2 * 2 * 4410
+    one = _line(_bench(["--gpus", "1", "--voices", "8", "--frames", "4410", "--steps", "2", "--warmup", "1",
+                        "--no-cpu"], seqexec))
+    assert one["n_gpus"] == 1 and one["config"]["frames_all_ranks"] == 2 * 4410
+    # the same bank on every rank: the all-rank checksum is the single rank's, twice
+    assert j["config"]["pcm_checksum_all_ranks"] == 2 * one["config"]["pcm_checksum_all_ranks"]
+
+
+def test_bench_under_a_launcher_and_world_mismatch(seqexec):
+    """Under torch.distributed.run the ranks are the launcher's; --gpus must agree with the world it made."""
+    j = _line(_bench(["--gpus", "2", "--voices", "8", "--frames", "4410", "--steps", "1", "--warmup", "0",
+                      "--no-cpu"], seqexec, launcher=True))
+    assert j["n_gpus"] == 2
+    bad = _bench(["--gpus", "4", "--voices", "8", "--frames", "4410", "--steps", "1", "--warmup", "0", "--no-cpu"],
+                 seqexec, launcher=True)
+    assert bad.returncode != 0 and "--gpus 4" in bad.stdout + bad.stderr
+
+
+def test_bench_launcher_reports_a_failed_rank(seqexec):
+    """A rank that cannot run (here: a test backend that does not exist) makes `bench.py --gpus 2` exit non-zero."""
+    out = _bench(["--gpus", "2", "--voices", "8", "--frames", "4410", "--steps", "1", "--warmup", "0", "--no-cpu"],
+                 seqexec, env_extra={"SAU_BENCH_TEST_BACKEND": "/nonexistent/libseqexec.so"}, timeout=300)
+    assert out.returncode != 0

@@ -444,3 +444,27 @@ def test_bank_builder_in_the_c_abi(sa, oracle):
     assert not sa.lib().sauAmd_build_bank(bad, 2, 1.0, 1000)
     bad[0].use = 6; bad[0].parent = 1; bad[1].parent = 0  # no carrier
     assert not sa.lib().sauAmd_build_bank(bad, 2, 1.0, 1000)
+
+    def one(**kw):  # a well-formed one-operator bank with one field spoiled
+        d = (OpDesc * 1)()
+        d[0].use, d[0].type, d[0].mode, d[0].time_ms = 0, 2, 0, 100
+        d[0].freq.present, d[0].freq.v0, d[0].amp.present, d[0].amp.v0 = 1, 440.0, 1, 1.0
+        for k, v in kw.items():
+            obj, name = d[0], k
+            if "__" in k:
+                obj, name = getattr(d[0], k.split("__")[0]), k.split("__")[1]
+            setattr(obj, name, v)
+        p = sa.lib().sauAmd_build_bank(d, 1, 1.0, 1000)
+        if p:
+            sa.lib().sauAmd_free_bank(p)
+        return bool(p)
+
+    assert one()
+    assert not one(type=4)                      # no such operator type
+    assert not one(mode=12)                     # no such wave
+    assert not one(type=1, mode=7)              # no such noise
+    assert not one(type=3, mode=13)             # R: no such line
+    assert not one(type=3, mode=6 << 16)        # R: no such function
+    assert not one(freq__shape=13)              # no such ramp shape
+    assert not one(time_ms=0)                   # a carrier without a length
+    assert not one(start_ms=0xFFFFFFF0, time_ms=100)  # duration beyond 32 bits
