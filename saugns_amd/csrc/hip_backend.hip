@@ -341,6 +341,8 @@ public:
 			chain_chunks_ = n >= 16 ? 16 : n >= 8 ? 8 : n >= 4 ? 4 : n >= 2 ? 2 : 1;
 		}
 		two_pass_enabled_ = getenv("SAU_AMD_NO_TWO_PASS") == nullptr; /* ... in two passes where possible */
+		dyn_enabled_ = getenv("SAU_AMD_NO_DYN") == nullptr; /* closed-form launches deal tasks out through a counter */
+		if (const char *dg = getenv("SAU_AMD_DYN_GROUPS")) { const int n = atoi(dg); dyn_groups_ = n >= 1 ? (uint32_t)n : 1u; }
 		/* voices per segment from which feedback voices get sixteen one-wave teams per workgroup
 		 * (0: never; 1: always, also without feedback -- tests) */
 		multi_min_ = 256;
@@ -813,7 +815,18 @@ public:
 						launch_fast(fp.sum_levels + 1);
 					}
 				} else {
+					/* closed-form voices only: tasks of about eight row groups, dealt out by a counter */
+					const bool dyn_on = dyn_enabled_;
+					const uint32_t dyn_groups = dyn_groups_;
+					if (dyn_on && main_build == 0) {
+						/* ... but at least four tasks per wave of the grid where the voices' groups allow (few voices) */
+						const uint32_t by_size = (groups + dyn_groups - 1) / (dyn_groups ? dyn_groups : 1);
+						const uint32_t by_waves = (uint32_t)(((unsigned long long)4 * fgrid * 16 + seg.n_voices - 1) / seg.n_voices);
+						const uint32_t k = by_size > by_waves ? by_size : by_waves;
+						fp.dyn_chunks = k < groups ? (k ? k : 1) : (groups ? groups : 1);
+					}
 					launch_fast(0);
+					fp.dyn_chunks = 0;
 				}
 				if (!launched) return false;
 				{ /* row groups noted for a second evaluation: returns at once when there are none */
@@ -1110,6 +1123,8 @@ private:
 	DevBuf<unsigned char> fplines_;
 	uint32_t block_grid_ = 1;
 	uint32_t fk_grid_ = FK_GRID;
+	bool dyn_enabled_ = true;
+	uint32_t dyn_groups_ = 8;   /* row groups per task of a closed-form launch (SAU_AMD_DYN_GROUPS) */
 	uint32_t look_wpv_ = 1;     /* this segment's single-pass launch: waves per voice, and whether every voice sits */
 	bool look_inside_ = true;   /* inside one workgroup (LDS rings, no waits across workgroups) */
 };

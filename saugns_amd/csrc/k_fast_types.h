@@ -49,7 +49,8 @@ constexpr uint32_t FAST_MAX_LEVELS = 3; /* running sums that depend on running s
 constexpr uint32_t FAST_REPAIR_SHIFT = 24; /* H + shift < 64 (H <= 32) */
 constexpr uint32_t FAST_MAX_REPAIR = 15;   /* noted row groups per voice and segment; more: block loop */
 constexpr uint32_t FAST_REPAIR_WORDS = 2 + 2 * FAST_MAX_REPAIR; /* count, pad, then (group, rows) pairs */
-constexpr uint32_t FAST_FLAGS = FAST_MAX_LEVELS + 3; /* pass_flags words */
+constexpr uint32_t FAST_FLAGS = FAST_MAX_LEVELS + 4; /* pass_flags words */
+constexpr uint32_t FAST_DYN_CTR = FAST_MAX_LEVELS + 3; /* ... the one that deals out fast_kernel<T, 0>'s tasks (dyn_chunks) */
 /* Decoded steps are kept once per pass that runs them ([list][voice][step]): a pass walks its own list and never
  * loads a step only to find that another pass needs it (the per-step cost of the interpreter is most of a pass). */
 constexpr uint32_t FAST_LISTS = 5; /* 0: only / final pass, 1..3: sum passes, 4: chain-input pass */
@@ -124,6 +125,11 @@ struct FastParams {
 	uint32_t look_wpv;  /* waves per voice in fast_kernel<T, 2>'s launches (1..64): a voice whose waves sit in one workgroup
 	                     * looks back through rings in LDS, one spread over neighbouring workgroups through words in HBM */
 	uint32_t rows_multi; /* rows per pass in the launches of the full running-sum build (kinds 1 and 2) */
+	/* The closed-form build's launch deals its work out through a counter (pass_flags[FAST_DYN_CTR], zero at the start of
+	 * every segment: finalize_kernel): task = (voice, one of dyn_chunks runs of consecutive row groups). Waves take the
+	 * next task when they finish one, so CUs that get less done (other kernels' workgroups sharing them: the previous
+	 * segment's mixer) hold nobody up at the end. 0: static shares (waves stride over voices and groups). */
+	uint32_t dyn_chunks;
 	uint32_t only_multi; /* this launch: only the voices fast_kernel<T, 2> leaves out (one wave in order, several passes) */
 	int8_t ctab_of_wave[12];
 	uint8_t cwave_of_tab[12];

@@ -39,7 +39,8 @@ __device__ __forceinline__ FastStep load_step_uniform(const FastStep *p) {
 template <int T, int SCAN, bool REPAIR = false>
 __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v, const FastInfo &fi,
 		float *slots, unsigned long long *carry, const HerpC23 *t23, const HerpC01 *t01, const int l,
-		const uint32_t wpv, const uint32_t cstart, unsigned long long *lring = nullptr) {
+		const uint32_t wpv, const uint32_t cstart, unsigned long long *lring = nullptr,
+		const uint32_t dyn_c = 0, const uint32_t dyn_k = 0 /* > 0: chunk dyn_c of dyn_k of the voice's row groups */) {
 	constexpr int NP = 64 * T;
 	(void)NP;
 	const uint32_t fast_total = uni(fi.total);
@@ -101,6 +102,11 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 				if (P.f_lo >= fast_total) n_iter = 0;
 			}
 		}
+	}
+	if (!REPAIR && SCAN == 0 && dyn_k) { /* this task's run of consecutive groups */
+		const uint32_t per = (ngroups + dyn_k - 1) / dyn_k;
+		it_lo = dyn_c * per;
+		n_iter = min(ngroups, it_lo + per);
 	}
 	uint32_t cgm = cstart; /* the group number mod the look-back ring (groups cstart, cstart + waves, ...) */
 	for (uint32_t it = it_lo + cstart; it < n_iter; it += gstride, cgm = cgm + wpv >= lk_ring ? cgm + wpv - lk_ring : cgm + wpv) {
@@ -734,8 +740,13 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 #ifndef FK_MINB
 #define FK_MINB 1
 #endif
+#ifdef FK_WAVES_EU /* tuning aid: a register budget that leaves room for another kernel's waves on the SIMD */
+#define FK_ATTR __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(FK_WAVES_EU)))
+#else
+#define FK_ATTR __launch_bounds__(1024, FK_MINB)
+#endif
 template <int T, int SCAN>
-__global__ void __launch_bounds__(1024, FK_MINB) fast_kernel(FastParams P) {
+__global__ void FK_ATTR fast_kernel(FastParams P) {
 	constexpr int NP = 64 * T;
 	constexpr int W = 16;
 	extern __shared__ __align__(16) unsigned char lds[];
@@ -771,9 +782,25 @@ __global__ void __launch_bounds__(1024, FK_MINB) fast_kernel(FastParams P) {
 	}
 	__syncthreads(); /* the only barrier: tables are shared, all else is per wave */
 
+	const uint32_t NV = P.n_voices;
+	if (SCAN == 0 && P.dyn_chunks) {
+		/* tasks dealt out by a counter: the next one is asked for before the current one is worked on, so the
+		 * atomic's round trip is never waited for */
+		const uint32_t K = P.dyn_chunks, n_tasks = NV * K;
+		uint32_t nxt = 0;
+		if (l == 0) nxt = atomicAdd(&P.pass_flags[FAST_DYN_CTR], 1u);
+		for (;;) {
+			const uint32_t task = uni(nxt);
+			if (task >= n_tasks) break;
+			if (l == 0) nxt = atomicAdd(&P.pass_flags[FAST_DYN_CTR], 1u);
+			const uint32_t v = task / K;
+			const FastInfo fi = P.info[v];
+			fast_voice<T, 0>(P, v, fi, slots, carry, t23, t01, l, 1u, 0u, nullptr, task - v * K, K);
+		}
+		return;
+	}
 	const uint32_t g = blockIdx.x * W + (uint32_t)w;
 	const uint32_t total_waves = gridDim.x * W;
-	const uint32_t NV = P.n_voices;
 	uint32_t wpv = total_waves >= NV ? total_waves / NV : 1; /* waves per voice */
 	if (SCAN == 2 && total_waves >= NV) wpv = P.look_wpv; /* (voices x waves <= the launch's waves: the host's choice) */
 	uint32_t v = total_waves >= NV ? g / wpv : g;

@@ -1,0 +1,99 @@
+"""GPU against the compiled reference, directly.
+
+The parity argument so far went in two hops: GPU == oracle mode 1 bit for bit (the vector-body forms of
+gcc's fast-math build), oracle mode 2 == oracle/_ref/libsau_ref.so bit for bit (mode 1 + gcc's scalar
+loop-tail forms at the reference's own block positions). This file replaces the bridge between the two by
+numbers measured on the GPU box: the 64 random operator graphs and the 48 random graphs with later events
+of test_gpu_units.py are rendered by the device and by the compiled reference with the same call size, and
+
+* wherever the two oracle modes agree on a program's whole render (no loop tail mattered), the GPU must be
+  within 1 LSB of the reference on every sample (it is then in fact identical);
+* where they do not, the GPU still equals mode 1 exactly, and the distance to the reference -- which comes
+  from the reference's own loop tails, amplified by whatever modulation sits behind them -- is counted and
+  reported: programs, samples off by more than 1 LSB, the largest difference.
+
+The summary is printed and written to gpurun_out/gpu_vs_ref.json (copied to profiles/ per round)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from saugns_amd import voicebank as vb
+import test_gpu_units as tu
+
+pytestmark = pytest.mark.gpu
+RATE = 44100
+_summary = {"programs": 0, "modes_agree": 0, "gpu_equals_ref_exactly": 0, "within_1_lsb": 0,
+            "beyond_1_lsb": [], "samples": 0, "samples_differing": 0, "samples_beyond_1_lsb": 0, "max_abs_diff": 0}
+
+
+def _programs():
+    for seed in range(64):  # test_random_operator_graphs
+        rng = np.random.default_rng(1000 + seed)
+        voices = [tu._random_voice(rng) for _ in range(int(rng.integers(1, 4)))]
+        yield f"graph{seed}", vb.build_program(voices), bool(seed & 1), int(rng.integers(700, 3000))
+    for seed in range(48):  # test_random_graphs_with_later_events
+        rng = np.random.default_rng(5000 + seed)
+        voices = [tu._random_voice(rng) for _ in range(int(rng.integers(1, 4)))]
+        tu._random_starts(rng, voices)
+        ups = tu._random_updates(rng, voices)
+        yield f"events{seed}", vb.build_program(voices, updates=ups), bool(seed & 1), int(rng.integers(700, 3000))
+
+
+def test_gpu_vs_compiled_reference_on_random_graphs(sa, oracle, tables):
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref/libsau_ref.so not present (built here from /root/reference; travels to the GPU box)")
+    oracle.ref()
+    # The reference builds its wave tables with libm's sin() when it starts (sau/wave.c:105-221), and glibc picks
+    # its sin() by CPU (with or without FMA): on the GPU box's host four tables differ from the fixture by an ulp
+    # here and there. All three sides use the tables this very reference library has built -- what a host linked
+    # against this backend gets too (the shim adopts the host binary's sauWave_piluts).
+    ref_tabs = oracle.ref_piluts()
+    sa.set_piluts(ref_tabs)
+    oracle.oracle_use_tables(ref_tabs)
+    try:
+        _compare(sa, oracle)
+    finally:
+        sa.set_piluts(tables)
+        oracle.oracle_use_tables(tables)
+
+
+def _compare(sa, oracle):
+    S = _summary
+    for name, prg, stereo, chunk in _programs():
+        # the same call size everywhere: where the reference's loop tails fall depends on it
+        ref = oracle.ref_render(prg.ptr, RATE, stereo, chunk=chunk)
+        oracle.oracle().ora_set_fastmath_forms(2)
+        m2 = oracle.oracle_render(prg.ptr, RATE, stereo, chunk=chunk)
+        oracle.oracle().ora_set_fastmath_forms(1)
+        m1 = oracle.oracle_render(prg.ptr, RATE, stereo, chunk=chunk)
+        gpu = sa.Batch([prg], RATE).render(stereo=stereo, chunk=chunk)[0]
+        assert len(gpu) == len(ref) == len(m1) == len(m2), name
+        assert (m2 == ref).all(), f"{name}: oracle mode 2 is not the compiled reference"
+        assert (gpu == m1).all(), f"{name}: GPU is not oracle mode 1"
+        d = np.abs(gpu.astype(np.int32) - ref.astype(np.int32))
+        S["programs"] += 1
+        S["samples"] += len(d)
+        S["samples_differing"] += int((d > 0).sum())
+        S["samples_beyond_1_lsb"] += int((d > 1).sum())
+        S["max_abs_diff"] = max(S["max_abs_diff"], int(d.max()) if len(d) else 0)
+        agree = bool((m1 == m2).all())
+        S["modes_agree"] += agree
+        S["gpu_equals_ref_exactly"] += bool((d == 0).all())
+        if len(d) == 0 or d.max() <= 1:
+            S["within_1_lsb"] += 1
+        else:
+            S["beyond_1_lsb"].append({"program": name, "call_size": chunk, "samples": len(d),
+                                      "beyond_1_lsb": int((d > 1).sum()), "max_abs_diff": int(d.max()),
+                                      "first_at": int(np.nonzero(d > 1)[0][0])})
+        if agree:  # the contract: no loop tail mattered, so nothing may differ by more than 1 LSB
+            assert len(d) == 0 or d.max() <= 1, f"{name}: {int((d > 1).sum())} samples beyond 1 LSB, max {int(d.max())}"
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    json.dump(S, open(os.path.join(out, "gpu_vs_ref.json"), "w"), indent=1)
+    print("\nGPU vs compiled reference, 112 random programs:", json.dumps({k: v for k, v in S.items() if k != "beyond_1_lsb"}))
+    for b in S["beyond_1_lsb"]:
+        print("   ", b)
+    assert S["programs"] == 112
