@@ -45,6 +45,12 @@ struct sauGenerator {
 	size_t q_len = 0;
 	bool ahead_stereo = false;
 	bool more = true;                      /* the engine has signal left after everything issued */
+	/* The first runs are short and double from one to the next (1, 2, 4, ... host calls) until they reach
+	 * ahead_frames: what the host waits for in its first call is the events at t = 0 and one call's worth of
+	 * rendering, not a whole read-ahead run (BASELINE config 5: a 176400-frame run is 25 ms of feedback chains).
+	 * The device is never idle meanwhile -- the next run is always issued before the current one is handed out. */
+	unsigned runs_issued = 0;
+	bool ramp = true;                      /* SAU_AMD_READAHEAD_RAMP=0: every run ahead_frames long */
 };
 
 /* sau/generator/noise.h:18-21 */
@@ -81,6 +87,7 @@ static sauGenerator *make_generator(const sauProgram *prg, uint32_t srate, Backe
 	sauGenerator *g = new sauGenerator();
 	if (!make_batch(g->batch, &prg, 1, srate, injected)) { delete g; return nullptr; }
 	if (const char *ra = getenv("SAU_AMD_READAHEAD")) g->ahead_frames = (size_t)atol(ra);
+	if (const char *rr = getenv("SAU_AMD_READAHEAD_RAMP")) g->ramp = atoi(rr) != 0;
 	return g;
 }
 
@@ -116,16 +123,20 @@ static bool generator_fail(sauGenerator *o, int16_t *buf, size_t buf_len, bool s
 }
 
 /* Start the next engine run; its PCM lands in the slot not being handed out. */
-static bool generator_issue(sauGenerator *o, size_t frames, bool stereo, std::string &err) {
+static bool generator_issue(sauGenerator *o, size_t big, size_t call_len, bool stereo, std::string &err) {
 	const int k = o->cur ^ 1;
 	const size_t ch = stereo ? 2 : 1;
 	Backend *be = o->batch.engine->backend();
-	if (o->slot_cap[k] < frames * ch) {
+	/* this run: whole host calls, doubling up to `big` */
+	size_t frames = big;
+	if (o->ramp && o->runs_issued < 24 && call_len && (call_len << o->runs_issued) < big) frames = call_len << o->runs_issued;
+	++o->runs_issued;
+	if (o->slot_cap[k] < big * ch) { /* (sized for the longest run at once: growing later would wait for the stream) */
 		be->free_host(o->slot[k]);
 		o->slot_cap[k] = 0;
-		o->slot[k] = (int16_t *)be->alloc_host(frames * ch * sizeof(int16_t));
+		o->slot[k] = (int16_t *)be->alloc_host(big * ch * sizeof(int16_t));
 		if (!o->slot[k]) { err = "out of page-locked memory"; return false; }
-		o->slot_cap[k] = frames * ch;
+		o->slot_cap[k] = big * ch;
 	}
 	bool more = false;
 	size_t len = 0;
@@ -174,7 +185,7 @@ extern "C" bool sauGenerator_run(sauGenerator *o, int16_t *buf, size_t buf_len,
 		if (o->pos == o->len) {
 			if (!o->queued) {
 				if (!o->more) break;
-				if (!generator_issue(o, big, stereo, err))
+				if (!generator_issue(o, big, buf_len, stereo, err))
 					return generator_fail(o, buf, buf_len, stereo, out_len, err);
 			}
 			if (!o->batch.engine->backend()->wait_fetch(o->cur ^ 1, err))
@@ -182,7 +193,7 @@ extern "C" bool sauGenerator_run(sauGenerator *o, int16_t *buf, size_t buf_len,
 			o->cur ^= 1;
 			o->pos = 0; o->len = o->q_len; o->queued = false;
 			/* the device goes on with the run after this one while the host consumes */
-			if (o->more && !generator_issue(o, big, stereo, err))
+			if (o->more && !generator_issue(o, big, buf_len, stereo, err))
 				return generator_fail(o, buf, buf_len, stereo, out_len, err);
 			if (o->len == 0) { if (!o->queued) break; continue; }
 		}

@@ -341,6 +341,8 @@ public:
 			chain_chunks_ = n >= 16 ? 16 : n >= 8 ? 8 : n >= 4 ? 4 : n >= 2 ? 2 : 1;
 		}
 		two_pass_enabled_ = getenv("SAU_AMD_NO_TWO_PASS") == nullptr; /* ... in two passes where possible */
+		if (const char *lr = getenv("SAU_AMD_LEAN_ROWS")) lean_rows_ = (uint32_t)atoi(lr);
+		lean_enabled_ = getenv("SAU_AMD_NO_LEAN") == nullptr; /* chains' passes in a build without the several-pass sums */
 		dyn_enabled_ = getenv("SAU_AMD_NO_DYN") == nullptr; /* closed-form launches deal tasks out through a counter */
 		if (const char *dg = getenv("SAU_AMD_DYN_GROUPS")) { const int n = atoi(dg); dyn_groups_ = n >= 1 ? (uint32_t)n : 1u; }
 		/* voices per segment from which feedback voices get sixteen one-wave teams per workgroup
@@ -679,6 +681,12 @@ public:
 				}
 			}
 			fp.n_tabs = ft;
+			/* the build for voices with chains and nothing to scan: as many rows per pass as fit beside the tables */
+			fp.lean_on = chains && lean_enabled_ ? 1u : 0u;
+			fp.rows_lean = 4;
+			for (uint32_t t : {8u, 6u, 5u})
+				if (t <= fast_rows_ && t <= lean_rows_ && ft * tab_bytes + 16 * area_of(t) + 1024 <= lds_limit_) { fp.rows_lean = t; break; }
+			if (ft * tab_bytes + 16 * area_of(fp.rows_lean) + 1024 > lds_limit_) fp.lean_on = 0; /* (a tight LDS budget: the full build's rows) */
 			TimedPair *ta = timing_on_ ? new_pair(3) : nullptr;
 			if (ta) (void)hipEventRecord(ta->a, stream_);
 			{
@@ -695,13 +703,16 @@ public:
 				/* build 0: closed-form phases only; 1: every kind of running-sum voice; 2: single-pass voices and closed-form ones */
 				const int main_build = !seq_ok ? 0 : look_split ? 2 : 1;
 				/* (rows per pass 2, 4, 5, 6, 8; the full build never runs at more than 4: its 5- and 6-row slots stand in with 4's) */
-				static const void *const fkernels[3][5] = {
+				static const void *const fkernels[4][5] = {
 					{(const void *)fast_kernel<2, 0>, (const void *)fast_kernel<4, 0>, (const void *)fast_kernel<5, 0>, (const void *)fast_kernel<6, 0>, (const void *)fast_kernel<8, 0>},
 					{(const void *)fast_kernel<2, 1>, (const void *)fast_kernel<4, 1>, (const void *)fast_kernel<4, 1>, (const void *)fast_kernel<4, 1>, (const void *)fast_kernel<8, 1>},
-					{(const void *)fast_kernel<2, 2>, (const void *)fast_kernel<4, 2>, (const void *)fast_kernel<5, 2>, (const void *)fast_kernel<6, 2>, (const void *)fast_kernel<8, 2>}};
-				static size_t fconfigured[16][3][5];
+					{(const void *)fast_kernel<2, 2>, (const void *)fast_kernel<4, 2>, (const void *)fast_kernel<5, 2>, (const void *)fast_kernel<6, 2>, (const void *)fast_kernel<8, 2>},
+					/* 3: voices with feedback chains and nothing to scan (4, 6 or 8 rows per pass) */
+					{(const void *)fast_kernel<4, 3>, (const void *)fast_kernel<4, 3>, (const void *)fast_kernel<5, 3>, (const void *)fast_kernel<6, 3>, (const void *)fast_kernel<8, 3>}};
+				static size_t fconfigured[16][4][5];
 				auto launch_build = [&](int build, uint32_t rows, uint32_t grid) -> bool {
 					if (build == 1 && (rows == 6 || rows == 5)) rows = 4;
+					if (build == 3 && rows < 5) rows = 4;
 					const int ri = rows == 8 ? 4 : rows == 6 ? 3 : rows == 5 ? 2 : rows == 4 ? 1 : 0;
 					const size_t lds = ft * tab_bytes + 16 * area_of(rows) + (build == 2 ? LOOK_LDS_BYTES : 0);
 					if (!raise_lds_attr(fkernels[build][ri], lds, fconfigured[dev_ & 15][build][ri], err)) return false;
@@ -721,6 +732,9 @@ public:
 				bool launched = true;
 				auto launch_fast = [&](uint32_t mode, uint32_t grid = 0) {
 					fp.mode = mode;
+					if (fp.lean_on && fp.chain_rows && (mode == fp.sum_levels + 1 || mode == fp.sum_levels + 2) &&
+					    !launch_build(3, fp.rows_lean, grid ? grid : fgrid))
+						launched = false;
 					if (main_build == 2) { /* what the single-pass build leaves out: returns at once when there is none */
 						fp.only_multi = 1;
 						if (!launch_build(1, FTM, grid ? grid : fgrid)) launched = false;
@@ -1123,7 +1137,8 @@ private:
 	DevBuf<unsigned char> fplines_;
 	uint32_t block_grid_ = 1;
 	uint32_t fk_grid_ = FK_GRID;
-	bool dyn_enabled_ = true;
+	bool dyn_enabled_ = true, lean_enabled_ = true;
+	uint32_t lean_rows_ = 8;    /* SAU_AMD_LEAN_ROWS: rows per pass of fast_kernel<T, 3> at most */
 	uint32_t dyn_groups_ = 8;   /* row groups per task of a closed-form launch (SAU_AMD_DYN_GROUPS) */
 	uint32_t look_wpv_ = 1;     /* this segment's single-pass launch: waves per voice, and whether every voice sits */
 	bool look_inside_ = true;   /* inside one workgroup (LDS rings, no waits across workgroups) */

@@ -400,7 +400,8 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 	if (!bad && vd.nops <= P.max_ops && vd.plan_len <= P.max_steps && maxd >= 1 && maxd + x_carrier <= P.np / 2)
 		fi.total = min(min_time, vd.run_len);
 	P.info[v] = fi;
-	if (fi.total && (seq_kind == 1 || seq_kind == 2)) atomicOr(&P.pass_flags[FAST_MAX_LEVELS + 2], 1u);
+	if (fi.total && seq_kind == 2 && n_scan_out == 0 && P.lean_on) atomicOr(&P.pass_flags[FAST_LEAN_FLAG], 1u);
+	else if (fi.total && (seq_kind == 1 || seq_kind == 2)) atomicOr(&P.pass_flags[FAST_MAX_LEVELS + 2], 1u);
 	P.fast_done[v] = 0;
 	P.repair[(size_t)v * FAST_REPAIR_WORDS] = 0;
 }

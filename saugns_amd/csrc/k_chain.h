@@ -131,7 +131,7 @@ __device__ __forceinline__ void chain_feed(const ChainDesc &cd, bool live, int l
 	}
 #pragma unroll
 	for (uint32_t q = 0; q < 4; ++q) {
-		uint4 b = bp[t / 4 + q];
+		uint4 b = bp[q]; /* (fetched a batch ahead: chain_fetch) */
 		if (cd.mode == CM_INC) { /* phase increments: summed here */
 			const uint32_t i = t + 4 * q;
 			b.x += a; b.y += b.x; b.z += b.y; b.w += b.z;
@@ -139,9 +139,18 @@ __device__ __forceinline__ void chain_feed(const ChainDesc &cd, bool live, int l
 			a_end = i + 3 < cd.n ? b.w : i + 2 < cd.n ? b.z : i + 1 < cd.n ? b.y : i < cd.n ? b.x : a_end;
 		}
 		*(uint4 *)(in_base + chain_io_word(q, l)) = b;
-		*(float4 *)(in_amt + chain_io_word(q, l)) = ap[t / 4 + q];
+		*(float4 *)(in_amt + chain_io_word(q, l)) = ap[q];
 	}
 	*acc = a_end;
+}
+
+/* the rows' share of batch t into registers: issued one batch before chain_feed needs it, so that the feeder
+ * never stands waiting for HBM inside the batch period (1.9 us) the chain wave gives it */
+__device__ __forceinline__ void chain_fetch(const ChainDesc &cd, bool live, uint32_t t, const uint4 *brow, const float4 *arow,
+		uint4 *bp, float4 *ap) {
+	if (!live || cd.mode == CM_INLINE) return;
+#pragma unroll
+	for (uint32_t q = 0; q < 4; ++q) { bp[q] = brow[t / 4 + q]; ap[q] = arow[t / 4 + q]; }
 }
 
 __global__ void __launch_bounds__(128) chain_kernel(FastParams P) {
@@ -201,10 +210,16 @@ __global__ void __launch_bounds__(128) chain_kernel(FastParams P) {
 	const uint32_t n_batches = (n_max + CHAIN_BATCH - 1) / CHAIN_BATCH;
 	if (feeder) {
 		uint32_t acc = c_lo ? o.st_phase : o.phase; /* CM_INC, CM_INLINE: the phase accumulator (staged by the chunk before) */
-		/* step k: feed batch k while the chain wave runs batch k - 1, store the samples of batch k - 2 */
+		/* step k: feed batch k while the chain wave runs batch k - 1, store the samples of batch k - 2; the rows of
+		 * batch k + 1 are asked for now and used in the next step */
+		uint4 fb[4]; float4 fa[4];
+#pragma unroll
+		for (int q = 0; q < 4; ++q) { fb[q] = make_uint4(0, 0, 0, 0); fa[q] = make_float4(0.f, 0.f, 0.f, 0.f); }
+		chain_fetch(cd, n_batches && c_lo < n, c_lo, bp, ap, fb, fa);
 		for (uint32_t k = 0; k <= n_batches; ++k) {
 			if (k < n_batches && c_lo + k * CHAIN_BATCH < n)
-				chain_feed(cd, true, l, c_lo + k * CHAIN_BATCH, &acc, bp, ap, in_base(k & 1), in_amt(k & 1));
+				chain_feed(cd, true, l, c_lo + k * CHAIN_BATCH, &acc, fb, fa, in_base(k & 1), in_amt(k & 1));
+			chain_fetch(cd, k + 1 < n_batches && c_lo + (k + 1) * CHAIN_BATCH < n, c_lo + (k + 1) * CHAIN_BATCH, bp, ap, fb, fa);
 			if (k >= 2 && c_lo + (k - 2) * CHAIN_BATCH < n) {
 				const float *sq = out_s(k & 1);
 #pragma unroll

@@ -49,7 +49,8 @@ constexpr uint32_t FAST_MAX_LEVELS = 3; /* running sums that depend on running s
 constexpr uint32_t FAST_REPAIR_SHIFT = 24; /* H + shift < 64 (H <= 32) */
 constexpr uint32_t FAST_MAX_REPAIR = 15;   /* noted row groups per voice and segment; more: block loop */
 constexpr uint32_t FAST_REPAIR_WORDS = 2 + 2 * FAST_MAX_REPAIR; /* count, pad, then (group, rows) pairs */
-constexpr uint32_t FAST_FLAGS = FAST_MAX_LEVELS + 4; /* pass_flags words */
+constexpr uint32_t FAST_FLAGS = FAST_MAX_LEVELS + 5; /* pass_flags words */
+constexpr uint32_t FAST_LEAN_FLAG = FAST_MAX_LEVELS + 4; /* ... some voice has feedback chains and no running sum to scan (fast_kernel<T, 3>) */
 constexpr uint32_t FAST_DYN_CTR = FAST_MAX_LEVELS + 3; /* ... the one that deals out fast_kernel<T, 0>'s tasks (dyn_chunks) */
 /* Decoded steps are kept once per pass that runs them ([list][voice][step]): a pass walks its own list and never
  * loads a step only to find that another pass needs it (the per-step cost of the interpreter is most of a pass). */
@@ -130,6 +131,11 @@ struct FastParams {
 	 * next task when they finish one, so CUs that get less done (other kernels' workgroups sharing them: the previous
 	 * segment's mixer) hold nobody up at the end. 0: static shares (waves stride over voices and groups). */
 	uint32_t dyn_chunks;
+	/* Voices with feedback chains whose other oscillators all have closed-form phases (a chain that sums its own
+	 * increments counts as such: BASELINE config 5) take no sum pass, no scan and no saved increments: their
+	 * chain-input and final passes run in a build of their own, fast_kernel<T, 3> -- fast_voice without the code of
+	 * the several-pass sums, rows_lean rows per pass. lean_on: such launches exist (the full build leaves those voices out). */
+	uint32_t rows_lean, lean_on;
 	uint32_t only_multi; /* this launch: only the voices fast_kernel<T, 2> leaves out (one wave in order, several passes) */
 	int8_t ctab_of_wave[12];
 	uint8_t cwave_of_tab[12];

@@ -52,7 +52,10 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 	/* SCAN: 0 closed-form phases only; 1 every kind of running-sum voice; 2 single-pass (look-back) voices only,
 	 * without the code of the several-pass forms and the feedback chains */
 	constexpr bool FULL = SCAN == 1;
-	const uint32_t li = FULL ? fast_list_of(P.mode, P.sum_levels) : 0u;
+	/* SCAN 3: voices with feedback chains and no running sum to scan -- the chain-input and final passes (their own
+	 * step lists, launches in chunks of frames, chains' rows) without the several-pass sums */
+	constexpr bool CH = SCAN == 1 || SCAN == 3;
+	const uint32_t li = CH ? fast_list_of(P.mode, P.sum_levels) : 0u;
 	const uint32_t n_fsteps = uni(li == 0 ? fi.n_fsteps : li == 1 ? fi.n_pass[0] : li == 2 ? fi.n_pass[1] : li == 3 ? fi.n_pass[2] : fi.n_pass[3]);
 	const size_t list_at = ((size_t)li * P.n_voices + v) * P.max_steps;
 	const FastStep *fsteps = P.fsteps + list_at;
@@ -131,16 +134,16 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 			const uint32_t flags = (f.kind >> 8) & 0xff;
 			const bool sum_pass = FULL && P.mode != 0 && P.mode <= P.sum_levels;
 			if (sum_pass && !(f.ramp & (2u << P.mode))) continue; /* not needed for this pass's phase increments */
-			const bool chain_in = FULL && P.mode == P.sum_levels + 2; /* the pass that writes the chains' inputs */
+			const bool chain_in = CH && P.mode == P.sum_levels + 2; /* the pass that writes the chains' inputs */
 			if (chain_in && !(f.ramp & FR_CHAIN_IN)) continue;
-			if (FULL && P.mode == P.sum_levels + 1 && (f.ramp & FR_FINAL_SKIP)) continue;
+			if (CH && P.mode == P.sum_levels + 1 && (f.ramp & FR_FINAL_SKIP)) continue;
 			if (kind == ST_OSC) {
 				const uint32_t type = f.type & 0xff;
 				const bool wave_env = (flags & SF_WAVE_ENV) != 0;
 				const bool layer = (flags & SF_LAYER) != 0;
 				const bool to_voice = ((f.kind >> 16) & OX_VOICE) != 0;
 				float s[T];
-				const bool chain = FULL && (f.type & FT_CHAIN) != 0;
+				const bool chain = CH && (f.type & FT_CHAIN) != 0;
 				if (type == OT_WAVE && chain && P.mode == P.sum_levels + 1) { /* (the final pass) */
 					/* a feedback chain: chain_kernel has run it; its samples are in the row */
 					const float *crow = P.chain_rows + (size_t)2 * f_bits(f.pan) * P.chain_stride;
@@ -273,7 +276,9 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 #pragma unroll
 									for (int k = 0; k < T; ++k) {
 										const int t = t0 + k * (int)C;
-										S[k] = wave_incl_scan_dpp((t >= 0 && t < (int)fast_total) ? r[k] : 0u);
+										const uint32_t inc = (t >= 0 && t < (int)fast_total) ? r[k] : 0u;
+										if (SCAN == 3 && chain && fa.pad[2]) S[k] = inc; /* chain_kernel does the summing */
+										else S[k] = wave_incl_scan_dpp(inc);
 									}
 								}
 								if (chain && fa.pad[2]) {
@@ -757,6 +762,7 @@ __global__ void FK_ATTR fast_kernel(FastParams P) {
 	if (SCAN == 1 && P.mode != 0 && P.mode <= P.sum_levels && P.pass_flags[P.mode - 1] == 0) return;
 	if (SCAN == 1 && P.mode == P.sum_levels + 2 && P.pass_flags[FAST_MAX_LEVELS + 1] == 0) return; /* no chains */
 	if (SCAN == 1 && P.only_multi && P.pass_flags[FAST_MAX_LEVELS + 2] == 0) return; /* no voice the single-pass build left out */
+	if (SCAN == 3 && P.pass_flags[FAST_LEAN_FLAG] == 0) return; /* no voice with chains and nothing to scan */
 
 	HerpC23 *t23 = (HerpC23 *)lds;
 	HerpC01 *t01 = (HerpC01 *)(lds + (size_t)P.n_tabs * WAVE_LEN * sizeof(HerpC23));
@@ -810,6 +816,13 @@ __global__ void FK_ATTR fast_kernel(FastParams P) {
 	for (; v < NV; v += vstride) {
 		const FastInfo fi = P.info[v];
 		const uint32_t seq_kind = SCAN ? uni(fi.seq) : 0u;
+		const bool lean_voice = SCAN && P.lean_on && seq_kind == 2 && uni(fi.n_scan) == 0; /* the build of its own takes it */
+		if (SCAN == 3) {
+			if (P.mode == P.sum_levels + 2 && uni(fi.n_chain) == 0) continue; /* (its chains are fed by chain_kernel itself) */
+			if (lean_voice) fast_voice<T, 3>(P, v, fi, slots, carry, t23, t01, l, wpv, cstart);
+			continue;
+		}
+		if (SCAN == 1 && lean_voice) continue;
 		if (SCAN == 1 && P.mode != 0 && P.mode <= P.sum_levels && (seq_kind != 2 || uni(fi.levels) < P.mode))
 			continue; /* a sum pass only concerns multi-pass voices that deep */
 		if (SCAN == 1 && P.mode == P.sum_levels + 2 && (seq_kind != 2 || uni(fi.n_chain) == 0))
