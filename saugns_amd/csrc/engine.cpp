@@ -22,6 +22,20 @@ static uint64_t ms_to_samples(uint64_t ms, uint64_t srate, int *carry) {
 
 Engine::~Engine() { delete backend_; }
 
+size_t chain_rows_budget() {
+	static const size_t b = [] {
+		const char *v = getenv("SAU_AMD_CHAIN_ROWS_MB");
+		return ((size_t)(v ? atoll(v) : 24 * 1024)) << 20;
+	}();
+	return b;
+}
+uint32_t chain_seg_frames(size_t n_chains) {
+	if (!n_chains) return CHAIN_SEG;
+	const size_t f = chain_rows_budget() / (n_chains * 8);
+	if (f <= CHAIN_SEG) return CHAIN_SEG;
+	return f > (1u << 22) ? (1u << 22) : (uint32_t)f & ~63u;
+}
+
 /* generator.c:135-217 */
 Engine *Engine::create(const sauProgram *const *prgs, size_t n_prgs, uint32_t srate,
 		Backend *backend, std::string &err) {
@@ -463,12 +477,12 @@ bool Engine::run(int16_t *const *host_bufs, size_t buf_len, bool stereo,
 		constexpr uint32_t EXPIRY_GRID = 8192;
 		if (seg > EXPIRY_GRID) {
 			uint32_t first = seg;
-			bool chains = false;
+			size_t chains = 0;
 			for (Stream &st : streams_)
 				for (uint32_t v = st.voice; v < st.voices.size(); ++v) {
 					const VoiceHost &vn = st.voices[v];
 					if (vn.duration == 0 || vn.carr_op >= st.ops.size()) continue;
-					if (vn.plan.n_chain) chains = true;
+					chains += vn.plan.n_chain;
 					/* (voices that merely have running-sum phases need no cap: they take one pass with look-back, whose
 					 * state is per row group; where they take several passes instead, the backend saves increments only
 					 * for segments within CHAIN_SEG and recomputes them beyond) */
@@ -481,7 +495,7 @@ bool Engine::run(int16_t *const *host_bufs, size_t buf_len, bool stereo,
 				const uint32_t cut = (first + EXPIRY_GRID - 1) / EXPIRY_GRID * EXPIRY_GRID;
 				if (cut < seg) seg = cut;
 			}
-			if (chains && seg > CHAIN_SEG) seg = CHAIN_SEG; /* rows in HBM carry one segment of every recurrence */
+			if (chains && seg > chain_seg_frames(chains)) seg = chain_seg_frames(chains); /* rows in HBM carry one segment of every recurrence */
 		}
 		for (Stream &st : streams_)
 			if (st.event < st.events.size()) st.event_pos += seg;

@@ -144,6 +144,11 @@ bool compile_voice_plan(const std::vector<OpMirror> &ops, uint32_t carrier,
 /* Segments with feedback voices are at most this long: the recurrences' inputs and outputs pass
  * through per-chain rows in HBM, sized for one segment. */
 constexpr uint32_t CHAIN_SEG = 131072;
+/* ... at least; longer where the rows of the segment's chains (8 B per chain and frame) stay within the budget below:
+ * 288 GB of HBM hold BASELINE config 5's 4096 chains x 441000 frames (14.4 GB) as one segment, and a segment is one
+ * fill and one drain of the pass / chain pipeline. SAU_AMD_CHAIN_ROWS_MB sets another budget. */
+size_t chain_rows_budget();
+uint32_t chain_seg_frames(size_t n_chains);
 
 class Engine {
 public:

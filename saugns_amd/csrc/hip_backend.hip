@@ -99,9 +99,9 @@ public:
 		(void)hipGetDevice(&dev);
 		std::lock_guard<std::mutex> lk(mu_);
 		size_t &held = pinned ? held_pin_ : held_dev_;
-		/* what the pool may keep between generators: 16 GiB of the 288 GB of HBM, 1 GiB page-locked;
+		/* what the pool may keep between generators: 64 GiB of the 288 GB of HBM, 1 GiB page-locked;
 		 * SAU_AMD_POOL_MB / SAU_AMD_PINNED_POOL_MB set other caps (0: keep nothing) */
-		static const size_t cap_dev = env_mb("SAU_AMD_POOL_MB", (size_t)16 << 10);
+		static const size_t cap_dev = env_mb("SAU_AMD_POOL_MB", (size_t)64 << 10);
 		static const size_t cap_pin = env_mb("SAU_AMD_PINNED_POOL_MB", (size_t)1 << 10);
 		if (held + bytes > (pinned ? cap_pin : cap_dev)) return false;
 		(pinned ? pin_ : dev_[dev & 15]).emplace(bytes, q);
@@ -336,10 +336,11 @@ public:
 		lookback_enabled_ = getenv("SAU_AMD_NO_LOOKBACK") == nullptr; /* single-pass running sums */
 		if (const char *lr = getenv("SAU_AMD_LOOK_ROWS")) look_rows_ = (uint32_t)atoi(lr);
 		if (const char *lm = getenv("SAU_AMD_LOOK_MIN_VOICES")) look_min_voices_ = (uint32_t)atoi(lm);
-		if (const char *cc = getenv("SAU_AMD_CHAIN_CHUNKS")) { /* pipeline depth of a segment with chains (1: off) */
+		if (const char *cc = getenv("SAU_AMD_CHAIN_CHUNKS")) { /* pipeline depth of a segment with chains (1: off; default: by frames) */
 			const int n = atoi(cc);
-			chain_chunks_ = n >= 16 ? 16 : n >= 8 ? 8 : n >= 4 ? 4 : n >= 2 ? 2 : 1;
+			chain_chunks_ = n >= 32 ? 32 : n >= 1 ? (uint32_t)n : 1;
 		}
+		if (const char *cf = getenv("SAU_AMD_CHAIN_CHUNK_FRAMES")) { const int n = atoi(cf); if (n >= 4096) chain_chunk_frames_ = (uint32_t)n; }
 		two_pass_enabled_ = getenv("SAU_AMD_NO_TWO_PASS") == nullptr; /* ... in two passes where possible */
 		if (const char *lr = getenv("SAU_AMD_LEAN_ROWS")) lean_rows_ = (uint32_t)atoi(lr);
 		lean_enabled_ = getenv("SAU_AMD_NO_LEAN") == nullptr; /* chains' passes in a build without the several-pass sums */
@@ -649,7 +650,7 @@ public:
 			/* feedback chains: a pair of rows per chain in HBM, one segment long (the engine keeps segments
 			 * with such voices within CHAIN_SEG frames); without them those voices take the block loop */
 			const bool chains = chain_enabled_ && use_fast && fp.scan && seg.serial && seg.n_chain_rows &&
-				seg.len <= sauengine::CHAIN_SEG;
+				seg.len <= sauengine::chain_seg_frames(seg.n_chain_rows);
 			if (chains) {
 				const uint32_t cstride = (seg.len + 63) & ~63u;
 				if (!chain_rows_.ensure((size_t)seg.n_chain_rows * 2 * cstride + 64, err) ||
@@ -780,8 +781,11 @@ public:
 						static size_t cconfigured[16];
 						if (!raise_lds_attr((const void *)chain_kernel, clds, cconfigured[dev_ & 15], err)) return false;
 						const uint32_t cgrid = (seg.n_chain_rows + 63) / 64;
-						uint32_t n_chunks = chain_chunks_;
-						while (n_chunks > 1 && seg.len / n_chunks < 4096) n_chunks /= 2;
+						/* chunks of about chain_chunk_frames_ frames (what the first chunk's inputs and the last chunk's final
+						 * pass take is not overlapped with the chains), 32 at most */
+						uint32_t n_chunks = chain_chunks_ ? chain_chunks_ : (seg.len + chain_chunk_frames_ - 1) / chain_chunk_frames_;
+						if (n_chunks > 32) n_chunks = 32;
+						while (n_chunks > 1 && seg.len / n_chunks < 4096) --n_chunks;
 						if (!chain_stream_ && n_chunks > 1) {
 							chain_stream_ = StreamPool::get().take(dev_);
 							if (!chain_stream_) HIP_OK(hipStreamCreateWithFlags(&chain_stream_, hipStreamNonBlocking));
@@ -1122,7 +1126,8 @@ private:
 	uint32_t multi_min_ = 256;
 	uint32_t fast_rows_ = 8;
 	bool seq_enabled_ = true, two_pass_enabled_ = true, chain_enabled_ = true, chain_inline_ = false;
-	uint32_t chain_chunks_ = 8;
+	uint32_t chain_chunks_ = 0;           /* SAU_AMD_CHAIN_CHUNKS: a fixed number of chunks per segment (0: by frames) */
+	uint32_t chain_chunk_frames_ = 16384; /* SAU_AMD_CHAIN_CHUNK_FRAMES */
 	bool inc_rows_enabled_ = true;
 	bool lookback_enabled_ = true;
 	uint32_t look_min_voices_ = 1; /* SAU_AMD_LOOK_MIN_VOICES: segments with fewer voices keep the several-pass form */

@@ -15,7 +15,13 @@
  * all; and it stores the previous batch of samples to the chain's first row, where the final pass takes them
  * (amplitude, mixing into the parent, voice output). One barrier per batch. 4096 chains are 64 workgroups on
  * 64 CUs, and the render takes frames x chain latency. */
-constexpr uint32_t CHAIN_BATCH = 16;               /* frames per lane and batch */
+#ifndef SAU_CHAIN_BATCH_FRAMES
+#define SAU_CHAIN_BATCH_FRAMES 32
+#endif
+/* frames per lane and batch: what a batch costs beside the recurrence itself (its LDS reads and writes, the bound check
+ * of the short rounding form, the barrier) is spread over that many sample steps -- 16: 117 ns per step, 32: see DESIGN.md 4.3 */
+constexpr uint32_t CHAIN_BATCH = SAU_CHAIN_BATCH_FRAMES;
+constexpr uint32_t CHAIN_NQ = CHAIN_BATCH / 4;     /* 16-byte quads of a batch */
 constexpr uint32_t CHAIN_IO_WORDS = CHAIN_BATCH * 64; /* one array of one batch */
 constexpr size_t CHAIN_IO_BYTES = (size_t)(2 * 2 + 2) * CHAIN_IO_WORDS * 4; /* in[2][2] + out[2] */
 
@@ -36,7 +42,7 @@ __device__ __forceinline__ void chain_batch(const uint4 *bq, const float4 *aq, f
 	typedef const f64x2 __attribute__((address_space(3))) *lds_f64x2;
 	typedef const f32x2 __attribute__((address_space(3))) *lds_f32x2;
 #pragma unroll
-	for (int u = 0; u < 4; ++u) {
+	for (int u = 0; u < (int)CHAIN_NQ; ++u) {
 		const uint32_t b4[4] = {bq[u].x, bq[u].y, bq[u].z, bq[u].w};
 		const float a4[4] = {aq[u].x, aq[u].y, aq[u].z, aq[u].w};
 		float s4[4];
@@ -122,7 +128,7 @@ __device__ __forceinline__ void chain_feed(const ChainDesc &cd, bool live, int l
 			b[j] = a;
 		}
 #pragma unroll
-		for (uint32_t q = 0; q < 4; ++q) {
+		for (uint32_t q = 0; q < CHAIN_NQ; ++q) {
 			*(uint4 *)(in_base + chain_io_word(q, l)) = make_uint4(b[4 * q], b[4 * q + 1], b[4 * q + 2], b[4 * q + 3]);
 			*(float4 *)(in_amt + chain_io_word(q, l)) = make_float4(m[4 * q], m[4 * q + 1], m[4 * q + 2], m[4 * q + 3]);
 		}
@@ -130,7 +136,7 @@ __device__ __forceinline__ void chain_feed(const ChainDesc &cd, bool live, int l
 		return;
 	}
 #pragma unroll
-	for (uint32_t q = 0; q < 4; ++q) {
+	for (uint32_t q = 0; q < CHAIN_NQ; ++q) {
 		uint4 b = bp[q]; /* (fetched a batch ahead: chain_fetch) */
 		if (cd.mode == CM_INC) { /* phase increments: summed here */
 			const uint32_t i = t + 4 * q;
@@ -150,7 +156,7 @@ __device__ __forceinline__ void chain_fetch(const ChainDesc &cd, bool live, uint
 		uint4 *bp, float4 *ap) {
 	if (!live || cd.mode == CM_INLINE) return;
 #pragma unroll
-	for (uint32_t q = 0; q < 4; ++q) { bp[q] = brow[t / 4 + q]; ap[q] = arow[t / 4 + q]; }
+	for (uint32_t q = 0; q < CHAIN_NQ; ++q) { bp[q] = brow[t / 4 + q]; ap[q] = arow[t / 4 + q]; }
 }
 
 __global__ void __launch_bounds__(128) chain_kernel(FastParams P) {
@@ -212,9 +218,9 @@ __global__ void __launch_bounds__(128) chain_kernel(FastParams P) {
 		uint32_t acc = c_lo ? o.st_phase : o.phase; /* CM_INC, CM_INLINE: the phase accumulator (staged by the chunk before) */
 		/* step k: feed batch k while the chain wave runs batch k - 1, store the samples of batch k - 2; the rows of
 		 * batch k + 1 are asked for now and used in the next step */
-		uint4 fb[4]; float4 fa[4];
+		uint4 fb[CHAIN_NQ]; float4 fa[CHAIN_NQ];
 #pragma unroll
-		for (int q = 0; q < 4; ++q) { fb[q] = make_uint4(0, 0, 0, 0); fa[q] = make_float4(0.f, 0.f, 0.f, 0.f); }
+		for (int q = 0; q < (int)CHAIN_NQ; ++q) { fb[q] = make_uint4(0, 0, 0, 0); fa[q] = make_float4(0.f, 0.f, 0.f, 0.f); }
 		chain_fetch(cd, n_batches && c_lo < n, c_lo, bp, ap, fb, fa);
 		for (uint32_t k = 0; k <= n_batches; ++k) {
 			if (k < n_batches && c_lo + k * CHAIN_BATCH < n)
@@ -223,14 +229,14 @@ __global__ void __launch_bounds__(128) chain_kernel(FastParams P) {
 			if (k >= 2 && c_lo + (k - 2) * CHAIN_BATCH < n) {
 				const float *sq = out_s(k & 1);
 #pragma unroll
-				for (uint32_t q = 0; q < 4; ++q) op[(c_lo + (k - 2) * CHAIN_BATCH) / 4 + q] = *(const float4 *)(sq + chain_io_word(q, l));
+				for (uint32_t q = 0; q < CHAIN_NQ; ++q) op[(c_lo + (k - 2) * CHAIN_BATCH) / 4 + q] = *(const float4 *)(sq + chain_io_word(q, l));
 			}
 			__syncthreads(); /* (the first one also: tables staged) */
 		}
 		if (n_batches && c_lo + (n_batches - 1) * CHAIN_BATCH < n) {
 			const float *sq = out_s((n_batches - 1) & 1);
 #pragma unroll
-			for (uint32_t q = 0; q < 4; ++q) op[(c_lo + (n_batches - 1) * CHAIN_BATCH) / 4 + q] = *(const float4 *)(sq + chain_io_word(q, l));
+			for (uint32_t q = 0; q < CHAIN_NQ; ++q) op[(c_lo + (n_batches - 1) * CHAIN_BATCH) / 4 + q] = *(const float4 *)(sq + chain_io_word(q, l));
 		}
 		if (n && cd.mode != CM_BASE && !(cd.mode == CM_INLINE && (cd.lflags & CL_FCONST))) o.st_phase = acc;
 		return;
@@ -252,15 +258,15 @@ __global__ void __launch_bounds__(128) chain_kernel(FastParams P) {
 	}
 	for (uint32_t k = 0; k < n_batches; ++k) {
 		const uint32_t t = c_lo + k * CHAIN_BATCH;
-		uint4 bq[4]; float4 aq[4]; float4 sq[4];
+		uint4 bq[CHAIN_NQ]; float4 aq[CHAIN_NQ]; float4 sq[CHAIN_NQ];
 		const uint32_t *ib = in_base(k & 1);
 		const float *ia = in_amt(k & 1);
 #pragma unroll
-		for (uint32_t q = 0; q < 4; ++q) { bq[q] = *(const uint4 *)(ib + chain_io_word(q, l)); aq[q] = *(const float4 *)(ia + chain_io_word(q, l)); }
+		for (uint32_t q = 0; q < CHAIN_NQ; ++q) { bq[q] = *(const uint4 *)(ib + chain_io_word(q, l)); aq[q] = *(const float4 *)(ia + chain_io_word(q, l)); }
 		/* the short rounding form needs |fb_s * amount| < 2^20: amounts below 2^14 and |fb_s| <= 64 (checked after) */
 		float a_max = 0.f;
 #pragma unroll
-		for (int u = 0; u < 4; ++u)
+		for (int u = 0; u < (int)CHAIN_NQ; ++u)
 			a_max = fmaxf(fmaxf(a_max, fmaxf(fabsf(aq[u].x), fabsf(aq[u].y))), fmaxf(fabsf(aq[u].z), fabsf(aq[u].w)));
 		const uint32_t s_prev_phase = prev_phase; const double s_prev_Is = prev_Is;
 		const float s_prev_s = prev_s, s_fb_s = fb_s;
@@ -283,7 +289,7 @@ __global__ void __launch_bounds__(128) chain_kernel(FastParams P) {
 #undef SAU_CHAIN_BATCH
 		float *os = out_s(k & 1);
 #pragma unroll
-		for (uint32_t q = 0; q < 4; ++q) *(float4 *)(os + chain_io_word(q, l)) = sq[q];
+		for (uint32_t q = 0; q < CHAIN_NQ; ++q) *(float4 *)(os + chain_io_word(q, l)) = sq[q];
 		__syncthreads();
 	}
 	if (n) { /* staged: finalize_kernel makes it the operator's state unless the voice's segment is redone */
