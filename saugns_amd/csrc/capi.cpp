@@ -131,6 +131,7 @@ static bool generator_issue(sauGenerator *o, size_t big, size_t call_len, bool s
 	size_t frames = big;
 	if (o->ramp && o->runs_issued < 24 && call_len && (call_len << o->runs_issued) < big) frames = call_len << o->runs_issued;
 	++o->runs_issued;
+	if (o->runs_issued == 1 && !o->batch.engine->reserve(big, stereo, err)) return false; /* (device buffers too) */
 	if (o->slot_cap[k] < big * ch) { /* (sized for the longest run at once: growing later would wait for the stream) */
 		be->free_host(o->slot[k]);
 		o->slot_cap[k] = 0;

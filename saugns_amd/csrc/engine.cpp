@@ -66,6 +66,8 @@ Engine *Engine::create(const sauProgram *const *prgs, size_t n_prgs, uint32_t sr
 	}
 	e->total_ops_ = op_base;
 	e->total_voices_ = vo_base;
+	e->plan_cache_ = getenv("SAU_AMD_NO_PLAN_CACHE") == nullptr;
+	e->plan_check_ = getenv("SAU_AMD_PLAN_CHECK") != nullptr; /* tests: every cached plan against a fresh compile */
 	e->plan_refs_.resize(vo_base);
 	BackendConfig cfg;
 	cfg.srate = srate;
@@ -196,6 +198,7 @@ bool Engine::handle_event(Stream &st, const EventNode &e, std::vector<OpUpdate> 
 }
 
 bool Engine::rebuild_plans(std::string &err) {
+	++rebuilds_;
 	all_steps_.clear();
 	all_fast_ids_.clear();
 	all_fast_ids_full_.clear();
@@ -207,27 +210,81 @@ bool Engine::rebuild_plans(std::string &err) {
 			ref = PlanRef{0, 0, 0, 0};
 			if (!vn.init) continue;
 			if (!vn.plan_valid) {
-				if (!compile_voice_plan(st.ops, vn.carr_op, vn.plan, err)) {
+				vn.shape = -1;
+				uint64_t wmask = 0;
+				if (plan_cache_ && ++shape_mark_ != 0 &&
+				    voice_plan_shape(st.ops, vn.carr_op, shape_tokens_, shape_ids_, shape_stamp_, shape_mark_, wmask)) {
+					uint64_t h = 1469598103934665603ull;
+					for (uint32_t t : shape_tokens_) { h ^= t; h *= 1099511628211ull; }
+					auto range = shape_by_hash_.equal_range(h);
+					for (auto it = range.first; it != range.second; ++it)
+						if (shapes_[it->second].tokens == shape_tokens_) { vn.shape = (int32_t)it->second; break; }
+					if (vn.shape < 0) {
+						Shape sh;
+						sh.tokens = shape_tokens_;
+						if (compile_voice_plan(st.ops, vn.carr_op, sh.plan, err) && sh.plan.op_ids == shape_ids_) {
+							vn.shape = (int32_t)shapes_.size();
+							shape_by_hash_.emplace(h, (uint32_t)shapes_.size());
+							shapes_.push_back(std::move(sh));
+						} else {
+							err.clear(); /* (compiled again, and reported, below) */
+						}
+					}
+				}
+				if (vn.shape >= 0) {
+					/* everything but the operator ids and the wave tables in use is the shape's */
+					const VoicePlan &sp = shapes_[vn.shape].plan;
+					if (plan_check_) {
+						VoicePlan chk;
+						std::string e2;
+						const bool ok = compile_voice_plan(st.ops, vn.carr_op, chk, e2);
+						if (!ok || chk.op_ids != shape_ids_ || chk.steps.size() != sp.steps.size() ||
+						    memcmp(chk.steps.data(), sp.steps.data(), sp.steps.size() * sizeof(Step)) != 0 ||
+						    chk.wave_mask != wmask || chk.n_fast != sp.n_fast || chk.n_fast_full != sp.n_fast_full ||
+						    chk.n_slots != sp.n_slots || chk.n_main != sp.n_main || chk.no_fast != sp.no_fast ||
+						    chk.static_block != sp.static_block || chk.selfmod != sp.selfmod || chk.n_chain != sp.n_chain ||
+						    chk.n_osc != sp.n_osc || chk.has_camods != sp.has_camods || chk.carr_local != sp.carr_local) {
+							err = "plan cache: a cached plan differs from a fresh compile (SAU_AMD_PLAN_CHECK)";
+							return false;
+						}
+					}
+					vn.plan.steps.clear(); vn.plan.fast_ids.clear(); vn.plan.fast_ids_full.clear(); /* (the shape's are used) */
+					vn.plan.op_ids = shape_ids_;
+					vn.plan.carr_local = sp.carr_local; vn.plan.n_slots = sp.n_slots; vn.plan.n_main = sp.n_main;
+					vn.plan.n_fast = sp.n_fast; vn.plan.n_fast_full = sp.n_fast_full; vn.plan.wave_mask = wmask;
+					vn.plan.has_camods = sp.has_camods; vn.plan.no_fast = sp.no_fast; vn.plan.static_block = sp.static_block;
+					vn.plan.selfmod = sp.selfmod; vn.plan.n_chain = sp.n_chain; vn.plan.n_osc = sp.n_osc;
+					vn.plan.n_steps = (uint32_t)sp.steps.size();
+				} else if (!compile_voice_plan(st.ops, vn.carr_op, vn.plan, err)) {
 					/* a voice whose carrier never got data stays silent */
 					vn.plan.steps.clear();
 					vn.plan.fast_ids.clear();
 					vn.plan.fast_ids_full.clear();
 					vn.plan.op_ids.clear();
+					vn.plan.n_steps = 0;
 					if (err != "voice carrier operator was never initialised")
 						return false;
 					err.clear();
+				} else {
+					vn.plan.n_steps = (uint32_t)vn.plan.steps.size();
 				}
 				vn.plan_valid = true;
 			}
-			ref.plan_ofs = (uint32_t)all_steps_.size();
-			ref.plan_len = (uint32_t)vn.plan.steps.size();
+			const VoicePlan &steps_of = vn.shape >= 0 ? shapes_[vn.shape].plan : vn.plan;
 			ref.ops_ofs = (uint32_t)all_op_ids_.size();
 			ref.nops = (uint32_t)vn.plan.op_ids.size();
-			all_steps_.insert(all_steps_.end(), vn.plan.steps.begin(), vn.plan.steps.end());
-			all_fast_ids_.insert(all_fast_ids_.end(), vn.plan.fast_ids.begin(), vn.plan.fast_ids.end());
-			all_fast_ids_.resize(all_steps_.size());
-			all_fast_ids_full_.insert(all_fast_ids_full_.end(), vn.plan.fast_ids_full.begin(), vn.plan.fast_ids_full.end());
-			all_fast_ids_full_.resize(all_steps_.size());
+			ref.plan_len = (uint32_t)steps_of.steps.size();
+			if (vn.shape >= 0 && shapes_[vn.shape].placed == rebuilds_) {
+				ref.plan_ofs = shapes_[vn.shape].plan_ofs; /* the shape's steps are in this upload already */
+			} else {
+				ref.plan_ofs = (uint32_t)all_steps_.size();
+				if (vn.shape >= 0) { shapes_[vn.shape].plan_ofs = ref.plan_ofs; shapes_[vn.shape].placed = rebuilds_; }
+				all_steps_.insert(all_steps_.end(), steps_of.steps.begin(), steps_of.steps.end());
+				all_fast_ids_.insert(all_fast_ids_.end(), steps_of.fast_ids.begin(), steps_of.fast_ids.end());
+				all_fast_ids_.resize(all_steps_.size());
+				all_fast_ids_full_.insert(all_fast_ids_full_.end(), steps_of.fast_ids_full.begin(), steps_of.fast_ids_full.end());
+				all_fast_ids_full_.resize(all_steps_.size());
+			}
 			for (uint32_t id : vn.plan.op_ids)
 				all_op_ids_.push_back(st.op_base + id);
 		}
@@ -326,7 +383,7 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 			uint32_t out_len = 0;
 			if (carr.time > 0) /* generator.c:839; implicit-time carriers have time 0 */
 				out_len = carr.time_inf ? run_len : std::min(run_len, carr.time);
-			if (out_len == 0 || vn.plan.steps.empty()) continue;
+			if (out_len == 0 || vn.plan.n_steps == 0) continue;
 			if (!carr.time_inf) carr.time -= out_len;
 			const PlanRef &ref = plan_refs_[st.vo_base + v];
 			VoiceDesc d;
@@ -352,7 +409,7 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 			if (!vn.plan.no_fast) n_fast = std::max(n_fast, vn.plan.n_fast);
 			n_fpool = std::max(n_fpool, vn.plan.n_slots - vn.plan.n_main);
 			max_ops = std::max(max_ops, (uint32_t)vn.plan.op_ids.size());
-			max_steps = std::max(max_steps, (uint32_t)vn.plan.steps.size());
+			max_steps = std::max(max_steps, vn.plan.n_steps);
 			wave_mask |= vn.plan.wave_mask;
 			/* will the time-parallel path surely cover this voice's whole run? */
 			bool voice_block = vn.plan.static_block; /* this voice may leave the closed-form path */
@@ -404,6 +461,17 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 	seg.n_inc_rows = n_inc_rows;
 	seg.n_look_rows = n_look_rows;
 	return backend_->render(seg, err);
+}
+
+bool Engine::reserve(size_t frames, bool stereo, std::string &err) {
+	if (frames > UINT32_MAX) { err = "buffer too long"; return false; }
+	if ((uint32_t)frames > reserved_frames_ || (stereo && !reserved_stereo_)) {
+		const uint32_t want = std::max((uint32_t)frames, reserved_frames_);
+		if (!backend_->reserve_frames(want, stereo || reserved_stereo_, err)) return false;
+		reserved_frames_ = want;
+		reserved_stereo_ = stereo || reserved_stereo_;
+	}
+	return true;
 }
 
 /* generator.c:905-973, for all streams in lock step. */

@@ -18,6 +18,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 namespace sauengine {
@@ -116,7 +117,8 @@ struct OpMirror { /* host-side knowledge about one operator */
 };
 
 struct VoicePlan {
-	std::vector<Step> steps;
+	std::vector<Step> steps;       /* (empty in a voice that uses its shape's: Engine::shapes_) */
+	uint32_t n_steps = 0;          /* length of the step list the voice runs */
 	std::vector<uint32_t> op_ids;  /* voice-local index -> stream-local op id */
 	uint32_t carr_local = 0;
 	uint32_t n_slots = 0;          /* memory slots: main pool + frequency pool */
@@ -138,6 +140,9 @@ struct VoicePlan {
  * the graph exceeds what a workgroup can hold. */
 bool compile_voice_plan(const std::vector<OpMirror> &ops, uint32_t carrier,
 		VoicePlan &out, std::string &err);
+/* the graph's shape as a token stream + its operators in plan order (plan.cpp); false: not cacheable */
+bool voice_plan_shape(const std::vector<OpMirror> &ops, uint32_t carrier, std::vector<uint32_t> &tokens,
+		std::vector<uint32_t> &op_ids, std::vector<uint32_t> &stamp, uint32_t mark, uint64_t &wave_mask);
 
 /* ---- engine ---------------------------------------------------------------- */
 
@@ -162,6 +167,10 @@ public:
 	bool run(int16_t *const *host_bufs, size_t buf_len, bool stereo,
 			bool *more, size_t *out_len, std::string &err);
 
+	/* Size the device buffers for runs of up to `frames` frames now (run() grows them on demand, which waits for the
+	 * stream: a host that knows its longest run says so once). */
+	bool reserve(size_t frames, bool stereo, std::string &err);
+
 	/* The size of the sauGenerator_run calls whose block lattice the engine reproduces (see
 	 * Lattice in sau_dev_math.h): the reference starts a new <= 1024-frame block at every call
 	 * (generator.c:854-878). 0 (default): every run() is one such call; otherwise a run() covers
@@ -182,7 +191,16 @@ private:
 		uint32_t carr_op = 0;
 		VoicePlan plan;
 		bool plan_valid = false;
+		int32_t shape = -1;  /* its entry of shapes_ (voices of one shape share one step list on the device), or -1 */
 	};
+	/* compiled plans by graph shape (voice_plan_shape) */
+	struct Shape { std::vector<uint32_t> tokens; VoicePlan plan; uint32_t plan_ofs = 0; uint64_t placed = 0; };
+	std::vector<Shape> shapes_;
+	std::unordered_multimap<uint64_t, uint32_t> shape_by_hash_;
+	std::vector<uint32_t> shape_tokens_, shape_ids_, shape_stamp_;
+	uint32_t shape_mark_ = 0;
+	uint64_t rebuilds_ = 0;
+	bool plan_cache_ = true, plan_check_ = false;
 	struct Stream {
 		const sauProgram *prg = nullptr;
 		std::vector<EventNode> events;

@@ -202,6 +202,67 @@ struct Compiler {
 
 } /* namespace */
 
+/* The shape of a voice's operator graph as compile_voice_plan sees it: one token stream over the same walk
+ * (local_of() order, the modulator lists in the order eval() visits them) holding everything the step list depends
+ * on -- operator types, which lists have members, the pm_a line, red noise, pan modulators, a pan ramp pending.
+ * Voices with equal streams get equal step lists; only their operator ids (and wave tables in use) differ. Banks
+ * of thousands of like voices (BASELINE configs 2, 3, 5) then compile one plan, not thousands.
+ * False: not cacheable (an operator met twice, a cycle, a member that never got data, very deep nesting) --
+ * compile_voice_plan decides those. */
+namespace {
+struct ShapeWalk {
+	const std::vector<OpMirror> &ops;
+	std::vector<uint32_t> &tokens, &op_ids;
+	std::vector<uint32_t> &stamp; /* per operator: the voice counter when it was last seen */
+	uint32_t mark;
+	uint64_t wave_mask = 0;
+	uint32_t depth = 0;
+	bool ok = true;
+	static uint32_t count(const sauProgramIDArr *a) { return a ? a->count : 0; }
+	void list(const sauProgramIDArr *ids) { for (uint32_t i = 0; ok && i < count(ids); ++i) walk(ids->ids[i]); }
+	void walk(uint32_t op) {
+		if (op >= ops.size() || !ops[op].inited || stamp[op] == mark || depth >= 64) { ok = false; return; }
+		stamp[op] = mark;
+		op_ids.push_back(op);
+		const OpMirror &m = ops[op];
+		const bool is_osc = m.type == SAU_POPT_N_wave || m.type == SAU_POPT_N_raseg;
+		uint32_t t = m.type | ((m.line_set & (1u << L_PMA)) ? 0x100u : 0u) |
+			((m.type == SAU_POPT_N_noise && m.wave == SAU_NOISE_N_re) ? 0x200u : 0u);
+		for (int use = 1; use < SAU_POP_NAMED; ++use) if (count(m.mods[use])) t |= 0x1000u << use;
+		tokens.push_back(t);
+		for (int use = 1; use < SAU_POP_NAMED; ++use) if (count(m.mods[use])) tokens.push_back(count(m.mods[use]));
+		if (m.type == SAU_POPT_N_wave) wave_mask |= 1ull << (m.wave & 63);
+		++depth;
+		if (is_osc) {
+			list(m.mods[SAU_POP_N_rfmod]); list(m.mods[SAU_POP_N_fmod]);
+			list(m.mods[SAU_POP_N_pmod]); list(m.mods[SAU_POP_N_fpmod]);
+			list(m.mods[SAU_POP_N_ramod]); list(m.mods[SAU_POP_N_amod]);
+			list(m.mods[SAU_POP_N_apmod]);
+		} else {
+			list(m.mods[SAU_POP_N_ramod]); list(m.mods[SAU_POP_N_amod]);
+		}
+		--depth;
+	}
+};
+} /* namespace */
+
+bool voice_plan_shape(const std::vector<OpMirror> &ops, uint32_t carrier, std::vector<uint32_t> &tokens,
+		std::vector<uint32_t> &op_ids, std::vector<uint32_t> &stamp, uint32_t mark, uint64_t &wave_mask) {
+	tokens.clear();
+	op_ids.clear();
+	if (carrier >= ops.size() || !ops[carrier].inited) return false;
+	if (stamp.size() < ops.size()) stamp.resize(ops.size(), 0);
+	ShapeWalk w{ops, tokens, op_ids, stamp, mark};
+	const OpMirror &cm = ops[carrier];
+	tokens.push_back((cm.pan.flags & LP_GOAL) ? 1u : 0u);
+	w.walk(carrier);
+	/* (the carrier's camods come after everything else: compile_voice_plan) -- they are in its token (use bits and
+	 * counts); their members: */
+	if (w.ok) w.list(cm.mods[SAU_POP_N_camod]);
+	wave_mask = w.wave_mask;
+	return w.ok;
+}
+
 bool compile_voice_plan(const std::vector<OpMirror> &ops, uint32_t carrier,
 		VoicePlan &out, std::string &err) {
 	out.steps.clear();

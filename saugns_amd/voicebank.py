@@ -281,6 +281,10 @@ def config2(n=256, seconds=10):
 def config3(n=1024, seconds=10, first=0):
     """n voices, each carrier + 3-deep PM chain (the headline workload); `first` shifts the
     voice indices (voices first .. first+n-1 of a larger bank)."""
+    return build_program(config3_voices(n, seconds, first))
+
+
+def config3_voices(n=1024, seconds=10, first=0):
     voices = []
     for i in range(first, first + n):
         m3 = Op("sin", freq=Line(float(3 + i % 4), ratio=True), amp=_f32(0.4))
@@ -290,11 +294,15 @@ def config3(n=1024, seconds=10, first=0):
                 amp=_num(".2f", 0.5 + (i % 7) * 0.1), mods={POP_PMOD: [m2]})
         voices.append(Op("sin", freq=_num(".4f", 110.0 + i * 0.731), time_ms=seconds * 1000,
                          mods={POP_PMOD: [m1]}))
-    return build_program(voices)
+    return voices
 
 
 def config5(n=4096, seconds=10):
     """n voices: self-feedback FM carrier with ramps + range-AM modulator."""
+    return build_program(config5_voices(n, seconds))
+
+
+def config5_voices(n=4096, seconds=10):
     voices = []
     for i in range(n):
         lfo = Op("sin", freq=float(3 + i % 9), amp=1.0)
@@ -306,7 +314,7 @@ def config5(n=4096, seconds=10):
                   amp2=Line(_f32(0.2)),
                   time_ms=seconds * 1000, mods={POP_RAMOD: [lfo]})
         voices.append(carr)
-    return build_program(voices)
+    return voices
 
 
 def config_scripts():

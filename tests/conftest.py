@@ -10,6 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# every plan the engine takes from its cache of graph shapes is compared with a fresh compile (engine.cpp)
+os.environ.setdefault("SAU_AMD_PLAN_CHECK", "1")
 
 
 def pytest_configure(config):

@@ -202,3 +202,23 @@ def test_config4_at_its_stated_size(gpu, index):
     bad = [a + i for i, pcm in enumerate(outs)
            if len(pcm) != int(fx["frames"][a + i]) or hashlib.sha256(pcm.tobytes()).hexdigest() != str(fx["sha256"][a + i])]
     assert not bad, bad
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["config3", "config5"])
+def test_banks_built_by_the_c_abi_render_like_the_parsers(sa, oracle, shape):
+    """a bank handed over as flat operator descriptions (sauAmd_build_bank, no parser) renders
+    on the device exactly as the oracle renders it, and exactly as the bank the Python builder makes -- which is
+    pinned on parser-made images -- for the shapes of BASELINE configs 3 and 5 (128 voices, 1 s)."""
+    from saugns_amd import voicebank as vb
+    oracle.oracle().ora_set_fastmath_forms(1)
+    voices = vb.config3_voices(128, 1) if shape == "config3" else vb.config5_voices(128, 1)
+    bank = vb.build_bank_c(voices)
+    ref_bank = vb.build_program(voices)
+    want = oracle.oracle_render(bank.ptr, 44100, False)
+    assert (want == oracle.oracle_render(ref_bank.ptr, 44100, False)).all()
+    got = sa.Batch([bank], 44100).render(stereo=False, chunk=44100)[0]
+    assert len(got) == len(want) == 44100 and (got == want).all()
+    # ... and through the drop-in generator with the reference host's call size
+    got2 = sa.Generator(bank, 44100).render(stereo=False, chunk=11289)
+    assert len(got2) == len(want) and (got2 == want).all()
