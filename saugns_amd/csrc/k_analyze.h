@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 	const VoiceDesc vd = P.voices[v];
 	const uint32_t *ids = P.op_ids + vd.ops_ofs;
 	bool bad = (vd.flags & VD_NO_FAST) != 0 || !P.enable;
-	bool seq = false;
+	bool seq = false, has_red = false;
 	uint32_t min_time = 0xFFFFFFFFu;
 	const Step *plan = P.steps + vd.plan_ofs;
 	/* An operator that has run out of time yields nothing, and neither it nor
@@ -113,7 +113,9 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 			} else if (ln == L_PMA) { if (!(chain_ok && o.type == OT_WAVE)) bad = true; }
 			else if (ln != L_AMP && ln != L_AMP2) bad = true;
 		}
-		if (o.type == OT_NOISE && o.wave == NZ_re) bad = true;
+		/* red noise (noise.h:136-147) is a wrapping running sum of a counter hash: the single-pass build takes it
+		 * like a running-sum phase, prefixes by look-back (has_red: only there) */
+		if (o.type == OT_NOISE && o.wave == NZ_re) { seq = true; has_red = true; }
 		/* self-modulation is a recurrence: W oscillators' go to chain_kernel, R's to the block loop */
 		if (o.line[L_PMA].v0 != 0.f && !(chain_ok && o.type == OT_WAVE)) bad = true;
 		if (o.type == OT_WAVE) o.ras_level = 0; /* (CHAIN_MARK of an earlier segment) */
@@ -354,8 +356,8 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 			} else if (st.kind == ST_LERP) {
 				set_level(st.out, max2(level_of(st.freq), level_of(st.pm)), true);
 			} else if (st.kind == ST_OSC) {
-				const bool fvar = (o.type == OT_WAVE || o.type == OT_RASEG) && !o.rt_fconst_valid &&
-					!(chain_ok && step_is_chain_acc(st, o));
+				const bool fvar = ((o.type == OT_WAVE || o.type == OT_RASEG) && !o.rt_fconst_valid &&
+					!(chain_ok && step_is_chain_acc(st, o))) || (o.type == OT_NOISE && o.wave == NZ_re);
 				uint32_t lv = max2(max2(level_of(st.pm), level_of(st.fpm)), max2(level_of(st.amp),
 						max2(level_of(st.freq), level_of(st.fmul))));
 				if (fvar) {
@@ -380,6 +382,7 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 		}
 		n_scan_out = n_scan;
 	}
+	if (has_red && seq_kind != 3) bad = true; /* (the several-pass and in-order forms do not carry noise sums) */
 	if (has_chain && !bad) {
 		if (seq_kind == 1) bad = true; /* (one wave in order: not with chains) */
 		else {

@@ -415,16 +415,19 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 				fa.pad[1] = (o.type == OT_WAVE || o.type == OT_RASEG) && !o.rt_fconst_valid && !step_is_chain_acc(st, o) ? o.rt_fblk_valid : 0u;
 				fa.pad[0] = xi;
 			}
-			if (seq == 3 && st.kind == ST_OSC && is_osc && !o.rt_fconst_valid) {
-				/* single-pass voice: which of its look-back arrays this oscillator has */
+			const bool is_red = o.type == OT_NOISE && o.wave == NZ_re;
+			if (seq == 3 && st.kind == ST_OSC && ((is_osc && !o.rt_fconst_valid) || is_red)) {
+				/* single-pass voice: which of its look-back arrays this oscillator (or red noise: a running sum too) has */
 				uint32_t xi = 0;
 				for (uint32_t q = 0; q < (uint32_t)l; ++q) {
 					const Step sq = plan[q];
 					const DevOp &oq = P.ops[ids[sq.op]];
 					if (oq.rt_frozen) continue;
-					if (sq.kind == ST_OSC && (oq.type == OT_WAVE || oq.type == OT_RASEG) && !oq.rt_fconst_valid) ++xi;
+					if (sq.kind == ST_OSC && (((oq.type == OT_WAVE || oq.type == OT_RASEG) && !oq.rt_fconst_valid) ||
+					                          (oq.type == OT_NOISE && oq.wave == NZ_re))) ++xi;
 				}
 				fa.pad[0] = xi; fa.pad[1] = 0;
+				if (is_red) f.ramp |= 2; /* (its aux record carries the array's index) */
 			}
 			if (st.kind == ST_OSC && is_osc && !o.rt_fconst_valid) {
 				/* frequency per frame: from its block, or from its own line when it has no block */

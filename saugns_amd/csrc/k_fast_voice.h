@@ -616,6 +616,41 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 				} else if (type == OT_NOISE) {
 					const uint32_t nz = (f.type >> 8) & 0xff;
 					const uint32_t n0 = f.phase0, nprev = f.prev_phase;
+					if (SCAN == 2 && nz == NZ_re) {
+						/* noise.h:136-147: sum += (int32_t)hash(n++) >> 6, wrapping; the sample is the folded sum. A running
+						 * sum like a phase's: per-row DPP scans, what the groups before have added by look-back */
+						const FastAux fa = load_aux_uniform(faux + si);
+						uint32_t S[T];
+#pragma unroll
+						for (int k = 0; k < T; ++k) {
+							const int t = t0 + k * (int)C;
+							const uint32_t inc = (t >= 0 && t < (int)fast_total) ? (uint32_t)((int32_t)ranfast32(n0 + (uint32_t)t) >> 6) : 0u;
+							S[k] = wave_incl_scan_dpp(inc);
+						}
+						uint32_t acc;
+						if (look_own) {
+							acc = first_group ? nprev : (uint32_t)carry[si];
+						} else {
+							uint32_t tot = 0;
+#pragma unroll
+							for (int k = 0; k < T; ++k)
+								tot += (uint32_t)__builtin_amdgcn_readlane((int)S[k], 63) - (uint32_t)__builtin_amdgcn_readlane((int)S[k], (int)H - 1);
+							acc = nprev + (look_lds ? lookback32<true>(lk_base + (size_t)fa.pad[0] * 2 * 64, cg, tot, 0, lk_ring, cgm, l, zero_acc)
+							                        : lookback32<false>(lookv + (size_t)fa.pad[0] * 2 * P.scan_groups, cg, tot, P.look_epoch, 0, 0, l, zero_acc));
+						}
+#pragma unroll
+						for (int k = 0; k < T; ++k) {
+							const int t = t0 + k * (int)C;
+							const uint32_t lead = (uint32_t)__builtin_amdgcn_readlane((int)S[k], (int)H - 1);
+							const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)S[k], 63);
+							const uint32_t sum = acc + (S[k] - lead);
+							acc += last - lead;
+							s[k] = fscalei((uint32_t)foldhd32((int32_t)sum), 0x1p-31f);
+							/* the sum after the segment's last frame: the operator's next `prev` (finalize_kernel) */
+							if (is_last_group && t == (int)fast_total - 1 && l >= (int)H) P.ops[f.gop].st_prev_phase = sum;
+						}
+						if (look_own && l == 0) carry[si] = (unsigned long long)acc;
+					} else {
 #pragma unroll
 					for (int k = 0; k < T; ++k) {
 						const int t = t0 + k * (int)C;
@@ -631,6 +666,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 						} else {
 							s[k] = noise_stateless(nz, n);
 						}
+					}
 					}
 				} else { /* OT_AMP (generator.c:517-518: 1), or an oscillator whose output stands still */
 #pragma unroll

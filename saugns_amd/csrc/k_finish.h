@@ -85,6 +85,7 @@ __global__ void __launch_bounds__(64) finalize_kernel(FastParams P) {
 			const uint32_t n0 = o.noise_n;
 			if (o.wave == NZ_vi) o.noise_prev = ranfast32(n0 + total - 1);
 			else if (o.wave == NZ_bv) o.noise_prev = (uint32_t)noise_bv_term(n0 + total - 1);
+			else if (o.wave == NZ_re) o.noise_prev = o.st_prev_phase; /* the running sum, staged by fast_voice */
 			o.noise_n = n0 + total;
 		}
 		}

@@ -313,8 +313,10 @@ bool compile_voice_plan(const std::vector<OpMirror> &ops, uint32_t carrier,
 	for (const Step &st : out.steps) {
 		if (step_may_chain(st)) ++out.n_chain;
 		if (st.kind == ST_OSC && st.op < out.op_ids.size()) {
-			const uint8_t ty = ops[out.op_ids[st.op]].type;
-			if (ty == SAU_POPT_N_wave || ty == SAU_POPT_N_raseg) ++out.n_osc;
+			const OpMirror &om = ops[out.op_ids[st.op]];
+			const uint8_t ty = om.type;
+			/* (red noise is a running sum too: a look-back row like an oscillator's, k_fast_voice.h) */
+			if (ty == SAU_POPT_N_wave || ty == SAU_POPT_N_raseg || (ty == SAU_POPT_N_noise && om.wave == SAU_NOISE_N_re)) ++out.n_osc;
 		}
 		if (st.kind == ST_SMLINE) { out.static_block = true; out.selfmod = true; }
 		if (st.kind == ST_LINE && st.which == L_FREQ && (st.flags & SF_FORCE)) out.static_block = true;

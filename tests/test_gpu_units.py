@@ -474,6 +474,36 @@ def test_noise_types(sa, oracle):
         check(sa, oracle, [vb.Op("sin", freq=300.0, time_ms=40, mods={POP_PMOD: [n]})])
 
 
+def test_red_noise_stays_on_the_time_parallel_path(sa, oracle):
+    """Red noise (noise.h:136-147) is a wrapping running sum of a counter hash: prefixes by look-back, like a
+    running-sum phase -- as carrier, as PM source of an FM'd carrier (two sums in one voice), with an amplitude
+    ramp, over several engine runs (the sum carried from one to the next), 1 to 64 waves per voice; and none of
+    it in the block loop."""
+    from saugns_amd.api import POPT_NOISE
+    oracle.oracle().ora_set_fastmath_forms(1)
+    for n_voices, ms in ((1, 700), (3, 300), (40, 120), (300, 60)):
+        voices = []
+        for k in range(n_voices):
+            red = vb.Op(amp=0.3 + 0.01 * (k % 5), op_type=POPT_NOISE, noise=4, seed=1000 + k)
+            kind = k % 3
+            if kind == 0:
+                voices.append(vb.Op(amp=vb.Line(0.8, goal=0.1, shape="lin"), time_ms=ms, op_type=POPT_NOISE, noise=4, seed=k))
+            elif kind == 1:
+                voices.append(vb.Op("sin", freq=200.0 + k, time_ms=ms, mods={POP_PMOD: [red]}))
+            else:
+                voices.append(vb.Op("tri", freq=vb.Line(150.0 + k, goal=300.0, shape="exp"), time_ms=ms,
+                                    mods={POP_PMOD: [red], POP_FMOD: [vb.Op("sin", freq=5.0, amp=10.0)]}))
+        prg = vb.build_program(voices)
+        want = oracle.oracle_render(prg.ptr, RATE, False)
+        for chunk in (4000000, 1733):
+            b = sa.Batch([prg], RATE)
+            b.set_timing(2)
+            got = b.render(stereo=False, chunk=chunk)[0]
+            assert len(got) == len(want) and (got == want).all(), (n_voices, chunk)
+            if chunk > len(want):
+                assert b.timing_ex()["block_ms"] < 0.5, (n_voices, b.timing_ex())  # (a token launch only)
+
+
 @pytest.mark.parametrize("line", LINES)
 def test_r_oscillator_options(sa, oracle, line):
     """R oscillator: every line shape x segment function x a spread of function flags
