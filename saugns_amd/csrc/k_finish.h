@@ -130,26 +130,25 @@ struct MixParams {
  * ahead of the (serially dependent) adds. */
 constexpr int MIX_TILE = 256; /* voices whose constants are staged at a time */
 constexpr int MIX_AHEAD = 32; /* loads per batch and thread */
-__global__ void __launch_bounds__(256) mix_kernel(MixParams P) {
-	__shared__ float s_pan[MIX_TILE];
-	__shared__ uint32_t s_valid[MIX_TILE];
-	__shared__ uint32_t s_prow[MIX_TILE]; /* pan row, or ~0u */
-	__shared__ uint32_t s_special;        /* tile has a short row or a pan row */
-	const MixStream ms = P.streams[blockIdx.y];
-	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-	if (blockIdx.x * 256 >= ms.write_len) return;
+/* PERSIST: a few workgroups (MixParams.grid_x of them) walk the frames in strides -- the form that runs beside the next
+ * segment's time-parallel kernel on the handful of CUs that kernel's grid leaves free (hip_backend.hip, MixSet). */
+template <bool PERSIST>
+__device__ __forceinline__ void mix_body(const MixParams &P, const MixStream &ms, const uint32_t bx,
+		float *s_pan, uint32_t *s_valid, uint32_t *s_prow, uint32_t &s_special) {
+	const uint32_t tl = PERSIST ? (threadIdx.x & 255u) : threadIdx.x; /* within the 256 frames of bx */
+	const uint32_t i = bx * 256 + tl;
 	const bool act = i < ms.write_len;
 	float L = 0.f, R = 0.f;
 	for (uint32_t r0 = 0; r0 < ms.n_rows; r0 += MIX_TILE) {
 		const uint32_t nt = min((uint32_t)MIX_TILE, ms.n_rows - r0);
 		__syncthreads();
-		if (threadIdx.x == 0) s_special = 0;
+		if (tl == 0) s_special = 0;
 		__syncthreads();
-		if (threadIdx.x < nt) {
-			const VoiceOut vo = P.vinfo[ms.first_row + r0 + threadIdx.x];
-			s_pan[threadIdx.x] = vo.pan_const;
-			s_valid[threadIdx.x] = vo.valid_len;
-			s_prow[threadIdx.x] = vo.has_pan ? vo.pan_row : ~0u;
+		if (tl < nt) {
+			const VoiceOut vo = P.vinfo[ms.first_row + r0 + tl];
+			s_pan[tl] = vo.pan_const;
+			s_valid[tl] = vo.valid_len;
+			s_prow[tl] = vo.has_pan ? vo.pan_row : ~0u;
 			if (vo.has_pan || vo.valid_len < ms.write_len) s_special = 1;
 		}
 		__syncthreads();
@@ -227,6 +226,31 @@ __global__ void __launch_bounds__(256) mix_kernel(MixParams P) {
 	} else {
 		const int16_t m16 = pcm16((L + R) * 0.5f);
 		ms.pcm[P.pcm_offset + i] = P.swap_bytes ? pcm_swap(m16) : m16;
+	}
+}
+
+__global__ void __launch_bounds__(256) mix_kernel(MixParams P) {
+	__shared__ float s_pan[MIX_TILE];
+	__shared__ uint32_t s_valid[MIX_TILE];
+	__shared__ uint32_t s_prow[MIX_TILE]; /* pan row, or ~0u */
+	__shared__ uint32_t s_special;        /* tile has a short row or a pan row */
+	const MixStream ms = P.streams[blockIdx.y];
+	if (blockIdx.x * 256 >= ms.write_len) return;
+	mix_body<false>(P, ms, blockIdx.x, s_pan, s_valid, s_prow, s_special);
+}
+
+/* four 256-thread mixers per workgroup, each with its own tile arrays; a workgroup per CU the other kernel leaves free */
+__global__ void __launch_bounds__(1024) mix_persist_kernel(MixParams P) {
+	__shared__ float s_pan[4][MIX_TILE];
+	__shared__ uint32_t s_valid[4][MIX_TILE];
+	__shared__ uint32_t s_prow[4][MIX_TILE];
+	__shared__ uint32_t s_special[4];
+	const MixStream ms = P.streams[blockIdx.y];
+	const uint32_t n_bx = (ms.write_len + 255) / 256;
+	/* every thread of the workgroup makes the same number of rounds (mix_body has workgroup barriers) */
+	for (uint32_t b0 = blockIdx.x * 4; b0 < n_bx; b0 += gridDim.x * 4) {
+		const uint32_t q = threadIdx.x >> 8;
+		mix_body<true>(P, ms, b0 + q, s_pan[q], s_valid[q], s_prow[q], s_special[q]);
 	}
 }
 

@@ -23,8 +23,11 @@ out = {"command": "rocprofv3 --pmc <C> --kernel-trace --output-format csv -- pyt
                "dispatches; gfx950 correction: FETCH_SIZE doubled (MI355X_MICROARCH.md HBM section; confirmed "
                "here: mix_kernel reads voices x frames f32 and FETCH_SIZE reports half of it), WRITE_SIZE "
                "exact (fast_kernel writes the same bytes of voice rows)", "kernels": {}}
-for d, f in (("fetch", "f"), ("write", "w"), ("sq", "s"), ("inst", "i")):
+import os
+for d, f in (("fetch", "f"), ("write", "w"), ("sq", "s"), ("inst", "i"), ("grbm", "g")):
     src = f"gpurun_out/pmc_{tag}_{d}/{f}_counter_collection.csv"
+    if not os.path.exists(src):
+        continue
     shutil.copy(src, f"profiles/{name}_pmc_{d}_counter_collection.csv")
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(src)):
@@ -40,9 +43,19 @@ for d, f in (("fetch", "f"), ("write", "w"), ("sq", "s"), ("inst", "i")):
 for k, v in out["kernels"].items():
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         v["hbm_bytes_per_launch_corrected"] = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
+    if "SQ_INSTS_VALU" in v and "GRBM_GUI_ACTIVE" in v and v["GRBM_GUI_ACTIVE"] > 0:
+        # the VALU side of the roofline. A wave64 VALU instruction occupies its SIMD's 16 lanes for 4 cycles
+        # (f32 and f64 alike on CDNA4; transcendentals longer: a lower bound); 256 CUs x 4 SIMDs; GRBM_GUI_ACTIVE is
+        # summed over the 8 XCDs (MI355X_MICROARCH.md, DVFS give-back), so launch cycles = GRBM_GUI_ACTIVE / 8
+        cycles = v["GRBM_GUI_ACTIVE"] / 8
+        v["valu"] = {"insts_per_launch": v["SQ_INSTS_VALU"], "launch_cycles": cycles, "simds": 1024,
+                     "busy_frac": 4 * v["SQ_INSTS_VALU"] / (1024 * cycles),
+                     "formula": "4 cycles x SQ_INSTS_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)",
+                     "salu_per_valu": v.get("SQ_INSTS_SALU", 0) / v["SQ_INSTS_VALU"]}
 json.dump(out, open(f"profiles/{name}_pmc_summary.json", "w"), indent=1)
 # the other workloads' bench lines and kernel statistics, when the round measured them
-import os
+if os.path.exists(f"gpurun_out/bench_{tag}_full.json"):
+    open(f"profiles/{name}_bench_full.json", "w").write(open(f"gpurun_out/bench_{tag}_full.json").read().strip().splitlines()[-1] + "\n")
 for wl in ("c5", "c4"):
     b = f"gpurun_out/bench_{tag}_{wl}.json"
     if os.path.exists(b):

@@ -6,16 +6,17 @@
 # rocprofv3 section).
 TAG=$1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
-python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
+python bench.py --no-others > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
 python bench.py --workload config5 > gpurun_out/bench_${TAG}_c5.json 2> gpurun_out/bench_${TAG}_c5.err
 python bench.py --workload config4 > gpurun_out/bench_${TAG}_c4.json 2> gpurun_out/bench_${TAG}_c4.err
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -o $TAG -- python3 bench.py --no-cpu > gpurun_out/prof_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -o $TAG -- python3 bench.py --no-cpu --no-others > gpurun_out/prof_$TAG.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_c5 -o ${TAG}_c5 -- python3 bench.py --workload config5 --steps 3 --no-cpu > gpurun_out/prof_${TAG}_c5.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_c4 -o ${TAG}_c4 -- python3 bench.py --workload config4 --steps 3 --no-cpu > gpurun_out/prof_${TAG}_c4.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_fetch -o f -- python3 bench.py --steps 4 --warmup 1 --no-cpu > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_write -o w -- python3 bench.py --steps 4 --warmup 1 --no-cpu > /dev/null 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_sq -o s -- python3 bench.py --steps 4 --warmup 1 --no-cpu > /dev/null 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_inst -o i -- python3 bench.py --steps 4 --warmup 1 --no-cpu > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_fetch -o f -- python3 bench.py --steps 4 --warmup 1 --no-cpu --no-others > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_write -o w -- python3 bench.py --steps 4 --warmup 1 --no-cpu --no-others > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_sq -o s -- python3 bench.py --steps 4 --warmup 1 --no-cpu --no-others > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_inst -o i -- python3 bench.py --steps 4 --warmup 1 --no-cpu --no-others > /dev/null 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_grbm -o g -- python3 bench.py --steps 4 --warmup 1 --no-cpu --no-others > /dev/null 2>&1
 # config 5: HBM bytes and instruction mix of the chain kernel and the passes around it
 # (one counter per pass: FETCH_SIZE and WRITE_SIZE together never finished on this pool -- r02a lost 25 minutes to it)
 timeout 180 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_c5_fetch -o m -- python3 bench.py --workload config5 --steps 1 --warmup 0 --no-cpu > /dev/null 2>&1
@@ -25,5 +26,6 @@ timeout 180 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SM
 TLEVEL=0 timeout 180 python3 tools/gpu_sweep.py c3f fmstack mixed > gpurun_out/sweep_${TAG}_fm.txt 2>&1
 timeout 180 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_fm -o ${TAG}_fm -- python3 tools/gpu_sweep.py c3f fmstack > gpurun_out/prof_${TAG}_fm.log 2>&1
 timeout 180 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_fm_inst -o i -- python3 tools/gpu_sweep.py c3f > /dev/null 2>&1
+python bench.py > gpurun_out/bench_${TAG}_full.json 2> gpurun_out/bench_${TAG}_full.err   # the driver's command: all three workloads in one line
 for f in "" _c5 _c4; do tail -1 gpurun_out/bench_$TAG$f.json | cut -c1-200; done
 cat gpurun_out/sweep_${TAG}_fm.txt
