@@ -126,3 +126,29 @@ def test_bench_launcher_reports_a_failed_rank(seqexec):
     out = _bench(["--gpus", "2", "--voices", "8", "--frames", "4410", "--steps", "1", "--warmup", "0", "--no-cpu"],
                  seqexec, env_extra={"SAU_BENCH_TEST_BACKEND": "/nonexistent/libseqexec.so"}, timeout=300)
     assert out.returncode != 0
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_on_one_gpu_box_with_cpu_rendezvous():
+    """The same command on a GPU box: `bench.py --gpus 2` starts two ranks that share the one device (rendezvous and
+    reductions through gloo), each rendering its shard of BASELINE config 4 at full length on the HIP backend, every
+    render's SHA-256 checked against the compiled reference's; then config 3, where both ranks render the same bank."""
+    env = dict(os.environ, SAU_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "SAU_BENCH_TEST_BACKEND"):
+        env.pop(k, None)
+
+    def run(argv):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True,
+                             env=env, timeout=900)
+        return _line(out)
+
+    j = run(["--gpus", "2", "--workload", "config4", "--renders", "4", "--steps", "1", "--warmup", "0", "--no-cpu"])
+    assert j["n_gpus"] == 2 and j["config"]["renders_all_ranks"] == 8
+    assert j["config"]["frames_all_ranks"] == 8 * 2646000 and "TEST BACKEND" not in j["data"]
+    assert "SHA-256 of every one of the 8 renders" in j["config"]["verified"]
+    k = run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu", "--no-others"])
+    assert k["n_gpus"] == 2 and k["config"]["frames_all_ranks"] == 2 * 3 * 441000
+    assert k["config"]["first_step_verified"]["sha256"].startswith("3211740aca595248")
