@@ -880,19 +880,19 @@ public:
 					}
 				} else {
 					/* closed-form voices only: tasks of about eight row groups, dealt out by a counter */
-					const bool dyn_on = dyn_enabled_;
 					const uint32_t dyn_groups = dyn_groups_;
-					if (dyn_on && main_build == 0) {
+					if (main_build == 0) {
 						/* ... but at least four tasks per wave of the grid where the voices' groups allow (few voices) */
 						const uint32_t by_size = (groups + dyn_groups - 1) / (dyn_groups ? dyn_groups : 1);
 						const uint32_t by_waves = (uint32_t)(((unsigned long long)4 * fgrid * 16 + seg.n_voices - 1) / seg.n_voices);
 						const uint32_t k = by_size > by_waves ? by_size : by_waves;
 						fp.dyn_chunks = k < groups ? (k ? k : 1) : (groups ? groups : 1);
+						fp.dyn_static = dyn_enabled_ ? 0u : 1u;
 					}
 					/* the last segment's mixer is at work on mix_cus_ CUs: this launch takes the others (its tasks are dealt
 					 * out by a counter, so a smaller grid just means more tasks per wave) */
 					uint32_t g0 = 0;
-					if (fp.dyn_chunks && mix_cus_ && (sets_[cur_ ^ 1].pending) && fgrid + mix_cus_ > fk_grid_ && fk_grid_ > mix_cus_ + 32)
+					if (fp.dyn_chunks && !fp.dyn_static && mix_cus_ && (sets_[cur_ ^ 1].pending) && fgrid + mix_cus_ > fk_grid_ && fk_grid_ > mix_cus_ + 32)
 						g0 = fk_grid_ - mix_cus_;
 					launch_fast(0, g0);
 					fp.dyn_chunks = 0;

@@ -131,6 +131,7 @@ struct FastParams {
 	 * next task when they finish one, so CUs that get less done (other kernels' workgroups sharing them: the previous
 	 * segment's mixer) hold nobody up at the end. 0: static shares (waves stride over voices and groups). */
 	uint32_t dyn_chunks;
+	uint32_t dyn_static; /* 1: the same tasks in fixed strides over the launch's waves, no counter (SAU_AMD_NO_DYN) */
 	/* Voices with feedback chains whose other oscillators all have closed-form phases (a chain that sums its own
 	 * increments counts as such: BASELINE config 5) take no sum pass, no scan and no saved increments: their
 	 * chain-input and final passes run in a build of their own, fast_kernel<T, 3> -- fast_voice without the code of

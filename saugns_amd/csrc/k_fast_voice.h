@@ -825,16 +825,22 @@ __global__ void FK_ATTR fast_kernel(FastParams P) {
 	__syncthreads(); /* the only barrier: tables are shared, all else is per wave */
 
 	const uint32_t NV = P.n_voices;
-	if (SCAN == 0 && P.dyn_chunks) {
-		/* tasks dealt out by a counter: the next one is asked for before the current one is worked on, so the
-		 * atomic's round trip is never waited for */
-		const uint32_t K = P.dyn_chunks, n_tasks = NV * K;
-		uint32_t nxt = 0;
-		if (l == 0) nxt = atomicAdd(&P.pass_flags[FAST_DYN_CTR], 1u);
+	if (SCAN == 0) {
+		/* The closed-form build: task = (voice, one of dyn_chunks runs of consecutive row groups), in voice order.
+		 * Dealt out by a counter, or -- dyn_static -- in fixed strides over the launch's waves. One loop, one copy of
+		 * fast_voice, and the atomic's answer is waited for where it is asked for (the SIMD's other waves run meanwhile):
+		 * a second call site, or the answer held in a vector register across a task so as to ask a task ahead, cost
+		 * the 8-row build 60 spilled VGPRs, 2.6 GB of scratch traffic per launch and 16 % more VALU instructions (r03). */
+		const uint32_t K = P.dyn_chunks ? P.dyn_chunks : 1u, n_tasks = NV * K;
+		const bool counted = P.dyn_static == 0;
+		const uint32_t stride = gridDim.x * W;
+		uint32_t snext = blockIdx.x * W + (uint32_t)w;
 		for (;;) {
-			const uint32_t task = uni(nxt);
+			uint32_t t_ = snext;
+			if (counted) { t_ = 0; if (l == 0) t_ = atomicAdd(&P.pass_flags[FAST_DYN_CTR], 1u); }
+			const uint32_t task = uni(t_);
 			if (task >= n_tasks) break;
-			if (l == 0) nxt = atomicAdd(&P.pass_flags[FAST_DYN_CTR], 1u);
+			snext = task + stride;
 			const uint32_t v = task / K;
 			const FastInfo fi = P.info[v];
 			fast_voice<T, 0>(P, v, fi, slots, carry, t23, t01, l, 1u, 0u, nullptr, task - v * K, K);

@@ -1,6 +1,6 @@
 /* chain_probe.hip -- latency probe for the feedback recurrence (wosc.h:273-310) with lanes = voices:
  * one wave runs 64 independent chains, base phases / amounts streamed from per-chain rows in HBM.
- *   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I saugns_amd/csrc tools/scratch/chain_probe.hip -o /tmp/chain_probe
+ *   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I saugns_amd/csrc tools/chain_probe.hip -o /tmp/chain_probe
  * prints ns per sample step (all 64 chains advance one sample per step). */
 #include <hip/hip_runtime.h>
 #include <stdio.h>

@@ -51,7 +51,7 @@ for k, v in out["kernels"].items():
         v["valu"] = {"insts_per_launch": v["SQ_INSTS_VALU"], "launch_cycles": cycles, "simds": 1024,
                      "busy_frac": 4 * v["SQ_INSTS_VALU"] / (1024 * cycles),
                      "formula": "4 cycles x SQ_INSTS_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)",
-                     "salu_per_valu": v.get("SQ_INSTS_SALU", 0) / v["SQ_INSTS_VALU"]}
+                     "salu_per_valu": (v.get("SQ_INSTS_SALU", 0) / v["SQ_INSTS_VALU"]) if v["SQ_INSTS_VALU"] else None}
 json.dump(out, open(f"profiles/{name}_pmc_summary.json", "w"), indent=1)
 # the other workloads' bench lines and kernel statistics, when the round measured them
 if os.path.exists(f"gpurun_out/bench_{tag}_full.json"):
