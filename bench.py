@@ -46,7 +46,7 @@ def kernel_source_hash():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "saugns_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h", ".cpp")):
+        if f.startswith(("k_", "sau_dev_")) and f.endswith(".h"):  # device code: the kernels' parts and the arithmetic they share
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 

@@ -880,14 +880,27 @@ public:
 					}
 				} else {
 					/* closed-form voices only: tasks of about eight row groups, dealt out by a counter */
-					const uint32_t dyn_groups = dyn_groups_;
 					if (main_build == 0) {
-						/* ... but at least four tasks per wave of the grid where the voices' groups allow (few voices) */
-						const uint32_t by_size = (groups + dyn_groups - 1) / (dyn_groups ? dyn_groups : 1);
-						const uint32_t by_waves = (uint32_t)(((unsigned long long)4 * fgrid * 16 + seg.n_voices - 1) / seg.n_voices);
-						const uint32_t k = by_size > by_waves ? by_size : by_waves;
-						fp.dyn_chunks = k < groups ? (k ? k : 1) : (groups ? groups : 1);
-						fp.dyn_static = dyn_enabled_ ? 0u : 1u;
+						/* Tasks of G row groups. The counter takes about one add per 12 ns chip-wide (r03: config 3 with tasks
+						 * of 3 or 4 groups x 4 steps, one add per 8 ns, ran 1.3-1.6x slower), and a task of G groups x S steps
+						 * keeps a wave for about G x S x 2.2 us, so G x S >= 48 leaves a factor of two; and dealing tasks out
+						 * only pays when there are several per wave -- a short segment's few tasks go out in fixed strides,
+						 * one contiguous run of groups per wave (1024 one-operator voices x 44100 frames: 0.18 ms in strides,
+						 * 0.31 ms through the counter). */
+						const uint32_t waves = fgrid * 16;
+						const uint32_t S = seg.max_steps ? seg.max_steps : 1;
+						uint32_t G = dyn_groups_;
+						if (G * S < 48) G = (48 + S - 1) / S;
+						const uint32_t k_dyn = (groups + G - 1) / G;
+						if (dyn_enabled_ && (unsigned long long)seg.n_voices * k_dyn >= 4ull * waves) {
+							fp.dyn_chunks = k_dyn ? k_dyn : 1;
+							fp.dyn_static = 0;
+						} else {
+							uint32_t k = waves / seg.n_voices;
+							if (k > groups) k = groups;
+							fp.dyn_chunks = k ? k : 1;
+							fp.dyn_static = 1;
+						}
 					}
 					/* the last segment's mixer is at work on mix_cus_ CUs: this launch takes the others (its tasks are dealt
 					 * out by a counter, so a smaller grid just means more tasks per wave) */
@@ -1258,7 +1271,7 @@ private:
 	uint32_t fk_grid_ = FK_GRID;
 	bool dyn_enabled_ = true, lean_enabled_ = true;
 	uint32_t lean_rows_ = 8;    /* SAU_AMD_LEAN_ROWS: rows per pass of fast_kernel<T, 3> at most */
-	uint32_t dyn_groups_ = 8;   /* row groups per task of a closed-form launch (SAU_AMD_DYN_GROUPS) */
+	uint32_t dyn_groups_ = 12;  /* row groups per task of a closed-form launch, at least (SAU_AMD_DYN_GROUPS) */
 	uint32_t look_wpv_ = 1;     /* this segment's single-pass launch: waves per voice, and whether every voice sits */
 	bool look_inside_ = true;   /* inside one workgroup (LDS rings, no waits across workgroups) */
 };
