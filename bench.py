@@ -347,7 +347,7 @@ def run_config4(args, R, sa, tabs, steps=None, warmup=None):
     a, b = shard_range(total, R.rank, R.world)
     prgs = [sa.Program.from_image(fx["images"][k].tobytes()) for k in range(a, b)]
     frames_each = int(fx["frames"][0])
-    run_len = 441000
+    run_len = args.c4_run if args.c4_run else frames_each  # one engine run per render unless told otherwise
     if args.c4_frames:  # tests: the head of every render only (then compared with the fixtures' PCM heads)
         frames_each = run_len = min(frames_each, args.c4_frames)
 
@@ -559,6 +559,7 @@ def main():
     ap.add_argument("--voices", type=int, default=1024, help="config3: voices")
     ap.add_argument("--renders", type=int, default=64, help="config4: renders per GPU")
     ap.add_argument("--voices5", type=int, default=4096, help="config5: voices")
+    ap.add_argument("--c4-run", type=int, default=0, help="config4: frames per engine run (default: the whole 60 s)")
     ap.add_argument("--c4-frames", type=int, default=0, help="config4 (tests): render only the first frames of each script")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="config3: no short config 5 / config 4 runs after it")

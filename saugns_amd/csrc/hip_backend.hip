@@ -350,6 +350,7 @@ public:
 		overlap_enabled_ = getenv("SAU_AMD_MIX_OVERLAP") != nullptr && atoi(getenv("SAU_AMD_MIX_OVERLAP")) != 0;
 		if (const char *mc = getenv("SAU_AMD_MIX_CUS")) { const int n = atoi(mc); mix_cus_ = n >= 0 && n < 128 ? (uint32_t)n : 16u; }
 		if (const char *om = getenv("SAU_AMD_MIX_OVERLAP_MIN")) overlap_min_ = (size_t)atoll(om);
+		mix_few_enabled_ = getenv("SAU_AMD_NO_MIX_FEW") == nullptr;
 		lean_enabled_ = getenv("SAU_AMD_NO_LEAN") == nullptr; /* chains' passes in a build without the several-pass sums */
 		dyn_enabled_ = getenv("SAU_AMD_NO_DYN") == nullptr; /* closed-form launches deal tasks out through a counter */
 		if (const char *dg = getenv("SAU_AMD_DYN_GROUPS")) { const int n = atoi(dg); dyn_groups_ = n >= 1 ? (uint32_t)n : 1u; }
@@ -549,7 +550,7 @@ public:
 		 * previous segment's copies have left it */
 		/* in steady state (no event between two segments) the descriptors repeat: upload only changes */
 		ms_host_.resize(seg.n_streams);
-		uint32_t max_write = 0;
+		uint32_t max_write = 0, max_rows = 0;
 		for (uint32_t s = 0; s < seg.n_streams; ++s) {
 			MixStream &m = ms_host_[s];
 			memset(&m, 0, sizeof m);
@@ -559,6 +560,7 @@ public:
 			m.write_len = seg.streams[s].write_len;
 			m.pcm = pcm_[pcm_cur_].p + pcm_row_ * s;
 			if (m.write_len > max_write) max_write = m.write_len;
+			if (m.n_rows > max_rows) max_rows = m.n_rows;
 		}
 		const bool same_voices = voices_sent_.size() == seg.n_voices && voices_dev_ == voices_.p &&
 			memcmp(voices_sent_.data(), seg.voices, seg.n_voices * sizeof(VoiceDesc)) == 0;
@@ -987,6 +989,9 @@ public:
 			if (tm) (void)hipEventRecord(tm->a, ms);
 			if (beside && mix_cus_) /* a workgroup per CU the next segment's kernel leaves free (fk_reserve_) */
 				hipLaunchKernelGGL(mix_persist_kernel, dim3(mix_cus_, seg.n_streams), dim3(1024), 0, ms, mp);
+			else if (mix_few_enabled_ && max_rows <= 8 && seg.n_streams >= 8 && (seg.pcm_offset & 3u) == 0 && (pcm_row_ & 3u) == 0)
+				/* many streams of a few voices each: four frames per thread, no tile staging (k_finish.h) */
+				hipLaunchKernelGGL(mix_few_kernel, dim3((max_write + 1023) / 1024, seg.n_streams), dim3(256), 0, ms, mp);
 			else
 				hipLaunchKernelGGL(mix_kernel, dim3((max_write + 255) / 256, seg.n_streams), dim3(256), 0, ms, mp);
 			HIP_OK(hipGetLastError());
@@ -1269,7 +1274,7 @@ private:
 	DevBuf<unsigned char> fplines_;
 	uint32_t block_grid_ = 1;
 	uint32_t fk_grid_ = FK_GRID;
-	bool dyn_enabled_ = true, lean_enabled_ = true;
+	bool dyn_enabled_ = true, lean_enabled_ = true, mix_few_enabled_ = true;
 	uint32_t lean_rows_ = 8;    /* SAU_AMD_LEAN_ROWS: rows per pass of fast_kernel<T, 3> at most */
 	uint32_t dyn_groups_ = 12;  /* row groups per task of a closed-form launch, at least (SAU_AMD_DYN_GROUPS) */
 	uint32_t look_wpv_ = 1;     /* this segment's single-pass launch: waves per voice, and whether every voice sits */

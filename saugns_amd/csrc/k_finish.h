@@ -239,6 +239,67 @@ __global__ void __launch_bounds__(256) mix_kernel(MixParams P) {
 	mix_body<false>(P, ms, blockIdx.x, s_pan, s_valid, s_prow, s_special);
 }
 
+/* Streams of a few voices each (a batch of many small scripts: BASELINE config 4 has two voices per render): four
+ * consecutive frames per thread, 16-byte row loads, per-row records read straight from memory -- mix_kernel's tile
+ * staging (three barriers per workgroup for a tile of two rows) and one workgroup per 256 frames left the 64-stream
+ * batch's mixer at 1 TB/s. Same sums in the same order. pcm_offset is a multiple of 4 (the host checks). */
+__global__ void __launch_bounds__(256) mix_few_kernel(MixParams P) {
+	const MixStream ms = P.streams[blockIdx.y];
+	const uint32_t i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+	if (i0 >= ms.write_len) return;
+	float L[4] = {0.f, 0.f, 0.f, 0.f}, R[4] = {0.f, 0.f, 0.f, 0.f};
+	const bool full = i0 + 4 <= ms.write_len;
+	for (uint32_t r = 0; r < ms.n_rows; ++r) {
+		const VoiceOut vo = P.vinfo[ms.first_row + r];
+		const float *row = P.vout + (size_t)(ms.first_row + r) * P.row_stride + i0;
+		float v4[4], p4[4] = {vo.pan_const, vo.pan_const, vo.pan_const, vo.pan_const};
+		bool ok[4];
+		if (full && i0 + 4 <= vo.valid_len) {
+			const float4 q = *(const float4 *)row;
+			v4[0] = q.x; v4[1] = q.y; v4[2] = q.z; v4[3] = q.w;
+			ok[0] = ok[1] = ok[2] = ok[3] = true;
+		} else {
+#pragma unroll
+			for (int k = 0; k < 4; ++k) { ok[k] = i0 + k < ms.write_len && i0 + k < vo.valid_len; v4[k] = ok[k] ? row[k] : 0.f; }
+		}
+		if (vo.has_pan) {
+			const float *prow = P.pan + (size_t)vo.pan_row * P.row_stride + i0;
+#pragma unroll
+			for (int k = 0; k < 4; ++k) if (ok[k]) p4[k] = prow[k];
+		}
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			if (ok[k]) { /* generator.c:842-843: a voice adds only the frames it produced */
+				const float v = v4[k] * ms.amp_scale;
+				const float s_r = v * p4[k];
+				L[k] = (L[k] + v) - s_r;
+				R[k] = (R[k] + v) + s_r;
+			}
+		}
+	}
+	int16_t o[8];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		if (P.stereo) {
+			const int16_t l16 = pcm16(L[k]), r16 = pcm16(R[k]);
+			o[2 * k] = P.swap_bytes ? pcm_swap(l16) : l16;
+			o[2 * k + 1] = P.swap_bytes ? pcm_swap(r16) : r16;
+		} else {
+			const int16_t m16 = pcm16((L[k] + R[k]) * 0.5f);
+			o[k] = P.swap_bytes ? pcm_swap(m16) : m16;
+		}
+	}
+	if (P.stereo) {
+		int16_t *d = ms.pcm + 2 * (size_t)(P.pcm_offset + i0);
+		if (full) *(uint4 *)d = *(const uint4 *)o;
+		else for (uint32_t k = 0; i0 + k < ms.write_len; ++k) { d[2 * k] = o[2 * k]; d[2 * k + 1] = o[2 * k + 1]; }
+	} else {
+		int16_t *d = ms.pcm + (size_t)(P.pcm_offset + i0);
+		if (full) *(uint2 *)d = *(const uint2 *)o;
+		else for (uint32_t k = 0; i0 + k < ms.write_len; ++k) d[k] = o[k];
+	}
+}
+
 /* four 256-thread mixers per workgroup, each with its own tile arrays; a workgroup per CU the other kernel leaves free */
 __global__ void __launch_bounds__(1024) mix_persist_kernel(MixParams P) {
 	__shared__ float s_pan[4][MIX_TILE];
