@@ -419,13 +419,13 @@ def run_config4(args, R, sa, tabs, steps=None, warmup=None):
                                f"first {frames_each} frames of seeds 0..3 within 1 LSB of tests/golden/pcm_heads.npz"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                      "frac": achieved / 8000.0, "traffic": None, "traffic_source": None,
-                     "kernel": "fast_kernel<4, 2> (running sums in one pass with look-back; one launch per segment)",
+                     "kernel": "fast_kernel<8, 0> over the closed-form voices + fast_kernel<5, 2> over the look-back voices "
+                               "(two launches per segment, over analyze_kernel's voice lists)",
                      "kernel_ms_per_step": kern_s * 1e3, "other_kernels_ms_per_step":
                      {k: tm[k] / steps for k in ("block_ms", "mix_ms", "aux_ms")},
                      "segments_per_step": tm["segments"] / steps,
                      "algorithmic_bytes_per_step": alg,
-                     "note": "64 renders per GPU are a few hundred voices: below the voice count that fills 256 CUs, and "
-                             "a quarter of the step is the per-segment launch sequence around the kernel"},
+                     "note": "64 renders per GPU are 128 voices; one engine run (one segment) per render since r03"},
     }
     if not args.no_cpu and R.world == 1:
         out["cpu_baseline"] = cpu_reference_config4(fx, tabs)

@@ -656,11 +656,14 @@ public:
 					const bool no_lds = getenv("SAU_AMD_LOOK_NO_LDS") != nullptr;
 					auto is_inside = [&](unsigned long long w) { return w <= 16 && (16 % w) == 0 && !no_lds; };
 					const size_t look_words = (size_t)seg.n_look_rows * 2 * fp.scan_groups;
-					if (!is_inside(wpv) && !no_lds && look_words * sizeof(unsigned long long) > ((size_t)1 << 30))
+					/* the words exist whenever they fit 1 GiB: the kernel then picks the waves per voice from the number of
+					 * look-back voices analyze_kernel finds (the host only knows how many there may be) */
+					look_words_real_ = look_words * sizeof(unsigned long long) <= ((size_t)1 << 30);
+					if (!look_words_real_ && !is_inside(wpv) && !no_lds)
 						wpv = wpv > 16 ? 16 : wpv > 8 ? 8 : wpv > 4 ? 4 : 2;
 					look_wpv_ = (uint32_t)wpv;
-					look_inside_ = is_inside(wpv);
-					if (!look_inside_) {
+					look_inside_ = !look_words_real_ && is_inside(wpv);
+					if (look_words_real_ || !look_inside_) {
 						/* look-back words: valid for this segment's epoch only, so a fresh block starts out zeroed */
 						const unsigned long long *before = look_.p;
 						if (!look_.ensure(look_words, err)) return false;
@@ -730,6 +733,17 @@ public:
 				}
 			}
 			fp.n_tabs = ft;
+			/* the closed-form voices of a segment that may also have look-back voices: a launch of their own (FastParams.vlists) */
+			const bool split_cf = use_fast && seq_ok && look_split;
+			uint32_t rows_cf = 2;
+			auto area_cf = [&](uint32_t t) { return (size_t)seg.n_fast * 64 * t * sizeof(float) + (size_t)fmax_steps * sizeof(unsigned long long); };
+			if (split_cf) {
+				for (uint32_t t : {8u, 6u, 5u, 4u})
+					if (t <= fast_rows_ && ft * tab_bytes + 16 * area_cf(t) + 1024 <= lds_limit_) { rows_cf = t; break; }
+				if (!vlists_.ensure((size_t)2 * seg.n_voices, err)) return false;
+				fp.vlists = vlists_.p; fp.split_cf = 1; fp.rows_cf = rows_cf;
+				fp.look_words_real = look_words_real_ && fp.look ? 1u : 0u;
+			}
 			/* the build for voices with chains and nothing to scan: as many rows per pass as fit beside the tables */
 			fp.lean_on = chains && lean_enabled_ ? 1u : 0u;
 			fp.rows_lean = 4;
@@ -759,13 +773,13 @@ public:
 					/* 3: voices with feedback chains and nothing to scan (4, 6 or 8 rows per pass) */
 					{(const void *)fast_kernel<4, 3>, (const void *)fast_kernel<4, 3>, (const void *)fast_kernel<5, 3>, (const void *)fast_kernel<6, 3>, (const void *)fast_kernel<8, 3>}};
 				static size_t fconfigured[16][4][5];
-				auto launch_build = [&](int build, uint32_t rows, uint32_t grid) -> bool {
+				auto launch_build = [&](int build, uint32_t rows, uint32_t grid, const FastParams *prm = nullptr, size_t area16 = 0) -> bool {
 					if (build == 1 && (rows == 6 || rows == 5)) rows = 4;
 					if (build == 3 && rows < 5) rows = 4;
 					const int ri = rows == 8 ? 4 : rows == 6 ? 3 : rows == 5 ? 2 : rows == 4 ? 1 : 0;
-					const size_t lds = ft * tab_bytes + 16 * area_of(rows) + (build == 2 ? LOOK_LDS_BYTES : 0);
+					const size_t lds = ft * tab_bytes + (area16 ? area16 : 16 * area_of(rows)) + (build == 2 ? LOOK_LDS_BYTES : 0);
 					if (!raise_lds_attr(fkernels[build][ri], lds, fconfigured[dev_ & 15][build][ri], err)) return false;
-					void *args[] = {(void *)&fp};
+					void *args[] = {(void *)(prm ? prm : &fp)};
 					HIP_OK(hipLaunchKernel(fkernels[build][ri], dim3(grid), dim3(1024), args, lds, stream_));
 					return true;
 				};
@@ -792,25 +806,48 @@ public:
 						launched = false;
 					}
 				};
-				if (main_build == 2) {
-					/* closed-form and single-pass voices: one launch, whole segment; as many waves per voice as it has row
-					 * groups (up to 64) when voices are few */
-					unsigned long long wpv = look_wpv_;
-					if (!fp.look) { /* (no running-sum oscillator in any voice: closed-form voices only) */
-						wpv = ((unsigned long long)fk_grid_ * 16) / seg.n_voices;
-						if (wpv > 64) wpv = 64;
-						if (wpv > groups) wpv = groups;
-						if (wpv < 1) wpv = 1;
+				/* Tasks of a closed-form launch: G row groups each. The counter takes about one add per 12 ns chip-wide (r03:
+				 * config 3 with tasks of 3 or 4 groups x 4 steps, one add per 8 ns, ran 1.3-1.6x slower), and a task of G groups
+				 * x S steps keeps a wave for about G x S x 2.2 us, so G x S >= 48 leaves a factor of two; and dealing tasks
+				 * out only pays when there are several per wave -- a short segment's few tasks go out in fixed strides, one
+				 * contiguous run of groups per wave (1024 one-operator voices x 44100 frames: 0.15 ms in strides, 0.31 ms
+				 * through the counter). */
+				auto set_tasks = [&](FastParams &q, uint32_t n_groups, uint32_t grid) {
+					const uint32_t waves = grid * 16;
+					const uint32_t S = seg.max_steps ? seg.max_steps : 1;
+					uint32_t G = dyn_groups_;
+					if (G * S < 48) G = (48 + S - 1) / S;
+					const uint32_t k_dyn = (n_groups + G - 1) / G;
+					if (dyn_enabled_ && (unsigned long long)seg.n_voices * k_dyn >= 4ull * waves) {
+						q.dyn_chunks = k_dyn ? k_dyn : 1;
+						q.dyn_static = 0;
+					} else {
+						uint32_t k = waves / seg.n_voices;
+						if (k > n_groups) k = n_groups;
+						q.dyn_chunks = k ? k : 1;
+						q.dyn_static = 1;
 					}
-					const unsigned long long waves = (unsigned long long)seg.n_voices * wpv;
-					const uint32_t grid2 = waves > (unsigned long long)fk_grid_ * 16 ? fk_grid_ : (uint32_t)((waves + 15) / 16);
-					fp.mode = fp.sum_levels + 1; fp.only_multi = 0; fp.look_wpv = (uint32_t)wpv;
+				};
+				FastParams cfp; /* the closed-form launch of a split segment (also what repair_kernel runs with) */
+				if (main_build == 2) {
+					/* two launches over analyze_kernel's lists: the closed-form voices, then the look-back voices */
+					cfp = fp;
+					cfp.n_fast = seg.n_fast; cfp.rows = rows_cf; cfp.mode = 0; cfp.only_multi = 0;
+					const uint32_t groups_cf = (seg.len + (60 * rows_cf) - 1) / (60 * rows_cf);
+					const unsigned long long want_cf = (unsigned long long)seg.n_voices * (groups_cf < 64 ? groups_cf : 64);
+					const uint32_t grid_cf = (uint32_t)((want_cf + 15) / 16 > fk_grid_ ? fk_grid_ : (want_cf + 15) / 16);
+					set_tasks(cfp, groups_cf, grid_cf ? grid_cf : 1);
+					if (!launch_build(0, rows_cf, grid_cf ? grid_cf : 1, &cfp, 16 * area_cf(rows_cf))) launched = false;
+					fp.mode = fp.sum_levels + 1; fp.only_multi = 0; fp.look_wpv = look_wpv_; fp.look_groups = groups;
 					fp.look_wpv_flags = getenv("SAU_AMD_LOOK_NO_LDS") ? 1u : 0u;
-					const bool inside = !fp.look || look_inside_; /* every voice within one workgroup */
-					if (inside || !fp.look) {
-						if (!launch_build(2, FT, grid2 ? grid2 : 1)) launched = false;
-					} else if (!SpreadLaunchOrder::get().ordered(dev_, stream_, [&]() { return launch_build(2, FT, grid2 ? grid2 : 1); })) {
-						launched = false;
+					if (fp.look) {
+						const unsigned long long waves = (unsigned long long)seg.n_voices * (fp.look_words_real ? (groups < 64 ? groups : 64) : look_wpv_);
+						const uint32_t grid2 = waves > (unsigned long long)fk_grid_ * 16 ? fk_grid_ : (uint32_t)((waves + 15) / 16);
+						if (look_inside_) { /* (every voice within one workgroup: no waits across workgroups) */
+							if (!launch_build(2, FT, grid2 ? grid2 : 1)) launched = false;
+						} else if (!SpreadLaunchOrder::get().ordered(dev_, stream_, [&]() { return launch_build(2, FT, grid2 ? grid2 : 1); })) {
+							launched = false;
+						}
 					}
 				}
 				if (fp.scan) {
@@ -882,28 +919,7 @@ public:
 					}
 				} else {
 					/* closed-form voices only: tasks of about eight row groups, dealt out by a counter */
-					if (main_build == 0) {
-						/* Tasks of G row groups. The counter takes about one add per 12 ns chip-wide (r03: config 3 with tasks
-						 * of 3 or 4 groups x 4 steps, one add per 8 ns, ran 1.3-1.6x slower), and a task of G groups x S steps
-						 * keeps a wave for about G x S x 2.2 us, so G x S >= 48 leaves a factor of two; and dealing tasks out
-						 * only pays when there are several per wave -- a short segment's few tasks go out in fixed strides,
-						 * one contiguous run of groups per wave (1024 one-operator voices x 44100 frames: 0.18 ms in strides,
-						 * 0.31 ms through the counter). */
-						const uint32_t waves = fgrid * 16;
-						const uint32_t S = seg.max_steps ? seg.max_steps : 1;
-						uint32_t G = dyn_groups_;
-						if (G * S < 48) G = (48 + S - 1) / S;
-						const uint32_t k_dyn = (groups + G - 1) / G;
-						if (dyn_enabled_ && (unsigned long long)seg.n_voices * k_dyn >= 4ull * waves) {
-							fp.dyn_chunks = k_dyn ? k_dyn : 1;
-							fp.dyn_static = 0;
-						} else {
-							uint32_t k = waves / seg.n_voices;
-							if (k > groups) k = groups;
-							fp.dyn_chunks = k ? k : 1;
-							fp.dyn_static = 1;
-						}
-					}
+					if (main_build == 0) set_tasks(fp, groups, fgrid);
 					/* the last segment's mixer is at work on mix_cus_ CUs: this launch takes the others (its tasks are dealt
 					 * out by a counter, so a smaller grid just means more tasks per wave) */
 					uint32_t g0 = 0;
@@ -914,18 +930,20 @@ public:
 				}
 				if (!launched) return false;
 				{ /* row groups noted for a second evaluation: returns at once when there are none */
-					const void *rk = FT == 8 ? (const void *)repair_kernel<8> : FT == 6 ? (const void *)repair_kernel<6>
-					               : FT == 5 ? (const void *)repair_kernel<5> : FT == 4 ? (const void *)repair_kernel<4>
+					/* (only closed-form voices note any: with split launches they run at rows_cf rows per pass, in cfp's layout) */
+					const uint32_t RT = main_build == 2 ? rows_cf : FT;
+					const size_t rlds = main_build == 2 ? ft * tab_bytes + 16 * area_cf(rows_cf) : flds;
+					FastParams rpar = main_build == 2 ? cfp : fp;
+					rpar.mode = 0;
+					const void *rk = RT == 8 ? (const void *)repair_kernel<8> : RT == 6 ? (const void *)repair_kernel<6>
+					               : RT == 5 ? (const void *)repair_kernel<5> : RT == 4 ? (const void *)repair_kernel<4>
 					               : (const void *)repair_kernel<2>;
 					static size_t rconfigured[16][5];
-					if (!raise_lds_attr(rk, flds, rconfigured[dev_ & 15][FT == 8 ? 4 : FT == 6 ? 3 : FT == 5 ? 2 : FT == 4 ? 1 : 0], err)) return false;
+					if (!raise_lds_attr(rk, rlds, rconfigured[dev_ & 15][RT == 8 ? 4 : RT == 6 ? 3 : RT == 5 ? 2 : RT == 4 ? 1 : 0], err)) return false;
 					const uint32_t rgrid = (seg.n_voices + 15) / 16 < 64 ? (seg.n_voices + 15) / 16 : 64;
 					fp.mode = 0;
-					if (FT == 8) hipLaunchKernelGGL((repair_kernel<8>), dim3(rgrid), dim3(1024), flds, stream_, fp);
-					else if (FT == 6) hipLaunchKernelGGL((repair_kernel<6>), dim3(rgrid), dim3(1024), flds, stream_, fp);
-					else if (FT == 5) hipLaunchKernelGGL((repair_kernel<5>), dim3(rgrid), dim3(1024), flds, stream_, fp);
-					else if (FT == 4) hipLaunchKernelGGL((repair_kernel<4>), dim3(rgrid), dim3(1024), flds, stream_, fp);
-					else hipLaunchKernelGGL((repair_kernel<2>), dim3(rgrid), dim3(1024), flds, stream_, fp);
+					void *rargs[] = {(void *)&rpar};
+					HIP_OK(hipLaunchKernel(rk, dim3(rgrid), dim3(1024), rargs, rlds, stream_));
 				}
 				if (tf) (void)hipEventRecord(tf->b, stream_);
 			}
@@ -1277,6 +1295,8 @@ private:
 	bool dyn_enabled_ = true, lean_enabled_ = true, mix_few_enabled_ = true;
 	uint32_t lean_rows_ = 8;    /* SAU_AMD_LEAN_ROWS: rows per pass of fast_kernel<T, 3> at most */
 	uint32_t dyn_groups_ = 12;  /* row groups per task of a closed-form launch, at least (SAU_AMD_DYN_GROUPS) */
+	bool look_words_real_ = false; /* this segment's look-back words in HBM are usable (not the token block) */
+	DevBuf<uint32_t> vlists_;   /* [2][n_voices]: analyze_kernel's lists of closed-form and look-back voices (split launches) */
 	uint32_t look_wpv_ = 1;     /* this segment's single-pass launch: waves per voice, and whether every voice sits */
 	bool look_inside_ = true;   /* inside one workgroup (LDS rings, no waits across workgroups) */
 };

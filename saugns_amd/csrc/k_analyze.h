@@ -407,4 +407,8 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 	else if (fi.total && (seq_kind == 1 || seq_kind == 2)) atomicOr(&P.pass_flags[FAST_MAX_LEVELS + 2], 1u);
 	P.fast_done[v] = 0;
 	P.repair[(size_t)v * FAST_REPAIR_WORDS] = 0;
+	if (P.split_cf && fi.total) { /* the two launches' voice lists (any order: voices are independent) */
+		if (seq_kind == 0) P.vlists[atomicAdd(&P.pass_flags[FAST_CF_COUNT], 1u)] = v;
+		else if (seq_kind == 3) P.vlists[P.n_voices + atomicAdd(&P.pass_flags[FAST_LK_COUNT], 1u)] = v;
+	}
 }

@@ -49,7 +49,9 @@ constexpr uint32_t FAST_MAX_LEVELS = 3; /* running sums that depend on running s
 constexpr uint32_t FAST_REPAIR_SHIFT = 24; /* H + shift < 64 (H <= 32) */
 constexpr uint32_t FAST_MAX_REPAIR = 15;   /* noted row groups per voice and segment; more: block loop */
 constexpr uint32_t FAST_REPAIR_WORDS = 2 + 2 * FAST_MAX_REPAIR; /* count, pad, then (group, rows) pairs */
-constexpr uint32_t FAST_FLAGS = FAST_MAX_LEVELS + 5; /* pass_flags words */
+constexpr uint32_t FAST_FLAGS = FAST_MAX_LEVELS + 7; /* pass_flags words */
+constexpr uint32_t FAST_CF_COUNT = FAST_MAX_LEVELS + 5; /* voices in FastParams.vlists[0]: closed-form ones of a segment that also has look-back voices */
+constexpr uint32_t FAST_LK_COUNT = FAST_MAX_LEVELS + 6; /* ... in vlists[1]: the look-back voices */
 constexpr uint32_t FAST_LEAN_FLAG = FAST_MAX_LEVELS + 4; /* ... some voice has feedback chains and no running sum to scan (fast_kernel<T, 3>) */
 constexpr uint32_t FAST_DYN_CTR = FAST_MAX_LEVELS + 3; /* ... the one that deals out fast_kernel<T, 0>'s tasks (dyn_chunks) */
 /* Decoded steps are kept once per pass that runs them ([list][voice][step]): a pass walks its own list and never
@@ -137,6 +139,15 @@ struct FastParams {
 	 * chain-input and final passes run in a build of their own, fast_kernel<T, 3> -- fast_voice without the code of
 	 * the several-pass sums, rows_lean rows per pass. lean_on: such launches exist (the full build leaves those voices out). */
 	uint32_t rows_lean, lean_on;
+	/* A segment whose voices may have running sums (the host cannot tell: analyze_kernel decides per voice) is rendered
+	 * by two launches since round 3, each over a list of voices analyze_kernel builds: the closed-form voices by the
+	 * closed-form build -- rows_cf rows per pass, block buffers without frequency blocks, tasks dealt out by the counter
+	 * -- and the look-back voices by the single-pass build, which then chooses the waves per voice from how many such
+	 * voices there are (look_words_real: the words in HBM exist, so a voice may spread over workgroups). Together in
+	 * one launch they had the same number of waves per voice whatever a voice cost: BASELINE config 4's two voices
+	 * per render (one closed-form, one with nested running sums) took 6.0 ms where they take 1.6 + 3.1 ms apart. */
+	uint32_t *vlists;     /* [2][n_voices], or NULL (one launch over every voice) */
+	uint32_t split_cf, rows_cf, look_words_real, look_groups;
 	uint32_t only_multi; /* this launch: only the voices fast_kernel<T, 2> leaves out (one wave in order, several passes) */
 	int8_t ctab_of_wave[12];
 	uint8_t cwave_of_tab[12];

@@ -40,7 +40,8 @@ template <int T, int SCAN, bool REPAIR = false>
 __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v, const FastInfo &fi,
 		float *slots, unsigned long long *carry, const HerpC23 *t23, const HerpC01 *t01, const int l,
 		const uint32_t wpv, const uint32_t cstart, unsigned long long *lring = nullptr,
-		const uint32_t dyn_c = 0, const uint32_t dyn_k = 0 /* > 0: chunk dyn_c of dyn_k of the voice's row groups */) {
+		const uint32_t dyn_c = 0, const uint32_t dyn_k = 0 /* > 0: chunk dyn_c of dyn_k of the voice's row groups */,
+		const uint32_t vpos = ~0u /* the voice's place among the launch's voices when that is not v (look-back lists) */) {
 	constexpr int NP = 64 * T;
 	(void)NP;
 	const uint32_t fast_total = uni(fi.total);
@@ -71,7 +72,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 	/* the single-pass build: a voice with one wave carries its sums in LDS like an in-order voice; the waves of
 	 * one workgroup look back through rings in LDS; voices spread wider go through HBM */
 	const bool look_own = SCAN == 2 && wpv == 1;
-	const uint32_t w0 = (v * wpv) & 15u; /* the voice's first wave within its workgroup (fast_kernel: waves v * wpv ...) */
+	const uint32_t w0 = ((vpos != ~0u ? vpos : v) * wpv) & 15u; /* the voice's first wave within its workgroup (fast_kernel: waves v * wpv ...) */
 	const bool look_lds = SCAN == 2 && lring && wpv >= 2 && w0 + wpv <= 16 && !(P.look_wpv_flags & 1u);
 	const uint32_t lk_ring = 4 * wpv;
 	unsigned long long *lk_base = look_lds ? lring + w0 * 4 : nullptr;
@@ -799,6 +800,8 @@ __global__ void FK_ATTR fast_kernel(FastParams P) {
 	if (SCAN == 1 && P.mode == P.sum_levels + 2 && P.pass_flags[FAST_MAX_LEVELS + 1] == 0) return; /* no chains */
 	if (SCAN == 1 && P.only_multi && P.pass_flags[FAST_MAX_LEVELS + 2] == 0) return; /* no voice the single-pass build left out */
 	if (SCAN == 3 && P.pass_flags[FAST_LEAN_FLAG] == 0) return; /* no voice with chains and nothing to scan */
+	if (SCAN == 0 && P.split_cf && P.pass_flags[FAST_CF_COUNT] == 0) return; /* no closed-form voice beside the look-back ones */
+	if (SCAN == 2 && P.pass_flags[FAST_LK_COUNT] == 0) return; /* ... and the other way round */
 
 	HerpC23 *t23 = (HerpC23 *)lds;
 	HerpC01 *t01 = (HerpC01 *)(lds + (size_t)P.n_tabs * WAVE_LEN * sizeof(HerpC23));
@@ -831,7 +834,8 @@ __global__ void FK_ATTR fast_kernel(FastParams P) {
 		 * fast_voice, and the atomic's answer is waited for where it is asked for (the SIMD's other waves run meanwhile):
 		 * a second call site, or the answer held in a vector register across a task so as to ask a task ahead, cost
 		 * the 8-row build 60 spilled VGPRs, 2.6 GB of scratch traffic per launch and 16 % more VALU instructions (r03). */
-		const uint32_t K = P.dyn_chunks ? P.dyn_chunks : 1u, n_tasks = NV * K;
+		const uint32_t NVc = P.split_cf ? P.pass_flags[FAST_CF_COUNT] : NV; /* (split: the voices of vlists[0]) */
+		const uint32_t K = P.dyn_chunks ? P.dyn_chunks : 1u, n_tasks = NVc * K;
 		const bool counted = P.dyn_static == 0;
 		const uint32_t stride = gridDim.x * W;
 		uint32_t snext = blockIdx.x * W + (uint32_t)w;
@@ -841,16 +845,35 @@ __global__ void FK_ATTR fast_kernel(FastParams P) {
 			const uint32_t task = uni(t_);
 			if (task >= n_tasks) break;
 			snext = task + stride;
-			const uint32_t v = task / K;
+			const uint32_t vi = task / K;
+			const uint32_t v = P.split_cf ? P.vlists[vi] : vi;
 			const FastInfo fi = P.info[v];
-			fast_voice<T, 0>(P, v, fi, slots, carry, t23, t01, l, 1u, 0u, nullptr, task - v * K, K);
+			fast_voice<T, 0>(P, v, fi, slots, carry, t23, t01, l, 1u, 0u, nullptr, task - vi * K, K);
 		}
 		return;
 	}
 	const uint32_t g = blockIdx.x * W + (uint32_t)w;
 	const uint32_t total_waves = gridDim.x * W;
+	if (SCAN == 2) {
+		/* (this build's launches always come with the lists) the look-back voices of vlists[1]: waves per voice from how many there are -- as many as a voice has row
+		 * groups, 64 at most, where the words in HBM exist; 16, 8, 4, 2 or 1 keep a voice inside a workgroup (rings in LDS) */
+		const uint32_t NVl = P.pass_flags[FAST_LK_COUNT];
+		uint32_t wpv = P.look_wpv;
+		if (P.look_words_real) {
+			wpv = total_waves / NVl;
+			if (wpv > P.look_groups) wpv = P.look_groups;
+			wpv = wpv >= 64 ? 64u : wpv >= 32 ? 32u : wpv >= 16 ? 16u : wpv >= 8 ? 8u : wpv >= 4 ? 4u : wpv >= 2 ? 2u : 1u;
+		}
+		const uint32_t slots_v = total_waves / wpv; /* voices in flight at once */
+		if (g / wpv >= slots_v) return; /* (waves beyond the last whole voice) */
+		for (uint32_t j = g / wpv; j < NVl; j += slots_v) {
+			const uint32_t v = P.vlists[NV + j];
+			const FastInfo fi = P.info[v];
+			fast_voice<T, 2>(P, v, fi, slots, carry, t23, t01, l, wpv, g % wpv, lring, 0u, 0u, j);
+		}
+		return;
+	}
 	uint32_t wpv = total_waves >= NV ? total_waves / NV : 1; /* waves per voice */
-	if (SCAN == 2 && total_waves >= NV) wpv = P.look_wpv; /* (voices x waves <= the launch's waves: the host's choice) */
 	uint32_t v = total_waves >= NV ? g / wpv : g;
 	const uint32_t vstride = total_waves >= NV ? NV : total_waves;
 	const uint32_t cstart = total_waves >= NV ? g % wpv : 0;
@@ -869,12 +892,6 @@ __global__ void FK_ATTR fast_kernel(FastParams P) {
 			continue; /* a sum pass only concerns multi-pass voices that deep */
 		if (SCAN == 1 && P.mode == P.sum_levels + 2 && (seq_kind != 2 || uni(fi.n_chain) == 0))
 			continue; /* the chain-input pass only concerns voices with feedback chains */
-		if (SCAN == 2) { /* the other kinds of running-sum voice have a launch of the full build to themselves */
-			if (seq_kind == 1 || seq_kind == 2) continue;
-			if (seq_kind == 3) fast_voice<T, 2>(P, v, fi, slots, carry, t23, t01, l, wpv, cstart, total_waves >= NV ? lring : nullptr);
-			else fast_voice<T, 0>(P, v, fi, slots, carry, t23, t01, l, wpv, cstart);
-			continue;
-		}
 		if (SCAN == 1 && (P.only_multi ? (seq_kind != 1 && seq_kind != 2) : seq_kind == 3)) continue;
 		if (SCAN && seq_kind != 0) fast_voice<T, 1>(P, v, fi, slots, carry, t23, t01, l, wpv, cstart);
 		else fast_voice<T, 0>(P, v, fi, slots, carry, t23, t01, l, wpv, cstart);
