@@ -66,6 +66,8 @@ Engine *Engine::create(const sauProgram *const *prgs, size_t n_prgs, uint32_t sr
 	}
 	e->total_ops_ = op_base;
 	e->total_voices_ = vo_base;
+	/* the reference build's loop tails (`cub` lines: sau_dev_math.h, TailCtx); SAU_AMD_LOOP_TAILS=0: the loop bodies' forms everywhere */
+	if (const char *lt = getenv("SAU_AMD_LOOP_TAILS")) e->loop_tails_ = atoi(lt) != 0;
 	e->plan_cache_ = getenv("SAU_AMD_NO_PLAN_CACHE") == nullptr;
 	e->plan_check_ = getenv("SAU_AMD_PLAN_CHECK") != nullptr; /* tests: every cached plan against a fresh compile */
 	e->plan_refs_.resize(vo_base);
@@ -161,7 +163,8 @@ bool Engine::handle_event(Stream &st, const EventNode &e, std::vector<OpUpdate> 
 				if (l == L_FREQ || l == L_FREQ2) m.freq_goal_seen = true;
 			}
 		}
-		line_copy(m.pan, u.line[L_PAN]);
+		u.loop_tails = loop_tails_ ? 1u : 0u;
+		line_copy(m.pan, u.line[L_PAN], loop_tails_);
 		if (od->params & SAU_POPP_TIME) {
 			if (od->time.flags & SAU_TIMEP_IMPLICIT) {
 				m.time = 0; m.time_inf = true;
@@ -367,10 +370,12 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 		lat.call_len = lat_call_;
 		lat.e0 = st.since_event < seg_call_pos_ ? (uint32_t)st.since_event : seg_call_pos_;
 		lat.span_left = lat_call_ - seg_call_pos_;
+		uint32_t ev_left = 0xffffffffu;
 		if (st.event < st.events.size()) {
 			/* (event_pos was advanced past this segment already) */
 			const uint32_t wt = st.events[st.event].wait - (st.event_pos - len);
 			if (wt < lat.span_left) lat.span_left = wt;
+			ev_left = wt;
 		}
 		st.since_event += len;
 		for (uint32_t v = st.voice; v < st.voices.size(); ++v) {
@@ -395,8 +400,9 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 			/* generator.c:756-762: dynamic pan needs per-sample values */
 			bool dyn = (carr.pan.flags & LP_GOAL) || vn.plan.has_camods;
 			d.pan_dynamic_row = dyn ? n_pan++ : ~0u;
-			d.flags = vn.plan.no_fast ? VD_NO_FAST : 0;
+			d.flags = (vn.plan.no_fast ? VD_NO_FAST : 0) | (vn.duration ? VD_MORE : 0) | (loop_tails_ ? VD_TAILS : 0);
 			d.lat = lat;
+			d.ev_left = ev_left;
 			d.chain_base = n_chain_rows; d.n_chain = vn.plan.n_chain;
 			n_chain_rows += vn.plan.n_chain;
 			d.inc_base = 0; d.n_inc = 0; /* (set below for voices that may have running-sum phases) */

@@ -201,6 +201,7 @@ private:
 	uint32_t shape_mark_ = 0;
 	uint64_t rebuilds_ = 0;
 	bool plan_cache_ = true, plan_check_ = false;
+	bool loop_tails_ = true;
 	struct Stream {
 		const sauProgram *prg = nullptr;
 		std::vector<EventNode> events;

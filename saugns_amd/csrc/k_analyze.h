@@ -105,8 +105,12 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 		/* ramps in progress: amplitude lines are closed-form per frame (sau/line.c
 		 * fills depend on the position only); frequency ramps need a phase scan,
 		 * self-modulation and pan ramps stay with the block loop */
+		/* `cub` with the reference build's loop tails (sau_dev_math.h: TailCtx): which samples take the tail form depends
+		 * on where the reference's blocks end; the block loop walks them, the closed forms here do not */
+		if ((vd.flags & VD_TAILS) && o.type == OT_RASEG && o.wave == LN_cub) bad = true;
 		for (uint32_t ln = 0; ln < L_COUNT; ++ln) {
 			if (!(o.line[ln].flags & LP_GOAL)) continue;
+			if ((vd.flags & VD_TAILS) && o.line[ln].type == LN_cub) bad = true;
 			if (ln == L_FREQ || ln == L_FREQ2) seq = true; /* phase becomes a running sum */
 			else if (ln == L_PAN) { /* fine when the plan gives the pan line a step of its own */
 				if (!(vd.plan_len && plan[vd.plan_len - 1].kind == ST_VOICE)) bad = true;

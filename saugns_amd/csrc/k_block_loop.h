@@ -223,6 +223,9 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 		const uint32_t blen = min((uint32_t)G::NB, vd.run_len - done);
 		uint32_t depth = 0;
 		uint32_t cur_len = blen;
+		/* frames until the operator being evaluated, an ancestor or the voice stops: where the reference cuts its
+		 * blocks (the loop tails of `cub`, sau_dev_math.h: TailCtx) */
+		uint32_t cur_rem = (vd.flags & VD_MORE) ? TAIL_FAR : min(vd.run_len - done, TAIL_FAR);
 		bool block_ended = false;
 
 		for (uint32_t si = 0; si < vd.plan_len && !block_ended; ++si) {
@@ -238,16 +241,19 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 				if (st.sm != NO_SLOT) st.sm = (uint8_t)slot_index(st.sm, nm);
 				if (st.kind == ST_OSC && st.tmp != NO_SLOT) st.tmp = (uint8_t)slot_index(st.tmp, nm);
 			}
-			const uint32_t parent_len = cur_len;
+			const uint32_t parent_len = cur_len, parent_rem = cur_rem;
 			DevOp *op = &ops[st.op];
 			const uint32_t op_flags = uni(op->flags);
 			if (st.flags & SF_BEGIN) { /* generator.c:694-698 */
-				if (tid == 0) misc->len_stack[depth] = (uint16_t)cur_len;
+				if (tid == 0) { misc->len_stack[depth] = (uint16_t)cur_len; misc->rem_stack[depth] = (uint16_t)cur_rem; }
 				++depth;
 				const uint32_t op_time = uni(op->time);
 				if (!(op_flags & OPF_TIME_INF) && op_time < cur_len) cur_len = op_time;
+				if (!(op_flags & OPF_TIME_INF) && op_time < cur_rem) cur_rem = op_time;
 			}
 			const uint32_t len = cur_len;
+			TailCtx tc;
+			tc.lat = lat; tc.ev_left = uni(vd.ev_left); tc.off = done; tc.rem = cur_rem; tc.on = (vd.flags & VD_TAILS) ? 1u : 0u;
 			bool owned[T];
 #pragma unroll
 			for (int k = 0; k < T; ++k) owned[k] = (p0 + k >= 1) && (jbase + k < (int)len);
@@ -285,7 +291,7 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 					for (int k = 0; k < T; ++k) {
 						if (owned[k]) {
 							float m = mul ? (mconst ? pf : mul[w * G::NP + p0 + k]) : 1.f;
-							v[k] = line_value_v(lb, (uint32_t)(jbase + k), m);
+							v[k] = ((tc.on && lb.sw.type == LN_cub) ? line_value_vt(lb, (uint32_t)(jbase + k), m, tc) : line_value_v(lb, (uint32_t)(jbase + k), m));
 						}
 					}
 				} else {
@@ -318,7 +324,7 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 					line_begin_state(ls, len, false, 0.f, lat, done);
 #pragma unroll
 					for (int k = 0; k < T; ++k)
-						v[k] = owned[k] ? line_value_v(lb, (uint32_t)(jbase + k), 1.f) : 0.f;
+						v[k] = owned[k] ? ((tc.on && lb.sw.type == LN_cub) ? line_value_vt(lb, (uint32_t)(jbase + k), 1.f, tc) : line_value_v(lb, (uint32_t)(jbase + k), 1.f)) : 0.f;
 				} else {
 					line_skip(ls, len, lat, done);
 #pragma unroll
@@ -408,7 +414,7 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 						line_begin_state(als, len, false, 0.f, lat, done);
 #pragma unroll
 						for (int k = 0; k < T; ++k)
-							av[k] = owned[k] ? line_value_v(alb, (uint32_t)(jbase + k), 1.f) : 0.f;
+							av[k] = owned[k] ? ((tc.on && alb.sw.type == LN_cub) ? line_value_vt(alb, (uint32_t)(jbase + k), 1.f, tc) : line_value_v(alb, (uint32_t)(jbase + k), 1.f)) : 0.f;
 					}
 				} else {
 #pragma unroll
@@ -489,7 +495,7 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 								const int e = w * G::NP + p0 + k;
 								const int j = jbase + k;
 								float f = fslot ? fslot[e]
-								                : line_value_v(flb, (uint32_t)j, fmul ? (mconst ? pf : fmul[e]) : 1.f);
+								                : ((tc.on && flb.sw.type == LN_cub) ? line_value_vt(flb, (uint32_t)j, fmul ? (mconst ? pf : fmul[e]) : 1.f, tc) : line_value_v(flb, (uint32_t)j, fmul ? (mconst ? pf : fmul[e]) : 1.f));
 								if (owned[k]) inc[k] = rint32w(coeff * f);
 								ofs[k] = (uint32_t)pm_offset(pmS != nullptr, fpmS != nullptr,
 										pmS ? pmS[e] : 0.f, fpmS ? fpmS[e] : 0.f, f, 0x1p31f);
@@ -562,7 +568,7 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 							plb = line_block_v(pls0, len, false, 0.f);
 #pragma unroll
 							for (int k = 0; k < T; ++k)
-								if (owned[k]) out[w * G::NP + p0 + k] = line_value_v(plb, (uint32_t)(jbase + k), 1.f);
+								if (owned[k]) out[w * G::NP + p0 + k] = ((tc.on && plb.sw.type == LN_cub) ? line_value_vt(plb, (uint32_t)(jbase + k), 1.f, tc) : line_value_v(plb, (uint32_t)(jbase + k), 1.f));
 							pmaS = out;
 						}
 #pragma unroll
@@ -613,7 +619,7 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 							const int e = w * G::NP + p0 + k;
 							const int j = jbase + k;
 							float f = fconst ? fc : (fslot ? fslot[e]
-							                : line_value_v(flb, (uint32_t)j, fmul ? (mconst ? pf : fmul[e]) : 1.f));
+							                : ((tc.on && flb.sw.type == LN_cub) ? line_value_vt(flb, (uint32_t)j, fmul ? (mconst ? pf : fmul[e]) : 1.f, tc) : line_value_v(flb, (uint32_t)j, fmul ? (mconst ? pf : fmul[e]) : 1.f)));
 							inc[k] = (unsigned long long)rint64(coeff * f);
 							ofs[k] = (unsigned long long)pm_offset(pmS != nullptr, fpmS != nullptr,
 									pmS ? pmS[e] : 0.f, fpmS ? fpmS[e] : 0.f, f, phase_scale);
@@ -642,7 +648,7 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 					if (!selfmod) {
 #pragma unroll
 						for (int k = 0; k < T; ++k)
-							if (owned[k]) s[k] = ras_sample(rp, cyc[k], phf[k], true); /* rasg.h:692-743 */
+							if (owned[k]) s[k] = ras_sample(rp, cyc[k], phf[k], true, rp.line == LN_cub && cub_map_is_tail(tc, (uint32_t)(jbase + k))); /* rasg.h:692-743 */
 					} else {
 						/* rasg.h:242-280 per-sample form with feedback */
 						u32_alias *tmp = (u32_alias *)(slots + (size_t)st.tmp * G::SLOT);
@@ -660,7 +666,7 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 							float fb_s = op->fb_s, prev_s = op->prev_s;
 							for (uint32_t j = 0; j < len; ++j) {
 								const uint32_t e = entry_of<W, T>(j);
-								float pma_v = smS ? smS[e] : line_value_v(plb, j, 1.f);
+								float pma_v = smS ? smS[e] : ((tc.on && plb.sw.type == LN_cub) ? line_value_vt(plb, j, 1.f, tc) : line_value_v(plb, j, 1.f));
 								float pm_a = fb_s * pma_v * 0.5f;
 								float phase = scratch[e] + pm_a;
 								int32_t cycle_adj = (int32_t)floorf(phase);
@@ -806,7 +812,7 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 						if (to_voice) {
 							const int j = jbase + k;
 							vrow[done + j] = r;
-							if (prow) prow[done + j] = pan_goal ? line_value_v(plb2, (uint32_t)j, 1.f) : pl.v0;
+							if (prow) prow[done + j] = pan_goal ? ((tc.on && plb2.sw.type == LN_cub) ? line_value_vt(plb2, (uint32_t)j, 1.f, tc) : line_value_v(plb2, (uint32_t)j, 1.f)) : pl.v0;
 						} else {
 							slot_put<W, T>(out, w, p0 + k, r);
 						}
@@ -866,7 +872,7 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 						vrow[done + j] = src[e];
 						if (prow)
 							prow[done + j] = panS ? panS[e]
-								: (pan_goal ? line_value_v(plb2, (uint32_t)j, 1.f) : pl.v0);
+								: (pan_goal ? ((tc.on && plb2.sw.type == LN_cub) ? line_value_vt(plb2, (uint32_t)j, 1.f, tc) : line_value_v(plb2, (uint32_t)j, 1.f)) : pl.v0);
 					}
 				}
 				team_sync<V>();
@@ -883,6 +889,7 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 				const bool inf = (op_flags & OPF_TIME_INF) != 0;
 				--depth;
 				const uint32_t outer = (st.flags & SF_BEGIN) ? parent_len : uni((uint32_t)misc->len_stack[depth]);
+				const uint32_t outer_rem = (st.flags & SF_BEGIN) ? parent_rem : uni((uint32_t)misc->rem_stack[depth]);
 				if (!inf && !(st.flags & SF_LAYER) && !(st.which & OX_VOICE)) {
 					float *out = slots + (size_t)st.out * G::SLOT;
 #pragma unroll
@@ -900,6 +907,7 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 					/* (a pan modulator ending at the voice's level gives the length back to
 					 * the steps after it: generator.c:762-771 run them for the carrier's) */
 					cur_len = outer;
+					cur_rem = outer_rem;
 				}
 				if (tid == 0 && !inf) op->time -= len;
 			}

@@ -34,6 +34,7 @@ struct Misc {
 	WaveConst wc[12];      /* per-wave constants, copied from the launch parameters */
 	int32_t tab_of_wave[12];
 	uint16_t len_stack[MAX_NEST + 1]; /* block lengths per nesting level (<= 1024 each) */
+	uint16_t rem_stack[MAX_NEST + 1]; /* frames until the level's operator stops, TAIL_FAR at most (TailCtx.rem) */
 	uint32_t tot32[16];
 	unsigned long long tot64[16];
 	uint32_t flag;

@@ -271,6 +271,25 @@ SAU_HD float sweep_value_inl(const Sweep &s, uint32_t i) {
 
 SAU_HD_CALL float sweep_value(const Sweep &s, uint32_t i) { return sweep_value_inl(s, i); }
 
+/* The reference build's loop tails. gcc vectorises sauLine_fill_cub two samples at a time and sauLine_map_cub four at a
+ * time, and gives the scalar epilogues another association than the vector bodies: x*x*x*h + h instead of
+ * (x*x*x + 1)*h, h = (v0 - vt)/2 -- the last sample of a fill of odd length, the last len % 4 samples of a map. Every
+ * other loop of sau/line.c has the same form in body and tail (the oracle's mode 2 = mode 1 + exactly these two,
+ * and equals the compiled reference on 15000 random programs). `len` is the length of the reference's call: its
+ * block -- 1024 frames from the start of its span, the span's last one shorter (Lattice below) -- cut where the
+ * operator, one of its ancestors or the voice stops (generator.c:694-698, 833-846), and for a fill where the sweep
+ * ends (sau/line.c:349-378). */
+SAU_HD float sweep_cub_tail(const Sweep &s, uint32_t i) {
+	const float x = (float)((int32_t)i + s.adj_pos) * s.k;
+	const float h = (s.v0 - s.vt) * 0.5f;
+	return s.vt + (x * x * x * h + h);
+}
+SAU_HD float shape_cub_tail(float x, float a, float b) {
+	const float y = (0.5f - x) * 2;
+	const float h = (a - b) * 0.5f;
+	return b + (y * y * y * h + h);
+}
+
 /* ---- ramp state machine -------------------------------------------------- */
 
 struct LineState { /* device copy of sauLine minus time_ms */
@@ -308,6 +327,53 @@ struct Lattice {
 	uint32_t call_len;  /* length of the spans after it: the host's call size */
 };
 SAU_HD Lattice lattice_none() { Lattice l; l.e0 = 0; l.span_left = 0xffffffffu; l.call_len = 0xffffffffu; return l; }
+
+/* Where the reference's calls end, for the loop tails of `cub` (sweep_cub_tail): the block being evaluated starts at frame
+ * `off` of the segment; `rem` frames from there the operator, one of its ancestors or the voice stops (TAIL_FAR or more:
+ * not within reach of any reference block that overlaps this one). */
+constexpr uint32_t TAIL_FAR = 0xFFFFu;
+struct TailCtx {
+	Lattice lat;
+	uint32_t ev_left; /* frames from the segment's start to the program's next event (~0u: none): blocks end there too */
+	uint32_t off, rem, on;
+};
+SAU_HD TailCtx tail_none() { TailCtx c; c.lat = lattice_none(); c.ev_left = 0xffffffffu; c.off = 0; c.rem = TAIL_FAR; c.on = 0; return c; }
+/* the reference block that holds frame f of the segment: [bs, be), segment-relative (bs may lie before the segment) */
+SAU_HD void ref_block_at(const Lattice &lat, uint32_t ev_left, uint32_t f, long long &bs, long long &be) {
+	uint32_t sp;
+	long long span_end;
+	if (f < lat.span_left) { sp = lat.e0 + f; span_end = (long long)lat.span_left; }
+	else {
+		const uint32_t r = (f - lat.span_left) % lat.call_len;
+		sp = r; span_end = (long long)f + (long long)(lat.call_len - r);
+	}
+	if (span_end > (long long)ev_left) span_end = (long long)ev_left; /* (the program's next event ends the span it falls in) */
+	bs = (long long)f - (long long)(sp % LAT_BLOCK);
+	be = bs + (long long)LAT_BLOCK;
+	if (be > span_end) be = span_end;
+}
+/* sample j of the block is the last of a sauLine_fill_cub call of odd length; goal_rem: frames of the sweep left at sample 0 */
+SAU_HD bool cub_fill_is_tail(const TailCtx &c, uint32_t j, uint32_t goal_rem) {
+	if (!c.on) return false;
+	const uint32_t f = c.off + j;
+	long long bs, be;
+	ref_block_at(c.lat, c.ev_left, f, bs, be);
+	long long fe = be;
+	if (c.rem < TAIL_FAR && (long long)c.off + c.rem < fe) fe = (long long)c.off + c.rem;
+	if ((long long)c.off + goal_rem < fe) fe = (long long)c.off + goal_rem;
+	return (long long)f + 1 == fe && (((fe - bs) & 1) != 0);
+}
+/* sample j of the block is among the last len % 4 of a sauLine_map_cub call */
+SAU_HD bool cub_map_is_tail(const TailCtx &c, uint32_t j) {
+	if (!c.on) return false;
+	const uint32_t f = c.off + j;
+	long long bs, be;
+	ref_block_at(c.lat, c.ev_left, f, bs, be);
+	long long fe = be;
+	if (c.rem < TAIL_FAR && (long long)c.off + c.rem < fe) fe = (long long)c.off + c.rem;
+	const long long len = fe - bs;
+	return (long long)f - bs >= (len & ~3ll);
+}
 
 /* advance_len (sau/line.c:385-398) for k >= 1 consecutive blocks of b >= 1 frames each, closed form */
 SAU_HD void line_hold_blocks(LineState &o, uint32_t b, uint32_t k) {
@@ -397,6 +463,7 @@ struct LineBlock {
 	uint32_t goal_len;
 	bool mul_goal, mul_hold;
 	float hold;
+	uint32_t goal_rem; /* frames of the sweep left at the block's first sample, not cut at the block's length (TailCtx) */
 };
 
 /* The no-sweep part of sauLine_run: advance_len (sau/line.c:385-398). After it
@@ -411,7 +478,7 @@ SAU_HD void line_advance_hold(LineState &o, uint32_t len, const Lattice &lat, ui
 SAU_HD LineBlock line_begin_body(LineState &o, uint32_t len, bool have_mul, float mul0,
 		const Lattice &lat, uint32_t off) {
 	LineBlock b;
-	b.goal_len = 0; b.mul_goal = false; b.mul_hold = false; b.hold = 0.f;
+	b.goal_len = 0; b.mul_goal = false; b.mul_hold = false; b.hold = 0.f; b.goal_rem = 0;
 	b.sw = sweep_setup(LN_sah, 0.f, 0.f, 0, 1);
 	bool hold;
 	if (!(o.flags & LP_GOAL)) {
@@ -434,6 +501,7 @@ SAU_HD LineBlock line_begin_body(LineState &o, uint32_t len, bool have_mul, floa
 		uint32_t glen = 0;
 		if (o.pos < o.end) {
 			glen = o.end - o.pos;
+			b.goal_rem = glen;
 			if (glen > len) glen = len;
 			b.sw = sweep_setup(o.type, o.v0, o.vt, o.pos, o.end);
 			b.mul_goal = mul;
@@ -467,6 +535,14 @@ SAU_HD_CALL float line_value(const LineBlock &b, uint32_t i, float mul_i) {
 		return b.mul_goal ? v * mul_i : v;
 	}
 	return b.mul_hold ? b.hold * mul_i : b.hold;
+}
+/* ... with the reference's loop tails (only `cub` has any) */
+SAU_HD_CALL float line_value_t(const LineBlock &b, uint32_t i, float mul_i, const TailCtx &tc) {
+	if (i < b.goal_len && b.sw.type == LN_cub && cub_fill_is_tail(tc, i, b.goal_rem)) {
+		const float v = sweep_cub_tail(b.sw, i);
+		return b.mul_goal ? v * mul_i : v;
+	}
+	return line_value(b, i, mul_i);
 }
 
 /* The same two for callers that keep line states and blocks in registers: arguments and
@@ -513,6 +589,14 @@ SAU_HD_CALL float line_value_v(LineBlock b, uint32_t i, float mul_i) {
 	}
 	return b.mul_hold ? b.hold * mul_i : b.hold;
 }
+/* ... with the reference's loop tails (only `cub` has any); the block loop's form of line_value_t */
+SAU_HD_CALL float line_value_vt(LineBlock b, uint32_t i, float mul_i, TailCtx tc) {
+	if (tc.on && i < b.goal_len && b.sw.type == LN_cub && cub_fill_is_tail(tc, i, b.goal_rem)) {
+		const float v = sweep_cub_tail(b.sw, i);
+		return b.mul_goal ? v * mul_i : v;
+	}
+	return line_value_v(b, i, mul_i);
+}
 
 /* sau/line.c:456-473 */
 SAU_HD void line_skip(LineState &o, uint32_t len, const Lattice &lat, uint32_t off) {
@@ -547,7 +631,7 @@ struct LineUpdate {
 	uint32_t flags; /* LP_*; 0 = no update */
 };
 
-SAU_HD void line_copy(LineState &o, const LineUpdate &src) {
+SAU_HD void line_copy(LineState &o, const LineUpdate &src, bool loop_tails = false) {
 	if (!src.flags)
 		return;
 	line_lat_flush(o); /* an event ends the reference's block */
@@ -565,8 +649,8 @@ SAU_HD void line_copy(LineState &o, const LineUpdate &src) {
 			 * without a ratio buffer). */
 			if (o.flags & LP_GOAL_RATIO) o.flags |= LP_STATE_RATIO;
 			else o.flags &= ~LP_STATE_RATIO;
-			if (b.goal_len > 0)
-				o.v0 = sweep_value(b.sw, 0);
+			if (b.goal_len > 0) /* (a fill of length 1: for `cub` the reference's scalar loop tail, sweep_cub_tail) */
+				o.v0 = (loop_tails && b.sw.type == LN_cub) ? sweep_cub_tail(b.sw, 0) : sweep_value(b.sw, 0);
 			/* else: sauLine_get wrote nothing; reference then reads an
 			 * uninitialised float -- unreachable in practice because a set
 			 * goal always has pos < end between blocks. */
@@ -863,7 +947,7 @@ SAU_HD void ras_ends(const RasParams &c, uint32_t cycle, float &a, float &b) {
  * reference build only in how -ffast-math associated the Perlin scaling: the block loop (vector
  * body and scalar tail alike) computes (a * phase) * amp and (b * amp) * (phase - 1), the six
  * per-sample loops keep the source's a * (amp * phase) and b * (amp * (phase - 1)). */
-SAU_HD float ras_sample(const RasParams &c, uint32_t cycle, float phase, bool block) {
+SAU_HD float ras_sample(const RasParams &c, uint32_t cycle, float phase, bool block, bool cub_tail = false) {
 	float a, b;
 	ras_ends(c, cycle, a, b);
 	if (c.flags & RO_PERLIN) {
@@ -887,6 +971,7 @@ SAU_HD float ras_sample(const RasParams &c, uint32_t cycle, float phase, bool bl
 		a *= fabsf(a);
 		b *= fabsf(b);
 	}
+	if (cub_tail && c.line == LN_cub) return shape_cub_tail(phase, a, b); /* (the last 1-3 samples of the reference's block: TailCtx) */
 	return shape_val(c.line, phase, a, b);
 }
 

@@ -92,17 +92,17 @@ SAU_HD void apply_update(DevOp &n, const OpUpdate &u, const WaveConst *wc) {
 	default: break;
 	}
 	if (osc) {
-		line_copy(n.line[L_FREQ], u.line[L_FREQ]);
-		line_copy(n.line[L_FREQ2], u.line[L_FREQ2]);
-		line_copy(n.line[L_PMA], u.line[L_PMA]);
+		line_copy(n.line[L_FREQ], u.line[L_FREQ], u.loop_tails != 0);
+		line_copy(n.line[L_FREQ2], u.line[L_FREQ2], u.loop_tails != 0);
+		line_copy(n.line[L_PMA], u.line[L_PMA], u.loop_tails != 0);
 	}
 	if (u.params & POPP_TIME) {
 		n.time = u.time;
 		if (u.time_inf) n.flags |= OPF_TIME_INF; else n.flags &= ~OPF_TIME_INF;
 	}
-	line_copy(n.line[L_AMP], u.line[L_AMP]);
-	line_copy(n.line[L_AMP2], u.line[L_AMP2]);
-	line_copy(n.line[L_PAN], u.line[L_PAN]);
+	line_copy(n.line[L_AMP], u.line[L_AMP], u.loop_tails != 0);
+	line_copy(n.line[L_AMP2], u.line[L_AMP2], u.loop_tails != 0);
+	line_copy(n.line[L_PAN], u.line[L_PAN], u.loop_tails != 0);
 }
 
 } /* namespace saudev */

@@ -66,7 +66,7 @@ struct OpUpdate {
 	uint32_t ras_line, ras_flags, ras_func, ras_level, ras_alpha;
 	uint32_t phase, seed;
 	float coeff;
-	uint32_t pad;
+	uint32_t loop_tails;   /* the reference build's loop tails are reproduced (sau_dev_math.h: TailCtx); was padding */
 	LineUpdate line[L_COUNT];
 };
 
@@ -239,10 +239,14 @@ struct VoiceDesc {
 	uint32_t chain_base, n_chain;/* row pairs for its self-modulated oscillators (step_may_chain steps, in plan order) */
 	uint32_t inc_base, n_inc;    /* row pairs for saved phase increments of its oscillator steps (in plan order), or n_inc = 0 */
 	uint32_t look_base, n_look;  /* look-back rows for its running-sum oscillators (a voice without feedback chains), or n_look = 0 */
+	uint32_t ev_left;            /* frames from the segment's first frame to its program's next event (~0u: none): a reference
+	                              * block ends there whichever span it lies in (TailCtx) */
 };
 
 enum : uint32_t {
 	VD_NO_FAST = 1u << 0, /* graph visits an operator twice or has a cycle guard */
+	VD_MORE = 1u << 1,    /* the voice goes on after this segment (its blocks are not cut at run_len: TailCtx.rem) */
+	VD_TAILS = 1u << 2,   /* the reference build's loop tails are reproduced */
 };
 
 /* Per-voice result of a segment, read by the mixer. */

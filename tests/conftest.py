@@ -12,6 +12,10 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 # every plan the engine takes from its cache of graph shapes is compared with a fresh compile (engine.cpp)
 os.environ.setdefault("SAU_AMD_PLAN_CHECK", "1")
+# The suite's programs are compared with the oracle's mode 1 (the loop bodies' forms everywhere), which does not depend on
+# the host's call size; the product's default reproduces the compiled reference's loop tails of `cub` as well (mode 2, which
+# does), and tests/test_loop_tails.py and tests/test_gpu_vs_ref.py switch that on for their renders.
+os.environ.setdefault("SAU_AMD_LOOP_TAILS", "0")
 
 
 def pytest_configure(config):

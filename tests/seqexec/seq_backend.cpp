@@ -75,11 +75,13 @@ struct SeqBackend : public Backend {
 		std::vector<uint32_t> tmpu(block);
 		vrow.assign(seg_len, 0.f);
 		uint32_t done = 0, produced = 0;
-		uint32_t stack[MAX_NEST + 2];
+		uint32_t stack[MAX_NEST + 2], rstack[MAX_NEST + 2];
 		while (done < vd.run_len) {
 			if (lo[vd.carr_local].time == 0) break;
 			uint32_t blen = std::min(block, vd.run_len - done);
 			uint32_t depth = 0, cur_len = blen;
+			/* frames until the operator being evaluated, an ancestor or the voice stops (the reference cuts its blocks there) */
+			uint32_t cur_rem = (vd.flags & VD_MORE) ? TAIL_FAR : std::min(vd.run_len - done, TAIL_FAR);
 			bool ended = false;
 			for (uint32_t si = 0; si < vd.plan_len && !ended; ++si) {
 				Step st = steps[vd.plan_ofs + si];
@@ -91,10 +93,14 @@ struct SeqBackend : public Backend {
 				DevOp &op = lo[st.op];
 				uint32_t parent_len = cur_len;
 				if (st.flags & SF_BEGIN) {
+					rstack[depth] = cur_rem;
 					stack[depth++] = cur_len;
 					if (!(op.flags & OPF_TIME_INF) && op.time < cur_len) cur_len = op.time;
+					if (!(op.flags & OPF_TIME_INF) && op.time < cur_rem) cur_rem = op.time;
 				}
 				const uint32_t len = cur_len;
+				TailCtx tc;
+				tc.lat = vd.lat; tc.ev_left = vd.ev_left; tc.off = done; tc.rem = cur_rem; tc.on = (vd.flags & VD_TAILS) ? 1u : 0u;
 				switch (st.kind) {
 				case ST_ZERO:
 					for (uint32_t j = 0; j < len; ++j) slot[st.out][j] = 0.f;
@@ -103,7 +109,7 @@ struct SeqBackend : public Backend {
 					const float *mul = st.fmul != NO_SLOT ? slot[st.fmul].data() : nullptr;
 					LineBlock lb = line_begin(op.line[st.which], len, mul != nullptr, mul ? mul[0] : 0.f, vd.lat, done);
 					for (uint32_t j = 0; j < len; ++j)
-						slot[st.out][j] = line_value(lb, j, mul ? mul[j] : 1.f);
+						slot[st.out][j] = line_value_t(lb, j, mul ? mul[j] : 1.f, tc);
 					if (st.flags & SF_SKIP2) line_skip(op.line[st.tmp], len, vd.lat, done);
 					break;
 				}
@@ -112,7 +118,7 @@ struct SeqBackend : public Backend {
 					bool active = (ls.v0 != 0.f) || (ls.flags & LP_GOAL);
 					if (active) {
 						LineBlock lb = line_begin(ls, len, false, 0.f, vd.lat, done);
-						for (uint32_t j = 0; j < len; ++j) slot[st.out][j] = line_value(lb, j, 1.f);
+						for (uint32_t j = 0; j < len; ++j) slot[st.out][j] = line_value_t(lb, j, 1.f, tc);
 					} else {
 						line_skip(ls, len, vd.lat, done);
 						for (uint32_t j = 0; j < len; ++j) slot[st.out][j] = 0.f;
@@ -140,14 +146,14 @@ struct SeqBackend : public Backend {
 						if (fslot) for (uint32_t j = 0; j < len; ++j) fv[j] = fslot[j];
 						else {
 							LineBlock lb = line_begin(op.line[L_FREQ], len, fmul != nullptr, fmul ? fmul[0] : 0.f, vd.lat, done);
-							for (uint32_t j = 0; j < len; ++j) fv[j] = line_value(lb, j, fmul ? fmul[j] : 1.f);
+							for (uint32_t j = 0; j < len; ++j) fv[j] = line_value_t(lb, j, fmul ? fmul[j] : 1.f, tc);
 							line_skip(op.line[L_FREQ2], len, vd.lat, done);
 						}
 					}
 					if (ampS) for (uint32_t j = 0; j < len; ++j) av[j] = ampS[j];
 					else {
 						LineBlock lb = line_begin(op.line[L_AMP], len, false, 0.f, vd.lat, done);
-						for (uint32_t j = 0; j < len; ++j) av[j] = line_value(lb, j, 1.f);
+						for (uint32_t j = 0; j < len; ++j) av[j] = line_value_t(lb, j, 1.f, tc);
 						line_skip(op.line[L_AMP2], len, vd.lat, done);
 					}
 					bool selfmod = is_osc && smS != nullptr;
@@ -155,7 +161,7 @@ struct SeqBackend : public Backend {
 						LineState &pl = op.line[L_PMA];
 						if ((pl.v0 != 0.f) || (pl.flags & LP_GOAL)) {
 							LineBlock lb = line_begin(pl, len, false, 0.f, vd.lat, done);
-							for (uint32_t j = 0; j < len; ++j) pv[j] = line_value(lb, j, 1.f);
+							for (uint32_t j = 0; j < len; ++j) pv[j] = line_value_t(lb, j, 1.f, tc);
 							selfmod = true;
 						} else line_skip(pl, len, vd.lat, done);
 					} else if (smS) for (uint32_t j = 0; j < len; ++j) pv[j] = smS[j];
@@ -200,7 +206,7 @@ struct SeqBackend : public Backend {
 							op.cycle_phase += (uint64_t)rint64(coeff * fv[j]);
 							uint32_t cyc; float ph;
 							ras_split(cp, cyc, ph);
-							if (!selfmod) s[j] = ras_sample(rp, cyc, ph, true);
+							if (!selfmod) s[j] = ras_sample(rp, cyc, ph, true, rp.line == LN_cub && cub_map_is_tail(tc, j));
 							else { /* rasg.h:242-280 */
 								float pm_a = op.fb_s * pv[j] * 0.5f;
 								float phase = ph + pm_a;
@@ -251,7 +257,7 @@ struct SeqBackend : public Backend {
 						if (goal) lb = line_begin(pl, len, false, 0.f, vd.lat, done); else line_skip(pl, len, vd.lat, done);
 						for (uint32_t j = 0; j < len; ++j) {
 							vrow[done + j] = slot[st.out][j];
-							if (!prow.empty()) prow[done + j] = goal ? line_value(lb, j, 1.f) : pl.v0;
+							if (!prow.empty()) prow[done + j] = goal ? line_value_t(lb, j, 1.f, tc) : pl.v0;
 						}
 						produced += len;
 					}
@@ -266,7 +272,7 @@ struct SeqBackend : public Backend {
 					for (uint32_t j = 0; j < len; ++j) {
 						vrow[done + j] = slot[st.out][j];
 						if (!prow.empty())
-							prow[done + j] = panS ? panS[j] : (goal ? line_value(lb, j, 1.f) : pl.v0);
+							prow[done + j] = panS ? panS[j] : (goal ? line_value_t(lb, j, 1.f, tc) : pl.v0);
 					}
 					produced += len;
 					break;
@@ -283,7 +289,7 @@ struct SeqBackend : public Backend {
 					/* the carrier's end sets the length of the voice-level steps (generator.c:839-846);
 					 * a pan modulator ending at this level gives the length back (generator.c:762-771) */
 					if (depth == 0 && st.op == vd.carr_local) { cur_len = len; if (len == 0) ended = true; }
-					else cur_len = stack[depth];
+					else { cur_len = stack[depth]; cur_rem = rstack[depth]; }
 				}
 			}
 			done += blen;
