@@ -744,6 +744,7 @@ public:
 				fp.vlists = vlists_.p; fp.split_cf = 1; fp.rows_cf = rows_cf;
 				fp.look_words_real = look_words_real_ && fp.look ? 1u : 0u;
 			}
+			fp.cub_ok = use_fast && ft * tab_bytes + 16 * area_cf(FAST_CUB_ROWS) + 1024 <= lds_limit_ ? 1u : 0u;
 			/* the build for voices with chains and nothing to scan: as many rows per pass as fit beside the tables */
 			fp.lean_on = chains && lean_enabled_ ? 1u : 0u;
 			fp.rows_lean = 4;
@@ -927,6 +928,26 @@ public:
 						g0 = fk_grid_ - mix_cus_;
 					launch_fast(0, g0);
 					fp.dyn_chunks = 0;
+				}
+				{ /* closed-form voices with the loop tails of `cub` R segments (FastInfo.cub): the build with that code,
+				   * FAST_CUB_ROWS rows per pass, fixed strides over the same voices as the closed-form launch; returns at
+				   * once when analyze_kernel found none */
+					static size_t cub_configured[16];
+					FastParams q = main_build == 2 ? cfp : fp;
+					q.n_fast = seg.n_fast; q.rows = FAST_CUB_ROWS; q.mode = 0; q.only_multi = 0;
+					const size_t qlds = ft * tab_bytes + 16 * area_cf(FAST_CUB_ROWS);
+					if (fp.cub_ok) {
+						const uint32_t g4 = (seg.len + (60 * FAST_CUB_ROWS) - 1) / (60 * FAST_CUB_ROWS);
+						const unsigned long long want4 = (unsigned long long)seg.n_voices * (g4 < 64 ? g4 : 64);
+						const uint32_t grid4 = (uint32_t)((want4 + 15) / 16 > fk_grid_ ? fk_grid_ : (want4 + 15) / 16);
+						uint32_t k = (grid4 ? grid4 : 1) * 16 / seg.n_voices;
+						if (k > g4) k = g4;
+						q.dyn_chunks = k ? k : 1; q.dyn_static = 1;
+						const void *ck = (const void *)fast_kernel<(int)FAST_CUB_ROWS, 0, true>;
+						if (!raise_lds_attr(ck, qlds, cub_configured[dev_ & 15], err)) return false;
+						void *qargs[] = {(void *)&q};
+						HIP_OK(hipLaunchKernel(ck, dim3(grid4 ? grid4 : 1), dim3(1024), qargs, qlds, stream_));
+					}
 				}
 				if (!launched) return false;
 				{ /* row groups noted for a second evaluation: returns at once when there are none */

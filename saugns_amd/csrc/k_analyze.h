@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 	const VoiceDesc vd = P.voices[v];
 	const uint32_t *ids = P.op_ids + vd.ops_ofs;
 	bool bad = (vd.flags & VD_NO_FAST) != 0 || !P.enable;
-	bool seq = false, has_red = false;
+	bool seq = false, has_red = false, has_rcub = false;
 	uint32_t min_time = 0xFFFFFFFFu;
 	const Step *plan = P.steps + vd.plan_ofs;
 	/* An operator that has run out of time yields nothing, and neither it nor
@@ -107,7 +107,10 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 		 * self-modulation and pan ramps stay with the block loop */
 		/* `cub` with the reference build's loop tails (sau_dev_math.h: TailCtx): which samples take the tail form depends
 		 * on where the reference's blocks end; the block loop walks them, the closed forms here do not */
-		if ((vd.flags & VD_TAILS) && o.type == OT_RASEG && o.wave == LN_cub) bad = true;
+		/* (an R oscillator's `cub` segments are a map over whole blocks: closed-form voices with one take a build of the
+		 * time-parallel kernel with that code, FastInfo.cub; a `cub` sweep in progress is a fill that ends where the
+		 * sweep does: block loop) */
+		if ((vd.flags & VD_TAILS) && o.type == OT_RASEG && o.wave == LN_cub) has_rcub = true;
 		for (uint32_t ln = 0; ln < L_COUNT; ++ln) {
 			if (!(o.line[ln].flags & LP_GOAL)) continue;
 			if ((vd.flags & VD_TAILS) && o.line[ln].type == LN_cub) bad = true;
@@ -387,6 +390,7 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 		n_scan_out = n_scan;
 	}
 	if (has_red && seq_kind != 3) bad = true; /* (the several-pass and in-order forms do not carry noise sums) */
+	if (has_rcub && (!P.cub_ok || seq_kind != 0 || has_chain)) bad = true; /* (only the closed-form build has the tail code) */
 	if (has_chain && !bad) {
 		if (seq_kind == 1) bad = true; /* (one wave in order: not with chains) */
 		else {
@@ -401,7 +405,7 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 	 * closed-form voices have repair_kernel for that case (see FAST_REPAIR_SHIFT). */
 	if (seq || has_chain) ++x_carrier;
 	fi.n_chain = has_chain && !bad ? 1u : 0u;
-	fi.H = maxd + x_carrier; fi.xlead = x_carrier; fi.bail = 0; fi.n_fsteps = 0; fi.n_pass[0] = fi.n_pass[1] = fi.n_pass[2] = fi.n_pass[3] = 0; fi.seq = seq_kind; fi.n_scan = n_scan_out; fi.levels = levels_out; fi.lvl_bits = lvl_bits_out;
+	fi.H = maxd + x_carrier; fi.xlead = x_carrier; fi.bail = 0; fi.n_fsteps = 0; fi.n_pass[0] = fi.n_pass[1] = fi.n_pass[2] = fi.n_pass[3] = 0; fi.seq = seq_kind; fi.cub = has_rcub ? 1u : 0u; fi.n_scan = n_scan_out; fi.levels = levels_out; fi.lvl_bits = lvl_bits_out;
 	fi.total = 0;
 	if ((seq || has_chain) && !P.seq_enable) bad = true;
 	if (!bad && vd.nops <= P.max_ops && vd.plan_len <= P.max_steps && maxd >= 1 && maxd + x_carrier <= P.np / 2)
@@ -411,6 +415,7 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 	else if (fi.total && (seq_kind == 1 || seq_kind == 2)) atomicOr(&P.pass_flags[FAST_MAX_LEVELS + 2], 1u);
 	P.fast_done[v] = 0;
 	P.repair[(size_t)v * FAST_REPAIR_WORDS] = 0;
+	if (fi.total && fi.cub) atomicOr(&P.pass_flags[FAST_CUB_FLAG], 1u);
 	if (P.split_cf && fi.total) { /* the two launches' voice lists (any order: voices are independent) */
 		if (seq_kind == 0) P.vlists[atomicAdd(&P.pass_flags[FAST_CF_COUNT], 1u)] = v;
 		else if (seq_kind == 3) P.vlists[P.n_voices + atomicAdd(&P.pass_flags[FAST_LK_COUNT], 1u)] = v;

@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 	if (P.info[v].total == 0) return;
 	/* frames per block buffer: the launch that takes this kind of voice has its own rows per pass */
 	const bool lean = P.lean_on && P.info[v].seq == 2 && P.info[v].n_scan == 0; /* fast_kernel<T, 3>'s */
-	const uint32_t NP = 64 * (lean ? P.rows_lean : (P.info[v].seq == 1 || P.info[v].seq == 2) ? P.rows_multi :
+	const uint32_t NP = 64 * (P.info[v].cub ? FAST_CUB_ROWS : lean ? P.rows_lean : (P.info[v].seq == 1 || P.info[v].seq == 2) ? P.rows_multi :
 		(P.split_cf && P.info[v].seq == 0) ? P.rows_cf : P.rows);
 	const VoiceDesc vd = P.voices[v];
 	const uint32_t *ids = P.op_ids + vd.ops_ofs;

@@ -28,6 +28,8 @@ struct FastInfo {
 	uint32_t lvl_bits; /* 2 bits per such oscillator, in plan order: its level */
 	uint32_t xlead;  /* lead-in lanes beyond the nesting depth (ratio frequencies below modulated blocks); in H */
 	uint32_t n_chain; /* self-modulated oscillators handed to chain_kernel this segment */
+	uint32_t cub;     /* a closed-form voice with an R oscillator of `cub` segments and the reference's loop tails on: rendered by
+	                   * the closed-form build with the tail code, fast_kernel<4, 0, true>, and by no other launch */
 };
 
 struct FastStep;
@@ -49,7 +51,9 @@ constexpr uint32_t FAST_MAX_LEVELS = 3; /* running sums that depend on running s
 constexpr uint32_t FAST_REPAIR_SHIFT = 24; /* H + shift < 64 (H <= 32) */
 constexpr uint32_t FAST_MAX_REPAIR = 15;   /* noted row groups per voice and segment; more: block loop */
 constexpr uint32_t FAST_REPAIR_WORDS = 2 + 2 * FAST_MAX_REPAIR; /* count, pad, then (group, rows) pairs */
-constexpr uint32_t FAST_FLAGS = FAST_MAX_LEVELS + 7; /* pass_flags words */
+constexpr uint32_t FAST_FLAGS = FAST_MAX_LEVELS + 8; /* pass_flags words */
+constexpr uint32_t FAST_CUB_FLAG = FAST_MAX_LEVELS + 7; /* some voice has FastInfo.cub set */
+constexpr uint32_t FAST_CUB_ROWS = 4;                  /* rows per pass of that build */
 constexpr uint32_t FAST_CF_COUNT = FAST_MAX_LEVELS + 5; /* voices in FastParams.vlists[0]: closed-form ones of a segment that also has look-back voices */
 constexpr uint32_t FAST_LK_COUNT = FAST_MAX_LEVELS + 6; /* ... in vlists[1]: the look-back voices */
 constexpr uint32_t FAST_LEAN_FLAG = FAST_MAX_LEVELS + 4; /* ... some voice has feedback chains and no running sum to scan (fast_kernel<T, 3>) */
@@ -63,6 +67,8 @@ __device__ __forceinline__ uint32_t fast_list_of(uint32_t mode, uint32_t sum_lev
 constexpr uint32_t FR_CHAIN_IN = 4u << FAST_MAX_LEVELS; /* FastStep.ramp: the chain-input pass runs this step */
 constexpr uint32_t FR_FINAL_SKIP = 8u << FAST_MAX_LEVELS; /* ... the final pass does not: only chains' inputs needed it */
 constexpr uint32_t FT_CHAIN = 1u << 18;     /* FastStep.type: a feedback chain (rows = bits of FastStep.pan) */
+constexpr uint32_t FT_CUBTAIL = 1u << 19;   /* ... an R oscillator with `cub` segments and the reference's loop tails on: FastStep.phase0 =
+                                             * frames until it, an ancestor or the voice stops (TailCtx.rem) */
 constexpr uint32_t CHAIN_MARK = 0xC4A10001u; /* DevOp.ras_level of a W operator: chain_kernel staged its state */
 struct FastParams {
 	const VoiceDesc *voices;
@@ -148,6 +154,7 @@ struct FastParams {
 	 * per render (one closed-form, one with nested running sums) took 6.0 ms where they take 1.6 + 3.1 ms apart. */
 	uint32_t *vlists;     /* [2][n_voices], or NULL (one launch over every voice) */
 	uint32_t split_cf, rows_cf, look_words_real, look_groups;
+	uint32_t cub_ok;      /* the build with the `cub` tails will be launched (it fits LDS): FastInfo.cub voices may stay on this path */
 	uint32_t only_multi; /* this launch: only the voices fast_kernel<T, 2> leaves out (one wave in order, several passes) */
 	int8_t ctab_of_wave[12];
 	uint8_t cwave_of_tab[12];

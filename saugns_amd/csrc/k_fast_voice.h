@@ -36,7 +36,7 @@ __device__ __forceinline__ FastStep load_step_uniform(const FastStep *p) {
  * (frequency ramps, FM); the plain build stays as lean as closed-form voices
  * need it (the same code with the running-sum branches compiled in was 27 %
  * slower on them), and a kernel that may meet both kinds holds both copies. */
-template <int T, int SCAN, bool REPAIR = false>
+template <int T, int SCAN, bool REPAIR = false, bool CUB = false>
 __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v, const FastInfo &fi,
 		float *slots, unsigned long long *carry, const HerpC23 *t23, const HerpC01 *t01, const int l,
 		const uint32_t wpv, const uint32_t cstart, unsigned long long *lring = nullptr,
@@ -46,6 +46,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 	(void)NP;
 	const uint32_t fast_total = uni(fi.total);
 	if (fast_total == 0) return;
+	if ((uni(fi.cub) != 0) != CUB) return; /* (voices with the loop tails of `cub` R segments: the build with that code, and only it) */
 	const VoiceDesc vd = P.voices[v];
 	const uint32_t H = uni(fi.H);
 
@@ -612,7 +613,16 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 						uint32_t cyc;
 						float phf;
 						ras_split(cp, cyc, phf);
-						s[k] = ras_sample(rp, cyc, phf, true);
+						bool ctail = false;
+						if constexpr (CUB) {
+							if (f.type & FT_CUBTAIL) { /* the last len % 4 samples of the reference's block (sau_dev_math.h: TailCtx) */
+								TailCtx tc;
+								tc.lat = vd.lat; tc.ev_left = vd.ev_left; tc.off = 0; tc.rem = f.phase0; tc.on = 1;
+								const int t = t0 + k * (int)C;
+								ctail = t >= 0 && cub_map_is_tail(tc, (uint32_t)t);
+							}
+						}
+						s[k] = ras_sample(rp, cyc, phf, true, ctail);
 					}
 				} else if (type == OT_NOISE) {
 					const uint32_t nz = (f.type >> 8) & 0xff;
@@ -757,7 +767,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 			/* to the repair pass -- unless this is it, the group touches an end of the segment
 			 * (carried state sits at fixed lanes there) or the voice has running sums */
 			bool noted = false;
-			if (!REPAIR && !SCAN && P.repair_on && !first_group && !is_last_group &&
+			if (!REPAIR && !SCAN && !CUB && P.repair_on && !first_group && !is_last_group &&
 			    (int)(cg * T * C) - (int)H >= (int)FAST_REPAIR_SHIFT) {
 				uint32_t at = 0;
 				if (l == 0) at = atomicAdd(&rep[0], 1u);
@@ -787,7 +797,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 #else
 #define FK_ATTR __launch_bounds__(1024, FK_MINB)
 #endif
-template <int T, int SCAN>
+template <int T, int SCAN, bool CUB = false>
 __global__ void FK_ATTR fast_kernel(FastParams P) {
 	constexpr int NP = 64 * T;
 	constexpr int W = 16;
@@ -801,6 +811,7 @@ __global__ void FK_ATTR fast_kernel(FastParams P) {
 	if (SCAN == 1 && P.only_multi && P.pass_flags[FAST_MAX_LEVELS + 2] == 0) return; /* no voice the single-pass build left out */
 	if (SCAN == 3 && P.pass_flags[FAST_LEAN_FLAG] == 0) return; /* no voice with chains and nothing to scan */
 	if (SCAN == 0 && P.split_cf && P.pass_flags[FAST_CF_COUNT] == 0) return; /* no closed-form voice beside the look-back ones */
+	if (CUB && P.pass_flags[FAST_CUB_FLAG] == 0) return; /* no voice for the build with the `cub` tails */
 	if (SCAN == 2 && P.pass_flags[FAST_LK_COUNT] == 0) return; /* ... and the other way round */
 
 	HerpC23 *t23 = (HerpC23 *)lds;
@@ -848,7 +859,7 @@ __global__ void FK_ATTR fast_kernel(FastParams P) {
 			const uint32_t vi = task / K;
 			const uint32_t v = P.split_cf ? P.vlists[vi] : vi;
 			const FastInfo fi = P.info[v];
-			fast_voice<T, 0>(P, v, fi, slots, carry, t23, t01, l, 1u, 0u, nullptr, task - vi * K, K);
+			fast_voice<T, 0, false, CUB>(P, v, fi, slots, carry, t23, t01, l, 1u, 0u, nullptr, task - vi * K, K);
 		}
 		return;
 	}

@@ -338,41 +338,44 @@ struct TailCtx {
 	uint32_t off, rem, on;
 };
 SAU_HD TailCtx tail_none() { TailCtx c; c.lat = lattice_none(); c.ev_left = 0xffffffffu; c.off = 0; c.rem = TAIL_FAR; c.on = 0; return c; }
-/* the reference block that holds frame f of the segment: [bs, be), segment-relative (bs may lie before the segment) */
-SAU_HD void ref_block_at(const Lattice &lat, uint32_t ev_left, uint32_t f, long long &bs, long long &be) {
-	uint32_t sp;
-	long long span_end;
-	if (f < lat.span_left) { sp = lat.e0 + f; span_end = (long long)lat.span_left; }
+/* the reference block that holds sample j: frames already in it before the sample, frames from the sample to its end
+ * (>= 1) -- the block of 1024 from the start of its span, ended by the span's end, the program's next event, and
+ * where the operator (an ancestor, the voice) stops. 32-bit arithmetic throughout (frames stay far below 2^31). */
+SAU_HD void ref_block_at(const TailCtx &c, uint32_t j, uint32_t &in_blk, uint32_t &blk_rem) {
+	const uint32_t f = c.off + j;
+	uint32_t sp, span_rem;
+	if (f < c.lat.span_left) { sp = c.lat.e0 + f; span_rem = c.lat.span_left - f; }
 	else {
-		const uint32_t r = (f - lat.span_left) % lat.call_len;
-		sp = r; span_end = (long long)f + (long long)(lat.call_len - r);
+		const uint32_t r = (f - c.lat.span_left) % c.lat.call_len;
+		sp = r; span_rem = c.lat.call_len - r;
 	}
-	if (span_end > (long long)ev_left) span_end = (long long)ev_left; /* (the program's next event ends the span it falls in) */
-	bs = (long long)f - (long long)(sp % LAT_BLOCK);
-	be = bs + (long long)LAT_BLOCK;
-	if (be > span_end) be = span_end;
+	if (c.ev_left != 0xffffffffu && c.ev_left > f && c.ev_left - f < span_rem) span_rem = c.ev_left - f;
+	in_blk = sp % LAT_BLOCK;
+	blk_rem = LAT_BLOCK - in_blk;
+	if (span_rem < blk_rem) blk_rem = span_rem;
+	if (c.rem < TAIL_FAR && c.rem > j && c.rem - j < blk_rem) blk_rem = c.rem - j;
 }
 /* sample j of the block is the last of a sauLine_fill_cub call of odd length; goal_rem: frames of the sweep left at sample 0 */
 SAU_HD bool cub_fill_is_tail(const TailCtx &c, uint32_t j, uint32_t goal_rem) {
 	if (!c.on) return false;
-	const uint32_t f = c.off + j;
-	long long bs, be;
-	ref_block_at(c.lat, c.ev_left, f, bs, be);
-	long long fe = be;
-	if (c.rem < TAIL_FAR && (long long)c.off + c.rem < fe) fe = (long long)c.off + c.rem;
-	if ((long long)c.off + goal_rem < fe) fe = (long long)c.off + goal_rem;
-	return (long long)f + 1 == fe && (((fe - bs) & 1) != 0);
+	uint32_t in_blk, blk_rem;
+	ref_block_at(c, j, in_blk, blk_rem);
+	if (goal_rem > j && goal_rem - j < blk_rem) blk_rem = goal_rem - j;
+	return blk_rem == 1 && (((in_blk + blk_rem) & 1u) != 0);
 }
 /* sample j of the block is among the last len % 4 of a sauLine_map_cub call */
 SAU_HD bool cub_map_is_tail(const TailCtx &c, uint32_t j) {
 	if (!c.on) return false;
-	const uint32_t f = c.off + j;
-	long long bs, be;
-	ref_block_at(c.lat, c.ev_left, f, bs, be);
-	long long fe = be;
-	if (c.rem < TAIL_FAR && (long long)c.off + c.rem < fe) fe = (long long)c.off + c.rem;
-	const long long len = fe - bs;
-	return (long long)f - bs >= (len & ~3ll);
+	uint32_t in_blk, blk_rem;
+	ref_block_at(c, j, in_blk, blk_rem);
+	return in_blk >= ((in_blk + blk_rem) & ~3u);
+}
+/* (a real call for the time-parallel kernels, scalars only: inlined into their R branch once per row the predicate cost
+ * them up to 130 spilled VGPRs) */
+SAU_HD_CALL bool cub_map_is_tail_v(uint32_t e0, uint32_t span_left, uint32_t call_len, uint32_t ev_left, uint32_t rem, uint32_t j) {
+	TailCtx c;
+	c.lat.e0 = e0; c.lat.span_left = span_left; c.lat.call_len = call_len; c.ev_left = ev_left; c.off = 0; c.rem = rem; c.on = 1;
+	return cub_map_is_tail(c, j);
 }
 
 /* advance_len (sau/line.c:385-398) for k >= 1 consecutive blocks of b >= 1 frames each, closed form */
