@@ -744,7 +744,8 @@ public:
 				fp.vlists = vlists_.p; fp.split_cf = 1; fp.rows_cf = rows_cf;
 				fp.look_words_real = look_words_real_ && fp.look ? 1u : 0u;
 			}
-			fp.cub_ok = use_fast && ft * tab_bytes + 16 * area_cf(FAST_CUB_ROWS) + 1024 <= lds_limit_ ? 1u : 0u;
+			fp.cub_ok = use_fast && ft * tab_bytes + 16 * area_cf(FAST_CUB_ROWS) + 1024 <= lds_limit_ &&
+				(!look_split || ft * tab_bytes + 16 * area_of(FAST_CUB_ROWS) + LOOK_LDS_BYTES + 1024 <= lds_limit_) ? 1u : 0u;
 			/* the build for voices with chains and nothing to scan: as many rows per pass as fit beside the tables */
 			fp.lean_on = chains && lean_enabled_ ? 1u : 0u;
 			fp.rows_lean = 4;
@@ -848,6 +849,17 @@ public:
 							if (!launch_build(2, FT, grid2 ? grid2 : 1)) launched = false;
 						} else if (!SpreadLaunchOrder::get().ordered(dev_, stream_, [&]() { return launch_build(2, FT, grid2 ? grid2 : 1); })) {
 							launched = false;
+						}
+						if (fp.cub_ok) { /* look-back voices with the loop tails of `cub` R segments: the build with that code, same lists */
+							static size_t cub2_configured[16];
+							const void *ck2 = (const void *)fast_kernel<(int)FAST_CUB_ROWS, 2, true>;
+							const size_t lds2 = ft * tab_bytes + 16 * area_of(FAST_CUB_ROWS) + LOOK_LDS_BYTES;
+							if (!raise_lds_attr(ck2, lds2, cub2_configured[dev_ & 15], err)) return false;
+							auto go = [&]() -> bool {
+								void *a2[] = {(void *)&fp};
+								return hipLaunchKernel(ck2, dim3(grid2 ? grid2 : 1), dim3(1024), a2, lds2, stream_) == hipSuccess;
+							};
+							if (look_inside_ ? !go() : !SpreadLaunchOrder::get().ordered(dev_, stream_, go)) launched = false;
 						}
 					}
 				}

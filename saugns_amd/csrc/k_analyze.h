@@ -390,7 +390,7 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 		n_scan_out = n_scan;
 	}
 	if (has_red && seq_kind != 3) bad = true; /* (the several-pass and in-order forms do not carry noise sums) */
-	if (has_rcub && (!P.cub_ok || seq_kind != 0 || has_chain)) bad = true; /* (only the closed-form build has the tail code) */
+	if (has_rcub && (!P.cub_ok || (seq_kind != 0 && seq_kind != 3) || has_chain)) bad = true; /* (only the closed-form build has the tail code) */
 	if (has_chain && !bad) {
 		if (seq_kind == 1) bad = true; /* (one wave in order: not with chains) */
 		else {

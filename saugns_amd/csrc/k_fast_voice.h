@@ -880,7 +880,7 @@ __global__ void FK_ATTR fast_kernel(FastParams P) {
 		for (uint32_t j = g / wpv; j < NVl; j += slots_v) {
 			const uint32_t v = P.vlists[NV + j];
 			const FastInfo fi = P.info[v];
-			fast_voice<T, 2>(P, v, fi, slots, carry, t23, t01, l, wpv, g % wpv, lring, 0u, 0u, j);
+			fast_voice<T, 2, false, CUB>(P, v, fi, slots, carry, t23, t01, l, wpv, g % wpv, lring, 0u, 0u, j);
 		}
 		return;
 	}
