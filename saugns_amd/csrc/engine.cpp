@@ -139,6 +139,7 @@ bool Engine::handle_event(Stream &st, const EventNode &e, std::vector<OpUpdate> 
 			u.ras_func = od->mode.ras.func;
 			u.ras_level = od->mode.ras.level;
 			u.ras_alpha = od->mode.ras.alpha;
+			if (od->mode.ras.line == SAU_LINE_N_cub) m.ras_cub_seen = true;
 		}
 		if (od->type == SAU_POPT_N_wave && (od->params & SAU_POPP_MODE))
 			m.wave = od->mode.main < SAU_WAVE_NAMED ? od->mode.main : 0;
@@ -257,6 +258,8 @@ bool Engine::rebuild_plans(std::string &err) {
 					vn.plan.n_fast = sp.n_fast; vn.plan.n_fast_full = sp.n_fast_full; vn.plan.wave_mask = wmask;
 					vn.plan.has_camods = sp.has_camods; vn.plan.no_fast = sp.no_fast; vn.plan.static_block = sp.static_block;
 					vn.plan.selfmod = sp.selfmod; vn.plan.n_chain = sp.n_chain; vn.plan.n_osc = sp.n_osc;
+					vn.plan.ras_cub = false;
+					for (uint32_t id : shape_ids_) if (st.ops[id].ras_cub_seen) vn.plan.ras_cub = true;
 					vn.plan.n_steps = (uint32_t)sp.steps.size();
 				} else if (!compile_voice_plan(st.ops, vn.carr_op, vn.plan, err)) {
 					/* a voice whose carrier never got data stays silent */
@@ -356,7 +359,7 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 	std::vector<SegmentDesc::Stream> sdescs(streams_.size());
 	uint32_t n_main = 1, n_fpool = 0, max_ops = 1, n_pan = 0, max_steps = 1, n_fast = 1, n_fast_full = 0;
 	uint64_t wave_mask = 0;
-	bool maybe_block = false, serial = false, may_scan = false;
+	bool maybe_block = false, serial = false, may_scan = false, maybe_cub = false;
 	uint32_t sum_levels = 0, n_chain_rows = 0, n_inc_rows = 0, n_look_rows = 0;
 	for (size_t s = 0; s < streams_.size(); ++s) {
 		Stream &st = streams_[s];
@@ -421,6 +424,7 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 			bool voice_block = vn.plan.static_block; /* this voice may leave the closed-form path */
 			if (vn.plan.static_block || vn.plan.no_fast) maybe_block = true;
 			if (vn.plan.selfmod) serial = true;
+			if (vn.plan.ras_cub && loop_tails_) maybe_cub = true;
 			for (uint32_t id : vn.plan.op_ids) {
 				OpMirror &m = st.ops[id];
 				if (m.goal_seen || (m.line_set & (1u << L_PMA))) { maybe_block = true; voice_block = true; }
@@ -461,6 +465,7 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 	seg.wave_mask = wave_mask;
 	seg.maybe_block = maybe_block;
 	seg.serial = serial;
+	seg.maybe_cub = maybe_cub;
 	seg.may_scan = may_scan;
 	seg.sum_levels = sum_levels;
 	seg.n_chain_rows = n_chain_rows;

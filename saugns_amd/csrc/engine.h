@@ -54,6 +54,7 @@ struct SegmentDesc {
 	uint64_t wave_mask;       /* wave ids in use (bit per id) */
 	bool maybe_block;         /* some voice may need the block loop (sweeps, FM, ...) */
 	bool serial;              /* some voice may run a per-sample feedback recurrence (self-modulation) */
+	bool maybe_cub = false;   /* some voice has an R operator with `cub` segments and the loop tails are on (the builds with that code are launched) */
 	uint32_t n_chain_rows = 0;/* row pairs the voices' chain_base/n_chain span */
 	uint32_t n_inc_rows = 0;  /* row pairs the voices' inc_base/n_inc span (voices that may have running-sum phases) */
 	uint32_t n_look_rows = 0; /* rows the voices' look_base/n_look span (those of them without feedback chains) */
@@ -111,6 +112,7 @@ struct OpMirror { /* host-side knowledge about one operator */
 	LineState pan;                    /* mirrored exactly (never ratio-scaled) */
 	const sauProgramIDArr *mods[SAU_POP_NAMED] = {}; /* by use type; [0] unused */
 	uint8_t wave = 0;
+	bool ras_cub_seen = false;        /* an R operator that was ever given `cub` segments (conservative: SegmentDesc.maybe_cub) */
 	bool goal_seen = false;           /* some event gave one of its lines a sweep */
 	bool freq_goal_seen = false;      /* ... one of its frequency lines */
 	OpMirror() { pan = LineState{0, 0, 0, 0, 0, 0}; }
@@ -132,6 +134,7 @@ struct VoicePlan {
 	bool no_fast = false;          /* an operator is evaluated twice per block */
 	bool static_block = false;     /* graph has FM / feedback / R / filtered noise: block loop */
 	bool selfmod = false;          /* a self-modulation amount has modulators of its own */
+	bool ras_cub = false;          /* an R operator that was ever given `cub` segments */
 	uint32_t n_chain = 0;          /* oscillator steps that may run a feedback recurrence (step_may_chain) */
 	uint32_t n_osc = 0;            /* W and R oscillator steps (their phase increments may be saved between passes) */
 };

@@ -744,7 +744,7 @@ public:
 				fp.vlists = vlists_.p; fp.split_cf = 1; fp.rows_cf = rows_cf;
 				fp.look_words_real = look_words_real_ && fp.look ? 1u : 0u;
 			}
-			fp.cub_ok = use_fast && ft * tab_bytes + 16 * area_cf(FAST_CUB_ROWS) + 1024 <= lds_limit_ &&
+			fp.cub_ok = use_fast && seg.maybe_cub && ft * tab_bytes + 16 * area_cf(FAST_CUB_ROWS) + 1024 <= lds_limit_ &&
 				(!look_split || ft * tab_bytes + 16 * area_of(FAST_CUB_ROWS) + LOOK_LDS_BYTES + 1024 <= lds_limit_) ? 1u : 0u;
 			/* the build for voices with chains and nothing to scan: as many rows per pass as fit beside the tables */
 			fp.lean_on = chains && lean_enabled_ ? 1u : 0u;

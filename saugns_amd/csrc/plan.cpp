@@ -308,6 +308,8 @@ bool compile_voice_plan(const std::vector<OpMirror> &ops, uint32_t carrier,
 		if (m.type == SAU_POPT_N_raseg) out.static_block = true;
 		if (m.type == SAU_POPT_N_noise && m.wave == SAU_NOISE_N_re) out.static_block = true;
 	}
+	out.ras_cub = false;
+	for (uint32_t id : out.op_ids) if (ops[id].ras_cub_seen) out.ras_cub = true;
 	out.n_chain = 0;
 	out.n_osc = 0;
 	for (const Step &st : out.steps) {
