@@ -379,7 +379,11 @@ public:
 		(void)stereo;
 		for (int i = 0; i < (overlap_enabled_ ? 2 : 1); ++i) {
 			if (!pcm_[i].ensure(pcm_row_ * cfg_.n_streams, err)) return false;
-			HIP_OK(hipMemset(pcm_[i].p, 0, pcm_[i].cap * sizeof(int16_t)));
+			/* on the generator's own stream: a memset on the null stream is not ordered with a non-blocking stream's kernels,
+			 * and it may still be at work (it is asynchronous for device memory) when the first mixer writes -- zeros in the
+			 * PCM from some page on, seen on the second and later generators of a process (pooled blocks come back at once,
+			 * a first hipMalloc takes long enough to hide it) */
+			HIP_OK(hipMemsetAsync(pcm_[i].p, 0, pcm_[i].cap * sizeof(int16_t), stream_));
 		}
 		sets_[0].vout_rows = sets_[1].vout_rows = 0; /* re-sized on the next render */
 		return true;

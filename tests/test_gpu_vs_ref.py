@@ -116,3 +116,38 @@ def _compare(sa, oracle, tails):
     assert S["programs"] == 112
     if tails:
         assert S["gpu_equals_ref_exactly"] == 112
+
+
+def test_corpus_equals_the_compiled_reference_bit_for_bit(sa, oracle, tables, index):
+    """The reference's 95 scripts (program images of its own parser's output) through the drop-in generator with the
+    reference host's call size, against libsau_ref.so's render of the same images on this box: identical, every sample
+    (with the loop tails of `cub` reproduced -- the product's default; the rest of the suite compares with the oracle's
+    mode 1 and the committed heads of the reference's renders within 1 LSB)."""
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref/libsau_ref.so not present")
+    oracle.ref()
+    ref_tabs = oracle.ref_piluts()
+    sa.set_piluts(ref_tabs)
+    old = os.environ.get("SAU_AMD_LOOP_TAILS")
+    os.environ["SAU_AMD_LOOP_TAILS"] = "1"
+    try:
+        from conftest import load_program
+        n, frames, bad = 0, 0, []
+        for key in sorted(index["corpus"]):
+            prg = load_program(sa, key)
+            for stereo, rate in ((True, 44100), (False, 48000)):
+                ref = oracle.ref_render(prg.ptr, rate, stereo, chunk=11289, max_frames=400000)
+                got = sa.Generator(prg, rate).render(stereo=stereo, chunk=11289, max_frames=400000)
+                frames += len(ref)
+                if len(got) != len(ref) or (got != ref).any():
+                    d = np.abs(got[:len(ref)].astype(np.int32) - ref[:len(got)].astype(np.int32))
+                    bad.append((key, rate, int((d > 0).sum()), int(d.max())))
+            n += 1
+        print(f"\\ncorpus vs compiled reference: {n} scripts x 2 renders, {frames} samples, differing: {bad}")
+        assert n >= 90 and not bad, bad
+    finally:
+        if old is None:
+            os.environ.pop("SAU_AMD_LOOP_TAILS", None)
+        else:
+            os.environ["SAU_AMD_LOOP_TAILS"] = old
+        sa.set_piluts(tables)
