@@ -4,6 +4,23 @@
  * (-DFK_SWZ_BITS=2, 4, 5, tried in r02 against the 58 % bank-conflict cycles of the table gather) left
  * SQ_LDS_BANK_CONFLICT where it was or raised it by 3-5 % and cost 1-5 % in time for the two extra VALU
  * instructions per lookup (profiles/r02_b_lds_swizzle.json): the conflicts are the gather's own. */
+/* The voice rows are written once and read once, by another kernel (the mixer), 1.8 GB per config-3 step: streaming
+ * (non-temporal) stores here and loads there, so that they do not push anything else out of L2 and the Infinity Cache --
+ * 2.51 -> 2.41 ms per 441000-frame step (r03; the loads alone: 2.48). -DFK_TEMPORAL_ROWS: ordinary accesses. */
+#ifndef FK_TEMPORAL_ROWS
+#define FK_VSTORE(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define FK_VSTORE(p, v) (*(p) = (v))
+#endif
+/* ... and so are the chains' rows (inputs written by the chain-input pass, samples read by the final pass: 14 GB per
+ * config-5 step; 52.6 -> 51.3 ms, the feeder wave's loads compete with less) */
+#ifndef FK_TEMPORAL_ROWS
+#define FK_CSTORE(p, v) __builtin_nontemporal_store((v), (p))
+#define FK_CLOAD(p) __builtin_nontemporal_load(p)
+#else
+#define FK_CSTORE(p, v) (*(p) = (v))
+#define FK_CLOAD(p) (*(p))
+#endif
 #ifndef FK_SWZ_BITS
 #define FK_SWZ(i) (i)
 #else
@@ -152,7 +169,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 #pragma unroll
 					for (int k = 0; k < T; ++k) {
 						const int t = t0 + k * (int)C;
-						s[k] = (t >= 0 && t < (int)fast_total) ? crow[t] : 0.f;
+						s[k] = (t >= 0 && t < (int)fast_total) ? FK_CLOAD(&crow[t]) : 0.f;
 					}
 				} else if (type == OT_WAVE) {
 					const bool has_pm = f.pm_off != ~0u, has_fpm = f.fpm_off != ~0u;
@@ -295,8 +312,8 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 										const int t = t0 + k * (int)C;
 										const float a = from_line ? fast_line_value(pl, t) : slots[f.aux_off + k * 64];
 										if (l >= (int)H && t >= 0 && t < (int)fast_total) {
-											((u32_alias *)brow)[t] = S[k];
-											arow[t] = a;
+											FK_CSTORE(&((u32_alias *)brow)[t], S[k]);
+											FK_CSTORE(&arow[t], a);
 										}
 									}
 									continue;
@@ -404,8 +421,8 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 								const int t = t0 + k * (int)C;
 								const float a = from_line ? fast_line_value(pl, t) : slots[f.aux_off + k * 64];
 								if (l >= (int)H && t >= 0 && t < (int)fast_total) {
-									((u32_alias *)brow)[t] = ph[k];
-									arow[t] = a;
+									FK_CSTORE(&((u32_alias *)brow)[t], ph[k]);
+									FK_CSTORE(&arow[t], a);
 									if (FULL && t == (int)fast_total - 1) P.ops[f.gop].st_phase = phu[FULL ? k : 0];
 								}
 							}
@@ -712,7 +729,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 					for (int k = 0; k < T; ++k) {
 						const int t = t0 + k * (int)C;
 						const bool mine = REPAIR ? (l == (int)(H + FAST_REPAIR_SHIFT) && ((repair_rows >> k) & 1u)) : (l >= (int)H);
-						if (mine && t < (int)fast_total) vrow[t] = r[k];
+						if (mine && t < (int)fast_total) FK_VSTORE(&vrow[t], r[k]);
 					}
 				} else {
 #pragma unroll
@@ -757,7 +774,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 					const int t = t0 + k * (int)C;
 					const bool mine = REPAIR ? (l == (int)(H + FAST_REPAIR_SHIFT) && ((repair_rows >> k) & 1u)) : (l >= (int)H);
 					if (mine && t < (int)fast_total) {
-						vrow[t] = slots[f.out_off + k * 64];
+						FK_VSTORE(&vrow[t], slots[f.out_off + k * 64]);
 						if (prow) prow[t] = f.pm_off != ~0u ? slots[f.pm_off + k * 64] : f.pan;
 					}
 				}

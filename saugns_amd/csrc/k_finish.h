@@ -128,6 +128,11 @@ struct MixParams {
  * the reference's f32 accumulation order -- so the sum is bit-identical to
  * the CPU's and independent of scheduling.  Loads are issued eight voices
  * ahead of the (serially dependent) adds. */
+#ifndef FK_TEMPORAL_ROWS /* the voice rows are read once: streaming loads (see FK_VSTORE in k_fast_voice.h) */
+#define MIX_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define MIX_LOAD(p) (*(p))
+#endif
 constexpr int MIX_TILE = 256; /* voices whose constants are staged at a time */
 constexpr int MIX_AHEAD = 32; /* loads per batch and thread */
 /* PERSIST: a few workgroups (MixParams.grid_x of them) walk the frames in strides -- the form that runs beside the next
@@ -162,7 +167,7 @@ __device__ __forceinline__ void mix_body(const MixParams &P, const MixStream &ms
 			uint32_t r = 0;
 			auto load = [&](float *sv, uint32_t at) {
 #pragma unroll
-				for (int u = 0; u < MIX_AHEAD; ++u) sv[u] = base[(size_t)(at + u) * P.row_stride];
+				for (int u = 0; u < MIX_AHEAD; ++u) sv[u] = MIX_LOAD(&base[(size_t)(at + u) * P.row_stride]);
 			};
 			auto add = [&](const float *sv, uint32_t at) {
 #pragma unroll

@@ -8,7 +8,7 @@ from saugns_amd import voicebank as vb
 from oracle import pyoracle as po
 import test_gpu_units as tu
 tabs = np.fromfile(os.path.join(ROOT, "tests/golden/piluts_ref.f32"), dtype="<f4").reshape(12, 2048)
-sa.set_piluts(tabs); po.oracle_use_tables(tabs); po.oracle().ora_set_fastmath_forms(1)
+sa.set_piluts(tabs); po.oracle_use_tables(tabs); po.oracle().ora_set_fastmath_forms(1 if os.environ.get("SAU_AMD_LOOP_TAILS") == "0" else 2)  # the product default reproduces the loop tails: mode 2
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
 events = len(sys.argv) > 3 and sys.argv[3] == "events"
 rate = int(os.environ.get("RATE", "44100"))

@@ -11,7 +11,7 @@ from saugns_amd import voicebank as vb
 from oracle import pyoracle as po
 import test_gpu_units as T
 tabs = np.fromfile(os.path.join(ROOT, "tests/golden/piluts_ref.f32"), dtype="<f4").reshape(12, 2048)
-sa.set_piluts(tabs); po.build(ref=False); po.oracle_use_tables(tabs); po.oracle().ora_set_fastmath_forms(1)
+sa.set_piluts(tabs); po.build(ref=False); po.oracle_use_tables(tabs); po.oracle().ora_set_fastmath_forms(1 if os.environ.get("SAU_AMD_LOOP_TAILS") == "0" else 2)  # the product default reproduces the loop tails: mode 2
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 bad = 0
