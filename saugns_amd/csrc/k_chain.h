@@ -150,13 +150,41 @@ __device__ __forceinline__ void chain_feed(const ChainDesc &cd, bool live, int l
 	*acc = a_end;
 }
 
+/* (-DCHAIN_NT_ROWS: streaming accesses for the rows here as well -- measured 61.6 against 51.8 ms per config-5 step, r03:
+ * the feeder's loads then always go to HBM, where ordinary ones find part of what the chain-input pass wrote in the caches) */
+typedef uint32_t __attribute__((ext_vector_type(4))) chain_u32x4;
+typedef float __attribute__((ext_vector_type(4))) chain_f32x4;
+__device__ __forceinline__ uint4 chain_ld(const uint4 *p) {
+#ifdef CHAIN_NT_ROWS
+	const chain_u32x4 v = __builtin_nontemporal_load((const chain_u32x4 *)p);
+	return make_uint4(v.x, v.y, v.z, v.w);
+#else
+	return *p;
+#endif
+}
+__device__ __forceinline__ float4 chain_ld(const float4 *p) {
+#ifdef CHAIN_NT_ROWS
+	const chain_f32x4 v = __builtin_nontemporal_load((const chain_f32x4 *)p);
+	return make_float4(v.x, v.y, v.z, v.w);
+#else
+	return *p;
+#endif
+}
+__device__ __forceinline__ void chain_st(float4 *p, const float4 v) {
+#ifdef CHAIN_NT_ROWS
+	chain_f32x4 w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+	__builtin_nontemporal_store(w, (chain_f32x4 *)p);
+#else
+	*p = v;
+#endif
+}
 /* the rows' share of batch t into registers: issued one batch before chain_feed needs it, so that the feeder
  * never stands waiting for HBM inside the batch period (1.9 us) the chain wave gives it */
 __device__ __forceinline__ void chain_fetch(const ChainDesc &cd, bool live, uint32_t t, const uint4 *brow, const float4 *arow,
 		uint4 *bp, float4 *ap) {
 	if (!live || cd.mode == CM_INLINE) return;
 #pragma unroll
-	for (uint32_t q = 0; q < CHAIN_NQ; ++q) { bp[q] = brow[t / 4 + q]; ap[q] = arow[t / 4 + q]; }
+	for (uint32_t q = 0; q < CHAIN_NQ; ++q) { bp[q] = chain_ld(&brow[t / 4 + q]); ap[q] = chain_ld(&arow[t / 4 + q]); }
 }
 
 __global__ void __launch_bounds__(128) chain_kernel(FastParams P) {
@@ -229,14 +257,14 @@ __global__ void __launch_bounds__(128) chain_kernel(FastParams P) {
 			if (k >= 2 && c_lo + (k - 2) * CHAIN_BATCH < n) {
 				const float *sq = out_s(k & 1);
 #pragma unroll
-				for (uint32_t q = 0; q < CHAIN_NQ; ++q) op[(c_lo + (k - 2) * CHAIN_BATCH) / 4 + q] = *(const float4 *)(sq + chain_io_word(q, l));
+				for (uint32_t q = 0; q < CHAIN_NQ; ++q) chain_st(&op[(c_lo + (k - 2) * CHAIN_BATCH) / 4 + q], *(const float4 *)(sq + chain_io_word(q, l)));
 			}
 			__syncthreads(); /* (the first one also: tables staged) */
 		}
 		if (n_batches && c_lo + (n_batches - 1) * CHAIN_BATCH < n) {
 			const float *sq = out_s((n_batches - 1) & 1);
 #pragma unroll
-			for (uint32_t q = 0; q < CHAIN_NQ; ++q) op[(c_lo + (n_batches - 1) * CHAIN_BATCH) / 4 + q] = *(const float4 *)(sq + chain_io_word(q, l));
+			for (uint32_t q = 0; q < CHAIN_NQ; ++q) chain_st(&op[(c_lo + (n_batches - 1) * CHAIN_BATCH) / 4 + q], *(const float4 *)(sq + chain_io_word(q, l)));
 		}
 		if (n && cd.mode != CM_BASE && !(cd.mode == CM_INLINE && (cd.lflags & CL_FCONST))) o.st_phase = acc;
 		return;
