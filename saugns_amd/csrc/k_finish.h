@@ -260,7 +260,12 @@ __global__ void __launch_bounds__(256) mix_few_kernel(MixParams P) {
 		float v4[4], p4[4] = {vo.pan_const, vo.pan_const, vo.pan_const, vo.pan_const};
 		bool ok[4];
 		if (full && i0 + 4 <= vo.valid_len) {
-			const float4 q = *(const float4 *)row;
+			typedef float __attribute__((ext_vector_type(4))) f32x4;
+#ifndef FK_TEMPORAL_ROWS
+			const f32x4 q = __builtin_nontemporal_load((const f32x4 *)row);
+#else
+			const f32x4 q = *(const f32x4 *)row;
+#endif
 			v4[0] = q.x; v4[1] = q.y; v4[2] = q.z; v4[3] = q.w;
 			ok[0] = ok[1] = ok[2] = ok[3] = true;
 		} else {
