@@ -247,7 +247,7 @@ bool Engine::rebuild_plans(std::string &err) {
 						    chk.wave_mask != wmask || chk.n_fast != sp.n_fast || chk.n_fast_full != sp.n_fast_full ||
 						    chk.n_slots != sp.n_slots || chk.n_main != sp.n_main || chk.no_fast != sp.no_fast ||
 						    chk.static_block != sp.static_block || chk.selfmod != sp.selfmod || chk.n_chain != sp.n_chain ||
-						    chk.n_osc != sp.n_osc || chk.has_camods != sp.has_camods || chk.carr_local != sp.carr_local) {
+						    chk.n_osc != sp.n_osc || chk.has_camods != sp.has_camods || chk.carr_local != sp.carr_local || chk.wide != sp.wide) {
 							err = "plan cache: a cached plan differs from a fresh compile (SAU_AMD_PLAN_CHECK)";
 							return false;
 						}
@@ -257,7 +257,7 @@ bool Engine::rebuild_plans(std::string &err) {
 					vn.plan.carr_local = sp.carr_local; vn.plan.n_slots = sp.n_slots; vn.plan.n_main = sp.n_main;
 					vn.plan.n_fast = sp.n_fast; vn.plan.n_fast_full = sp.n_fast_full; vn.plan.wave_mask = wmask;
 					vn.plan.has_camods = sp.has_camods; vn.plan.no_fast = sp.no_fast; vn.plan.static_block = sp.static_block;
-					vn.plan.selfmod = sp.selfmod; vn.plan.n_chain = sp.n_chain; vn.plan.n_osc = sp.n_osc;
+					vn.plan.selfmod = sp.selfmod; vn.plan.n_chain = sp.n_chain; vn.plan.n_osc = sp.n_osc; vn.plan.wide = sp.wide;
 					vn.plan.ras_cub = false;
 					for (uint32_t id : shape_ids_) if (st.ops[id].ras_cub_seen) vn.plan.ras_cub = true;
 					vn.plan.n_steps = (uint32_t)sp.steps.size();
@@ -403,7 +403,8 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 			/* generator.c:756-762: dynamic pan needs per-sample values */
 			bool dyn = (carr.pan.flags & LP_GOAL) || vn.plan.has_camods;
 			d.pan_dynamic_row = dyn ? n_pan++ : ~0u;
-			d.flags = (vn.plan.no_fast ? VD_NO_FAST : 0) | (vn.duration ? VD_MORE : 0) | (loop_tails_ ? VD_TAILS : 0);
+			d.flags = (vn.plan.no_fast ? VD_NO_FAST : 0) | (vn.duration ? VD_MORE : 0) | (loop_tails_ ? VD_TAILS : 0) |
+				(vn.plan.wide ? VD_WIDE : 0);
 			d.lat = lat;
 			d.ev_left = ev_left;
 			d.chain_base = n_chain_rows; d.n_chain = vn.plan.n_chain;

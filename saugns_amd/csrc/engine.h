@@ -132,6 +132,7 @@ struct VoicePlan {
 	uint64_t wave_mask = 0;
 	bool has_camods = false;
 	bool no_fast = false;          /* an operator is evaluated twice per block */
+	bool wide = false;             /* step pairs with 16-bit buffer ids (sau_dev_types.h: wide plans); no_fast too */
 	bool static_block = false;     /* graph has FM / feedback / R / filtered noise: block loop */
 	bool selfmod = false;          /* a self-modulation amount has modulators of its own */
 	bool ras_cub = false;          /* an R operator that was ever given `cub` segments */

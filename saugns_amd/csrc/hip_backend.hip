@@ -476,11 +476,11 @@ public:
 		return true;
 	}
 
-	template <int W, int T, int V>
+	template <int W, int T, int V, bool HB = false>
 	bool launch_render(const RenderParams &rp, uint32_t grid, size_t lds, std::string &err) {
 		static size_t configured[16]; /* per device (function attributes are per device) */
-		if (!raise_lds_attr((const void *)render_kernel<W, T, V>, lds, configured[dev_ & 15], err)) return false;
-		hipLaunchKernelGGL((render_kernel<W, T, V>), dim3(grid), dim3(64 * W * V), lds, stream_, rp);
+		if (!raise_lds_attr((const void *)render_kernel<W, T, V, HB>, lds, configured[dev_ & 15], err)) return false;
+		hipLaunchKernelGGL((render_kernel<W, T, V, HB>), dim3(grid), dim3(64 * W * V), lds, stream_, rp);
 		HIP_OK(hipGetLastError());
 		return true;
 	}
@@ -494,8 +494,9 @@ public:
 		 * frames per lane). Many voices: sixteen single-wave teams per workgroup,
 		 * each with its own voice, so that every CU has 16 voices in flight. */
 		uint32_t W = geo_ ? 4 : 8, T = geo_ ? 4 : 2, V = 1;
+		bool HB = false; /* block buffers in HBM (render_kernel<1, 1, 1, true>) */
 		auto team_size = [&](uint32_t w, uint32_t t) {
-			size_t b = (size_t)w * 64 * t * sizeof(float) * seg.n_slots + (size_t)seg.max_ops * sizeof(DevOp) +
+			size_t b = (HB ? 0 : (size_t)w * 64 * t * sizeof(float) * seg.n_slots) + (size_t)seg.max_ops * sizeof(DevOp) +
 				sizeof(Misc) + (size_t)seg.max_steps * sizeof(Step) + 64;
 			return (b + 15) & ~(size_t)15;
 		};
@@ -510,6 +511,8 @@ public:
 		}
 		/* a voice with very many block buffers: one wave, one frame per lane (256 B per buffer) */
 		if (V == 1 && team_size(W, T) > lds_limit_) { W = 1; T = 1; }
+		/* more of them than LDS holds (wide plans: graphs nested hundreds of levels deep): the buffers go to HBM */
+		if (V == 1 && W == 1 && team_size(1, 1) > lds_limit_) HB = true;
 		/* LDS budget: slots + operator cache + misc per team, rest for tables */
 		const size_t team_bytes = team_size(W, T);
 		size_t fixed = team_bytes * V;
@@ -1015,12 +1018,17 @@ public:
 				block_grid_ = (seg.maybe_block || !use_fast) ? (seg.n_voices < 1024 ? seg.n_voices : 1024) : 16;
 			}
 		}
+		if (HB) {
+			if (!big_slots_.ensure((size_t)block_grid_ * seg.n_slots * 64, err)) return false;
+			rp.big_slots = big_slots_.p;
+		}
 		TimedPair *tp = timing_on_ ? new_pair(0) : nullptr;
 		if (tp) (void)hipEventRecord(tp->a, stream_);
 		bool ok = V > 1 ? (T == 4 ? launch_render<1, 4, 16>(rp, block_grid_, lds, err)
 		                 : T == 3 ? launch_render<1, 3, 16>(rp, block_grid_, lds, err)
 		                 : T == 2 ? launch_render<1, 2, 16>(rp, block_grid_, lds, err)
 		                          : launch_render<1, 1, 16>(rp, block_grid_, lds, err))
+		        : HB ? launch_render<1, 1, 1, true>(rp, block_grid_, lds, err)
 		        : (W == 1) ? launch_render<1, 1, 1>(rp, block_grid_, lds, err)
 		        : geo_ ? launch_render<4, 4, 1>(rp, block_grid_, lds, err)
 		               : launch_render<8, 2, 1>(rp, block_grid_, lds, err);
@@ -1304,6 +1312,7 @@ private:
 	int timing_level_ = 2;
 	DevBuf<FastInfo> finfo_;
 	DevBuf<uint32_t> fdone_, worklist_, work_count_;
+	DevBuf<float> big_slots_;     /* block buffers of render_kernel<1, 1, 1, true>: [workgroup][slot][64] */
 	DevBuf<unsigned char> fsteps_, flines_, faux_;
 	DevBuf<unsigned long long> scan_;
 	DevBuf<uint32_t> pass_flags_, repair_;

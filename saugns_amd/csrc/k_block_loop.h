@@ -154,9 +154,13 @@ __device__ __forceinline__ void team_sync() {
 	else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
-template <int W, int T, int V>
+/* HB: the block buffers of this workgroup's voice lie in HBM (P.big_slots, one area per workgroup) instead
+ * of LDS -- voices with more buffers than LDS holds (wide plans of very deep graphs: one wave, one frame per
+ * lane, 256 B per buffer; a 256-level chain has 500-800 of them beside 64 KiB of operator states). */
+template <int W, int T, int V, bool HB = false>
 __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 	static_assert(V == 1 || W == 1, "several teams per workgroup are single waves");
+	static_assert(!HB || (W == 1 && V == 1), "buffers in HBM: one wave per workgroup");
 	using G = Geo<W, T>;
 	constexpr int NTHREADS = 64 * W * V;
 	extern __shared__ __align__(16) unsigned char lds[];
@@ -167,9 +171,17 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 
 	HerpC23 *t23 = (HerpC23 *)lds;
 	HerpC01 *t01 = (HerpC01 *)(lds + (size_t)P.n_tabs * WAVE_LEN * sizeof(HerpC23));
-	float *slots = (float *)(lds + (size_t)P.n_tabs * WAVE_LEN * (sizeof(HerpC23) + sizeof(HerpC01)) +
-			(size_t)team * P.team_bytes);
-	DevOp *ops = (DevOp *)(slots + (size_t)P.n_slots * G::SLOT);
+	unsigned char *team_lds = lds + (size_t)P.n_tabs * WAVE_LEN * (sizeof(HerpC23) + sizeof(HerpC01)) +
+			(size_t)team * P.team_bytes;
+	float *slots;
+	DevOp *ops;
+	if constexpr (HB) {
+		slots = P.big_slots + (size_t)blockIdx.x * P.n_slots * G::SLOT;
+		ops = (DevOp *)team_lds;
+	} else {
+		slots = (float *)team_lds;
+		ops = (DevOp *)(slots + (size_t)P.n_slots * G::SLOT);
+	}
 	Misc *misc = (Misc *)(ops + P.max_ops);
 	Step *plan = (Step *)(misc + 1); /* this voice's steps, read every block */
 
@@ -229,17 +241,16 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 		bool block_ended = false;
 
 		for (uint32_t si = 0; si < vd.plan_len && !block_ended; ++si) {
-			Step st = uni(plan[si]);
-			{ /* slot ids -> memory indices (two pools, sau_dev_types.h) */
-				const uint32_t nm = P.n_main;
-				if (st.out != NO_SLOT) st.out = (uint8_t)slot_index(st.out, nm);
-				if (st.freq != NO_SLOT) st.freq = (uint8_t)slot_index(st.freq, nm);
-				if (st.fmul != NO_SLOT) st.fmul = (uint8_t)slot_index(st.fmul, nm);
-				if (st.pm != NO_SLOT) st.pm = (uint8_t)slot_index(st.pm, nm);
-				if (st.fpm != NO_SLOT) st.fpm = (uint8_t)slot_index(st.fpm, nm);
-				if (st.amp != NO_SLOT) st.amp = (uint8_t)slot_index(st.amp, nm);
-				if (st.sm != NO_SLOT) st.sm = (uint8_t)slot_index(st.sm, nm);
-				if (st.kind == ST_OSC && st.tmp != NO_SLOT) st.tmp = (uint8_t)slot_index(st.tmp, nm);
+			/* buffer ids -> memory indices (two pools; wide plans: the next step holds the ids' high bytes:
+			 * sau_dev_types.h) */
+			const Step st_lo = uni(plan[si]);
+			WideStep st;
+			if (vd.flags & VD_WIDE) {
+				const Step st_hi = uni(plan[si + 1]);
+				++si;
+				st = step_widen(st_lo, &st_hi, P.n_main);
+			} else {
+				st = step_widen(st_lo, nullptr, P.n_main);
 			}
 			const uint32_t parent_len = cur_len, parent_rem = cur_rem;
 			DevOp *op = &ops[st.op];
@@ -272,11 +283,11 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 			}
 			case ST_LINE: {
 				float *out = slots + (size_t)st.out * G::SLOT;
-				const float *mul = st.fmul != NO_SLOT ? slots + (size_t)st.fmul * G::SLOT : nullptr;
+				const float *mul = st.fmul != NO_WSLOT ? slots + (size_t)st.fmul * G::SLOT : nullptr;
 				LineState ls = uni(op->line[st.which]);
 				/* a held frequency is passed on as one value instead of a block */
 				bool pconst = false; float pf = 0.f;
-				if (mul && st.prov != NO_SLOT) { pconst = uni(ops[st.prov].rt_fconst_valid) != 0; pf = uni(ops[st.prov].rt_fconst); }
+				if (mul && st.prov != NO_WSLOT) { pconst = uni(ops[st.prov].rt_fconst_valid) != 0; pf = uni(ops[st.prov].rt_fconst); }
 				float fc = 0.f;
 				const bool lazy = st.which == L_FREQ && !(st.flags & SF_FORCE) && st.op < 255 &&
 					const_freq(ls, mul != nullptr, pconst, pf, fc);
@@ -361,12 +372,12 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 				float *out = slots + (size_t)st.out * G::SLOT;
 				float *scratch = slots; /* SCRATCH_SLOT */
 				u32_alias *scratch_u = (u32_alias *)slots;
-				const float *fslot = st.freq != NO_SLOT ? slots + (size_t)st.freq * G::SLOT : nullptr;
-				const float *fmul = st.fmul != NO_SLOT ? slots + (size_t)st.fmul * G::SLOT : nullptr;
-				const float *pmS = st.pm != NO_SLOT ? slots + (size_t)st.pm * G::SLOT : nullptr;
-				const float *fpmS = st.fpm != NO_SLOT ? slots + (size_t)st.fpm * G::SLOT : nullptr;
-				const float *ampS = st.amp != NO_SLOT ? slots + (size_t)st.amp * G::SLOT : nullptr;
-				const float *smS = st.sm != NO_SLOT ? slots + (size_t)st.sm * G::SLOT : nullptr;
+				const float *fslot = st.freq != NO_WSLOT ? slots + (size_t)st.freq * G::SLOT : nullptr;
+				const float *fmul = st.fmul != NO_WSLOT ? slots + (size_t)st.fmul * G::SLOT : nullptr;
+				const float *pmS = st.pm != NO_WSLOT ? slots + (size_t)st.pm * G::SLOT : nullptr;
+				const float *fpmS = st.fpm != NO_WSLOT ? slots + (size_t)st.fpm * G::SLOT : nullptr;
+				const float *ampS = st.amp != NO_WSLOT ? slots + (size_t)st.amp * G::SLOT : nullptr;
+				const float *smS = st.sm != NO_WSLOT ? slots + (size_t)st.sm * G::SLOT : nullptr;
 				const uint32_t type = uni(op->type);
 				const bool is_osc = (type == OT_WAVE || type == OT_RASEG);
 				const bool wave_env = (st.flags & SF_WAVE_ENV) != 0;
@@ -378,7 +389,7 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 
 				/* ---- frequency: one value for the block, a slot, or a line ---- */
 				bool pconst = false; float pf = 0.f;
-				if (st.prov != NO_SLOT) { pconst = uni(ops[st.prov].rt_fconst_valid) != 0; pf = uni(ops[st.prov].rt_fconst); }
+				if (st.prov != NO_WSLOT) { pconst = uni(ops[st.prov].rt_fconst_valid) != 0; pf = uni(ops[st.prov].rt_fconst); }
 				LineState fls, als, pls;
 				LineBlock flb;
 				const bool f_inline = is_osc && !fslot;
@@ -856,7 +867,7 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 			}
 			case ST_VOICE: { /* generator.c:749-788 with pan modulators */
 				const float *src = slots + (size_t)st.out * G::SLOT;
-				const float *panS = st.pm != NO_SLOT ? slots + (size_t)st.pm * G::SLOT : nullptr;
+				const float *panS = st.pm != NO_WSLOT ? slots + (size_t)st.pm * G::SLOT : nullptr;
 				LineState pl = op->line[L_PAN];
 				LineBlock plb2;
 				const bool pan_goal = !panS && (pl.flags & LP_GOAL);

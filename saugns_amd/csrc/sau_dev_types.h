@@ -98,6 +98,7 @@ enum : uint8_t {
 	ST_ZERO,     /* out <- 0 (circular reference guard, gen.c:685-689)*/
 	ST_SMLINE,   /* out <- pm_a line or zeros; latch self-mod state   */
 	ST_VOICE,    /* hand carrier block (+pan) to the mixer            */
+	ST_WIDE,     /* high bytes of the previous step's ids (wide plans)  */
 };
 
 enum : uint8_t {
@@ -220,6 +221,48 @@ SAU_HD uint32_t fast_slot_compact(const Step *plan, uint32_t n, FastIds *ids, bo
 	return count;
 }
 
+/* Wide plans. A step names its buffers in 8 bits: 127 main and 122 frequency ids, which a straight modulator
+ * chain of about 120 levels uses up (every level holds its frequency block and its modulator sum while the
+ * levels below run). The reference takes 256 levels (sauProgram.op_nest_depth is a uint8: sau/program.h:259,
+ * generator.c:133 gives each level 7 buffers). A voice whose graph needs more ids gets a *wide* plan: every
+ * step is followed by an ST_WIDE step that holds the high bytes of the ids (and of `prov`) in the same
+ * fields; 16-bit ids, main pool 1..0x7FFE, frequency pool from WSLOT_FBASE, NO_WSLOT = none. Only the block
+ * loop runs wide plans (VD_WIDE voices are VD_NO_FAST too); it reads every step through step_widen(), ids
+ * turned into memory indices on the way. */
+constexpr uint16_t NO_WSLOT = 0xFFFF;
+constexpr uint16_t WSLOT_FBASE = 0x8000;
+struct WideStep {
+	uint8_t kind, flags, which;
+	uint16_t out, freq, fmul, pm, fpm, amp, sm;
+	uint16_t tmp;  /* ST_OSC: scratch buffer (memory index); lines: the partner line */
+	uint16_t prov; /* voice-local operator or NO_WSLOT */
+	uint32_t op;
+};
+SAU_HD uint16_t wslot_index(uint32_t lo, uint32_t hi, bool wide, uint32_t n_main) {
+	if (!wide) return lo == NO_SLOT ? NO_WSLOT : (uint16_t)slot_index(lo, n_main);
+	const uint32_t id = lo | (hi << 8);
+	if (id == NO_WSLOT) return NO_WSLOT;
+	return (uint16_t)(id < WSLOT_FBASE ? id : n_main + (id - WSLOT_FBASE));
+}
+/* `hi`: the ST_WIDE step behind `lo` in a wide plan, else null */
+SAU_HD WideStep step_widen(const Step &lo, const Step *hi, uint32_t n_main) {
+	const bool w = hi != nullptr;
+	WideStep s;
+	s.kind = lo.kind; s.flags = lo.flags; s.which = lo.which; s.op = lo.op;
+	s.out = wslot_index(lo.out, w ? hi->out : 0, w, n_main);
+	s.freq = wslot_index(lo.freq, w ? hi->freq : 0, w, n_main);
+	s.fmul = wslot_index(lo.fmul, w ? hi->fmul : 0, w, n_main);
+	s.pm = wslot_index(lo.pm, w ? hi->pm : 0, w, n_main);
+	s.fpm = wslot_index(lo.fpm, w ? hi->fpm : 0, w, n_main);
+	s.amp = wslot_index(lo.amp, w ? hi->amp : 0, w, n_main);
+	s.sm = wslot_index(lo.sm, w ? hi->sm : 0, w, n_main);
+	if (lo.kind == ST_OSC) s.tmp = wslot_index(lo.tmp, w ? hi->tmp : 0, w, n_main);
+	else s.tmp = lo.tmp;
+	if (w) { const uint32_t p = lo.prov | ((uint32_t)hi->prov << 8); s.prov = (uint16_t)p; }
+	else s.prov = lo.prov == NO_SLOT ? NO_WSLOT : lo.prov;
+	return s;
+}
+
 /* A self-modulated W oscillator ("chain": wosc.h:273-310) as the time-parallel path handles it: its
  * inputs (base phases, self-modulation amounts) go to a pair of rows in HBM, chain_kernel runs the
  * per-sample recurrence with one lane per chain, the final pass reads the samples back. */
@@ -247,6 +290,7 @@ enum : uint32_t {
 	VD_NO_FAST = 1u << 0, /* graph visits an operator twice or has a cycle guard */
 	VD_MORE = 1u << 1,    /* the voice goes on after this segment (its blocks are not cut at run_len: TailCtx.rem) */
 	VD_TAILS = 1u << 2,   /* the reference build's loop tails are reproduced */
+	VD_WIDE = 1u << 3,    /* wide plan: step pairs with 16-bit buffer ids (step_widen) */
 };
 
 /* Per-voice result of a segment, read by the mixer. */
@@ -257,7 +301,7 @@ struct VoiceOut {
 	uint32_t pan_row;   /* row of the pan matrix when has_pan */
 };
 
-constexpr uint32_t MAX_NEST = 255; /* deepest operator nesting a plan may have: sauProgram.op_nest_depth is a uint8 (sau/program.h:259) */
+constexpr uint32_t MAX_NEST = 256; /* operators on a path from the carrier down: sauProgram.op_nest_depth, the deepest level's number, is a uint8 (sau/program.h:259) */
 
 } /* namespace saudev */
 #endif

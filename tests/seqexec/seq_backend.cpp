@@ -84,12 +84,11 @@ struct SeqBackend : public Backend {
 			uint32_t cur_rem = (vd.flags & VD_MORE) ? TAIL_FAR : std::min(vd.run_len - done, TAIL_FAR);
 			bool ended = false;
 			for (uint32_t si = 0; si < vd.plan_len && !ended; ++si) {
-				Step st = steps[vd.plan_ofs + si];
-				{ /* slot ids -> memory indices */
-					uint8_t *f[] = {&st.out, &st.freq, &st.fmul, &st.pm, &st.fpm, &st.amp, &st.sm};
-					for (uint8_t *x : f) if (*x != NO_SLOT) *x = (uint8_t)slot_index(*x, n_main);
-					if (st.kind == ST_OSC && st.tmp != NO_SLOT) st.tmp = (uint8_t)slot_index(st.tmp, n_main);
-				}
+				/* slot ids -> memory indices (wide plans: step pairs, sau_dev_types.h) */
+				const Step &st_lo = steps[vd.plan_ofs + si];
+				const bool wide = (vd.flags & VD_WIDE) != 0;
+				const WideStep st = step_widen(st_lo, wide ? &steps[vd.plan_ofs + si + 1] : nullptr, n_main);
+				if (wide) ++si;
 				DevOp &op = lo[st.op];
 				uint32_t parent_len = cur_len;
 				if (st.flags & SF_BEGIN) {
@@ -106,7 +105,7 @@ struct SeqBackend : public Backend {
 					for (uint32_t j = 0; j < len; ++j) slot[st.out][j] = 0.f;
 					break;
 				case ST_LINE: {
-					const float *mul = st.fmul != NO_SLOT ? slot[st.fmul].data() : nullptr;
+					const float *mul = st.fmul != NO_WSLOT ? slot[st.fmul].data() : nullptr;
 					LineBlock lb = line_begin(op.line[st.which], len, mul != nullptr, mul ? mul[0] : 0.f, vd.lat, done);
 					for (uint32_t j = 0; j < len; ++j)
 						slot[st.out][j] = line_value_t(lb, j, mul ? mul[j] : 1.f, tc);
@@ -133,12 +132,12 @@ struct SeqBackend : public Backend {
 					}
 					break;
 				case ST_OSC: {
-					const float *fslot = st.freq != NO_SLOT ? slot[st.freq].data() : nullptr;
-					const float *fmul = st.fmul != NO_SLOT ? slot[st.fmul].data() : nullptr;
-					const float *pmS = st.pm != NO_SLOT ? slot[st.pm].data() : nullptr;
-					const float *fpmS = st.fpm != NO_SLOT ? slot[st.fpm].data() : nullptr;
-					const float *ampS = st.amp != NO_SLOT ? slot[st.amp].data() : nullptr;
-					const float *smS = st.sm != NO_SLOT ? slot[st.sm].data() : nullptr;
+					const float *fslot = st.freq != NO_WSLOT ? slot[st.freq].data() : nullptr;
+					const float *fmul = st.fmul != NO_WSLOT ? slot[st.fmul].data() : nullptr;
+					const float *pmS = st.pm != NO_WSLOT ? slot[st.pm].data() : nullptr;
+					const float *fpmS = st.fpm != NO_WSLOT ? slot[st.fpm].data() : nullptr;
+					const float *ampS = st.amp != NO_WSLOT ? slot[st.amp].data() : nullptr;
+					const float *smS = st.sm != NO_WSLOT ? slot[st.sm].data() : nullptr;
 					const uint32_t type = op.type;
 					const bool is_osc = type == OT_WAVE || type == OT_RASEG;
 					std::vector<float> fv(len), av(len), pv(len), s(len);
@@ -265,7 +264,7 @@ struct SeqBackend : public Backend {
 				}
 				case ST_VOICE: {
 					LineState &pl = op.line[L_PAN];
-					const float *panS = st.pm != NO_SLOT ? slot[st.pm].data() : nullptr;
+					const float *panS = st.pm != NO_WSLOT ? slot[st.pm].data() : nullptr;
 					LineBlock lb;
 					bool goal = !panS && (pl.flags & LP_GOAL);
 					if (!panS) { if (goal) lb = line_begin(pl, len, false, 0.f, vd.lat, done); else line_skip(pl, len, vd.lat, done); }

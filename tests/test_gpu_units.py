@@ -708,17 +708,30 @@ def test_dropin_generator_on_random_programs(sa, oracle):
 
 
 def test_deep_nesting(sa, oracle):
-    """Nesting far beyond what scripts use: straight PM chains of 65 and 120 levels (one wave, one
-    frame per lane, about 240 block buffers in LDS), bit-exact vs the oracle."""
-    def chain(depth):
+    """Nesting as deep as a sauProgram can state (op_nest_depth is a uint8: 256 operators on a path,
+    sau/program.h:259). Straight PM chains of 33, 65 and 120 levels (8-bit buffer ids; one wave, one frame per
+    lane, about 240 block buffers in LDS), of 130 (a wide plan -- step pairs with 16-bit ids -- still in LDS) and
+    of 255 and 256 levels (512 buffers in HBM: render_kernel<1, 1, 1, true>); chains through the other
+    modulator lists at 256 levels (range modulators hold three buffers per level); a wide voice beside ordinary
+    voices in one segment, several calls; bit-exact vs the oracle."""
+    def chain(depth, use=POP_PMOD, ms=40):
         op = None
         for d in range(depth):
             top = d == depth - 1
-            op = vb.Op("sin", freq=200.0 if top else vb.Line(2.0, ratio=True), amp=0.5,
-                       time_ms=40 if top else None, mods={POP_PMOD: [op]} if op else {})
+            if use in (POP_FMOD, POP_RFMOD):
+                f = 200.0 if top else 30.0 + 11.0 * (d % 7)
+            else:
+                f = 200.0 if top else vb.Line(1.0 + (d % 4) * 0.5, ratio=True)
+            op = vb.Op("sin", freq=f, amp=20.0 if use in (POP_FMOD, POP_RFMOD) else 0.5,
+                       time_ms=ms if top else None, mods={use: [op]} if op else {})
         return op
-    for depth in (33, 65, 120):
+    for depth in (33, 65, 120, 130, 255, 256):
         check(sa, oracle, [chain(depth)], chunk=1500)
+    for use in (POP_FMOD, POP_RFMOD, POP_AMOD, POP_RAMOD, POP_FPMOD):
+        check(sa, oracle, [chain(256, use)], chunk=1700)
+    check(sa, oracle, [chain(150), vb.Op("saw", freq=110.0, amp=0.3, time_ms=80), chain(256, POP_AMOD, ms=55),
+                       vb.Op("sin", freq=330.0, time_ms=70, mods={POP_PMOD: [vb.Op("tri", freq=vb.Line(2.0, ratio=True), amp=0.4)]})],
+          stereo=True, chunk=997)
 
 
 @pytest.mark.parametrize("chunks", ["1", "2", "16"])

@@ -191,26 +191,57 @@ def _pm_chain(depth):
     return op
 
 
-def test_limits_beyond_the_reference(sa, oracle, seqexec):
-    """any nesting depth a sauProgram can state (uint8) is accepted; what bounds
-    a voice tree is its block buffers -- a straight PM chain renders bit-exact down to 120 levels, a
-    deeper one is refused with a message and silence (the reference host then simply ends:
-    generator.c:905 cannot fail); any number of modulators in one list is fine (they share a buffer)."""
+def _chain(depth, use, ratio=True, wave="sin"):
+    """A straight chain of `depth` operators, each the only member of its parent's list `use`."""
+    from saugns_amd.voicebank import Op, Line
+    op = None
+    for d in range(depth):
+        top = d == depth - 1
+        kw = {}
+        if top:
+            kw = dict(freq=200.0, time_ms=50)
+        else:
+            kw = dict(freq=Line(1.0 + (d % 5) * 0.5, ratio=True) if ratio else 30.0 + 11.0 * (d % 7))
+        op = Op(wave, amp=0.5 if use != "f" else 20.0, mods={use: [op]} if op else {}, **kw)
+    return op
+
+
+def test_nesting_as_deep_as_the_reference(sa, oracle, seqexec):
+    """sauProgram.op_nest_depth is a uint8 (sau/program.h:259; generator.c:133 gives every level its 7 buffers):
+    the reference takes 256 operators on a path. A straight PM chain renders bit-exact at 63, 65, 120 (plans
+    with 8-bit buffer ids) and at 130, 255, 256 levels (wide plans: step pairs with 16-bit ids, DESIGN 4.2);
+    chains through the other modulator lists -- FM, range FM (three buffers per level), AM, range AM,
+    frequency-scaled PM -- at 200 and 256 levels; a path of 257 operators is not a sauProgram: refused with a
+    message and silence (the reference host then simply ends: generator.c:905 cannot fail). Any number of
+    modulators in one list is fine (they share a buffer)."""
     from saugns_amd import voicebank
     from saugns_amd.voicebank import Op, Line
-    from saugns_amd.api import POP_PMOD
+    from saugns_amd.api import POP_PMOD, POP_FMOD, POP_RFMOD, POP_AMOD, POP_RAMOD, POP_FPMOD
     oracle.oracle().ora_set_fastmath_forms(1)
-    for depth in (63, 65, 120):
+    for depth in (63, 65, 120, 130, 255, 256):
         prg = voicebank.build_program([_pm_chain(depth)])
         got = sa.Batch([prg], 12000, backend=seqexec.seq_backend_create(256)).render()[0]
-        assert max_diff(got, oracle.oracle_render(prg.ptr, 12000, False)) == 0
-    prg = voicebank.build_program([_pm_chain(130)])
-    with pytest.raises(RuntimeError, match="more than 122 frequency buffers"):
+        assert max_diff(got, oracle.oracle_render(prg.ptr, 12000, False)) == 0, depth
+    for use in (POP_FMOD, POP_RFMOD, POP_AMOD, POP_RAMOD, POP_FPMOD):
+        for depth in (200, 256):
+            prg = voicebank.build_program([_chain(depth, use, ratio=use not in (POP_FMOD, POP_RFMOD))])
+            got = sa.Batch([prg], 12000, backend=seqexec.seq_backend_create(333)).render()[0]
+            want = oracle.oracle_render(prg.ptr, 12000, False)
+            assert len(got) == len(want) and max_diff(got, want) == 0, (use, depth)
+    # a wide plan beside ordinary voices, events on both, several calls
+    voices = [_pm_chain(150), Op("saw", freq=110.0, amp=0.3, time_ms=80), _chain(140, POP_AMOD)]
+    prg = voicebank.build_program(voices)
+    want = oracle.oracle_render(prg.ptr, 12000, True)
+    for chunk in (0, 257):
+        got = sa.Batch([prg], 12000, backend=seqexec.seq_backend_create(200)).render(stereo=True, **({"chunk": chunk} if chunk else {}))[0]
+        assert len(got) == len(want) and max_diff(got, want) == 0
+    prg = voicebank.build_program([_pm_chain(257)])
+    with pytest.raises(RuntimeError, match="nesting deeper than 256 levels"):
         sa.Batch([prg], 12000, backend=seqexec.seq_backend_create(256)).render()
     g = sa.Generator(prg, 12000, backend=seqexec.seq_backend_create(256))
     buf = np.full(1000, 5, np.int16)
     assert g.run(buf, 1000) == (False, 0) and not buf.any()
-    assert "more than 122 frequency buffers" in sa.last_error()
+    assert "nesting deeper than 256 levels" in sa.last_error()
     g.close()
     mods = [Op("sin", freq=Line(float(1 + i % 7), ratio=True), amp=0.1) for i in range(300)]
     prg = voicebank.build_program([Op("sin", freq=200.0, amp=0.5, time_ms=50, mods={POP_PMOD: mods})])
