@@ -336,6 +336,7 @@ public:
 		seq_enabled_ = getenv("SAU_AMD_NO_SEQ") == nullptr; /* running-sum phases in the time-parallel kernel */
 		chain_enabled_ = getenv("SAU_AMD_NO_CHAIN") == nullptr; /* feedback recurrences with lanes = voices */
 		chain_inline_ = getenv("SAU_AMD_CHAIN_INLINE") != nullptr;
+		chain_early_ = getenv("SAU_AMD_NO_EARLY_CHAINS") == nullptr;
 		inc_rows_enabled_ = getenv("SAU_AMD_NO_INC_ROWS") == nullptr;
 		lookback_enabled_ = getenv("SAU_AMD_NO_LOOKBACK") == nullptr; /* single-pass running sums */
 		if (const char *lr = getenv("SAU_AMD_LOOK_ROWS")) look_rows_ = (uint32_t)atoi(lr);
@@ -717,6 +718,7 @@ public:
 				fp.chain_rows = chain_rows_.p; fp.chain_stride = cstride; fp.n_chain_rows = seg.n_chain_rows;
 				fp.chain_desc = chain_desc_.p; fp.fplines = (FastLine *)fplines_.p;
 				fp.chain_inline = chain_inline_ ? 1u : 0u;
+				fp.chain_early_ok = chain_early_ ? 1u : 0u;
 				uint32_t ct = 0;
 				for (int wv = 0; wv < 12; ++wv) {
 					fp.ctab_of_wave[wv] = -1;
@@ -873,6 +875,15 @@ public:
 				if (fp.scan) {
 					/* some voice may have running-sum phases: sums per row group, their prefixes, final pass */
 					/* (with look-back only voices that have, or may get, feedback chains still take sum passes) */
+					if (fp.chain_rows && fp.chain_early_ok) {
+						/* chains that sums or other chains' inputs depend on, fed from their own lines: whole segment, before
+						 * anything else (FastInfo.early); returns at once when analyze_kernel found none */
+						const size_t clds = (size_t)fp.n_ctabs * tab_bytes + CHAIN_IO_BYTES;
+						if (!raise_lds_attr((const void *)chain_kernel, clds, chain_lds_configured_[dev_ & 15], err)) return false;
+						fp.chain_early = 1; fp.range_mode = 0;
+						hipLaunchKernelGGL(chain_kernel, dim3((seg.n_chain_rows + 63) / 64), dim3(128), clds, stream_, fp);
+						fp.chain_early = 0;
+					}
 					for (uint32_t pass = 1; pass <= fp.sum_levels && (!fp.look || seg.n_chain_rows); ++pass) {
 						launch_fast(pass);
 						hipLaunchKernelGGL(scan_kernel, dim3(seg.n_voices), dim3(64), 0, stream_, fp);
@@ -883,8 +894,7 @@ public:
 						 * so it runs on a stream of its own while, on the other CUs, the chain-input pass prepares the
 						 * chunks after it and the final pass finishes the chunks before it. */
 						const size_t clds = (size_t)fp.n_ctabs * tab_bytes + CHAIN_IO_BYTES;
-						static size_t cconfigured[16];
-						if (!raise_lds_attr((const void *)chain_kernel, clds, cconfigured[dev_ & 15], err)) return false;
+						if (!raise_lds_attr((const void *)chain_kernel, clds, chain_lds_configured_[dev_ & 15], err)) return false;
 						const uint32_t cgrid = (seg.n_chain_rows + 63) / 64;
 						/* chunks of about chain_chunk_frames_ frames (what the first chunk's inputs and the last chunk's final
 						 * pass take is not overlapped with the chains), 32 at most */
@@ -1321,7 +1331,8 @@ private:
 	std::map<void *, size_t> host_blocks_; /* alloc_host() blocks and their pool sizes */
 	uint32_t multi_min_ = 256;
 	uint32_t fast_rows_ = 8;
-	bool seq_enabled_ = true, two_pass_enabled_ = true, chain_enabled_ = true, chain_inline_ = false;
+	static inline size_t chain_lds_configured_[16] = {}; /* chain_kernel's LDS attribute per device (two launch sites) */
+	bool seq_enabled_ = true, two_pass_enabled_ = true, chain_enabled_ = true, chain_inline_ = false, chain_early_ = true;
 	uint32_t chain_chunks_ = 0;           /* SAU_AMD_CHAIN_CHUNKS: a fixed number of chunks per segment (0: by frames) */
 	uint32_t chain_chunk_frames_ = 16384; /* SAU_AMD_CHAIN_CHUNK_FRAMES */
 	bool inc_rows_enabled_ = true;

@@ -297,36 +297,50 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 	/* Feedback chains: the recurrence's inputs (frequency, phase modulators, amounts) must not depend on any
 	 * chain's output, and no running sum may either -- the sum passes and the chain-input pass run before
 	 * chain_kernel. Forward data-flow, one bit per block buffer ("depends on a chain's output"). */
+	bool early = false;
 	if (has_chain && !bad) {
-		unsigned long long c0[4] = {0, 0, 0, 0};
-		auto dep = [&](uint32_t sl) -> bool {
+		/* c0: depends on some chain's output; c1: ... on the output of a chain that is not fed from its own lines.
+		 * Chains of the latter kind run in chunks between the chain-input and final passes, after the sum passes:
+		 * nothing those passes compute may depend on them. The former kind can run before everything else (early). */
+		unsigned long long c0[4] = {0, 0, 0, 0}, c1[4] = {0, 0, 0, 0};
+		auto dep = [&](const unsigned long long *c, uint32_t sl) -> bool {
 			if (sl == NO_SLOT) return false;
 			const uint32_t q = sl >> 6;
-			const unsigned long long a = q == 0 ? c0[0] : q == 1 ? c0[1] : q == 2 ? c0[2] : c0[3];
+			const unsigned long long a = q == 0 ? c[0] : q == 1 ? c[1] : q == 2 ? c[2] : c[3];
 			return ((a >> (sl & 63)) & 1ull) != 0;
 		};
-		auto set_dep = [&](uint32_t sl, bool v, bool keep) {
+		auto set_dep = [&](unsigned long long *c, uint32_t sl, bool v, bool keep) {
 			if (sl == NO_SLOT) return;
 			const unsigned long long bit = 1ull << (sl & 63);
 #pragma unroll
 			for (int q = 0; q < 4; ++q)
-				if ((int)(sl >> 6) == q) c0[q] = v ? (c0[q] | bit) : (keep ? c0[q] : (c0[q] & ~bit));
+				if ((int)(sl >> 6) == q) c[q] = v ? (c[q] | bit) : (keep ? c[q] : (c[q] & ~bit));
 		};
 		for (uint32_t si = 0; si < vd.plan_len && !bad; ++si) {
 			const Step st = plan[si];
 			const DevOp &o = P.ops[ids[st.op]];
 			if (o.rt_frozen) continue;
-			if (st.kind == ST_LINE) set_dep(st.out, dep(st.fmul), false);
-			else if (st.kind == ST_SMLINE) set_dep(st.out, false, false);
-			else if (st.kind == ST_LERP) set_dep(st.out, dep(st.freq) || dep(st.pm), true);
-			else if (st.kind == ST_OSC) {
-				const bool in_dep = dep(st.pm) || dep(st.fpm) || dep(st.freq) || dep(st.fmul) || dep(st.sm);
+			if (st.kind == ST_LINE) { set_dep(c0, st.out, dep(c0, st.fmul), false); set_dep(c1, st.out, dep(c1, st.fmul), false); }
+			else if (st.kind == ST_SMLINE) { set_dep(c0, st.out, false, false); set_dep(c1, st.out, false, false); }
+			else if (st.kind == ST_LERP) {
+				set_dep(c0, st.out, dep(c0, st.freq) || dep(c0, st.pm), true);
+				set_dep(c1, st.out, dep(c1, st.freq) || dep(c1, st.pm), true);
+			} else if (st.kind == ST_OSC) {
+				const bool in_dep = dep(c0, st.pm) || dep(c0, st.fpm) || dep(c0, st.freq) || dep(c0, st.fmul) || dep(c0, st.sm);
+				const bool in_late = dep(c1, st.pm) || dep(c1, st.fpm) || dep(c1, st.freq) || dep(c1, st.fmul) || dep(c1, st.sm);
 				const bool chain = step_may_chain(st) && o.type == OT_WAVE &&
 					(st.sm != NO_SLOT || o.line[L_PMA].v0 != 0.f || (o.line[L_PMA].flags & LP_GOAL));
 				const bool fvar = (o.type == OT_WAVE || o.type == OT_RASEG) && !o.rt_fconst_valid;
-				if (chain && in_dep) bad = true;
-				if (fvar && (dep(st.freq) || dep(st.fmul))) bad = true;
-				if (!(st.which & OX_VOICE)) set_dep(st.out, chain || in_dep || dep(st.amp), (st.flags & SF_LAYER) != 0);
+				uint32_t ls_ = ~0u;
+				const bool inl = chain && step_is_chain_inline(P.chain_early_ok != 0, plan, si, ids, P.ops, &ls_);
+				if (chain && in_late) bad = true;
+				else if (chain && in_dep) early = true;
+				if (fvar && (dep(c1, st.freq) || dep(c1, st.fmul))) bad = true;
+				else if (fvar && (dep(c0, st.freq) || dep(c0, st.fmul))) early = true;
+				if (!(st.which & OX_VOICE)) {
+					set_dep(c0, st.out, chain || in_dep || dep(c0, st.amp), (st.flags & SF_LAYER) != 0);
+					set_dep(c1, st.out, (chain && !inl) || in_late || dep(c1, st.amp), (st.flags & SF_LAYER) != 0);
+				}
 			}
 		}
 	}
@@ -405,7 +419,7 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 	 * closed-form voices have repair_kernel for that case (see FAST_REPAIR_SHIFT). */
 	if (seq || has_chain) ++x_carrier;
 	fi.n_chain = has_chain && !bad ? 1u : 0u;
-	fi.H = maxd + x_carrier; fi.xlead = x_carrier; fi.bail = 0; fi.n_fsteps = 0; fi.n_pass[0] = fi.n_pass[1] = fi.n_pass[2] = fi.n_pass[3] = 0; fi.seq = seq_kind; fi.cub = has_rcub ? 1u : 0u; fi.n_scan = n_scan_out; fi.levels = levels_out; fi.lvl_bits = lvl_bits_out;
+	fi.H = maxd + x_carrier; fi.xlead = x_carrier; fi.bail = 0; fi.n_fsteps = 0; fi.n_pass[0] = fi.n_pass[1] = fi.n_pass[2] = fi.n_pass[3] = 0; fi.seq = seq_kind; fi.cub = has_rcub ? 1u : 0u; fi.early = (early && has_chain && !bad) ? 1u : 0u; fi.n_scan = n_scan_out; fi.levels = levels_out; fi.lvl_bits = lvl_bits_out;
 	fi.total = 0;
 	if ((seq || has_chain) && !P.seq_enable) bad = true;
 	if (!bad && vd.nops <= P.max_ops && vd.plan_len <= P.max_steps && maxd >= 1 && maxd + x_carrier <= P.np / 2)
@@ -416,6 +430,7 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 	P.fast_done[v] = 0;
 	P.repair[(size_t)v * FAST_REPAIR_WORDS] = 0;
 	if (fi.total && fi.cub) atomicOr(&P.pass_flags[FAST_CUB_FLAG], 1u);
+	if (fi.total && fi.early) atomicOr(&P.pass_flags[FAST_EARLY_FLAG], 1u);
 	if (P.split_cf && fi.total) { /* the two launches' voice lists (any order: voices are independent) */
 		if (seq_kind == 0) P.vlists[atomicAdd(&P.pass_flags[FAST_CF_COUNT], 1u)] = v;
 		else if (seq_kind == 3) P.vlists[P.n_voices + atomicAdd(&P.pass_flags[FAST_LK_COUNT], 1u)] = v;

@@ -190,6 +190,7 @@ __device__ __forceinline__ void chain_fetch(const ChainDesc &cd, bool live, uint
 __global__ void __launch_bounds__(128) chain_kernel(FastParams P) {
 	extern __shared__ __align__(16) unsigned char lds[];
 	if (P.pass_flags[FAST_MAX_LEVELS + 1] == 0) return; /* no voice of the segment has a chain */
+	if (P.chain_early && P.pass_flags[FAST_EARLY_FLAG] == 0) return;
 	const int l = threadIdx.x & 63;
 	const bool feeder = uni((uint32_t)threadIdx.x >> 6) != 0;
 	const uint32_t c = blockIdx.x * 64 + (uint32_t)l;
@@ -199,6 +200,7 @@ __global__ void __launch_bounds__(128) chain_kernel(FastParams P) {
 	/* this launch's share of the chain: frames [c_lo, n) of the segment, n cut at the chunk's end */
 	const uint32_t c_lo = P.range_mode ? P.f_lo : 0u;
 	uint32_t n = cd.n;
+	if (((cd.lflags & CL_EARLY) != 0) != (P.chain_early != 0)) n = 0; /* the early chains have a launch of their own, ahead of the passes */
 	if (P.range_mode && n > P.f_hi) n = P.f_hi;
 	if (n <= c_lo) n = 0;
 	if (!__any(n != 0)) return;

@@ -34,7 +34,7 @@ enum : uint32_t {
 	CM_INC = 1,    /* first row: phase increments (the chain sums them), second: amounts */
 	CM_INLINE = 2, /* no input rows: frequency and amounts are the operator's own lines, evaluated by the feeder wave */
 };
-enum : uint32_t { CL_FCONST = 1, CL_MUL_GOAL = 2, CL_MUL_HOLD = 4 };
+enum : uint32_t { CL_FCONST = 1, CL_MUL_GOAL = 2, CL_MUL_HOLD = 4, CL_EARLY = 8 /* runs in the launch ahead of the passes (FastInfo.early) */ };
 struct ChainDesc {
 	uint32_t n;      /* frames to run this segment (0: row pair unused; the other fields are then unset) */
 	uint32_t gop;    /* the operator's state (global index) */
@@ -244,14 +244,15 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 				chain_line = true;
 			}
 			uint32_t lstep = ~0u;
-			if (step_is_chain_inline(P.chain_inline != 0, plan, (uint32_t)l, ids, P.ops, &lstep)) {
+			if (step_is_chain_inline(P.chain_inline != 0 || P.info[v].early != 0, plan, (uint32_t)l, ids, P.ops, &lstep)) {
 				chain_inline = true;
 				cd.mode = CM_INLINE;
+				if (P.info[v].early) { cd.lflags |= CL_EARLY; f.type |= FT_CHAIN_EARLY; }
 				cd.coeff = o.coeff;
 				cd.pl = pl;
 				cd.mulc = 1.f;
 				if (o.rt_fconst_valid) {
-					cd.lflags = CL_FCONST;
+					cd.lflags |= CL_FCONST;
 					cd.inc_const = rint32w(o.coeff * o.rt_fconst);
 				} else {
 					const Step ls = lstep != ~0u ? plan[lstep] : st;
@@ -356,13 +357,20 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 					const bool writes = sq.kind == ST_LINE || sq.kind == ST_LERP || sq.kind == ST_SMLINE ||
 						(sq.kind == ST_OSC && !(sq.which & OX_VOICE));
 					const bool rmw = sq.kind == ST_LERP || (sq.kind == ST_OSC && (sq.flags & SF_LAYER));
+					const bool v_early = P.info[v].early != 0;
+					const bool q_chain = step_is_chain(sq, oq);
+					uint32_t q_ls = ~0u;
+					const bool q_inline = q_chain && step_is_chain_inline(P.chain_inline != 0 || v_early, plan, q, ids, P.ops, &q_ls);
+					const bool q_early = q_inline && v_early;
 					{
-						const bool q_chain = step_is_chain(sq, oq);
-						uint32_t q_ls = ~0u;
-						const bool q_inline = q_chain && step_is_chain_inline(P.chain_inline != 0, plan, q, ids, P.ops, &q_ls);
 						bool needed = false;
 						if (q_inline) {
 							/* its inputs are its own lines: the feeder wave of chain_kernel evaluates them */
+							if (v_early && writes && (want_c & bit(cq.out))) { /* an early chain another chain's inputs read: from its row */
+								needed = true;
+								if (!rmw) want_c &= ~bit(cq.out);
+								want_c |= bit(cq.amp);
+							}
 						} else if (q_chain) {
 							needed = true; /* writes its inputs to the rows, nothing else */
 							want_c |= bit(cq.freq) | bit(cq.fmul) | bit(cq.pm) | bit(cq.fpm) | bit(cq.sm);
@@ -389,7 +397,13 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 					}
 					for (uint32_t p = 0; p < FAST_MAX_LEVELS; ++p) { /* sum pass p + 1 */
 						bool needed = false;
-						if (q_fvar && q_level == p + 1) {
+						if (q_early) { /* an early chain: its samples are in its row, only the amplitude is computed */
+							if (writes && (want[p] & bit(cq.out))) {
+								needed = true;
+								if (!rmw) want[p] &= ~bit(cq.out);
+								want[p] |= bit(cq.amp);
+							}
+						} else if (q_fvar && q_level == p + 1) {
 							needed = true; /* as a sums-only step */
 							want[p] |= bit(cq.freq) | bit(cq.fmul);
 						} else if (!(q_fvar && q_level > p + 1)) {

@@ -28,6 +28,10 @@ struct FastInfo {
 	uint32_t lvl_bits; /* 2 bits per such oscillator, in plan order: its level */
 	uint32_t xlead;  /* lead-in lanes beyond the nesting depth (ratio frequencies below modulated blocks); in H */
 	uint32_t n_chain; /* self-modulated oscillators handed to chain_kernel this segment */
+	uint32_t early;   /* something that runs before chain_kernel's chunks -- a running sum, another chain's inputs -- depends on
+	                   * the output of a chain of this voice, and every chain it depends on is fed from its own lines
+	                   * (step_is_chain_inline): those chains run first, whole segment, in a chain_kernel launch ahead of the
+	                   * sum passes (FastParams.chain_early), and every pass reads their samples from the rows (FT_CHAIN_EARLY) */
 	uint32_t cub;     /* a closed-form voice with an R oscillator of `cub` segments and the reference's loop tails on: rendered by
 	                   * the closed-form build with the tail code, fast_kernel<4, 0, true>, and by no other launch */
 };
@@ -51,7 +55,8 @@ constexpr uint32_t FAST_MAX_LEVELS = 3; /* running sums that depend on running s
 constexpr uint32_t FAST_REPAIR_SHIFT = 24; /* H + shift < 64 (H <= 32) */
 constexpr uint32_t FAST_MAX_REPAIR = 15;   /* noted row groups per voice and segment; more: block loop */
 constexpr uint32_t FAST_REPAIR_WORDS = 2 + 2 * FAST_MAX_REPAIR; /* count, pad, then (group, rows) pairs */
-constexpr uint32_t FAST_FLAGS = FAST_MAX_LEVELS + 8; /* pass_flags words */
+constexpr uint32_t FAST_FLAGS = FAST_MAX_LEVELS + 9; /* pass_flags words */
+constexpr uint32_t FAST_EARLY_FLAG = FAST_MAX_LEVELS + 8; /* some voice has early chains (FastInfo.early) */
 constexpr uint32_t FAST_CUB_FLAG = FAST_MAX_LEVELS + 7; /* some voice has FastInfo.cub set */
 constexpr uint32_t FAST_CUB_ROWS = 4;                  /* rows per pass of that build */
 constexpr uint32_t FAST_CF_COUNT = FAST_MAX_LEVELS + 5; /* voices in FastParams.vlists[0]: closed-form ones of a segment that also has look-back voices */
@@ -67,6 +72,7 @@ __device__ __forceinline__ uint32_t fast_list_of(uint32_t mode, uint32_t sum_lev
 constexpr uint32_t FR_CHAIN_IN = 4u << FAST_MAX_LEVELS; /* FastStep.ramp: the chain-input pass runs this step */
 constexpr uint32_t FR_FINAL_SKIP = 8u << FAST_MAX_LEVELS; /* ... the final pass does not: only chains' inputs needed it */
 constexpr uint32_t FT_CHAIN = 1u << 18;     /* FastStep.type: a feedback chain (rows = bits of FastStep.pan) */
+constexpr uint32_t FT_CHAIN_EARLY = 1u << 20; /* ... whose samples are in its row before any pass runs (FastInfo.early) */
 constexpr uint32_t FT_CUBTAIL = 1u << 19;   /* ... an R oscillator with `cub` segments and the reference's loop tails on: FastStep.phase0 =
                                              * frames until it, an ancestor or the voice stops (TailCtx.rem) */
 constexpr uint32_t CHAIN_MARK = 0xC4A10001u; /* DevOp.ras_level of a W operator: chain_kernel staged its state */
@@ -118,6 +124,8 @@ struct FastParams {
 	 * fast_kernel: range_mode 1 = the row groups that start in [f_lo, f_hi), 2 = those that end in (f_lo, f_hi]
 	 * (0: all). chain_kernel: frames [f_lo, f_hi) of every chain, continuing from the staged state when f_lo > 0. */
 	uint32_t range_mode, f_lo, f_hi, range_last;
+	uint32_t chain_early_ok; /* analyze_kernel may mark voices early (SAU_AMD_NO_EARLY_CHAINS=1: off -- such voices go to the block loop) */
+	uint32_t chain_early; /* chain_kernel: 1: this launch runs the early chains (CL_EARLY), whole segment; 0: the others */
 	/* Saved phase increments: a running-sum oscillator's per-frame increments, computed in the sum pass of its
 	 * level, go to a row pair in HBM (W: 32 bits in the first row; R: low and high words), and the final pass
 	 * reads them back instead of evaluating the frequency again -- whatever only produced that frequency (FM

@@ -753,6 +753,40 @@ def test_feedback_chains_at_other_pipeline_depths(sa, oracle, chunks, monkeypatc
     check(sa, oracle, voices, chunk=50000)
 
 
+@pytest.mark.parametrize("early", ["on", "off"])
+def test_feedback_chains_that_running_sums_depend_on(sa, oracle, early, monkeypatch):
+    """A feedback chain whose inputs are its own lines runs before every pass when something the passes compute
+    depends on it (FastInfo.early): the shape of examples/sounds/kaboom1.sau -- a self-modulating W
+    oscillator range-modulating the frequency of an R oscillator that range-modulates the carrier's frequency --,
+    a chain FM-ing a W carrier, a chain whose phase is modulated by such a chain (the outer one runs in chunks as
+    usual and reads the inner one's row), frequency and amount ramps on the early chain, an early and an ordinary
+    chain in one voice. Bit-exact vs the oracle, also with SAU_AMD_NO_EARLY_CHAINS=1 (such voices then take the block loop:
+    kaboom1 71 against 32 ms, tools/gpu_script_phases.py)."""
+    if early == "off":
+        monkeypatch.setenv("SAU_AMD_NO_EARLY_CHAINS", "1")
+    oracle.oracle().ora_set_fastmath_forms(1)
+    def fb(f=0.2, a=0.5, amp=1.0, **kw):
+        return vb.Op("sin", freq=f, pm_a=a, amp=amp, **kw)
+    kaboom = vb.Op("sin", freq=-500.0, freq2=500.0, amp=vb.Line(0.0, goal=1.0, shape="exp"), time_ms=1500,
+                   mods={POP_RFMOD: [vb.Op(op_type=POPT_RASEG, ras=("smo", 0, 0), seed=7, freq=1.0, freq2=10.0,
+                                           mods={POP_RFMOD: [fb(phase=0.25)]})]})
+    fm = vb.Op("tri", freq=220.0, time_ms=900, mods={POP_FMOD: [fb(3.0, vb.Line(0.2, goal=0.7, shape="lin"), amp=40.0)]})
+    nested = vb.Op("sin", freq=150.0, pm_a=0.4, time_ms=800,
+                   mods={POP_PMOD: [vb.Op("sin", freq=vb.Line(2.0, goal=5.0, shape="cos"), pm_a=0.6, amp=0.8)]})
+    both = vb.Op("saw", freq=110.0, time_ms=700,
+                 mods={POP_FMOD: [fb(2.5, 0.3, amp=25.0)],
+                       POP_PMOD: [vb.Op("sin", freq=vb.Line(2.0, ratio=True), pm_a=0.5, amp=0.7,
+                                        mods={POP_PMOD: [vb.Op("tri", freq=vb.Line(3.0, ratio=True), amp=0.3)]})]})
+    voices = [kaboom, fm, nested, both]
+    for vs in ([kaboom], [fm], [nested], [both], voices):
+        prg = vb.build_program(vs)
+        want = oracle.oracle_render(prg.ptr, RATE, True)
+        for chunk in (1000000, 30000):
+            got = sa.Batch([prg], RATE).render(stereo=True, chunk=chunk)[0]
+            d = np.nonzero(got != want)[0]
+            assert len(got) == len(want) and len(d) == 0, (len(vs), chunk, len(d), d[:4])
+
+
 @pytest.mark.parametrize("lookback", ["on", "off"])
 def test_running_sums_by_look_back(sa, oracle, lookback, monkeypatch):
     """Running-sum phases in one pass (every wave publishes its row group's sum and looks back
