@@ -232,7 +232,8 @@ def run_config3(args, R, sa, tabs):
     import numpy as np
     from saugns_amd import voicebank
     index = json.load(open(os.path.join(GOLDEN, "index.json")))
-    seconds = max(1, (args.frames * (args.steps + args.warmup + 2)) // 44100 + 2)
+    sustain = 0 if test_backend() else max(0, args.sustain)
+    seconds = max(1, (args.frames * (args.steps + args.warmup + sustain + 2)) // 44100 + 2)
     prg = voicebank.config3(n=args.voices, seconds=seconds)
     batch = new_batch(sa, [prg])
     # what is about to be timed is the reference's render: the first step (the script's first 10 s)
@@ -255,6 +256,20 @@ def run_config3(args, R, sa, tabs):
     dt = R.max(time.perf_counter() - t0)
     tm = batch.timing_ex()
     frames_total = args.frames * args.steps * R.world
+    # The same step a thousand times over, a few seconds of nothing but these kernels: what the timed K steps give
+    # when the device stays busy (clocks, thermals), and long enough for a sampled GPU-utilisation reading to see it.
+    # Reported beside `value`, never as it.
+    sustained = None
+    if sustain:
+        batch.set_timing(0)
+        R.barrier([batch])
+        t1 = time.perf_counter()
+        for _ in range(sustain):
+            batch.run(args.frames, stereo=False, fetch=False)
+        R.barrier([batch])
+        ds = R.max(time.perf_counter() - t1)
+        sustained = {"steps": sustain, "seconds": ds, "ms_per_step": ds / sustain * 1e3,
+                     "value": args.frames * sustain * R.world / ds}
     # the only exchange of the whole job is this after-the-fact reduction of
     # {frames rendered, PCM checksum} for the scaling report (outside the timed region)
     pcm = batch.run(args.frames, stereo=False)[0]
@@ -283,7 +298,7 @@ def run_config3(args, R, sa, tabs):
                                f"{args.frames} frames per step, per GPU",
                    "voices": args.voices, "operators": n_ops, "frames_per_step": args.frames,
                    "frames_all_ranks": tally[0], "pcm_checksum_all_ranks": tally[1],
-                   "first_step_verified": verified,
+                   "first_step_verified": verified, "sustained": sustained,
                    "voice_samples_per_s": frames_total / dt * args.voices,
                    "operator_samples_per_s": frames_total / dt * n_ops},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
@@ -561,6 +576,8 @@ def main():
     ap.add_argument("--voices5", type=int, default=4096, help="config5: voices")
     ap.add_argument("--c4-run", type=int, default=0, help="config4: frames per engine run (default: the whole 60 s)")
     ap.add_argument("--c4-frames", type=int, default=0, help="config4 (tests): render only the first frames of each script")
+    ap.add_argument("--sustain", type=int, default=1000, help="config3: steps of the sustained run after the timed region "
+                    "(reported under `sustained`, never `value`; 0: none)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="config3: no short config 5 / config 4 runs after it")
     args = ap.parse_args()
