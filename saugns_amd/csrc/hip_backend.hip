@@ -882,6 +882,7 @@ public:
 						if (!raise_lds_attr((const void *)chain_kernel, clds, chain_lds_configured_[dev_ & 15], err)) return false;
 						fp.chain_early = 1; fp.range_mode = 0;
 						hipLaunchKernelGGL(chain_kernel, dim3((seg.n_chain_rows + 63) / 64), dim3(128), clds, stream_, fp);
+						hipLaunchKernelGGL(rchain_kernel, dim3((seg.n_chain_rows + 63) / 64), dim3(64), 0, stream_, fp); /* R feedback */
 						fp.chain_early = 0;
 					}
 					for (uint32_t pass = 1; pass <= fp.sum_levels && (!fp.look || seg.n_chain_rows); ++pass) {

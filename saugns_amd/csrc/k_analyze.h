@@ -1,9 +1,11 @@
 /* k_analyze.h -- part of hip_backend.hip (included there, inside namespace sauhip; not a header of its own).
  * analyze_kernel: which voices the time-parallel path takes this segment, and in which form. */
 
-/* a W oscillator step whose self-modulation is on (generator.c:479-498, wosc.h:273-310): chain_kernel's */
+/* a W oscillator step whose self-modulation is on (generator.c:479-498, wosc.h:273-310): chain_kernel's; or an R
+ * oscillator's (rasg.h:242-294): rchain_kernel's -- on this path only when its inputs are its own lines
+ * (step_is_chain_inline; analyze_kernel sends every other voice with R feedback to the block loop) */
 __device__ __forceinline__ bool step_is_chain(const Step &st, const DevOp &o) {
-	return !o.rt_frozen && step_may_chain(st) && o.type == OT_WAVE &&
+	return !o.rt_frozen && step_may_chain(st) && (o.type == OT_WAVE || o.type == OT_RASEG) &&
 		(st.sm != NO_SLOT || o.line[L_PMA].v0 != 0.f || (o.line[L_PMA].flags & LP_GOAL));
 }
 /* ... and whose varying frequency is its only phase input: chain_kernel sums the phase increments itself
@@ -70,7 +72,7 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 	const VoiceDesc vd = P.voices[v];
 	const uint32_t *ids = P.op_ids + vd.ops_ofs;
 	bool bad = (vd.flags & VD_NO_FAST) != 0 || !P.enable;
-	bool seq = false, has_red = false, has_rcub = false;
+	bool seq = false, has_red = false, has_rcub = false, has_rchain = false;
 	uint32_t min_time = 0xFFFFFFFFu;
 	const Step *plan = P.steps + vd.plan_ofs;
 	/* An operator that has run out of time yields nothing, and neither it nor
@@ -117,14 +119,15 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 			if (ln == L_FREQ || ln == L_FREQ2) seq = true; /* phase becomes a running sum */
 			else if (ln == L_PAN) { /* fine when the plan gives the pan line a step of its own */
 				if (!(vd.plan_len && plan[vd.plan_len - 1].kind == ST_VOICE)) bad = true;
-			} else if (ln == L_PMA) { if (!(chain_ok && o.type == OT_WAVE)) bad = true; }
+			} else if (ln == L_PMA) { if (!(chain_ok && (o.type == OT_WAVE || (o.type == OT_RASEG && P.chain_early_ok)))) bad = true; }
 			else if (ln != L_AMP && ln != L_AMP2) bad = true;
 		}
 		/* red noise (noise.h:136-147) is a wrapping running sum of a counter hash: the single-pass build takes it
 		 * like a running-sum phase, prefixes by look-back (has_red: only there) */
 		if (o.type == OT_NOISE && o.wave == NZ_re) { seq = true; has_red = true; }
-		/* self-modulation is a recurrence: W oscillators' go to chain_kernel, R's to the block loop */
-		if (o.line[L_PMA].v0 != 0.f && !(chain_ok && o.type == OT_WAVE)) bad = true;
+		/* self-modulation is a recurrence: W oscillators' go to chain_kernel, R's to rchain_kernel when their inputs are
+		 * their own lines (decided per step below), else to the block loop */
+		if (o.line[L_PMA].v0 != 0.f && !(chain_ok && (o.type == OT_WAVE || (o.type == OT_RASEG && P.chain_early_ok)))) bad = true;
 		if (o.type == OT_WAVE) o.ras_level = 0; /* (CHAIN_MARK of an earlier segment) */
 		o.rt_fconst_valid = 0;
 		o.rt_fblk_valid = 0;
@@ -178,6 +181,11 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 		if (step_may_chain(st) && o.type == OT_WAVE &&
 		    (st.sm != NO_SLOT || o.line[L_PMA].v0 != 0.f || (o.line[L_PMA].flags & LP_GOAL)))
 			has_chain = true;
+		if (step_may_chain(st) && o.type == OT_RASEG && !o.rt_frozen &&
+		    (st.sm != NO_SLOT || o.line[L_PMA].v0 != 0.f || (o.line[L_PMA].flags & LP_GOAL))) {
+			has_chain = true; /* (its eligibility -- fed from its own lines -- is decided with the chains' data flow below) */
+			has_rchain = true;
+		}
 		/* a ratio line (sau/line.c:72) multiplies by the parent's frequency: one value, or a block */
 		bool pconst = false; float pf = 0.f;
 		if (st.fmul != NO_SLOT && st.fmul >= FSLOT_BASE) {
@@ -328,11 +336,15 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 			} else if (st.kind == ST_OSC) {
 				const bool in_dep = dep(c0, st.pm) || dep(c0, st.fpm) || dep(c0, st.freq) || dep(c0, st.fmul) || dep(c0, st.sm);
 				const bool in_late = dep(c1, st.pm) || dep(c1, st.fpm) || dep(c1, st.freq) || dep(c1, st.fmul) || dep(c1, st.sm);
-				const bool chain = step_may_chain(st) && o.type == OT_WAVE &&
+				const bool chain = step_may_chain(st) && (o.type == OT_WAVE || o.type == OT_RASEG) &&
 					(st.sm != NO_SLOT || o.line[L_PMA].v0 != 0.f || (o.line[L_PMA].flags & LP_GOAL));
-				const bool fvar = (o.type == OT_WAVE || o.type == OT_RASEG) && !o.rt_fconst_valid;
 				uint32_t ls_ = ~0u;
 				const bool inl = chain && step_is_chain_inline(P.chain_early_ok != 0, plan, si, ids, P.ops, &ls_);
+				/* (a chain that sums its own increments is no running sum of the passes) */
+				const bool fvar = (o.type == OT_WAVE || o.type == OT_RASEG) && !o.rt_fconst_valid && !(chain && inl);
+				if (chain && o.type == OT_RASEG) { /* R feedback: only as an early chain fed from its own lines */
+					if (inl) early = true; else bad = true;
+				}
 				if (chain && in_late) bad = true;
 				else if (chain && in_dep) early = true;
 				if (fvar && (dep(c1, st.freq) || dep(c1, st.fmul))) bad = true;
@@ -404,6 +416,7 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 		n_scan_out = n_scan;
 	}
 	if (has_red && seq_kind != 3) bad = true; /* (the several-pass and in-order forms do not carry noise sums) */
+	(void)has_rchain;
 	if (has_rcub && (!P.cub_ok || (seq_kind != 0 && seq_kind != 3) || has_chain)) bad = true; /* (only the closed-form build has the tail code) */
 	if (has_chain && !bad) {
 		if (seq_kind == 1) bad = true; /* (one wave in order: not with chains) */

@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(128) chain_kernel(FastParams P) {
 	/* this launch's share of the chain: frames [c_lo, n) of the segment, n cut at the chunk's end */
 	const uint32_t c_lo = P.range_mode ? P.f_lo : 0u;
 	uint32_t n = cd.n;
-	if (((cd.lflags & CL_EARLY) != 0) != (P.chain_early != 0)) n = 0; /* the early chains have a launch of their own, ahead of the passes */
+	if (((cd.lflags & CL_EARLY) != 0) != (P.chain_early != 0) || (cd.lflags & CL_RASEG)) n = 0; /* the early chains have a launch of their own, ahead of the passes */
 	if (P.range_mode && n > P.f_hi) n = P.f_hi;
 	if (n <= c_lo) n = 0;
 	if (!__any(n != 0)) return;
@@ -329,4 +329,52 @@ __global__ void __launch_bounds__(128) chain_kernel(FastParams P) {
 		o.ras_alpha = f_bits(fb_s);
 		o.ras_level = CHAIN_MARK;
 	}
+}
+
+/* R-oscillator feedback (rasg.h:242-294: per sample, feedback -> phase offset -> cycle carry -> segment value ->
+ * feedback), lanes = chains, for R oscillators fed from their own lines (CL_RASEG: always early chains, whole
+ * segment, ahead of every pass). No feeder wave: the counter is the lane's own running sum of its frequency line's
+ * increments, the amounts come from its pm_a line; samples go to the chain's first row, where every pass that
+ * needs them reads them (FT_CHAIN_EARLY). Nothing here is tuned -- no BASELINE configuration or corpus script has
+ * R feedback; what it buys is that such voices no longer take the block loop's one-lane loop. */
+__global__ void __launch_bounds__(64) rchain_kernel(FastParams P) {
+	if (P.pass_flags[FAST_EARLY_FLAG] == 0) return;
+	const uint32_t c = blockIdx.x * 64 + threadIdx.x;
+	if (c >= P.n_chain_rows || P.chain_desc[c].n == 0) return;
+	const ChainDesc cd = P.chain_desc[c];
+	if (!(cd.lflags & CL_RASEG)) return;
+	DevOp &o = P.ops[cd.gop];
+	const bool rate2x = (o.flags & OPF_RATE2X) != 0;
+	const float rcoeff = rate2x ? cd.coeff * 2 : cd.coeff;
+	const RasParams rp = ras_params(o.ras_func, o.ras_flags, o.ras_level, o.ras_alpha, o.wave);
+	float *row = P.chain_rows + (size_t)2 * c * P.chain_stride;
+	unsigned long long cp = o.cycle_phase;
+	const unsigned long long inc_c = (unsigned long long)rint64(rcoeff * o.rt_fconst);
+	float fb_s = o.fb_s, prev_s = o.prev_s;
+	for (uint32_t t = 0; t < cd.n; ++t) {
+		unsigned long long inc = inc_c;
+		if (!(cd.lflags & CL_FCONST)) {
+			float v = fast_line_value(cd.fl, (int)t);
+			if (cd.lflags & (t < cd.fl.goal_len ? CL_MUL_GOAL : CL_MUL_HOLD)) v *= cd.mulc;
+			inc = (unsigned long long)rint64(rcoeff * v);
+		}
+		uint32_t cyc; float phf;
+		ras_split(cp, cyc, phf); /* rasg.h:184-186, post-increment */
+		cp += inc;
+		const float pma_v = fast_line_value(cd.pl, (int)t);
+		const float pm_a = fb_s * pma_v * 0.5f;
+		float phase = phf + pm_a;
+		const int32_t cycle_adj = (int32_t)floorf(phase);
+		const uint32_t cycle = cyc + (uint32_t)cycle_adj;
+		phase -= (float)cycle_adj;
+		const float sv = ras_sample(rp, cycle, phase, false);
+		row[t] = sv;
+		fb_s = ((fb_s + prev_s) + sv) * 0.5f; /* the reference build's association (see the oracle) */
+		prev_s = sv;
+	}
+	/* staged: finalize_kernel makes it the operator's state unless the voice's segment is redone */
+	o.st_prev_Is = __longlong_as_double((long long)cp);
+	o.st_prev_s = prev_s;
+	o.st_prev_phase = f_bits(fb_s);
+	o.st_phase = CHAIN_MARK;
 }

@@ -34,7 +34,8 @@ enum : uint32_t {
 	CM_INC = 1,    /* first row: phase increments (the chain sums them), second: amounts */
 	CM_INLINE = 2, /* no input rows: frequency and amounts are the operator's own lines, evaluated by the feeder wave */
 };
-enum : uint32_t { CL_FCONST = 1, CL_MUL_GOAL = 2, CL_MUL_HOLD = 4, CL_EARLY = 8 /* runs in the launch ahead of the passes (FastInfo.early) */ };
+enum : uint32_t { CL_FCONST = 1, CL_MUL_GOAL = 2, CL_MUL_HOLD = 4, CL_EARLY = 8 /* runs in the launch ahead of the passes (FastInfo.early) */,
+	CL_RASEG = 16 /* an R oscillator: rchain_kernel's (always early) */ };
 struct ChainDesc {
 	uint32_t n;      /* frames to run this segment (0: row pair unused; the other fields are then unset) */
 	uint32_t gop;    /* the operator's state (global index) */
@@ -248,6 +249,7 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 				chain_inline = true;
 				cd.mode = CM_INLINE;
 				if (P.info[v].early) { cd.lflags |= CL_EARLY; f.type |= FT_CHAIN_EARLY; }
+				if (o.type == OT_RASEG) cd.lflags |= CL_RASEG;
 				cd.coeff = o.coeff;
 				cd.pl = pl;
 				cd.mulc = 1.f;

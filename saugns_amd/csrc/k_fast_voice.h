@@ -163,7 +163,8 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 				const bool to_voice = ((f.kind >> 16) & OX_VOICE) != 0;
 				float s[T];
 				const bool chain = CH && (f.type & FT_CHAIN) != 0;
-				if (type == OT_WAVE && chain && (P.mode == P.sum_levels + 1 || (f.type & FT_CHAIN_EARLY))) { /* (the final pass; any pass) */
+				if ((type == OT_WAVE && chain && (P.mode == P.sum_levels + 1 || (f.type & FT_CHAIN_EARLY))) ||
+				    (type == OT_RASEG && chain)) { /* (R feedback: always an early chain, rchain_kernel) */ /* (the final pass; any pass) */
 					/* a feedback chain: chain_kernel has run it; its samples are in the row */
 					const float *crow = P.chain_rows + (size_t)2 * f_bits(f.pan) * P.chain_stride;
 #pragma unroll

@@ -79,7 +79,13 @@ __global__ void __launch_bounds__(64) finalize_kernel(FastParams P) {
 		} else if (o.type == OT_RASEG) {
 			const bool rate2x = (o.flags & OPF_RATE2X) != 0;
 			const unsigned long long inc64 = (unsigned long long)rint64((rate2x ? o.coeff * 2 : o.coeff) * o.rt_fconst);
-			if (o.rt_fconst_valid) o.cycle_phase += inc64 * total;
+			if (o.st_phase == CHAIN_MARK) { /* a feedback chain: rchain_kernel staged the counter and the feedback state */
+				o.cycle_phase = (unsigned long long)__double_as_longlong(o.st_prev_Is);
+				o.prev_s = o.st_prev_s;
+				o.fb_s = bits_f(o.st_prev_phase);
+				o.st_phase = 0;
+			}
+			else if (o.rt_fconst_valid) o.cycle_phase += inc64 * total;
 			else o.cycle_phase = (unsigned long long)__double_as_longlong(o.st_prev_Is); /* running sum, staged */
 		} else if (o.type == OT_NOISE) {
 			const uint32_t n0 = o.noise_n;

@@ -777,8 +777,15 @@ def test_feedback_chains_that_running_sums_depend_on(sa, oracle, early, monkeypa
                  mods={POP_FMOD: [fb(2.5, 0.3, amp=25.0)],
                        POP_PMOD: [vb.Op("sin", freq=vb.Line(2.0, ratio=True), pm_a=0.5, amp=0.7,
                                         mods={POP_PMOD: [vb.Op("tri", freq=vb.Line(3.0, ratio=True), amp=0.3)]})]})
-    voices = [kaboom, fm, nested, both]
-    for vs in ([kaboom], [fm], [nested], [both], voices):
+    # R-oscillator feedback (rasg.h:242-294), fed from its own lines: rchain_kernel, always early -- as a carrier with
+    # frequency and amount ramps, as a PM source, as the modulator of a running sum, beside a W chain
+    rfb = vb.Op(op_type=POPT_RASEG, ras=("cos", 1, 9), seed=11, freq=vb.Line(90.0, goal=240.0, shape="exp"),
+                pm_a=vb.Line(0.3, goal=1.2, shape="lin"), amp=0.6, time_ms=600)
+    rpm = vb.Op("sin", freq=200.0, time_ms=500, pm_a=0.3,
+                mods={POP_PMOD: [vb.Op(op_type=POPT_RASEG, ras=("lin", 3, 2), seed=12, freq=vb.Line(1.5, ratio=True), pm_a=0.8, amp=0.5)],
+                      POP_FMOD: [vb.Op(op_type=POPT_RASEG, ras=("smo", 0, 16), seed=13, freq=7.0, pm_a=0.5, amp=30.0)]})
+    voices = [kaboom, fm, nested, both, rfb, rpm]
+    for vs in ([kaboom], [fm], [nested], [both], [rfb], [rpm], voices):
         prg = vb.build_program(vs)
         want = oracle.oracle_render(prg.ptr, RATE, True)
         for chunk in (1000000, 30000):
