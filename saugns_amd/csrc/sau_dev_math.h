@@ -395,6 +395,36 @@ SAU_HD void line_hold_blocks(LineState &o, uint32_t b, uint32_t k) {
 	o.pos = (k % q) * b;
 }
 
+/* line_hold_blocks(o, LAT_BLOCK, k) and line_hold_blocks(o, b, 1) without their divisions (LAT_BLOCK is a power of two;
+ * one block either fits before the end or wraps to 0) */
+SAU_HD void line_hold_blocks_lat(LineState &o, uint32_t k) {
+	static_assert((LAT_BLOCK & (LAT_BLOCK - 1)) == 0, "shifts below");
+	constexpr uint32_t SH = 10;
+	static_assert((1u << SH) == LAT_BLOCK, "LAT_BLOCK is 1024");
+	if (o.pos >= o.end) {
+		o.pos = 0;
+		o.flags &= ~LP_TIME;
+		if (--k == 0 || o.end == 0) return;
+	}
+	const uint32_t left = o.end - o.pos;
+	const uint32_t j = (left + (LAT_BLOCK - 1)) >> SH;
+	if (k < j) { o.pos += k << SH; return; }
+	o.flags &= ~LP_TIME;
+	k -= j;
+	const uint32_t q = (o.end + (LAT_BLOCK - 1)) >> SH;
+	o.pos = (k < q ? k : k % q) << SH;
+}
+SAU_HD void line_hold_block_one(LineState &o, uint32_t b) {
+	if (o.pos >= o.end) {
+		o.pos = 0;
+		o.flags &= ~LP_TIME;
+		return;
+	}
+	if (o.end - o.pos > b) { o.pos += b; return; } /* (k = 1 < j = ceil(left / b)) */
+	o.flags &= ~LP_TIME;
+	o.pos = 0; /* j = 1, k - j = 0: (0 % q) * b */
+}
+
 /* one reference block of `b` frames has ended for a held line */
 SAU_HD void line_hold_block_end(LineState &o, uint32_t b) {
 	if (o.flags & LPX_SKIP) o.flags &= ~LPX_SKIP; /* its sweep ended inside this block: sau/line.c:436 pos = 0 stands */
@@ -423,6 +453,20 @@ SAU_HD void line_hold_lat(LineState &o, uint32_t n, const Lattice &lat, uint32_t
 		}
 		if (sp == 0 && (pend || (o.flags & LPX_SKIP))) { line_hold_block_end(o, pend); pend = 0; }
 		if (n == 0) break;
+		/* whole spans in a row (a 60 s segment has 234 spans of the host's call size; walking them through the general
+		 * code below, four integer divisions each, cost finalize_kernel 120 us per launch): every such span is the same
+		 * run of reference blocks -- `full` of LAT_BLOCK frames, then one of `tail` -- and for those two shapes
+		 * line_hold_blocks() needs no division but the one of a position that wraps */
+		if (sp == 0 && off >= lat.span_left && n >= lat.call_len) {
+			const uint32_t full = lat.call_len / LAT_BLOCK, tail = lat.call_len % LAT_BLOCK;
+			do {
+				if (full) line_hold_blocks_lat(o, full);
+				if (tail) line_hold_block_one(o, tail);
+				n -= lat.call_len; off += lat.call_len;
+			} while (n >= lat.call_len);
+			if (n == 0) break;
+			continue;
+		}
 		uint32_t m = n < rem ? n : rem; /* frames run within this span */
 		const bool to_end = m == rem;
 		n -= m; off += m;
