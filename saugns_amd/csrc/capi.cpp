@@ -31,18 +31,24 @@ struct sauAmdBatch {
  * for 11289 frames at a time (saugns.c:589-618), and a device round trip per
  * such call would cost more than the rendering. Output does not depend on how
  * the stream is cut into calls (as in the reference), so the PCM of one larger
- * engine run is handed out piecewise, from two page-locked buffers: while the
- * host consumes one, the device renders and copies the next run into the other.
+ * engine run is handed out piecewise, from three page-locked buffers: while the
+ * host consumes one, the device renders and copies the next two runs into the
+ * others -- two, so that a run is already queued when the one before it ends
+ * (with one run in flight the device stood idle between a run's completion and
+ * the host's next issue: 1.27 ms per 176400-frame run of BASELINE config 3
+ * against 0.93 ms of kernels; SAU_AMD_READAHEAD_DEPTH=1 gives that back).
  * SAU_AMD_READAHEAD=<frames> sets the size of a run, 0 turns the scheme off. */
 struct sauGenerator {
 	sauAmdBatch batch;
-	int16_t *slot[2] = {nullptr, nullptr}; /* backend->alloc_host() */
-	size_t slot_cap[2] = {0, 0};           /* int16 values */
+	static constexpr int SLOTS = 3;
+	int16_t *slot[SLOTS] = {nullptr, nullptr, nullptr}; /* backend->alloc_host() */
+	size_t slot_cap[SLOTS] = {0, 0, 0};    /* int16 values */
 	size_t ahead_frames = 176400;          /* frames per engine run */
 	int cur = 0;                           /* the slot being handed out */
 	size_t pos = 0, len = 0;               /* its unread part, in frames */
-	bool queued = false;                   /* a run into slot[cur^1] has been issued */
-	size_t q_len = 0;
+	int queued = 0;                        /* runs issued into slot[cur + 1 ..] and not yet handed out (0..depth) */
+	int depth = 2;                         /* runs in flight at most (SAU_AMD_READAHEAD_DEPTH, 1 or 2) */
+	size_t q_len[SLOTS] = {0, 0, 0};       /* frames of the run in each slot */
 	bool ahead_stereo = false;
 	bool more = true;                      /* the engine has signal left after everything issued */
 	/* The first runs are short and grow fourfold from one to the next (1, 4, 16, ... host calls) until they reach
@@ -88,6 +94,7 @@ static sauGenerator *make_generator(const sauProgram *prg, uint32_t srate, Backe
 	if (!make_batch(g->batch, &prg, 1, srate, injected)) { delete g; return nullptr; }
 	if (const char *ra = getenv("SAU_AMD_READAHEAD")) g->ahead_frames = (size_t)atol(ra);
 	if (const char *rr = getenv("SAU_AMD_READAHEAD_RAMP")) g->ramp = atoi(rr) != 0;
+	if (const char *rd = getenv("SAU_AMD_READAHEAD_DEPTH")) g->depth = atoi(rd) >= 2 ? 2 : 1;
 	return g;
 }
 
@@ -106,8 +113,7 @@ extern "C" void sau_destroy_Generator(sauGenerator *o) {
 	Backend *be = o->batch.engine->backend();
 	std::string err;
 	(void)be->sync(err); /* a queued run may still be writing into a slot */
-	be->free_host(o->slot[0]);
-	be->free_host(o->slot[1]);
+	for (int i = 0; i < sauGenerator::SLOTS; ++i) be->free_host(o->slot[i]);
 	delete o->batch.engine;
 	delete o;
 }
@@ -118,13 +124,13 @@ static bool generator_fail(sauGenerator *o, int16_t *buf, size_t buf_len, bool s
 	report("generator", err);
 	memset(buf, 0, sizeof(int16_t) * buf_len * (stereo ? 2 : 1));
 	if (out_len) *out_len = 0;
-	o->more = false; o->pos = o->len = 0; o->queued = false;
+	o->more = false; o->pos = o->len = 0; o->queued = 0;
 	return false;
 }
 
-/* Start the next engine run; its PCM lands in the slot not being handed out. */
+/* Start the next engine run; its PCM lands in the first slot behind the one being handed out and those queued. */
 static bool generator_issue(sauGenerator *o, size_t big, size_t call_len, bool stereo, std::string &err) {
-	const int k = o->cur ^ 1;
+	const int k = (o->cur + 1 + o->queued) % sauGenerator::SLOTS;
 	const size_t ch = stereo ? 2 : 1;
 	Backend *be = o->batch.engine->backend();
 	/* this run: whole host calls, four times as many as the run before, up to `big` (every run has a fixed cost of
@@ -145,8 +151,8 @@ static bool generator_issue(sauGenerator *o, size_t big, size_t call_len, bool s
 	/* PCM stays on the device; the copy queues behind the mixer */
 	if (!o->batch.engine->run(nullptr, frames, stereo, &more, &len, err)) return false;
 	if (len && !be->fetch_pcm_async(0, o->slot[k], (uint32_t)len, stereo, k, err)) return false;
-	o->queued = true;
-	o->q_len = len;
+	++o->queued;
+	o->q_len[k] = len;
 	o->more = more;
 	o->ahead_stereo = stereo;
 	return true;
@@ -183,6 +189,7 @@ extern "C" bool sauGenerator_run(sauGenerator *o, int16_t *buf, size_t buf_len,
 	const size_t big = buf_len >= o->ahead_frames ? buf_len : o->ahead_frames / buf_len * buf_len;
 	o->batch.engine->set_call_len(buf_len);
 	size_t filled = 0;
+	bool issued = false;
 	while (filled < buf_len) {
 		if (o->pos == o->len) {
 			if (!o->queued) {
@@ -190,13 +197,17 @@ extern "C" bool sauGenerator_run(sauGenerator *o, int16_t *buf, size_t buf_len,
 				if (!generator_issue(o, big, buf_len, stereo, err))
 					return generator_fail(o, buf, buf_len, stereo, out_len, err);
 			}
-			if (!o->batch.engine->backend()->wait_fetch(o->cur ^ 1, err))
+			const int nx = (o->cur + 1) % sauGenerator::SLOTS;
+			if (!o->batch.engine->backend()->wait_fetch(nx, err))
 				return generator_fail(o, buf, buf_len, stereo, out_len, err);
-			o->cur ^= 1;
-			o->pos = 0; o->len = o->q_len; o->queued = false;
+			o->cur = nx;
+			o->pos = 0; o->len = o->q_len[nx]; --o->queued;
 			/* the device goes on with the run after this one while the host consumes */
-			if (o->more && !generator_issue(o, big, buf_len, stereo, err))
-				return generator_fail(o, buf, buf_len, stereo, out_len, err);
+			if (o->more && o->queued < o->depth) {
+				if (!generator_issue(o, big, buf_len, stereo, err))
+					return generator_fail(o, buf, buf_len, stereo, out_len, err);
+				issued = true;
+			}
 			if (o->len == 0) { if (!o->queued) break; continue; }
 		}
 		size_t n = o->len - o->pos;
@@ -207,6 +218,11 @@ extern "C" bool sauGenerator_run(sauGenerator *o, int16_t *buf, size_t buf_len,
 	}
 	if (filled < buf_len) /* generator.c:911-914: the rest of the buffer is silence */
 		memset(buf + filled * ch, 0, (buf_len - filled) * ch * sizeof(int16_t));
+	/* a second run in flight, so that one is queued when the one before it ends -- topped up by a call that issued
+	 * nothing itself (never the first: what the host waits for there is one call's worth of rendering) */
+	if (!issued && o->more && o->queued >= 1 && o->queued < o->depth && o->ahead_stereo == stereo)
+		if (!generator_issue(o, big, buf_len, stereo, err))
+			return generator_fail(o, buf, buf_len, stereo, out_len, err);
 	if (out_len) *out_len = filled;
 	return o->more || o->queued || o->pos < o->len;
 }

@@ -92,7 +92,7 @@ public:
 	virtual const int16_t *device_pcm(uint32_t stream) = 0;
 	virtual bool sync(std::string &err) = 0;
 	/* Output stage: queue a copy of stream s PCM [0, frames) into host memory from
-	 * alloc_host(); `slot` (0 or 1) names the copy for wait_fetch(). Later device
+	 * alloc_host(); `slot` (0..3) names the copy for wait_fetch(). Later device
 	 * work is ordered behind the copy. Defaults suit CPU test backends. */
 	virtual bool fetch_pcm_async(uint32_t stream, int16_t *dst, uint32_t frames, bool stereo,
 			int slot, std::string &err) { (void)slot; return fetch_pcm(stream, dst, frames, stereo, err); }

@@ -294,7 +294,7 @@ public:
 		for (int i = 0; i < 2; ++i) { if (copy_ev_[i]) (void)hipEventDestroy(copy_ev_[i]); if (pcm_mix_ev_[i]) (void)hipEventDestroy(pcm_mix_ev_[i]); }
 		if (chain_stream_) { (void)hipStreamSynchronize(chain_stream_); StreamPool::get().give(dev_, chain_stream_); }
 		for (hipEvent_t e : chain_ev_) (void)hipEventDestroy(e);
-		for (int i = 0; i < 2; ++i) if (fetch_ev_[i]) (void)hipEventDestroy(fetch_ev_[i]);
+		for (int i = 0; i < 4; ++i) if (fetch_ev_[i]) (void)hipEventDestroy(fetch_ev_[i]);
 		for (auto &e : events_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
 		if (stream_) StreamPool::get().give(dev_, stream_); /* drained above */
 	}
@@ -1100,7 +1100,7 @@ public:
 	 * ahead of the next run's kernels on the one stream */
 	bool fetch_pcm_async(uint32_t stream, int16_t *dst, uint32_t frames, bool stereo, int slot,
 			std::string &err) override {
-		slot &= 1;
+		slot &= 3;
 		use_device();
 		if (!fetch_ev_[slot]) HIP_OK(hipEventCreateWithFlags(&fetch_ev_[slot], hipEventDisableTiming));
 		/* with mixers on mix_stream_ the copy follows them there, so that stream_ is free to start the next run */
@@ -1122,7 +1122,7 @@ public:
 		return true;
 	}
 	bool wait_fetch(int slot, std::string &err) override {
-		slot &= 1;
+		slot &= 3;
 		if (fetch_ev_[slot]) HIP_OK(hipEventSynchronize(fetch_ev_[slot]));
 		return true;
 	}
@@ -1327,7 +1327,7 @@ private:
 	DevBuf<unsigned char> fsteps_, flines_, faux_;
 	DevBuf<unsigned long long> scan_;
 	DevBuf<uint32_t> pass_flags_, repair_;
-	hipEvent_t fetch_ev_[2] = {nullptr, nullptr};
+	hipEvent_t fetch_ev_[4] = {nullptr, nullptr, nullptr, nullptr}; /* per host slot of the drop-in generator's read-ahead */
 	int dev_ = 0;
 	std::map<void *, size_t> host_blocks_; /* alloc_host() blocks and their pool sizes */
 	uint32_t multi_min_ = 256;
