@@ -1,7 +1,7 @@
 """Experiment (r03): what each of rainy_thunder.sau's two voices costs alone, 64 renders per batch, 60 s each
 (needs oracle/_ref/libsau_ref.so for the reference's parser)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import saugns_amd as sa

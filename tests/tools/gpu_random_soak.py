@@ -1,9 +1,9 @@
 """Random operator graphs in banks of hundreds of voices, with later events, GPU against the oracle:
 the random-program suites of tests/test_gpu_units.py have 1-3 voices per program (64 waves per voice,
 look-back through HBM words); these banks put the same graphs at 4-13 waves per voice (rings in LDS, voices
-across two workgroups) and at one wave per voice.   python tools/gpu_random_soak.py [first_seed [n_seeds]]"""
+across two workgroups) and at one wave per voice.   python tests/tools/gpu_random_soak.py [first_seed [n_seeds]]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import saugns_amd as sa

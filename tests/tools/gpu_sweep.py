@@ -1,6 +1,6 @@
 """Timing experiments: frames/s for voice banks of different shape (GPU)."""
 import sys, os, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import saugns_amd as sa

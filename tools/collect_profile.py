@@ -100,7 +100,7 @@ if os.path.exists(src):
             k = r["Kernel_Name"].split("(")[0].replace("void ", "")
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     fm = {k: dict({c: sum(x) / len(x) for c, x in v.items()}, launches=len(next(iter(v.values())))) for k, v in agg.items()}
-    json.dump({"command": "rocprofv3 --pmc <C> --kernel-trace -- python3 tools/gpu_sweep.py c3f",
+    json.dump({"command": "rocprofv3 --pmc <C> --kernel-trace -- python3 tests/tools/gpu_sweep.py c3f",
                "note": "1024 voices x 4 operators with carrier FM, then 1024 x 2 with a carrier glide; 44100-frame steps; "
                        "averages per launch over both", "kernels": fm},
               open(f"profiles/{name}_fm_pmc_summary.json", "w"), indent=1)

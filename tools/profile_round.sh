@@ -23,9 +23,9 @@ timeout 180 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpu
 timeout 180 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_c5_write -o m -- python3 bench.py --workload config5 --steps 1 --warmup 0 --no-cpu > /dev/null 2>&1
 timeout 180 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_c5_inst -o i -- python3 bench.py --workload config5 --steps 1 --warmup 0 --no-cpu > /dev/null 2>&1
 # running-sum workloads (carrier FM bank, carrier glide, FM + ratio PM stack): sweep lines, kernel trace, instruction mix
-TLEVEL=0 timeout 180 python3 tools/gpu_sweep.py c3f fmstack mixed > gpurun_out/sweep_${TAG}_fm.txt 2>&1
-timeout 180 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_fm -o ${TAG}_fm -- python3 tools/gpu_sweep.py c3f fmstack > gpurun_out/prof_${TAG}_fm.log 2>&1
-timeout 180 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_fm_inst -o i -- python3 tools/gpu_sweep.py c3f > /dev/null 2>&1
+TLEVEL=0 timeout 180 python3 tests/tools/gpu_sweep.py c3f fmstack mixed > gpurun_out/sweep_${TAG}_fm.txt 2>&1
+timeout 180 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_fm -o ${TAG}_fm -- python3 tests/tools/gpu_sweep.py c3f fmstack > gpurun_out/prof_${TAG}_fm.log 2>&1
+timeout 180 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_fm_inst -o i -- python3 tests/tools/gpu_sweep.py c3f > /dev/null 2>&1
 python bench.py > gpurun_out/bench_${TAG}_full.json 2> gpurun_out/bench_${TAG}_full.err   # the driver's command: all three workloads in one line
 for f in "" _c5 _c4; do tail -1 gpurun_out/bench_$TAG$f.json | cut -c1-200; done
 cat gpurun_out/sweep_${TAG}_fm.txt
