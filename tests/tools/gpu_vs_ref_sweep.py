@@ -1,0 +1,52 @@
+"""GPU against the compiled reference (oracle/_ref/libsau_ref.so) on random programs beyond the suite's 112:
+    python tests/tools/gpu_vs_ref_sweep.py [first_seed [count]]
+Random operator graphs (every modulator list, ramps, R / N / A operators, feedback) with later events and random
+start times, one to three voices, random call sizes, mono and stereo; the product's default (the reference build's
+loop tails reproduced). Every render must equal the reference's bit for bit; the summary goes to
+gpurun_out/gpu_vs_ref_sweep.json."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import saugns_amd as sa
+from saugns_amd import voicebank as vb
+from oracle import pyoracle as po
+import test_gpu_units as T
+
+os.environ["SAU_AMD_LOOP_TAILS"] = "1"
+if not po.have_ref():
+    sys.exit("oracle/_ref/libsau_ref.so is not here (built from /root/reference by oracle/Makefile)")
+po.ref()
+tabs = po.ref_piluts()  # the tables this very reference library built (glibc picks its sin() by CPU)
+sa.set_piluts(tabs)
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+S = {"programs": 0, "identical": 0, "samples": 0, "samples_differing": 0, "max_abs_diff": 0, "differing": [],
+     "first_seed": first, "loop_tails": True}
+t0 = time.time()
+for seed in range(first, first + count):
+    rng = np.random.default_rng(20000 + seed)
+    voices = [T._random_voice(rng) for _ in range(int(rng.integers(1, 4)))]
+    ups = ()
+    if seed % 2:
+        T._random_starts(rng, voices)
+        ups = T._random_updates(rng, voices)
+    prg = vb.build_program(voices, updates=ups)
+    stereo = bool(seed & 2)
+    chunk = int(rng.integers(300, 12000))
+    ref = po.ref_render(prg.ptr, 44100, stereo, chunk=chunk)
+    gpu = sa.Batch([prg], 44100).render(stereo=stereo, chunk=chunk)[0]
+    same = len(gpu) == len(ref) and bool((gpu == ref).all())
+    S["programs"] += 1; S["identical"] += same; S["samples"] += len(ref)
+    if not same:
+        n = min(len(gpu), len(ref))
+        d = np.abs(gpu[:n].astype(np.int32) - ref[:n].astype(np.int32))
+        S["samples_differing"] += int((d > 0).sum()) + abs(len(gpu) - len(ref))
+        S["max_abs_diff"] = max(S["max_abs_diff"], int(d.max()) if n else 0)
+        S["differing"].append({"seed": seed, "call_size": chunk, "stereo": stereo, "lengths": [len(gpu), len(ref)]})
+        print("seed", seed, "DIFFERS", S["differing"][-1], flush=True)
+S["seconds"] = round(time.time() - t0, 1)
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+json.dump(S, open(os.path.join(ROOT, "gpurun_out", "gpu_vs_ref_sweep.json"), "w"), indent=1)
+print(json.dumps({k: v for k, v in S.items() if k != "differing"}))
+sys.exit(0 if S["identical"] == S["programs"] else 1)
