@@ -1,5 +1,5 @@
 """GPU against the compiled reference (oracle/_ref/libsau_ref.so) on random programs beyond the suite's 112:
-    python tests/tools/gpu_vs_ref_sweep.py [first_seed [count]]
+    python tests/tools/gpu_vs_ref_sweep.py [first_seed [count [dropin]]]
 Random operator graphs (every modulator list, ramps, R / N / A operators, feedback) with later events and random
 start times, one to three voices, random call sizes, mono and stereo; the product's default (the reference build's
 loop tails reproduced). Every render must equal the reference's bit for bit; the summary goes to
@@ -21,8 +21,9 @@ tabs = po.ref_piluts()  # the tables this very reference library built (glibc pi
 sa.set_piluts(tabs)
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+dropin = len(sys.argv) > 3 and sys.argv[3] == "dropin"  # through sau_create_Generator / sauGenerator_run (read-ahead runs) instead of the batch API
 S = {"programs": 0, "identical": 0, "samples": 0, "samples_differing": 0, "max_abs_diff": 0, "differing": [],
-     "first_seed": first, "loop_tails": True}
+     "first_seed": first, "loop_tails": True, "api": "drop-in generator" if dropin else "batch"}
 t0 = time.time()
 for seed in range(first, first + count):
     rng = np.random.default_rng(20000 + seed)
@@ -35,7 +36,12 @@ for seed in range(first, first + count):
     stereo = bool(seed & 2)
     chunk = int(rng.integers(300, 12000))
     ref = po.ref_render(prg.ptr, 44100, stereo, chunk=chunk)
-    gpu = sa.Batch([prg], 44100).render(stereo=stereo, chunk=chunk)[0]
+    if dropin:
+        g = sa.Generator(prg, 44100)
+        gpu = g.render(stereo=stereo, chunk=chunk)
+        g.close()
+    else:
+        gpu = sa.Batch([prg], 44100).render(stereo=stereo, chunk=chunk)[0]
     same = len(gpu) == len(ref) and bool((gpu == ref).all())
     S["programs"] += 1; S["identical"] += same; S["samples"] += len(ref)
     if not same:
@@ -47,6 +53,6 @@ for seed in range(first, first + count):
         print("seed", seed, "DIFFERS", S["differing"][-1], flush=True)
 S["seconds"] = round(time.time() - t0, 1)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(S, open(os.path.join(ROOT, "gpurun_out", "gpu_vs_ref_sweep.json"), "w"), indent=1)
+json.dump(S, open(os.path.join(ROOT, "gpurun_out", "gpu_vs_ref_sweep%s.json" % ("_dropin" if dropin else "")), "w"), indent=1)
 print(json.dumps({k: v for k, v in S.items() if k != "differing"}))
 sys.exit(0 if S["identical"] == S["programs"] else 1)
