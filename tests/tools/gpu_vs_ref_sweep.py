@@ -1,7 +1,7 @@
 """GPU against the compiled reference (oracle/_ref/libsau_ref.so) on random programs beyond the suite's 112:
     python tests/tools/gpu_vs_ref_sweep.py [first_seed [count [dropin]]]
 Random operator graphs (every modulator list, ramps, R / N / A operators, feedback) with later events and random
-start times, one to three voices, random call sizes, mono and stereo; the product's default (the reference build's
+start times, one to three voices, random call sizes, mono and stereo, 44.1 kHz and (every third) 8 / 22.05 / 48 / 96 kHz; the product's default (the reference build's
 loop tails reproduced). Every render must equal the reference's bit for bit; the summary goes to
 gpurun_out/gpu_vs_ref_sweep.json."""
 import json, os, sys, time
@@ -35,13 +35,14 @@ for seed in range(first, first + count):
     prg = vb.build_program(voices, updates=ups)
     stereo = bool(seed & 2)
     chunk = int(rng.integers(300, 12000))
-    ref = po.ref_render(prg.ptr, 44100, stereo, chunk=chunk)
+    rate = 44100 if seed % 3 else int(rng.choice([8000, 22050, 48000, 96000]))
+    ref = po.ref_render(prg.ptr, rate, stereo, chunk=chunk)
     if dropin:
-        g = sa.Generator(prg, 44100)
+        g = sa.Generator(prg, rate)
         gpu = g.render(stereo=stereo, chunk=chunk)
         g.close()
     else:
-        gpu = sa.Batch([prg], 44100).render(stereo=stereo, chunk=chunk)[0]
+        gpu = sa.Batch([prg], rate).render(stereo=stereo, chunk=chunk)[0]
     same = len(gpu) == len(ref) and bool((gpu == ref).all())
     S["programs"] += 1; S["identical"] += same; S["samples"] += len(ref)
     if not same:
