@@ -73,6 +73,24 @@ def profile_traffic(workload, kernel_prefix):
     return best if best else (None, None, None)
 
 
+def profile_step_traffic(workload):
+    """HBM bytes per step of one of the other workloads (every kernel of the step, FETCH_SIZE doubled + WRITE_SIZE),
+    from the committed PMC passes of that command -- only from a summary collected on these very kernel sources."""
+    pdir = os.path.join(ROOT, "profiles")
+    best = (None, None)
+    for f in sorted(os.listdir(pdir)):
+        if not f.endswith("_pmc_summary.json"):
+            continue
+        try:
+            pmc = json.load(open(os.path.join(pdir, f)))
+            if pmc.get("kernel_source_sha") == kernel_source_hash() and pmc.get("workload", {}).get("name") == workload \
+                    and pmc.get("hbm_bytes_per_step_corrected"):
+                best = (pmc["hbm_bytes_per_step_corrected"], "profiles/" + f)
+        except (OSError, KeyError, ValueError, AttributeError):
+            pass
+    return best
+
+
 def cpu_reference(make_prg, what, voices, ops_per_voice, tabs, all_cores=False):
     """The reference's own generator (oracle/_ref, built from its sources by oracle/Makefile) when
     that library is present, else this repo's CPU restatement; a bounded sample of the workload."""
@@ -418,6 +436,8 @@ def run_config4(args, R, sa, tabs, steps=None, warmup=None):
     alg = (7 * 8 + 2) * frames_each * len(prgs)
     kern_s = tm["fast_ms"] / 1e3 / steps
     achieved = alg / kern_s / 1e9 if kern_s > 0 else 0.0
+    full4 = not args.c4_frames and args.renders == 64 and not args.c4_run
+    traffic4, source4 = profile_step_traffic("config4") if full4 else (None, None)
     out = {
         "metric": "mono samples/sec, examples/rainy_thunder.sau x 512 renders sharded over GPUs",
         "value": tally[0] / dt, "unit": "mixed mono int16 frames/s summed over renders",
@@ -433,7 +453,8 @@ def run_config4(args, R, sa, tabs, steps=None, warmup=None):
                                 "(tests/golden/config4_seeds.npz)") if not args.c4_frames else
                                f"first {frames_each} frames of seeds 0..3 within 1 LSB of tests/golden/pcm_heads.npz"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                     "frac": achieved / 8000.0, "traffic": None, "traffic_source": None,
+                     "frac": achieved / 8000.0, "traffic": traffic4, "traffic_source": source4,
+                     "traffic_is": "HBM bytes of every kernel of one step (64 renders)",
                      "kernel": "fast_kernel<8, 0> over the closed-form voices + fast_kernel<5, 2> over the look-back voices "
                                "(two launches per segment, over analyze_kernel's voice lists)",
                      "kernel_ms_per_step": kern_s * 1e3, "other_kernels_ms_per_step":
@@ -496,6 +517,7 @@ def run_config5(args, R, sa, tabs, steps=None, warmup=None):
     dom = max(("block_ms", "fast_ms"), key=lambda k: tm[k])
     kern_s = tm[dom] / 1e3 / steps
     achieved = alg / kern_s / 1e9 if kern_s > 0 else 0.0
+    traffic5, source5 = profile_step_traffic("config5") if args.voices5 == 4096 else (None, None)
     out = {
         "metric": "mono samples/sec/GPU @ N voices (self-feedback FM + AM + ramps)",
         "value": tally[0] / dt, "unit": "mixed mono int16 frames/s",
@@ -509,7 +531,8 @@ def run_config5(args, R, sa, tabs, steps=None, warmup=None):
                    "frames_all_ranks": tally[0], "pcm_checksum_all_ranks": tally[1], "verified": verified,
                    "operator_samples_per_s": tally[0] / dt * n_ops},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                     "frac": achieved / 8000.0, "traffic": None, "traffic_source": None,
+                     "frac": achieved / 8000.0, "traffic": traffic5, "traffic_source": source5,
+                     "traffic_is": "HBM bytes of every kernel of one step",
                      "kernel": "feedback recurrence + block loop (" + dom + ")",
                      "kernel_ms_per_step": kern_s * 1e3,
                      "all_kernels_ms_per_step": {k: tm[k] / steps for k in ("fast_ms", "block_ms", "mix_ms", "aux_ms")},

@@ -64,29 +64,38 @@ for wl in ("c5", "c4"):
     st = f"gpurun_out/prof_{tag}_{wl}/{tag}_{wl}_kernel_stats.csv"
     if os.path.exists(st):
         shutil.copy(st, f"profiles/{name}_{wl}_kernel_stats.csv")
-# config 5: per-kernel HBM bytes and instruction counts (averages per launch)
-c5 = {}
-for d, f in (("c5_fetch", "m"), ("c5_write", "m"), ("c5_inst", "i")):
-    src = f"gpurun_out/pmc_{tag}_{d}/{f}_counter_collection.csv"
-    if not os.path.exists(src):
+# configs 5 and 4: per-kernel HBM bytes and instruction counts (averages per launch), and the bytes of one step --
+# the profiled command renders twice (the first step, whose SHA-256 is checked, and one timed step)
+for wl, wname in (("c5", "config5"), ("c4", "config4")):
+    ks = {}
+    for d, f in ((wl + "_fetch", "m"), (wl + "_write", "m"), (wl + "_inst", "i")):
+        src = f"gpurun_out/pmc_{tag}_{d}/{f}_counter_collection.csv"
+        if not os.path.exists(src):
+            continue
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(src)):
+            if "sauhip" in r["Kernel_Name"]:
+                k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+                agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, v in agg.items():
+            for c, x in v.items():
+                ks.setdefault(k, {})[c] = sum(x) / len(x)
+                ks[k]["launches"] = len(x)
+    if not ks:
         continue
-    agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(src)):
-        if "sauhip" in r["Kernel_Name"]:
-            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
-            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for k, v in agg.items():
-        for c, x in v.items():
-            c5.setdefault(k, {})[c] = sum(x) / len(x)
-            c5[k]["launches"] = len(x)
-if c5:
-    for k, v in c5.items():
+    total = 0.0
+    for k, v in ks.items():
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             v["hbm_bytes_per_launch_corrected"] = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
-    json.dump({"command": "rocprofv3 --pmc <C> --kernel-trace -- python3 bench.py --workload config5 --steps 1 --warmup 0 --no-cpu",
-               "note": "averages per launch over the run (segments of 65536 frames, the last one shorter); "
-                       "zero-work launches of a pass nobody needs are included in that pass's average",
-               "kernels": c5}, open(f"profiles/{name}_c5_pmc_summary.json", "w"), indent=1)
+            total += v["hbm_bytes_per_launch_corrected"] * v["launches"]
+    json.dump({"command": f"rocprofv3 --pmc <C> --kernel-trace -- python3 bench.py --workload {wname} --steps 1 --warmup 0 --no-cpu",
+               "workload": {"name": wname, "renders_profiled": 2},
+               "kernel_source_sha": bench["roofline"].get("kernel_source_sha"),
+               "note": "averages per launch over the run; zero-work launches of a pass nobody needs are included in that "
+                       "pass's average; hbm_bytes_per_step_corrected = sum over the kernels of bytes per launch x launches, "
+                       "over the two renders of the command",
+               "hbm_bytes_per_step_corrected": total / 2 if total else None,
+               "kernels": ks}, open(f"profiles/{name}_{wl}_pmc_summary.json", "w"), indent=1)
 # running-sum workloads: the sweep's lines, kernel statistics, instruction counts per launch of the single-pass build
 if os.path.exists(f"gpurun_out/sweep_{tag}_fm.txt"):
     shutil.copy(f"gpurun_out/sweep_{tag}_fm.txt", f"profiles/{name}_fm_sweep.txt")

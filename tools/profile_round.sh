@@ -22,6 +22,10 @@ rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out
 timeout 180 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_c5_fetch -o m -- python3 bench.py --workload config5 --steps 1 --warmup 0 --no-cpu > /dev/null 2>&1
 timeout 180 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_c5_write -o m -- python3 bench.py --workload config5 --steps 1 --warmup 0 --no-cpu > /dev/null 2>&1
 timeout 180 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_c5_inst -o i -- python3 bench.py --workload config5 --steps 1 --warmup 0 --no-cpu > /dev/null 2>&1
+# config 4 likewise (HBM bytes per step of the two launches over the voice lists and the few-row mixer)
+timeout 180 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_c4_fetch -o m -- python3 bench.py --workload config4 --steps 1 --warmup 0 --no-cpu > /dev/null 2>&1
+timeout 180 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_c4_write -o m -- python3 bench.py --workload config4 --steps 1 --warmup 0 --no-cpu > /dev/null 2>&1
+timeout 180 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_c4_inst -o i -- python3 bench.py --workload config4 --steps 1 --warmup 0 --no-cpu > /dev/null 2>&1
 # running-sum workloads (carrier FM bank, carrier glide, FM + ratio PM stack): sweep lines, kernel trace, instruction mix
 TLEVEL=0 timeout 180 python3 tests/tools/gpu_sweep.py c3f fmstack mixed > gpurun_out/sweep_${TAG}_fm.txt 2>&1
 timeout 180 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_fm -o ${TAG}_fm -- python3 tests/tools/gpu_sweep.py c3f fmstack > gpurun_out/prof_${TAG}_fm.log 2>&1
