@@ -21,21 +21,31 @@ tabs = po.ref_piluts()  # the tables this very reference library built (glibc pi
 sa.set_piluts(tabs)
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 400
-dropin = len(sys.argv) > 3 and sys.argv[3] == "dropin"  # through sau_create_Generator / sauGenerator_run (read-ahead runs) instead of the batch API
+corpus = len(sys.argv) > 3 and sys.argv[3] == "corpus"  # the reference's 95 scripts (program images), `count` passes over them
+dropin = corpus or len(sys.argv) > 3 and sys.argv[3] == "dropin"  # through sau_create_Generator / sauGenerator_run (read-ahead runs) instead of the batch API
 S = {"programs": 0, "identical": 0, "samples": 0, "samples_differing": 0, "max_abs_diff": 0, "differing": [],
-     "first_seed": first, "loop_tails": True, "api": "drop-in generator" if dropin else "batch"}
+     "first_seed": first, "loop_tails": True, "api": "drop-in generator" if dropin else "batch", "programs_are": "the 95 corpus scripts" if corpus else "random graphs"}
 t0 = time.time()
-for seed in range(first, first + count):
-    rng = np.random.default_rng(20000 + seed)
-    voices = [T._random_voice(rng) for _ in range(int(rng.integers(1, 4)))]
-    ups = ()
-    if seed % 2:
-        T._random_starts(rng, voices)
-        ups = T._random_updates(rng, voices)
-    prg = vb.build_program(voices, updates=ups)
-    stereo = bool(seed & 2)
-    chunk = int(rng.integers(300, 12000))
-    rate = 44100 if seed % 3 else int(rng.choice([8000, 22050, 48000, 96000]))
+def cases():
+    if corpus:
+        index = json.load(open(os.path.join(ROOT, "tests", "golden", "index.json")))
+        keys = sorted(index["corpus"])
+        progs = {k: sa.Program.from_image(open(os.path.join(ROOT, "tests", "golden", "programs", k + ".saup"), "rb").read()) for k in keys}
+        for p_ in range(first, first + count):
+            rng = np.random.default_rng(70000 + p_)
+            for k in keys:
+                yield (p_, k), progs[k], bool(rng.integers(2)), int(rng.integers(300, 20000)), int(rng.choice([22050, 44100, 44100, 48000, 96000]))
+        return
+    for seed in range(first, first + count):
+        rng = np.random.default_rng(20000 + seed)
+        voices = [T._random_voice(rng) for _ in range(int(rng.integers(1, 4)))]
+        ups = ()
+        if seed % 2:
+            T._random_starts(rng, voices)
+            ups = T._random_updates(rng, voices)
+        prg = vb.build_program(voices, updates=ups)
+        yield seed, prg, bool(seed & 2), int(rng.integers(300, 12000)), (44100 if seed % 3 else int(rng.choice([8000, 22050, 48000, 96000])))
+for seed, prg, stereo, chunk, rate in cases():
     ref = po.ref_render(prg.ptr, rate, stereo, chunk=chunk)
     if dropin:
         g = sa.Generator(prg, rate)
@@ -50,10 +60,10 @@ for seed in range(first, first + count):
         d = np.abs(gpu[:n].astype(np.int32) - ref[:n].astype(np.int32))
         S["samples_differing"] += int((d > 0).sum()) + abs(len(gpu) - len(ref))
         S["max_abs_diff"] = max(S["max_abs_diff"], int(d.max()) if n else 0)
-        S["differing"].append({"seed": seed, "call_size": chunk, "stereo": stereo, "lengths": [len(gpu), len(ref)]})
+        S["differing"].append({"seed": list(seed) if isinstance(seed, tuple) else seed, "rate": rate, "call_size": chunk, "stereo": stereo, "lengths": [len(gpu), len(ref)]})
         print("seed", seed, "DIFFERS", S["differing"][-1], flush=True)
 S["seconds"] = round(time.time() - t0, 1)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(S, open(os.path.join(ROOT, "gpurun_out", "gpu_vs_ref_sweep%s.json" % ("_dropin" if dropin else "")), "w"), indent=1)
+json.dump(S, open(os.path.join(ROOT, "gpurun_out", "gpu_vs_ref_sweep%s.json" % ("_corpus" if corpus else "_dropin" if dropin else "")), "w"), indent=1)
 print(json.dumps({k: v for k, v in S.items() if k != "differing"}))
 sys.exit(0 if S["identical"] == S["programs"] else 1)
