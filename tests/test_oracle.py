@@ -220,6 +220,29 @@ def test_amp_operator_vs_reference(oracle):
         assert len(a) > 0 and np.abs(a.astype(np.int32)).max() > 0, name
 
 
+def test_deep_nesting_vs_reference(oracle):
+    """Straight modulator chains of 200 and 256 operators through each kind of modulator list (what
+    tests/test_host.py::test_nesting_as_deep_as_the_reference and tests/test_gpu_units.py::test_deep_nesting render with
+    wide plans): the oracle that judges them equals the compiled reference there too, bit for bit."""
+    if not oracle.have_ref():
+        pytest.skip("compiled reference not present")
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_host import _chain, _pm_chain
+    from saugns_amd import voicebank as vb
+    from saugns_amd.api import POP_PMOD, POP_FMOD, POP_RFMOD, POP_AMOD, POP_RAMOD, POP_FPMOD
+    oracle.oracle().ora_set_fastmath_forms(2)
+    for depth in (200, 256):
+        cases = [("pm", _pm_chain(depth))] + [(use, _chain(depth, use, ratio=use not in (POP_FMOD, POP_RFMOD)))
+                                               for use in (POP_FMOD, POP_RFMOD, POP_AMOD, POP_RAMOD, POP_FPMOD)]
+        for name, v in cases:
+            prg = vb.build_program([v])
+            for chunk in (4000000, 333):
+                a = oracle.oracle_render(prg.ptr, 12000, False, chunk=chunk)
+                b = oracle.ref_render(prg.ptr, 12000, False, chunk=chunk)
+                assert len(a) == len(b) and len(a) > 0 and max_diff(a, b) == 0, (name, depth, chunk)
+
+
 def test_config4_all_seeds_fixture(oracle, sa, index):
     """tests/golden/config4_seeds.npz: 512 program images of rainy_thunder.sau (seed = k) and the
     SHA-256 of each full 60 s render by the compiled reference. Seeds 0..3 are also kept singly
