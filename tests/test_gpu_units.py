@@ -688,10 +688,13 @@ def test_random_graphs_in_other_kernel_configurations(sa, oracle, env):
                 os.environ[k] = v
 
 
-def test_dropin_generator_on_random_programs(sa, oracle):
+@pytest.mark.parametrize("depth", ["2", "1"])
+def test_dropin_generator_on_random_programs(sa, oracle, depth, monkeypatch):
     """sau_create_Generator / sauGenerator_run with the host's 11289-frame calls (and odd sizes) on
     randomized programs with events; long ones, so that the read-ahead hands out several device runs
-    from its two buffers. The device runs are 176400 frames: the oracle is asked for the same."""
+    from its three buffers (two runs in flight, or one: SAU_AMD_READAHEAD_DEPTH). The device runs are 176400
+    frames: the oracle is asked for the same."""
+    monkeypatch.setenv("SAU_AMD_READAHEAD_DEPTH", depth)
     oracle.oracle().ora_set_fastmath_forms(1)
     for seed in range(300, 308):
         rng = np.random.default_rng(5000 + seed)
