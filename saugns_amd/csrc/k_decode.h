@@ -224,6 +224,27 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 			f.diff_scale = bits_f(o.ras_level);
 			f.diff_offset = bits_f(o.ras_alpha);
 			f.type |= rate2x ? 1u << 17 : 0u;
+			if (P.info[v].cub && (vd.flags & VD_TAILS) && o.wave == LN_cub && !o.rt_frozen) {
+				/* the reference's loop tails of a `cub` map (sau_dev_math.h: TailCtx): the block that holds a frame ends
+				 * where this operator, one it is nested in or the voice stops -- frames from the segment's start, as
+				 * the block loop keeps them per nesting level (cur_rem). Backwards over the plan: a BEGIN whose END has
+				 * not been met on the way is this operator's or an ancestor's. */
+				uint32_t rem = (vd.flags & VD_MORE) ? TAIL_FAR : min(vd.run_len, TAIL_FAR);
+				uint32_t closed = 0;
+				for (uint32_t q = (uint32_t)l + 1; q-- > 0;) {
+					const Step sq = plan[q];
+					if (q != (uint32_t)l && (sq.flags & SF_END)) ++closed;
+					if (sq.flags & SF_BEGIN) {
+						if (closed) --closed;
+						else {
+							const DevOp &oa = P.ops[ids[sq.op]];
+							if (!(oa.flags & OPF_TIME_INF) && oa.time < rem) rem = oa.time;
+						}
+					}
+				}
+				f.type |= FT_CUBTAIL;
+				f.phase0 = rem;
+			}
 		}
 		f.pan = o.line[L_PAN].v0;
 		f.ramp = 0;

@@ -134,3 +134,54 @@ def test_device_reproduces_the_loop_tails(sa, oracle, tails_on):
             assert len(got) == len(want) and (got == want).all()
     finally:
         oracle.oracle().ora_set_fastmath_forms(1)
+
+
+def _rcub_bank(n=16):
+    """R oscillators with `cub` segments that the time-parallel path takes (steady, nothing modulated): carriers, one with
+    a shorter R-cub modulator nested in it (the operator's stop cuts the reference's block: TailCtx.rem)."""
+    voices = [vb.Op(op_type=POPT_RASEG, ras=("cub", k % 6, (0, 1, 9, 16)[k % 4]), seed=11 + k, freq=90.0 + 7 * k, amp=0.9,
+                    time_ms=400) for k in range(n)]
+    voices.append(vb.Op("sin", freq=250.0, time_ms=300, mods={POP_PMOD: [
+        vb.Op(op_type=POPT_RASEG, ras=("cub", 1, 9), seed=3, freq=vb.Line(1.5, ratio=True), amp=0.7, time_ms=170)]}))
+    # ... and with running-sum phases (the look-back build with the tail code, fast_kernel<4, 2, true>)
+    voices.append(vb.Op(op_type=POPT_RASEG, ras=("cub", 0, 1), seed=21, freq=vb.Line(120.0, goal=420.0, shape="lin"), amp=0.8, time_ms=350))
+    voices.append(vb.Op(op_type=POPT_RASEG, ras=("cub", 3, 0), seed=22, freq=200.0, amp=0.8, time_ms=350,
+                        mods={POP_FMOD: [vb.Op("sin", freq=5.0, amp=40.0)]}))
+    return voices
+
+
+def test_r_segment_map_tails_matter_at_tiny_call_sizes(oracle):
+    """With host calls of a few frames almost every sample is among the last len % 4 of a sauLine_map_cub call: there the
+    two forms differ in the int16 output (at ordinary call sizes they practically never do -- which is how the
+    time-parallel build could lack the map's tails for most of round 3 without any test noticing)."""
+    n = 0
+    for v in _rcub_bank():
+        prg = vb.build_program([v])
+        oracle.oracle().ora_set_fastmath_forms(2)
+        m2 = oracle.oracle_render(prg.ptr, RATE, False, chunk=3)
+        oracle.oracle().ora_set_fastmath_forms(1)
+        m1 = oracle.oracle_render(prg.ptr, RATE, False, chunk=3)
+        n += int((m1 != m2).sum())
+    assert n >= 20, n
+
+
+@pytest.mark.gpu
+def test_device_reproduces_the_map_tails_at_tiny_call_sizes(sa, oracle, tails_on):
+    """R oscillators with `cub` segments on the time-parallel path (fast_kernel<4, 0, true>: FT_CUBTAIL) with host calls of
+    3 and 7 frames, engine runs of thousands of such calls: bit-exact vs the oracle's mode 2 (= the compiled reference),
+    voice by voice and as one bank; and off the block loop."""
+    oracle.oracle().ora_set_fastmath_forms(2)
+    try:
+        bank = _rcub_bank()
+        for call in (3, 7):
+            for vs in [[v] for v in bank] + [bank]:
+                prg = vb.build_program(vs)
+                want = oracle.oracle_render(prg.ptr, RATE, False, chunk=call)
+                b = sa.Batch([prg], RATE)
+                b.set_call_len(call)
+                b.set_timing(2)
+                got = b.render(stereo=False, chunk=call * 3000)[0]
+                assert len(got) == len(want) and (got == want).all(), (call, len(vs), int((got != want).sum()))
+            assert b.timing_ex()["block_ms"] < 1.0  # (the bank: every voice but the one whose modulator stops stays closed-form)
+    finally:
+        oracle.oracle().ora_set_fastmath_forms(1)
