@@ -1483,6 +1483,11 @@ static uint32_t voice_run(OraGen *o, Voice *vn, uint32_t len) {
 }
 
 static inline float clampf(float x, float lo, float hi) {
+	/* sau/math.h:133-137 as the reference build has it: -ffast-math turns the two selections into
+	 * minss(maxss(x, lo), hi), and maxss returns its second operand when the first is a NaN -- a NaN in
+	 * the mix leaves as lo (-32767 in the PCM), in loop bodies and tails alike (pinned against
+	 * oracle/_ref on programs whose feedback runs to infinity: tests/test_oracle.py) */
+	if (x != x) return lo;
 	x = x < lo ? lo : x;
 	x = x > hi ? hi : x;
 	return x;

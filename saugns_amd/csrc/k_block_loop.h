@@ -680,7 +680,7 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 								float pma_v = smS ? smS[e] : ((tc.on && plb.sw.type == LN_cub) ? line_value_vt(plb, j, 1.f, tc) : line_value_v(plb, j, 1.f));
 								float pm_a = fb_s * pma_v * 0.5f;
 								float phase = scratch[e] + pm_a;
-								int32_t cycle_adj = (int32_t)floorf(phase);
+								int32_t cycle_adj = f2i_x86(floorf(phase)); /* (a feedback offset of 2^31 cycles and more: the host's conversion, not the device's) */
 								uint32_t cycle = tmp[e] + (uint32_t)cycle_adj;
 								phase -= (float)cycle_adj;
 								float sv = ras_sample(rp, cycle, phase, false);

@@ -60,9 +60,21 @@ constexpr uint32_t SLEN = 1u << SLEN_BITS;
 /* sau/math.h:63-64 + generator.c:17: llrintf, kept as int64 */
 SAU_HD int64_t rint64(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-	return __float2ll_rn(x);
+	/* out of range (and NaN) the reference's host gives the x86 "integer indefinite", 0x8000...0 (cvtss2si), where
+	 * the device's conversion saturates: frequency-scaled PM of thousands of cycles under a frequency of gigahertz
+	 * gets there (found by the sweep with extreme parameters, round 3) */
+	const long long v = __float2ll_rn(x);
+	return fabsf(x) < 0x1p63f ? v : (long long)0x8000000000000000ull;
 #else
 	return llrintf(x);
+#endif
+}
+/* (int32_t)x as the reference's host computes it: out of range (and NaN) cvttss2si gives 0x80000000, the device saturates */
+SAU_HD int32_t f2i_x86(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	return fabsf(x) < 0x1p31f ? (int32_t)x : (int32_t)0x80000000u;
+#else
+	return (int32_t)x;
 #endif
 }
 /* ... and wrapped into a 32-bit phase */
@@ -1054,6 +1066,10 @@ SAU_HD int16_t pcm_swap(int16_t v) {
 	return (int16_t)(uint16_t)((s >> 8) | (s << 8));
 }
 SAU_HD int16_t pcm16(float s) {
+	/* a NaN in the mix (feedback that ran to infinity, inf - inf: absurd amounts only) leaves the reference build's clamp as
+	 * its lower bound -- gcc's fast-math form of sau_fclampf is minss(maxss(s, -1), 1), and maxss hands back its second
+	 * operand when the first is a NaN -- and so as -32767, in the loops' bodies and tails alike */
+	if (s != s) s = -1.f;
 	s = clampf(s, -1.f, 1.f);
 #if defined(__HIP_DEVICE_COMPILE__)
 	return (int16_t)__float2int_rn(s * (float)INT16_MAX);

@@ -242,6 +242,34 @@ def _random_voice(rng, depth=0):
                  phase=float(rng.uniform(0, 1)), mods=mods, **kw)
 
 
+def _push_extremes(rng, voices):
+    """Frequencies of zero, a few microhertz, beyond Nyquist and negative; amplitudes of thousands and negative ones;
+    modulation amounts of hundreds of cycles; operators of 0, 1 and 2 ms."""
+    def walk(op, top):
+        for name in ("freq", "freq2", "amp", "amp2", "pm_a"):
+            ln = getattr(op, name, None)
+            if ln is None or rng.random() > 0.3:
+                continue
+            if name in ("freq", "freq2") and not ln.ratio:
+                pick = [0.0, 1e-6, -1e-6, 3e4, -3e4, 1e6, 22050.0, 0.5]
+            elif name in ("freq", "freq2"):
+                pick = [0.0, 1e-4, 1e3, -2.0, 7.25]
+            elif name == "pm_a":
+                pick = [0.0, 1e-7, 40.0, 2.5, -1.0]
+            else:
+                pick = [0.0, -1.0, 1e4, 1e-30, 300.0, -77.0]
+            ln.v0 = float(rng.choice(pick))
+            if ln.goal is not None and rng.random() < 0.5:
+                ln.goal = float(rng.choice(pick))
+        if not top and rng.random() < 0.2:
+            op.time_ms = int(rng.choice([0, 1, 2, 5]))
+        for lst in op.mods.values():
+            for m in lst:
+                walk(m, False)
+    for v in voices:
+        walk(v, True)
+
+
 def _random_starts(rng, voices):
     """Some voices begin later than the first (a script's timing separators)."""
     for carr in voices[1:]:
@@ -320,6 +348,50 @@ def _random_updates(rng, voices):
                     what["mods"] = {use: list(op.mods[use][:keep_n])}
             ups.append((at, vi, op, what))
     return ups
+
+
+def extreme_program(seed):
+    """Program `seed` of tests/tools/gpu_vs_ref_sweep.py's `extreme` mode: a random graph with parameters pushed to extremes.
+    -> (program, rate, call size)"""
+    rng = np.random.default_rng(20000 + seed)
+    voices = [_random_voice(rng) for _ in range(int(rng.integers(1, 4)))]
+    ups = ()
+    if seed % 2:
+        _random_starts(rng, voices)
+        ups = _random_updates(rng, voices)
+    _push_extremes(rng, voices)
+    rate = int(rng.choice([1000, 3000, 11025, 44100, 192000, 384000]))
+    prg = vb.build_program(voices, updates=ups)
+    call = int(rng.integers(1, 12)) if seed % 5 == 4 else int(rng.integers(300, 12000))
+    return prg, rate, call
+
+
+# seeds of that sweep that differed from the compiled reference before round 3's fixes: frequency-scaled PM beyond 2^63 phase
+# units (the host's float -> int64 conversion gives 0x8000...0 there, the device's saturates), feedback that runs to infinity
+# (a NaN in the mix leaves the reference build's clamp as -1)
+EXTREME_SEEDS = (211, 278, 344, 449, 612, 820, 871, 1168, 1274, 1377, 1417, 1482, 1498, 1808, 2127, 2274, 2802, 2865, 10687)
+
+
+@pytest.mark.parametrize("seed", EXTREME_SEEDS)
+def test_extreme_parameters(sa, oracle, seed):
+    """Frequencies of zero, microhertz, megahertz and negative, amplitudes of tens of thousands, modulation amounts of hundreds
+    of cycles, operators of 0-2 ms, sample rates of 1 kHz to 384 kHz: the programs that exposed where the device's arithmetic
+    left the host's at the edges (conversions out of range, NaN in the mix). Bit-exact vs the oracle (pinned against the
+    compiled reference on the same programs, tests/test_oracle.py), batch API and drop-in generator."""
+    oracle.oracle().ora_set_fastmath_forms(1)
+    prg, rate, call = extreme_program(seed)
+    for stereo in (False, True):
+        want = oracle.oracle_render(prg.ptr, rate, stereo, chunk=call)
+        b = sa.Batch([prg], rate)
+        if call < 300:
+            b.set_call_len(call)
+        got = b.render(stereo=stereo, chunk=call * 1500 if call < 300 else call)[0]
+        assert len(got) == len(want) and (got == want).all(), (seed, stereo, int((got != want).sum()))
+    g = sa.Generator(prg, rate)
+    got = g.render(stereo=False, chunk=call)
+    g.close()
+    want = oracle.oracle_render(prg.ptr, rate, False, chunk=call)
+    assert len(got) == len(want) and (got == want).all(), (seed, "drop-in")
 
 
 @pytest.mark.parametrize("seed", range(48))

@@ -243,6 +243,26 @@ def test_deep_nesting_vs_reference(oracle):
                 assert len(a) == len(b) and len(a) > 0 and max_diff(a, b) == 0, (name, depth, chunk)
 
 
+def test_extreme_parameters_vs_reference(oracle):
+    """The programs of tests/test_gpu_units.py::test_extreme_parameters (and forty more of that kind): the oracle equals the
+    compiled reference where conversions overflow and the mix holds NaNs too -- mono, stereo, both oracle modes' call sizes."""
+    if not oracle.have_ref():
+        pytest.skip("compiled reference not present")
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_gpu_units as tu
+    oracle.oracle().ora_set_fastmath_forms(2)
+    nan_like = 0
+    for seed in tuple(tu.EXTREME_SEEDS) + tuple(range(5000, 5040)):
+        prg, rate, call = tu.extreme_program(seed)
+        for stereo in (False, True):
+            a = oracle.oracle_render(prg.ptr, rate, stereo, chunk=call)
+            b = oracle.ref_render(prg.ptr, rate, stereo, chunk=call)
+            assert len(a) == len(b) and max_diff(a, b) == 0, (seed, stereo)
+        nan_like += seed in (612, 10687) and int((b == -32767).sum()) > 1000
+    assert nan_like == 2  # (the two whose feedback runs to infinity: long runs of -32767)
+
+
 def test_config4_all_seeds_fixture(oracle, sa, index):
     """tests/golden/config4_seeds.npz: 512 program images of rainy_thunder.sau (seed = k) and the
     SHA-256 of each full 60 s render by the compiled reference. Seeds 0..3 are also kept singly

@@ -21,11 +21,13 @@ tabs = po.ref_piluts()  # the tables this very reference library built (glibc pi
 sa.set_piluts(tabs)
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+extreme = len(sys.argv) > 3 and sys.argv[3] == "extreme"  # the same graphs with parameters pushed to extremes
 corpus = len(sys.argv) > 3 and sys.argv[3] == "corpus"  # the reference's 95 scripts (program images), `count` passes over them
 dropin = corpus or len(sys.argv) > 3 and sys.argv[3] == "dropin"  # through sau_create_Generator / sauGenerator_run (read-ahead runs) instead of the batch API
 S = {"programs": 0, "identical": 0, "samples": 0, "samples_differing": 0, "max_abs_diff": 0, "differing": [],
-     "first_seed": first, "loop_tails": True, "api": "drop-in generator" if dropin else "batch", "programs_are": "the 95 corpus scripts" if corpus else "random graphs"}
+     "first_seed": first, "loop_tails": True, "api": "drop-in generator" if dropin else "batch", "programs_are": "the 95 corpus scripts" if corpus else "random graphs, extreme parameters" if extreme else "random graphs"}
 t0 = time.time()
+_push = T._push_extremes
 def cases():
     if corpus:
         index = json.load(open(os.path.join(ROOT, "tests", "golden", "index.json")))
@@ -43,12 +45,16 @@ def cases():
         if seed % 2:
             T._random_starts(rng, voices)
             ups = T._random_updates(rng, voices)
+        rate_x = None
+        if extreme:
+            _push(rng, voices)
+            rate_x = int(rng.choice([1000, 3000, 11025, 44100, 192000, 384000]))
         prg = vb.build_program(voices, updates=ups)
         # every fifth program with a host call of a few frames: where the reference's blocks end -- and with them the loop
         # tails of `cub` -- then falls on almost every sample (round 3: the R-segment map's tails were missing from the
         # time-parallel build and showed at such call sizes only)
         call = int(rng.integers(1, 12)) if seed % 5 == 4 else int(rng.integers(300, 12000))
-        yield seed, prg, bool(seed & 2), call, (44100 if seed % 3 else int(rng.choice([8000, 22050, 48000, 96000])))
+        yield seed, prg, bool(seed & 2), call, (rate_x or (44100 if seed % 3 else int(rng.choice([8000, 22050, 48000, 96000]))))
 for seed, prg, stereo, chunk, rate in cases():
     ref = po.ref_render(prg.ptr, rate, stereo, chunk=chunk)
     if dropin:
@@ -73,6 +79,6 @@ for seed, prg, stereo, chunk, rate in cases():
         print("seed", seed, "DIFFERS", S["differing"][-1], flush=True)
 S["seconds"] = round(time.time() - t0, 1)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(S, open(os.path.join(ROOT, "gpurun_out", "gpu_vs_ref_sweep%s.json" % ("_corpus" if corpus else "_dropin" if dropin else "")), "w"), indent=1)
+json.dump(S, open(os.path.join(ROOT, "gpurun_out", "gpu_vs_ref_sweep%s.json" % ("_corpus" if corpus else "_extreme" if extreme else "_dropin" if dropin else "")), "w"), indent=1)
 print(json.dumps({k: v for k, v in S.items() if k != "differing"}))
 sys.exit(0 if S["identical"] == S["programs"] else 1)
