@@ -20,6 +20,8 @@ for seed in range(first, first + count):
         if n > 1024 and seed % 4: continue
         rng = np.random.default_rng(900000 + 1000 * n + seed)
         voices = [T._random_voice(rng) for _ in range(n)]
+        if os.environ.get("SOAK_EXTREME"):  # parameters pushed to extremes (tests/test_gpu_units.py: _push_extremes)
+            T._push_extremes(rng, voices)
         T._random_starts(rng, voices)
         ups = T._random_updates(rng, voices[:40])
         prg = vb.build_program(voices, updates=ups)
