@@ -67,10 +67,13 @@ struct SelfmodState {
  * one skipped (halo) entry per `span` samples. The next sample's inputs are
  * fetched while the current one is computed; a repeated phase holds the
  * previous sample (wosc.h:292-293), decided by selects, not by a branch. */
-template <bool LDS, int SPAN /* samples per wave span when several waves share a block, else 0 */>
+template <bool LDS, int SPAN /* samples per wave span when several waves share a block, else 0 */,
+          bool SLDS = true /* the block buffers lie in LDS (false: in HBM, render_kernel<.., HB>: plain pointers) */>
 __device__ __forceinline__ void selfmod_serial(const TabRef &tab, SelfmodState &st, const WaveConst &wc,
 		const float *pmaS, u32_alias *baseS /* also receives the samples */, uint32_t len) {
-	typedef uint32_t __attribute__((address_space(3))) *lds_u32_w;
+	typedef uint32_t __attribute__((address_space(3))) *lds_u32_w_;
+	using lds_u32_w = std::conditional_t<SLDS, lds_u32_w_, uint32_t *>;
+	using lds_f32_ptr = std::conditional_t<SLDS, ::sauhip::lds_f32_ptr, const float *>;
 	const TabAt<LDS> at(tab);
 	uint32_t prev_phase = st.prev_phase;
 	double prev_Is = st.prev_Is;
@@ -601,8 +604,8 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 							SelfmodState ss;
 							ss.prev_phase = prev_phase; ss.prev_Is = prev_Is; ss.prev_s = prev_s; ss.fb_s = fb_s;
 							constexpr int SPAN = W > 1 ? G::NP - 1 : 0;
-							if (tab.in_lds) selfmod_serial<true, SPAN>(tab, ss, wc, pmaS, scratch_u, len);
-							else selfmod_serial<false, SPAN>(tab, ss, wc, pmaS, scratch_u, len);
+							if (tab.in_lds) selfmod_serial<true, SPAN, !HB>(tab, ss, wc, pmaS, scratch_u, len);
+							else selfmod_serial<false, SPAN, !HB>(tab, ss, wc, pmaS, scratch_u, len);
 							prev_phase = ss.prev_phase; prev_Is = ss.prev_Is; prev_s = ss.prev_s; fb_s = ss.fb_s;
 							op->prev_phase = prev_phase;
 							op->prev_Is = prev_Is;

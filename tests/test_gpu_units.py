@@ -270,6 +270,33 @@ def _push_extremes(rng, voices):
         walk(v, True)
 
 
+def _tall_tree(rng):
+    """A chain of 2..256 operators, each level's list kind, operator type and parameters drawn at random; now and then a
+    second member in a list (a leaf)."""
+    depth = int(rng.choice([2, 10, 40, 100, 121, 130, 200, 255, 256]))
+    op = None
+    for d in range(depth):
+        top = d == depth - 1
+        node = _random_voice(rng, depth=3 if not top else 0)  # (depth 3: no random children of its own)
+        node.mods = {}
+        if top:
+            node.time_ms = int(rng.integers(20, 60))
+        elif node.time_ms is not None and rng.random() < 0.9:
+            node.time_ms = None
+        if op is not None:
+            use = int(rng.choice([POP_PMOD, POP_FMOD, POP_AMOD, POP_RAMOD, POP_RFMOD, POP_FPMOD] + ([POP_APMOD] if node.op_type != POPT_NOISE else [])))
+            if node.op_type == POPT_NOISE and use in (POP_PMOD, POP_FMOD, POP_RFMOD, POP_FPMOD):
+                use = POP_AMOD
+            members = [op] + ([_random_voice(rng, depth=3)] if rng.random() < 0.05 else [])  # (a leaf: the path stays within 256)
+            node.mods = {use: members}
+            if use == POP_RAMOD and node.amp2 is None: node.amp2 = vb.Line(float(rng.uniform(0, 1)))
+            if use == POP_RFMOD and node.freq2 is None and node.freq is not None:
+                node.freq2 = vb.Line(float(rng.uniform(0.5, 3)), ratio=True) if not top else vb.Line(float(rng.uniform(60, 900)))
+            if use == POP_APMOD and node.pm_a is None: node.pm_a = vb.Line(float(rng.uniform(0.1, 0.9)))
+        op = node
+    return op
+
+
 def _random_starts(rng, voices):
     """Some voices begin later than the first (a script's timing separators)."""
     for carr in voices[1:]:
@@ -807,6 +834,28 @@ def test_deep_nesting(sa, oracle):
     check(sa, oracle, [chain(150), vb.Op("saw", freq=110.0, amp=0.3, time_ms=80), chain(256, POP_AMOD, ms=55),
                        vb.Op("sin", freq=330.0, time_ms=70, mods={POP_PMOD: [vb.Op("tri", freq=vb.Line(2.0, ratio=True), amp=0.4)]})],
           stereo=True, chunk=997)
+
+
+@pytest.mark.parametrize("seed", [266, 270, 273, 274] + list(range(600, 620)))
+def test_tall_random_trees(sa, oracle, seed):
+    """Operator trees of 2..256 levels with the list kind, operator type and parameters drawn per level (program `seed` of
+    tests/tools/gpu_vs_ref_sweep.py's `tall` mode): wide plans with range modulators, R and N operators, feedback -- the first
+    four are the ones that found render_kernel<1, 1, 1, true> reading its block buffers in HBM through LDS-typed pointers in
+    the W feedback loop (a memory fault at worst). Bit-exact vs the oracle."""
+    oracle.oracle().ora_set_fastmath_forms(1)
+    rng = np.random.default_rng(20000 + seed)
+    _ = [_random_voice(rng) for _ in range(int(rng.integers(1, 4)))]
+    voices = [_tall_tree(rng) for _ in range(int(rng.integers(1, 3)))]
+    ups = ()
+    if seed % 2:
+        _random_starts(rng, voices)
+        ups = _random_updates(rng, voices)
+    prg = vb.build_program(voices, updates=ups)
+    call = int(rng.integers(300, 12000))
+    stereo = bool(seed & 2)
+    want = oracle.oracle_render(prg.ptr, RATE, stereo, chunk=call)
+    got = sa.Batch([prg], RATE).render(stereo=stereo, chunk=call)[0]
+    assert len(got) == len(want) and (got == want).all(), (seed, int((got != want).sum()))
 
 
 @pytest.mark.parametrize("chunks", ["1", "2", "16"])

@@ -21,13 +21,15 @@ tabs = po.ref_piluts()  # the tables this very reference library built (glibc pi
 sa.set_piluts(tabs)
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+tall = len(sys.argv) > 3 and sys.argv[3] == "tall"  # operator trees up to 256 levels deep, the list kind drawn per level (wide plans)
 extreme = len(sys.argv) > 3 and sys.argv[3] == "extreme"  # the same graphs with parameters pushed to extremes
 corpus = len(sys.argv) > 3 and sys.argv[3] == "corpus"  # the reference's 95 scripts (program images), `count` passes over them
 dropin = corpus or len(sys.argv) > 3 and sys.argv[3] == "dropin"  # through sau_create_Generator / sauGenerator_run (read-ahead runs) instead of the batch API
 S = {"programs": 0, "identical": 0, "samples": 0, "samples_differing": 0, "max_abs_diff": 0, "differing": [],
-     "first_seed": first, "loop_tails": True, "api": "drop-in generator" if dropin else "batch", "programs_are": "the 95 corpus scripts" if corpus else "random graphs, extreme parameters" if extreme else "random graphs"}
+     "first_seed": first, "loop_tails": True, "api": "drop-in generator" if dropin else "batch", "programs_are": "the 95 corpus scripts" if corpus else "random graphs, extreme parameters" if extreme else "trees up to 256 levels deep" if tall else "random graphs"}
 t0 = time.time()
 _push = T._push_extremes
+_tall = T._tall_tree
 def cases():
     if corpus:
         index = json.load(open(os.path.join(ROOT, "tests", "golden", "index.json")))
@@ -41,6 +43,8 @@ def cases():
     for seed in range(first, first + count):
         rng = np.random.default_rng(20000 + seed)
         voices = [T._random_voice(rng) for _ in range(int(rng.integers(1, 4)))]
+        if tall:
+            voices = [_tall(rng) for _ in range(int(rng.integers(1, 3)))]
         ups = ()
         if seed % 2:
             T._random_starts(rng, voices)
@@ -79,6 +83,6 @@ for seed, prg, stereo, chunk, rate in cases():
         print("seed", seed, "DIFFERS", S["differing"][-1], flush=True)
 S["seconds"] = round(time.time() - t0, 1)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(S, open(os.path.join(ROOT, "gpurun_out", "gpu_vs_ref_sweep%s.json" % ("_corpus" if corpus else "_extreme" if extreme else "_dropin" if dropin else "")), "w"), indent=1)
+json.dump(S, open(os.path.join(ROOT, "gpurun_out", "gpu_vs_ref_sweep%s.json" % ("_corpus" if corpus else "_tall" if tall else "_extreme" if extreme else "_dropin" if dropin else "")), "w"), indent=1)
 print(json.dumps({k: v for k, v in S.items() if k != "differing"}))
 sys.exit(0 if S["identical"] == S["programs"] else 1)
