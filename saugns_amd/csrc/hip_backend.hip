@@ -497,7 +497,8 @@ public:
 		uint32_t W = geo_ ? 4 : 8, T = geo_ ? 4 : 2, V = 1;
 		bool HB = false; /* block buffers in HBM (render_kernel<1, 1, 1, true>) */
 		auto team_size = [&](uint32_t w, uint32_t t) {
-			size_t b = (HB ? 0 : (size_t)w * 64 * t * sizeof(float) * seg.n_slots) + (size_t)seg.max_ops * sizeof(DevOp) +
+			size_t b = HB ? sizeof(Misc) + 64 /* (buffers, operator records and steps in HBM) */
+				: (size_t)w * 64 * t * sizeof(float) * seg.n_slots + (size_t)seg.max_ops * sizeof(DevOp) +
 				sizeof(Misc) + (size_t)seg.max_steps * sizeof(Step) + 64;
 			return (b + 15) & ~(size_t)15;
 		};
@@ -1030,8 +1031,11 @@ public:
 			}
 		}
 		if (HB) {
-			if (!big_slots_.ensure((size_t)block_grid_ * seg.n_slots * 64, err)) return false;
-			rp.big_slots = big_slots_.p;
+			const size_t stride = ((size_t)seg.n_slots * 64 * sizeof(float) + (size_t)seg.max_ops * sizeof(DevOp) +
+				(size_t)seg.max_steps * sizeof(Step) + 255) / 256 * 256 / sizeof(float);
+			if (stride > 0xffffffffu) { err = "voice too large (block buffers + operator records beyond 16 GiB)"; return false; }
+			if (!big_slots_.ensure((size_t)block_grid_ * stride, err)) return false;
+			rp.big_slots = big_slots_.p; rp.big_stride = (uint32_t)stride;
 		}
 		TimedPair *tp = timing_on_ ? new_pair(0) : nullptr;
 		if (tp) (void)hipEventRecord(tp->a, stream_);

@@ -178,15 +178,21 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 			(size_t)team * P.team_bytes;
 	float *slots;
 	DevOp *ops;
+	Misc *misc;
+	Step *plan; /* this voice's steps, read every block */
 	if constexpr (HB) {
-		slots = P.big_slots + (size_t)blockIdx.x * P.n_slots * G::SLOT;
-		ops = (DevOp *)team_lds;
+		/* block buffers, operator records and steps in the workgroup's area in HBM (what bounds a voice then is memory,
+		 * not LDS: thousands of operators), the bookkeeping in LDS */
+		slots = P.big_slots + (size_t)blockIdx.x * P.big_stride;
+		ops = (DevOp *)(slots + (size_t)P.n_slots * G::SLOT);
+		plan = (Step *)(ops + P.max_ops);
+		misc = (Misc *)team_lds;
 	} else {
 		slots = (float *)team_lds;
 		ops = (DevOp *)(slots + (size_t)P.n_slots * G::SLOT);
+		misc = (Misc *)(ops + P.max_ops);
+		plan = (Step *)(misc + 1);
 	}
-	Misc *misc = (Misc *)(ops + P.max_ops);
-	Step *plan = (Step *)(misc + 1); /* this voice's steps, read every block */
 
 	const uint32_t n_work = *P.work_count;
 	if (blockIdx.x * V >= n_work) return;

@@ -25,7 +25,9 @@ struct RenderParams {
 	const uint32_t *work_count;
 	uint32_t n_tabs;       /* wave types staged in LDS */
 	uint32_t team_bytes;   /* LDS bytes per team (several teams per workgroup only) */
-	float *big_slots;      /* render_kernel<.., HB>: [workgroup][n_slots][64] block buffers in HBM */
+	float *big_slots;      /* render_kernel<.., HB>: [workgroup][big_stride] floats in HBM: n_slots x 64 block buffers, max_ops operator
+	                        * records, max_steps steps */
+	uint32_t big_stride;
 	int8_t tab_of_wave[12];/* LDS table index per wave id, or -1 */
 	uint8_t wave_of_tab[12];
 	WaveConst wc[12];

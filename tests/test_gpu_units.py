@@ -858,6 +858,22 @@ def test_tall_random_trees(sa, oracle, seed):
     assert len(got) == len(want) and (got == want).all(), (seed, int((got != want).sum()))
 
 
+def test_voices_with_thousands_of_operators(sa, oracle):
+    """What bounds a voice's tree is memory, not LDS: when block buffers, operator records (256 B each) and steps of a voice do
+    not fit a workgroup's LDS they all go to the workgroup's area in HBM (render_kernel<1, 1, 1, true>). A carrier with 40 PM
+    modulators of 40 AM modulators each (1641 operators), one with 700 modulators in one list and feedback, and both beside
+    ordinary voices; bit-exact vs the oracle."""
+    big = vb.Op("sin", freq=200.0, amp=0.5, time_ms=30, mods={POP_PMOD: [
+        vb.Op(("sin", "tri", "saw")[i % 3], freq=vb.Line(1.0 + (i % 5) * 0.5, ratio=True), amp=0.02 + 0.001 * i, mods={POP_AMOD: [
+            vb.Op("sin", freq=3.0 + j + i, amp=0.01 + 0.002 * j) for j in range(40)]}) for i in range(40)]})
+    flat = vb.Op("tri", freq=150.0, amp=0.6, pm_a=0.3, time_ms=25, mods={POP_PMOD: [
+        vb.Op("sin", freq=vb.Line(float(1 + i % 7), ratio=True), amp=0.004, phase=(i % 10) / 10) for i in range(700)]})
+    small = vb.Op("saw", freq=110.0, amp=0.3, time_ms=40)
+    check(sa, oracle, [big], chunk=700)
+    check(sa, oracle, [flat], chunk=900)
+    check(sa, oracle, [small, big, vb.Op("sin", freq=330.0, time_ms=35), flat], stereo=True, chunk=555)
+
+
 @pytest.mark.parametrize("chunks", ["1", "2", "16"])
 def test_feedback_chains_at_other_pipeline_depths(sa, oracle, chunks, monkeypatch):
     """chain_kernel beside the time-parallel passes: segments with feedback voices cut into
