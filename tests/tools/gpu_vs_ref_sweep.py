@@ -52,8 +52,17 @@ def cases():
         rate_x = None
         if extreme:
             _push(rng, voices)
+            if os.environ.get("SWEEP_PAN"):  # carriers' pan positions beyond [-1, 1] too (a generator of its own: the programs stay what they were otherwise)
+                r2 = np.random.default_rng(777000 + seed)
+                for v in voices:
+                    if r2.random() < 0.5:
+                        v.pan = vb.Line(float(r2.choice([-3.0, 0.0, 1.0, 7.5, 1e4, -1e-3])), goal=float(r2.choice([-2.0, 0.5, 30.0])) if r2.random() < 0.5 else None, shape="lin")
             rate_x = int(rng.choice([1000, 3000, 11025, 44100, 192000, 384000]))
-        prg = vb.build_program(voices, updates=ups)
+        if os.environ.get("SWEEP_AMP"):  # the program's amplitude multiplier and its division by the voice count (sauProgram.ampmult, mode)
+            r3 = np.random.default_rng(778000 + seed)
+            prg = vb.build_program(voices, updates=ups, ampmult=float(r3.choice([1.0, 0.25, 3.0, 1e-3, 50.0])), amp_div_voices=bool(r3.integers(2)))
+        else:
+            prg = vb.build_program(voices, updates=ups)
         # every fifth program with a host call of a few frames: where the reference's blocks end -- and with them the loop
         # tails of `cub` -- then falls on almost every sample (round 3: the R-segment map's tails were missing from the
         # time-parallel build and showed at such call sizes only)
