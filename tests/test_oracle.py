@@ -267,7 +267,8 @@ def test_extreme_parameters_vs_reference(oracle):
                    "batch programs) -- the oracle, and the device with it, leave the compiled reference by 1 LSB in about one "
                    "sample of 10^4 when a W oscillator of wave `ean` with feedback under a *ramped* amount modulates a frequency "
                    "(FM or range FM); every other wave, a constant amount, or the same operator as PM / AM source or carrier: "
-                   "identical. Cause not found yet (DESIGN.md section 5)")
+                   "identical. Cause found at the end of round 3 (DESIGN.md section 9, 8b): the reference build's sauWOsc_reset evaluates "
+                   "Is - prev_Is as (Is - y1') - P'; the fix touches the hot kernel's first-frame path and is left for round 4")
 def test_known_residual_ean_feedback_ramp_as_frequency_modulator(oracle):
     if not oracle.have_ref():
         pytest.skip("compiled reference not present")
