@@ -225,6 +225,19 @@ static inline double herp(const float *lut, uint32_t phase) {
 	double c3 = 1 / 2.0 * (s3 - s0) + 3 / 2.0 * (s1 - s2);
 	return ((c3 * x + c2) * x + c1) * x + c0;
 }
+/* ... its polynomial part alone (herp() = herp_rise() + the table value lut[phase >> SLEN_BITS]) */
+static inline double herp_rise(const float *lut, uint32_t phase) {
+	uint32_t ind = phase >> SLEN_BITS;
+	float s0 = lut[(ind - 1) & WMASK];
+	float s1 = lut[ind];
+	float s2 = lut[(ind + 1) & WMASK];
+	float s3 = lut[(ind + 2) & WMASK];
+	double x = ((phase & ((1u << SLEN_BITS) - 1)) * (1.f / (1u << SLEN_BITS)));
+	double c1 = 1 / 2.0 * (s2 - s0);
+	double c2 = s0 - 5 / 2.0 * s1 + 2 * s2 - 1 / 2.0 * s3;
+	double c3 = 1 / 2.0 * (s3 - s0) + 3 / 2.0 * (s1 - s2);
+	return ((c3 * x + c2) * x + c1) * x;
+}
 
 ORA_API double ora_herp(int wave, uint32_t phase) {
 	ensure_tables();
@@ -1001,6 +1014,14 @@ static void wosc_reset(Op *n, uint32_t phase) {
 		n->prev_Is = herp(lut, phase - phase_diff);
 		double Is = herp(lut, phase);
 		double x = (diff_scale / phase_diff);
+		if (g_fm_forms) {
+			/* the reference build: sauWOsc_reset is a function of its own there, and gcc's fast-math subtracts the
+			 * table value and the polynomial part of the earlier Hermite value one after the other,
+			 * (Is - y1') - P', not their rounded sum (objdump of oracle/_ref/generator.o; pinned by
+			 * tests/test_oracle.py: the `ean` feedback case) */
+			const uint32_t pp = phase - (uint32_t)phase_diff;
+			n->prev_s = ((Is - (double)lut[pp >> SLEN_BITS]) - herp_rise(lut, pp)) * x + diff_offset;
+		} else
 		n->prev_s = (Is - n->prev_Is) * x + diff_offset;
 		n->prev_Is = Is;
 		n->prev_phase = phase;

@@ -29,6 +29,23 @@ __device__ __forceinline__ double herp_lookup(const TabRef &t, uint32_t phase) {
 	return herp_poly(hi, lo, phase);
 }
 
+/* the sample a (re)started oscillator begins with (sau_dev_math.h: wosc_reset_s), from the tables */
+__device__ __forceinline__ float wosc_reset_lookup(const TabRef &t, uint32_t phase0, double Is0, float diff_scale, float diff_offset) {
+	const uint32_t pp = phase0 - SLEN, ind = pp >> SLEN_BITS;
+	HerpC23 hi;
+	HerpC01 lo;
+	if (t.in_lds) {
+		lds_f64_ptr p23 = (lds_f64_ptr)(const double *)(t.c23 + ind);
+		lds_f32_ptr p01 = (lds_f32_ptr)(const float *)(t.c01 + ind);
+		hi.c3 = p23[0]; hi.c2 = p23[1];
+		lo.c1 = p01[0]; lo.c0 = p01[1];
+	} else {
+		hi = t.c23[ind];
+		lo = t.c01[ind];
+	}
+	return wosc_reset_s(Is0, herp_poly_rise(hi, lo, pp), lo.c0, diff_scale, diff_offset);
+}
+
 /* One wave type's tables as LDS addresses (32-bit) or global pointers. */
 template <bool LDS> struct TabAt;
 typedef const HerpC23 __attribute__((address_space(3))) *lds_c23_ptr;
@@ -603,7 +620,7 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 								uint32_t phase00 = scratch_u[entry_of<W, T>(0)];
 								prev_Is = herp_lookup(tab, phase00 - SLEN);
 								double Is0 = herp_lookup(tab, phase00);
-								prev_s = wosc_diff(Is0, prev_Is, (int32_t)SLEN, wc.diff_scale, wc.diff_offset);
+								prev_s = wosc_reset_lookup(tab, phase00, Is0, wc.diff_scale, wc.diff_offset);
 								prev_Is = Is0;
 								prev_phase = phase00;
 							}
@@ -783,7 +800,7 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 							uint32_t phase00 = scratch_u[entry_of<W, T>(0)];
 							prev_Is = herp_lookup(tab, phase00 - SLEN);
 							double Is0 = herp_lookup(tab, phase00);
-							prev_s = wosc_diff(Is0, prev_Is, (int32_t)SLEN, wc.diff_scale, wc.diff_offset);
+							prev_s = wosc_reset_lookup(tab, phase00, Is0, wc.diff_scale, wc.diff_offset);
 							prev_Is = Is0;
 							prev_phase = phase00;
 						}

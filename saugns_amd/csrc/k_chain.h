@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(128) chain_kernel(FastParams P) {
 		const uint32_t pa = phase00 - SLEN;
 		prev_Is = herp_poly(g23[pa >> SLEN_BITS], g01[pa >> SLEN_BITS], pa);
 		const double Is0 = herp_poly(g23[phase00 >> SLEN_BITS], g01[phase00 >> SLEN_BITS], phase00);
-		prev_s = wosc_diff(Is0, prev_Is, (int32_t)SLEN, dscale, doff);
+		prev_s = wosc_reset_s(Is0, herp_poly_rise(g23[pa >> SLEN_BITS], g01[pa >> SLEN_BITS], pa), g01[pa >> SLEN_BITS].c0, dscale, doff);
 		prev_Is = Is0;
 		prev_phase = phase00;
 	}

@@ -306,8 +306,8 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 				const HerpC01 *g01 = P.g_c01 + (size_t)wv * WAVE_LEN;
 				const uint32_t pa = o.phase, pb = o.phase - SLEN;
 				Is0 = herp_poly(g23[pa >> SLEN_BITS], g01[pa >> SLEN_BITS], pa);
-				const double IsP = herp_poly(g23[pb >> SLEN_BITS], g01[pb >> SLEN_BITS], pb);
-				held = wosc_diff(Is0, IsP, (int32_t)SLEN, P.wc[wv].diff_scale, P.wc[wv].diff_offset);
+				held = wosc_reset_s(Is0, herp_poly_rise(g23[pb >> SLEN_BITS], g01[pb >> SLEN_BITS], pb), g01[pb >> SLEN_BITS].c0,
+						P.wc[wv].diff_scale, P.wc[wv].diff_offset);
 				pprev = pa;
 			}
 			DevOp &ow = P.ops[ids[st.op]];

@@ -477,6 +477,23 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 								s[k] = wosc_diff(Is[k], pIs, d, f.diff_scale, f.diff_offset);
 							}
 						}
+						if (first_group && reset) {
+							/* a (re)started oscillator's first sample as the reference build computes it (sau_dev_math.h:
+							 * wosc_reset_s): lane H - 1 holds the phase one table step back -- its Hermite value taken apart */
+							const uint32_t indp = ph[0] >> SLEN_BITS;
+							HerpC23 hp; HerpC01 lp;
+							if (f.tab >= 0) {
+								hp = (t23 + (size_t)f.tab * WAVE_LEN)[FK_SWZ(indp)];
+								lp = (t01 + (size_t)f.tab * WAVE_LEN)[FK_SWZ(indp)];
+							} else {
+								const uint32_t wave = (f.type >> 8) & 0xff;
+								hp = (P.g_c23 + (size_t)wave * WAVE_LEN)[indp];
+								lp = (P.g_c01 + (size_t)wave * WAVE_LEN)[indp];
+							}
+							const double rise_p = lane_prev(herp_poly_rise(hp, lp, ph[0]));
+							const float c0_p = bits_f(lane_prev(f_bits(lp.c0)));
+							if (l == (int)H) s[0] = wosc_reset_s(Is[0], rise_p, c0_p, f.diff_scale, f.diff_offset);
+						}
 						if (__any(zero && l >= p_min)) {
 							/* dphase == 0: the differentiator holds its previous output
 							 * (wosc.h:251-252). Isolated cases resolve inside the row; a

@@ -773,6 +773,18 @@ SAU_HD double herp_poly(const HerpC23 &hi, const HerpC01 &lo, uint32_t phase) {
 	return ((hi.c3 * x + hi.c2) * x + (double)lo.c1) * x + (double)lo.c0;
 }
 
+/* herp_poly() without its table value: herp_poly(hi, lo, p) == herp_poly_rise(hi, lo, p) + (double)lo.c0, the last step */
+SAU_HD double herp_poly_rise(const HerpC23 &hi, const HerpC01 &lo, uint32_t phase) {
+	double x = (double)(phase & (SLEN - 1));
+	return ((hi.c3 * x + hi.c2) * x + (double)lo.c1) * x;
+}
+/* wosc.h:215-231, the sample a (re)started oscillator begins with, as the reference build computes it: sauWOsc_reset is a
+ * function of its own there, and gcc's fast-math takes the Hermite value one table step back apart -- (Is - y1') - P', its
+ * table value y1' and its polynomial part P' subtracted one after the other, not their rounded sum (objdump of
+ * oracle/_ref/generator.o; an ulp now and then, which reaches the PCM through feedback plus a running sum: DESIGN.md 9, 8b).
+ * Is0: herp_poly at the first phase; rise_p, c0_p: herp_poly_rise and lo.c0 at that phase - SLEN. */
+SAU_HD float wosc_reset_s(double Is0, double rise_p, float c0_p, float diff_scale, float diff_offset);
+
 /* Correctly rounded a/b for operands well inside the normal range (here
  * a ~ 1e8..1e9 and 1 <= |b| <= 2^31): the reciprocal-refinement sequence the
  * compiler itself emits for IEEE division, without the range scaling and the
@@ -815,6 +827,11 @@ SAU_HD float wosc_diff(double Is, double prev_Is, int32_t phase_diff,
 		float diff_scale, float diff_offset) {
 	double x = (double)div_diff_scale(diff_scale, (float)phase_diff);
 	return (float)((Is - prev_Is) * x + (double)diff_offset);
+}
+
+SAU_HD float wosc_reset_s(double Is0, double rise_p, float c0_p, float diff_scale, float diff_offset) {
+	const double x = (double)div_diff_scale(diff_scale, (float)(int32_t)SLEN);
+	return (float)(((Is0 - (double)c0_p) - rise_p) * x + (double)diff_offset);
 }
 
 /* Phase offset from the PM inputs, wosc.h:135-169 / rasg.h:165-222 in

@@ -175,7 +175,10 @@ struct SeqBackend : public Backend {
 						if (len > 0 && (op.flags & OPF_OSC_RESET)) { /* wosc.h:215-231 */
 							op.prev_Is = herp(op.wave, tmpu[0] - SLEN);
 							double Is0 = herp(op.wave, tmpu[0]);
-							op.prev_s = wosc_diff(Is0, op.prev_Is, (int32_t)SLEN, k.diff_scale, k.diff_offset);
+							{ /* the reference build's form of the restart sample (sau_dev_math.h: wosc_reset_s) */
+								const uint32_t pp = tmpu[0] - SLEN, ip = op.wave * WAVE_LEN + (pp >> SLEN_BITS);
+								op.prev_s = wosc_reset_s(Is0, herp_poly_rise(c23[ip], c01[ip], pp), c01[ip].c0, k.diff_scale, k.diff_offset);
+							}
 							op.prev_Is = Is0; op.prev_phase = tmpu[0];
 							op.flags &= ~OPF_OSC_RESET;
 						}

@@ -263,13 +263,10 @@ def test_extreme_parameters_vs_reference(oracle):
     assert nan_like == 2  # (the two whose feedback runs to infinity: long runs of -32767)
 
 
-@pytest.mark.xfail(strict=False, reason="open: found by the last sweep of round 3 (1 of 40000 random programs, seed 639877; 2 of 36000 "
-                   "batch programs) -- the oracle, and the device with it, leave the compiled reference by 1 LSB in about one "
-                   "sample of 10^4 when a W oscillator of wave `ean` with feedback under a *ramped* amount modulates a frequency "
-                   "(FM or range FM); every other wave, a constant amount, or the same operator as PM / AM source or carrier: "
-                   "identical. Cause found at the end of round 3 (DESIGN.md section 9, 8b): the reference build's sauWOsc_reset evaluates "
-                   "Is - prev_Is as (Is - y1') - P'; the fix touches the hot kernel's first-frame path and is left for round 4")
-def test_known_residual_ean_feedback_ramp_as_frequency_modulator(oracle):
+def test_restart_sample_in_the_reference_builds_form(oracle):
+    """sauWOsc_reset as the reference build has it -- (Is - y1') - P', not Is - (P' + y1') (oracle: wosc_reset): an ulp in the
+    first sample of a W oscillator, which reaches the PCM through feedback plus a running sum. Found by the last sweep of round 3 (1 of 40000
+    random programs, seed 639877): a W oscillator of wave `ean` with feedback under a ramped amount as FM source, here reduced."""
     if not oracle.have_ref():
         pytest.skip("compiled reference not present")
     from saugns_amd import voicebank as vb
