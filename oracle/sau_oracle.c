@@ -1242,9 +1242,19 @@ static void rasg_run_selfmod(Op *n, size_t len, float *main_buf,
 	const float perlin_amp =
 		(flags & (SAU_RAS_O_HALFSHAPE | SAU_RAS_O_ZIGZAG)) ? 1.f : g_perlin_amp[line];
 	for (size_t i = 0; i < len; ++i) {
-		float pm_a = n->fb_s * pm_abuf[i] * 0.5f;
+		/* the reference build halves the amount first: fb_s * (0.5f * pm_abuf[i]) -- the same
+		 * value unless a product leaves the normal range (generator.o, every sauRasG_map_*_s) */
+		float pm_a = g_fm_forms ? n->fb_s * (0.5f * pm_abuf[i]) : n->fb_s * pm_abuf[i] * 0.5f;
 		float phase = main_buf[i] + pm_a;
-		int32_t cycle_adj = floorf(phase);
+		int32_t cycle_adj;
+		if (g_fm_forms) {
+			/* -ffast-math inlines floorf: cvttss2si (0x80000000 out of range), then one less where the
+			 * truncated value lies above phase -- in 32-bit integer arithmetic: below -2^31 the integer
+			 * indefinite wraps to INT32_MAX (generator.o, every sauRasG_map_*_s) */
+			cycle_adj = (fabsf(phase) < 0x1p31f) ? (int32_t)phase : INT32_MIN;
+			if ((float)cycle_adj > phase) cycle_adj = (int32_t)((uint32_t)cycle_adj - 1u);
+		} else
+			cycle_adj = floorf(phase);
 		uint32_t cycle = cycle_buf[i] + cycle_adj;
 		phase -= cycle_adj;
 		float a, b;
@@ -1254,8 +1264,10 @@ static void rasg_run_selfmod(Op *n, size_t len, float *main_buf,
 			b *= perlin_amp * (phase - 1.f);
 		}
 		if (flags & SAU_RAS_O_HALFSHAPE) {
-			float mx = a < b ? b : a;
-			float mn = a > b ? b : a;
+			/* sau_maxf(a, b), sau_minf(a, b) as the build has them: maxss a,b / minss b,a --
+			 * an unordered pair (NaN) comes out swapped, equal values too (signed zeros) */
+			float mx = a > b ? a : b;
+			float mn = b < a ? b : a;
 			a = mx; b = mn;
 		}
 		if (flags & SAU_RAS_O_ZIGZAG) {

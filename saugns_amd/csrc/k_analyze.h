@@ -243,8 +243,9 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 							/* the block is exact from lane H - wd + 1 + its own extra; this reader
 							 * would sum from lane H - need + 1 */
 							x_step = (need > wd ? need - wd : 0u) + extra_of(st.fmul);
-							/* this operator's own block derives from the modulated one */
-							if (st.kind == ST_LINE && st.which == L_FREQ && (o.st_phase == 0 || wd < o.st_phase))
+							/* this operator's own block derives from the modulated one (its second frequency's line too: the
+							 * range modulation mixes it into the block, generator.c:466-467) */
+							if (st.kind == ST_LINE && (st.which == L_FREQ || st.which == L_FREQ2) && (o.st_phase == 0 || wd < o.st_phase))
 								o.st_phase = wd;
 						}
 					}
@@ -274,7 +275,11 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 			 * needs on top waits in st_prev_phase for its oscillator step */
 			if (x_step > 7) bad = true;
 			set_extra(st.out, extra_of(st.fmul), false);
-			if (st.which == L_FREQ) o.st_prev_phase = x_step;
+			/* (the second frequency's line as well -- round 4: a ratio f2 under a modulated parent frequency, on an oscillator
+			 * with frequency-scaled PM, dropped its lane here; the oscillator's value on its first defined lane was then
+			 * wrong in every row, which shows when a repeated phase on the next lane copies it: batch 3883 of
+			 * tests/tools/gpu_vs_ref_batches.py, one frame of a pan modulator, only under some segment cuts) */
+			if ((st.which == L_FREQ || st.which == L_FREQ2) && x_step > o.st_prev_phase) o.st_prev_phase = x_step;
 		} else if (st.kind == ST_LERP) {
 			if (x_step > 7) bad = true;
 			set_extra(st.out, x_step, true);

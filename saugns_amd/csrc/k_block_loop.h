@@ -704,9 +704,9 @@ __global__ void __launch_bounds__(64 * W * V) render_kernel(RenderParams P) {
 							for (uint32_t j = 0; j < len; ++j) {
 								const uint32_t e = entry_of<W, T>(j);
 								float pma_v = smS ? smS[e] : ((tc.on && plb.sw.type == LN_cub) ? line_value_vt(plb, j, 1.f, tc) : line_value_v(plb, j, 1.f));
-								float pm_a = fb_s * pma_v * 0.5f;
+								float pm_a = ras_fb_amount(fb_s, pma_v);
 								float phase = scratch[e] + pm_a;
-								int32_t cycle_adj = f2i_x86(floorf(phase)); /* (a feedback offset of 2^31 cycles and more: the host's conversion, not the device's) */
+								int32_t cycle_adj = floor_i32_ref(phase); /* (a feedback offset of 2^31 cycles and more: the host's conversion and its wrap) */
 								uint32_t cycle = tmp[e] + (uint32_t)cycle_adj;
 								phase -= (float)cycle_adj;
 								float sv = ras_sample(rp, cycle, phase, false);

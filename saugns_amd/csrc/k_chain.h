@@ -362,9 +362,9 @@ __global__ void __launch_bounds__(64) rchain_kernel(FastParams P) {
 		ras_split(cp, cyc, phf); /* rasg.h:184-186, post-increment */
 		cp += inc;
 		const float pma_v = fast_line_value(cd.pl, (int)t);
-		const float pm_a = fb_s * pma_v * 0.5f;
+		const float pm_a = ras_fb_amount(fb_s, pma_v);
 		float phase = phf + pm_a;
-		const int32_t cycle_adj = f2i_x86(floorf(phase)); /* (a feedback offset of 2^31 cycles and more: the host's conversion, not the device's) */
+		const int32_t cycle_adj = floor_i32_ref(phase); /* (a feedback offset of 2^31 cycles and more: the host's conversion and its wrap) */
 		const uint32_t cycle = cyc + (uint32_t)cycle_adj;
 		phase -= (float)cycle_adj;
 		const float sv = ras_sample(rp, cycle, phase, false);

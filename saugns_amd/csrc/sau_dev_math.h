@@ -77,6 +77,18 @@ SAU_HD int32_t f2i_x86(float x) {
 	return (int32_t)x;
 #endif
 }
+/* floorf(x) taken to int32_t as the reference build's six sauRasG_map_*_s loops have it (rasg.h:251; -ffast-math
+ * inlines floorf): truncate (cvttss2si), and where the truncated value lies above x take one off -- in 32-bit
+ * integer arithmetic, so that below -2^31 the "integer indefinite" 0x80000000 wraps to INT32_MAX and the phase
+ * moves the other way (oracle/_ref/generator.o; found by the batch sweep with extreme parameters, round 3) */
+SAU_HD int32_t floor_i32_ref(float x) {
+	int32_t t = f2i_x86(x);
+	if ((float)t > x) t = (int32_t)((uint32_t)t - 1u);
+	return t;
+}
+/* the feedback amount of the same loops: the build halves the amount first, fb_s * (0.5f * pm_a) -- the source's
+ * (fb_s * pm_a) * 0.5f unless a product leaves the normal range */
+SAU_HD float ras_fb_amount(float fb_s, float pm_a) { return fb_s * (0.5f * pm_a); }
 /* ... and wrapped into a 32-bit phase */
 SAU_HD uint32_t rint32w(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1036,8 +1048,12 @@ SAU_HD float ras_sample(const RasParams &c, uint32_t cycle, float phase, bool bl
 		}
 	}
 	if (c.flags & RO_HALFSHAPE) {
-		float mx = a < b ? b : a;
-		float mn = a > b ? b : a;
+		/* sau_maxf / sau_minf (sau/math.h:121-130) as the build has them. Block loop (maxps b,a / minps a,b in the
+		 * body, min/max b,a in the tails -- they part only for NaN and signed-zero pairs, which the block form's
+		 * finite ends and phases in [0, 1) cannot produce); feedback loops: maxss a,b / minss b,a -- an unordered
+		 * pair comes out swapped */
+		float mx = block ? (a < b ? b : a) : (a > b ? a : b);
+		float mn = block ? (a > b ? b : a) : (b < a ? b : a);
 		a = mx; b = mn;
 	}
 	if (c.flags & RO_ZIGZAG) {

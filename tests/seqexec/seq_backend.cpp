@@ -210,9 +210,9 @@ struct SeqBackend : public Backend {
 							ras_split(cp, cyc, ph);
 							if (!selfmod) s[j] = ras_sample(rp, cyc, ph, true, rp.line == LN_cub && cub_map_is_tail(tc, j));
 							else { /* rasg.h:242-280 */
-								float pm_a = op.fb_s * pv[j] * 0.5f;
+								float pm_a = ras_fb_amount(op.fb_s, pv[j]);
 								float phase = ph + pm_a;
-								int32_t adj = (int32_t)floorf(phase);
+								int32_t adj = floor_i32_ref(phase);
 								uint32_t cycle = cyc + (uint32_t)adj;
 								phase -= (float)adj;
 								float sv = ras_sample(rp, cycle, phase, false);

@@ -21,6 +21,7 @@ import pytest
 
 from conftest import ROOT
 from saugns_amd import voicebank as vb
+from saugns_amd.api import POP_CAMOD, POP_FPMOD, POP_PMOD, POP_RFMOD, POPT_RASEG
 import test_gpu_units as tu
 
 pytestmark = pytest.mark.gpu
@@ -151,3 +152,107 @@ def test_corpus_equals_the_compiled_reference_bit_for_bit(sa, oracle, tables, in
         else:
             os.environ["SAU_AMD_LOOP_TAILS"] = old
         sa.set_piluts(tables)
+
+
+# ---- the two programs of round 3's last batch sweep that differed from the reference -------------
+def _sweep_batch(bseed):
+    """Batch `bseed` of tests/tools/gpu_vs_ref_batches.py: twelve random programs with events (every fourth batch with
+    extreme parameters), the batch's rate, channel count, host call size and engine run length -- the same draws."""
+    rng = np.random.default_rng(300000 + bseed)
+    prgs = []
+    for _ in range(12):
+        voices = [tu._random_voice(rng) for _ in range(int(rng.integers(1, 4)))]
+        tu._random_starts(rng, voices)
+        ups = tu._random_updates(rng, voices)
+        if bseed % 4 == 3:
+            tu._push_extremes(rng, voices)
+        prgs.append(vb.build_program(voices, updates=ups))
+    rate = int(rng.choice([44100, 44100, 48000, 96000, 8000]))
+    stereo = bool(bseed & 1)
+    call = int(rng.integers(1, 12)) if bseed % 5 == 4 else int(rng.integers(300, 12000))
+    return prgs, rate, stereo, call, call * (1500 if call < 300 else int(rng.integers(1, 6)))
+
+
+class _RefSetup:
+    """All sides on the tables the reference library builds on this box, loop tails on (the product's default)."""
+    def __init__(self, sa, oracle, tables):
+        self.sa, self.oracle, self.tables = sa, oracle, tables
+    def __enter__(self):
+        self.oracle.ref()
+        t = self.oracle.ref_piluts()
+        self.sa.set_piluts(t); self.oracle.oracle_use_tables(t)
+        self.old = os.environ.get("SAU_AMD_LOOP_TAILS")
+        os.environ["SAU_AMD_LOOP_TAILS"] = "1"
+        self.oracle.oracle().ora_set_fastmath_forms(2)
+    def __exit__(self, *a):
+        if self.old is None:
+            os.environ.pop("SAU_AMD_LOOP_TAILS", None)
+        else:
+            os.environ["SAU_AMD_LOOP_TAILS"] = self.old
+        self.sa.set_piluts(self.tables); self.oracle.oracle_use_tables(self.tables)
+
+
+@pytest.mark.parametrize("bseed,subset", [(3883, (3, 9)), (3883, (9, 3)), (3883, None), (4899, (7,)), (4899, None)])
+def test_open_batch_cases(sa, oracle, tables, bseed, subset):
+    """Round 3 ended with two of 36000 batch programs differing from the compiled reference (profiles/r03_gpu_vs_ref_batches_last.json):
+    * batch 3883, program 9 -- one frame (4838, 997 LSB in each channel) wrong only beside program 3: not cross-talk but row
+      geometry. Program 3's event cuts program 9's segment; a pan modulator's PM source there has a ratio second frequency under
+      a range-modulated parent frequency and takes frequency-scaled PM, so it reads its frequency block one lane before its first
+      defined lane, and analyze_kernel dropped that lane of lead-in for second-frequency lines (k_analyze.h). The oscillator's
+      value on its first defined lane was wrong in every row; a repeated phase on the next lane copies it into a stored frame.
+    * batch 4899, program 7 (extreme parameters) -- +32767 in the reference, -32767 in device and oracle: an R oscillator's
+      feedback drove its phase below -2^31 cycles, where the reference build's inlined floorf wraps (sau_dev_math.h:
+      floor_i32_ref; rasg.h:251).
+    Both must equal libsau_ref.so's render of the program alone, also as part of their whole batch."""
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref/libsau_ref.so not present")
+    with _RefSetup(sa, oracle, tables):
+        prgs, rate, stereo, call, chunk = _sweep_batch(bseed)
+        idx = list(subset) if subset else list(range(12))
+        b = sa.Batch([prgs[i] for i in idx], rate)
+        b.set_call_len(call)
+        outs = b.render(stereo=stereo, chunk=chunk)
+        for i, got in zip(idx, outs):
+            ref = oracle.ref_render(prgs[i].ptr, rate, stereo, chunk=call)
+            ora = oracle.oracle_render(prgs[i].ptr, rate, stereo, chunk=call)
+            assert len(ora) == len(ref) and (ora == ref).all(), f"batch {bseed} program {i}: oracle mode 2 is not the reference"
+            # (a batch renders until its longest program ends: shorter programs are followed by silence)
+            assert len(got) >= len(ref) and (got[:len(ref)] == ref).all() and not got[len(ref):].any(), \
+                f"batch {bseed} program {i}: {int((got[:len(ref)] != ref).sum())} samples differ from the reference"
+
+
+def _ratio_f2_under_modulated_parent(event_ms):
+    """Batch 3883's program 9 shrunk on the GPU (tests/tools/debug_batch_shrink.py) to what the difference needed, with an
+    event of its own where program 3's used to cut its segment: a pan modulator whose PM source (`srs`) has f2 = a ratio
+    of the pan modulator's range-modulated frequency and takes frequency-scaled PM."""
+    O = vb.Op
+    R = lambda v: vb.Line(v, ratio=True)
+    pm_src = O("srs", freq=367.0641989623553, freq2=R(2.347404147485239), amp=10000.0, time_ms=62, phase=0.958726926583664,
+               mods={POP_RFMOD: [O("par", freq=R(7.25), amp=10000.0, phase=0.9208734835260876)],
+                     POP_FPMOD: [O("saw", op_type=POPT_RASEG, ras=("xpe", 3, 30), seed=1035248422, freq=-1e-06, amp=-1.0,
+                                   phase=0.06775408388823645)]})
+    f_mod = O("srs", freq=R(-2.0), amp=vb.Line(39.74413891462279, goal=0.7357378343765243, shape="nhl"), phase=0.2666345644019249,
+              mods={POP_PMOD: [O("sin", freq=R(7.25), amp=0.6670438939494174, phase=0.02437911905137513)]})
+    pan_mod = O("sin", freq=271.26080125048736, freq2=R(1000.0), amp=0.6230048495695079, phase=0.06238235417556026,
+                mods={POP_PMOD: [pm_src], POP_RFMOD: [f_mod]})
+    carr = O("srs", freq=331.61453862405807, amp=0.5602443945192759, time_ms=55, phase=0.24262704740404495,
+             mods={POP_CAMOD: [pan_mod]})
+    carr.start_ms = 60
+    ups = [(event_ms, 0, carr, {"amp": vb.Line(0.5602443945192759)})] if event_ms else []
+    return vb.build_program([carr], updates=ups)
+
+
+def test_ratio_second_frequency_under_a_modulated_parent_with_scaled_pm(sa, oracle, tables):
+    """The single-program form of batch 3883's case: every cut of the segment between 80 and 112 ms (two of six cuts showed the
+    wrong frame before the fix; holds -- repeated phases -- are frequent in this program, its frequencies are megahertz)."""
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref/libsau_ref.so not present")
+    with _RefSetup(sa, oracle, tables):
+        bad = []
+        for ms in [0] + list(range(80, 113)):
+            prg = _ratio_f2_under_modulated_parent(ms)
+            ref = oracle.ref_render(prg.ptr, RATE, True, chunk=11274)
+            got = sa.Batch([prg], RATE).render(stereo=True, chunk=45096)[0]
+            if len(got) != len(ref) or (got != ref).any():
+                bad.append((ms, sorted(set(int(i) // 2 for i in np.nonzero(got[:len(ref)] != ref[:len(got)])[0]))[:6]))
+        assert not bad, bad
