@@ -6,6 +6,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include <chrono>
+#include <exception>
 #include <string>
 #include <vector>
 
@@ -77,6 +78,8 @@ static bool make_batch(sauAmdBatch &b, const sauProgram *const *prgs, size_t n,
 		be = b.hip;
 	}
 	const auto t1 = std::chrono::steady_clock::now();
+	for (size_t i = 0; i < n; ++i)
+		if (!prgs[i]) { report("generator", "NULL program"); delete be; b.hip = nullptr; return false; }
 	b.engine = Engine::create(prgs, n, srate, be, err);
 	if (!b.engine) { b.hip = nullptr; report("generator", err); return false; }
 	if (getenv("SAU_AMD_DEBUG_CREATE")) {
@@ -158,8 +161,18 @@ static bool generator_issue(sauGenerator *o, size_t big, size_t call_len, bool s
 	return true;
 }
 
+static bool generator_run(sauGenerator *o, int16_t *buf, size_t buf_len, bool stereo, size_t *out_len);
+/* No C++ exception may cross the C ABI (the hosts are C): an allocation that fails in mid-run ends the render the way a
+ * backend error does -- a message, silence, false. */
 extern "C" bool sauGenerator_run(sauGenerator *o, int16_t *buf, size_t buf_len,
 		bool stereo, size_t *out_len) {
+	try {
+		return generator_run(o, buf, buf_len, stereo, out_len);
+	} catch (const std::exception &ex) {
+		return generator_fail(o, buf, buf_len, stereo, out_len, std::string("internal error: ") + ex.what());
+	}
+}
+static bool generator_run(sauGenerator *o, int16_t *buf, size_t buf_len, bool stereo, size_t *out_len) {
 	std::string err;
 	const size_t ch = stereo ? 2 : 1;
 	if (buf_len == 0) {
@@ -255,8 +268,13 @@ extern "C" void sauAmd_destroy_Batch(sauAmdBatch *b) {
 extern "C" bool sauAmd_Batch_run(sauAmdBatch *b, int16_t *const *bufs, size_t buf_len,
 		bool stereo, bool *more, size_t *out_len) {
 	std::string err;
-	if (!b->engine->run(bufs, buf_len, stereo, more, out_len, err)) {
-		report("batch", err);
+	try {
+		if (!b->engine->run(bufs, buf_len, stereo, more, out_len, err)) {
+			report("batch", err);
+			return false;
+		}
+	} catch (const std::exception &ex) { /* (nothing C++ crosses the C ABI) */
+		report("batch", std::string("internal error: ") + ex.what());
 		return false;
 	}
 	return true;

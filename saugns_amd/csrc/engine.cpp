@@ -1,6 +1,7 @@
 /* engine.cpp -- host control plane (see engine.h). */
 #include "engine.h"
 #include <algorithm>
+#include <exception>
 #include <chrono>
 #include <stdio.h>
 #include <stdlib.h>
@@ -42,6 +43,9 @@ Engine *Engine::create(const sauProgram *const *prgs, size_t n_prgs, uint32_t sr
 	Engine *e = new Engine();
 	e->backend_ = backend;
 	e->srate_ = srate;
+	/* (no C++ exception may reach the C ABI above: a program whose counts cannot be allocated -- a hand-made image -- is a
+	 * failed constructor like any other, generator.c:200-217) */
+	try {
 	e->streams_.resize(n_prgs);
 	uint32_t op_base = 0, vo_base = 0;
 	for (size_t s = 0; s < n_prgs; ++s) {
@@ -80,6 +84,11 @@ Engine *Engine::create(const sauProgram *const *prgs, size_t n_prgs, uint32_t sr
 	cfg.piluts = builtin_piluts();
 	cfg.wconst = wave_consts();
 	if (!backend->init(cfg, err)) {
+		delete e;
+		return nullptr;
+	}
+	} catch (const std::exception &ex) {
+		err = std::string("out of memory for the program's operator / voice / event counts (") + ex.what() + ")";
 		delete e;
 		return nullptr;
 	}

@@ -851,7 +851,7 @@ public:
 					set_tasks(cfp, groups_cf, grid_cf ? grid_cf : 1);
 					if (!launch_build(0, rows_cf, grid_cf ? grid_cf : 1, &cfp, 16 * area_cf(rows_cf))) launched = false;
 					fp.mode = fp.sum_levels + 1; fp.only_multi = 0; fp.look_wpv = look_wpv_; fp.look_groups = groups;
-					fp.look_wpv_flags = getenv("SAU_AMD_LOOK_NO_LDS") ? 1u : 0u;
+					fp.look_wpv_flags = (getenv("SAU_AMD_LOOK_NO_LDS") ? 1u : 0u) | (getenv("SAU_AMD_LOOK_WITHHOLD") ? 2u : 0u);
 					if (fp.look) {
 						const unsigned long long waves = (unsigned long long)seg.n_voices * (fp.look_words_real ? (groups < 64 ? groups : 64) : look_wpv_);
 						const uint32_t grid2 = waves > (unsigned long long)fk_grid_ * 16 ? fk_grid_ : (uint32_t)((waves + 15) / 16);

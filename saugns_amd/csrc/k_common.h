@@ -152,7 +152,8 @@ template <bool LDS> __device__ __forceinline__ unsigned long long look_load(unsi
 }
 /* LDS: entry of group i at ent[i % ring] (the caller keeps cg % ring), tag i + 1; HBM: at ent[i], tag = the segment's epoch */
 template <bool LDS> __device__ __forceinline__ uint32_t lookback32(unsigned long long *ent, const uint32_t cg, const uint32_t tot,
-		const uint32_t epoch, const uint32_t ring, const uint32_t cgm /* LDS: cg % ring */, const int l, uint32_t &stuck) {
+		const uint32_t epoch, const uint32_t ring, const uint32_t cgm /* LDS: cg % ring */, const int l, uint32_t &stuck,
+		const bool withhold = false /* test aid (SAU_AMD_LOOK_WITHHOLD): group 1 never publishes, what waits for it gives up */) {
 	/* (LDS: groups up to `ring` back have their entries; what lies further back is dead and reads as empty) */
 	auto at = [&](uint32_t i) { const int s_ = (int)cgm - (int)(cg - i); return LDS ? (uint32_t)(s_ < 0 ? s_ + (int)ring : s_) : i; };
 	auto tag = [&](uint32_t i) { return LDS ? i + 1 : epoch; };
@@ -160,8 +161,10 @@ template <bool LDS> __device__ __forceinline__ uint32_t lookback32(unsigned long
 		if (l == 0) look_store<LDS>(&ent[0], look_word(tag(0), LOOK_PREFIX, tot));
 		return 0;
 	}
-	if (l == 0) look_store<LDS>(&ent[at(cg)], look_word(tag(cg), LOOK_AGG, tot));
+	const bool mute = !LDS && withhold && cg == 1;
+	if (l == 0 && !mute) look_store<LDS>(&ent[at(cg)], look_word(tag(cg), LOOK_AGG, tot));
 	uint32_t excl = 0;
+	uint32_t empty = 0; /* polls in a row that found nothing new (words in HBM: bounded, see LOOK_SPIN_MAX) */
 	int p = (int)cg - 1; /* the nearest group not yet accounted for */
 	for (;;) {
 		const int idx = p - l; /* lane l looks at the group l before it; before group 0 the prefix is 0 */
@@ -177,16 +180,23 @@ template <bool LDS> __device__ __forceinline__ uint32_t lookback32(unsigned long
 		excl += (uint32_t)__builtin_amdgcn_readlane((int)part, 63);
 		if (first_pref < first_none) break;
 		p -= upto;
-		if (upto == 0) __builtin_amdgcn_s_sleep(LDS ? 1 : 2);
+		if (upto == 0) {
+			if (!LDS && ++empty >= LOOK_SPIN_MAX) { stuck = 1; break; } /* give up: the voice's segment goes to the block loop */
+			__builtin_amdgcn_s_sleep(LDS ? 1 : 2);
+		} else {
+			empty = 0;
+		}
 	}
-	if (l == 0) look_store<LDS>(&ent[at(cg)], look_word(tag(cg), LOOK_PREFIX, excl + tot));
+	/* (after giving up the word still goes out, as a prefix, so that the groups behind do not wait in turn: their sums
+	 * are as void as this one's, and the voice is redone) */
+	if (l == 0 && !mute) look_store<LDS>(&ent[at(cg)], look_word(tag(cg), LOOK_PREFIX, excl + tot));
 	return excl;
 }
 /* 64-bit totals (R oscillators' cycle counters): low and high halves in two arrays, a pair counts once both
  * words show the same status */
 template <bool LDS> __device__ __forceinline__ unsigned long long lookback64(unsigned long long *ent_lo, unsigned long long *ent_hi,
 		const uint32_t cg, const unsigned long long tot, const uint32_t epoch, const uint32_t ring, const uint32_t cgm, const int l,
-		uint32_t &stuck) {
+		uint32_t &stuck, const bool withhold = false) {
 	auto at = [&](uint32_t i) { const int s_ = (int)cgm - (int)(cg - i); return LDS ? (uint32_t)(s_ < 0 ? s_ + (int)ring : s_) : i; };
 	auto tag = [&](uint32_t i) { return LDS ? i + 1 : epoch; };
 	auto publish = [&](uint32_t i, uint32_t status, unsigned long long v) {
@@ -197,8 +207,10 @@ template <bool LDS> __device__ __forceinline__ unsigned long long lookback64(uns
 		if (l == 0) publish(0, LOOK_PREFIX, tot);
 		return 0;
 	}
-	if (l == 0) publish(cg, LOOK_AGG, tot);
+	const bool mute = !LDS && withhold && cg == 1;
+	if (l == 0 && !mute) publish(cg, LOOK_AGG, tot);
 	unsigned long long excl = 0;
+	uint32_t empty = 0;
 	int p = (int)cg - 1;
 	for (;;) {
 		const int idx = p - l;
@@ -218,9 +230,14 @@ template <bool LDS> __device__ __forceinline__ unsigned long long lookback64(uns
 		excl += readlane64(part, 63);
 		if (first_pref < first_none) break;
 		p -= upto;
-		if (upto == 0) __builtin_amdgcn_s_sleep(LDS ? 1 : 2);
+		if (upto == 0) {
+			if (!LDS && ++empty >= LOOK_SPIN_MAX) { stuck = 1; break; }
+			__builtin_amdgcn_s_sleep(LDS ? 1 : 2);
+		} else {
+			empty = 0;
+		}
 	}
-	if (l == 0) publish(cg, LOOK_PREFIX, excl + tot);
+	if (l == 0 && !mute) publish(cg, LOOK_PREFIX, excl + tot);
 	return excl;
 }
 

@@ -332,7 +332,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 									for (int k = 0; k < T; ++k)
 										tot += (uint32_t)__builtin_amdgcn_readlane((int)S[k], 63) - (uint32_t)__builtin_amdgcn_readlane((int)S[k], (int)H - 1);
 									acc = f.phase0 + (look_lds ? lookback32<true>(lk_base + (size_t)fa.pad[0] * 2 * 64, cg, tot, 0, lk_ring, cgm, l, zero_acc)
-									                           : lookback32<false>(lookv + (size_t)fa.pad[0] * 2 * P.scan_groups, cg, tot, P.look_epoch, 0, 0, l, zero_acc));
+									                           : lookback32<false>(lookv + (size_t)fa.pad[0] * 2 * P.scan_groups, cg, tot, P.look_epoch, 0, 0, l, zero_acc, (P.look_wpv_flags & 2u) != 0));
 								} else {
 									acc = two ? (sum_me ? 0u : f.phase0 + (uint32_t)sums[cg])
 									          : (first_group ? f.phase0 : (uint32_t)carry[si]);
@@ -599,7 +599,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 									acc = cp0 + lookback64<true>(e_lo, e_lo + 64, cg, tot, 0, lk_ring, cgm, l, zero_acc);
 								} else {
 									unsigned long long *e_lo = lookv + (size_t)fa.pad[0] * 2 * P.scan_groups;
-									acc = cp0 + lookback64<false>(e_lo, e_lo + P.scan_groups, cg, tot, P.look_epoch, 0, 0, l, zero_acc);
+									acc = cp0 + lookback64<false>(e_lo, e_lo + P.scan_groups, cg, tot, P.look_epoch, 0, 0, l, zero_acc, (P.look_wpv_flags & 2u) != 0);
 								}
 							} else {
 								acc = two ? (sum_me ? 0ull : cp0 + sums[cg])
@@ -682,7 +682,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 							for (int k = 0; k < T; ++k)
 								tot += (uint32_t)__builtin_amdgcn_readlane((int)S[k], 63) - (uint32_t)__builtin_amdgcn_readlane((int)S[k], (int)H - 1);
 							acc = nprev + (look_lds ? lookback32<true>(lk_base + (size_t)fa.pad[0] * 2 * 64, cg, tot, 0, lk_ring, cgm, l, zero_acc)
-							                        : lookback32<false>(lookv + (size_t)fa.pad[0] * 2 * P.scan_groups, cg, tot, P.look_epoch, 0, 0, l, zero_acc));
+							                        : lookback32<false>(lookv + (size_t)fa.pad[0] * 2 * P.scan_groups, cg, tot, P.look_epoch, 0, 0, l, zero_acc, (P.look_wpv_flags & 2u) != 0));
 						}
 #pragma unroll
 						for (int k = 0; k < T; ++k) {

@@ -11,6 +11,7 @@
  * memcpy plus pointer fix-ups.
  */
 #include "../../include/saugns_amd.h"
+#include <exception>
 #include <map>
 #include <stdlib.h>
 #include <string.h>
@@ -53,8 +54,12 @@ template <typename T> void set_ptr(T *&field, uint64_t off) {
 
 } /* namespace */
 
+static size_t serialize(const sauProgram *prg, void *buf, size_t cap);
 extern "C" size_t sauAmd_program_serialize(const sauProgram *prg, void *buf, size_t cap) {
 	if (!prg) return 0;
+	try { return serialize(prg, buf, cap); } catch (const std::exception &) { return 0; } /* (nothing C++ crosses the C ABI) */
+}
+static size_t serialize(const sauProgram *prg, void *buf, size_t cap) {
 	Writer w;
 	w.bytes.resize(16, 0);
 	memcpy(&w.bytes[0], MAGIC, 8);
@@ -147,6 +152,10 @@ extern "C" sauProgram *sauAmd_program_load(const void *image, size_t len) {
 			}
 		}
 	}
+	/* An image of n bytes does not describe more than n operators (the parser may count ids that no event ever gives data
+	 * for -- devtests/freelist.sau: 4 ids, 2 with data -- so the count is not bounded by the operator data); one that claims
+	 * 2^31 of them would only have the engine allocate for them. (vo_count is 16 bits wide.) */
+	ok = ok && prg->op_count <= total;
 	if (!ok) { free(base); return nullptr; }
 	prg->name = "image";
 	return prg;

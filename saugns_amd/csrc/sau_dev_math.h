@@ -132,7 +132,10 @@ SAU_HD uint32_t ranfast32(uint32_t n) {
 /* sau/math.h:283-285 */
 SAU_HD uint32_t mcg32(uint32_t seed) { return seed * 0xe47135u; }
 /* sau/math.h:94-96 */
-SAU_HD int32_t sar32(int32_t x, int s) { return x < 0 ? ~(~x >> s) : x >> s; }
+/* (the shift count taken mod 32, as the host's scalar `sar` and the device's shifts take it: the reference's parser gives R
+ * levels 0..30, sau/program.h:145-149 -- only a hand-made program image can ask for more, and there the reference's own
+ * `x >> s` is undefined; found by the sanitizer fuzz of round 4) */
+SAU_HD int32_t sar32(int32_t x, int s) { s &= 31; return x < 0 ? ~(~x >> s) : x >> s; }
 /* sau/math.h:112-118 */
 SAU_HD int32_t foldhd32(int32_t x) {
 	uint32_t s = (uint32_t)x;

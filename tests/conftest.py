@@ -12,10 +12,42 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 # every plan the engine takes from its cache of graph shapes is compared with a fresh compile (engine.cpp)
 os.environ.setdefault("SAU_AMD_PLAN_CHECK", "1")
-# The suite's programs are compared with the oracle's mode 1 (the loop bodies' forms everywhere), which does not depend on
-# the host's call size; the product's default reproduces the compiled reference's loop tails of `cub` as well (mode 2, which
-# does), and tests/test_loop_tails.py and tests/test_gpu_vs_ref.py switch that on for their renders.
-os.environ.setdefault("SAU_AMD_LOOP_TAILS", "0")
+# The suite runs what ships: the product's default reproduces the compiled reference's loop tails of `cub` (oracle mode 2,
+# which depends on the host's call size -- device and oracle are given the same one); `SAU_AMD_LOOP_TAILS=0 pytest ...` runs
+# the same suite with the loop bodies' forms everywhere (oracle mode 1), and tests/test_gpu_vs_ref.py and
+# tests/test_loop_tails.py keep legs of their own in that setting.
+TAILS = os.environ.get("SAU_AMD_LOOP_TAILS", "1") != "0"
+ORACLE_FORMS = 2 if TAILS else 1  # ora_set_fastmath_forms(): what the device is compared with
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def loop_tails(on):
+    """Engines created inside render with the reference build's loop tails of `cub` on or off (SAU_AMD_LOOP_TAILS is read
+    when an engine is created)."""
+    old = os.environ.get("SAU_AMD_LOOP_TAILS")
+    os.environ["SAU_AMD_LOOP_TAILS"] = "1" if on else "0"
+    try:
+        yield
+    finally:
+        if old is None:
+            os.environ.pop("SAU_AMD_LOOP_TAILS", None)
+        else:
+            os.environ["SAU_AMD_LOOP_TAILS"] = old
+
+
+@pytest.fixture()
+def tails_on():
+    with loop_tails(True):
+        yield
+
+
+@pytest.fixture()
+def tails_off():
+    with loop_tails(False):
+        yield
 
 
 def pytest_configure(config):
@@ -75,8 +107,13 @@ def sa(tables):
 @pytest.fixture(scope="session")
 def seqexec():
     import subprocess
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "seqexec")])
-    lib = C.CDLL(os.path.join(ROOT, "tests", "seqexec", "libseqexec.so"))
+    # SAU_SEQEXEC_LIB: another build that holds the executor (tests/test_sanitizers.py: the ASan + UBSan library, which is
+    # also what SAU_AMD_LIB then points the product's loader at)
+    path = os.environ.get("SAU_SEQEXEC_LIB")
+    if not path:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "seqexec")])
+        path = os.path.join(ROOT, "tests", "seqexec", "libseqexec.so")
+    lib = C.CDLL(path)
     lib.seq_backend_create.restype = C.c_void_p
     lib.seq_backend_create.argtypes = [C.c_uint32]
     return lib

@@ -5,10 +5,11 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import saugns_amd as sa
 from oracle import pyoracle as po
+from conftest import ORACLE_FORMS  # 2 by default: the reference build's loop tails reproduced (the 11289-frame calls of both sides)
 G = os.path.join(ROOT, "tests", "golden")
 index = json.load(open(os.path.join(G, "index.json")))
 tabs = np.fromfile(os.path.join(G, "piluts_ref.f32"), dtype="<f4").reshape(12, 2048)
-sa.set_piluts(tabs); po.oracle_use_tables(tabs); po.oracle().ora_set_fastmath_forms(1)
+sa.set_piluts(tabs); po.oracle_use_tables(tabs); po.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
 rate = index["corpus_rate"]
 bad = []
 for key in sorted(index["corpus"]):

@@ -42,7 +42,9 @@ def wav_parts(blob):
 
 def close(a, b, what):
     assert len(a) == len(b) and len(a) > 0, (what, len(a), len(b))
-    assert int(np.abs(a - b).max()) <= 1, what  # the north star's tolerance: +-1 LSB int16
+    # (the north star's tolerance is +-1 LSB int16; both hosts make the same calls, so with the reference build's loop
+    #  tails reproduced -- the default -- the files are identical)
+    assert int(np.abs(a - b).max()) == 0, what
 
 
 @pytest.mark.skipif(not have_hosts, reason="reference hosts not built (oracle/Makefile hosts)")
@@ -135,3 +137,26 @@ def test_two_generators_at_two_rates(tmp_path):
         close(pg, pc, (script, "file"))
         close(dg, dc, (script, "device"))
         assert len(dg) > len(pg)  # 48 kHz against 44.1 kHz
+
+
+REF_SRC = "/root/reference"
+PARSER_CRASHERS = ("devtests/crashes/testbindmultiple.sau", "devtests/crashes/testbindmultiple2.sau",
+                   "devtests/crashes/testbindmultiple3.sau", "devtests/warning/label_without_operator.sau")
+
+
+@pytest.mark.skipif(not have_hosts or not os.path.isdir(os.path.join(REF_SRC, "devtests")),
+                    reason="needs the reference hosts and the reference's script files (build container only)")
+def test_scripts_that_crash_the_reference_parser_end_both_hosts_alike(tmp_path):
+    """Four scripts of the reference's corpus are outside every fixture because its parser crashes on them (devtests/crashes/
+    is its collection of such cases; no program ever reaches a generator). The parser stays the reference's (SURVEY section 2,
+    out of scope), so the host linked against this library must end exactly as the reference's own does: same signal, no
+    output file. No GPU needed -- the crash comes before sau_create_Generator. (The fifth script that used to be skipped,
+    alarm-25m, is an ordinary corpus fixture since round 4.)"""
+    for rel in PARSER_CRASHERS:
+        rc = {}
+        for name, exe in (("cpu", CPU), ("gpu", GPU)):
+            path = str(tmp_path / f"{name}.wav")
+            out = run(exe, ["-m", "-d", "-r", "44100", "-o", path, os.path.join(REF_SRC, rel)])
+            rc[name] = out.returncode
+            assert not os.path.exists(path) or os.path.getsize(path) <= 44, (rel, name)
+        assert rc["cpu"] < 0 and rc["gpu"] == rc["cpu"], (rel, rc)  # (negative: ended by a signal -- SIGSEGV here)

@@ -3,7 +3,7 @@ line positions (sau/line.c:385-398, 430-445, 305-309; tests/lattice_cases.py).""
 import numpy as np
 import pytest
 
-from conftest import max_diff
+from conftest import max_diff, ORACLE_FORMS
 from lattice_cases import expiry_value_goal_program, lattice_case
 
 pytestmark = pytest.mark.gpu
@@ -25,7 +25,7 @@ def test_expiry_value_goal_sequences(sa, oracle, rate, path, monkeypatch):
     there (tests/test_host.py)."""
     if path:
         monkeypatch.setenv("SAU_AMD_NO_FAST", "1")
-    oracle.oracle().ora_set_fastmath_forms(1)
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
     differs = 0
     for seed in range(6):
         prg = expiry_value_goal_program(seed)
@@ -46,7 +46,7 @@ def test_expiry_value_goal_sequences(sa, oracle, rate, path, monkeypatch):
 def test_random_lattice_programs(sa, oracle, rate):
     """Random trees with such event sequences on any line of any operator: engine runs of one
     length over host calls of another (sauAmd_Batch_set_call_len), and the drop-in generator."""
-    oracle.oracle().ora_set_fastmath_forms(1)
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
     for seed in range(40):
         rng = np.random.default_rng(77000 + seed)
         prg = lattice_case(rng)
@@ -65,7 +65,7 @@ def test_random_lattice_programs(sa, oracle, rate):
 
 def test_lattice_programs_in_one_batch(sa, oracle):
     """Twelve such programs side by side: every program's events cut the others' segments."""
-    oracle.oracle().ora_set_fastmath_forms(1)
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
     prgs = [lattice_case(np.random.default_rng(77100 + k)) for k in range(12)]
     outs = sa.Batch(prgs, 44100).render(stereo=False, chunk=2500)
     for k, (prg, got) in enumerate(zip(prgs, outs)):

@@ -4,7 +4,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import max_diff
+from conftest import max_diff, ORACLE_FORMS
 from saugns_amd import voicebank as vb
 from saugns_amd.api import (LINES, POP_AMOD, POP_APMOD, POP_CAMOD, POP_FMOD, POP_FPMOD, POP_PMOD,
                             POP_RAMOD, POP_RFMOD, POPT_NOISE, POPT_RASEG, POPT_WAVE, WAVES)
@@ -14,9 +14,11 @@ RATE = 44100
 
 
 def check(sa, oracle, voices, frames=None, stereo=False, chunk=4000):
-    oracle.oracle().ora_set_fastmath_forms(1)
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
     prg = vb.build_program(voices)
-    want = oracle.oracle_render(prg.ptr, RATE, stereo)
+    # (both sides make calls of `chunk` frames: the reference build's loop tails -- oracle mode 2, the suite's default --
+    #  fall where its blocks end, which depends on the host's call size)
+    want = oracle.oracle_render(prg.ptr, RATE, stereo, chunk=chunk)
     got = sa.Generator(prg, RATE).render(stereo=stereo, chunk=chunk)
     assert len(got) == len(want)
     d = np.nonzero(got != want)[0]
@@ -127,9 +129,9 @@ def test_line_arithmetic_device_vs_host(sa):
 def check_runs(sa, oracle, voices, chunk, stereo=False):
     """As check(), but through the batch API with one engine run per `chunk` frames, so that
     later runs start from the state earlier ones left (expired operators, finished ramps)."""
-    oracle.oracle().ora_set_fastmath_forms(1)
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
     prg = vb.build_program(voices)
-    want = oracle.oracle_render(prg.ptr, RATE, stereo)
+    want = oracle.oracle_render(prg.ptr, RATE, stereo, chunk=chunk)  # (a run of the batch API stands for one host call)
     got = sa.Batch([prg], RATE).render(stereo=stereo, chunk=chunk)[0]
     assert len(got) == len(want)
     d = np.nonzero(got != want)[0]
@@ -405,7 +407,7 @@ def test_extreme_parameters(sa, oracle, seed):
     of cycles, operators of 0-2 ms, sample rates of 1 kHz to 384 kHz: the programs that exposed where the device's arithmetic
     left the host's at the edges (conversions out of range, NaN in the mix). Bit-exact vs the oracle (pinned against the
     compiled reference on the same programs, tests/test_oracle.py), batch API and drop-in generator."""
-    oracle.oracle().ora_set_fastmath_forms(1)
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
     prg, rate, call = extreme_program(seed)
     for stereo in (False, True):
         want = oracle.oracle_render(prg.ptr, rate, stereo, chunk=call)
@@ -429,7 +431,7 @@ def test_random_graphs_with_later_events(sa, oracle, seed):
     voices = [_random_voice(rng) for _ in range(int(rng.integers(1, 4)))]
     _random_starts(rng, voices)
     ups = _random_updates(rng, voices)
-    oracle.oracle().ora_set_fastmath_forms(1)
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
     prg = vb.build_program(voices, updates=ups)
     stereo = bool(seed & 1)
     for chunk in (4000000, int(rng.integers(700, 3000))):
@@ -456,7 +458,7 @@ def test_random_operator_graphs(sa, oracle, seed):
 def test_deep_and_wide_graphs(sa, oracle):
     """Nesting at the limit (64 levels of PM) and 300 modulators in one list, on the device."""
     from saugns_amd.voicebank import Op, Line
-    oracle.oracle().ora_set_fastmath_forms(1)
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
     op = None
     for d in range(64):
         top = d == 63
@@ -487,7 +489,7 @@ def test_two_generators_alternately_on_device(sa, oracle):
     `split_gen` arrangement, saugns.c:585), each rendering ahead on its own stream and pooled
     buffers: neither disturbs the other."""
     from conftest import load_program
-    oracle.oracle().ora_set_fastmath_forms(1)
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
     prg = load_program(sa, "examples__dull_seq-fm_pm")
     rates = (44100, 48000)
     want = [oracle.oracle_render(prg.ptr, r, True) for r in rates]
@@ -529,7 +531,7 @@ def test_repeated_phases_at_row_starts_stay_on_the_fast_path(sa, oracle, rows, m
     is handed to the block loop (which would take milliseconds per voice here). At every number of
     rows per pass that has a build of its own."""
     monkeypatch.setenv("SAU_AMD_FAST_ROWS", rows)
-    oracle.oracle().ora_set_fastmath_forms(1)
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
     prg = _through_zero_bank(256, 20)
     want = oracle.oracle_render(prg.ptr, RATE, False)
     b = sa.Batch([prg], RATE)
@@ -579,7 +581,7 @@ def test_red_noise_stays_on_the_time_parallel_path(sa, oracle):
     ramp, over several engine runs (the sum carried from one to the next), 1 to 64 waves per voice; and none of
     it in the block loop."""
     from saugns_amd.api import POPT_NOISE
-    oracle.oracle().ora_set_fastmath_forms(1)
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
     for n_voices, ms in ((1, 700), (3, 300), (40, 120), (300, 60)):
         voices = []
         for k in range(n_voices):
@@ -609,7 +611,7 @@ def test_r_oscillator_options(sa, oracle, line):
     (rasg.h:299-743), plain, as a PM source with PM of its own, and self-modulated
     (rasg.h:242-294). tests/test_oracle.py pins the same grid against the compiled reference."""
     from saugns_amd.api import POPT_RASEG
-    oracle.oracle().ora_set_fastmath_forms(1)
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
     for func in range(6):
         voices = []
         for k, flags in enumerate((0, 1, 2, 4, 8, 16, 9, 25, 31)):
@@ -677,7 +679,7 @@ def amp_operator_cases():
 def test_amp_operator(sa, oracle):
     """A operator in every role (amp_operator_cases), bit-exact vs the oracle; tests/test_oracle.py
     pins the oracle on the same cases against the compiled reference."""
-    oracle.oracle().ora_set_fastmath_forms(1)
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
     for name, voices, ups in amp_operator_cases():
         prg = vb.build_program(voices, updates=ups)
         for stereo, chunk in ((True, 4000000), (False, 777)):
@@ -708,7 +710,7 @@ def test_pan_modulators(sa, oracle):
 def test_batch_of_different_programs(sa, oracle, stereo):
     """sauAmd_create_Batch over 24 random programs with their own event timelines, lengths and
     voice counts: every stream equals its own single render (streams share launches, nothing else)."""
-    oracle.oracle().ora_set_fastmath_forms(1)
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
     prgs, wants = [], []
     for seed in range(24):
         rng = np.random.default_rng(9000 + seed)
@@ -716,11 +718,11 @@ def test_batch_of_different_programs(sa, oracle, stereo):
         _random_starts(rng, voices)
         prg = vb.build_program(voices, updates=_random_updates(rng, voices))
         prgs.append(prg)
-        wants.append(oracle.oracle_render(prg.ptr, RATE, stereo))
     for chunk in (4000000, 1777):
         outs = sa.Batch(prgs, RATE).render(stereo=stereo, chunk=chunk)
-        for k, (got, want) in enumerate(zip(outs, wants)):
-            assert len(got) == len(want) and (got == want).all(), (k, chunk)
+        for k, (got, prg) in enumerate(zip(outs, prgs)):
+            want = oracle.oracle_render(prg.ptr, RATE, stereo, chunk=chunk)  # (the same call size: loop tails)
+            assert len(got) >= len(want) and (got[:len(want)] == want).all() and not got[len(want):].any(), (k, chunk)
 
 
 def test_ratio_chains_below_modulated_frequencies(sa, oracle):
@@ -765,7 +767,7 @@ def test_random_graphs_in_other_kernel_configurations(sa, oracle, env):
     tight LDS budget, single-wave teams in the block loop, running sums in several passes instead of
     one pass with look-back (with and without the saved increments), and -- few voices as these programs
     have -- one pass with look-back where the default keeps several passes (8 and 4 rows per pass)."""
-    oracle.oracle().ora_set_fastmath_forms(1)
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
@@ -791,10 +793,10 @@ def test_random_graphs_in_other_kernel_configurations(sa, oracle, env):
 def test_dropin_generator_on_random_programs(sa, oracle, depth, monkeypatch):
     """sau_create_Generator / sauGenerator_run with the host's 11289-frame calls (and odd sizes) on
     randomized programs with events; long ones, so that the read-ahead hands out several device runs
-    from its three buffers (two runs in flight, or one: SAU_AMD_READAHEAD_DEPTH). The device runs are 176400
-    frames: the oracle is asked for the same."""
+    from its three buffers (two runs in flight, or one: SAU_AMD_READAHEAD_DEPTH). The device renders runs of 176400
+    frames ahead, each a whole number of the host's calls; the oracle makes the host's calls."""
     monkeypatch.setenv("SAU_AMD_READAHEAD_DEPTH", depth)
-    oracle.oracle().ora_set_fastmath_forms(1)
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
     for seed in range(300, 308):
         rng = np.random.default_rng(5000 + seed)
         voices = [_random_voice(rng) for _ in range(int(rng.integers(1, 4)))]
@@ -803,8 +805,9 @@ def test_dropin_generator_on_random_programs(sa, oracle, depth, monkeypatch):
         _random_starts(rng, voices)
         prg = vb.build_program(voices, updates=_random_updates(rng, voices))
         stereo = bool(seed & 1)
-        want = oracle.oracle_render(prg.ptr, RATE, stereo, chunk=176400)
         for call in (11289, 4099):
+            # (the oracle makes the host's calls; the device renders runs of many of them ahead)
+            want = oracle.oracle_render(prg.ptr, RATE, stereo, chunk=call)
             got = sa.Generator(prg, RATE).render(stereo=stereo, chunk=call)
             assert len(got) == len(want) and (got == want).all(), (seed, call)
 
@@ -842,7 +845,7 @@ def test_tall_random_trees(sa, oracle, seed):
     tests/tools/gpu_vs_ref_sweep.py's `tall` mode): wide plans with range modulators, R and N operators, feedback -- the first
     four are the ones that found render_kernel<1, 1, 1, true> reading its block buffers in HBM through LDS-typed pointers in
     the W feedback loop (a memory fault at worst). Bit-exact vs the oracle."""
-    oracle.oracle().ora_set_fastmath_forms(1)
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
     rng = np.random.default_rng(20000 + seed)
     _ = [_random_voice(rng) for _ in range(int(rng.integers(1, 4)))]
     voices = [_tall_tree(rng) for _ in range(int(rng.integers(1, 3)))]
@@ -882,7 +885,7 @@ def test_feedback_chains_at_other_pipeline_depths(sa, oracle, chunks, monkeypatc
     monkeypatch.setenv("SAU_AMD_CHAIN_CHUNKS", chunks)
     if chunks == "2":
         monkeypatch.setenv("SAU_AMD_CHAIN_INLINE", "1")
-    oracle.oracle().ora_set_fastmath_forms(1)
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
     prg = vb.config5(n=96, seconds=2)
     want = oracle.oracle_render(prg.ptr, RATE, False)
     got = sa.Batch([prg], RATE).render(stereo=False, chunk=88200)[0]
@@ -904,7 +907,7 @@ def test_feedback_chains_that_running_sums_depend_on(sa, oracle, early, monkeypa
     kaboom1 71 against 32 ms, tools/gpu_script_phases.py)."""
     if early == "off":
         monkeypatch.setenv("SAU_AMD_NO_EARLY_CHAINS", "1")
-    oracle.oracle().ora_set_fastmath_forms(1)
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
     def fb(f=0.2, a=0.5, amp=1.0, **kw):
         return vb.Op("sin", freq=f, pm_a=a, amp=amp, **kw)
     kaboom = vb.Op("sin", freq=-500.0, freq2=500.0, amp=vb.Line(0.0, goal=1.0, shape="exp"), time_ms=1500,
@@ -985,6 +988,30 @@ def test_running_sums_by_look_back(sa, oracle, lookback, monkeypatch):
     assert b.timing_ex()["block_ms"] < 1.0  # the time-parallel kernel took them, not the block loop
 
 
+@pytest.mark.timeout(120)
+def test_look_back_wait_is_bounded(sa, oracle, monkeypatch):
+    """a wave that waits for another workgroup's sums (look-back words in HBM) must not spin forever when that
+    workgroup never comes -- a second process on the device, a CU-masked one. SAU_AMD_LOOK_WITHHOLD makes group 1 of every
+    spread voice keep its words to itself: the wave behind it gives up after LOOK_SPIN_MAX empty polls (k_common.h),
+    publishes so that nobody waits for *it*, and the voice's segment is redone by the block loop -- slow, exact, never hung."""
+    monkeypatch.setenv("SAU_AMD_LOOK_MIN_VOICES", "1")
+    monkeypatch.setenv("SAU_AMD_LOOK_NO_LDS", "1")  # (every voice through the words in HBM)
+    monkeypatch.setenv("SAU_AMD_LOOK_WITHHOLD", "1")
+    long_one = vb.Op("sin", freq=vb.Line(55.0, goal=1760.0, shape="exp"), time_ms=3000,
+                     mods={POP_FMOD: [vb.Op("sin", freq=4.0, amp=8.0, mods={POP_FMOD: [vb.Op("sin", freq=0.7, amp=2.0)]})]})
+    from saugns_amd.api import POPT_RASEG
+    r_one = vb.Op(freq=vb.Line(120.0, goal=480.0, shape="exp"), amp=0.7, time_ms=2500, op_type=POPT_RASEG, seed=77, ras=("cos", 1, 9))
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
+    for voices in ([long_one], [r_one], [long_one, r_one]):
+        prg = vb.build_program(voices)
+        want = oracle.oracle_render(prg.ptr, RATE, False, chunk=1000000)
+        b = sa.Batch([prg], RATE)
+        b.set_timing(2)
+        got = b.render(stereo=False, chunk=1000000)[0]
+        assert len(got) == len(want) and (got == want).all()
+        assert b.timing_ex()["block_ms"] > 1.0  # (the block loop did redo them: the hook really withheld the words)
+
+
 @pytest.mark.timeout(180)
 def test_two_generators_at_once_with_running_sums(sa, oracle):
     """Two host threads, a generator each, rendering banks of FM voices at the same time: their single-pass
@@ -992,7 +1019,7 @@ def test_two_generators_at_once_with_running_sums(sa, oracle):
     across workgroups -- the process lets such launches take turns on a device (SpreadLaunchOrder), everything
     else of the two generators overlaps. Both renders equal the oracle's."""
     import threading
-    oracle.oracle().ora_set_fastmath_forms(1)
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
     def bank(seed):
         return [vb.Op("sin", freq=vb.Line(100.0 + 7 * k + seed, goal=300.0 + 3 * k, shape="exp"), time_ms=1500 + 10 * k,
                       mods={POP_FMOD: [vb.Op("sin", freq=3.0 + k % 5, amp=15.0 + seed,

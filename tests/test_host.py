@@ -7,7 +7,7 @@ import re
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, ROOT, load_program, max_diff
+from conftest import GOLDEN, ROOT, load_program, max_diff, ORACLE_FORMS
 
 
 def test_library_exports_every_declared_symbol(sa):
@@ -61,7 +61,7 @@ HOST_KEYS = ["devtests__voice-reuse", "devtests__pm-addremaddrem", "examples__du
 def test_control_plane_and_plans_vs_oracle(sa, oracle, seqexec, key):
     """Engine (events, voices, end detection) + plan compiler + shared arithmetic,
     executed sequentially, against the oracle: bit-exact, any block length."""
-    oracle.oracle().ora_set_fastmath_forms(1)
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
     prg = load_program(sa, key)
     want = oracle.oracle_render(prg.ptr, 12000, True)
     for block, chunk in ((1016, 11289), (64, 1000)):
@@ -97,7 +97,7 @@ def test_dropin_generator_call_sizes(sa, oracle, seqexec, readahead, monkeypatch
     (generator.c:905-973), whatever the call size and the size of a run."""
     if readahead:
         monkeypatch.setenv("SAU_AMD_READAHEAD", readahead)
-    oracle.oracle().ora_set_fastmath_forms(1)
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
     lib = oracle.oracle()
     for key, stereo, call in (("devtests__voice-reuse", False, 3001), ("examples__tests__scales", True, 11289),
                               ("examples__dull_seq-fm_pm", False, 25000), ("devtests__voice-reuse", True, 1)):
@@ -127,7 +127,7 @@ def test_dropin_generator_call_sizes(sa, oracle, seqexec, readahead, monkeypatch
 
 def test_batch_streams_are_independent(sa, oracle, seqexec):
     """Programs with different event timelines in one batch == each alone."""
-    oracle.oracle().ora_set_fastmath_forms(1)
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
     keys = ["devtests__voice-reuse", "examples__tests__scales", "examples__dull_seq-fm_pm"]
     prgs = [load_program(sa, k) for k in keys]
     outs = sa.Batch(prgs, 12000, backend=seqexec.seq_backend_create(1016)).render(stereo=False, chunk=5000)
@@ -217,7 +217,7 @@ def test_nesting_as_deep_as_the_reference(sa, oracle, seqexec):
     from saugns_amd import voicebank
     from saugns_amd.voicebank import Op, Line
     from saugns_amd.api import POP_PMOD, POP_FMOD, POP_RFMOD, POP_AMOD, POP_RAMOD, POP_FPMOD
-    oracle.oracle().ora_set_fastmath_forms(1)
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
     for depth in (63, 65, 120, 130, 255, 256):
         prg = voicebank.build_program([_pm_chain(depth)])
         got = sa.Batch([prg], 12000, backend=seqexec.seq_backend_create(256)).render()[0]
@@ -252,7 +252,7 @@ def test_nesting_as_deep_as_the_reference(sa, oracle, seqexec):
 def test_two_generators_alternately(sa, oracle, seqexec):
     """saugns.c:585 creates a second generator at the device rate (`split_gen`) and calls both in
     turn from one thread: the two must not share mutable state (threading row)."""
-    oracle.oracle().ora_set_fastmath_forms(1)
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
     prg = load_program(sa, "examples__dull_seq-fm_pm")
     rates = (12000, 16000)
     want = [oracle.oracle_render(prg.ptr, r, True) for r in rates]
@@ -279,7 +279,7 @@ def test_pan_modulator_shorter_than_its_carrier(sa, oracle, seqexec):
     from saugns_amd import voicebank
     from saugns_amd.voicebank import Op, Line
     from saugns_amd.api import POP_CAMOD
-    oracle.oracle().ora_set_fastmath_forms(1)
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
     for mod_ms in (None, 30, 70, 200):
         m = Op("spa", freq=Line(1.0, ratio=True), amp=0.48, time_ms=mod_ms)
         c = Op("tri", freq=144.3, amp=0.7, time_ms=136, pan=0.25, mods={POP_CAMOD: [m]})
@@ -298,7 +298,7 @@ def test_program_images_of_random_programs(sa, oracle):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import test_gpu_units as tu
     from saugns_amd import voicebank as vb
-    oracle.oracle().ora_set_fastmath_forms(1)
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
     for seed in range(40):
         rng = np.random.default_rng(5000 + seed)
         voices = [tu._random_voice(rng) for _ in range(int(rng.integers(1, 4)))]
@@ -321,7 +321,7 @@ def test_line_positions_follow_the_reference_block_lattice(sa, oracle, seqexec, 
     sizes is the reference's behaviour; asserted so that the programs keep exercising it.)"""
     from saugns_amd import voicebank as vb
     from lattice_cases import expiry_value_goal_program
-    oracle.oracle().ora_set_fastmath_forms(1)
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
     seen_dependence = False
     for seed in range(6):
         prg = expiry_value_goal_program(seed)
@@ -333,7 +333,7 @@ def test_line_positions_follow_the_reference_block_lattice(sa, oracle, seqexec, 
                 oracle.oracle().ora_set_fastmath_forms(2)
                 ref = oracle.ref_render(prg.ptr, rate, True, chunk=chunk)
                 assert max_diff(oracle.oracle_render(prg.ptr, rate, True, chunk=chunk), ref) == 0, (seed, chunk)
-                oracle.oracle().ora_set_fastmath_forms(1)
+                oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
             for block in ((333, 1016, 50000) if seed < 2 else (1016,)):
                 got = sa.Batch([prg], rate, backend=seqexec.seq_backend_create(block)).render(stereo=True, chunk=chunk)[0]
                 assert max_diff(got, want) == 0, (seed, chunk, block)
@@ -377,7 +377,7 @@ def test_random_lattice_programs(sa, oracle, seqexec, rate):
             oracle.oracle().ora_set_fastmath_forms(2)
             assert max_diff(oracle.oracle_render(prg.ptr, rate, stereo, chunk=call),
                             oracle.ref_render(prg.ptr, rate, stereo, chunk=call)) == 0, seed
-        oracle.oracle().ora_set_fastmath_forms(1)
+        oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
         want = oracle.oracle_render(prg.ptr, rate, stereo, chunk=call)
         bt = sa.Batch([prg], rate, backend=seqexec.seq_backend_create(block))
         bt.set_call_len(call)
@@ -430,7 +430,7 @@ def test_amp_operator_through_the_plan(sa, oracle, seqexec):
     plan format, executed sequentially: bit-exact vs the oracle."""
     import test_gpu_units as tu
     from saugns_amd import voicebank as vb
-    oracle.oracle().ora_set_fastmath_forms(1)
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
     for name, voices, ups in tu.amp_operator_cases():
         prg = vb.build_program(voices, updates=ups)
         want = oracle.oracle_render(prg.ptr, 44100, True, chunk=777)
@@ -447,7 +447,7 @@ def test_bank_builder_in_the_c_abi(sa, oracle):
     import test_gpu_units as tu
     from saugns_amd import voicebank as vb
     from saugns_amd.api import OpDesc
-    oracle.oracle().ora_set_fastmath_forms(1)
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
 
     def voices_of(kind):
         if kind == "config3":

@@ -18,17 +18,6 @@ import test_gpu_units as tu
 RATE = 44100
 
 
-@pytest.fixture()
-def tails_on():
-    old = os.environ.get("SAU_AMD_LOOP_TAILS")
-    os.environ["SAU_AMD_LOOP_TAILS"] = "1"
-    yield
-    if old is None:
-        os.environ.pop("SAU_AMD_LOOP_TAILS", None)
-    else:
-        os.environ["SAU_AMD_LOOP_TAILS"] = old
-
-
 def cub_programs():
     """`cub` on every kind of line, under time clipping, with events in mid-sweep, and in R segments."""
     C = lambda v0, g, **kw: vb.Line(v0, goal=g, shape="cub", **kw)
@@ -97,7 +86,7 @@ def test_sequential_executor_reproduces_the_loop_tails(sa, oracle, seqexec, tail
         oracle.oracle().ora_set_fastmath_forms(1)
 
 
-def test_loop_tails_matter_and_can_be_switched_off(sa, oracle, seqexec):
+def test_loop_tails_matter_and_can_be_switched_off(sa, oracle, seqexec, tails_off):
     """The two forms really differ on these programs (else the test above proves nothing), and with the switch off the
     executor gives the loop bodies' forms (mode 1), whatever the call size."""
     n_diff = 0
@@ -108,7 +97,7 @@ def test_loop_tails_matter_and_can_be_switched_off(sa, oracle, seqexec):
         m1 = oracle.oracle_render(prg.ptr, RATE, stereo, chunk=1746)
         n_diff += bool((m1 != m2).any())
         got = sa.Batch([prg], RATE, backend=seqexec.seq_backend_create(1016)).render(stereo=stereo, chunk=1746)[0]
-        assert (got == m1).all(), name  # (SAU_AMD_LOOP_TAILS=0 from conftest.py)
+        assert (got == m1).all(), name  # (SAU_AMD_LOOP_TAILS=0: the tails_off fixture)
     assert n_diff >= 3, n_diff  # (an ulp in a ramp reaches the int16 output only behind enough modulation)
 
 
