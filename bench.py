@@ -91,7 +91,7 @@ def profile_step_traffic(workload):
     return best
 
 
-def cpu_reference(make_prg, what, voices, ops_per_voice, tabs, all_cores=False):
+def cpu_reference(make_prg, what, voices, ops_per_voice, tabs, all_cores=False, budget_s=12.0):
     """The reference's own generator (oracle/_ref, built from its sources by oracle/Makefile) when
     that library is present, else this repo's CPU restatement; a bounded sample of the workload."""
     from oracle import pyoracle as po
@@ -109,13 +109,13 @@ def cpu_reference(make_prg, what, voices, ops_per_voice, tabs, all_cores=False):
 
         def render(frames):
             return po.oracle_render(prg.ptr, 44100, False, max_frames=frames, chunk=11289)
-    frames = 2205  # calibrate (the first call also pays for one-time set-up), then run ~12 s of CPU work
+    frames = 2205  # calibrate (the first call also pays for one-time set-up), then run ~budget_s of CPU work
     render(frames)
     frames = 8820
     t0 = time.perf_counter()
     render(frames)
     dt = time.perf_counter() - t0
-    frames = int(min(44100 * 30, max(frames, frames * 12.0 / max(dt, 1e-3))))
+    frames = int(min(44100 * 30, max(frames, frames * budget_s / max(dt, 1e-3))))
     t0 = time.perf_counter()
     render(frames)
     dt = time.perf_counter() - t0
@@ -241,9 +241,119 @@ class Ranks:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return [int(x) for x in t.tolist()]
 
+    def gather(self, obj):
+        """every rank's `obj`, in rank order, on every rank"""
+        if self.world == 1:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def identity(self, sa, ms_per_step):
+        """Who rendered what: rank, host, the HIP device it used and that device's PCI address, its own ms per step (the
+        line's value uses the slowest rank's clock). With RCCL as the backend two ranks on one board are an error: the
+        scaling figure would be that of a shared GPU."""
+        import socket
+        dev = int(os.environ.get("SAU_AMD_DEVICE", "0"))
+        bus = None if os.environ.get("SAU_BENCH_TEST_BACKEND") else sa.api.device_pci_bus_id(dev)
+        mine = {"rank": self.rank, "host": socket.gethostname(), "device": dev, "pci_bus_id": bus,
+                "ms_per_step": ms_per_step}
+        ranks = self.gather(mine)
+        if self.backend == "nccl" and self.world > 1:
+            seen = {}
+            for r in ranks:
+                key = (r["host"], r["pci_bus_id"])
+                if r["pci_bus_id"] is None or key in seen:
+                    raise SystemExit(f"rank {self.rank}: ranks {seen.get(key)} and {r['rank']} report the same GPU {key}: "
+                                     "one process per GPU is the contract")
+                seen[key] = r["rank"]
+        return ranks
+
     def close(self):
         if self.world > 1:
             self.dist.destroy_process_group()
+
+
+def dropin_rate(sa, args):
+    """Config 3's 10 s through sau_create_Generator / sauGenerator_run as the reference host drives them (saugns.c:589-618:
+    11289-frame calls into a host buffer), creation to the last frame, best of three -- host copies and PCIe included."""
+    import numpy as np
+    from saugns_amd import voicebank
+    prg = voicebank.config3(n=args.voices, seconds=10)
+    buf = np.zeros(11289, np.int16)
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        g = sa.Generator(prg, 44100)
+        n, more = 0, True
+        while more:
+            more, k = g.run(buf, 11289)
+            n += k
+        g.close()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return {"value": n / best, "unit": "mixed mono int16 frames/s", "frames": n, "seconds": best,
+            "what": "sau_create_Generator -> sauGenerator_run in 11289-frame calls into host memory -> sau_destroy_Generator, "
+                    "the script's whole 10 s, best of 3"}
+
+
+def run_bank(args, R, sa, tabs, name, steps=20, warmup=2):
+    """A voice bank rendered like config 3 -- one step = the script's whole 10 s (441000 frames), state and PCM resident in
+    HBM, the first step's SHA-256 checked against the compiled reference's -- for the two workloads the r03 verdict asked onto
+    the driver's line: BASELINE config 2 (256 flat sines) and the carrier-FM bank (config 3 with the carrier's modulator
+    list an FM list: running-sum phases, look-back build)."""
+    import numpy as np
+    from saugns_amd import voicebank
+    index = json.load(open(os.path.join(GOLDEN, "index.json")))
+    frames = 441000
+    spec = {"config2": dict(make=lambda s: voicebank.config2(n=256, seconds=s), voices=256, ops=1,
+                            what="BASELINE config 2: 256 independent Wsin voices, no modulation",
+                            metric="mono samples/sec/GPU @ 256 flat voices", kernel="fast_kernel<8, 0>"),
+            "fm": dict(make=lambda s: voicebank.config3_fm(n=1024, seconds=s), voices=1024, ops=4,
+                       what="carrier-FM bank: 1024 voices x (carrier taking FM from a modulator with a 2-deep PM chain) = 4096 "
+                            "operators (config 3 with f[...] for p[...]; the carrier's phase is a running sum)",
+                       metric="mono samples/sec/GPU @ 1024 voices (carrier FM + depth-2 PM under it)",
+                       kernel="fast_kernel<T, 2> (running sums in one pass, decoupled look-back)")}[name]
+    prg = spec["make"](10 * (steps + warmup + 3) + 2)
+    batch = new_batch(sa, [prg])
+    pcm = batch.run(frames, stereo=False)[0]
+    got, want = sha256(pcm[0]), index["configs"][name]["sha256"]
+    if got != want:
+        raise SystemExit(f"rank {R.rank}: {name}: first step's PCM {got[:16]} is not the reference's {want[:16]}")
+    verified = {"sha256": got, "equals": f"tests/golden/index.json configs.{name}.sha256 (compiled reference)"}
+    for _ in range(warmup):
+        batch.run(frames, stereo=False, fetch=False)
+    R.barrier([batch])
+    batch.timing_ex(reset=True)
+    batch.set_timing(1)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        batch.run(frames, stereo=False, fetch=False)
+    R.barrier([batch])
+    dt = R.max(time.perf_counter() - t0)
+    tm = batch.timing_ex()
+    batch.close()
+    if R.rank != 0:
+        return None
+    n_ops = spec["voices"] * spec["ops"]
+    alg = (n_ops * 8 + 2) * frames
+    launch_s = tm["fast_ms"] / 1e3 / steps  # (every time-parallel launch of a step)
+    achieved = alg / launch_s / 1e9 if launch_s > 0 else 0.0
+    out = {"metric": spec["metric"], "value": frames * steps * R.world / dt, "unit": "mixed mono int16 frames/s",
+           "n_gpus": R.world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32 (f64 table interpolation, u32 phase)", "data": "synthetic",
+           "config": {"workload": spec["what"] + f", 44.1 kHz mono, {frames} frames per step, per GPU", "voices": spec["voices"],
+                      "operators": n_ops, "frames_per_step": frames, "first_step_verified": verified,
+                      "operator_samples_per_s": frames * steps * R.world / dt * n_ops},
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                        "traffic": None, "kernel": spec["kernel"], "kernel_ms_per_step": launch_s * 1e3,
+                        "segments_per_step": tm["segments"] / steps, "algorithmic_bytes_per_step": alg}}
+    tr, src = profile_step_traffic(name)
+    out["roofline"]["traffic"], out["roofline"]["traffic_source"] = tr, src
+    if not args.no_cpu and R.world == 1:
+        out["cpu_baseline"] = cpu_reference(lambda: spec["make"](30), spec["what"].split(":")[0], spec["voices"], spec["ops"],
+                                            tabs, budget_s=5.0)
+    return out
 
 
 def run_config3(args, R, sa, tabs):
@@ -271,8 +381,10 @@ def run_config3(args, R, sa, tabs):
     for _ in range(args.steps):
         batch.run(args.frames, stereo=False, fetch=False)
     R.barrier([batch])
-    dt = R.max(time.perf_counter() - t0)
+    dt_mine = time.perf_counter() - t0
+    dt = R.max(dt_mine)
     tm = batch.timing_ex()
+    ranks = R.identity(sa, dt_mine / args.steps * 1e3)
     frames_total = args.frames * args.steps * R.world
     # The same step a thousand times over, a few seconds of nothing but these kernels: what the timed K steps give
     # when the device stays busy (clocks, thermals), and long enough for a sampled GPU-utilisation reading to see it.
@@ -295,6 +407,7 @@ def run_config3(args, R, sa, tabs):
     tally = R.sum(mine)
     if tally[0] != frames_total or tally[1] != mine[1] * R.world:
         raise SystemExit(f"rank {R.rank}: ranks disagree on the rendered PCM ({tally} vs {mine} x {R.world})")
+    dropin = dropin_rate(sa, args) if R.world == 1 and not test_backend() and not args.no_dropin else None
     if R.rank != 0:
         return None
     n_ops = args.voices * 4
@@ -317,6 +430,9 @@ def run_config3(args, R, sa, tabs):
                    "voices": args.voices, "operators": n_ops, "frames_per_step": args.frames,
                    "frames_all_ranks": tally[0], "pcm_checksum_all_ranks": tally[1],
                    "first_step_verified": verified, "sustained": sustained,
+                   # the PCIe-inclusive rate through the drop-in API (never `value`): sauGenerator_run with the reference
+                   # host's 11289-frame calls, PCM copied into the caller's buffer every call
+                   "dropin_value": dropin,
                    "voice_samples_per_s": frames_total / dt * args.voices,
                    "operator_samples_per_s": frames_total / dt * n_ops},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
@@ -326,6 +442,7 @@ def run_config3(args, R, sa, tabs):
                      "valu": valu,
                      "kernel": "fast_kernel<8, 0>", "avg_launch_ms": launch_s * 1e3,
                      "launches": tm["segments"], "algorithmic_bytes_per_launch": alg_bytes},
+        "ranks": ranks,
     }
     if not args.no_cpu and R.world == 1:
         out["cpu_baseline"] = cpu_reference(lambda: voicebank.config3(n=args.voices, seconds=30),
@@ -592,7 +709,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", choices=["config3", "config4", "config5"], default="config3")
+    ap.add_argument("--workload", choices=["config3", "config4", "config5", "config2", "fm"], default="config3")
     ap.add_argument("--frames", type=int, default=441000, help="config3: frames per step")
     ap.add_argument("--voices", type=int, default=1024, help="config3: voices")
     ap.add_argument("--renders", type=int, default=64, help="config4: renders per GPU")
@@ -602,11 +719,13 @@ def main():
     ap.add_argument("--sustain", type=int, default=1000, help="config3: steps of the sustained run after the timed region "
                     "(reported under `sustained`, never `value`; 0: none)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true", help="config3: skip the drop-in API's PCIe-inclusive rate")
     ap.add_argument("--no-others", action="store_true", help="config3: no short config 5 / config 4 runs after it")
+    ap.add_argument("--force-others", action="store_true", help="tests: the other workloads also beside a reduced config 3")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args.gpus)  # before anything touches the GPU
-    defaults = {"config3": (100, 3), "config4": (5, 1), "config5": (5, 1)}[args.workload]
+    defaults = {"config3": (100, 3), "config4": (5, 1), "config5": (5, 1), "config2": (20, 2), "fm": (20, 2)}[args.workload]
     if args.steps is None:
         args.steps = defaults[0]
     if args.warmup is None:
@@ -619,21 +738,40 @@ def main():
     import saugns_amd as sa
     tabs = np.fromfile(os.path.join(GOLDEN, "piluts_ref.f32"), dtype="<f4").reshape(12, 2048)
     sa.set_piluts(tabs)
-    out = {"config3": run_config3, "config4": run_config4, "config5": run_config5}[args.workload](args, R, sa, tabs)
+    if args.workload in ("config2", "fm"):
+        out = run_bank(args, R, sa, tabs, args.workload, steps=args.steps, warmup=args.warmup)
+    else:
+        out = {"config3": run_config3, "config4": run_config4, "config5": run_config5}[args.workload](args, R, sa, tabs)
     others = {}
-    if args.workload == "config3" and not args.no_others and args.voices == 1024 and args.frames == 441000:
+    if args.workload == "config3" and not args.no_others and ((args.voices == 1024 and args.frames == 441000) or args.force_others):
         # the other two BASELINE workloads, every rank alike (their barriers are collective), short runs
         for name, fn in (("config5", run_config5), ("config4", run_config4)):
+            if name == "config5" and test_backend():
+                continue  # (4096 feedback voices on the CPU plan executor of the rank-logic tests: minutes)
             o = fn(args, R, sa, tabs, steps=3, warmup=1)
             if o is not None:
                 o["roofline"]["kernel_source_sha"] = kernel_source_hash()
                 others[name] = o
+        if not test_backend():  # (the CPU plan executor of the rank-logic tests would take minutes over these)
+            for name in ("fm", "config2"):
+                o = run_bank(args, R, sa, tabs, name, steps=10, warmup=2)
+                if o is not None:
+                    o["roofline"]["kernel_source_sha"] = kernel_source_hash()
+                    others[name] = o
     if out is not None:
         out["roofline"]["kernel_source_sha"] = kernel_source_hash()
         if os.environ.get("SAU_BENCH_TEST_BACKEND"):
             out["data"] = "TEST BACKEND (CPU plan executor of tests/seqexec): rank logic only, not a measurement"
         if others:
             out["other_workloads"] = others
+            if R.world > 1 and "config4" in others:
+                # the north star's multi-GPU case at the top of an N > 1 line: 64 renders of rainy_thunder.sau per GPU,
+                # seeds shard_range(64 N, rank, N), no data-path collective (the full record stays under other_workloads)
+                c4 = others["config4"]
+                out["config4_sharded"] = {k: c4[k] for k in ("metric", "value", "unit", "n_gpus", "ms_per_step", "scaling")}
+                out["config4_sharded"].update(renders_all_ranks=c4["config"]["renders_all_ranks"],
+                                              frames_all_ranks=c4["config"]["frames_all_ranks"],
+                                              verified=c4["config"]["verified"])
         print(json.dumps(out))
     R.close()
 

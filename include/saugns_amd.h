@@ -103,6 +103,9 @@ SAU_AMD_API const char *sauAmd_last_error(void);
 
 /* Number of visible HIP devices; <= 0 when none or HIP is unusable. */
 SAU_AMD_API int sauAmd_device_count(void);
+/* PCI address ("0000:c1:00.0") of HIP device `device` into buf (len >= 16); false when there is no such device. One
+ * process per GPU (SAU_AMD_DEVICE selects it): a multi-rank job can show that its ranks sit on distinct boards. */
+SAU_AMD_API bool sauAmd_device_pci_bus_id(int device, char *buf, size_t len);
 
 /* Program image: every struct of a sauProgram in one relocatable block.
  * serialize returns the size needed; nothing is written if cap is smaller. */

@@ -137,6 +137,8 @@ def lib():
     L.sauAmd_get_piluts.restype = C.POINTER(C.c_float)
     L.sauAmd_last_error.restype = C.c_char_p
     L.sauAmd_device_count.restype = C.c_int
+    L.sauAmd_device_pci_bus_id.restype = C.c_bool
+    L.sauAmd_device_pci_bus_id.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
     L.sauAmd_program_serialize.restype = C.c_size_t
     L.sauAmd_program_serialize.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.sauAmd_program_load.restype = C.c_void_p
@@ -151,6 +153,12 @@ def lib():
 
 def last_error():
     return lib().sauAmd_last_error().decode()
+
+
+def device_pci_bus_id(device=0):
+    """PCI address of HIP device `device` ("0000:c1:00.0"), or None without one."""
+    buf = C.create_string_buffer(64)
+    return buf.value.decode() if lib().sauAmd_device_pci_bus_id(int(device), buf, 64) else None
 
 
 def set_piluts(tables):

@@ -324,6 +324,9 @@ extern "C" const float *sauAmd_get_piluts(void) { return sauengine::builtin_pilu
 extern "C" const char *sauAmd_last_error(void) { return g_last_error.c_str(); }
 
 extern "C" int sauAmd_device_count(void) { return sauhip::device_count(); }
+extern "C" bool sauAmd_device_pci_bus_id(int device, char *buf, size_t len) {
+	return sauhip::device_pci_bus_id(device, buf, (int)(len > 255 ? 255 : len));
+}
 
 /* Test probes (not in the public header): the shared line arithmetic as
  * compiled for the device and for the host. state = {v0, vt, pos, end, type,

@@ -23,6 +23,11 @@ static uint64_t ms_to_samples(uint64_t ms, uint64_t srate, int *carry) {
 
 Engine::~Engine() { delete backend_; }
 
+const char *tune_env(const char *name) {
+	static const bool on = getenv("SAU_AMD_TUNE") != nullptr;
+	return on ? getenv(name) : nullptr;
+}
+
 size_t chain_rows_budget() {
 	static const size_t b = [] {
 		const char *v = getenv("SAU_AMD_CHAIN_ROWS_MB");
@@ -72,8 +77,8 @@ Engine *Engine::create(const sauProgram *const *prgs, size_t n_prgs, uint32_t sr
 	e->total_voices_ = vo_base;
 	/* the reference build's loop tails (`cub` lines: sau_dev_math.h, TailCtx); SAU_AMD_LOOP_TAILS=0: the loop bodies' forms everywhere */
 	if (const char *lt = getenv("SAU_AMD_LOOP_TAILS")) e->loop_tails_ = atoi(lt) != 0;
-	e->plan_cache_ = getenv("SAU_AMD_NO_PLAN_CACHE") == nullptr;
-	e->plan_check_ = getenv("SAU_AMD_PLAN_CHECK") != nullptr; /* tests: every cached plan against a fresh compile */
+	e->plan_cache_ = tune_env("SAU_AMD_NO_PLAN_CACHE") == nullptr;
+	e->plan_check_ = tune_env("SAU_AMD_PLAN_CHECK") != nullptr; /* tests: every cached plan against a fresh compile */
 	e->plan_refs_.resize(vo_base);
 	BackendConfig cfg;
 	cfg.srate = srate;

@@ -157,6 +157,11 @@ constexpr uint32_t CHAIN_SEG = 131072;
  * 288 GB of HBM hold BASELINE config 5's 4096 chains x 441000 frames (14.4 GB) as one segment, and a segment is one
  * fill and one drain of the pass / chain pipeline. SAU_AMD_CHAIN_ROWS_MB sets another budget. */
 size_t chain_rows_budget();
+/* Environment switches. Product settings are read as they are (INTEGRATION.md has the table: SAU_AMD_DEVICE,
+ * SAU_AMD_READAHEAD*, SAU_AMD_LOOP_TAILS, SAU_AMD_CHAIN_ROWS_MB, SAU_AMD_POOL_MB, SAU_AMD_PINNED_POOL_MB, SAU_AMD_DEBUG*);
+ * every other SAU_AMD_* name is a tuning or test aid and is looked at only when SAU_AMD_TUNE is set -- a stray variable
+ * in a host's environment cannot change how, or on which kernels, a render runs. */
+const char *tune_env(const char *name);
 uint32_t chain_seg_frames(size_t n_chains);
 
 class Engine {

@@ -47,6 +47,7 @@ namespace sauhip {
 
 using namespace saudev;
 using sauengine::BackendConfig;
+using sauengine::tune_env;
 using sauengine::SegmentDesc;
 
 /* ------------------------------------------------------------------------ */
@@ -277,6 +278,12 @@ int device_count() {
 	return n;
 }
 
+bool device_pci_bus_id(int dev, char *buf, int len) {
+	if (!buf || len < 16) return false;
+	buf[0] = 0;
+	return hipDeviceGetPCIBusId(buf, len, dev) == hipSuccess;
+}
+
 class HipBackendImpl : public HipBackend {
 public:
 	/* every entry point runs on this backend's device, whatever the host thread's current one is
@@ -325,44 +332,45 @@ public:
 			 * workgroups' sums (spread look-back launches) need the whole grid resident, so the grid follows the CUs
 			 * this device really has (a partitioned or CU-masked device has fewer than 256) */
 			fk_grid_ = dev_cus[dev & 15] < FK_GRID ? dev_cus[dev & 15] : FK_GRID;
-			if (const char *fg = getenv("SAU_AMD_FK_GRID")) { const int n = atoi(fg); if (n >= 1 && n <= (int)FK_GRID) fk_grid_ = (uint32_t)n; }
+			if (const char *fg = tune_env("SAU_AMD_FK_GRID")) { const int n = atoi(fg); if (n >= 1 && n <= (int)FK_GRID) fk_grid_ = (uint32_t)n; }
 		}
 		if (lds_limit_ > 160 * 1024) lds_limit_ = 160 * 1024;
-		if (const char *ll = getenv("SAU_AMD_LDS_LIMIT")) lds_limit_ = (size_t)atol(ll);
-		const char *wt = getenv("SAU_AMD_GEOMETRY"); /* "4x4" (default) or "8x2" */
+		if (const char *ll = tune_env("SAU_AMD_LDS_LIMIT")) lds_limit_ = (size_t)atol(ll);
+		const char *wt = tune_env("SAU_AMD_GEOMETRY"); /* "4x4" (default) or "8x2" */
 		geo_ = (wt && !strcmp(wt, "8x2")) ? 0 : 1; /* default 4 waves x 4 samples per lane */
 		debug_ = getenv("SAU_AMD_DEBUG") != nullptr;
-		fast_enabled_ = getenv("SAU_AMD_NO_FAST") == nullptr;
-		seq_enabled_ = getenv("SAU_AMD_NO_SEQ") == nullptr; /* running-sum phases in the time-parallel kernel */
-		chain_enabled_ = getenv("SAU_AMD_NO_CHAIN") == nullptr; /* feedback recurrences with lanes = voices */
-		chain_inline_ = getenv("SAU_AMD_CHAIN_INLINE") != nullptr;
-		chain_early_ = getenv("SAU_AMD_NO_EARLY_CHAINS") == nullptr;
-		inc_rows_enabled_ = getenv("SAU_AMD_NO_INC_ROWS") == nullptr;
-		lookback_enabled_ = getenv("SAU_AMD_NO_LOOKBACK") == nullptr; /* single-pass running sums */
-		if (const char *lr = getenv("SAU_AMD_LOOK_ROWS")) look_rows_ = (uint32_t)atoi(lr);
-		if (const char *lm = getenv("SAU_AMD_LOOK_MIN_VOICES")) look_min_voices_ = (uint32_t)atoi(lm);
-		if (const char *cc = getenv("SAU_AMD_CHAIN_CHUNKS")) { /* pipeline depth of a segment with chains (1: off; default: by frames) */
+		fast_enabled_ = tune_env("SAU_AMD_NO_FAST") == nullptr;
+		seq_enabled_ = tune_env("SAU_AMD_NO_SEQ") == nullptr; /* running-sum phases in the time-parallel kernel */
+		chain_enabled_ = tune_env("SAU_AMD_NO_CHAIN") == nullptr; /* feedback recurrences with lanes = voices */
+		chain_inline_ = tune_env("SAU_AMD_CHAIN_INLINE") != nullptr;
+		chain_early_ = tune_env("SAU_AMD_NO_EARLY_CHAINS") == nullptr;
+		inc_rows_enabled_ = tune_env("SAU_AMD_NO_INC_ROWS") == nullptr;
+		lookback_enabled_ = tune_env("SAU_AMD_NO_LOOKBACK") == nullptr; /* single-pass running sums */
+		if (const char *lr = tune_env("SAU_AMD_LOOK_ROWS")) look_rows_ = (uint32_t)atoi(lr);
+		if (const char *lm = tune_env("SAU_AMD_LOOK_MIN_VOICES")) look_min_voices_ = (uint32_t)atoi(lm);
+		if (const char *cc = tune_env("SAU_AMD_CHAIN_CHUNKS")) { /* pipeline depth of a segment with chains (1: off; default: by frames) */
 			const int n = atoi(cc);
 			chain_chunks_ = n >= 32 ? 32 : n >= 1 ? (uint32_t)n : 1;
 		}
-		if (const char *cf = getenv("SAU_AMD_CHAIN_CHUNK_FRAMES")) { const int n = atoi(cf); if (n >= 4096) chain_chunk_frames_ = (uint32_t)n; }
-		two_pass_enabled_ = getenv("SAU_AMD_NO_TWO_PASS") == nullptr; /* ... in two passes where possible */
-		if (const char *lr = getenv("SAU_AMD_LEAN_ROWS")) lean_rows_ = (uint32_t)atoi(lr);
-		overlap_enabled_ = getenv("SAU_AMD_MIX_OVERLAP") != nullptr && atoi(getenv("SAU_AMD_MIX_OVERLAP")) != 0;
-		if (const char *mc = getenv("SAU_AMD_MIX_CUS")) { const int n = atoi(mc); mix_cus_ = n >= 0 && n < 128 ? (uint32_t)n : 16u; }
-		if (const char *om = getenv("SAU_AMD_MIX_OVERLAP_MIN")) overlap_min_ = (size_t)atoll(om);
-		mix_few_enabled_ = getenv("SAU_AMD_NO_MIX_FEW") == nullptr;
-		lean_enabled_ = getenv("SAU_AMD_NO_LEAN") == nullptr; /* chains' passes in a build without the several-pass sums */
-		dyn_enabled_ = getenv("SAU_AMD_NO_DYN") == nullptr; /* closed-form launches deal tasks out through a counter */
-		if (const char *dg = getenv("SAU_AMD_DYN_GROUPS")) { const int n = atoi(dg); dyn_groups_ = n >= 1 ? (uint32_t)n : 1u; }
+		if (const char *cf = tune_env("SAU_AMD_CHAIN_CHUNK_FRAMES")) { const int n = atoi(cf); if (n >= 4096) chain_chunk_frames_ = (uint32_t)n; }
+		two_pass_enabled_ = tune_env("SAU_AMD_NO_TWO_PASS") == nullptr; /* ... in two passes where possible */
+		if (const char *lr = tune_env("SAU_AMD_LEAN_ROWS")) lean_rows_ = (uint32_t)atoi(lr);
+		overlap_enabled_ = tune_env("SAU_AMD_MIX_OVERLAP") != nullptr && atoi(tune_env("SAU_AMD_MIX_OVERLAP")) != 0;
+		if (const char *mc = tune_env("SAU_AMD_MIX_CUS")) { const int n = atoi(mc); mix_cus_ = n >= 0 && n < 128 ? (uint32_t)n : 16u; }
+		if (const char *om = tune_env("SAU_AMD_MIX_OVERLAP_MIN")) overlap_min_ = (size_t)atoll(om);
+		mix_few_enabled_ = tune_env("SAU_AMD_NO_MIX_FEW") == nullptr;
+		lean_enabled_ = tune_env("SAU_AMD_NO_LEAN") == nullptr; /* chains' passes in a build without the several-pass sums */
+		dyn_enabled_ = tune_env("SAU_AMD_NO_DYN") == nullptr; /* closed-form launches deal tasks out through a counter */
+		wide_tabs_ = tune_env("SAU_AMD_NO_WIDE_TABS") == nullptr; /* closed-form launches with f64 [c1, c0] table entries in LDS */
+		if (const char *dg = tune_env("SAU_AMD_DYN_GROUPS")) { const int n = atoi(dg); dyn_groups_ = n >= 1 ? (uint32_t)n : 1u; }
 		/* voices per segment from which feedback voices get sixteen one-wave teams per workgroup
 		 * (0: never; 1: always, also without feedback -- tests) */
 		multi_min_ = 256;
-		if (const char *fr = getenv("SAU_AMD_FAST_ROWS")) { /* 8 (default), 4 or 2 */
+		if (const char *fr = tune_env("SAU_AMD_FAST_ROWS")) { /* 8 (default), 4 or 2 */
 			const int r = atoi(fr);
 			fast_rows_ = r >= 8 ? 8 : r >= 6 ? 6 : r >= 5 ? 5 : r >= 4 ? 4 : 2;
 		}
-		if (const char *mm = getenv("SAU_AMD_MULTI_MIN")) multi_min_ = (uint32_t)atol(mm);
+		if (const char *mm = tune_env("SAU_AMD_MULTI_MIN")) multi_min_ = (uint32_t)atol(mm);
 		if (!ops_.ensure(cfg.op_count ? cfg.op_count : 1, err)) return false;
 		HIP_OK(hipMemsetAsync(ops_.p, 0, ops_.cap * sizeof(DevOp), stream_));
 		tables_ = shared_tables(cfg.piluts, cfg.wconst, err);
@@ -491,6 +499,8 @@ public:
 		if (!seg.n_voices) return true;
 		++acc_launches_; /* segments rendered */
 		const size_t tab_bytes = (size_t)WAVE_LEN * (sizeof(HerpC23) + sizeof(HerpC01));
+		/* (the time-parallel kernels keep their LDS copy of a table in another form: FAST_TAB_BYTES, k_fast_types.h) */
+		const size_t ftab_bytes = FAST_TAB_BYTES;
 		/* Block-loop geometry. Few voices: W waves share one voice (4x4 or 8x2
 		 * frames per lane). Many voices: sixteen single-wave teams per workgroup,
 		 * each with its own voice, so that every CU has 16 voices in flight. */
@@ -616,12 +626,12 @@ public:
 			auto area_of = [&](uint32_t t) {
 				return (size_t)n_fast * 64 * t * sizeof(float) + (size_t)fmax_steps * sizeof(unsigned long long);
 			};
-			const size_t one_tab = seg.wave_mask ? tab_bytes : 0;
+			const size_t one_tab = seg.wave_mask ? ftab_bytes : 0;
 			const size_t look_lds = look_split ? LOOK_LDS_BYTES : 0;
 			while (FT > 2 && 16 * area_of(FT) + one_tab + look_lds + 1024 > lds_limit_) FT = fewer(FT);
 			{ /* every wave table the segment uses in LDS is worth more than rows per pass (an oscillator whose table
 			   * is left out reads it from L2 per sample): fewer rows where that makes them all fit */
-				const size_t need = (size_t)__builtin_popcount(seg.wave_mask) * tab_bytes + look_lds + 1024;
+				const size_t need = (size_t)__builtin_popcount(seg.wave_mask) * ftab_bytes + look_lds + 1024;
 				uint32_t t = FT;
 				while (t > 4 && 16 * area_of(t) + need > lds_limit_) t = fewer(t); /* (but not below 4 rows: that costs more) */
 				if (16 * area_of(t) + need <= lds_limit_) FT = t;
@@ -662,7 +672,7 @@ public:
 					if (wpv > 64) wpv = 64;
 					if (wpv > groups) wpv = groups;
 					if (wpv < 1) wpv = 1;
-					const bool no_lds = getenv("SAU_AMD_LOOK_NO_LDS") != nullptr;
+					const bool no_lds = tune_env("SAU_AMD_LOOK_NO_LDS") != nullptr;
 					auto is_inside = [&](unsigned long long w) { return w <= 16 && (16 % w) == 0 && !no_lds; };
 					const size_t look_words = (size_t)seg.n_look_rows * 2 * fp.scan_groups;
 					/* the words exist whenever they fit 1 GiB: the kernel then picks the waves per voice from the number of
@@ -695,7 +705,7 @@ public:
 			fp.sum_levels = seg.sum_levels >= FAST_MAX_LEVELS ? FAST_MAX_LEVELS : 2u;
 			if (!repair_.ensure((size_t)seg.n_voices * FAST_REPAIR_WORDS, err)) return false;
 			fp.repair = repair_.p;
-			fp.repair_on = getenv("SAU_AMD_NO_REPAIR") ? 0u : 1u;
+			fp.repair_on = tune_env("SAU_AMD_NO_REPAIR") ? 0u : 1u;
 			fp.max_ops = seg.max_ops; fp.max_steps = fmax_steps; fp.np = 64; fp.rows = FT; fp.rows_multi = FTM;
 			fp.enable = use_fast ? 1u : 0u;
 			/* saved phase increments of running-sum oscillators (sum pass -> final pass), one segment long */
@@ -736,7 +746,7 @@ public:
 			for (int wv = 0; wv < 12; ++wv) {
 				fp.tab_of_wave[wv] = -1;
 				if (use_fast && ((seg.wave_mask >> wv) & 1) &&
-				    16 * area + look_lds + (ft + 1) * tab_bytes + 1024 <= lds_limit_) {
+				    16 * area + look_lds + (ft + 1) * ftab_bytes + 1024 <= lds_limit_) {
 					fp.tab_of_wave[wv] = (int8_t)ft;
 					fp.wave_of_tab[ft] = (uint8_t)wv;
 					++ft;
@@ -749,52 +759,74 @@ public:
 			auto area_cf = [&](uint32_t t) { return (size_t)seg.n_fast * 64 * t * sizeof(float) + (size_t)fmax_steps * sizeof(unsigned long long); };
 			if (split_cf) {
 				for (uint32_t t : {8u, 6u, 5u, 4u})
-					if (t <= fast_rows_ && ft * tab_bytes + 16 * area_cf(t) + 1024 <= lds_limit_) { rows_cf = t; break; }
+					if (t <= fast_rows_ && ft * ftab_bytes + 16 * area_cf(t) + 1024 <= lds_limit_) { rows_cf = t; break; }
 				if (!vlists_.ensure((size_t)2 * seg.n_voices, err)) return false;
 				fp.vlists = vlists_.p; fp.split_cf = 1; fp.rows_cf = rows_cf;
 				fp.look_words_real = look_words_real_ && fp.look ? 1u : 0u;
 			}
-			fp.cub_ok = use_fast && seg.maybe_cub && ft * tab_bytes + 16 * area_cf(FAST_CUB_ROWS) + 1024 <= lds_limit_ &&
-				(!look_split || ft * tab_bytes + 16 * area_of(FAST_CUB_ROWS) + LOOK_LDS_BYTES + 1024 <= lds_limit_) ? 1u : 0u;
+			fp.cub_ok = use_fast && seg.maybe_cub && ft * ftab_bytes + 16 * area_cf(FAST_CUB_ROWS) + 1024 <= lds_limit_ &&
+				(!look_split || ft * ftab_bytes + 16 * area_of(FAST_CUB_ROWS) + LOOK_LDS_BYTES + 1024 <= lds_limit_) ? 1u : 0u;
 			/* the build for voices with chains and nothing to scan: as many rows per pass as fit beside the tables */
 			fp.lean_on = chains && lean_enabled_ ? 1u : 0u;
 			fp.rows_lean = 4;
-			for (uint32_t t : {8u, 6u, 5u})
-				if (t <= fast_rows_ && t <= lean_rows_ && ft * tab_bytes + 16 * area_of(t) + 1024 <= lds_limit_) { fp.rows_lean = t; break; }
-			if (ft * tab_bytes + 16 * area_of(fp.rows_lean) + 1024 > lds_limit_) fp.lean_on = 0; /* (a tight LDS budget: the full build's rows) */
+			for (uint32_t t : {6u, 5u}) /* (decode_kernel lays the slots out for exactly the rows the build has: 4, 5 or 6) */
+				if (t <= fast_rows_ && t <= lean_rows_ && ft * ftab_bytes + 16 * area_of(t) + 1024 <= lds_limit_) { fp.rows_lean = t; break; }
+			if (ft * ftab_bytes + 16 * area_of(fp.rows_lean) + 1024 > lds_limit_) fp.lean_on = 0; /* (a tight LDS budget: the full build's rows) */
 			TimedPair *ta = timing_on_ ? new_pair(3) : nullptr;
 			if (ta) (void)hipEventRecord(ta->a, stream_);
 			{
 				/* a thread per voice, a chain of dependent loads each: few voices per wave shorten it a little (their
 				 * loads diverge; measured per launch, 1024 FM voices / config 4 / config 3: 64 per wave 34 us, 16: 30, 4: 28.5) */
-				static const uint32_t lanes = getenv("SAU_AMD_ANALYZE_LANES") ? (uint32_t)atoi(getenv("SAU_AMD_ANALYZE_LANES")) : 4u;
+				static const uint32_t lanes = tune_env("SAU_AMD_ANALYZE_LANES") ? (uint32_t)atoi(tune_env("SAU_AMD_ANALYZE_LANES")) : 4u;
 				const uint32_t al = lanes >= 1 && lanes <= 64 ? lanes : 4u;
 				hipLaunchKernelGGL(analyze_kernel, dim3((seg.n_voices + al - 1) / al), dim3(al), 0, stream_, fp);
 			}
 			if (ta) (void)hipEventRecord(ta->b, stream_);
 			if (use_fast) {
 				hipLaunchKernelGGL(decode_kernel, dim3(seg.n_voices), dim3(64), 0, stream_, fp);
-				const size_t flds = ft * tab_bytes + 16 * area;
 				/* build 0: closed-form phases only; 1: every kind of running-sum voice; 2: single-pass voices and closed-form ones */
 				const int main_build = !seq_ok ? 0 : look_split ? 2 : 1;
 				/* (rows per pass 2, 4, 5, 6, 8; the full build never runs at more than 4: its 5- and 6-row slots stand in with 4's) */
 				static const void *const fkernels[4][5] = {
 					{(const void *)fast_kernel<2, 0>, (const void *)fast_kernel<4, 0>, (const void *)fast_kernel<5, 0>, (const void *)fast_kernel<6, 0>, (const void *)fast_kernel<8, 0>},
-					{(const void *)fast_kernel<2, 1>, (const void *)fast_kernel<4, 1>, (const void *)fast_kernel<4, 1>, (const void *)fast_kernel<4, 1>, (const void *)fast_kernel<8, 1>},
+					{(const void *)fast_kernel<2, 1>, (const void *)fast_kernel<4, 1>, (const void *)fast_kernel<4, 1>, (const void *)fast_kernel<4, 1>, (const void *)fast_kernel<4, 1>},
 					{(const void *)fast_kernel<2, 2>, (const void *)fast_kernel<4, 2>, (const void *)fast_kernel<5, 2>, (const void *)fast_kernel<6, 2>, (const void *)fast_kernel<8, 2>},
-					/* 3: voices with feedback chains and nothing to scan (4, 6 or 8 rows per pass) */
-					{(const void *)fast_kernel<4, 3>, (const void *)fast_kernel<4, 3>, (const void *)fast_kernel<5, 3>, (const void *)fast_kernel<6, 3>, (const void *)fast_kernel<8, 3>}};
+					/* 3: voices with feedback chains and nothing to scan (4, 5 or 6 rows per pass; 6 spills 170 VGPRs and is still the
+					 * fastest on config 5 -- 52.3 against 53.1 ms per step at 5; the 8-row instantiation, 298 spilled, is gone since
+					 * round 4, like the full build's 8-row one) */
+					{(const void *)fast_kernel<4, 3>, (const void *)fast_kernel<4, 3>, (const void *)fast_kernel<5, 3>, (const void *)fast_kernel<6, 3>, (const void *)fast_kernel<6, 3>}};
 				static size_t fconfigured[16][4][5];
-				auto launch_build = [&](int build, uint32_t rows, uint32_t grid, const FastParams *prm = nullptr, size_t area16 = 0) -> bool {
-					if (build == 1 && (rows == 6 || rows == 5)) rows = 4;
-					if (build == 3 && rows < 5) rows = 4;
+				/* the closed-form build with wide table blocks in LDS (k_fast_types.h: FkTab), at 6 and 8 rows per pass: taken when
+				 * every table the segment wants is in LDS and still fits in that form at the launch's rows */
+				static const void *const fk_wide[2] = {(const void *)fast_kernel<6, 0, false, true>, (const void *)fast_kernel<8, 0, false, true>};
+				static size_t wconfigured[16][2];
+				const uint32_t n_want = (uint32_t)__builtin_popcount(seg.wave_mask);
+				auto wide_fits = [&](uint32_t rows, size_t area16) {
+					/* (voices of one step -- flat banks, BASELINE config 2 -- have no modulation to evaluate: fewer VALU
+					 * instructions per sample to begin with, and the wider gather costs them 3-4 %) */
+					return wide_tabs_ && (rows == 8 || rows == 6) && ft > 0 && ft == n_want && seg.max_steps >= 2 &&
+						ft * (size_t)FAST_TAB_BYTES_WIDE + area16 + 1024 <= lds_limit_;
+				};
+				auto launch_build = [&](int build, uint32_t rows, uint32_t grid, const FastParams *prm = nullptr, size_t area16 = 0,
+						bool wide = false) -> bool {
+					if (build == 1 && rows > 4) rows = 4;
+					if (build == 3) rows = rows < 5 ? 4 : rows > 6 ? 6 : rows;
 					const int ri = rows == 8 ? 4 : rows == 6 ? 3 : rows == 5 ? 2 : rows == 4 ? 1 : 0;
-					const size_t lds = ft * tab_bytes + (area16 ? area16 : 16 * area_of(rows)) + (build == 2 ? LOOK_LDS_BYTES : 0);
-					if (!raise_lds_attr(fkernels[build][ri], lds, fconfigured[dev_ & 15][build][ri], err)) return false;
+					const size_t a16 = area16 ? area16 : 16 * area_of(rows);
 					void *args[] = {(void *)(prm ? prm : &fp)};
+					if (wide && build == 0 && (rows == 8 || rows == 6)) {
+						const size_t lds = ft * (size_t)FAST_TAB_BYTES_WIDE + a16;
+						if (!raise_lds_attr(fk_wide[rows == 8], lds, wconfigured[dev_ & 15][rows == 8], err)) return false;
+						HIP_OK(hipLaunchKernel(fk_wide[rows == 8], dim3(grid), dim3(1024), args, lds, stream_));
+						return true;
+					}
+					const size_t lds = ft * ftab_bytes + a16 + (build == 2 ? LOOK_LDS_BYTES : 0);
+					if (!raise_lds_attr(fkernels[build][ri], lds, fconfigured[dev_ & 15][build][ri], err)) return false;
 					HIP_OK(hipLaunchKernel(fkernels[build][ri], dim3(grid), dim3(1024), args, lds, stream_));
 					return true;
 				};
+				/* (which form the closed-form launch of this segment takes -- repair_kernel runs in the same layout) */
+				const bool wide_cf = main_build == 2 ? wide_fits(rows_cf, 16 * area_cf(rows_cf)) : main_build == 0 && wide_fits(FT, 16 * area);
 				/* as many waves per voice as it has row groups (up to 64) when voices are
 				 * few, one CU-filling grid at most */
 				const uint32_t groups = (seg.len + (60 * FT) - 1) / (60 * FT);
@@ -814,7 +846,7 @@ public:
 						fp.only_multi = 1;
 						if (!launch_build(1, FTM, grid ? grid : fgrid)) launched = false;
 						fp.only_multi = 0;
-					} else if (!launch_build(main_build, FT, grid ? grid : fgrid)) {
+					} else if (!launch_build(main_build, FT, grid ? grid : fgrid, nullptr, 0, wide_cf)) {
 						launched = false;
 					}
 				};
@@ -849,9 +881,9 @@ public:
 					const unsigned long long want_cf = (unsigned long long)seg.n_voices * (groups_cf < 64 ? groups_cf : 64);
 					const uint32_t grid_cf = (uint32_t)((want_cf + 15) / 16 > fk_grid_ ? fk_grid_ : (want_cf + 15) / 16);
 					set_tasks(cfp, groups_cf, grid_cf ? grid_cf : 1);
-					if (!launch_build(0, rows_cf, grid_cf ? grid_cf : 1, &cfp, 16 * area_cf(rows_cf))) launched = false;
+					if (!launch_build(0, rows_cf, grid_cf ? grid_cf : 1, &cfp, 16 * area_cf(rows_cf), wide_cf)) launched = false;
 					fp.mode = fp.sum_levels + 1; fp.only_multi = 0; fp.look_wpv = look_wpv_; fp.look_groups = groups;
-					fp.look_wpv_flags = (getenv("SAU_AMD_LOOK_NO_LDS") ? 1u : 0u) | (getenv("SAU_AMD_LOOK_WITHHOLD") ? 2u : 0u);
+					fp.look_wpv_flags = (tune_env("SAU_AMD_LOOK_NO_LDS") ? 1u : 0u) | (tune_env("SAU_AMD_LOOK_WITHHOLD") ? 2u : 0u);
 					if (fp.look) {
 						const unsigned long long waves = (unsigned long long)seg.n_voices * (fp.look_words_real ? (groups < 64 ? groups : 64) : look_wpv_);
 						const uint32_t grid2 = waves > (unsigned long long)fk_grid_ * 16 ? fk_grid_ : (uint32_t)((waves + 15) / 16);
@@ -863,7 +895,7 @@ public:
 						if (fp.cub_ok) { /* look-back voices with the loop tails of `cub` R segments: the build with that code, same lists */
 							static size_t cub2_configured[16];
 							const void *ck2 = (const void *)fast_kernel<(int)FAST_CUB_ROWS, 2, true>;
-							const size_t lds2 = ft * tab_bytes + 16 * area_of(FAST_CUB_ROWS) + LOOK_LDS_BYTES;
+							const size_t lds2 = ft * ftab_bytes + 16 * area_of(FAST_CUB_ROWS) + LOOK_LDS_BYTES;
 							if (!raise_lds_attr(ck2, lds2, cub2_configured[dev_ & 15], err)) return false;
 							auto go = [&]() -> bool {
 								void *a2[] = {(void *)&fp};
@@ -966,7 +998,7 @@ public:
 					static size_t cub_configured[16];
 					FastParams q = main_build == 2 ? cfp : fp;
 					q.n_fast = seg.n_fast; q.rows = FAST_CUB_ROWS; q.mode = 0; q.only_multi = 0;
-					const size_t qlds = ft * tab_bytes + 16 * area_cf(FAST_CUB_ROWS);
+					const size_t qlds = ft * ftab_bytes + 16 * area_cf(FAST_CUB_ROWS);
 					if (fp.cub_ok) {
 						const uint32_t g4 = (seg.len + (60 * FAST_CUB_ROWS) - 1) / (60 * FAST_CUB_ROWS);
 						const unsigned long long want4 = (unsigned long long)seg.n_voices * (g4 < 64 ? g4 : 64);
@@ -984,14 +1016,16 @@ public:
 				{ /* row groups noted for a second evaluation: returns at once when there are none */
 					/* (only closed-form voices note any: with split launches they run at rows_cf rows per pass, in cfp's layout) */
 					const uint32_t RT = main_build == 2 ? rows_cf : FT;
-					const size_t rlds = main_build == 2 ? ft * tab_bytes + 16 * area_cf(rows_cf) : flds;
+					const size_t rtab = wide_cf ? (size_t)FAST_TAB_BYTES_WIDE : ftab_bytes;
+					const size_t rlds = main_build == 2 ? ft * rtab + 16 * area_cf(rows_cf) : ft * rtab + 16 * area;
 					FastParams rpar = main_build == 2 ? cfp : fp;
 					rpar.mode = 0;
-					const void *rk = RT == 8 ? (const void *)repair_kernel<8> : RT == 6 ? (const void *)repair_kernel<6>
+					const void *rk = wide_cf && RT == 8 ? (const void *)repair_kernel<8, true> : wide_cf && RT == 6 ? (const void *)repair_kernel<6, true>
+					               : RT == 8 ? (const void *)repair_kernel<8> : RT == 6 ? (const void *)repair_kernel<6>
 					               : RT == 5 ? (const void *)repair_kernel<5> : RT == 4 ? (const void *)repair_kernel<4>
 					               : (const void *)repair_kernel<2>;
-					static size_t rconfigured[16][5];
-					if (!raise_lds_attr(rk, rlds, rconfigured[dev_ & 15][RT == 8 ? 4 : RT == 6 ? 3 : RT == 5 ? 2 : RT == 4 ? 1 : 0], err)) return false;
+					static size_t rconfigured[16][7];
+					if (!raise_lds_attr(rk, rlds, rconfigured[dev_ & 15][wide_cf && RT == 8 ? 6 : wide_cf && RT == 6 ? 5 : RT == 8 ? 4 : RT == 6 ? 3 : RT == 5 ? 2 : RT == 4 ? 1 : 0], err)) return false;
 					const uint32_t rgrid = (seg.n_voices + 15) / 16 < 64 ? (seg.n_voices + 15) / 16 : 64;
 					fp.mode = 0;
 					void *rargs[] = {(void *)&rpar};
@@ -1355,7 +1389,8 @@ private:
 	uint32_t block_grid_ = 1;
 	uint32_t fk_grid_ = FK_GRID;
 	bool dyn_enabled_ = true, lean_enabled_ = true, mix_few_enabled_ = true;
-	uint32_t lean_rows_ = 8;    /* SAU_AMD_LEAN_ROWS: rows per pass of fast_kernel<T, 3> at most */
+	bool wide_tabs_ = true;
+	uint32_t lean_rows_ = 6;    /* SAU_AMD_LEAN_ROWS: rows per pass of fast_kernel<T, 3> at most (6, 5 or 4) */
 	uint32_t dyn_groups_ = 12;  /* row groups per task of a closed-form launch, at least (SAU_AMD_DYN_GROUPS) */
 	bool look_words_real_ = false; /* this segment's look-back words in HBM are usable (not the token block) */
 	DevBuf<uint32_t> vlists_;   /* [2][n_voices]: analyze_kernel's lists of closed-form and look-back voices (split launches) */

@@ -36,6 +36,20 @@ struct FastInfo {
 	                   * the closed-form build with the tail code, fast_kernel<4, 0, true>, and by no other launch */
 };
 
+/* A wave table in the time-parallel kernels' LDS: per table one block -- [c3, c2] x 2048 (f64 pairs), then [c1, c0] x 2048.
+ * Two forms (a template parameter of the kernels, WIDE). Narrow: [c1, c0] as the f32 pairs they are in HBM (sau_dev_math.h,
+ * HerpC01), 48 KiB per table, two conversions per sample. Wide (round 4): widened to f64 when the block is staged, 64 KiB per
+ * table -- no conversion per sample, and with a power-of-two block one address computation serves both reads: 3 of the 38
+ * VALU instructions per operator-sample of config 3 for 8 more bytes of LDS gather per sample. It pays where the launch
+ * keeps its rows per pass (config 3: 2.03 -> 1.97 ms per launch) and costs where the wider blocks push rows out of LDS
+ * (carrier-FM bank 6 -> 5 rows: +3.7 %, config 4 +9 %; profiles/r04_headline_ab.json) -- so only the closed-form builds at 8
+ * and 6 rows have a wide form, and the host picks it only when every table the segment wants still fits at those rows. */
+template <bool WIDE> struct FkTab {
+	static constexpr uint32_t BYTES = WIDE ? 65536u : (uint32_t)(WAVE_LEN * (sizeof(HerpC23) + sizeof(HerpC01)));
+	static constexpr uint32_t C01 = (uint32_t)(WAVE_LEN * sizeof(HerpC23)); /* where a block's [c1, c0] entries begin */
+};
+constexpr uint32_t FAST_TAB_BYTES = FkTab<false>::BYTES, FAST_TAB_BYTES_WIDE = FkTab<true>::BYTES;
+
 struct FastStep;
 struct FastLine;
 struct FastAux;

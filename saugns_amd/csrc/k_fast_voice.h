@@ -21,11 +21,6 @@
 #define FK_CSTORE(p, v) (*(p) = (v))
 #define FK_CLOAD(p) (*(p))
 #endif
-#ifndef FK_SWZ_BITS
-#define FK_SWZ(i) (i)
-#else
-#define FK_SWZ(i) ((i) ^ (((i) >> FK_SWZ_BITS) & ((1u << FK_SWZ_BITS) - 1u)))
-#endif
 
 /* lane l receives lane l-1's value (lane 0: zero; it is lead-in) */
 __device__ __forceinline__ uint32_t lane_prev(uint32_t x) {
@@ -35,6 +30,57 @@ __device__ __forceinline__ double lane_prev(double x) {
 	const uint32_t lo = lane_prev((uint32_t)__double2loint(x));
 	const uint32_t hi = lane_prev((uint32_t)__double2hiint(x));
 	return __hiloint2double((int)hi, (int)lo);
+}
+
+/* The Hermite value from a table block in LDS (FAST_TAB_BYTES: see k_fast_types.h). `tab`: the block's LDS address. */
+typedef double __attribute__((ext_vector_type(2))) fk_f64x2;
+typedef float __attribute__((ext_vector_type(2))) fk_f32x2;
+typedef const fk_f64x2 __attribute__((address_space(3))) *fk_lds_f64x2;
+typedef const fk_f32x2 __attribute__((address_space(3))) *fk_lds_f32x2;
+struct FkHerp { double c3, c2, c1, c0; };
+template <bool WIDE>
+__device__ __forceinline__ FkHerp fk_entry(const uint32_t tab, const uint32_t ph) {
+	FkHerp h;
+	if (WIDE) {
+		/* entry index x 16 = bits 31..21 of the phase moved to bits 14..4; both reads from one address */
+		const uint32_t a = tab + ((ph >> (SLEN_BITS - 4)) & ((WAVE_LEN - 1u) << 4));
+		const fk_f64x2 hi = *(fk_lds_f64x2)(uintptr_t)a;
+		const fk_f64x2 lo = *(fk_lds_f64x2)(uintptr_t)(a + FkTab<true>::C01);
+		h.c3 = hi.x; h.c2 = hi.y; h.c1 = lo.x; h.c0 = lo.y;
+	} else {
+		const uint32_t ind = ph >> SLEN_BITS;
+		const fk_f64x2 hi = *(fk_lds_f64x2)(uintptr_t)(tab + ind * 16u);
+		const fk_f32x2 lo = *(fk_lds_f32x2)(uintptr_t)(tab + FkTab<false>::C01 + ind * 8u);
+		h.c3 = hi.x; h.c2 = hi.y; h.c1 = (double)lo.x; h.c0 = (double)lo.y;
+	}
+	return h;
+}
+/* sau_dev_math.h: herp_poly / herp_poly_rise on such an entry (the same operations in the same order) */
+__device__ __forceinline__ double fk_poly(const FkHerp &h, const uint32_t ph) {
+	const double x = (double)(ph & (SLEN - 1));
+	return ((h.c3 * x + h.c2) * x + h.c1) * x + h.c0;
+}
+__device__ __forceinline__ double fk_poly_rise(const FkHerp &h, const uint32_t ph) {
+	const double x = (double)(ph & (SLEN - 1));
+	return ((h.c3 * x + h.c2) * x + h.c1) * x;
+}
+/* stage the tables a launch uses into its LDS blocks (all threads of the workgroup; a barrier follows) */
+template <bool WIDE>
+__device__ __forceinline__ void fk_stage_tables(const FastParams &P, unsigned char *lds, const uint32_t tid, const uint32_t nthreads) {
+	for (uint32_t t = 0; t < P.n_tabs; ++t) {
+		const uint32_t wave = P.wave_of_tab[t];
+		const uint4 *s23 = (const uint4 *)(P.g_c23 + (size_t)wave * WAVE_LEN);
+		uint4 *d23 = (uint4 *)(lds + (size_t)t * FkTab<WIDE>::BYTES);
+		for (uint32_t i = tid; i < WAVE_LEN; i += nthreads) d23[i] = s23[i];
+		const HerpC01 *s01 = P.g_c01 + (size_t)wave * WAVE_LEN;
+		if (WIDE) {
+			fk_f64x2 *d01 = (fk_f64x2 *)(lds + (size_t)t * FkTab<WIDE>::BYTES + FkTab<WIDE>::C01);
+			for (uint32_t i = tid; i < WAVE_LEN; i += nthreads) { fk_f64x2 v; v.x = (double)s01[i].c1; v.y = (double)s01[i].c0; d01[i] = v; }
+		} else {
+			uint2 *d01 = (uint2 *)(lds + (size_t)t * FkTab<WIDE>::BYTES + FkTab<WIDE>::C01);
+			for (uint32_t i = tid; i < WAVE_LEN; i += nthreads) d01[i] = ((const uint2 *)s01)[i];
+		}
+	}
 }
 
 /* Uniform (scalar-cache) load of one decoded step: the address is the same
@@ -53,9 +99,9 @@ __device__ __forceinline__ FastStep load_step_uniform(const FastStep *p) {
  * (frequency ramps, FM); the plain build stays as lean as closed-form voices
  * need it (the same code with the running-sum branches compiled in was 27 %
  * slower on them), and a kernel that may meet both kinds holds both copies. */
-template <int T, int SCAN, bool REPAIR = false, bool CUB = false>
+template <int T, int SCAN, bool REPAIR = false, bool CUB = false, bool WIDE = false>
 __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v, const FastInfo &fi,
-		float *slots, unsigned long long *carry, const HerpC23 *t23, const HerpC01 *t01, const int l,
+		float *slots, unsigned long long *carry, const uint32_t tabs /* LDS address of the launch's table blocks */, const int l,
 		const uint32_t wpv, const uint32_t cstart, unsigned long long *lring = nullptr,
 		const uint32_t dyn_c = 0, const uint32_t dyn_k = 0 /* > 0: chunk dyn_c of dyn_k of the voice's row groups */,
 		const uint32_t vpos = ~0u /* the voice's place among the launch's voices when that is not v (look-back lists) */) {
@@ -202,14 +248,10 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 							for (int k = 0; k < T; ++k) ph[k] += rint32w_p31_small(pm[k]);
 						}
 						if (ok) {
-							const HerpC23 *l23 = t23 + (size_t)f.tab * WAVE_LEN;
-							const HerpC01 *l01 = t01 + (size_t)f.tab * WAVE_LEN;
+							const uint32_t ltab = tabs + (uint32_t)f.tab * FkTab<WIDE>::BYTES;
 							double Is[T];
 #pragma unroll
-							for (int k = 0; k < T; ++k) {
-								const uint32_t ind = ph[k] >> SLEN_BITS;
-								Is[k] = herp_poly(l23[FK_SWZ(ind)], l01[FK_SWZ(ind)], ph[k]);
-							}
+							for (int k = 0; k < T; ++k) Is[k] = fk_poly(fk_entry<WIDE>(ltab, ph[k]), ph[k]);
 							if (FK_CONSTD && !has_pm && f.inc != 0) {
 								/* unmodulated: every phase step is inc, one division serves all */
 								const double x = (double)div_f32_normal(f.diff_scale, (float)(int32_t)f.inc);
@@ -218,6 +260,9 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 									s[k] = (float)((Is[k] - lane_prev(Is[k])) * x + (double)f.diff_offset);
 								done = true;
 							} else {
+								/* (round 4: the unsigned minimum of the steps -- v_min3_u32, one compare per group instead of one per
+								 * row -- rendered wrong samples from the second row group on, with the DPP move folded into the
+								 * subtraction; the per-row compare stays) */
 								bool zero = false;
 #pragma unroll
 								for (int k = 0; k < T; ++k) {
@@ -436,13 +481,9 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 							if (l == (int)H - 1) ph[0] = reset ? nxt - SLEN : f.prev_phase;
 						}
 						if (f.tab >= 0) {
-							const HerpC23 *l23 = t23 + (size_t)f.tab * WAVE_LEN;
-							const HerpC01 *l01 = t01 + (size_t)f.tab * WAVE_LEN;
+							const uint32_t ltab = tabs + (uint32_t)f.tab * FkTab<WIDE>::BYTES;
 #pragma unroll
-							for (int k = 0; k < T; ++k) {
-								const uint32_t ind = ph[k] >> SLEN_BITS;
-								Is[k] = herp_poly(l23[FK_SWZ(ind)], l01[FK_SWZ(ind)], ph[k]);
-							}
+							for (int k = 0; k < T; ++k) Is[k] = fk_poly(fk_entry<WIDE>(ltab, ph[k]), ph[k]);
 						} else {
 							const uint32_t wave = (f.type >> 8) & 0xff;
 							const HerpC23 *g23 = P.g_c23 + (size_t)wave * WAVE_LEN;
@@ -481,17 +522,17 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 							/* a (re)started oscillator's first sample as the reference build computes it (sau_dev_math.h:
 							 * wosc_reset_s): lane H - 1 holds the phase one table step back -- its Hermite value taken apart */
 							const uint32_t indp = ph[0] >> SLEN_BITS;
-							HerpC23 hp; HerpC01 lp;
+							FkHerp ep;
 							if (f.tab >= 0) {
-								hp = (t23 + (size_t)f.tab * WAVE_LEN)[FK_SWZ(indp)];
-								lp = (t01 + (size_t)f.tab * WAVE_LEN)[FK_SWZ(indp)];
+								ep = fk_entry<WIDE>(tabs + (uint32_t)f.tab * FkTab<WIDE>::BYTES, ph[0]);
 							} else {
 								const uint32_t wave = (f.type >> 8) & 0xff;
-								hp = (P.g_c23 + (size_t)wave * WAVE_LEN)[indp];
-								lp = (P.g_c01 + (size_t)wave * WAVE_LEN)[indp];
+								const HerpC23 hp = (P.g_c23 + (size_t)wave * WAVE_LEN)[indp];
+								const HerpC01 lp = (P.g_c01 + (size_t)wave * WAVE_LEN)[indp];
+								ep.c3 = hp.c3; ep.c2 = hp.c2; ep.c1 = (double)lp.c1; ep.c0 = (double)lp.c0;
 							}
-							const double rise_p = lane_prev(herp_poly_rise(hp, lp, ph[0]));
-							const float c0_p = bits_f(lane_prev(f_bits(lp.c0)));
+							const double rise_p = lane_prev(fk_poly_rise(ep, ph[0]));
+							const float c0_p = bits_f(lane_prev(f_bits((float)ep.c0))); /* (the table value: an f32, exactly) */
 							if (l == (int)H) s[0] = wosc_reset_s(Is[0], rise_p, c0_p, f.diff_scale, f.diff_offset);
 						}
 						if (__any(zero && l >= p_min)) {
@@ -832,8 +873,9 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 #else
 #define FK_ATTR __launch_bounds__(1024, FK_MINB)
 #endif
-template <int T, int SCAN, bool CUB = false>
+template <int T, int SCAN, bool CUB = false, bool WIDE = false>
 __global__ void FK_ATTR fast_kernel(FastParams P) {
+	static_assert(!WIDE || (SCAN == 0 && !CUB), "only the closed-form builds have a wide-table form");
 	constexpr int NP = 64 * T;
 	constexpr int W = 16;
 	extern __shared__ __align__(16) unsigned char lds[];
@@ -849,9 +891,8 @@ __global__ void FK_ATTR fast_kernel(FastParams P) {
 	if (CUB && P.pass_flags[FAST_CUB_FLAG] == 0) return; /* no voice for the build with the `cub` tails */
 	if (SCAN == 2 && P.pass_flags[FAST_LK_COUNT] == 0) return; /* ... and the other way round */
 
-	HerpC23 *t23 = (HerpC23 *)lds;
-	HerpC01 *t01 = (HerpC01 *)(lds + (size_t)P.n_tabs * WAVE_LEN * sizeof(HerpC23));
-	unsigned char *areas = lds + (size_t)P.n_tabs * WAVE_LEN * (sizeof(HerpC23) + sizeof(HerpC01));
+	const uint32_t tabs = (uint32_t)(uintptr_t)lds;
+	unsigned char *areas = lds + (size_t)P.n_tabs * FkTab<WIDE>::BYTES;
 	const size_t area_bytes = (size_t)P.n_fast * NP * sizeof(float) + (size_t)P.max_steps * sizeof(unsigned long long);
 	float *slots = (float *)(areas + (size_t)w * area_bytes) + l; /* lane's column of every row */
 	unsigned long long *carry = (unsigned long long *)(areas + (size_t)w * area_bytes + (size_t)P.n_fast * NP * sizeof(float)); /* per step */
@@ -862,15 +903,7 @@ __global__ void FK_ATTR fast_kernel(FastParams P) {
 		static_assert(LOOK_LDS_BYTES == 1024 * sizeof(unsigned long long), "one word per thread");
 	}
 
-	for (uint32_t t = 0; t < P.n_tabs; ++t) {
-		const uint32_t wave = P.wave_of_tab[t];
-		const uint4 *s23 = (const uint4 *)(P.g_c23 + (size_t)wave * WAVE_LEN);
-		uint4 *d23 = (uint4 *)(t23 + (size_t)t * WAVE_LEN);
-		for (uint32_t i = tid; i < WAVE_LEN; i += 64 * W) d23[FK_SWZ(i)] = s23[i];
-		const uint2 *s01 = (const uint2 *)(P.g_c01 + (size_t)wave * WAVE_LEN);
-		uint2 *d01 = (uint2 *)(t01 + (size_t)t * WAVE_LEN);
-		for (uint32_t i = tid; i < WAVE_LEN; i += 64 * W) d01[FK_SWZ(i)] = s01[i];
-	}
+	fk_stage_tables<WIDE>(P, lds, (uint32_t)tid, 64 * W);
 	__syncthreads(); /* the only barrier: tables are shared, all else is per wave */
 
 	const uint32_t NV = P.n_voices;
@@ -894,7 +927,7 @@ __global__ void FK_ATTR fast_kernel(FastParams P) {
 			const uint32_t vi = task / K;
 			const uint32_t v = P.split_cf ? P.vlists[vi] : vi;
 			const FastInfo fi = P.info[v];
-			fast_voice<T, 0, false, CUB>(P, v, fi, slots, carry, t23, t01, l, 1u, 0u, nullptr, task - vi * K, K);
+			fast_voice<T, 0, false, CUB, WIDE>(P, v, fi, slots, carry, tabs, l, 1u, 0u, nullptr, task - vi * K, K);
 		}
 		return;
 	}
@@ -915,7 +948,7 @@ __global__ void FK_ATTR fast_kernel(FastParams P) {
 		for (uint32_t j = g / wpv; j < NVl; j += slots_v) {
 			const uint32_t v = P.vlists[NV + j];
 			const FastInfo fi = P.info[v];
-			fast_voice<T, 2, false, CUB>(P, v, fi, slots, carry, t23, t01, l, wpv, g % wpv, lring, 0u, 0u, j);
+			fast_voice<T, 2, false, CUB>(P, v, fi, slots, carry, tabs, l, wpv, g % wpv, lring, 0u, 0u, j);
 		}
 		return;
 	}
@@ -930,7 +963,7 @@ __global__ void FK_ATTR fast_kernel(FastParams P) {
 		const bool lean_voice = SCAN && P.lean_on && seq_kind == 2 && uni(fi.n_scan) == 0; /* the build of its own takes it */
 		if (SCAN == 3) {
 			if (P.mode == P.sum_levels + 2 && uni(fi.n_chain) == 0) continue; /* (its chains are fed by chain_kernel itself) */
-			if (lean_voice) fast_voice<T, 3>(P, v, fi, slots, carry, t23, t01, l, wpv, cstart);
+			if (lean_voice) fast_voice<T, 3>(P, v, fi, slots, carry, tabs, l, wpv, cstart);
 			continue;
 		}
 		if (SCAN == 1 && lean_voice) continue;
@@ -939,13 +972,13 @@ __global__ void FK_ATTR fast_kernel(FastParams P) {
 		if (SCAN == 1 && P.mode == P.sum_levels + 2 && (seq_kind != 2 || uni(fi.n_chain) == 0))
 			continue; /* the chain-input pass only concerns voices with feedback chains */
 		if (SCAN == 1 && (P.only_multi ? (seq_kind != 1 && seq_kind != 2) : seq_kind == 3)) continue;
-		if (SCAN && seq_kind != 0) fast_voice<T, 1>(P, v, fi, slots, carry, t23, t01, l, wpv, cstart);
-		else fast_voice<T, 0>(P, v, fi, slots, carry, t23, t01, l, wpv, cstart);
+		if (SCAN && seq_kind != 0) fast_voice<T, 1>(P, v, fi, slots, carry, tabs, l, wpv, cstart);
+		else fast_voice<T, 0>(P, v, fi, slots, carry, tabs, l, wpv, cstart);
 	}
 }
 
 /* The row groups fast_kernel noted (see FAST_REPAIR_SHIFT): same workgroup shape and LDS layout. */
-template <int T>
+template <int T, bool WIDE = false>
 __global__ void __launch_bounds__(1024) repair_kernel(FastParams P) {
 	constexpr int NP = 64 * T;
 	constexpr int W = 16;
@@ -954,27 +987,18 @@ __global__ void __launch_bounds__(1024) repair_kernel(FastParams P) {
 	const int tid = threadIdx.x;
 	const int w = (int)uni((uint32_t)tid >> 6);
 	const int l = tid & 63;
-	HerpC23 *t23 = (HerpC23 *)lds;
-	HerpC01 *t01 = (HerpC01 *)(lds + (size_t)P.n_tabs * WAVE_LEN * sizeof(HerpC23));
-	unsigned char *areas = lds + (size_t)P.n_tabs * WAVE_LEN * (sizeof(HerpC23) + sizeof(HerpC01));
+	const uint32_t tabs = (uint32_t)(uintptr_t)lds;
+	unsigned char *areas = lds + (size_t)P.n_tabs * FkTab<WIDE>::BYTES;
 	const size_t area_bytes = (size_t)P.n_fast * NP * sizeof(float) + (size_t)P.max_steps * sizeof(unsigned long long);
 	float *slots = (float *)(areas + (size_t)w * area_bytes) + l;
 	unsigned long long *carry = (unsigned long long *)(areas + (size_t)w * area_bytes + (size_t)P.n_fast * NP * sizeof(float));
-	for (uint32_t t = 0; t < P.n_tabs; ++t) {
-		const uint32_t wave = P.wave_of_tab[t];
-		const uint4 *s23 = (const uint4 *)(P.g_c23 + (size_t)wave * WAVE_LEN);
-		uint4 *d23 = (uint4 *)(t23 + (size_t)t * WAVE_LEN);
-		for (uint32_t i = tid; i < WAVE_LEN; i += 64 * W) d23[FK_SWZ(i)] = s23[i];
-		const uint2 *s01 = (const uint2 *)(P.g_c01 + (size_t)wave * WAVE_LEN);
-		uint2 *d01 = (uint2 *)(t01 + (size_t)t * WAVE_LEN);
-		for (uint32_t i = tid; i < WAVE_LEN; i += 64 * W) d01[FK_SWZ(i)] = s01[i];
-	}
+	fk_stage_tables<WIDE>(P, lds, (uint32_t)tid, 64 * W);
 	__syncthreads();
 	/* one wave per voice with noted groups */
 	for (uint32_t v = blockIdx.x * W + (uint32_t)w; v < P.n_voices; v += gridDim.x * W) {
 		if (uni(P.repair[(size_t)v * FAST_REPAIR_WORDS]) == 0) continue;
 		const FastInfo fi = P.info[v];
 		if (uni(fi.total) == 0 || uni(fi.seq) != 0) continue;
-		fast_voice<T, 0, true>(P, v, fi, slots, carry, t23, t01, l, 1u, 0u);
+		fast_voice<T, 0, true, false, WIDE>(P, v, fi, slots, carry, tabs, l, 1u, 0u);
 	}
 }

@@ -297,6 +297,19 @@ def config3_voices(n=1024, seconds=10, first=0):
     return voices
 
 
+def config3_fm(n=1024, seconds=10):
+    """Config 3's voices with the carrier's modulator list an FM list (`f[...]` for `p[...]`, deviations of 20-50 Hz): the
+    carrier's phase is a running sum of per-frame increments (wosc.h:135-169), its modulator keeps the depth-2 PM chain --
+    the metric's "depth-3 FM" read literally. Script text: config_scripts()["fm"]."""
+    voices = []
+    for i in range(n):
+        m3 = Op("sin", freq=Line(float(3 + i % 4), ratio=True), amp=_f32(0.4))
+        m2 = Op("sin", freq=Line(float(2 + i % 3), ratio=True), amp=_f32(0.7), mods={POP_PMOD: [m3]})
+        m1 = Op("sin", freq=Line(float(1 + i % 5), ratio=True), amp=_num(".1f", 20.0 + (i % 7) * 5.0), mods={POP_PMOD: [m2]})
+        voices.append(Op("sin", freq=_num(".4f", 110.0 + i * 0.731), time_ms=seconds * 1000, mods={POP_FMOD: [m1]}))
+    return build_program(voices)
+
+
 def config5(n=4096, seconds=10):
     """n voices: self-feedback FM carrier with ramps + range-AM modulator."""
     return build_program(config5_voices(n, seconds))
@@ -318,7 +331,7 @@ def config5_voices(n=4096, seconds=10):
 
 
 def config_scripts():
-    """Script text of configs 2, 3, 5 (for the reference parser; fixtures only)."""
+    """Script text of configs 2, 3, 5 and the carrier-FM bank (for the reference parser; fixtures only)."""
     c2 = "\n".join(f"Wsin f{55.0*(1+i%64)+(i//64)*0.37:.4f} p{(i*0.6180339887)%1:.6f} t10"
                    for i in range(256))
     c3 = "\n".join(f"Wsin f{110.0+i*0.731:.4f} t10 p[Wsin r{1+i%5} a{0.5+(i%7)*0.1:.2f} "
@@ -326,7 +339,9 @@ def config_scripts():
     c5 = "\n".join(f"Wsin f{80.0+i*0.211:.4f}[g{160.0+i*0.1:.3f} lexp] "
                    f"p.a{0.3+(i%8)*0.1:.2f}[g0.1 llin] a1[g0.2 lxpe].r0.2[Wsin f{3+i%9}] t10"
                    for i in range(4096))
-    return {"config2": c2, "config3": c3, "config5": c5}
+    fm = "\n".join(f"Wsin f{110.0+i*0.731:.4f} t10 f[Wsin r{1+i%5} a{20.0+(i%7)*5.0:.1f} "
+                   f"p[Wsin r{2+i%3} a0.7 p[Wsin r{3+i%4} a0.4]]]" for i in range(1024))
+    return {"config2": c2, "config3": c3, "config5": c5, "fm": fm}
 
 
 # ---- the same banks through the C ABI's builder (sauAmd_build_bank) --------------------------

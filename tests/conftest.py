@@ -12,6 +12,9 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 # every plan the engine takes from its cache of graph shapes is compared with a fresh compile (engine.cpp)
 os.environ.setdefault("SAU_AMD_PLAN_CHECK", "1")
+# tuning and test switches (SAU_AMD_NO_FAST, SAU_AMD_LDS_LIMIT, ... -- everything that is not a product setting) are only
+# looked at when SAU_AMD_TUNE is set (engine.h: tune_env); the suite uses many of them to force every kernel build
+os.environ.setdefault("SAU_AMD_TUNE", "1")
 # The suite runs what ships: the product's default reproduces the compiled reference's loop tails of `cub` (oracle mode 2,
 # which depends on the host's call size -- device and oracle are given the same one); `SAU_AMD_LOOP_TAILS=0 pytest ...` runs
 # the same suite with the loop bodies' forms everywhere (oracle mode 1), and tests/test_gpu_vs_ref.py and

@@ -84,13 +84,24 @@ def corpus_add(index, match="alarm-25m"):
     np.savez_compressed(os.path.join(OUT, "pcm_heads.npz"), **heads)
 
 
+def fm_full(index):
+    """The carrier-FM bank of bench.py's `other_workloads.fm` (voicebank.config3_fm: config 3 with the carrier's list an
+    FM list), parsed from its script text by the reference and rendered whole by it."""
+    p = po.ref_build_program(voicebank.config_scripts()["fm"])
+    pcm = po.ref_render(p, 44100, False)
+    index["configs"]["fm"] = {"frames": int(len(pcm)), "sha256": sha(pcm), "head_frames": 11025,
+                              "head_sha256": sha(pcm[:11025]),
+                              "script_md5": hashlib.md5((voicebank.config_scripts()["fm"] + "\n").encode()).hexdigest()}
+    print("fm", index["configs"]["fm"])
+
+
 def update_only(what):
     """Add fixtures to an existing tests/golden/ without touching the others:
     python tests/golden/make_golden.py --only config4_all,config5_full"""
     path = os.path.join(OUT, "index.json")
     index = json.load(open(path))
     for w in what:
-        {"config4_all": config4_all, "config5_full": config5_full, "corpus_add": corpus_add}[w](index)
+        {"config4_all": config4_all, "config5_full": config5_full, "corpus_add": corpus_add, "fm_full": fm_full}[w](index)
     json.dump(index, open(path, "w"), indent=1, sort_keys=True)
 
 
@@ -204,6 +215,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "pcm_heads.npz"), **pcm_store)
     config4_all(index)
     config5_full(index)
+    fm_full(index)
     json.dump(index, open(os.path.join(OUT, "index.json"), "w"), indent=1, sort_keys=True)
     print("programs:", len(index["corpus"]), "configs:", list(index["configs"]))
 

@@ -109,6 +109,24 @@ def test_bench_gpus_2_starts_two_ranks_config3(seqexec):
     assert one["n_gpus"] == 1 and one["config"]["frames_all_ranks"] == 2 * 4410
     # the same bank on every rank: the all-rank checksum is the single rank's, twice
     assert j["config"]["pcm_checksum_all_ranks"] == 2 * one["config"]["pcm_checksum_all_ranks"]
+    # who rendered: one record per rank (host, device, PCI address -- none on the CPU test backend --, its own clock)
+    assert [r["rank"] for r in j["ranks"]] == [0, 1] and len(one["ranks"]) == 1
+    assert all(r["host"] and r["ms_per_step"] > 0 and r["pci_bus_id"] is None for r in j["ranks"])
+    assert max(r["ms_per_step"] for r in j["ranks"]) <= j["ms_per_step"] * 1.001  # (the line's clock is the slowest rank's)
+
+
+def test_bench_gpus_2_default_workload_carries_config4_sharded(seqexec):
+    """With N > 1 the default command's line has the north star's multi-GPU case at its top: config 4, 64 renders per GPU
+    sharded by seed (here 2 per rank, heads only), next to config 3's value."""
+    j = _line(_bench(["--gpus", "2", "--voices", "8", "--frames", "4410", "--steps", "1", "--warmup", "0", "--no-cpu",
+                      "--force-others", "--renders", "2", "--c4-frames", "11025"], seqexec))
+    c4 = j["config4_sharded"]
+    assert c4["n_gpus"] == 2 and c4["renders_all_ranks"] == 4 and c4["frames_all_ranks"] == 3 * 4 * 11025
+    assert c4["scaling"] == "weak" and c4["value"] > 0
+    assert j["other_workloads"]["config4"]["config"]["renders_all_ranks"] == 4
+    one = _line(_bench(["--gpus", "1", "--voices", "8", "--frames", "4410", "--steps", "1", "--warmup", "0", "--no-cpu",
+                        "--force-others", "--renders", "2", "--c4-frames", "11025"], seqexec))
+    assert "config4_sharded" not in one and one["other_workloads"]["config4"]["config"]["renders_all_ranks"] == 2
 
 
 def test_bench_under_a_launcher_and_world_mismatch(seqexec):

@@ -1,6 +1,6 @@
 """Debug aid: render one hand-built voice bank on the GPU and compare with the oracle."""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import saugns_amd as sa

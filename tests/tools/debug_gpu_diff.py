@@ -1,6 +1,6 @@
 """Debug helper: render corpus programs on the GPU and report where they leave the oracle."""
 import sys, os, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import saugns_amd as sa

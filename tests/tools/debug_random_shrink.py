@@ -1,6 +1,6 @@
 """Debug aid: shrink a failing random graph (remove subtrees / simplify lines while it still fails)."""
 import sys, os, copy
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import saugns_amd as sa

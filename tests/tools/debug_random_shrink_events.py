@@ -1,7 +1,7 @@
 """Debug aid (GPU): shrink a failing random program with events (drop voices, events, subtrees):
-    RATE=96000 python tests/debug_random_shrink_events.py <seed> <chunk>"""
+    RATE=96000 python tests/tools/debug_random_shrink_events.py <seed> <chunk>"""
 import sys, os, copy
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import saugns_amd as sa

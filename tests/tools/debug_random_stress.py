@@ -1,8 +1,8 @@
 """Debug aid: the random operator graphs stretched -- seconds instead of tenths of seconds, up to
 twelve voices, frequencies up to 20 kHz and below zero -- GPU vs oracle (and, with REF=1 on a box
-that has it, oracle vs the compiled reference):  python tests/debug_random_stress.py <lo> <hi>"""
+that has it, oracle vs the compiled reference):  python tests/tools/debug_random_stress.py <lo> <hi>"""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from saugns_amd import voicebank as vb

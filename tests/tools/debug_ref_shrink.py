@@ -1,7 +1,7 @@
 """Debug aid (CPU): shrink a random graph on which the restatement and the compiled reference differ
-by more than `tol` LSB:  python tests/debug_ref_shrink.py <seed> <voice index> [tol]"""
+by more than `tol` LSB:  python tests/tools/debug_ref_shrink.py <seed> <voice index> [tol]"""
 import sys, os, copy
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from saugns_amd import voicebank as vb
