@@ -42,8 +42,11 @@ template <bool WIDE>
 __device__ __forceinline__ FkHerp fk_entry(const uint32_t tab, const uint32_t ph) {
 	FkHerp h;
 	if (WIDE) {
-		/* entry index x 16 = bits 31..21 of the phase moved to bits 14..4; both reads from one address */
-		const uint32_t a = tab + ((ph >> (SLEN_BITS - 4)) & ((WAVE_LEN - 1u) << 4));
+		/* one address (v_lshrrev + v_lshl_add) serves both reads: the [c1, c0] entry sits a constant 32 KiB further on */
+		/* (the empty asm keeps LLVM from rewriting (ph >> 21) << 4 as (ph >> 17) & 0x7ff0, which costs a third instruction) */
+		uint32_t ind = ph >> SLEN_BITS;
+		asm("" : "+v"(ind));
+		const uint32_t a = tab + (ind << 4);
 		const fk_f64x2 hi = *(fk_lds_f64x2)(uintptr_t)a;
 		const fk_f64x2 lo = *(fk_lds_f64x2)(uintptr_t)(a + FkTab<true>::C01);
 		h.c3 = hi.x; h.c2 = hi.y; h.c1 = lo.x; h.c0 = lo.y;
@@ -145,12 +148,17 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 	unsigned long long *scan = two ? P.scan + (size_t)v * FAST_MAX_SCAN * P.scan_groups : nullptr;
 	float *vrow = P.vout + (size_t)vd.out_row * P.row_stride;
 	float *prow = (vd.pan_dynamic_row != ~0u) ? P.pan + (size_t)vd.pan_dynamic_row * P.row_stride : nullptr;
-	/* A wave renders T rows at a time; a row is 64 consecutive frames, one per
-	 * lane, of which the first H are lead-in (recomputed, not stored). */
-	const uint32_t C = 64u - H;                       /* new frames per row */
-	const uint32_t nrows = (fast_total + C - 1) / C;
-	const uint32_t ngroups = (nrows + T - 1) / T;
-	const uint32_t last_group = ((fast_total - 1) / C) / T; /* holds the segment's last frame */
+	/* A wave renders T rows at a time; a row is 64 consecutive frames, one per lane. Running-sum builds: the first H lanes
+	 * of every row are lead-in (recomputed, not stored), rows lie C = 64 - H frames apart. Closed-form builds (round 4,
+	 * CONTIG): a group's rows are contiguous in time -- row k + 1 goes on where row k ends, and what its lane 0 needs of
+	 * the sample before (phase, Hermite value: prev32 / prev64 below) is row k's lane 63 -- so only a group's first row
+	 * pays the lead-in: 64 T - H new frames per group instead of T (64 - H), 5.8 % more at T = 8, H = 4. */
+	constexpr bool CONTIG = SCAN == 0;
+	const uint32_t C = 64u - H;                                   /* new frames of a row that has lead-in lanes */
+	const uint32_t RS = CONTIG ? 64u : C;                         /* frames from one row of a group to the next */
+	const uint32_t GF = CONTIG ? 64u * T - H : (uint32_t)T * C;   /* new frames per group */
+	const uint32_t ngroups = (fast_total + GF - 1) / GF;
+	const uint32_t last_group = (fast_total - 1) / GF; /* holds the segment's last frame */
 	uint32_t zero_acc = 0; /* nonzero: some hold-previous run could not be resolved here */
 
 	uint32_t *const rep = P.repair + (size_t)v * FAST_REPAIR_WORDS;
@@ -160,7 +168,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 	if (!REPAIR && SCAN != 2 && P.range_mode != 0) { /* (the single-pass build never runs in chunks) */
 		if (seq) { if (!P.range_last) return; } /* one wave in order, carries in LDS: in the last chunk's launch, all of it */
 		else {
-			const uint32_t tc = (uint32_t)T * C;
+			const uint32_t tc = GF;
 			if (P.range_mode == 1) { /* groups that start in [f_lo, f_hi) */
 				it_lo = (P.f_lo + tc - 1) / tc;
 				n_iter = min(ngroups, P.f_hi > 0xffffffffu - tc ? ngroups : (P.f_hi + tc - 1) / tc);
@@ -180,7 +188,25 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 	for (uint32_t it = it_lo + cstart; it < n_iter; it += gstride, cgm = cgm + wpv >= lk_ring ? cgm + wpv - lk_ring : cgm + wpv) {
 		const uint32_t cg = REPAIR ? uni(rep[2 + 2 * it]) : it;
 		const uint32_t repair_rows = REPAIR ? uni(rep[3 + 2 * it]) : 0u;
-		const int t0 = (int)(cg * T * C) - (int)H + l - (REPAIR ? (int)FAST_REPAIR_SHIFT : 0); /* this lane's frame in row 0 */
+		const int t0 = (int)(cg * GF) - (int)H + l - (REPAIR ? (int)FAST_REPAIR_SHIFT : 0); /* this lane's frame in row 0 */
+		/* does this lane's frame of row k belong to the group (lead-in lanes: rows that have them, i.e. row 0 when CONTIG)? */
+		auto own = [&](int k) -> bool { return (CONTIG && k > 0) || l >= (int)H; };
+		/* what the lane before holds of row k's x -- for lane 0 of a later row of a contiguous group: the row before's lane 63 */
+		/* (the DPP move's lane 0 has no lane to read from: it keeps the `old` operand, here the row before's lane 63) */
+		auto prev_of = [&](uint32_t cur, uint32_t before, int k) -> uint32_t {
+			if (CONTIG && k > 0) { /* (two DPP moves: the row before rotated by a lane puts its lane 63 into lane 0) */
+				const int rot = __builtin_amdgcn_update_dpp(0, (int)before, 0x13c /* wave_ror:1 */, 0xf, 0xf, false);
+				return (uint32_t)__builtin_amdgcn_update_dpp(rot, (int)cur, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+			}
+			return lane_prev(cur);
+		};
+		auto prev32 = [&](const uint32_t *x, int k) -> uint32_t { return prev_of(x[k], x[k > 0 ? k - 1 : 0], k); };
+		auto prev64 = [&](const double *x, int k) -> double {
+			const double b = x[k > 0 ? k - 1 : 0];
+			const uint32_t lo = prev_of((uint32_t)__double2loint(x[k]), (uint32_t)__double2loint(b), k);
+			const uint32_t hi = prev_of((uint32_t)__double2hiint(x[k]), (uint32_t)__double2hiint(b), k);
+			return __hiloint2double((int)hi, (int)lo);
+		};
 		const bool first_group = (cg == 0);
 		const bool is_last_group = (cg == last_group);
 		uint32_t held_rows = 0; /* rows with a hold this evaluation could not resolve */
@@ -215,7 +241,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 					const float *crow = P.chain_rows + (size_t)2 * f_bits(f.pan) * P.chain_stride;
 #pragma unroll
 					for (int k = 0; k < T; ++k) {
-						const int t = t0 + k * (int)C;
+						const int t = t0 + k * (int)RS;
 						s[k] = (t >= 0 && t < (int)fast_total) ? FK_CLOAD(&crow[t]) : 0.f;
 					}
 				} else if (type == OT_WAVE) {
@@ -230,7 +256,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 						uint32_t ph[T];
 						{
 							uint32_t acc = f.phase0 + f.inc * (uint32_t)(t0 + 1);
-							const uint32_t row_inc = f.inc * C;
+							const uint32_t row_inc = f.inc * RS;
 #pragma unroll
 							for (int k = 0; k < T; ++k) { ph[k] = acc; acc += row_inc; }
 						}
@@ -257,20 +283,21 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 								const double x = (double)div_f32_normal(f.diff_scale, (float)(int32_t)f.inc);
 #pragma unroll
 								for (int k = 0; k < T; ++k)
-									s[k] = (float)((Is[k] - lane_prev(Is[k])) * x + (double)f.diff_offset);
+									s[k] = (float)((Is[k] - prev64(Is, k)) * x + (double)f.diff_offset);
 								done = true;
 							} else {
 								/* (round 4: the unsigned minimum of the steps -- v_min3_u32, one compare per group instead of one per
 								 * row -- rendered wrong samples from the second row group on, with the DPP move folded into the
 								 * subtraction; the per-row compare stays) */
-								bool zero = false;
+								bool zero = false, zero_n = false; /* a phase step of zero in row 0 / in a later row */
 #pragma unroll
 								for (int k = 0; k < T; ++k) {
-									const int32_t d = (int32_t)(ph[k] - lane_prev(ph[k]));
-									zero |= (d == 0);
-									s[k] = wosc_diff(Is[k], lane_prev(Is[k]), d, f.diff_scale, f.diff_offset);
+									const int32_t d = (int32_t)(ph[k] - prev32(ph, k));
+									if (CONTIG && k > 0) zero_n |= (d == 0); else zero |= (d == 0);
+									s[k] = wosc_diff(Is[k], prev64(Is, k), d, f.diff_scale, f.diff_offset);
 								}
-								done = !__any(zero && l >= p_min);
+								/* (every lane of a contiguous group's later rows is a defined one) */
+								done = !__any((zero && l >= p_min) || zero_n);
 							}
 						}
 					}
@@ -303,7 +330,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 								if (FULL) {
 #pragma unroll
 									for (int k = 0; k < T; ++k) {
-										const int t = t0 + k * (int)C;
+										const int t = t0 + k * (int)RS;
 										uint32_t r;
 										if (inc_read) {
 											r = (t >= 0 && t < (int)fast_total) ? irow[t] : 0u;
@@ -326,7 +353,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 									bool big = false;
 #pragma unroll
 									for (int k = 0; k < T; ++k) {
-										fv[k] = freq_at(k, t0 + k * (int)C);
+										fv[k] = freq_at(k, t0 + k * (int)RS);
 										x[k] = fa.coeff * fv[k];
 										big |= !(fabsf(x[k]) < 0x1p50f);
 									}
@@ -340,7 +367,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 									}
 #pragma unroll
 									for (int k = 0; k < T; ++k) {
-										const int t = t0 + k * (int)C;
+										const int t = t0 + k * (int)RS;
 										const uint32_t inc = (t >= 0 && t < (int)fast_total) ? r[k] : 0u;
 										if (SCAN == 3 && chain && fa.pad[2]) S[k] = inc; /* chain_kernel does the summing */
 										else S[k] = wave_incl_scan_dpp(inc);
@@ -355,7 +382,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 									if (from_line) pl = load_line_uniform(fplines + si);
 #pragma unroll
 									for (int k = 0; k < T; ++k) {
-										const int t = t0 + k * (int)C;
+										const int t = t0 + k * (int)RS;
 										const float a = from_line ? fast_line_value(pl, t) : slots[f.aux_off + k * 64];
 										if (l >= (int)H && t >= 0 && t < (int)fast_total) {
 											FK_CSTORE(&((u32_alias *)brow)[t], S[k]);
@@ -402,7 +429,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 						if (!fvar) {
 							/* phase0 + inc*(t+1): one multiply per lane, then adds */
 							uint32_t acc = f.phase0 + f.inc * (uint32_t)(t0 + 1);
-							const uint32_t row_inc = f.inc * C;
+							const uint32_t row_inc = f.inc * RS;
 #pragma unroll
 							for (int k = 0; k < T; ++k) { ph[k] = acc; acc += row_inc; fv[k] = f.fc; }
 						}
@@ -415,7 +442,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 						} else if (SCAN && is_last_group) {
 #pragma unroll
 							for (int k = 0; k < T; ++k) {
-								const int t = t0 + k * (int)C;
+								const int t = t0 + k * (int)RS;
 								if (t == (int)fast_total - 1 && l >= (int)H) P.ops[f.gop].st_phase = ph[k];
 							}
 						}
@@ -464,7 +491,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 							if (from_line) pl = load_line_uniform(fplines + si);
 #pragma unroll
 							for (int k = 0; k < T; ++k) {
-								const int t = t0 + k * (int)C;
+								const int t = t0 + k * (int)RS;
 								const float a = from_line ? fast_line_value(pl, t) : slots[f.aux_off + k * 64];
 								if (l >= (int)H && t >= 0 && t < (int)fast_total) {
 									FK_CSTORE(&((u32_alias *)brow)[t], ph[k]);
@@ -505,16 +532,16 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 #pragma unroll
 							for (int k = 0; k < T; ++k) {
 								pph[k] = ph[k] - f.inc;
-								const double pIs = lane_prev(Is[k]);
+								const double pIs = prev64(Is, k);
 								s[k] = (float)((Is[k] - pIs) * x + (double)f.diff_offset);
 							}
 						} else {
 #pragma unroll
 							for (int k = 0; k < T; ++k) {
-								pph[k] = lane_prev(ph[k]);
-								const double pIs = lane_prev(Is[k]);
+								pph[k] = prev32(ph, k);
+								const double pIs = prev64(Is, k);
 								const int32_t d = (int32_t)(ph[k] - pph[k]);
-								zero |= (d == 0);
+								zero |= (d == 0) && ((CONTIG && k > 0) || l >= p_min);
 								s[k] = wosc_diff(Is[k], pIs, d, f.diff_scale, f.diff_offset);
 							}
 						}
@@ -535,15 +562,15 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 							const float c0_p = bits_f(lane_prev(f_bits((float)ep.c0))); /* (the table value: an f32, exactly) */
 							if (l == (int)H) s[0] = wosc_reset_s(Is[0], rise_p, c0_p, f.diff_scale, f.diff_offset);
 						}
-						if (__any(zero && l >= p_min)) {
+						if (__any(zero)) {
 							/* dphase == 0: the differentiator holds its previous output
 							 * (wosc.h:251-252). Isolated cases resolve inside the row; a
 							 * run that reaches back past the lead-in goes to the block loop. */
 							bool held[T], src[T]; /* src: holds a defined output to copy from */
 #pragma unroll
 							for (int k = 0; k < T; ++k) {
-								const int t = t0 + k * (int)C;
-								const bool defined = l >= p_min && t >= 0;
+								const int t = t0 + k * (int)RS;
+								const bool defined = ((CONTIG && k > 0) || l >= p_min) && t >= 0;
 								held[k] = (ph[k] == pph[k]) && defined && t < (int)fast_total;
 								src[k] = defined && !held[k];
 							}
@@ -551,9 +578,14 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 								bool changed = false;
 #pragma unroll
 								for (int k = 0; k < T; ++k) {
-									const float sp = __shfl_up(s[k], 1);
-									const bool okp = __shfl_up(src[k], 1);
-									if (held[k] && okp && l > 0) { s[k] = sp; held[k] = false; src[k] = true; changed = true; }
+									float sp = __shfl_up(s[k], 1);
+									bool okp = __shfl_up(src[k], 1);
+									if (CONTIG && k > 0) { /* lane 0 looks at the row before's lane 63 */
+										const float se = __shfl(s[k - 1], 63);
+										const bool oke = __shfl(src[k - 1], 63);
+										if (l == 0) { sp = se; okp = oke; }
+									}
+									if (held[k] && okp && (l > 0 || (CONTIG && k > 0))) { s[k] = sp; held[k] = false; src[k] = true; changed = true; }
 								}
 								if (!__any(changed)) break;
 							}
@@ -570,8 +602,8 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 							/* the row that holds the segment's last frame stages the state */
 #pragma unroll
 							for (int k = 0; k < T; ++k) {
-								const int t = t0 + k * (int)C;
-								if (t == (int)fast_total - 1 && l >= (int)H) {
+								const int t = t0 + k * (int)RS;
+								if (t == (int)fast_total - 1 && own(k)) {
 									DevOp &o = P.ops[f.gop];
 									if (FULL) o.st_phase = phu[FULL ? k : 0];
 									o.st_prev_phase = ph[k];
@@ -605,7 +637,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 							const bool inc_write = irow && two && P.mode == fa.pad[1];
 #pragma unroll
 							for (int k = 0; k < T; ++k) {
-								const int t = t0 + k * (int)C;
+								const int t = t0 + k * (int)RS;
 								const bool in_seg = t >= 0 && t < (int)fast_total;
 								if (inc_read) { /* saved by the sum pass of its level: low and high words */
 									incv[k] = in_seg ? ((unsigned long long)irow[P.inc_stride + t] << 32) | irow[t] : 0ull;
@@ -664,7 +696,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 							if (is_last_group) { /* the counter after the segment's last frame */
 #pragma unroll
 								for (int k = 0; k < T; ++k) {
-									const int t = t0 + k * (int)C;
+									const int t = t0 + k * (int)RS;
 									if (t == (int)fast_total - 1 && l >= (int)H)
 										P.ops[f.gop].st_prev_Is = __longlong_as_double((long long)(cpv[k] + incv[k]));
 								}
@@ -674,7 +706,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 					if (!fvar) {
 #pragma unroll
 						for (int k = 0; k < T; ++k) {
-							const int t = t0 + k * (int)C;
+							const int t = t0 + k * (int)RS;
 							cpv[k] = cp0 + inc64 * (unsigned long long)(long long)t;
 							fv[k] = f.fc;
 						}
@@ -694,7 +726,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 							if (f.type & FT_CUBTAIL) { /* the last len % 4 samples of the reference's block (sau_dev_math.h: TailCtx) */
 								TailCtx tc;
 								tc.lat = vd.lat; tc.ev_left = vd.ev_left; tc.off = 0; tc.rem = f.phase0; tc.on = 1;
-								const int t = t0 + k * (int)C;
+								const int t = t0 + k * (int)RS;
 								ctail = t >= 0 && cub_map_is_tail(tc, (uint32_t)t);
 							}
 						}
@@ -710,7 +742,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 						uint32_t S[T];
 #pragma unroll
 						for (int k = 0; k < T; ++k) {
-							const int t = t0 + k * (int)C;
+							const int t = t0 + k * (int)RS;
 							const uint32_t inc = (t >= 0 && t < (int)fast_total) ? (uint32_t)((int32_t)ranfast32(n0 + (uint32_t)t) >> 6) : 0u;
 							S[k] = wave_incl_scan_dpp(inc);
 						}
@@ -727,7 +759,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 						}
 #pragma unroll
 						for (int k = 0; k < T; ++k) {
-							const int t = t0 + k * (int)C;
+							const int t = t0 + k * (int)RS;
 							const uint32_t lead = (uint32_t)__builtin_amdgcn_readlane((int)S[k], (int)H - 1);
 							const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)S[k], 63);
 							const uint32_t sum = acc + (S[k] - lead);
@@ -740,7 +772,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 					} else {
 #pragma unroll
 					for (int k = 0; k < T; ++k) {
-						const int t = t0 + k * (int)C;
+						const int t = t0 + k * (int)RS;
 						const uint32_t n = n0 + (uint32_t)t;
 						if (nz == NZ_vi) {
 							uint32_t s1 = ranfast32(n);
@@ -767,7 +799,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 				} else if (f.ramp & 1) { /* amplitude ramp in progress, sau/line.c:65-281 */
 					const FastLine fl = load_line_uniform(flines + si);
 #pragma unroll
-					for (int k = 0; k < T; ++k) r[k] = fast_line_value(fl, t0 + k * (int)C);
+					for (int k = 0; k < T; ++k) r[k] = fast_line_value(fl, t0 + k * (int)RS);
 				} else {
 #pragma unroll
 					for (int k = 0; k < T; ++k) r[k] = f.ac;
@@ -786,8 +818,8 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 				if (to_voice) {
 #pragma unroll
 					for (int k = 0; k < T; ++k) {
-						const int t = t0 + k * (int)C;
-						const bool mine = REPAIR ? (l == (int)(H + FAST_REPAIR_SHIFT) && ((repair_rows >> k) & 1u)) : (l >= (int)H);
+						const int t = t0 + k * (int)RS;
+						const bool mine = REPAIR ? (l == (int)(H + FAST_REPAIR_SHIFT) && ((repair_rows >> k) & 1u)) : own(k);
 						if (mine && t < (int)fast_total) FK_VSTORE(&vrow[t], r[k]);
 					}
 				} else {
@@ -809,7 +841,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 					}
 #pragma unroll
 					for (int k = 0; k < T; ++k) {
-						const int t = t0 + k * (int)C;
+						const int t = t0 + k * (int)RS;
 						float v = fast_line_value(fl, t);
 						const bool in_goal = (uint32_t)t < fl.goal_len;
 						if (mflags & (in_goal ? FA_MUL_GOAL : FA_MUL_HOLD))
@@ -830,8 +862,8 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 			} else if (kind == ST_VOICE) { /* generator.c:749-788 with pan modulators */
 #pragma unroll
 				for (int k = 0; k < T; ++k) {
-					const int t = t0 + k * (int)C;
-					const bool mine = REPAIR ? (l == (int)(H + FAST_REPAIR_SHIFT) && ((repair_rows >> k) & 1u)) : (l >= (int)H);
+					const int t = t0 + k * (int)RS;
+					const bool mine = REPAIR ? (l == (int)(H + FAST_REPAIR_SHIFT) && ((repair_rows >> k) & 1u)) : own(k);
 					if (mine && t < (int)fast_total) {
 						FK_VSTORE(&vrow[t], slots[f.out_off + k * 64]);
 						if (prow) prow[t] = f.pm_off != ~0u ? slots[f.pm_off + k * 64] : f.pan;
@@ -843,8 +875,10 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 			/* to the repair pass -- unless this is it, the group touches an end of the segment
 			 * (carried state sits at fixed lanes there) or the voice has running sums */
 			bool noted = false;
-			if (!REPAIR && !SCAN && !CUB && P.repair_on && !first_group && !is_last_group &&
-			    (int)(cg * T * C) - (int)H >= (int)FAST_REPAIR_SHIFT) {
+			/* (a contiguous group's later rows resolve their holds through the rows before: one left there means a run that
+			 * reaches back to the group's lead-in -- not a case for the one-frame repair) */
+			if (!REPAIR && !SCAN && !CUB && P.repair_on && !first_group && !is_last_group && !(CONTIG && (held_rows >> 1)) &&
+			    (int)(cg * GF) - (int)H >= (int)FAST_REPAIR_SHIFT) {
 				uint32_t at = 0;
 				if (l == 0) at = atomicAdd(&rep[0], 1u);
 				at = uni(at);
