@@ -362,6 +362,7 @@ public:
 		lean_enabled_ = tune_env("SAU_AMD_NO_LEAN") == nullptr; /* chains' passes in a build without the several-pass sums */
 		dyn_enabled_ = tune_env("SAU_AMD_NO_DYN") == nullptr; /* closed-form launches deal tasks out through a counter */
 		wide_tabs_ = tune_env("SAU_AMD_NO_WIDE_TABS") == nullptr; /* closed-form launches with f64 [c1, c0] table entries in LDS */
+		if (const char *mr = tune_env("SAU_AMD_MORE_ROWS")) more_rows_ = (uint32_t)atoi(mr); /* 0, 10 or 12 */
 		if (const char *dg = tune_env("SAU_AMD_DYN_GROUPS")) { const int n = atoi(dg); dyn_groups_ = n >= 1 ? (uint32_t)n : 1u; }
 		/* voices per segment from which feedback voices get sixteen one-wave teams per workgroup
 		 * (0: never; 1: always, also without feedback -- tests) */
@@ -636,7 +637,7 @@ public:
 				while (t > 4 && 16 * area_of(t) + need > lds_limit_) t = fewer(t); /* (but not below 4 rows: that costs more) */
 				if (16 * area_of(t) + need <= lds_limit_) FT = t;
 			}
-			const size_t area = area_of(FT);
+			size_t area = area_of(FT);
 			const bool use_fast = fast_enabled_ && (16 * area + look_lds + 1024 <= lds_limit_);
 			const uint32_t FTM = FT > 4 && seq_enabled_ && seg.may_scan ? 4 : FT; /* rows per pass of the full build */
 			if (!finfo_.ensure(seg.n_voices, err) || !fdone_.ensure(seg.n_voices, err) ||
@@ -733,7 +734,7 @@ public:
 				uint32_t ct = 0;
 				for (int wv = 0; wv < 12; ++wv) {
 					fp.ctab_of_wave[wv] = -1;
-					if (((seg.wave_mask >> wv) & 1) && (ct + 1) * tab_bytes + CHAIN_IO_BYTES + 1024 <= lds_limit_) {
+					if (((seg.wave_mask >> wv) & 1) && (ct + 1) * (size_t)CHAIN_TAB_BYTES + CHAIN_IO_BYTES + 1024 <= lds_limit_) {
 						fp.ctab_of_wave[wv] = (int8_t)ct;
 						fp.cwave_of_tab[ct] = (uint8_t)wv;
 						++ct;
@@ -753,6 +754,16 @@ public:
 				}
 			}
 			fp.n_tabs = ft;
+			/* Closed-form segments whose tables all sit in LDS in the wide form: more rows per pass where LDS holds them (round 4:
+			 * a group's rows are contiguous in time since then, which took the 8-row build from 128 to 114 VGPRs) */
+			if (use_fast && !seq_ok && wide_tabs_ && more_rows_ && FT == 8 && ft > 0 && ft == (uint32_t)__builtin_popcount(seg.wave_mask) &&
+			    seg.max_steps >= 2) {
+				for (uint32_t t : {12u, 10u}) /* (14 and 16 rows: hipcc's "requires even aligned vector registers" error on their spills) */
+					if (t <= more_rows_ && ft * (size_t)FAST_TAB_BYTES_WIDE + 16 * area_of(t) + 1024 <= lds_limit_) {
+						FT = t; area = area_of(FT); fp.rows = FT; fp.rows_multi = FT;
+						break;
+					}
+			}
 			/* the closed-form voices of a segment that may also have look-back voices: a launch of their own (FastParams.vlists) */
 			const bool split_cf = use_fast && seq_ok && look_split;
 			uint32_t rows_cf = 2;
@@ -760,6 +771,10 @@ public:
 			if (split_cf) {
 				for (uint32_t t : {8u, 6u, 5u, 4u})
 					if (t <= fast_rows_ && ft * ftab_bytes + 16 * area_cf(t) + 1024 <= lds_limit_) { rows_cf = t; break; }
+				/* (10 or 12 rows exist in the wide-table form only: where that fits -- the same test as wide_fits below) */
+				if (rows_cf == 8 && wide_tabs_ && more_rows_ && ft > 0 && ft == (uint32_t)__builtin_popcount(seg.wave_mask) && seg.max_steps >= 2)
+					for (uint32_t t : {12u, 10u})
+						if (t <= more_rows_ && ft * (size_t)FAST_TAB_BYTES_WIDE + 16 * area_cf(t) + 1024 <= lds_limit_) { rows_cf = t; break; }
 				if (!vlists_.ensure((size_t)2 * seg.n_voices, err)) return false;
 				fp.vlists = vlists_.p; fp.split_cf = 1; fp.rows_cf = rows_cf;
 				fp.look_words_real = look_words_real_ && fp.look ? 1u : 0u;
@@ -798,13 +813,14 @@ public:
 				static size_t fconfigured[16][4][5];
 				/* the closed-form build with wide table blocks in LDS (k_fast_types.h: FkTab), at 6 and 8 rows per pass: taken when
 				 * every table the segment wants is in LDS and still fits in that form at the launch's rows */
-				static const void *const fk_wide[2] = {(const void *)fast_kernel<6, 0, false, true>, (const void *)fast_kernel<8, 0, false, true>};
-				static size_t wconfigured[16][2];
+				static const void *const fk_wide[4] = {(const void *)fast_kernel<6, 0, false, true>, (const void *)fast_kernel<8, 0, false, true>,
+					(const void *)fast_kernel<10, 0, false, true>, (const void *)fast_kernel<12, 0, false, true>};
+				static size_t wconfigured[16][4];
 				const uint32_t n_want = (uint32_t)__builtin_popcount(seg.wave_mask);
 				auto wide_fits = [&](uint32_t rows, size_t area16) {
 					/* (voices of one step -- flat banks, BASELINE config 2 -- have no modulation to evaluate: fewer VALU
 					 * instructions per sample to begin with, and the wider gather costs them 3-4 %) */
-					return wide_tabs_ && (rows == 8 || rows == 6) && ft > 0 && ft == n_want && seg.max_steps >= 2 &&
+					return wide_tabs_ && (rows == 8 || rows == 6 || rows == 10 || rows == 12) && ft > 0 && ft == n_want && seg.max_steps >= 2 &&
 						ft * (size_t)FAST_TAB_BYTES_WIDE + area16 + 1024 <= lds_limit_;
 				};
 				auto launch_build = [&](int build, uint32_t rows, uint32_t grid, const FastParams *prm = nullptr, size_t area16 = 0,
@@ -814,10 +830,11 @@ public:
 					const int ri = rows == 8 ? 4 : rows == 6 ? 3 : rows == 5 ? 2 : rows == 4 ? 1 : 0;
 					const size_t a16 = area16 ? area16 : 16 * area_of(rows);
 					void *args[] = {(void *)(prm ? prm : &fp)};
-					if (wide && build == 0 && (rows == 8 || rows == 6)) {
+					if (wide && build == 0 && (rows == 8 || rows == 6 || rows == 10 || rows == 12)) {
+						const int wi = rows == 12 ? 3 : rows == 10 ? 2 : rows == 8 ? 1 : 0;
 						const size_t lds = ft * (size_t)FAST_TAB_BYTES_WIDE + a16;
-						if (!raise_lds_attr(fk_wide[rows == 8], lds, wconfigured[dev_ & 15][rows == 8], err)) return false;
-						HIP_OK(hipLaunchKernel(fk_wide[rows == 8], dim3(grid), dim3(1024), args, lds, stream_));
+						if (!raise_lds_attr(fk_wide[wi], lds, wconfigured[dev_ & 15][wi], err)) return false;
+						HIP_OK(hipLaunchKernel(fk_wide[wi], dim3(grid), dim3(1024), args, lds, stream_));
 						return true;
 					}
 					const size_t lds = ft * ftab_bytes + a16 + (build == 2 ? LOOK_LDS_BYTES : 0);
@@ -911,7 +928,7 @@ public:
 					if (fp.chain_rows && fp.chain_early_ok) {
 						/* chains that sums or other chains' inputs depend on, fed from their own lines: whole segment, before
 						 * anything else (FastInfo.early); returns at once when analyze_kernel found none */
-						const size_t clds = (size_t)fp.n_ctabs * tab_bytes + CHAIN_IO_BYTES;
+						const size_t clds = (size_t)fp.n_ctabs * CHAIN_TAB_BYTES + CHAIN_IO_BYTES;
 						if (!raise_lds_attr((const void *)chain_kernel, clds, chain_lds_configured_[dev_ & 15], err)) return false;
 						fp.chain_early = 1; fp.range_mode = 0;
 						hipLaunchKernelGGL(chain_kernel, dim3((seg.n_chain_rows + 63) / 64), dim3(128), clds, stream_, fp);
@@ -927,7 +944,7 @@ public:
 						 * chunks of the segment: chain_kernel occupies one CU per 64 chains for frames x chain latency,
 						 * so it runs on a stream of its own while, on the other CUs, the chain-input pass prepares the
 						 * chunks after it and the final pass finishes the chunks before it. */
-						const size_t clds = (size_t)fp.n_ctabs * tab_bytes + CHAIN_IO_BYTES;
+						const size_t clds = (size_t)fp.n_ctabs * CHAIN_TAB_BYTES + CHAIN_IO_BYTES;
 						if (!raise_lds_attr((const void *)chain_kernel, clds, chain_lds_configured_[dev_ & 15], err)) return false;
 						const uint32_t cgrid = (seg.n_chain_rows + 63) / 64;
 						/* chunks of about chain_chunk_frames_ frames (what the first chunk's inputs and the last chunk's final
@@ -1020,12 +1037,13 @@ public:
 					const size_t rlds = main_build == 2 ? ft * rtab + 16 * area_cf(rows_cf) : ft * rtab + 16 * area;
 					FastParams rpar = main_build == 2 ? cfp : fp;
 					rpar.mode = 0;
-					const void *rk = wide_cf && RT == 8 ? (const void *)repair_kernel<8, true> : wide_cf && RT == 6 ? (const void *)repair_kernel<6, true>
+					const void *rk = wide_cf && RT == 12 ? (const void *)repair_kernel<12, true> : wide_cf && RT == 10 ? (const void *)repair_kernel<10, true>
+					               : wide_cf && RT == 8 ? (const void *)repair_kernel<8, true> : wide_cf && RT == 6 ? (const void *)repair_kernel<6, true>
 					               : RT == 8 ? (const void *)repair_kernel<8> : RT == 6 ? (const void *)repair_kernel<6>
 					               : RT == 5 ? (const void *)repair_kernel<5> : RT == 4 ? (const void *)repair_kernel<4>
 					               : (const void *)repair_kernel<2>;
-					static size_t rconfigured[16][7];
-					if (!raise_lds_attr(rk, rlds, rconfigured[dev_ & 15][wide_cf && RT == 8 ? 6 : wide_cf && RT == 6 ? 5 : RT == 8 ? 4 : RT == 6 ? 3 : RT == 5 ? 2 : RT == 4 ? 1 : 0], err)) return false;
+					static size_t rconfigured[16][9];
+					if (!raise_lds_attr(rk, rlds, rconfigured[dev_ & 15][wide_cf && RT == 12 ? 8 : wide_cf && RT == 10 ? 7 : wide_cf && RT == 8 ? 6 : wide_cf && RT == 6 ? 5 : RT == 8 ? 4 : RT == 6 ? 3 : RT == 5 ? 2 : RT == 4 ? 1 : 0], err)) return false;
 					const uint32_t rgrid = (seg.n_voices + 15) / 16 < 64 ? (seg.n_voices + 15) / 16 : 64;
 					fp.mode = 0;
 					void *rargs[] = {(void *)&rpar};
@@ -1390,6 +1408,7 @@ private:
 	uint32_t fk_grid_ = FK_GRID;
 	bool dyn_enabled_ = true, lean_enabled_ = true, mix_few_enabled_ = true;
 	bool wide_tabs_ = true;
+	uint32_t more_rows_ = 12;
 	uint32_t lean_rows_ = 6;    /* SAU_AMD_LEAN_ROWS: rows per pass of fast_kernel<T, 3> at most (6, 5 or 4) */
 	uint32_t dyn_groups_ = 12;  /* row groups per task of a closed-form launch, at least (SAU_AMD_DYN_GROUPS) */
 	bool look_words_real_ = false; /* this segment's look-back words in HBM are usable (not the token block) */

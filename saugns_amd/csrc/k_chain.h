@@ -23,6 +23,7 @@
 constexpr uint32_t CHAIN_BATCH = SAU_CHAIN_BATCH_FRAMES;
 constexpr uint32_t CHAIN_NQ = CHAIN_BATCH / 4;     /* 16-byte quads of a batch */
 constexpr uint32_t CHAIN_IO_WORDS = CHAIN_BATCH * 64; /* one array of one batch */
+constexpr uint32_t CHAIN_TAB_BYTES = 65536, CHAIN_TAB_C01 = 32768; /* a wave table in chain_kernel's LDS: [c3, c2] x 2048, then [c1, c0] x 2048 as f64 */
 constexpr size_t CHAIN_IO_BYTES = (size_t)(2 * 2 + 2) * CHAIN_IO_WORDS * 4; /* in[2][2] + out[2] */
 
 /* LDS layout of a batch array: frame 4q + r of lane l at word (q * 64 + l) * 4 + r -- a lane's four 16-byte
@@ -36,11 +37,11 @@ template <bool LDS_TAB, bool TAIL, bool SMALL>
 __device__ __forceinline__ void chain_batch(const uint4 *bq, const float4 *aq, float4 *sq, uint32_t t, uint32_t n,
 		uint32_t tab23, uint32_t tab01, const HerpC23 *g23, const HerpC01 *g01, float dscale, float doff,
 		uint32_t &prev_phase, double &prev_Is, float &prev_s, float &fb_s, float &fb_max) {
-	/* one 16-byte and one 8-byte LDS read per sample (ds_read_b128 / ds_read_b64): the entries are that aligned */
+	/* two 16-byte LDS reads per sample from one address: the table block holds [c3, c2] and, 32 KiB further on, [c1, c0]
+	 * widened to f64 when it was staged (CHAIN_TAB_BYTES) -- no conversion and one address computation less on and
+	 * beside the dependent chain: 110.5 -> 96.9 ns per step in the bare loop (tools/chain_probe2.hip, round 4) */
 	typedef double __attribute__((ext_vector_type(2))) f64x2;
-	typedef float __attribute__((ext_vector_type(2))) f32x2;
 	typedef const f64x2 __attribute__((address_space(3))) *lds_f64x2;
-	typedef const f32x2 __attribute__((address_space(3))) *lds_f32x2;
 #pragma unroll
 	for (int u = 0; u < (int)CHAIN_NQ; ++u) {
 		const uint32_t b4[4] = {bq[u].x, bq[u].y, bq[u].z, bq[u].w};
@@ -54,15 +55,16 @@ __device__ __forceinline__ void chain_batch(const uint4 *bq, const float4 *aq, f
 			const uint32_t phase = b4[j] + ofs;
 			const int32_t d = (int32_t)(phase - prev_phase);
 			const uint32_t ind = phase >> SLEN_BITS;
-			HerpC23 hi; HerpC01 lo;
+			double Isv;
 			if (LDS_TAB) {
-				const f64x2 c23 = *(lds_f64x2)(uintptr_t)(tab23 + ind * (uint32_t)sizeof(HerpC23));
-				const f32x2 c01 = *(lds_f32x2)(uintptr_t)(tab01 + ind * (uint32_t)sizeof(HerpC01));
-				hi.c3 = c23.x; hi.c2 = c23.y; lo.c1 = c01.x; lo.c0 = c01.y;
+				const uint32_t a = tab23 + ind * 16u;
+				const f64x2 c32 = *(lds_f64x2)(uintptr_t)a;
+				const f64x2 c10 = *(lds_f64x2)(uintptr_t)(a + CHAIN_TAB_C01);
+				const double x = (double)(phase & (SLEN - 1)); /* herp_poly (sau_dev_math.h), the same operations in the same order */
+				Isv = ((c32.x * x + c32.y) * x + c10.x) * x + c10.y;
 			} else {
-				hi = g23[ind]; lo = g01[ind];
+				Isv = herp_poly(g23[ind], g01[ind], phase);
 			}
-			const double Isv = herp_poly(hi, lo, phase);
 			const float sv_new = wosc_diff(Isv, prev_Is, d, dscale, doff);
 			bool hold = d == 0; /* wosc.h:292-293: a repeated phase holds the previous sample */
 			const bool act = !TAIL || t + (uint32_t)(4 * u + j) < n;
@@ -204,23 +206,22 @@ __global__ void __launch_bounds__(128) chain_kernel(FastParams P) {
 	if (P.range_mode && n > P.f_hi) n = P.f_hi;
 	if (n <= c_lo) n = 0;
 	if (!__any(n != 0)) return;
-	HerpC23 *t23 = (HerpC23 *)lds;
-	HerpC01 *t01 = (HerpC01 *)(lds + (size_t)P.n_ctabs * WAVE_LEN * sizeof(HerpC23));
-	uint32_t *io = (uint32_t *)(lds + (size_t)P.n_ctabs * WAVE_LEN * (sizeof(HerpC23) + sizeof(HerpC01)));
+	uint32_t *io = (uint32_t *)(lds + (size_t)P.n_ctabs * CHAIN_TAB_BYTES);
 	for (uint32_t t = 0; t < P.n_ctabs; ++t) {
+		typedef double __attribute__((ext_vector_type(2))) f64x2;
 		const uint32_t wave = P.cwave_of_tab[t];
 		const uint4 *s23 = (const uint4 *)(P.g_c23 + (size_t)wave * WAVE_LEN);
-		uint4 *d23 = (uint4 *)(t23 + (size_t)t * WAVE_LEN);
+		uint4 *d23 = (uint4 *)(lds + (size_t)t * CHAIN_TAB_BYTES);
 		for (uint32_t i = threadIdx.x; i < WAVE_LEN; i += 128) d23[i] = s23[i];
-		const uint2 *s01 = (const uint2 *)(P.g_c01 + (size_t)wave * WAVE_LEN);
-		uint2 *d01 = (uint2 *)(t01 + (size_t)t * WAVE_LEN);
-		for (uint32_t i = threadIdx.x; i < WAVE_LEN; i += 128) d01[i] = s01[i];
+		const HerpC01 *s01 = P.g_c01 + (size_t)wave * WAVE_LEN;
+		f64x2 *d01 = (f64x2 *)(lds + (size_t)t * CHAIN_TAB_BYTES + CHAIN_TAB_C01);
+		for (uint32_t i = threadIdx.x; i < WAVE_LEN; i += 128) { f64x2 v; v.x = (double)s01[i].c1; v.y = (double)s01[i].c0; d01[i] = v; }
 	}
 	const uint32_t wave = cd.wave < 12 ? cd.wave : 0;
 	const int ti = P.ctab_of_wave[wave];
 	const bool all_lds = __all(n == 0 || ti >= 0) != 0;
-	const uint32_t tab23 = (uint32_t)(uintptr_t)(t23 + (size_t)(ti >= 0 ? ti : 0) * WAVE_LEN);
-	const uint32_t tab01 = (uint32_t)(uintptr_t)(t01 + (size_t)(ti >= 0 ? ti : 0) * WAVE_LEN);
+	const uint32_t tab23 = (uint32_t)(uintptr_t)lds + (uint32_t)(ti >= 0 ? ti : 0) * CHAIN_TAB_BYTES;
+	const uint32_t tab01 = tab23 + CHAIN_TAB_C01;
 	const HerpC23 *g23 = P.g_c23 + (size_t)wave * WAVE_LEN;
 	const HerpC01 *g01 = P.g_c01 + (size_t)wave * WAVE_LEN;
 	const float dscale = P.wc[wave].diff_scale, doff = P.wc[wave].diff_offset;
