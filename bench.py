@@ -440,7 +440,14 @@ def run_config3(args, R, sa, tabs):
                      # the kernel is VALU-bound in fact -- issued VALU instructions x 4 cycles over
                      # SIMDs x launch cycles, from the same hash-matched PMC summary (tools/collect_profile.py)
                      "valu": valu,
-                     "kernel": "fast_kernel<8, 0>", "avg_launch_ms": launch_s * 1e3,
+                     "kernel": "fast_kernel<12, 0, false, true> (closed-form build, 12 rows per pass, wide table blocks in LDS)",
+                     "avg_launch_ms": launch_s * 1e3,
+                     # what `frac` is and is not: SURVEY 8d's convention prices every operator's block output as one
+                     # f32 write + one f32 read in HBM; this kernel keeps those blocks in LDS, so `achieved` can exceed what HBM
+                     # could carry -- the real HBM bytes per launch are `traffic` (voice rows only, about an eighth of the
+                     # algorithmic figure) and the kernel is bound by VALU issue (`valu.busy_frac`) and the LDS table gather
+                     "caveat": "algorithmic bytes (SURVEY 8d: 8 B per operator-sample + 2 B per frame) over the launch time; operator "
+                               "blocks stay in LDS, HBM carries the voice rows only (`traffic`); binding resources: VALU issue and LDS gather",
                      "launches": tm["segments"], "algorithmic_bytes_per_launch": alg_bytes},
         "ranks": ranks,
     }

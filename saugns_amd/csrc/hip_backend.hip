@@ -294,11 +294,7 @@ public:
 	~HipBackendImpl() override {
 		use_device();
 		/* the buffers go back to the pool (member destructors): nothing may still be using them */
-		if (mix_stream_) (void)hipStreamSynchronize(mix_stream_); /* (before stream_'s kernels are waited for: they may wait for its events) */
 		if (stream_) (void)hipStreamSynchronize(stream_);
-		if (mix_stream_) { (void)hipStreamSynchronize(mix_stream_); StreamPool::get().give(dev_, mix_stream_); }
-		for (MixSet &m : sets_) { if (m.ready) (void)hipEventDestroy(m.ready); if (m.done) (void)hipEventDestroy(m.done); }
-		for (int i = 0; i < 2; ++i) { if (copy_ev_[i]) (void)hipEventDestroy(copy_ev_[i]); if (pcm_mix_ev_[i]) (void)hipEventDestroy(pcm_mix_ev_[i]); }
 		if (chain_stream_) { (void)hipStreamSynchronize(chain_stream_); StreamPool::get().give(dev_, chain_stream_); }
 		for (hipEvent_t e : chain_ev_) (void)hipEventDestroy(e);
 		for (int i = 0; i < 4; ++i) if (fetch_ev_[i]) (void)hipEventDestroy(fetch_ev_[i]);
@@ -355,9 +351,6 @@ public:
 		if (const char *cf = tune_env("SAU_AMD_CHAIN_CHUNK_FRAMES")) { const int n = atoi(cf); if (n >= 4096) chain_chunk_frames_ = (uint32_t)n; }
 		two_pass_enabled_ = tune_env("SAU_AMD_NO_TWO_PASS") == nullptr; /* ... in two passes where possible */
 		if (const char *lr = tune_env("SAU_AMD_LEAN_ROWS")) lean_rows_ = (uint32_t)atoi(lr);
-		overlap_enabled_ = tune_env("SAU_AMD_MIX_OVERLAP") != nullptr && atoi(tune_env("SAU_AMD_MIX_OVERLAP")) != 0;
-		if (const char *mc = tune_env("SAU_AMD_MIX_CUS")) { const int n = atoi(mc); mix_cus_ = n >= 0 && n < 128 ? (uint32_t)n : 16u; }
-		if (const char *om = tune_env("SAU_AMD_MIX_OVERLAP_MIN")) overlap_min_ = (size_t)atoll(om);
 		mix_few_enabled_ = tune_env("SAU_AMD_NO_MIX_FEW") == nullptr;
 		lean_enabled_ = tune_env("SAU_AMD_NO_LEAN") == nullptr; /* chains' passes in a build without the several-pass sums */
 		dyn_enabled_ = tune_env("SAU_AMD_NO_DYN") == nullptr; /* closed-form launches deal tasks out through a counter */
@@ -382,20 +375,19 @@ public:
 
 	bool reserve_frames(uint32_t max_frames, bool stereo, std::string &err) override {
 		use_device();
-		if (!join_mix(err)) return false;
 		HIP_OK(hipStreamSynchronize(stream_));
 		row_stride_ = (max_frames + 63) & ~63u;
 		pcm_row_ = (size_t)row_stride_ * 2; /* room for stereo */
 		(void)stereo;
-		for (int i = 0; i < (overlap_enabled_ ? 2 : 1); ++i) {
-			if (!pcm_[i].ensure(pcm_row_ * cfg_.n_streams, err)) return false;
+		{
+			if (!pcm_.ensure(pcm_row_ * cfg_.n_streams, err)) return false;
 			/* on the generator's own stream: a memset on the null stream is not ordered with a non-blocking stream's kernels,
 			 * and it may still be at work (it is asynchronous for device memory) when the first mixer writes -- zeros in the
 			 * PCM from some page on, seen on the second and later generators of a process (pooled blocks come back at once,
 			 * a first hipMalloc takes long enough to hide it) */
-			HIP_OK(hipMemsetAsync(pcm_[i].p, 0, pcm_[i].cap * sizeof(int16_t), stream_));
+			HIP_OK(hipMemsetAsync(pcm_.p, 0, pcm_.cap * sizeof(int16_t), stream_));
 		}
-		sets_[0].vout_rows = sets_[1].vout_rows = 0; /* re-sized on the next render */
+		set_.vout_rows = 0; /* re-sized on the next render */
 		return true;
 	}
 
@@ -451,38 +443,7 @@ public:
 	bool clear_pcm(uint32_t frames, bool stereo, std::string &err) override {
 		use_device();
 		(void)frames; (void)stereo;
-		/* a new run: the other PCM block (the last run's mixers and copies may still be at work on this one) */
-		if (overlap_enabled_ && pcm_[pcm_cur_ ^ 1].p) pcm_cur_ ^= 1;
-		if (copy_pending_[pcm_cur_]) { HIP_OK(hipStreamWaitEvent(stream_, copy_ev_[pcm_cur_], 0)); copy_pending_[pcm_cur_] = false; }
-		if (pcm_mix_pending_[pcm_cur_]) { HIP_OK(hipStreamWaitEvent(stream_, pcm_mix_ev_[pcm_cur_], 0)); pcm_mix_pending_[pcm_cur_] = false; }
-		if (!overlap_enabled_ && !join_mix(err)) return false;
-		if (pcm_[pcm_cur_].p) HIP_OK(hipMemsetAsync(pcm_[pcm_cur_].p, 0, pcm_row_ * cfg_.n_streams * sizeof(int16_t), stream_));
-		return true;
-	}
-
-	/* stream_ goes on only after every mixer (and PCM copy) issued on mix_stream_ so far has finished */
-	bool join_mix(std::string &err) {
-		for (MixSet &m : sets_)
-			if (m.pending) { HIP_OK(hipStreamWaitEvent(stream_, m.done, 0)); m.pending = false; }
-		for (int i = 0; i < 2; ++i) {
-			if (pcm_mix_pending_[i]) { HIP_OK(hipStreamWaitEvent(stream_, pcm_mix_ev_[i], 0)); pcm_mix_pending_[i] = false; }
-			if (copy_pending_[i]) { HIP_OK(hipStreamWaitEvent(stream_, copy_ev_[i], 0)); copy_pending_[i] = false; }
-		}
-		return true;
-	}
-	bool mix_stream_ready(std::string &err) {
-		if (!mix_stream_) {
-			mix_stream_ = StreamPool::get().take(dev_);
-			if (!mix_stream_) HIP_OK(hipStreamCreateWithFlags(&mix_stream_, hipStreamNonBlocking));
-		}
-		for (MixSet &m : sets_) {
-			if (!m.ready) HIP_OK(hipEventCreateWithFlags(&m.ready, hipEventDisableTiming));
-			if (!m.done) HIP_OK(hipEventCreateWithFlags(&m.done, hipEventDisableTiming));
-		}
-		for (int i = 0; i < 2; ++i) {
-			if (!copy_ev_[i]) HIP_OK(hipEventCreateWithFlags(&copy_ev_[i], hipEventDisableTiming));
-			if (!pcm_mix_ev_[i]) HIP_OK(hipEventCreateWithFlags(&pcm_mix_ev_[i], hipEventDisableTiming));
-		}
+		if (pcm_.p) HIP_OK(hipMemsetAsync(pcm_.p, 0, pcm_row_ * cfg_.n_streams * sizeof(int16_t), stream_));
 		return true;
 	}
 
@@ -553,11 +514,7 @@ public:
 		}
 		const size_t lds = n_tabs * tab_bytes + fixed;
 		/* device buffers */
-		MixSet &S = sets_[cur_];
-		if (S.pending) { /* the mixer that read this set two segments ago */
-			HIP_OK(hipStreamWaitEvent(stream_, S.done, 0));
-			S.pending = false;
-		}
+		MixSet &S = set_;
 		if (!voices_.ensure(seg.n_voices, err) || !S.vinfo.ensure(seg.n_voices, err)) return false;
 		if (seg.n_voices > S.vout_rows || !S.vout.p) {
 			HIP_OK(hipStreamSynchronize(stream_));
@@ -578,7 +535,7 @@ public:
 			m.n_rows = seg.streams[s].n_voices;
 			m.amp_scale = seg.streams[s].amp_scale;
 			m.write_len = seg.streams[s].write_len;
-			m.pcm = pcm_[pcm_cur_].p + pcm_row_ * s;
+			m.pcm = pcm_.p + pcm_row_ * s;
 			if (m.write_len > max_write) max_write = m.write_len;
 			if (m.n_rows > max_rows) max_rows = m.n_rows;
 		}
@@ -1001,12 +958,7 @@ public:
 				} else {
 					/* closed-form voices only: tasks of about eight row groups, dealt out by a counter */
 					if (main_build == 0) set_tasks(fp, groups, fgrid);
-					/* the last segment's mixer is at work on mix_cus_ CUs: this launch takes the others (its tasks are dealt
-					 * out by a counter, so a smaller grid just means more tasks per wave) */
-					uint32_t g0 = 0;
-					if (fp.dyn_chunks && !fp.dyn_static && mix_cus_ && (sets_[cur_ ^ 1].pending) && fgrid + mix_cus_ > fk_grid_ && fk_grid_ > mix_cus_ + 32)
-						g0 = fk_grid_ - mix_cus_;
-					launch_fast(0, g0);
+					launch_fast(0);
 					fp.dyn_chunks = 0;
 				}
 				{ /* closed-form voices with the loop tails of `cub` R segments (FastInfo.cub): the build with that code,
@@ -1108,31 +1060,19 @@ public:
 			mp.row_stride = row_stride_; mp.pcm_offset = seg.pcm_offset;
 			mp.stereo = seg.stereo ? 1 : 0;
 			mp.swap_bytes = seg.swap_bytes ? 1 : 0;
-			/* a large segment's mixer goes to the other stream: the next segment (or run) starts beside it, on the other set */
-			const bool beside = overlap_enabled_ && pcm_[1].p && (size_t)max_write * seg.n_voices >= overlap_min_ && mix_stream_ready(err);
-			hipStream_t ms = beside ? mix_stream_ : stream_;
-			if (beside) {
-				HIP_OK(hipEventRecord(S.ready, stream_));
-				HIP_OK(hipStreamWaitEvent(mix_stream_, S.ready, 0));
-			}
+			/* (on the generator's one stream, behind the segment's kernels. Round 3 built the mixer on a stream of its own beside the
+			 * next segment's kernels -- ordinary grid or persistent on a few CUs, everything it reads and writes double-buffered --
+			 * and measured it no faster in any form, profiles/r03_headline_ab.json; that code is gone since round 4.) */
+			hipStream_t ms = stream_;
 			TimedPair *tm = timing_on_ ? new_pair(1) : nullptr;
 			if (tm) (void)hipEventRecord(tm->a, ms);
-			if (beside && mix_cus_) /* a workgroup per CU the next segment's kernel leaves free (fk_reserve_) */
-				hipLaunchKernelGGL(mix_persist_kernel, dim3(mix_cus_, seg.n_streams), dim3(1024), 0, ms, mp);
-			else if (mix_few_enabled_ && max_rows <= 8 && seg.n_streams >= 8 && (seg.pcm_offset & 3u) == 0 && (pcm_row_ & 3u) == 0)
+			if (mix_few_enabled_ && max_rows <= 8 && seg.n_streams >= 8 && (seg.pcm_offset & 3u) == 0 && (pcm_row_ & 3u) == 0)
 				/* many streams of a few voices each: four frames per thread, no tile staging (k_finish.h) */
 				hipLaunchKernelGGL(mix_few_kernel, dim3((max_write + 1023) / 1024, seg.n_streams), dim3(256), 0, ms, mp);
 			else
 				hipLaunchKernelGGL(mix_kernel, dim3((max_write + 255) / 256, seg.n_streams), dim3(256), 0, ms, mp);
 			HIP_OK(hipGetLastError());
 			if (tm) (void)hipEventRecord(tm->b, ms);
-			if (beside) {
-				HIP_OK(hipEventRecord(S.done, mix_stream_));
-				S.pending = true;
-				HIP_OK(hipEventRecord(pcm_mix_ev_[pcm_cur_], mix_stream_));
-				pcm_mix_pending_[pcm_cur_] = true;
-				cur_ ^= 1;
-			}
 		}
 		return true;
 	}
@@ -1144,8 +1084,7 @@ public:
 		 * pinning per call, so the PCM goes through a page-locked block (unless dst is one) */
 		const bool pinned = host_blocks_.count(dst) != 0;
 		if (!pinned && !h_pcm_.ensure(n, err)) return false;
-		if (!join_mix(err)) return false;
-		HIP_OK(hipMemcpyAsync(pinned ? dst : h_pcm_.p, pcm_[pcm_cur_].p + pcm_row_ * stream, n * sizeof(int16_t),
+		HIP_OK(hipMemcpyAsync(pinned ? dst : h_pcm_.p, pcm_.p + pcm_row_ * stream, n * sizeof(int16_t),
 				hipMemcpyDeviceToHost, stream_));
 		HIP_OK(hipStreamSynchronize(stream_));
 		if (!pinned) memcpy(dst, h_pcm_.p, n * sizeof(int16_t));
@@ -1159,22 +1098,10 @@ public:
 		slot &= 3;
 		use_device();
 		if (!fetch_ev_[slot]) HIP_OK(hipEventCreateWithFlags(&fetch_ev_[slot], hipEventDisableTiming));
-		/* with mixers on mix_stream_ the copy follows them there, so that stream_ is free to start the next run */
-		const bool beside = sets_[0].pending || sets_[1].pending || pcm_mix_pending_[pcm_cur_];
 		hipStream_t cs = stream_;
-		if (beside) {
-			if (!mix_stream_ready(err)) return false;
-			HIP_OK(hipEventRecord(copy_ev_[pcm_cur_], stream_)); /* (whatever this run put on stream_, small segments' mixers included) */
-			HIP_OK(hipStreamWaitEvent(mix_stream_, copy_ev_[pcm_cur_], 0));
-			cs = mix_stream_;
-		}
-		HIP_OK(hipMemcpyAsync(dst, pcm_[pcm_cur_].p + pcm_row_ * stream,
+		HIP_OK(hipMemcpyAsync(dst, pcm_.p + pcm_row_ * stream,
 				(size_t)frames * (stereo ? 2 : 1) * sizeof(int16_t), hipMemcpyDeviceToHost, cs));
 		HIP_OK(hipEventRecord(fetch_ev_[slot], cs));
-		if (beside) {
-			HIP_OK(hipEventRecord(copy_ev_[pcm_cur_], mix_stream_)); /* the next run into this PCM block waits for it (clear_pcm) */
-			copy_pending_[pcm_cur_] = true;
-		}
 		return true;
 	}
 	bool wait_fetch(int slot, std::string &err) override {
@@ -1193,17 +1120,15 @@ public:
 		use_device();
 		auto it = host_blocks_.find(p);
 		if (it == host_blocks_.end()) return;
-		if (mix_stream_) (void)hipStreamSynchronize(mix_stream_);
 		(void)hipStreamSynchronize(stream_);
 		pool_free(true, p, it->second);
 		host_blocks_.erase(it);
 	}
 
-	const int16_t *device_pcm(uint32_t stream) override { return pcm_[pcm_cur_].p ? pcm_[pcm_cur_].p + pcm_row_ * stream : nullptr; }
+	const int16_t *device_pcm(uint32_t stream) override { return pcm_.p ? pcm_.p + pcm_row_ * stream : nullptr; }
 
 	bool sync(std::string &err) override {
 		use_device();
-		if (!join_mix(err)) return false;
 		HIP_OK(hipStreamSynchronize(stream_));
 		arena_used_ = 0; /* every staged copy has left the arena */
 		return true;
@@ -1211,7 +1136,6 @@ public:
 
 	void timing(double *render_ms, double *mix_ms, uint64_t *launches, bool reset) override {
 		if (!timing_on_) { timing_on_ = true; }
-		{ std::string e; (void)join_mix(e); }
 		(void)hipStreamSynchronize(stream_);
 		drain_pairs();
 		if (render_ms) *render_ms = acc_ms_[0] + acc_ms_[2];
@@ -1225,7 +1149,6 @@ public:
 
 	void timing_ex(double *out4, uint64_t *segments, bool reset) override {
 		if (!timing_on_) timing_on_ = true;
-		{ std::string e; (void)join_mix(e); }
 		(void)hipStreamSynchronize(stream_);
 		drain_pairs();
 		/* out: time-parallel kernel, block-loop kernel, mixer, analyze+finalize (ms) */
@@ -1263,11 +1186,11 @@ public:
 			std::vector<VoiceOut> vi(seg.n_voices < 4 ? seg.n_voices : 4);
 			std::vector<uint32_t> fd(vi.size());
 			std::vector<FastInfo> fi(vi.size());
-			(void)hipMemcpy(vi.data(), sets_[cur_].vinfo.p, vi.size() * sizeof(VoiceOut), hipMemcpyDeviceToHost);
+			(void)hipMemcpy(vi.data(), set_.vinfo.p, vi.size() * sizeof(VoiceOut), hipMemcpyDeviceToHost);
 			(void)hipMemcpy(fd.data(), fdone_.p, fd.size() * 4, hipMemcpyDeviceToHost);
 			(void)hipMemcpy(fi.data(), finfo_.p, fi.size() * sizeof(FastInfo), hipMemcpyDeviceToHost);
 			float v8[8] = {0};
-			(void)hipMemcpy(v8, sets_[cur_].vout.p, sizeof v8, hipMemcpyDeviceToHost);
+			(void)hipMemcpy(v8, set_.vout.p, sizeof v8, hipMemcpyDeviceToHost);
 			fprintf(stderr, "  work_count %u block_grid %u; row0: %g %g %g %g %g %g\n", wc, block_grid_, v8[0], v8[1],
 					v8[2], v8[3], v8[4], v8[5]);
 			for (size_t v = 0; v < vi.size(); ++v)
@@ -1293,7 +1216,7 @@ private:
 	TimedPair *new_pair(int kind) {
 		if (timing_level_ == 1 && kind != 2) return nullptr; /* level 1: dominant kernel only */
 		if (n_used_ == events_.size()) {
-			if (events_.size() >= 4096) { std::string e; (void)join_mix(e); (void)hipStreamSynchronize(stream_); drain_pairs(); }
+			if (events_.size() >= 4096) { (void)hipStreamSynchronize(stream_); drain_pairs(); }
 			else {
 				TimedPair p; p.kind = 0; p.used = false;
 				if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return nullptr;
@@ -1328,18 +1251,7 @@ private:
 	uint32_t n_steps_total_ = 0;
 	DevBuf<uint32_t> op_ids_;
 	DevBuf<VoiceDesc> voices_;
-	/* What the mixer reads -- voice rows, pan rows, per-row records, stream records -- exists twice, and so does the PCM it
-	 * writes: the mixer of a large segment runs on a stream of its own (mix_stream_), beside the next segment's
-	 * time-parallel kernel, which fills the other set (the mixer is bound by HBM, that kernel by the VALUs). A set is
-	 * written again only after the mixer that read it has finished (stream_ waits for its event); everything that
-	 * reads PCM or frees buffers joins the mixers first (join_mix).
-	 * OFF by default (SAU_AMD_MIX_OVERLAP=1 turns it on), because it does not pay on this chip (r03, BASELINE config 3,
-	 * 441000-frame steps, same box): one stream 2.88-2.91 ms per step; the mixer on its own stream with an ordinary
-	 * grid 2.93-2.94 (fast_kernel's 1024-thread, 128-VGPR workgroups need whole CUs, the mixer's small ones get
-	 * there first, and the two end up one after the other); a persistent mixer on mix_cus_ CUs beside a grid of
-	 * 256 - mix_cus_ workgroups: 8 CUs 5.93, 12: 4.43, 16: 3.68, 24: 3.07, 32: 3.09 (a CU pulls about 30 GB/s of
-	 * these row reads, so the mixer needs 24+ CUs to keep up, and those cost the other kernel 10 %); a register
-	 * diet that would let the two share SIMDs (96 VGPRs) slows fast_kernel by 8-40 %. profiles/r03_headline_ab.json. */
+	/* what the mixer reads: voice rows, pan rows, per-row records, stream records */
 	struct MixSet {
 		DevBuf<float> vout, pan;
 		DevBuf<VoiceOut> vinfo;
@@ -1347,21 +1259,9 @@ private:
 		uint32_t vout_rows = 0;
 		std::vector<MixStream> ms_sent;
 		const void *ms_dev = nullptr;
-		hipEvent_t ready = nullptr, done = nullptr; /* the segment's kernels have written it / its mixer has read it */
-		bool pending = false;                        /* `done` has been recorded on mix_stream_ and not been waited for */
 	};
-	MixSet sets_[2];
-	int cur_ = 0;                 /* the set the next segment writes */
-	DevBuf<int16_t> pcm_[2];      /* alternating per run (clear_pcm): the mixers of run n may still write one while run n + 1 starts */
-	int pcm_cur_ = 0;
-	hipStream_t mix_stream_ = nullptr;
-	hipEvent_t copy_ev_[2] = {nullptr, nullptr}; /* the last copy out of pcm_[i] that went through mix_stream_ */
-	bool copy_pending_[2] = {false, false};
-	hipEvent_t pcm_mix_ev_[2] = {nullptr, nullptr}; /* the last mixer on mix_stream_ that wrote pcm_[i] */
-	bool pcm_mix_pending_[2] = {false, false};
-	bool overlap_enabled_ = false; /* SAU_AMD_MIX_OVERLAP=1 (off: measured no faster, see the comment above and profiles/r03_headline_ab.json) */
-	uint32_t mix_cus_ = 16;       /* SAU_AMD_MIX_CUS: CUs a mixer on mix_stream_ gets (0: an ordinary grid wherever it finds room) */
-	size_t overlap_min_ = (size_t)1 << 24; /* voice-frames of a segment from which its mixer takes the other stream */
+	MixSet set_;
+	DevBuf<int16_t> pcm_;
 	DevBuf<OpUpdate> recs_;
 	const TableSet *tables_ = nullptr;
 	PinBuf<int16_t> h_pcm_; /* fetch_pcm() staging */

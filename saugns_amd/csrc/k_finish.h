@@ -141,12 +141,9 @@ struct MixParams {
 #endif
 constexpr int MIX_TILE = 256; /* voices whose constants are staged at a time */
 constexpr int MIX_AHEAD = 32; /* loads per batch and thread */
-/* PERSIST: a few workgroups (MixParams.grid_x of them) walk the frames in strides -- the form that runs beside the next
- * segment's time-parallel kernel on the handful of CUs that kernel's grid leaves free (hip_backend.hip, MixSet). */
-template <bool PERSIST>
 __device__ __forceinline__ void mix_body(const MixParams &P, const MixStream &ms, const uint32_t bx,
 		float *s_pan, uint32_t *s_valid, uint32_t *s_prow, uint32_t &s_special) {
-	const uint32_t tl = PERSIST ? (threadIdx.x & 255u) : threadIdx.x; /* within the 256 frames of bx */
+	const uint32_t tl = threadIdx.x; /* within the 256 frames of bx */
 	const uint32_t i = bx * 256 + tl;
 	const bool act = i < ms.write_len;
 	float L = 0.f, R = 0.f;
@@ -247,7 +244,7 @@ __global__ void __launch_bounds__(256) mix_kernel(MixParams P) {
 	__shared__ uint32_t s_special;        /* tile has a short row or a pan row */
 	const MixStream ms = P.streams[blockIdx.y];
 	if (blockIdx.x * 256 >= ms.write_len) return;
-	mix_body<false>(P, ms, blockIdx.x, s_pan, s_valid, s_prow, s_special);
+	mix_body(P, ms, blockIdx.x, s_pan, s_valid, s_prow, s_special);
 }
 
 /* Streams of a few voices each (a batch of many small scripts: BASELINE config 4 has two voices per render): four
@@ -313,21 +310,6 @@ __global__ void __launch_bounds__(256) mix_few_kernel(MixParams P) {
 		int16_t *d = ms.pcm + (size_t)(P.pcm_offset + i0);
 		if (full) *(uint2 *)d = *(const uint2 *)o;
 		else for (uint32_t k = 0; i0 + k < ms.write_len; ++k) d[k] = o[k];
-	}
-}
-
-/* four 256-thread mixers per workgroup, each with its own tile arrays; a workgroup per CU the other kernel leaves free */
-__global__ void __launch_bounds__(1024) mix_persist_kernel(MixParams P) {
-	__shared__ float s_pan[4][MIX_TILE];
-	__shared__ uint32_t s_valid[4][MIX_TILE];
-	__shared__ uint32_t s_prow[4][MIX_TILE];
-	__shared__ uint32_t s_special[4];
-	const MixStream ms = P.streams[blockIdx.y];
-	const uint32_t n_bx = (ms.write_len + 255) / 256;
-	/* every thread of the workgroup makes the same number of rounds (mix_body has workgroup barriers) */
-	for (uint32_t b0 = blockIdx.x * 4; b0 < n_bx; b0 += gridDim.x * 4) {
-		const uint32_t q = threadIdx.x >> 8;
-		mix_body<true>(P, ms, b0 + q, s_pan[q], s_valid[q], s_prow[q], s_special[q]);
 	}
 }
 

@@ -759,8 +759,8 @@ def test_ratio_chains_below_modulated_frequencies(sa, oracle):
                                  {"SAU_AMD_LOOK_MIN_VOICES": "1"}, {"SAU_AMD_LOOK_MIN_VOICES": "1", "SAU_AMD_LOOK_ROWS": "4"},
                                  {"SAU_AMD_LOOK_NO_LDS": "1"}, {"SAU_AMD_NO_DYN": "1"}, {"SAU_AMD_DYN_GROUPS": "1"},
                                  {"SAU_AMD_NO_LEAN": "1"},
-                                 {"SAU_AMD_MIX_OVERLAP": "1", "SAU_AMD_MIX_OVERLAP_MIN": "1"},
-                                 {"SAU_AMD_MIX_OVERLAP": "1", "SAU_AMD_MIX_OVERLAP_MIN": "1", "SAU_AMD_MIX_CUS": "0"}])
+                                 # round 4's forms of the closed-form build: narrow tables, 8 and 10 rows per pass
+                                 {"SAU_AMD_NO_WIDE_TABS": "1"}, {"SAU_AMD_MORE_ROWS": "0"}, {"SAU_AMD_MORE_ROWS": "10"}])
 def test_random_graphs_in_other_kernel_configurations(sa, oracle, env):
     """The random programs with events through the other builds and modes of the kernels: two rows per
     pass, running sums by one wave in order, no running sums in the time-parallel path at all, a
