@@ -338,7 +338,7 @@ public:
 		fast_enabled_ = tune_env("SAU_AMD_NO_FAST") == nullptr;
 		seq_enabled_ = tune_env("SAU_AMD_NO_SEQ") == nullptr; /* running-sum phases in the time-parallel kernel */
 		chain_enabled_ = tune_env("SAU_AMD_NO_CHAIN") == nullptr; /* feedback recurrences with lanes = voices */
-		chain_inline_ = tune_env("SAU_AMD_CHAIN_INLINE") != nullptr;
+		chain_inline_ = tune_env("SAU_AMD_NO_CHAIN_INLINE") == nullptr; /* chains fed from their own lines: chain_kernel's feeder waves evaluate them */
 		chain_early_ = tune_env("SAU_AMD_NO_EARLY_CHAINS") == nullptr;
 		inc_rows_enabled_ = tune_env("SAU_AMD_NO_INC_ROWS") == nullptr;
 		lookback_enabled_ = tune_env("SAU_AMD_NO_LOOKBACK") == nullptr; /* single-pass running sums */
@@ -888,7 +888,7 @@ public:
 						const size_t clds = (size_t)fp.n_ctabs * CHAIN_TAB_BYTES + CHAIN_IO_BYTES;
 						if (!raise_lds_attr((const void *)chain_kernel, clds, chain_lds_configured_[dev_ & 15], err)) return false;
 						fp.chain_early = 1; fp.range_mode = 0;
-						hipLaunchKernelGGL(chain_kernel, dim3((seg.n_chain_rows + 63) / 64), dim3(128), clds, stream_, fp);
+						hipLaunchKernelGGL(chain_kernel, dim3((seg.n_chain_rows + 63) / 64), dim3(192), clds, stream_, fp);
 						hipLaunchKernelGGL(rchain_kernel, dim3((seg.n_chain_rows + 63) / 64), dim3(64), 0, stream_, fp); /* R feedback */
 						fp.chain_early = 0;
 					}
@@ -927,7 +927,7 @@ public:
 							fp.range_mode = 0;
 							launch_fast(fp.sum_levels + 2);
 							if (tc) (void)hipEventRecord(tc->a, stream_);
-							hipLaunchKernelGGL(chain_kernel, dim3(cgrid), dim3(128), clds, stream_, fp);
+							hipLaunchKernelGGL(chain_kernel, dim3(cgrid), dim3(192), clds, stream_, fp);
 							if (tc) (void)hipEventRecord(tc->b, stream_);
 							launch_fast(fp.sum_levels + 1);
 						} else {
@@ -940,7 +940,7 @@ public:
 								FastParams cp = fp;
 								cp.range_mode = 1; cp.f_lo = c * clen; cp.f_hi = c + 1 == n_chunks ? 0xffffffffu : (c + 1) * clen;
 								if (tc && c == 0) (void)hipEventRecord(tc->a, chain_stream_);
-								hipLaunchKernelGGL(chain_kernel, dim3(cgrid), dim3(128), clds, chain_stream_, cp);
+								hipLaunchKernelGGL(chain_kernel, dim3(cgrid), dim3(192), clds, chain_stream_, cp);
 								if (tc && c + 1 == n_chunks) (void)hipEventRecord(tc->b, chain_stream_);
 								HIP_OK(hipEventRecord(chain_ev_[2 * c + 1], chain_stream_));
 							}

@@ -33,10 +33,10 @@ __device__ __forceinline__ uint32_t chain_io_word(uint32_t q, int l) { return (q
 /* SMALL: every feedback offset of the batch is known to stay below 2^20 cycles in magnitude, where the short
  * rounding form is exact (rint32w_p31_small) -- no per-sample test on the chain; the caller verifies the bound
  * it assumed for |fb_s| afterwards (fb_max) and redoes the batch without SMALL if it was exceeded. */
-template <bool LDS_TAB, bool TAIL, bool SMALL>
+template <bool LDS_TAB, bool TAIL, bool SMALL, int INL /* 0: no lane sums increments, 1: every lane does, 2: some do (`inl`) */>
 __device__ __forceinline__ void chain_batch(const uint4 *bq, const float4 *aq, float4 *sq, uint32_t t, uint32_t n,
 		uint32_t tab23, uint32_t tab01, const HerpC23 *g23, const HerpC01 *g01, float dscale, float doff,
-		uint32_t &prev_phase, double &prev_Is, float &prev_s, float &fb_s, float &fb_max) {
+		uint32_t &prev_phase, double &prev_Is, float &prev_s, float &fb_s, float &fb_max, const bool inl, uint32_t &acc) {
 	/* two 16-byte LDS reads per sample from one address: the table block holds [c3, c2] and, 32 KiB further on, [c1, c0]
 	 * widened to f64 when it was staged (CHAIN_TAB_BYTES) -- no conversion and one address computation less on and
 	 * beside the dependent chain: 110.5 -> 96.9 ns per step in the bare loop (tools/chain_probe2.hip, round 4) */
@@ -52,7 +52,9 @@ __device__ __forceinline__ void chain_batch(const uint4 *bq, const float4 *aq, f
 			const float p = fb_s * a4[j];
 			uint32_t ofs = rint32w_p31_small(p);
 			if (!SMALL) { if (__builtin_expect(!(fabsf(p) < 0x1p20f), 0)) ofs = rint32w(p * 0x1p31f); }
-			const uint32_t phase = b4[j] + ofs;
+			/* (inline chains: the rows of LDS hold increments, summed here -- beside the dependent chain, not on it) */
+			const uint32_t acc_n = INL ? acc + b4[j] : 0u;
+			const uint32_t phase = (INL == 1 ? acc_n : INL == 2 ? (inl ? acc_n : b4[j]) : b4[j]) + ofs;
 			const int32_t d = (int32_t)(phase - prev_phase);
 			const uint32_t ind = phase >> SLEN_BITS;
 			double Isv;
@@ -68,6 +70,7 @@ __device__ __forceinline__ void chain_batch(const uint4 *bq, const float4 *aq, f
 			const float sv_new = wosc_diff(Isv, prev_Is, d, dscale, doff);
 			bool hold = d == 0; /* wosc.h:292-293: a repeated phase holds the previous sample */
 			const bool act = !TAIL || t + (uint32_t)(4 * u + j) < n;
+			if (INL) acc = (TAIL && !act) ? acc : acc_n; /* (wosc.h:145: pre-increment; stands still past the chain's last frame) */
 			if (TAIL) hold = hold || !act;
 			const float sv = hold ? prev_s : sv_new;
 			prev_Is = hold ? prev_Is : Isv;
@@ -84,59 +87,119 @@ __device__ __forceinline__ void chain_batch(const uint4 *bq, const float4 *aq, f
 
 /* Sixteen consecutive values of a line, frames [t, t + 16) of the segment. Lanes hold different lines: the shape
  * is tested once per batch and shape (not once per value), each shape's loop compiled with its type known. */
-template <uint32_t TYPE>
+template <uint32_t TYPE, uint32_t N>
 __device__ __forceinline__ void line_batch_shape(const FastLine &fl, uint32_t t, float *out) {
 	if (fl.sw.type != TYPE) return;
 	Sweep sw = fl.sw;
 	sw.type = TYPE;
+	/* (every value computed and then selected -- one straight run of independent polynomials the scheduler can interleave;
+	 * with a branch per value the feeder wave, alone on its SIMD, paid every instruction's latency: round 4) */
 #pragma unroll
-	for (uint32_t j = 0; j < CHAIN_BATCH; ++j)
-		if (t + j < fl.goal_len) out[j] = sweep_value_inl<true>(sw, t + j);
+	for (uint32_t j = 0; j < N; ++j) {
+		const float v = sweep_value_inl<true>(sw, t + j);
+		out[j] = t + j < fl.goal_len ? v : out[j];
+	}
 }
+/* xpe / lge (what `exp` and `log` sweeps resolve to, sau/line.c:125-148: the usual glide) stage by stage over the batch:
+ * sweep_value_inl's operations in its order, value by value the same -- but written as thirteen runs of independent
+ * instructions, so that the wave, alone on its SIMD, issues back to back instead of waiting out each value's dependent
+ * chain (round 4: the value-by-value form cost the inline feeder 4 us of a 32-frame batch, the chain wave needs 3.4) */
+template <bool XPE, uint32_t N>
+__device__ __forceinline__ void line_batch_exp(const FastLine &fl, uint32_t t, float *out) {
+	if (fl.sw.type != (XPE ? LN_xpe : LN_lge)) return;
+	const Sweep sw = fl.sw;
+	const float d = XPE ? (sw.v0 - sw.vt) : (sw.vt - sw.v0), base = XPE ? sw.vt : sw.v0;
+	float x[N], x2[N], x3[N], p[N];
+#pragma unroll
+	for (uint32_t j = 0; j < N; ++j) x[j] = (float)(t + j + sw.pos) * sw.inv_time;
+	if (XPE) {
+#pragma unroll
+		for (uint32_t j = 0; j < N; ++j) x[j] = 1.f - x[j];
+	}
+#pragma unroll
+	for (uint32_t j = 0; j < N; ++j) x2[j] = x[j] * x[j];
+#pragma unroll
+	for (uint32_t j = 0; j < N; ++j) x3[j] = x2[j] * x[j];
+#pragma unroll
+	for (uint32_t j = 0; j < N; ++j) p[j] = x[j] * (629.f / 1792.f);
+#pragma unroll
+	for (uint32_t j = 0; j < N; ++j) x[j] = x2[j] * (1163.f / 1792.f);
+#pragma unroll
+	for (uint32_t j = 0; j < N; ++j) p[j] = p[j] + x[j];
+#pragma unroll
+	for (uint32_t j = 0; j < N; ++j) x[j] = x3[j] + -1.f;
+#pragma unroll
+	for (uint32_t j = 0; j < N; ++j) p[j] = p[j] * x[j];
+#pragma unroll
+	for (uint32_t j = 0; j < N; ++j) p[j] = p[j] * x2[j];
+#pragma unroll
+	for (uint32_t j = 0; j < N; ++j) p[j] = x3[j] + p[j];
+#pragma unroll
+	for (uint32_t j = 0; j < N; ++j) p[j] = d * p[j];
+#pragma unroll
+	for (uint32_t j = 0; j < N; ++j) p[j] = base + p[j];
+#pragma unroll
+	for (uint32_t j = 0; j < N; ++j) out[j] = t + j < fl.goal_len ? p[j] : out[j];
+}
+template <uint32_t N>
 __device__ __forceinline__ void line_batch(const FastLine &fl, uint32_t t, float *out) {
 #pragma unroll
-	for (uint32_t j = 0; j < CHAIN_BATCH; ++j) out[j] = fl.hold;
+	for (uint32_t j = 0; j < N; ++j) out[j] = fl.hold;
 	if (t >= fl.goal_len) return;
-	line_batch_shape<LN_cos>(fl, t, out); line_batch_shape<LN_lin>(fl, t, out); line_batch_shape<LN_sah>(fl, t, out);
-	line_batch_shape<LN_xpe>(fl, t, out); line_batch_shape<LN_lge>(fl, t, out); line_batch_shape<LN_sqe>(fl, t, out);
-	line_batch_shape<LN_cub>(fl, t, out); line_batch_shape<LN_smo>(fl, t, out); line_batch_shape<LN_ncl>(fl, t, out);
-	line_batch_shape<LN_nhl>(fl, t, out); line_batch_shape<LN_uwh>(fl, t, out);
+	line_batch_shape<LN_cos, N>(fl, t, out); line_batch_shape<LN_lin, N>(fl, t, out); line_batch_shape<LN_sah, N>(fl, t, out);
+	line_batch_exp<true, N>(fl, t, out); line_batch_exp<false, N>(fl, t, out); line_batch_shape<LN_sqe, N>(fl, t, out);
+	line_batch_shape<LN_cub, N>(fl, t, out); line_batch_shape<LN_smo, N>(fl, t, out); line_batch_shape<LN_ncl, N>(fl, t, out);
+	line_batch_shape<LN_nhl, N>(fl, t, out); line_batch_shape<LN_uwh, N>(fl, t, out);
 	/* (LN_exp / LN_log were resolved to xpe / lge when the sweep was set up: sau/line.c:125-148) */
 }
 
 /* the feeder's share of one batch: inputs of frames [t, t + 16) into the LDS arrays */
 __device__ __forceinline__ void chain_feed(const ChainDesc &cd, bool live, int l, uint32_t t, uint32_t *acc,
-		const uint4 *bp, const float4 *ap, uint32_t *in_base, float *in_amt) {
+		const uint4 *bp, const float4 *ap, uint32_t *in_base, float *in_amt, const uint32_t half) {
 	if (!live) return;
 	uint32_t a = *acc, a_end = *acc; /* a_end: the accumulator after the segment's last frame, should it fall in this batch */
 	if (cd.mode == CM_INLINE) {
-		/* frequency and amounts from the operator's own lines (sau/line.c fills are functions of the position) */
-		float fv[CHAIN_BATCH], m[CHAIN_BATCH];
-		uint32_t b[CHAIN_BATCH];
-		line_batch(cd.pl, t, m);
-		if (!(cd.lflags & CL_FCONST)) line_batch(cd.fl, t, fv);
+		/* Frequency and amounts from the operator's own lines (sau/line.c fills are functions of the position). Two feeder
+		 * waves share a batch, half its frames each (`half`): a wave alone on its SIMD pays its instructions' latencies, and
+		 * one wave took 5 us for the 32 frames the chain wave consumes in 3.4 (round 4). What goes to LDS are phase
+		 * *increments*: the chain wave sums them itself (chain_batch: `inl`), so neither half waits for the other's sum. */
+		constexpr uint32_t HB = CHAIN_BATCH / 2, HQ = CHAIN_NQ / 2;
+		const uint32_t th = t + half * HB;
+		float fv[HB], m[HB];
+		uint32_t incs[HB];
+		line_batch<HB>(cd.pl, th, m);
+		if (!(cd.lflags & CL_FCONST)) {
+			line_batch<HB>(cd.fl, th, fv);
+			float x[HB];
+			bool big = false;
+			const bool any_mul = (cd.lflags & (CL_MUL_GOAL | CL_MUL_HOLD)) != 0;
 #pragma unroll
-		for (uint32_t j = 0; j < CHAIN_BATCH; ++j) {
-			const uint32_t i = t + j;
-			uint32_t inc = cd.inc_const;
-			if (!(cd.lflags & CL_FCONST)) {
+			for (uint32_t j = 0; j < HB; ++j) {
 				float v = fv[j];
-				if (cd.lflags & (i < cd.fl.goal_len ? CL_MUL_GOAL : CL_MUL_HOLD)) v *= cd.mulc;
-				const float x = cd.coeff * v;
-				inc = fabsf(x) < 0x1p50f ? (uint32_t)__double2loint((double)x + 0x1.8p52) : rint32w(x);
+				if (any_mul) v = (th + j < cd.fl.goal_len) ? ((cd.lflags & CL_MUL_GOAL) ? v * cd.mulc : v) : ((cd.lflags & CL_MUL_HOLD) ? v * cd.mulc : v);
+				x[j] = cd.coeff * v;
+				big |= !(fabsf(x[j]) < 0x1p50f);
 			}
-			a += inc; /* wosc.h:145: pre-increment */
-			if (i < cd.n) a_end = a;
-			b[j] = a;
+			/* llrintf(x) mod 2^32 (wosc.h:145): one test per batch for the rounding form */
+			if (!__any(big)) {
+#pragma unroll
+				for (uint32_t j = 0; j < HB; ++j) incs[j] = (uint32_t)__double2loint((double)x[j] + 0x1.8p52);
+			} else {
+#pragma unroll
+				for (uint32_t j = 0; j < HB; ++j) incs[j] = rint32w(x[j]);
+			}
+		} else {
+#pragma unroll
+			for (uint32_t j = 0; j < HB; ++j) incs[j] = cd.inc_const;
 		}
 #pragma unroll
-		for (uint32_t q = 0; q < CHAIN_NQ; ++q) {
-			*(uint4 *)(in_base + chain_io_word(q, l)) = make_uint4(b[4 * q], b[4 * q + 1], b[4 * q + 2], b[4 * q + 3]);
-			*(float4 *)(in_amt + chain_io_word(q, l)) = make_float4(m[4 * q], m[4 * q + 1], m[4 * q + 2], m[4 * q + 3]);
+		for (uint32_t q = 0; q < HQ; ++q) {
+			*(uint4 *)(in_base + chain_io_word(half * HQ + q, l)) = make_uint4(incs[4 * q], incs[4 * q + 1], incs[4 * q + 2], incs[4 * q + 3]);
+			*(float4 *)(in_amt + chain_io_word(half * HQ + q, l)) = make_float4(m[4 * q], m[4 * q + 1], m[4 * q + 2], m[4 * q + 3]);
 		}
-		*acc = a_end;
 		return;
 	}
+	if (half) return; /* (rows from HBM: the first feeder wave's alone) */
 #pragma unroll
 	for (uint32_t q = 0; q < CHAIN_NQ; ++q) {
 		uint4 b = bp[q]; /* (fetched a batch ahead: chain_fetch) */
@@ -189,12 +252,13 @@ __device__ __forceinline__ void chain_fetch(const ChainDesc &cd, bool live, uint
 	for (uint32_t q = 0; q < CHAIN_NQ; ++q) { bp[q] = chain_ld(&brow[t / 4 + q]); ap[q] = chain_ld(&arow[t / 4 + q]); }
 }
 
-__global__ void __launch_bounds__(128) chain_kernel(FastParams P) {
+__global__ void __launch_bounds__(192) chain_kernel(FastParams P) {
 	extern __shared__ __align__(16) unsigned char lds[];
 	if (P.pass_flags[FAST_MAX_LEVELS + 1] == 0) return; /* no voice of the segment has a chain */
 	if (P.chain_early && P.pass_flags[FAST_EARLY_FLAG] == 0) return;
 	const int l = threadIdx.x & 63;
-	const bool feeder = uni((uint32_t)threadIdx.x >> 6) != 0;
+	const uint32_t role = uni((uint32_t)threadIdx.x >> 6); /* 0: the chain wave; 1, 2: feeder waves (2: only the second half of inline chains' batches) */
+	const bool feeder = role != 0;
 	const uint32_t c = blockIdx.x * 64 + (uint32_t)l;
 	ChainDesc cd;
 	memset(&cd, 0, sizeof cd);
@@ -212,10 +276,10 @@ __global__ void __launch_bounds__(128) chain_kernel(FastParams P) {
 		const uint32_t wave = P.cwave_of_tab[t];
 		const uint4 *s23 = (const uint4 *)(P.g_c23 + (size_t)wave * WAVE_LEN);
 		uint4 *d23 = (uint4 *)(lds + (size_t)t * CHAIN_TAB_BYTES);
-		for (uint32_t i = threadIdx.x; i < WAVE_LEN; i += 128) d23[i] = s23[i];
+		for (uint32_t i = threadIdx.x; i < WAVE_LEN; i += 192) d23[i] = s23[i];
 		const HerpC01 *s01 = P.g_c01 + (size_t)wave * WAVE_LEN;
 		f64x2 *d01 = (f64x2 *)(lds + (size_t)t * CHAIN_TAB_BYTES + CHAIN_TAB_C01);
-		for (uint32_t i = threadIdx.x; i < WAVE_LEN; i += 128) { f64x2 v; v.x = (double)s01[i].c1; v.y = (double)s01[i].c0; d01[i] = v; }
+		for (uint32_t i = threadIdx.x; i < WAVE_LEN; i += 192) { f64x2 v; v.x = (double)s01[i].c1; v.y = (double)s01[i].c0; d01[i] = v; }
 	}
 	const uint32_t wave = cd.wave < 12 ? cd.wave : 0;
 	const int ti = P.ctab_of_wave[wave];
@@ -245,8 +309,17 @@ __global__ void __launch_bounds__(128) chain_kernel(FastParams P) {
 	auto in_amt = [&](uint32_t b) { return (float *)(io + (size_t)(2 * b + 1) * CHAIN_IO_WORDS); };
 	auto out_s = [&](uint32_t b) { return (float *)(io + (size_t)(4 + b) * CHAIN_IO_WORDS); };
 	const uint32_t n_batches = (n_max + CHAIN_BATCH - 1) / CHAIN_BATCH;
+	if (role == 2) { /* the second feeder wave: lines of inline chains, second half of every batch; the same barriers as the first */
+		uint32_t acc = 0;
+		for (uint32_t k = 0; k <= n_batches; ++k) {
+			if (k < n_batches && c_lo + k * CHAIN_BATCH < n && cd.mode == CM_INLINE)
+				chain_feed(cd, true, l, c_lo + k * CHAIN_BATCH, &acc, nullptr, nullptr, in_base(k & 1), in_amt(k & 1), 1u);
+			__syncthreads();
+		}
+		return;
+	}
 	if (feeder) {
-		uint32_t acc = c_lo ? o.st_phase : o.phase; /* CM_INC, CM_INLINE: the phase accumulator (staged by the chunk before) */
+		uint32_t acc = c_lo ? o.st_phase : o.phase; /* CM_INC: the phase accumulator (staged by the chunk before) */
 		/* step k: feed batch k while the chain wave runs batch k - 1, store the samples of batch k - 2; the rows of
 		 * batch k + 1 are asked for now and used in the next step */
 		uint4 fb[CHAIN_NQ]; float4 fa[CHAIN_NQ];
@@ -255,7 +328,7 @@ __global__ void __launch_bounds__(128) chain_kernel(FastParams P) {
 		chain_fetch(cd, n_batches && c_lo < n, c_lo, bp, ap, fb, fa);
 		for (uint32_t k = 0; k <= n_batches; ++k) {
 			if (k < n_batches && c_lo + k * CHAIN_BATCH < n)
-				chain_feed(cd, true, l, c_lo + k * CHAIN_BATCH, &acc, fb, fa, in_base(k & 1), in_amt(k & 1));
+				chain_feed(cd, true, l, c_lo + k * CHAIN_BATCH, &acc, fb, fa, in_base(k & 1), in_amt(k & 1), 0u);
 			chain_fetch(cd, k + 1 < n_batches && c_lo + (k + 1) * CHAIN_BATCH < n, c_lo + (k + 1) * CHAIN_BATCH, bp, ap, fb, fa);
 			if (k >= 2 && c_lo + (k - 2) * CHAIN_BATCH < n) {
 				const float *sq = out_s(k & 1);
@@ -269,7 +342,7 @@ __global__ void __launch_bounds__(128) chain_kernel(FastParams P) {
 #pragma unroll
 			for (uint32_t q = 0; q < CHAIN_NQ; ++q) chain_st(&op[(c_lo + (n_batches - 1) * CHAIN_BATCH) / 4 + q], *(const float4 *)(sq + chain_io_word(q, l)));
 		}
-		if (n && cd.mode != CM_BASE && !(cd.mode == CM_INLINE && (cd.lflags & CL_FCONST))) o.st_phase = acc;
+		if (n && cd.mode == CM_INC) o.st_phase = acc; /* (inline chains: the chain wave's, which sums their increments) */
 		return;
 	}
 	/* ---- the chain wave ---- */
@@ -277,9 +350,14 @@ __global__ void __launch_bounds__(128) chain_kernel(FastParams P) {
 	uint32_t prev_phase = c_lo ? o.st_prev_phase : o.prev_phase;
 	double prev_Is = c_lo ? o.st_prev_Is : o.prev_Is;
 	float prev_s = c_lo ? o.st_prev_s : o.prev_s, fb_s = c_lo ? bits_f(o.ras_alpha) : o.fb_s;
+	const bool inl = cd.mode == CM_INLINE; /* the feeder waves hand this chain phase increments: summed here */
+	const int inl_kind = __all(n == 0 || !inl) ? 0 : __all(n == 0 || inl) ? 1 : 2; /* (per wave: the usual bank is all of one kind) */
+	/* (a chain of one frequency stages no accumulator -- finalize_kernel advances its phase in closed form -- so a later
+	 * chunk's start is the closed form too) */
+	uint32_t acc = (inl && (cd.lflags & CL_FCONST)) ? o.phase + cd.inc_const * c_lo : (c_lo ? o.st_phase : o.phase);
 	__syncthreads();
 	if (n && c_lo == 0 && (o.flags & OPF_OSC_RESET)) { /* wosc.h:215-231 with the first base phase, as the block loop does */
-		const uint32_t phase00 = in_base(0)[chain_io_word(0, l)];
+		const uint32_t phase00 = (inl ? acc : 0u) + in_base(0)[chain_io_word(0, l)];
 		const uint32_t pa = phase00 - SLEN;
 		prev_Is = herp_poly(g23[pa >> SLEN_BITS], g01[pa >> SLEN_BITS], pa);
 		const double Is0 = herp_poly(g23[phase00 >> SLEN_BITS], g01[phase00 >> SLEN_BITS], phase00);
@@ -299,18 +377,19 @@ __global__ void __launch_bounds__(128) chain_kernel(FastParams P) {
 #pragma unroll
 		for (int u = 0; u < (int)CHAIN_NQ; ++u)
 			a_max = fmaxf(fmaxf(a_max, fmaxf(fabsf(aq[u].x), fabsf(aq[u].y))), fmaxf(fabsf(aq[u].z), fabsf(aq[u].w)));
-		const uint32_t s_prev_phase = prev_phase; const double s_prev_Is = prev_Is;
+		const uint32_t s_prev_phase = prev_phase, s_acc = acc; const double s_prev_Is = prev_Is;
 		const float s_prev_s = prev_s, s_fb_s = fb_s;
 		float fb_max = fabsf(fb_s);
 		bool small = !__any(n != 0 && !(a_max < 0x1p14f));
 		const bool tail = !((k + 1) * CHAIN_BATCH <= n_all);
-#define SAU_CHAIN_BATCH(L, TL, SM) chain_batch<L, TL, SM>(bq, aq, sq, t, n, tab23, tab01, g23, g01, dscale, doff, prev_phase, prev_Is, prev_s, fb_s, fb_max)
+#define SAU_CHAIN_BATCH_I(L, TL, SM, I) chain_batch<L, TL, SM, I>(bq, aq, sq, t, n, tab23, tab01, g23, g01, dscale, doff, prev_phase, prev_Is, prev_s, fb_s, fb_max, inl, acc)
+#define SAU_CHAIN_BATCH(L, TL, SM) do { if (inl_kind == 0) SAU_CHAIN_BATCH_I(L, TL, SM, 0); else if (inl_kind == 1) SAU_CHAIN_BATCH_I(L, TL, SM, 1); else SAU_CHAIN_BATCH_I(L, TL, SM, 2); } while (0)
 		if (small) {
 			if (all_lds) { if (tail) SAU_CHAIN_BATCH(true, true, true); else SAU_CHAIN_BATCH(true, false, true); }
 			else { if (tail) SAU_CHAIN_BATCH(false, true, true); else SAU_CHAIN_BATCH(false, false, true); }
 			if (__any(n != 0 && !(fb_max <= 64.f))) { /* (never seen: feedback is an average of samples) */
 				small = false;
-				prev_phase = s_prev_phase; prev_Is = s_prev_Is; prev_s = s_prev_s; fb_s = s_fb_s;
+				prev_phase = s_prev_phase; prev_Is = s_prev_Is; prev_s = s_prev_s; fb_s = s_fb_s; acc = s_acc;
 			}
 		}
 		if (!small) {
@@ -318,6 +397,7 @@ __global__ void __launch_bounds__(128) chain_kernel(FastParams P) {
 			else { if (tail) SAU_CHAIN_BATCH(false, true, false); else SAU_CHAIN_BATCH(false, false, false); }
 		}
 #undef SAU_CHAIN_BATCH
+#undef SAU_CHAIN_BATCH_I
 		float *os = out_s(k & 1);
 #pragma unroll
 		for (uint32_t q = 0; q < CHAIN_NQ; ++q) *(float4 *)(os + chain_io_word(q, l)) = sq[q];
@@ -329,6 +409,7 @@ __global__ void __launch_bounds__(128) chain_kernel(FastParams P) {
 		o.st_prev_s = prev_s;
 		o.ras_alpha = f_bits(fb_s);
 		o.ras_level = CHAIN_MARK;
+		if (inl && !(cd.lflags & CL_FCONST)) o.st_phase = acc;
 	}
 }
 

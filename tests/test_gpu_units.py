@@ -880,11 +880,12 @@ def test_voices_with_thousands_of_operators(sa, oracle):
 @pytest.mark.parametrize("chunks", ["1", "2", "16"])
 def test_feedback_chains_at_other_pipeline_depths(sa, oracle, chunks, monkeypatch):
     """chain_kernel beside the time-parallel passes: segments with feedback voices cut into
-    1, 2 or 16 chunks instead of the default 8, and chains fed from their own lines by the feeder wave --
-    bit-exact vs the oracle, frequency / amount / amplitude ramps and a feedback modulator included."""
+    1, 2 or 16 chunks instead of the default (by length), chains fed from their own lines by the feeder waves (the default
+    since round 4) and, in one leg, through rows written by a chain-input pass instead -- bit-exact vs the oracle, frequency /
+    amount / amplitude ramps, constant-frequency chains and a feedback modulator included."""
     monkeypatch.setenv("SAU_AMD_CHAIN_CHUNKS", chunks)
     if chunks == "2":
-        monkeypatch.setenv("SAU_AMD_CHAIN_INLINE", "1")
+        monkeypatch.setenv("SAU_AMD_NO_CHAIN_INLINE", "1")
     oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
     prg = vb.config5(n=96, seconds=2)
     want = oracle.oracle_render(prg.ptr, RATE, False)
@@ -894,6 +895,10 @@ def test_feedback_chains_at_other_pipeline_depths(sa, oracle, chunks, monkeypatc
     voices = [vb.Op("sin", freq=vb.Line(150.0 + 7 * k, goal=300.0, shape="exp"), time_ms=900 + 10 * k, pm_a=0.3 + 0.05 * k,
                     mods={POP_PMOD: [inner]} if k == 3 else {}) for k in range(6)]
     check(sa, oracle, voices, chunk=50000)
+    # chains of one frequency (no accumulator staged between chunks: the closed form), with amount ramps and without
+    flat = [vb.Op(("sin", "tri", "saw")[k % 3], freq=97.0 + 31 * k, time_ms=1500 + 40 * k,
+                  pm_a=(vb.Line(0.1 + 0.1 * k, goal=0.9, shape=("lin", "xpe", "cos")[k % 3]) if k & 1 else 0.4 + 0.1 * k)) for k in range(7)]
+    check(sa, oracle, flat, chunk=200000)
 
 
 @pytest.mark.parametrize("early", ["on", "off"])

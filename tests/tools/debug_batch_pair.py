@@ -63,7 +63,7 @@ else:
         run(pair, chunk_=c, tag="chunk %d" % c)
     for e in ("SAU_AMD_NO_SEQ", "SAU_AMD_NO_FAST", "SAU_AMD_NO_CHAIN", "SAU_AMD_NO_EARLY_CHAINS", "SAU_AMD_NO_LOOKBACK", "SAU_AMD_NO_TWO_PASS",
               "SAU_AMD_NO_INC_ROWS", "SAU_AMD_NO_LEAN", "SAU_AMD_NO_DYN", "SAU_AMD_NO_REPAIR", "SAU_AMD_LOOK_NO_LDS", "SAU_AMD_NO_PLAN_CACHE",
-              "SAU_AMD_CHAIN_INLINE"):
+              "SAU_AMD_NO_CHAIN_INLINE"):
         run(pair, {e: "1"})
     for r in ("8", "6", "5", "4", "2"):
         run(pair, {"SAU_AMD_FAST_ROWS": r})
