@@ -1,4 +1,5 @@
 /* engine.cpp -- host control plane (see engine.h). */
+#include <atomic>
 #include "engine.h"
 #include <algorithm>
 #include <exception>
@@ -28,12 +29,21 @@ const char *tune_env(const char *name) {
 	return on ? getenv(name) : nullptr;
 }
 
+static std::atomic<size_t> g_chain_rows_free_hint{0};
+void chain_rows_note_device_memory(size_t free_bytes) {
+	size_t zero = 0; /* the first device the process opens decides (one budget per process: segments are cut on the host) */
+	g_chain_rows_free_hint.compare_exchange_strong(zero, free_bytes);
+}
 size_t chain_rows_budget() {
-	static const size_t b = [] {
+	static const long long env_mb = [] {
 		const char *v = getenv("SAU_AMD_CHAIN_ROWS_MB");
-		return ((size_t)(v ? atoll(v) : 24 * 1024)) << 20;
+		return v ? atoll(v) : -1ll;
 	}();
-	return b;
+	if (env_mb >= 0) return (size_t)env_mb << 20;
+	const size_t dflt = (size_t)24 << 30; /* of an MI355X's 288 GB */
+	const size_t free_b = g_chain_rows_free_hint.load();
+	if (!free_b) return dflt; /* no device told (the sequential executor of the tests) */
+	return free_b / 8 < dflt ? free_b / 8 : dflt; /* a smaller or fuller device: an eighth of what was free when it was opened */
 }
 uint32_t chain_seg_frames(size_t n_chains) {
 	if (!n_chains) return CHAIN_SEG;

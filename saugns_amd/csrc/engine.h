@@ -157,6 +157,9 @@ constexpr uint32_t CHAIN_SEG = 131072;
  * 288 GB of HBM hold BASELINE config 5's 4096 chains x 441000 frames (14.4 GB) as one segment, and a segment is one
  * fill and one drain of the pass / chain pipeline. SAU_AMD_CHAIN_ROWS_MB sets another budget. */
 size_t chain_rows_budget();
+/* ... without that setting: 24 GiB, or an eighth of the memory that was free on the device when the process first opened it
+ * (hipMemGetInfo, told here by the backend) where that is less. */
+void chain_rows_note_device_memory(size_t free_bytes);
 /* Environment switches. Product settings are read as they are (INTEGRATION.md has the table: SAU_AMD_DEVICE,
  * SAU_AMD_READAHEAD*, SAU_AMD_LOOP_TAILS, SAU_AMD_CHAIN_ROWS_MB, SAU_AMD_POOL_MB, SAU_AMD_PINNED_POOL_MB, SAU_AMD_DEBUG*);
  * every other SAU_AMD_* name is a tuning or test aid and is looked at only when SAU_AMD_TUNE is set -- a stray variable

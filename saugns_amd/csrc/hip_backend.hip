@@ -322,6 +322,8 @@ public:
 				dev_lds[dev & 15] = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor
 				                                                          : prop.sharedMemPerBlock;
 				dev_cus[dev & 15] = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : FK_GRID;
+				size_t mfree = 0, mtotal = 0; /* the budget of the feedback chains' rows follows what this device has free */
+				if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess) sauengine::chain_rows_note_device_memory(mfree);
 			}
 			lds_limit_ = dev_lds[dev & 15];
 			/* the time-parallel kernels' grids are one 1024-thread workgroup per CU at most: waves that wait for other

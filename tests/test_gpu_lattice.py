@@ -70,3 +70,54 @@ def test_lattice_programs_in_one_batch(sa, oracle):
     outs = sa.Batch(prgs, 44100).render(stereo=False, chunk=2500)
     for k, (prg, got) in enumerate(zip(prgs, outs)):
         _same(got, oracle.oracle_render(prg.ptr, 44100, False, chunk=2500), k)
+
+
+def _render_pattern(create, run, destroy, prg, rate, stereo, sizes):
+    """A host that changes the size of its calls from one to the next: sizes in turn, the last one until the script ends."""
+    import ctypes as C
+    g = create(prg, rate)
+    assert g
+    ch = 2 if stereo else 1
+    n, out, k = C.c_size_t(), [], 0
+    while True:
+        size = sizes[min(k, len(sizes) - 1)]
+        k += 1
+        buf = np.zeros(size * ch, np.int16)
+        more = run(g, buf.ctypes.data, size, stereo, C.byref(n))
+        out.append(buf[: n.value * ch].copy())
+        if not more:
+            break
+    destroy(g)
+    return np.concatenate(out)
+
+
+def test_a_host_that_changes_its_call_size(sa, oracle, monkeypatch):
+    """The reference's output can depend on the size of the host's calls (its blocks restart at every call). With
+    SAU_AMD_READAHEAD=0 -- one engine run per call -- the drop-in generator follows any pattern of sizes exactly; with the
+    read-ahead (the default) every frame still arrives, calls of an unchanged size are exact, and a program that does not
+    depend on the lattice is exact whatever the host does."""
+    import saugns_amd.api as api
+    lib, ora = api.lib(), oracle.oracle()
+    ora.ora_set_fastmath_forms(ORACLE_FORMS)
+    patterns = [[1746, 300, 11289, 5, 1024, 4000], [11289, 11289, 11289, 700, 700, 20000], [1, 2, 3, 50000]]
+    dep = [expiry_value_goal_program(s) for s in range(4)]
+    for stereo in (False, True):
+        for k, prg in enumerate(dep):
+            for sizes in patterns:
+                want = _render_pattern(ora.ora_create, ora.ora_run, ora.ora_destroy, prg.ptr, 44100, stereo, sizes)
+                monkeypatch.setenv("SAU_AMD_READAHEAD", "0")
+                got = _render_pattern(lib.sau_create_Generator, lib.sauGenerator_run, lib.sau_destroy_Generator,
+                                      prg.ptr, 44100, stereo, sizes)
+                _same(got, want, (k, sizes, "one run per call"))
+                monkeypatch.delenv("SAU_AMD_READAHEAD")
+                got = _render_pattern(lib.sau_create_Generator, lib.sauGenerator_run, lib.sau_destroy_Generator,
+                                      prg.ptr, 44100, stereo, sizes)
+                assert len(got) == len(want), (k, sizes)
+    # a program without anything the lattice moves: exact with the read-ahead under every pattern
+    from saugns_amd import voicebank
+    prg = voicebank.config3(n=8, seconds=1)
+    for sizes in patterns:
+        want = _render_pattern(ora.ora_create, ora.ora_run, ora.ora_destroy, prg.ptr, 44100, False, sizes)
+        got = _render_pattern(lib.sau_create_Generator, lib.sauGenerator_run, lib.sau_destroy_Generator,
+                              prg.ptr, 44100, False, sizes)
+        _same(got, want, (sizes, "read-ahead"))
