@@ -164,38 +164,41 @@ __device__ __forceinline__ void chain_feed(const ChainDesc &cd, bool live, int l
 		 * one wave took 5 us for the 32 frames the chain wave consumes in 3.4 (round 4). What goes to LDS are phase
 		 * *increments*: the chain wave sums them itself (chain_batch: `inl`), so neither half waits for the other's sum. */
 		constexpr uint32_t HB = CHAIN_BATCH / 2, HQ = CHAIN_NQ / 2;
-		const uint32_t th = t + half * HB;
-		float fv[HB], m[HB];
-		uint32_t incs[HB];
-		line_batch<HB>(cd.pl, th, m);
-		if (!(cd.lflags & CL_FCONST)) {
-			line_batch<HB>(cd.fl, th, fv);
-			float x[HB];
-			bool big = false;
-			const bool any_mul = (cd.lflags & (CL_MUL_GOAL | CL_MUL_HOLD)) != 0;
+		/* (four frames at a time in a real loop: the instruction cache is shared with the chain wave, whose 32 unrolled steps
+		 * are 8 KiB by themselves, and with the CU next door -- the feeders' lines unrolled over sixteen frames made the
+		 * chain wave 5 % slower without it ever waiting at the barrier: -DCHAIN_PROF, round 4) */
+#pragma unroll 1
+		for (uint32_t q = 0; q < HQ; ++q) {
+			const uint32_t th = t + half * HB + 4 * q;
+			float fv[4], m[4];
+			uint32_t incs[4];
+			line_batch<4>(cd.pl, th, m);
+			if (!(cd.lflags & CL_FCONST)) {
+				line_batch<4>(cd.fl, th, fv);
+				float x[4];
+				bool big = false;
+				const bool any_mul = (cd.lflags & (CL_MUL_GOAL | CL_MUL_HOLD)) != 0;
 #pragma unroll
-			for (uint32_t j = 0; j < HB; ++j) {
-				float v = fv[j];
-				if (any_mul) v = (th + j < cd.fl.goal_len) ? ((cd.lflags & CL_MUL_GOAL) ? v * cd.mulc : v) : ((cd.lflags & CL_MUL_HOLD) ? v * cd.mulc : v);
-				x[j] = cd.coeff * v;
-				big |= !(fabsf(x[j]) < 0x1p50f);
-			}
-			/* llrintf(x) mod 2^32 (wosc.h:145): one test per batch for the rounding form */
-			if (!__any(big)) {
+				for (uint32_t j = 0; j < 4; ++j) {
+					float v = fv[j];
+					if (any_mul) v = (th + j < cd.fl.goal_len) ? ((cd.lflags & CL_MUL_GOAL) ? v * cd.mulc : v) : ((cd.lflags & CL_MUL_HOLD) ? v * cd.mulc : v);
+					x[j] = cd.coeff * v;
+					big |= !(fabsf(x[j]) < 0x1p50f);
+				}
+				/* llrintf(x) mod 2^32 (wosc.h:145): one test per four frames for the rounding form */
+				if (!__any(big)) {
 #pragma unroll
-				for (uint32_t j = 0; j < HB; ++j) incs[j] = (uint32_t)__double2loint((double)x[j] + 0x1.8p52);
+					for (uint32_t j = 0; j < 4; ++j) incs[j] = (uint32_t)__double2loint((double)x[j] + 0x1.8p52);
+				} else {
+#pragma unroll
+					for (uint32_t j = 0; j < 4; ++j) incs[j] = rint32w(x[j]);
+				}
 			} else {
 #pragma unroll
-				for (uint32_t j = 0; j < HB; ++j) incs[j] = rint32w(x[j]);
+				for (uint32_t j = 0; j < 4; ++j) incs[j] = cd.inc_const;
 			}
-		} else {
-#pragma unroll
-			for (uint32_t j = 0; j < HB; ++j) incs[j] = cd.inc_const;
-		}
-#pragma unroll
-		for (uint32_t q = 0; q < HQ; ++q) {
-			*(uint4 *)(in_base + chain_io_word(half * HQ + q, l)) = make_uint4(incs[4 * q], incs[4 * q + 1], incs[4 * q + 2], incs[4 * q + 3]);
-			*(float4 *)(in_amt + chain_io_word(half * HQ + q, l)) = make_float4(m[4 * q], m[4 * q + 1], m[4 * q + 2], m[4 * q + 3]);
+			*(uint4 *)(in_base + chain_io_word(half * HQ + q, l)) = make_uint4(incs[0], incs[1], incs[2], incs[3]);
+			*(float4 *)(in_amt + chain_io_word(half * HQ + q, l)) = make_float4(m[0], m[1], m[2], m[3]);
 		}
 		return;
 	}
@@ -252,6 +255,13 @@ __device__ __forceinline__ void chain_fetch(const ChainDesc &cd, bool live, uint
 	for (uint32_t q = 0; q < CHAIN_NQ; ++q) { bp[q] = chain_ld(&brow[t / 4 + q]); ap[q] = chain_ld(&arow[t / 4 + q]); }
 }
 
+#ifdef CHAIN_PROF /* tuning aid: where each wave of workgroup 0 spends a launch -- cycles in all, cycles waiting at the barrier */
+#define CHAIN_SYNC() do { const uint64_t w0_ = wall_clock64(); __syncthreads(); prof_wait += wall_clock64() - w0_; } while (0)
+#define CHAIN_PROF_END() do { if (blockIdx.x == 0 && l == 0) printf("chain_kernel role %u: %llu ticks, %llu at the barrier, %u batches\n", role, (unsigned long long)(wall_clock64() - prof_t0), (unsigned long long)prof_wait, n_batches); } while (0)
+#else
+#define CHAIN_SYNC() __syncthreads()
+#define CHAIN_PROF_END() do {} while (0)
+#endif
 __global__ void __launch_bounds__(192) chain_kernel(FastParams P) {
 	extern __shared__ __align__(16) unsigned char lds[];
 	if (P.pass_flags[FAST_MAX_LEVELS + 1] == 0) return; /* no voice of the segment has a chain */
@@ -309,13 +319,17 @@ __global__ void __launch_bounds__(192) chain_kernel(FastParams P) {
 	auto in_amt = [&](uint32_t b) { return (float *)(io + (size_t)(2 * b + 1) * CHAIN_IO_WORDS); };
 	auto out_s = [&](uint32_t b) { return (float *)(io + (size_t)(4 + b) * CHAIN_IO_WORDS); };
 	const uint32_t n_batches = (n_max + CHAIN_BATCH - 1) / CHAIN_BATCH;
+#ifdef CHAIN_PROF
+	uint64_t prof_wait = 0; const uint64_t prof_t0 = wall_clock64();
+#endif
 	if (role == 2) { /* the second feeder wave: lines of inline chains, second half of every batch; the same barriers as the first */
 		uint32_t acc = 0;
 		for (uint32_t k = 0; k <= n_batches; ++k) {
 			if (k < n_batches && c_lo + k * CHAIN_BATCH < n && cd.mode == CM_INLINE)
 				chain_feed(cd, true, l, c_lo + k * CHAIN_BATCH, &acc, nullptr, nullptr, in_base(k & 1), in_amt(k & 1), 1u);
-			__syncthreads();
+			CHAIN_SYNC();
 		}
+		CHAIN_PROF_END();
 		return;
 	}
 	if (feeder) {
@@ -335,7 +349,7 @@ __global__ void __launch_bounds__(192) chain_kernel(FastParams P) {
 #pragma unroll
 				for (uint32_t q = 0; q < CHAIN_NQ; ++q) chain_st(&op[(c_lo + (k - 2) * CHAIN_BATCH) / 4 + q], *(const float4 *)(sq + chain_io_word(q, l)));
 			}
-			__syncthreads(); /* (the first one also: tables staged) */
+			CHAIN_SYNC(); /* (the first one also: tables staged) */
 		}
 		if (n_batches && c_lo + (n_batches - 1) * CHAIN_BATCH < n) {
 			const float *sq = out_s((n_batches - 1) & 1);
@@ -343,6 +357,7 @@ __global__ void __launch_bounds__(192) chain_kernel(FastParams P) {
 			for (uint32_t q = 0; q < CHAIN_NQ; ++q) chain_st(&op[(c_lo + (n_batches - 1) * CHAIN_BATCH) / 4 + q], *(const float4 *)(sq + chain_io_word(q, l)));
 		}
 		if (n && cd.mode == CM_INC) o.st_phase = acc; /* (inline chains: the chain wave's, which sums their increments) */
+		CHAIN_PROF_END();
 		return;
 	}
 	/* ---- the chain wave ---- */
@@ -355,7 +370,7 @@ __global__ void __launch_bounds__(192) chain_kernel(FastParams P) {
 	/* (a chain of one frequency stages no accumulator -- finalize_kernel advances its phase in closed form -- so a later
 	 * chunk's start is the closed form too) */
 	uint32_t acc = (inl && (cd.lflags & CL_FCONST)) ? o.phase + cd.inc_const * c_lo : (c_lo ? o.st_phase : o.phase);
-	__syncthreads();
+	CHAIN_SYNC();
 	if (n && c_lo == 0 && (o.flags & OPF_OSC_RESET)) { /* wosc.h:215-231 with the first base phase, as the block loop does */
 		const uint32_t phase00 = (inl ? acc : 0u) + in_base(0)[chain_io_word(0, l)];
 		const uint32_t pa = phase00 - SLEN;
@@ -401,8 +416,9 @@ __global__ void __launch_bounds__(192) chain_kernel(FastParams P) {
 		float *os = out_s(k & 1);
 #pragma unroll
 		for (uint32_t q = 0; q < CHAIN_NQ; ++q) *(float4 *)(os + chain_io_word(q, l)) = sq[q];
-		__syncthreads();
+		CHAIN_SYNC();
 	}
+	CHAIN_PROF_END();
 	if (n) { /* staged: finalize_kernel makes it the operator's state unless the voice's segment is redone */
 		o.st_prev_phase = prev_phase;
 		o.st_prev_Is = prev_Is;
