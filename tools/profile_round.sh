@@ -12,11 +12,11 @@ python bench.py --workload config4 > gpurun_out/bench_${TAG}_c4.json 2> gpurun_o
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -o $TAG -- python3 bench.py --no-cpu --no-others > gpurun_out/prof_$TAG.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_c5 -o ${TAG}_c5 -- python3 bench.py --workload config5 --steps 3 --no-cpu > gpurun_out/prof_${TAG}_c5.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_c4 -o ${TAG}_c4 -- python3 bench.py --workload config4 --steps 3 --no-cpu > gpurun_out/prof_${TAG}_c4.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_fetch -o f -- python3 bench.py --steps 4 --warmup 1 --sustain 0 --no-cpu --no-others > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_write -o w -- python3 bench.py --steps 4 --warmup 1 --sustain 0 --no-cpu --no-others > /dev/null 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_sq -o s -- python3 bench.py --steps 4 --warmup 1 --sustain 0 --no-cpu --no-others > /dev/null 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_inst -o i -- python3 bench.py --steps 4 --warmup 1 --sustain 0 --no-cpu --no-others > /dev/null 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_grbm -o g -- python3 bench.py --steps 4 --warmup 1 --sustain 0 --no-cpu --no-others > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_fetch -o f -- python3 bench.py --steps 4 --warmup 1 --sustain 0 --no-cpu --no-others --no-dropin > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_write -o w -- python3 bench.py --steps 4 --warmup 1 --sustain 0 --no-cpu --no-others --no-dropin > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_sq -o s -- python3 bench.py --steps 4 --warmup 1 --sustain 0 --no-cpu --no-others --no-dropin > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_inst -o i -- python3 bench.py --steps 4 --warmup 1 --sustain 0 --no-cpu --no-others --no-dropin > /dev/null 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_grbm -o g -- python3 bench.py --steps 4 --warmup 1 --sustain 0 --no-cpu --no-others --no-dropin > /dev/null 2>&1
 # config 5: HBM bytes and instruction mix of the chain kernel and the passes around it
 # (one counter per pass: FETCH_SIZE and WRITE_SIZE together never finished on this pool -- r02a lost 25 minutes to it)
 timeout 180 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_c5_fetch -o m -- python3 bench.py --workload config5 --steps 1 --warmup 0 --no-cpu > /dev/null 2>&1
