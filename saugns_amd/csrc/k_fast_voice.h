@@ -153,7 +153,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 	 * CONTIG): a group's rows are contiguous in time -- row k + 1 goes on where row k ends, and what its lane 0 needs of
 	 * the sample before (phase, Hermite value: prev32 / prev64 below) is row k's lane 63 -- so only a group's first row
 	 * pays the lead-in: 64 T - H new frames per group instead of T (64 - H), 5.8 % more at T = 8, H = 4. */
-	constexpr bool CONTIG = SCAN == 0;
+	constexpr bool CONTIG = SCAN == 0 || SCAN == 2; /* (round 4, later: the look-back build too -- its rows chain through sums either way) */
 	const uint32_t C = 64u - H;                                   /* new frames of a row that has lead-in lanes */
 	const uint32_t RS = CONTIG ? 64u : C;                         /* frames from one row of a group to the next */
 	const uint32_t GF = CONTIG ? 64u * T - H : (uint32_t)T * C;   /* new frames per group */
@@ -191,6 +191,9 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 		const int t0 = (int)(cg * GF) - (int)H + l - (REPAIR ? (int)FAST_REPAIR_SHIFT : 0); /* this lane's frame in row 0 */
 		/* does this lane's frame of row k belong to the group (lead-in lanes: rows that have them, i.e. row 0 when CONTIG)? */
 		auto own = [&](int k) -> bool { return (CONTIG && k > 0) || l >= (int)H; };
+		/* running sums: what a row's inclusive scan holds at its last lead-in lane (rows without lead-in lanes: nothing) */
+		auto lead32 = [&](uint32_t Sk, int k) -> uint32_t { return (CONTIG && k > 0) ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)Sk, (int)H - 1); };
+		auto lead64 = [&](unsigned long long Sk, int k) -> unsigned long long { return (CONTIG && k > 0) ? 0ull : readlane64(Sk, (int)H - 1); };
 		/* what the lane before holds of row k's x -- for lane 0 of a later row of a contiguous group: the row before's lane 63 */
 		/* (the DPP move's lane 0 has no lane to read from: it keeps the `old` operand, here the row before's lane 63) */
 		auto prev_of = [&](uint32_t cur, uint32_t before, int k) -> uint32_t {
@@ -402,7 +405,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 									uint32_t tot = 0;
 #pragma unroll
 									for (int k = 0; k < T; ++k)
-										tot += (uint32_t)__builtin_amdgcn_readlane((int)S[k], 63) - (uint32_t)__builtin_amdgcn_readlane((int)S[k], (int)H - 1);
+										tot += (uint32_t)__builtin_amdgcn_readlane((int)S[k], 63) - lead32(S[k], k);
 									acc = f.phase0 + (look_lds ? lookback32<true>(lk_base + (size_t)fa.pad[0] * 2 * 64, cg, tot, 0, lk_ring, cgm, l, zero_acc)
 									                           : lookback32<false>(lookv + (size_t)fa.pad[0] * 2 * P.scan_groups, cg, tot, P.look_epoch, 0, 0, l, zero_acc, (P.look_wpv_flags & 2u) != 0));
 								} else {
@@ -411,7 +414,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 								}
 #pragma unroll
 								for (int k = 0; k < T; ++k) {
-									const uint32_t lead = (uint32_t)__builtin_amdgcn_readlane((int)S[k], (int)H - 1);
+									const uint32_t lead = lead32(S[k], k);
 									const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)S[k], 63);
 									ph[k] = acc + (S[k] - lead);
 									acc += last - lead;
@@ -443,7 +446,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 #pragma unroll
 							for (int k = 0; k < T; ++k) {
 								const int t = t0 + k * (int)RS;
-								if (t == (int)fast_total - 1 && l >= (int)H) P.ops[f.gop].st_phase = ph[k];
+								if (t == (int)fast_total - 1 && own(k)) P.ops[f.gop].st_phase = ph[k];
 							}
 						}
 						if (has_pm && !has_fpm) {
@@ -593,7 +596,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 							for (int k = 0; k < T; ++k) {
 								/* running-sum voices have a lane of slack (analyze_kernel): a hold left on the
 								 * operator's first defined lane is harmless there */
-								if (SCAN && l == p_min) held[k] = false;
+								if (SCAN && l == p_min && !(CONTIG && k > 0)) held[k] = false;
 								if (held[k]) rep[1] = ((uint32_t)(l - p_min) << 24) | ((uint32_t)k << 20) | (si << 12) | (cg & 0xfff); /* debug */
 								held_rows |= __any(held[k]) ? (1u << k) : 0u;
 							}
@@ -666,7 +669,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 							} else if (look) {
 								unsigned long long tot = 0;
 #pragma unroll
-								for (int k = 0; k < T; ++k) tot += readlane64(S[k], 63) - readlane64(S[k], (int)H - 1);
+								for (int k = 0; k < T; ++k) tot += readlane64(S[k], 63) - lead64(S[k], k);
 								if (look_lds) {
 									unsigned long long *e_lo = lk_base + (size_t)fa.pad[0] * 2 * 64;
 									acc = cp0 + lookback64<true>(e_lo, e_lo + 64, cg, tot, 0, lk_ring, cgm, l, zero_acc);
@@ -680,7 +683,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 							}
 #pragma unroll
 							for (int k = 0; k < T; ++k) {
-								const unsigned long long lead = readlane64(S[k], (int)H - 1);
+								const unsigned long long lead = lead64(S[k], k);
 								const unsigned long long last = readlane64(S[k], 63);
 								cpv[k] = acc + (S[k] - lead) - incv[k];
 								acc += last - lead;
@@ -697,7 +700,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 #pragma unroll
 								for (int k = 0; k < T; ++k) {
 									const int t = t0 + k * (int)RS;
-									if (t == (int)fast_total - 1 && l >= (int)H)
+									if (t == (int)fast_total - 1 && own(k))
 										P.ops[f.gop].st_prev_Is = __longlong_as_double((long long)(cpv[k] + incv[k]));
 								}
 							}
@@ -753,20 +756,20 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 							uint32_t tot = 0;
 #pragma unroll
 							for (int k = 0; k < T; ++k)
-								tot += (uint32_t)__builtin_amdgcn_readlane((int)S[k], 63) - (uint32_t)__builtin_amdgcn_readlane((int)S[k], (int)H - 1);
+								tot += (uint32_t)__builtin_amdgcn_readlane((int)S[k], 63) - lead32(S[k], k);
 							acc = nprev + (look_lds ? lookback32<true>(lk_base + (size_t)fa.pad[0] * 2 * 64, cg, tot, 0, lk_ring, cgm, l, zero_acc)
 							                        : lookback32<false>(lookv + (size_t)fa.pad[0] * 2 * P.scan_groups, cg, tot, P.look_epoch, 0, 0, l, zero_acc, (P.look_wpv_flags & 2u) != 0));
 						}
 #pragma unroll
 						for (int k = 0; k < T; ++k) {
 							const int t = t0 + k * (int)RS;
-							const uint32_t lead = (uint32_t)__builtin_amdgcn_readlane((int)S[k], (int)H - 1);
+							const uint32_t lead = lead32(S[k], k);
 							const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)S[k], 63);
 							const uint32_t sum = acc + (S[k] - lead);
 							acc += last - lead;
 							s[k] = fscalei((uint32_t)foldhd32((int32_t)sum), 0x1p-31f);
 							/* the sum after the segment's last frame: the operator's next `prev` (finalize_kernel) */
-							if (is_last_group && t == (int)fast_total - 1 && l >= (int)H) P.ops[f.gop].st_prev_phase = sum;
+							if (is_last_group && t == (int)fast_total - 1 && own(k)) P.ops[f.gop].st_prev_phase = sum;
 						}
 						if (look_own && l == 0) carry[si] = (unsigned long long)acc;
 					} else {
