@@ -263,7 +263,7 @@ class Ranks:
             seen = {}
             for r in ranks:
                 key = (r["host"], r["pci_bus_id"])
-                if r["pci_bus_id"] is None or key in seen:
+                if r["pci_bus_id"] is not None and key in seen:  # (an address the runtime would not give proves nothing either way)
                     raise SystemExit(f"rank {self.rank}: ranks {seen.get(key)} and {r['rank']} report the same GPU {key}: "
                                      "one process per GPU is the contract")
                 seen[key] = r["rank"]
@@ -508,7 +508,7 @@ def run_config4(args, R, sa, tabs, steps=None, warmup=None):
     if args.c4_frames:  # tests: the head of every render only (then compared with the fixtures' PCM heads)
         frames_each = run_len = min(frames_each, args.c4_frames)
 
-    def step(fetch, timing=None):
+    def step(fetch, timing=None, keep=False):
         batch = new_batch(sa, prgs)
         batch.set_call_len(11289)  # the reference host's call size (saugns.c:471,526)
         if timing is not None:
@@ -527,6 +527,8 @@ def run_config4(args, R, sa, tabs, steps=None, warmup=None):
             t = batch.timing_ex()
             for k in timing:
                 timing[k] += t[k]
+        if keep:
+            return n, outs, batch
         batch.close()
         return n, outs
 
@@ -554,6 +556,7 @@ def run_config4(args, R, sa, tabs, steps=None, warmup=None):
     tally = R.sum([frames_mine, n, checksum, len(prgs)])
     if tally[0] != steps * frames_each * total or tally[3] != total:
         raise SystemExit(f"rank {R.rank}: frame count {tally} does not add up to {total} renders")
+    gathered = pcm_gather(args, R, sa, step, fx, total, frames_each) if args.gather_pcm else None
     if R.rank != 0:
         return None
     # 7 operators per render (2 voices): 8 B per operator-sample + 2 B per output frame
@@ -587,9 +590,48 @@ def run_config4(args, R, sa, tabs, steps=None, warmup=None):
                      "algorithmic_bytes_per_step": alg,
                      "note": "64 renders per GPU are 128 voices; one engine run (one segment) per render since r03"},
     }
+    if gathered:
+        out["config"]["pcm_gather"] = gathered
     if not args.no_cpu and R.world == 1:
         out["cpu_baseline"] = cpu_reference_config4(fx, tabs)
     return out
+
+
+def pcm_gather(args, R, sa, step, fx, total, frames_each):
+    """--gather-pcm (the optional exchange): after everything else, render the rank's share once more, leave
+    the PCM in HBM and send it straight to rank 0 (RCCL send/recv inside one group; with gloo, tests, from host memory).
+    Rank 0 then holds all `total` renders and checks every one against the reference's SHA-256 -- or, with --c4-frames,
+    its own share against what it rendered. Never part of a timed step."""
+    import numpy as np
+    torch = R.torch
+    from saugns_amd import shard
+    if R.cuda and R.backend == "nccl":
+        n, _, batch = step(False, keep=True)
+        local = torch.stack([shard.device_pcm_tensor(batch, i, frames_each) for i in range(n // frames_each)])
+    else:
+        batch = None
+        n, outs = step(True)
+        local = torch.from_numpy(np.stack([np.concatenate(o)[:frames_each] for o in outs]))
+    R.barrier()
+    t0 = time.perf_counter()
+    everything = shard.gather_renders_to_root(local, 0)
+    R.barrier()
+    dt = time.perf_counter() - t0
+    if batch is not None:
+        batch.close()
+    if R.rank != 0:
+        return None
+    host = everything.cpu().numpy()
+    if len(host) != total:
+        raise SystemExit(f"rank 0: gathered {len(host)} renders, expected {total}")
+    if not args.c4_frames:
+        bad = [k for k in range(total) if sha256(host[k]) != str(fx["sha256"][k])]
+        if bad:
+            raise SystemExit(f"rank 0: gathered renders {bad[:8]} differ from the reference's SHA-256")
+    nbytes = int(host.nbytes)
+    return {"renders": int(len(host)), "bytes": nbytes, "seconds": dt, "GB_per_s": nbytes / dt / 1e9,
+            "backend": R.backend, "what": "torch.distributed.gather of int16 PCM to rank 0 (one direct send per rank), after "
+            "the timed region; every gathered render's SHA-256 checked on rank 0" + (" (heads only: not hashed)" if args.c4_frames else "")}
 
 
 def run_config5(args, R, sa, tabs, steps=None, warmup=None):
@@ -726,6 +768,8 @@ def main():
     ap.add_argument("--sustain", type=int, default=1000, help="config3: steps of the sustained run after the timed region "
                     "(reported under `sustained`, never `value`; 0: none)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--gather-pcm", action="store_true",
+                    help="--workload config4: afterwards send every rank's finished PCM to rank 0 (SURVEY 8e, optional) and check it there")
     ap.add_argument("--no-dropin", action="store_true", help="config3: skip the drop-in API's PCIe-inclusive rate")
     ap.add_argument("--no-others", action="store_true", help="config3: no short config 5 / config 4 runs after it")
     ap.add_argument("--force-others", action="store_true", help="tests: the other workloads also beside a reduced config 3")

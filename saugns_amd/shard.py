@@ -20,3 +20,34 @@ def reduce_report(frames, checksum, device=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return int(t[0]), int(t[1])
+
+
+class _DevicePCM:
+    """A block of int16 PCM in HBM (sauAmd_Batch_device_pcm) as something torch.as_tensor takes without a copy."""
+
+    def __init__(self, ptr, frames):
+        self.__cuda_array_interface__ = {"shape": (int(frames),), "typestr": "<i2", "data": (int(ptr), False), "version": 2}  # (torch takes no read-only flag; nothing here writes)
+
+
+def device_pcm_tensor(batch, stream, frames):
+    """The PCM of `stream` as the batch left it in HBM -> int16 torch tensor on the current device (no copy; valid
+    until the batch renders again or is closed)."""
+    import torch
+    return torch.as_tensor(_DevicePCM(batch.device_pcm(stream), frames), device="cuda")
+
+
+def gather_renders_to_root(local, dst=0):
+    """SURVEY.md 8e, the optional exchange after synthesis: every rank's finished renders -- `local`, an int16 tensor
+    [renders, frames], in HBM when the process group is RCCL ("nccl"), in host memory with gloo -- sent straight to
+    rank `dst` (torch.distributed.gather is one send per rank to the root inside one group: a direct xGMI hop each,
+    no ring). -> on `dst` a tensor [world * renders, frames] in rank order, None elsewhere. Nothing on the data path
+    of the renders themselves; ranks must hold equally many renders."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local
+    world, rank = dist.get_world_size(), dist.get_rank()
+    raw = local.contiguous().view(torch.uint8)  # (neither RCCL nor gloo carries int16: the same bytes as uint8)
+    parts = [torch.empty_like(raw) for _ in range(world)] if rank == dst else None
+    dist.gather(raw, parts, dst=dst)
+    return torch.cat(parts, 0).view(torch.int16) if rank == dst else None

@@ -115,6 +115,42 @@ def test_bench_gpus_2_starts_two_ranks_config3(seqexec):
     assert max(r["ms_per_step"] for r in j["ranks"]) <= j["ms_per_step"] * 1.001  # (the line's clock is the slowest rank's)
 
 
+def test_bench_gpus_2_gathers_finished_pcm_to_rank_0(seqexec):
+    """SURVEY.md 8e's optional exchange, `--gather-pcm`: after the timed region every rank sends its finished renders
+    straight to rank 0 (torch.distributed.gather; gloo from host memory here, RCCL from HBM on GPUs), which then holds
+    all of them in rank order."""
+    j = _line(_bench(["--gpus", "2", "--workload", "config4", "--renders", "2", "--c4-frames", "11025", "--steps", "1",
+                      "--warmup", "0", "--no-cpu", "--gather-pcm"], seqexec))
+    g = j["config"]["pcm_gather"]
+    assert g["renders"] == 4 and g["bytes"] == 4 * 11025 * 2 and g["backend"] == "gloo" and g["seconds"] > 0
+
+
+def test_gather_renders_to_root_keeps_rank_order(tmp_path):
+    """shard.gather_renders_to_root with two gloo ranks: rank 0 gets [rank 0's renders, rank 1's], rank 1 nothing."""
+    script = f"""
+import sys
+sys.path.insert(0, {ROOT!r})
+import torch, torch.distributed as dist
+from saugns_amd.shard import gather_renders_to_root
+dist.init_process_group("gloo")
+r = dist.get_rank()
+local = (torch.arange(6, dtype=torch.int16).reshape(2, 3) + 100 * r)
+got = gather_renders_to_root(local, 0)
+if r == 0:
+    assert got.tolist() == [[0, 1, 2], [3, 4, 5], [100, 101, 102], [103, 104, 105]], got
+    print("GATHER OK")
+else:
+    assert got is None
+dist.destroy_process_group()
+"""
+    f = tmp_path / "g.py"
+    f.write_text(script)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29547", str(f)], capture_output=True, text=True,
+                         env=dict(os.environ, MASTER_ADDR="127.0.0.1"), timeout=600)
+    assert out.returncode == 0 and "GATHER OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_bench_gpus_2_default_workload_carries_config4_sharded(seqexec):
     """With N > 1 the default command's line has the north star's multi-GPU case at its top: config 4, 64 renders per GPU
     sharded by seed (here 2 per rank, heads only), next to config 3's value."""
@@ -167,6 +203,14 @@ def test_bench_gpus_2_on_one_gpu_box_with_cpu_rendezvous():
     assert j["n_gpus"] == 2 and j["config"]["renders_all_ranks"] == 8
     assert j["config"]["frames_all_ranks"] == 8 * 2646000 and "TEST BACKEND" not in j["data"]
     assert "SHA-256 of every one of the 8 renders" in j["config"]["verified"]
+    # the optional exchange, both ways: two ranks through gloo from host memory; one rank with the PCM taken where the
+    # batch left it in HBM (the tensor RCCL would send) -- every gathered render's SHA-256 checked on rank 0
+    g = run(["--gpus", "2", "--workload", "config4", "--renders", "2", "--steps", "1", "--warmup", "0", "--no-cpu", "--gather-pcm"])
+    assert g["config"]["pcm_gather"]["renders"] == 4 and g["config"]["pcm_gather"]["bytes"] == 4 * 2646000 * 2
+    env.pop("SAU_BENCH_BACKEND")
+    g = run(["--gpus", "1", "--workload", "config4", "--renders", "3", "--steps", "1", "--warmup", "0", "--no-cpu", "--gather-pcm"])
+    assert g["config"]["pcm_gather"]["renders"] == 3 and g["config"]["pcm_gather"]["backend"] == "nccl"
+    env["SAU_BENCH_BACKEND"] = "gloo"
     k = run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu", "--no-others"])
     assert k["n_gpus"] == 2 and k["config"]["frames_all_ranks"] == 2 * 3 * 441000
     assert k["config"]["first_step_verified"]["sha256"].startswith("3211740aca595248")
