@@ -34,7 +34,10 @@ void chain_rows_note_device_memory(size_t free_bytes) {
 	size_t zero = 0; /* the first device the process opens decides (one budget per process: segments are cut on the host) */
 	g_chain_rows_free_hint.compare_exchange_strong(zero, free_bytes);
 }
+static std::atomic<bool> g_chain_rows_alloc_failed{false};
+void chain_rows_note_alloc_failure() { g_chain_rows_alloc_failed.store(true); }
 size_t chain_rows_budget() {
+	if (g_chain_rows_alloc_failed.load()) return 0; /* (segments with feedback voices: CHAIN_SEG frames from now on) */
 	static const long long env_mb = [] {
 		const char *v = getenv("SAU_AMD_CHAIN_ROWS_MB");
 		return v ? atoll(v) : -1ll;

@@ -679,12 +679,27 @@ public:
 			}
 			/* feedback chains: a pair of rows per chain in HBM, one segment long (the engine keeps segments
 			 * with such voices within CHAIN_SEG frames); without them those voices take the block loop */
-			const bool chains = chain_enabled_ && use_fast && fp.scan && seg.serial && seg.n_chain_rows &&
+			bool chains = chain_enabled_ && use_fast && fp.scan && seg.serial && seg.n_chain_rows &&
 				seg.len <= sauengine::chain_seg_frames(seg.n_chain_rows);
 			if (chains) {
 				const uint32_t cstride = (seg.len + 63) & ~63u;
-				if (!chain_rows_.ensure((size_t)seg.n_chain_rows * 2 * cstride + 64, err) ||
-				    !chain_desc_.ensure(seg.n_chain_rows, err) ||
+				/* The rows are the one large allocation that depends on how long the engine cut the segment. When the device
+				 * cannot give them (a smaller or fuller GPU than the budget assumed, several engines on it) this segment's
+				 * feedback voices take the block loop -- slow, exact -- and later segments are cut at CHAIN_SEG again
+				 * (ADVICE r03). SAU_AMD_CHAIN_ROWS_FAIL (tests) makes the first such allocation of an engine fail. */
+				std::string rows_err;
+				const bool rows_fail_test = tune_env("SAU_AMD_CHAIN_ROWS_FAIL") && !chain_rows_failed_once_;
+				if (rows_fail_test || !chain_rows_.ensure((size_t)seg.n_chain_rows * 2 * cstride + 64, rows_err)) {
+					chain_rows_failed_once_ = true;
+					sauengine::chain_rows_note_alloc_failure();
+					if (debug_) fprintf(stderr, "saugns_amd: %zu bytes of chain rows not available (%s): block loop for this segment\n",
+							((size_t)seg.n_chain_rows * 2 * cstride + 64) * sizeof(float), rows_err.c_str());
+					chains = false;
+				}
+			}
+			if (chains) {
+				const uint32_t cstride = (seg.len + 63) & ~63u;
+				if (!chain_desc_.ensure(seg.n_chain_rows, err) ||
 				    !fplines_.ensure((size_t)FAST_LISTS * seg.n_voices * fmax_steps * sizeof(FastLine), err)) return false;
 				fp.chain_rows = chain_rows_.p; fp.chain_stride = cstride; fp.n_chain_rows = seg.n_chain_rows;
 				fp.chain_desc = chain_desc_.p; fp.fplines = (FastLine *)fplines_.p;
@@ -1304,6 +1319,7 @@ private:
 	hipStream_t chain_stream_ = nullptr;
 	std::vector<hipEvent_t> chain_ev_;
 	DevBuf<float> chain_rows_;
+	bool chain_rows_failed_once_ = false;
 	DevBuf<ChainDesc> chain_desc_;
 	DevBuf<unsigned char> fplines_;
 	uint32_t block_grid_ = 1;

@@ -1046,3 +1046,37 @@ def test_two_generators_at_once_with_running_sums(sa, oracle):
     for i in range(2):
         for pcm in got[i]:
             assert len(pcm) == len(want[i]) and (pcm == want[i]).all()
+
+
+@pytest.mark.gpu
+def test_feedback_voices_render_when_the_chain_rows_cannot_be_allocated(tmp_path):
+    """the chains' rows are the one large allocation that depends on how the engine cut the segment. When the device
+    cannot give them (SAU_AMD_CHAIN_ROWS_FAIL makes an engine's first such allocation fail) the segment's feedback voices take
+    the block loop, the process's budget is gone and later segments are cut at 131072 frames -- the render stays exact. In a
+    process of its own: the lowered budget is process-wide."""
+    import subprocess, sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = f"""
+import os, sys
+sys.path.insert(0, {ROOT!r}); sys.path.insert(0, os.path.join({ROOT!r}, "tests"))
+os.environ["SAU_AMD_TUNE"] = "1"; os.environ["SAU_AMD_CHAIN_ROWS_FAIL"] = "1"
+import numpy as np
+import saugns_amd as sa
+from saugns_amd import voicebank as vb
+from oracle import pyoracle as po
+tabs = np.fromfile(os.path.join({ROOT!r}, "tests/golden/piluts_ref.f32"), dtype="<f4").reshape(12, 2048)
+po.build(ref=False); po.oracle_use_tables(tabs); sa.set_piluts(tabs)
+po.oracle().ora_set_fastmath_forms(2)
+prg = vb.config5(n=70, seconds=7)
+want = po.oracle_render(prg.ptr, 44100, False, chunk=150000)
+for rep in range(2):  # the first engine meets the failure, the second the lowered budget
+    b = sa.Batch([prg], 44100)
+    got = b.render(stereo=False, chunk=150000)[0]
+    tm = b.timing_ex(); b.close()
+    assert len(got) == len(want) and (got == want).all(), (rep, int((got != want).sum()))
+print("ROWS FALLBACK OK")
+"""
+    f = tmp_path / "rows.py"
+    f.write_text(script)
+    out = subprocess.run([sys.executable, str(f)], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "ROWS FALLBACK OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
