@@ -198,7 +198,9 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 		/* (the DPP move's lane 0 has no lane to read from: it keeps the `old` operand, here the row before's lane 63) */
 		auto prev_of = [&](uint32_t cur, uint32_t before, int k) -> uint32_t {
 			if (CONTIG && k > 0) { /* (two DPP moves: the row before rotated by a lane puts its lane 63 into lane 0) */
-				const int rot = __builtin_amdgcn_update_dpp(0, (int)before, 0x13c /* wave_ror:1 */, 0xf, 0xf, false);
+				/* (bound_ctrl for the rotation: every lane has a source, and with it the compiler needs no `old` value -- without,
+				 * it zeroed the destination first, one more VALU instruction per rotated value) */
+				const int rot = __builtin_amdgcn_update_dpp(0, (int)before, 0x13c /* wave_ror:1 */, 0xf, 0xf, true);
 				return (uint32_t)__builtin_amdgcn_update_dpp(rot, (int)cur, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 			}
 			return lane_prev(cur);
