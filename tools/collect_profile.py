@@ -66,7 +66,7 @@ for wl in ("c5", "c4"):
         shutil.copy(st, f"profiles/{name}_{wl}_kernel_stats.csv")
 # configs 5 and 4: per-kernel HBM bytes and instruction counts (averages per launch), and the bytes of one step --
 # the profiled command renders twice (the first step, whose SHA-256 is checked, and one timed step)
-for wl, wname in (("c5", "config5"), ("c4", "config4")):
+for wl, wname in (("c5", "config5"), ("c4", "config4"), ("fmbank", "fm"), ("config2", "config2")):
     ks = {}
     for d, f in ((wl + "_fetch", "m"), (wl + "_write", "m"), (wl + "_inst", "i")):
         src = f"gpurun_out/pmc_{tag}_{d}/{f}_counter_collection.csv"

@@ -26,6 +26,12 @@ timeout 180 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SM
 timeout 180 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_c4_fetch -o m -- python3 bench.py --workload config4 --steps 1 --warmup 0 --no-cpu > /dev/null 2>&1
 timeout 180 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_c4_write -o m -- python3 bench.py --workload config4 --steps 1 --warmup 0 --no-cpu > /dev/null 2>&1
 timeout 180 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_c4_inst -o i -- python3 bench.py --workload config4 --steps 1 --warmup 0 --no-cpu > /dev/null 2>&1
+# the two banks on the driver's line since round 4 (carrier-FM bank, config 2): HBM bytes of a step and the instruction mix
+for W in fm config2; do D=$W; [ $W = fm ] && D=fmbank   # (pmc_<tag>_fm_inst is the sweep's, below)
+timeout 180 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_${D}_fetch -o m -- python3 bench.py --workload $W --steps 1 --warmup 0 --no-cpu > /dev/null 2>&1
+timeout 180 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_${D}_write -o m -- python3 bench.py --workload $W --steps 1 --warmup 0 --no-cpu > /dev/null 2>&1
+timeout 180 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_${D}_inst -o i -- python3 bench.py --workload $W --steps 1 --warmup 0 --no-cpu > /dev/null 2>&1
+done
 # running-sum workloads (carrier FM bank, carrier glide, FM + ratio PM stack): sweep lines, kernel trace, instruction mix
 TLEVEL=0 timeout 180 python3 tests/tools/gpu_sweep.py c3f fmstack mixed > gpurun_out/sweep_${TAG}_fm.txt 2>&1
 timeout 180 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_fm -o ${TAG}_fm -- python3 tests/tools/gpu_sweep.py c3f fmstack > gpurun_out/prof_${TAG}_fm.log 2>&1
