@@ -46,7 +46,7 @@ __device__ __forceinline__ void chain_batch(const uint4 *bq, const float4 *aq, f
 	for (int u = 0; u < (int)CHAIN_NQ; ++u) {
 		const uint32_t b4[4] = {bq[u].x, bq[u].y, bq[u].z, bq[u].w};
 		const float a4[4] = {aq[u].x, aq[u].y, aq[u].z, aq[u].w};
-		float s4[4];
+		float s4[4], fbn[4];
 #pragma unroll
 		for (int j = 0; j < 4; ++j) {
 			const float p = fb_s * a4[j];
@@ -56,10 +56,13 @@ __device__ __forceinline__ void chain_batch(const uint4 *bq, const float4 *aq, f
 			const uint32_t acc_n = INL ? acc + b4[j] : 0u;
 			const uint32_t phase = (INL == 1 ? acc_n : INL == 2 ? (inl ? acc_n : b4[j]) : b4[j]) + ofs;
 			const int32_t d = (int32_t)(phase - prev_phase);
-			const uint32_t ind = phase >> SLEN_BITS;
+			uint32_t ind = phase >> SLEN_BITS;
 			double Isv;
 			if (LDS_TAB) {
-				const uint32_t a = tab23 + ind * 16u;
+				/* (two instructions on the chain, v_lshrrev + v_lshl_add: the empty asm keeps LLVM from rewriting the address as
+				 * ((phase >> 17) & 0x7ff0) + tab, which is three -- as in fk_entry, k_fast_voice.h) */
+				asm("" : "+v"(ind));
+				const uint32_t a = tab23 + (ind << 4);
 				const f64x2 c32 = *(lds_f64x2)(uintptr_t)a;
 				const f64x2 c10 = *(lds_f64x2)(uintptr_t)(a + CHAIN_TAB_C01);
 				const double x = (double)(phase & (SLEN - 1)); /* herp_poly (sau_dev_math.h), the same operations in the same order */
@@ -73,13 +76,22 @@ __device__ __forceinline__ void chain_batch(const uint4 *bq, const float4 *aq, f
 			if (INL) acc = (TAIL && !act) ? acc : acc_n; /* (wosc.h:145: pre-increment; stands still past the chain's last frame) */
 			if (TAIL) hold = hold || !act;
 			const float sv = hold ? prev_s : sv_new;
-			prev_Is = hold ? prev_Is : Isv;
+			/* (a repeated phase has the same Hermite value -- prev_Is is always the value at prev_phase: wosc.h:215-231 and
+			 * 247-262 keep them together -- so only a lane past its chain's end needs the select: two instructions per step) */
+			prev_Is = TAIL ? (hold ? prev_Is : Isv) : Isv;
 			prev_phase = (TAIL && !act) ? prev_phase : phase; /* (equal to the old one when held) */
 			prev_s = sv;
 			s4[j] = sv;
 			const float fb_n = (fb_s + sv) * 0.5f;
 			fb_s = (TAIL && !act) ? fb_s : fb_n;
-			if (SMALL) fb_max = fmaxf(fb_max, fabsf(fb_n)) + fb_n * 0.f; /* (beside the chain, not on it; NaN and Inf stick) */
+			fbn[j] = fb_n;
+		}
+		/* the bound the short rounding form assumed, beside the chain: one v_max3_f32 per two steps. It passes a NaN by, but a
+		 * NaN or an infinity in fb_s stays there (the average of it and anything is it again, or a NaN), so the caller's look
+		 * at the batch's last fb_s finds those */
+		if (SMALL) {
+			asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(fb_max) : "v"(fbn[0]), "v"(fbn[1]));
+			asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(fb_max) : "v"(fbn[2]), "v"(fbn[3]));
 		}
 		sq[u] = make_float4(s4[0], s4[1], s4[2], s4[3]);
 	}
@@ -388,10 +400,13 @@ __global__ void __launch_bounds__(192) chain_kernel(FastParams P) {
 #pragma unroll
 		for (uint32_t q = 0; q < CHAIN_NQ; ++q) { bq[q] = *(const uint4 *)(ib + chain_io_word(q, l)); aq[q] = *(const float4 *)(ia + chain_io_word(q, l)); }
 		/* the short rounding form needs |fb_s * amount| < 2^20: amounts below 2^14 and |fb_s| <= 64 (checked after) */
-		float a_max = 0.f;
+		float a_max = 0.f; /* (v_max3_f32 with |.| operands, two per four amounts: fmaxf(fabsf()) chains compiled to seven -- each
+		                    * operand canonicalised by a v_max of its own --, 1.25 instructions per sample step of the chain wave) */
 #pragma unroll
-		for (int u = 0; u < (int)CHAIN_NQ; ++u)
-			a_max = fmaxf(fmaxf(a_max, fmaxf(fabsf(aq[u].x), fabsf(aq[u].y))), fmaxf(fabsf(aq[u].z), fabsf(aq[u].w)));
+		for (int u = 0; u < (int)CHAIN_NQ; ++u) {
+			asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(a_max) : "v"(aq[u].x), "v"(aq[u].y));
+			asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(a_max) : "v"(aq[u].z), "v"(aq[u].w));
+		}
 		const uint32_t s_prev_phase = prev_phase, s_acc = acc; const double s_prev_Is = prev_Is;
 		const float s_prev_s = prev_s, s_fb_s = fb_s;
 		float fb_max = fabsf(fb_s);
@@ -402,7 +417,7 @@ __global__ void __launch_bounds__(192) chain_kernel(FastParams P) {
 		if (small) {
 			if (all_lds) { if (tail) SAU_CHAIN_BATCH(true, true, true); else SAU_CHAIN_BATCH(true, false, true); }
 			else { if (tail) SAU_CHAIN_BATCH(false, true, true); else SAU_CHAIN_BATCH(false, false, true); }
-			if (__any(n != 0 && !(fb_max <= 64.f))) { /* (never seen: feedback is an average of samples) */
+			if (__any(n != 0 && !(fb_max <= 64.f && fabsf(fb_s) <= 64.f))) { /* (never seen: feedback is an average of samples) */
 				small = false;
 				prev_phase = s_prev_phase; prev_Is = s_prev_Is; prev_s = s_prev_s; fb_s = s_fb_s; acc = s_acc;
 			}

@@ -191,6 +191,12 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 		const int t0 = (int)(cg * GF) - (int)H + l - (REPAIR ? (int)FAST_REPAIR_SHIFT : 0); /* this lane's frame in row 0 */
 		/* does this lane's frame of row k belong to the group (lead-in lanes: rows that have them, i.e. row 0 when CONTIG)? */
 		auto own = [&](int k) -> bool { return (CONTIG && k > 0) || l >= (int)H; };
+		/* REPAIR: a frame this pass is to store -- one of the noted ones among the group's first owned frames, which lie
+		 * FAST_REPAIR_SHIFT lanes further on in this evaluation's row 0 */
+		auto repair_mine = [&](int k) -> bool {
+			const int j = l - (int)(H + FAST_REPAIR_SHIFT);
+			return k == 0 && j >= 0 && j < 32 && ((repair_rows >> (j & 31)) & 1u);
+		};
 		/* running sums: what a row's inclusive scan holds at its last lead-in lane (rows without lead-in lanes: nothing) */
 		auto lead32 = [&](uint32_t Sk, int k) -> uint32_t { return (CONTIG && k > 0) ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)Sk, (int)H - 1); };
 		auto lead64 = [&](unsigned long long Sk, int k) -> unsigned long long { return (CONTIG && k > 0) ? 0ull : readlane64(Sk, (int)H - 1); };
@@ -214,7 +220,9 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 		};
 		const bool first_group = (cg == 0);
 		const bool is_last_group = (cg == last_group);
-		uint32_t held_rows = 0; /* rows with a hold this evaluation could not resolve */
+		uint32_t held_rows = 0; /* rows with a hold this evaluation could not resolve; the closed-form builds: which of the group's
+		                         * first owned frames such holds spoil (bit j: the frame at row 0's lane H + j) */
+		bool held_far = false;  /* ... or something the repair pass cannot put right (a later row, a frame further on) */
 		(void)repair_rows;
 #if FK_PREFETCH
 		FastStep fnext = load_step_uniform(fsteps);
@@ -600,6 +608,23 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 								 * operator's first defined lane is harmless there */
 								if (SCAN && l == p_min && !(CONTIG && k > 0)) held[k] = false;
 								if (held[k]) rep[1] = ((uint32_t)(l - p_min) << 24) | ((uint32_t)k << 20) | (si << 12) | (cg & 0xfff); /* debug */
+								if (!SCAN && CONTIG) {
+									/* What is left unresolved in row 0 is a run of repeats that begins on the operator's first defined lane,
+									 * p_min; the hold at lane p_min + j spoils the carrier's frame at lane H + j (one lane further per nesting
+									 * level on the way out). The repair pass stores exactly those frames, FAST_REPAIR_SHIFT lanes further on
+									 * in its evaluation -- so they must fit a row there. (Until round 4 only the run's first frame was noted:
+									 * a run of two or three at a group's start kept its later frames' garbage -- one extreme program in 3000
+									 * once contiguous rows had made such groups few enough per voice to be repaired rather than redone.) */
+									if (k == 0) {
+										const int jm = min(32, 64 - (int)FAST_REPAIR_SHIFT - (int)H);
+										const unsigned long long run = __ballot(held[0]) >> p_min;
+										if (jm <= 0) { if (run) held_far = true; }
+										else {
+											held_rows |= (uint32_t)(run & ((1ull << jm) - 1ull));
+											if (run >> jm) held_far = true;
+										}
+									} else if (__any(held[k])) held_far = true; /* (a later row's: the run reaches back through the rows before) */
+								} else
 								held_rows |= __any(held[k]) ? (1u << k) : 0u;
 							}
 						}
@@ -824,7 +849,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 #pragma unroll
 					for (int k = 0; k < T; ++k) {
 						const int t = t0 + k * (int)RS;
-						const bool mine = REPAIR ? (l == (int)(H + FAST_REPAIR_SHIFT) && ((repair_rows >> k) & 1u)) : own(k);
+						const bool mine = REPAIR ? repair_mine(k) : own(k);
 						if (mine && t < (int)fast_total) FK_VSTORE(&vrow[t], r[k]);
 					}
 				} else {
@@ -868,7 +893,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 #pragma unroll
 				for (int k = 0; k < T; ++k) {
 					const int t = t0 + k * (int)RS;
-					const bool mine = REPAIR ? (l == (int)(H + FAST_REPAIR_SHIFT) && ((repair_rows >> k) & 1u)) : own(k);
+					const bool mine = REPAIR ? repair_mine(k) : own(k);
 					if (mine && t < (int)fast_total) {
 						FK_VSTORE(&vrow[t], slots[f.out_off + k * 64]);
 						if (prow) prow[t] = f.pm_off != ~0u ? slots[f.pm_off + k * 64] : f.pan;
@@ -876,13 +901,13 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 				}
 			}
 		}
-		if (held_rows) {
+		if (held_rows || held_far) {
 			/* to the repair pass -- unless this is it, the group touches an end of the segment
 			 * (carried state sits at fixed lanes there) or the voice has running sums */
 			bool noted = false;
 			/* (a contiguous group's later rows resolve their holds through the rows before: one left there means a run that
 			 * reaches back to the group's lead-in -- not a case for the one-frame repair) */
-			if (!REPAIR && !SCAN && !CUB && P.repair_on && !first_group && !is_last_group && !(CONTIG && (held_rows >> 1)) &&
+			if (!REPAIR && !SCAN && !CUB && P.repair_on && !first_group && !is_last_group && !held_far &&
 			    (int)(cg * GF) - (int)H >= (int)FAST_REPAIR_SHIFT) {
 				uint32_t at = 0;
 				if (l == 0) at = atomicAdd(&rep[0], 1u);

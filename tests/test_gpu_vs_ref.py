@@ -256,3 +256,48 @@ def test_ratio_second_frequency_under_a_modulated_parent_with_scaled_pm(sa, orac
             if len(got) != len(ref) or (got != ref).any():
                 bad.append((ms, sorted(set(int(i) // 2 for i in np.nonzero(got[:len(ref)] != ref[:len(got)])[0]))[:6]))
         assert not bad, bad
+
+
+def _sweep_program(seed, extreme):
+    """Program `seed` of tests/tools/gpu_vs_ref_sweep.py (random graphs, `extreme`: parameters pushed to extremes) -- the same draws."""
+    rng = np.random.default_rng(20000 + seed)
+    voices = [tu._random_voice(rng) for _ in range(int(rng.integers(1, 4)))]
+    ups = ()
+    if seed % 2:
+        tu._random_starts(rng, voices)
+        ups = tu._random_updates(rng, voices)
+    rate = None
+    if extreme:
+        tu._push_extremes(rng, voices)
+        rate = int(rng.choice([1000, 3000, 11025, 44100, 192000, 384000]))
+    prg = vb.build_program(voices, updates=ups)
+    call = int(rng.integers(1, 12)) if seed % 5 == 4 else int(rng.integers(300, 12000))
+    return prg, bool(seed & 2), call, (rate or (44100 if seed % 3 else int(rng.choice([8000, 22050, 48000, 96000]))))
+
+
+def test_runs_of_repeated_phases_at_a_groups_start(sa, oracle, tables):
+    """Round 4's last sweep: extreme program 1501673 -- three samples at +32767 in the reference, -32767 on the device. A run of two
+    or three repeated phases beginning on a row group's first owned frame: the repair pass stored the run's first frame only, the
+    later ones kept the main pass's value (a division by the zero phase step). As old as the repair pass; contiguous rows made
+    such groups few enough per voice to be repaired rather than redone by the block loop, which had hidden it. The same program
+    with the repair pass off (every such group redone) and with narrow rows must equal the reference too."""
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref/libsau_ref.so not present")
+    with _RefSetup(sa, oracle, tables):
+        prg, stereo, call, rate = _sweep_program(1501673, True)
+        ref = oracle.ref_render(prg.ptr, rate, stereo, chunk=call)
+        ora = oracle.oracle_render(prg.ptr, rate, stereo, chunk=call)
+        assert len(ora) == len(ref) and (ora == ref).all()
+        for env in ({}, {"SAU_AMD_NO_REPAIR": "1"}, {"SAU_AMD_NO_WIDE_TABS": "1"}, {"SAU_AMD_FAST_ROWS": "4"}):
+            old = {k: os.environ.get(k) for k in env}
+            os.environ.update(env)
+            try:
+                got = sa.Batch([prg], rate).render(stereo=stereo, chunk=call)[0]
+            finally:
+                for k, v in old.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+            d = np.nonzero(got[:len(ref)] != ref[:len(got)])[0]
+            assert len(got) == len(ref) and len(d) == 0, (env, len(d), d[:6].tolist())
