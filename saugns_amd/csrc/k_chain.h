@@ -176,6 +176,87 @@ __device__ __forceinline__ void chain_feed(const ChainDesc &cd, bool live, int l
 		 * one wave took 5 us for the 32 frames the chain wave consumes in 3.4 (round 4). What goes to LDS are phase
 		 * *increments*: the chain wave sums them itself (chain_batch: `inl`), so neither half waits for the other's sum. */
 		constexpr uint32_t HB = CHAIN_BATCH / 2, HQ = CHAIN_NQ / 2;
+		{
+			/* The usual case in one straight run, no shape dispatch and no test per value: every lane's amount line is a `lin`
+			 * ramp that covers this half batch, or holds; its frequency is constant, or an xpe / lge glide (what `exp` and `log`
+			 * resolve to) that covers it, or holds; no ratio multiplier. The same operations per value as line_batch's, in its
+			 * order. (The feeders' busy time is what slows the chain wave beside them, in proportion: about a thousand
+			 * instructions per feeder and batch through the general code below, 450 here.) */
+			const uint32_t tb = t + half * HB;
+			const bool p_hold = tb >= cd.pl.goal_len, p_in = cd.pl.sw.type == LN_lin && tb + HB <= cd.pl.goal_len;
+			const bool fconst = (cd.lflags & CL_FCONST) != 0;
+			const bool f_hold = tb >= cd.fl.goal_len;
+			const bool xpe = cd.fl.sw.type == LN_xpe;
+			const bool f_in = (xpe || cd.fl.sw.type == LN_lge) && tb + HB <= cd.fl.goal_len;
+			const bool any_mul = (cd.lflags & (CL_MUL_GOAL | CL_MUL_HOLD)) != 0;
+			if (__all((p_hold || p_in) && (fconst || ((f_hold || f_in) && !any_mul)))) {
+				float m[HB];
+				uint32_t incs[HB];
+				{
+					const Sweep sw = cd.pl.sw;
+#pragma unroll
+					for (uint32_t j = 0; j < HB; ++j) {
+						const float v = sw.vm + sw.k * (float)((int32_t)(tb + j) + sw.adj_pos); /* (sweep_value_inl: LN_lin) */
+						m[j] = p_hold ? cd.pl.hold : v;
+					}
+				}
+				if (!__all(fconst)) {
+					const Sweep sw = cd.fl.sw;
+					const float d = xpe ? (sw.v0 - sw.vt) : (sw.vt - sw.v0), base = xpe ? sw.vt : sw.v0;
+					float x[HB], x2[HB], x3[HB], pp[HB];
+#pragma unroll
+					for (uint32_t j = 0; j < HB; ++j) x[j] = (float)(tb + j + sw.pos) * sw.inv_time;
+#pragma unroll
+					for (uint32_t j = 0; j < HB; ++j) x[j] = xpe ? 1.f - x[j] : x[j];
+#pragma unroll
+					for (uint32_t j = 0; j < HB; ++j) x2[j] = x[j] * x[j];
+#pragma unroll
+					for (uint32_t j = 0; j < HB; ++j) x3[j] = x2[j] * x[j];
+#pragma unroll
+					for (uint32_t j = 0; j < HB; ++j) pp[j] = x[j] * (629.f / 1792.f);
+#pragma unroll
+					for (uint32_t j = 0; j < HB; ++j) x[j] = x2[j] * (1163.f / 1792.f);
+#pragma unroll
+					for (uint32_t j = 0; j < HB; ++j) pp[j] = pp[j] + x[j];
+#pragma unroll
+					for (uint32_t j = 0; j < HB; ++j) x[j] = x3[j] + -1.f;
+#pragma unroll
+					for (uint32_t j = 0; j < HB; ++j) pp[j] = pp[j] * x[j];
+#pragma unroll
+					for (uint32_t j = 0; j < HB; ++j) pp[j] = pp[j] * x2[j];
+#pragma unroll
+					for (uint32_t j = 0; j < HB; ++j) pp[j] = x3[j] + pp[j];
+#pragma unroll
+					for (uint32_t j = 0; j < HB; ++j) pp[j] = d * pp[j];
+#pragma unroll
+					for (uint32_t j = 0; j < HB; ++j) pp[j] = base + pp[j];
+					bool big = false;
+#pragma unroll
+					for (uint32_t j = 0; j < HB; ++j) {
+						x[j] = cd.coeff * (f_hold ? cd.fl.hold : pp[j]);
+						big |= !(fabsf(x[j]) < 0x1p50f);
+					}
+					if (!__any(big)) {
+#pragma unroll
+						for (uint32_t j = 0; j < HB; ++j) incs[j] = (uint32_t)__double2loint((double)x[j] + 0x1.8p52);
+					} else {
+#pragma unroll
+						for (uint32_t j = 0; j < HB; ++j) incs[j] = rint32w(x[j]);
+					}
+#pragma unroll
+					for (uint32_t j = 0; j < HB; ++j) incs[j] = fconst ? cd.inc_const : incs[j];
+				} else {
+#pragma unroll
+					for (uint32_t j = 0; j < HB; ++j) incs[j] = cd.inc_const;
+				}
+#pragma unroll
+				for (uint32_t q = 0; q < HQ; ++q) {
+					*(uint4 *)(in_base + chain_io_word(half * HQ + q, l)) = make_uint4(incs[4 * q], incs[4 * q + 1], incs[4 * q + 2], incs[4 * q + 3]);
+					*(float4 *)(in_amt + chain_io_word(half * HQ + q, l)) = make_float4(m[4 * q], m[4 * q + 1], m[4 * q + 2], m[4 * q + 3]);
+				}
+				return;
+			}
+		}
 		/* (four frames at a time in a real loop: the instruction cache is shared with the chain wave, whose 32 unrolled steps
 		 * are 8 KiB by themselves, and with the CU next door -- the feeders' lines unrolled over sixteen frames made the
 		 * chain wave 5 % slower without it ever waiting at the barrier: -DCHAIN_PROF, round 4) */
