@@ -67,10 +67,12 @@ def profile_traffic(workload, kernel_prefix):
             if pmc.get("workload", {}).get("name") != workload:
                 continue
             k = [v for n, v in pmc["kernels"].items() if kernel_prefix in n]
-            best = (k[0]["hbm_bytes_per_launch_corrected"], "profiles/" + f, k[0].get("valu"))
+            # every kernel of a step is launched once per step (one segment per step): their sum is the step's HBM bytes
+            step_bytes = sum(v.get("hbm_bytes_per_launch_corrected", 0.0) for v in pmc["kernels"].values())
+            best = (k[0]["hbm_bytes_per_launch_corrected"], "profiles/" + f, k[0].get("valu"), step_bytes)
         except (OSError, KeyError, ValueError, IndexError):
             pass
-    return best if best else (None, None, None)
+    return best if best else (None, None, None, None)
 
 
 def profile_step_traffic(workload):
@@ -174,22 +176,21 @@ def sha256(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
+# tests/tools/bench_seqexec.py (tests/test_dist.py) imports this module, sets HARNESS to {"new_batch": fn} and calls main():
+# the N-rank logic of this script -- launcher, sharding, barriers, reductions -- then runs on a box without GPUs over the
+# tests' sequential plan executor. Lines produced that way say so in `data` and measure nothing. Nothing in this file
+# loads a test library or reads a test switch.
+HARNESS = None
+
+
 def test_backend():
-    """tests/test_dist.py only (SAU_BENCH_TEST_BACKEND = tests/seqexec/libseqexec.so): the host control plane over the
-    sequential plan executor, so that the N-rank logic of this script -- launcher, sharding, barriers, reductions --
-    runs on a box without GPUs. Lines produced this way say so in `data` and measure nothing."""
-    path = os.environ.get("SAU_BENCH_TEST_BACKEND")
-    if not path:
-        return None
-    import ctypes as C
-    seq = C.CDLL(path)
-    seq.seq_backend_create.restype = C.c_void_p
-    seq.seq_backend_create.argtypes = [C.c_uint32]
-    return seq.seq_backend_create(1016)
+    return HARNESS is not None
 
 
 def new_batch(sa, prgs):
-    return sa.Batch(prgs, 44100, backend=test_backend())
+    if HARNESS is not None:
+        return HARNESS["new_batch"](sa, prgs)
+    return sa.Batch(prgs, 44100)
 
 
 class Ranks:
@@ -206,7 +207,7 @@ class Ranks:
         # SAU_BENCH_BACKEND=gloo lets the N>1 logic be exercised on a box with fewer GPUs than
         # ranks (ranks then share devices; rendezvous and reductions on the CPU)
         self.backend = os.environ.get("SAU_BENCH_BACKEND", "nccl")
-        self.cuda = not os.environ.get("SAU_BENCH_TEST_BACKEND")
+        self.cuda = not test_backend()
         dev = local_rank % max(1, torch.cuda.device_count())
         os.environ.setdefault("SAU_AMD_DEVICE", str(dev))
         if self.cuda:
@@ -255,7 +256,7 @@ class Ranks:
         scaling figure would be that of a shared GPU."""
         import socket
         dev = int(os.environ.get("SAU_AMD_DEVICE", "0"))
-        bus = None if os.environ.get("SAU_BENCH_TEST_BACKEND") else sa.api.device_pci_bus_id(dev)
+        bus = None if test_backend() else sa.api.device_pci_bus_id(dev)
         mine = {"rank": self.rank, "host": socket.gethostname(), "device": dev, "pci_bus_id": bus,
                 "ms_per_step": ms_per_step}
         ranks = self.gather(mine)
@@ -347,9 +348,13 @@ def run_bank(args, R, sa, tabs, name, steps=20, warmup=2):
                       "operator_samples_per_s": frames * steps * R.world / dt * n_ops},
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                         "traffic": None, "kernel": spec["kernel"], "kernel_ms_per_step": launch_s * 1e3,
-                        "segments_per_step": tm["segments"] / steps, "algorithmic_bytes_per_step": alg}}
+                        "segments_per_step": tm["segments"] / steps, "algorithmic_bytes_per_step": alg,
+                        "is": "SURVEY 8d's algorithmic bytes over the kernel time (a convention: operator blocks stay in LDS); "
+                              "`hbm_real_frac` is the measured HBM traffic of a step over the step time"}}
     tr, src = profile_step_traffic(name)
     out["roofline"]["traffic"], out["roofline"]["traffic_source"] = tr, src
+    out["hbm_real_frac"] = tr / (dt / steps) / 8e12 if tr else None
+    out["first_step_sha_ok"] = True
     if not args.no_cpu and R.world == 1:
         out["cpu_baseline"] = cpu_reference(lambda: spec["make"](30), spec["what"].split(":")[0], spec["voices"], spec["ops"],
                                             tabs, budget_s=5.0)
@@ -416,7 +421,14 @@ def run_config3(args, R, sa, tabs):
     alg_bytes = (n_ops * 8 + 2) * args.frames
     launch_s = (tm["fast_ms"] / 1e3) / max(1, tm["segments"])
     achieved = alg_bytes / launch_s / 1e9 if launch_s > 0 else 0.0
-    traffic, source, valu = profile_traffic("config3", "fast_kernel<") if verified else (None, None, None)
+    traffic, source, valu, step_bytes = profile_traffic("config3", "fast_kernel<") if verified else (None, None, None, None)
+    # What binds this kernel (DESIGN.md 4.1 *Roofline*): vector-instruction issue. `valu` comes from the
+    # hash-matched PMC summary (tools/collect_profile.py): SQ_INSTS_VALU_* split the launch's vector instructions by class, each
+    # class is priced with the issue cost tools/valu_probe.hip measured on this part (profiles/r05_valu_costs.json; four waves
+    # per SIMD, as this kernel runs), and the sum is set against 1024 SIMDs x the launch's cycles. SURVEY 8d's byte model is
+    # kept beside it as `algorithmic` -- a convention (operator blocks priced as HBM traffic), not a bound this kernel meets.
+    valu_frac = valu.get("frac") if valu else None
+    hbm_real_frac = (step_bytes / (dt / args.steps) / 8e12) if step_bytes else None
     out = {
         "metric": "mono samples/sec/GPU @ N voices (depth-3 FM)",
         "value": frames_total / dt, "unit": "mixed mono int16 frames/s",
@@ -435,20 +447,27 @@ def run_config3(args, R, sa, tabs):
                    "dropin_value": dropin,
                    "voice_samples_per_s": frames_total / dt * args.voices,
                    "operator_samples_per_s": frames_total / dt * n_ops},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                     "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": source,
-                     # the kernel is VALU-bound in fact -- issued VALU instructions x 4 cycles over
-                     # SIMDs x launch cycles, from the same hash-matched PMC summary (tools/collect_profile.py)
+        "roofline": {"bound": "valu",
+                     "achieved": valu.get("weighted_cycles_per_launch") if valu else None,
+                     "peak": valu.get("simd_cycles_per_launch") if valu else None,
+                     "unit": "SIMD-cycles per launch (vector instructions by class x measured issue cost, against 1024 SIMDs x launch cycles)",
+                     "frac": valu_frac, "traffic": traffic, "traffic_source": source,
                      "valu": valu,
                      "kernel": "fast_kernel<12, 0, false, true> (closed-form build, 12 rows per pass, wide table blocks in LDS)",
-                     "avg_launch_ms": launch_s * 1e3,
-                     # what `frac` is and is not: SURVEY 8d's convention prices every operator's block output as one
-                     # f32 write + one f32 read in HBM; this kernel keeps those blocks in LDS, so `achieved` can exceed what HBM
-                     # could carry -- the real HBM bytes per launch are `traffic` (voice rows only, about an eighth of the
-                     # algorithmic figure) and the kernel is bound by VALU issue (`valu.busy_frac`) and the LDS table gather
-                     "caveat": "algorithmic bytes (SURVEY 8d: 8 B per operator-sample + 2 B per frame) over the launch time; operator "
-                               "blocks stay in LDS, HBM carries the voice rows only (`traffic`); binding resources: VALU issue and LDS gather",
-                     "launches": tm["segments"], "algorithmic_bytes_per_launch": alg_bytes},
+                     "avg_launch_ms": launch_s * 1e3, "launches": tm["segments"],
+                     # SURVEY 8d's convention: every operator's block output priced as one f32 write + one f32 read in HBM. This
+                     # kernel keeps those blocks in LDS -- HBM carries the voice rows only (`traffic`, about an eighth) -- so this
+                     # "fraction" is against a roof the kernel does not touch and may exceed 1; kept because 8d defines it
+                     "algorithmic": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                                     "bytes_per_launch": alg_bytes,
+                                     "is": "SURVEY 8d's 8 B per operator-sample + 2 B per frame over the launch time: a convention, not this kernel's traffic"},
+                     "hbm_real": {"bytes_per_step": step_bytes, "frac": hbm_real_frac,
+                                  "is": "HBM bytes of every kernel of one step (PMC: FETCH_SIZE x 2 + WRITE_SIZE) over the step time, against 8 TB/s"}},
+        # the same facts as top-level scalars (the driver's record keeps no nested objects: VERDICT r04 item 6)
+        "first_step_sha_ok": bool(verified), "valu_frac": valu_frac, "hbm_real_frac": hbm_real_frac,
+        "algorithmic_hbm_frac": achieved / 8000.0,
+        "dropin_frames_per_s": dropin["value"] if dropin else None,
+        "sustained_frames_per_s": sustained["value"] if sustained else None,
         "ranks": ranks,
     }
     if not args.no_cpu and R.world == 1:
@@ -725,7 +744,7 @@ def launch_ranks(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(sys.argv[0])] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
     import threading
     got = []
@@ -811,7 +830,7 @@ def main():
                     others[name] = o
     if out is not None:
         out["roofline"]["kernel_source_sha"] = kernel_source_hash()
-        if os.environ.get("SAU_BENCH_TEST_BACKEND"):
+        if test_backend():
             out["data"] = "TEST BACKEND (CPU plan executor of tests/seqexec): rank logic only, not a measurement"
         if others:
             out["other_workloads"] = others

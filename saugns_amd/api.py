@@ -91,14 +91,8 @@ class OpDesc(C.Structure):
                 ("freq2", LineDesc), ("pm_a", LineDesc)]
 
 
-def lib():
-    """Load (building if stale) libsaugns_amd.so and declare its C ABI."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    # SAU_AMD_LIB: load another build of the same library (A/B timing of kernel variants)
-    path = os.environ.get("SAU_AMD_LIB") or _build.build()
-    L = C.CDLL(path)
+def _declare(L):
+    """The C ABI of include/saugns_amd.h on a loaded library."""
     L.sau_create_Generator.restype = C.c_void_p
     L.sau_create_Generator.argtypes = [C.c_void_p, C.c_uint32]
     L.sau_destroy_Generator.argtypes = [C.c_void_p]
@@ -107,18 +101,10 @@ def lib():
                                    C.POINTER(C.c_size_t)]
     L.sauAmd_create_Batch.restype = C.c_void_p
     L.sauAmd_create_Batch.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint32]
-    L.sauAmd_create_Generator_with_backend.restype = C.c_void_p
-    L.sauAmd_create_Generator_with_backend.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
-    L.sauAmd_create_Batch_with_backend.restype = C.c_void_p
-    L.sauAmd_create_Batch_with_backend.argtypes = [C.POINTER(C.c_void_p), C.c_size_t,
-                                                   C.c_uint32, C.c_void_p]
     L.sauAmd_destroy_Batch.argtypes = [C.c_void_p]
     L.sauAmd_render_file.restype = C.c_bool
     L.sauAmd_render_file.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_int, C.c_int,
                                      C.POINTER(C.c_uint64)]
-    L.sauAmd_render_file_with_backend.restype = C.c_bool
-    L.sauAmd_render_file_with_backend.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_int, C.c_int,
-                                                  C.c_void_p, C.POINTER(C.c_uint64)]
     L.sauAmd_Batch_run.restype = C.c_bool
     L.sauAmd_Batch_run.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.c_bool,
                                    C.POINTER(C.c_bool), C.POINTER(C.c_size_t)]
@@ -147,12 +133,65 @@ def lib():
     L.sauAmd_build_bank.restype = C.c_void_p
     L.sauAmd_build_bank.argtypes = [C.c_void_p, C.c_size_t, C.c_float, C.c_uint32]
     L.sauAmd_free_bank.argtypes = [C.c_void_p]
-    _lib = L
     return L
 
 
-def last_error():
-    return lib().sauAmd_last_error().decode()
+def lib():
+    """Load (building if stale) libsaugns_amd.so and declare its C ABI."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # SAU_AMD_LIB: load another build of the same library (A/B timing of kernel variants)
+    path = os.environ.get("SAU_AMD_LIB") or _build.build()
+    _lib = _declare(C.CDLL(path))
+    if _tables is not None:
+        _lib.sauAmd_set_piluts(_tables.ctypes.data)
+    return _lib
+
+
+_hooks = None
+_tables = None
+
+
+def use_hooks(path):
+    """tests/ only: load the test-hook library (tests/hooks/libsaugns_amd_hooks.so: the product's object files + the entry
+    points that run the host control plane over an injected backend, + the known-answer probes). The product library has
+    none of those; objects made with ``backend=...`` live in, and are driven through, the hook library."""
+    global _hooks
+    if _hooks is None:
+        L = _declare(C.CDLL(path))
+        L.sauAmd_create_Generator_with_backend.restype = C.c_void_p
+        L.sauAmd_create_Generator_with_backend.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        L.sauAmd_create_Batch_with_backend.restype = C.c_void_p
+        L.sauAmd_create_Batch_with_backend.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint32, C.c_void_p]
+        L.sauAmd_render_file_with_backend.restype = C.c_bool
+        L.sauAmd_render_file_with_backend.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_int, C.c_int,
+                                                      C.c_void_p, C.POINTER(C.c_uint64)]
+        L.sauAmd_Generator_rewinds.restype = C.c_uint
+        L.sauAmd_Generator_rewinds.argtypes = [C.c_void_p]
+        if _tables is not None:
+            L.sauAmd_set_piluts(_tables.ctypes.data)
+        _hooks = L
+    return _hooks
+
+
+def hooks():
+    if _hooks is None:
+        raise RuntimeError("the test-hook library is not loaded (tests/conftest.py: use_hooks)")
+    return _hooks
+
+
+_last_used = None  # the library the most recent Generator / Batch call went to (the hook library for backend=... objects)
+
+
+def last_error(L=None):
+    return (L or _last_used or lib()).sauAmd_last_error().decode()
+
+
+def _used(L):
+    global _last_used
+    _last_used = L
+    return L
 
 
 def device_pci_bus_id(device=0):
@@ -162,9 +201,13 @@ def device_pci_bus_id(device=0):
 
 
 def set_piluts(tables):
-    t = np.ascontiguousarray(tables, dtype=np.float32)
+    global _tables
+    t = np.ascontiguousarray(tables, dtype=np.float32).copy()
     assert t.shape == (12, 2048)
+    _tables = t
     lib().sauAmd_set_piluts(t.ctypes.data)
+    if _hooks is not None:
+        _hooks.sauAmd_set_piluts(t.ctypes.data)
 
 
 SNDFILE_RAW, SNDFILE_AU, SNDFILE_WAV = 0, 1, 2
@@ -177,10 +220,10 @@ def render_file(program, srate, path, fmt=SNDFILE_WAV, channels=1, backend=None)
     if backend is None:
         ok = lib().sauAmd_render_file(program.ptr, srate, os.fsencode(path), fmt, channels, C.byref(n))
     else:
-        ok = lib().sauAmd_render_file_with_backend(program.ptr, srate, os.fsencode(path), fmt,
-                                                   channels, backend, C.byref(n))
+        ok = hooks().sauAmd_render_file_with_backend(program.ptr, srate, os.fsencode(path), fmt,
+                                                     channels, backend, C.byref(n))
     if not ok:
-        raise RuntimeError("sauAmd_render_file failed: " + last_error())
+        raise RuntimeError("sauAmd_render_file failed: " + last_error(None if backend is None else hooks()))
     return n.value
 
 
@@ -230,17 +273,18 @@ class Generator:
 
     def __init__(self, program, srate, backend=None):
         self._prg = program  # borrowed by the C side: keep alive
+        self._L = _used(lib() if backend is None else hooks())
         if backend is None:
-            self._g = lib().sau_create_Generator(program.ptr, srate)
-        else:  # tests: an injected backend (owned by the generator from here on)
-            self._g = lib().sauAmd_create_Generator_with_backend(program.ptr, srate, backend)
+            self._g = self._L.sau_create_Generator(program.ptr, srate)
+        else:  # tests: an injected backend (owned by the generator from here on), in the hook library
+            self._g = self._L.sauAmd_create_Generator_with_backend(program.ptr, srate, backend)
         if not self._g:
-            raise RuntimeError("sau_create_Generator returned NULL: " + last_error())
+            raise RuntimeError("sau_create_Generator returned NULL: " + last_error(self._L))
 
     def run(self, buf, buf_len, stereo=False):
         """-> (more, out_len); buf is an int16 numpy array of buf_len*(1|2)."""
         n = C.c_size_t()
-        more = lib().sauGenerator_run(self._g, buf.ctypes.data, buf_len, stereo, C.byref(n))
+        more = _used(self._L).sauGenerator_run(self._g, buf.ctypes.data, buf_len, stereo, C.byref(n))
         return bool(more), n.value
 
     def render(self, stereo=False, chunk=11289, max_frames=0):
@@ -256,9 +300,13 @@ class Generator:
         pcm = np.concatenate(out) if out else np.zeros(0, np.int16)
         return pcm[: max_frames * ch] if max_frames else pcm
 
+    def rewinds(self):
+        """tests: how often a call of another size / channel layout took the read-ahead back (hook library only)"""
+        return int(self._L.sauAmd_Generator_rewinds(self._g))
+
     def close(self):
-        if self._g:
-            lib().sau_destroy_Generator(self._g)
+        if getattr(self, "_g", None):
+            self._L.sau_destroy_Generator(self._g)
             self._g = None
 
     def __del__(self):
@@ -272,12 +320,13 @@ class Batch:
         self._prgs = list(programs)
         self.n = len(self._prgs)
         arr = (C.c_void_p * self.n)(*[p.ptr for p in self._prgs])
+        self._L = _used(lib() if backend is None else hooks())
         if backend is None:
-            self._b = lib().sauAmd_create_Batch(arr, self.n, srate)
-        else:  # tests only: host control plane on an injected executor
-            self._b = lib().sauAmd_create_Batch_with_backend(arr, self.n, srate, backend)
+            self._b = self._L.sauAmd_create_Batch(arr, self.n, srate)
+        else:  # tests only: host control plane on an injected executor, in the hook library
+            self._b = self._L.sauAmd_create_Batch_with_backend(arr, self.n, srate, backend)
         if not self._b:
-            raise RuntimeError("sauAmd_create_Batch returned NULL: " + last_error())
+            raise RuntimeError("sauAmd_create_Batch returned NULL: " + last_error(self._L))
 
     def run(self, buf_len, stereo=False, fetch=True):
         """-> (pcm [n, buf_len*ch] or None, more[n], out_len[n])"""
@@ -289,9 +338,9 @@ class Batch:
             ptrs = (C.c_void_p * self.n)(*[pcm[i].ctypes.data for i in range(self.n)])
         else:
             pcm, ptrs = None, None
-        ok = lib().sauAmd_Batch_run(self._b, ptrs, buf_len, stereo, more, lens)
+        ok = _used(self._L).sauAmd_Batch_run(self._b, ptrs, buf_len, stereo, more, lens)
         if not ok:
-            raise RuntimeError("sauAmd_Batch_run failed: " + last_error())
+            raise RuntimeError("sauAmd_Batch_run failed: " + last_error(self._L))
         return pcm, [bool(m) for m in more], [int(x) for x in lens]
 
     def render(self, stereo=False, chunk=11289, max_frames=0):
@@ -315,34 +364,34 @@ class Batch:
     def set_call_len(self, frames):
         """The sauGenerator_run call size whose block lattice the batch reproduces (0: every run
         is one call)."""
-        lib().sauAmd_Batch_set_call_len(self._b, frames)
+        self._L.sauAmd_Batch_set_call_len(self._b, frames)
 
     def sync(self):
-        if not lib().sauAmd_Batch_sync(self._b):
-            raise RuntimeError(last_error())
+        if not self._L.sauAmd_Batch_sync(self._b):
+            raise RuntimeError(last_error(self._L))
 
     def timing(self, reset=False):
         r, m, n = C.c_double(), C.c_double(), C.c_uint64()
-        lib().sauAmd_Batch_timing(self._b, C.byref(r), C.byref(m), C.byref(n), int(reset))
+        self._L.sauAmd_Batch_timing(self._b, C.byref(r), C.byref(m), C.byref(n), int(reset))
         return r.value, m.value, n.value
 
     def set_timing(self, level):
-        lib().sauAmd_Batch_set_timing(self._b, int(level))
+        self._L.sauAmd_Batch_set_timing(self._b, int(level))
 
     def timing_ex(self, reset=False):
         """-> dict of accumulated kernel times (ms) and the number of segments."""
         out = (C.c_double * 4)()
         n = C.c_uint64()
-        lib().sauAmd_Batch_timing_ex(self._b, out, C.byref(n), int(reset))
+        self._L.sauAmd_Batch_timing_ex(self._b, out, C.byref(n), int(reset))
         return {"fast_ms": out[0], "block_ms": out[1], "mix_ms": out[2], "aux_ms": out[3],
                 "segments": n.value}
 
     def device_pcm(self, stream):
-        return lib().sauAmd_Batch_device_pcm(self._b, stream)
+        return self._L.sauAmd_Batch_device_pcm(self._b, stream)
 
     def close(self):
-        if self._b:
-            lib().sauAmd_destroy_Batch(self._b)
+        if getattr(self, "_b", None):
+            self._L.sauAmd_destroy_Batch(self._b)
             self._b = None
 
     def __del__(self):

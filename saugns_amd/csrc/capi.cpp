@@ -2,6 +2,7 @@
 #include "../../include/saugns_amd.h"
 #include "engine.h"
 #include "hip_backend.h"
+#include "capi_internal.h"
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
@@ -30,15 +31,22 @@ struct sauAmdBatch {
 
 /* The drop-in generator renders ahead of its caller: the reference host asks
  * for 11289 frames at a time (saugns.c:589-618), and a device round trip per
- * such call would cost more than the rendering. Output does not depend on how
- * the stream is cut into calls (as in the reference), so the PCM of one larger
- * engine run is handed out piecewise, from three page-locked buffers: while the
+ * such call would cost more than the rendering. A host that keeps asking for what it asked for
+ * before -- every host there is -- is handed the PCM of one larger
+ * engine run piecewise (the run reproduces the reference's block lattice for calls of that size:
+ * engine.h, set_call_len), from three page-locked buffers: while the
  * host consumes one, the device renders and copies the next two runs into the
  * others -- two, so that a run is already queued when the one before it ends
  * (with one run in flight the device stood idle between a run's completion and
  * the host's next issue: 1.27 ms per 176400-frame run of BASELINE config 3
  * against 0.93 ms of kernels; SAU_AMD_READAHEAD_DEPTH=1 gives that back).
- * SAU_AMD_READAHEAD=<frames> sets the size of a run, 0 turns the scheme off. */
+ * SAU_AMD_READAHEAD=<frames> sets the size of a run, 0 turns the scheme off.
+ * sauGenerator_run takes `buf_len` and `stereo` per call, though (sau/generator.c:905-913), and frames rendered ahead for
+ * calls of one size and layout are not what the reference gives a host that then asks for another: the lattice of <= 1024-
+ * frame blocks restarts at every call (generator.c:854-878), and mono is (L + R) / 2 before rounding. So every run starts
+ * from a snapshot of the engine (Engine::snapshot: host mirrors + the operator records on the device); a call that differs
+ * from the ones the buffered runs were issued for takes the engine back to the start of the run being handed out, renders
+ * what the host has consumed of it once more (discarded) and goes on from there in the new size / layout (round 5). */
 struct sauGenerator {
 	sauAmdBatch batch;
 	static constexpr int SLOTS = 3;
@@ -58,6 +66,9 @@ struct sauGenerator {
 	 * The device is never idle meanwhile -- the next run is always issued before the current one is handed out. */
 	unsigned runs_issued = 0;
 	bool ramp = true;                      /* SAU_AMD_READAHEAD_RAMP=0: every run ahead_frames long */
+	size_t ahead_call = 0;                 /* the call size the buffered runs were issued for (their block lattice) */
+	Engine::Snapshot snap[SLOTS];          /* the engine before the run in each slot */
+	unsigned rewinds = 0;                  /* times a changed call took the engine back (sauAmd_Generator_rewinds: tests) */
 };
 
 /* sau/generator/noise.h:18-21 */
@@ -91,7 +102,7 @@ static bool make_batch(sauAmdBatch &b, const sauProgram *const *prgs, size_t n,
 	return true;
 }
 
-static sauGenerator *make_generator(const sauProgram *prg, uint32_t srate, Backend *injected) {
+sauGenerator *sauamd_internal::make_generator(const sauProgram *prg, uint32_t srate, Backend *injected) {
 	if (!prg) return nullptr;
 	sauGenerator *g = new sauGenerator();
 	if (!make_batch(g->batch, &prg, 1, srate, injected)) { delete g; return nullptr; }
@@ -102,14 +113,9 @@ static sauGenerator *make_generator(const sauProgram *prg, uint32_t srate, Backe
 }
 
 extern "C" sauGenerator *sau_create_Generator(const sauProgram *prg, uint32_t srate) {
-	return make_generator(prg, srate, nullptr);
+	return sauamd_internal::make_generator(prg, srate, nullptr);
 }
-
-/* test hook: the drop-in generator over an injected backend (tests/seqexec) */
-extern "C" SAU_AMD_API sauGenerator *sauAmd_create_Generator_with_backend(const sauProgram *prg,
-		uint32_t srate, void *backend) {
-	return make_generator(prg, srate, (Backend *)backend);
-}
+unsigned sauamd_internal::generator_rewinds(const sauGenerator *g) { return g ? g->rewinds : 0u; }
 
 extern "C" void sau_destroy_Generator(sauGenerator *o) {
 	if (!o) return;
@@ -151,6 +157,7 @@ static bool generator_issue(sauGenerator *o, size_t big, size_t call_len, bool s
 	}
 	bool more = false;
 	size_t len = 0;
+	if (!o->batch.engine->snapshot(o->snap[k], k, err)) return false; /* (where a call of another size or layout goes back to) */
 	/* PCM stays on the device; the copy queues behind the mixer */
 	if (!o->batch.engine->run(nullptr, frames, stereo, &more, &len, err)) return false;
 	if (len && !be->fetch_pcm_async(0, o->slot[k], (uint32_t)len, stereo, k, err)) return false;
@@ -158,6 +165,36 @@ static bool generator_issue(sauGenerator *o, size_t big, size_t call_len, bool s
 	o->q_len[k] = len;
 	o->more = more;
 	o->ahead_stereo = stereo;
+	o->ahead_call = call_len;
+	return true;
+}
+
+/* The host's call is not of the kind the buffered runs were rendered for: back to the start of the run being handed out
+ * (or, when that one is used up, of the first one queued), what the host has had of it rendered once more in the old size
+ * and layout -- the operators then stand where the reference's do after those calls -- and everything queued dropped. */
+static bool generator_rewind(sauGenerator *o, std::string &err) {
+	Backend *be = o->batch.engine->backend();
+	Engine *en = o->batch.engine;
+	int k = o->cur;
+	size_t consumed = o->pos;
+	if (o->pos == o->len) { /* (then something is queued: the caller has checked) */
+		k = (o->cur + 1) % sauGenerator::SLOTS;
+		consumed = 0;
+	}
+	if (!be->sync(err)) return false; /* the runs in flight end where they end; their PCM is dropped */
+	if (!en->restore(o->snap[k], k, err)) return false;
+	o->more = true; /* (a run is only ever issued while there is signal left) */
+	if (consumed) {
+		bool more = false;
+		size_t len = 0;
+		en->set_call_len(o->ahead_call);
+		if (!en->run(nullptr, consumed, o->ahead_stereo, &more, &len, err)) return false;
+		o->more = more;
+	}
+	o->pos = o->len = 0;
+	o->queued = 0;
+	o->runs_issued = 0; /* short runs first again: the host is waiting */
+	++o->rewinds;
 	return true;
 }
 
@@ -192,13 +229,16 @@ static bool generator_run(sauGenerator *o, int16_t *buf, size_t buf_len, bool st
 		if (out_len) *out_len = len;
 		return more;
 	}
-	if ((o->pos < o->len || o->queued) && o->ahead_stereo != stereo)
-		return generator_fail(o, buf, buf_len, stereo, out_len,
-				"channel layout changed between calls while frames were buffered");
 	/* An engine run covers whole host calls, so that it starts where one of them does: the
 	 * reference's block lattice restarts at every call (generator.c:854-878; Lattice in
 	 * sau_dev_math.h), and the engine lays it out for calls of this size. A host that changes its
-	 * call size mid-stream (saugns.c never does) gets the new lattice from the next run on. */
+	 * call size or its channel layout mid-stream (saugns.c never does; the interface allows both) gets what the
+	 * reference would give it: the frames buffered for the old kind of call are rendered again. */
+	if ((o->pos < o->len || o->queued) && (o->ahead_stereo != stereo || o->ahead_call != buf_len) &&
+	    !generator_rewind(o, err))
+		return generator_fail(o, buf, buf_len, stereo, out_len, err);
+	if (o->pos == o->len && !o->queued && (o->ahead_frames == 0 || buf_len >= o->ahead_frames))
+		return generator_run(o, buf, buf_len, stereo, out_len); /* (nothing buffered any more and the call is large: straight into the caller's buffer, above) */
 	const size_t big = buf_len >= o->ahead_frames ? buf_len : o->ahead_frames / buf_len * buf_len;
 	o->batch.engine->set_call_len(buf_len);
 	size_t filled = 0;
@@ -242,20 +282,13 @@ static bool generator_run(sauGenerator *o, int16_t *buf, size_t buf_len, bool st
 
 extern "C" sauAmdBatch *sauAmd_create_Batch(const sauProgram *const *prgs, size_t n,
 		uint32_t srate) {
-	if (!prgs || !n) return nullptr;
-	sauAmdBatch *b = new sauAmdBatch();
-	if (!make_batch(*b, prgs, n, srate, nullptr)) { delete b; return nullptr; }
-	return b;
+	return sauamd_internal::make_batch_over(prgs, n, srate, nullptr);
 }
 
-/* Test hook (not in the public header): run the host control plane on a
- * caller-supplied sauengine::Backend. Used by tests/ to exercise event
- * handling and plan compilation without a GPU. */
-extern "C" SAU_AMD_API sauAmdBatch *sauAmd_create_Batch_with_backend(const sauProgram *const *prgs,
-		size_t n, uint32_t srate, void *backend) {
-	if (!prgs || !n || !backend) return nullptr;
+sauAmdBatch *sauamd_internal::make_batch_over(const sauProgram *const *prgs, size_t n, uint32_t srate, Backend *injected) {
+	if (!prgs || !n) return nullptr;
 	sauAmdBatch *b = new sauAmdBatch();
-	if (!make_batch(*b, prgs, n, srate, (Backend *)backend)) { delete b; return nullptr; }
+	if (!make_batch(*b, prgs, n, srate, injected)) { delete b; return nullptr; }
 	return b;
 }
 
@@ -326,33 +359,4 @@ extern "C" const char *sauAmd_last_error(void) { return g_last_error.c_str(); }
 extern "C" int sauAmd_device_count(void) { return sauhip::device_count(); }
 extern "C" bool sauAmd_device_pci_bus_id(int device, char *buf, size_t len) {
 	return sauhip::device_pci_bus_id(device, buf, (int)(len > 255 ? 255 : len));
-}
-
-/* Test probes (not in the public header): the shared line arithmetic as
- * compiled for the device and for the host. state = {v0, vt, pos, end, type,
- * flags} as 6 dwords, updated in place. */
-extern "C" SAU_AMD_API int sauAmd_kat_line_device(uint32_t *state, uint32_t len, const float *mul, float *out) {
-	saudev::LineState st, st2;
-	memcpy(&st, state, sizeof st);
-	if (!sauhip::kat_line(st, len, mul, out, &st2)) return 0;
-	memcpy(state, &st2, sizeof st2);
-	return 1;
-}
-/* Test probe: for wave id w, how many divisors make div_diff_scale differ from
- * IEEE division (and the first such bit pattern); variant 1 is the uncorrected
- * product a * rcp(b), which the probe must catch. -1 on a device error. */
-extern "C" SAU_AMD_API long long sauAmd_kat_div_device(uint32_t wave, int variant, uint32_t *first_bad) {
-	unsigned long long m = 0;
-	uint32_t fb = 0xffffffffu;
-	if (wave >= 12 || !sauhip::kat_div(sauengine::wave_consts()[wave].diff_scale, variant, &m, &fb)) return -1;
-	if (first_bad) *first_bad = fb;
-	return (long long)m;
-}
-extern "C" SAU_AMD_API int sauAmd_kat_line_host(uint32_t *state, uint32_t len, const float *mul, float *out) {
-	saudev::LineState st;
-	memcpy(&st, state, sizeof st);
-	saudev::LineBlock lb = saudev::line_begin(st, len, mul != nullptr, mul ? mul[0] : 0.f, saudev::lattice_none(), 0);
-	for (uint32_t j = 0; j < len; ++j) out[j] = saudev::line_value(lb, j, mul ? mul[j] : 1.f);
-	memcpy(state, &st, sizeof st);
-	return 1;
 }

@@ -513,6 +513,47 @@ bool Engine::reserve(size_t frames, bool stereo, std::string &err) {
 	return true;
 }
 
+bool Engine::snapshot(Snapshot &s, int slot, std::string &err) {
+	s.valid = false;
+	s.streams.resize(streams_.size());
+	for (size_t i = 0; i < streams_.size(); ++i) {
+		const Stream &st = streams_[i];
+		Snapshot::StreamState &d = s.streams[i];
+		d.event = st.event; d.event_pos = st.event_pos; d.voice = st.voice; d.since_event = st.since_event;
+		d.voices.resize(st.voices.size());
+		for (size_t v = 0; v < st.voices.size(); ++v)
+			d.voices[v] = Snapshot::StreamState::Vo{st.voices[v].duration, st.voices[v].carr_op, st.voices[v].init};
+		d.ops = st.ops;
+	}
+	s.frames_done = frames_done_;
+	s.call_len = call_len_; s.lat_call = lat_call_; s.call_phase = call_phase_;
+	s.out_dirty = out_dirty_;
+	if (!backend_->save_state(slot, err)) return false;
+	s.valid = true;
+	return true;
+}
+
+bool Engine::restore(const Snapshot &s, int slot, std::string &err) {
+	if (!s.valid || s.streams.size() != streams_.size()) { err = "no snapshot to go back to"; return false; }
+	for (size_t i = 0; i < streams_.size(); ++i) {
+		Stream &st = streams_[i];
+		const Snapshot::StreamState &d = s.streams[i];
+		st.event = d.event; st.event_pos = d.event_pos; st.voice = d.voice; st.since_event = d.since_event;
+		st.call_gen = st.part_start = st.part_gen = 0;
+		for (size_t v = 0; v < st.voices.size(); ++v) {
+			VoiceHost &vn = st.voices[v];
+			vn.duration = d.voices[v].duration; vn.carr_op = d.voices[v].carr_op; vn.init = d.voices[v].init;
+			vn.plan_valid = false; /* (compiled again from the mirrors below: the graphs may have been other ones then) */
+		}
+		st.ops = d.ops;
+	}
+	plans_dirty_ = true;
+	frames_done_ = s.frames_done;
+	call_len_ = s.call_len; lat_call_ = s.lat_call; call_phase_ = s.call_phase;
+	out_dirty_ = true; /* (whatever the abandoned runs left in the PCM block is cleared before the next one) */
+	return backend_->load_state(slot, err);
+}
+
 /* generator.c:905-973, for all streams in lock step. */
 bool Engine::run(int16_t *const *host_bufs, size_t buf_len, bool stereo,
 		bool *more, size_t *out_len, std::string &err) {

@@ -99,6 +99,11 @@ public:
 	virtual bool wait_fetch(int slot, std::string &err) { (void)slot; (void)err; return true; }
 	virtual void *alloc_host(size_t bytes) { return malloc(bytes); }
 	virtual void free_host(void *p) { free(p); }
+	/* Operator state kept / brought back (Engine::snapshot / restore: the drop-in generator's read-ahead rewinds when
+	 * its host changes the size or the channel layout of its calls). `slot` (0..3) names the copy; both are ordered
+	 * with the rendering like any other device work. */
+	virtual bool save_state(int slot, std::string &err) { (void)slot; err = "this backend keeps no state snapshots"; return false; }
+	virtual bool load_state(int slot, std::string &err) { (void)slot; err = "this backend keeps no state snapshots"; return false; }
 };
 
 /* ---- plan compiler (plan.cpp) -------------------------------------------- */
@@ -196,6 +201,26 @@ public:
 	void set_pcm_byteswap(bool on) { pcm_swap_ = on; }
 	size_t n_streams() const { return streams_.size(); }
 	Backend *backend() { return backend_; }
+
+	/* The engine as it stands -- event positions, voice durations, operator mirrors, the call lattice's phase, and (by the
+	 * backend, under `slot`) every operator's record -- so that restore() can take a render back to this frame: sauGenerator_run
+	 * takes `buf_len` and `stereo` per call (sau/generator.c:905-913), and frames rendered ahead for calls of one kind are
+	 * not what the reference gives a host that then asks for another. Plans are not kept: they are a function of the
+	 * operator mirrors and are compiled again after a restore. */
+	struct Snapshot {
+		struct StreamState {
+			size_t event = 0; uint32_t event_pos = 0, voice = 0; uint64_t since_event = 0;
+			struct Vo { uint32_t duration, carr_op; bool init; };
+			std::vector<Vo> voices;
+			std::vector<OpMirror> ops;
+		};
+		std::vector<StreamState> streams;
+		uint64_t frames_done = 0;
+		uint32_t call_len = 0, lat_call = 0, call_phase = 0;
+		bool out_dirty = false, valid = false;
+	};
+	bool snapshot(Snapshot &s, int slot, std::string &err);
+	bool restore(const Snapshot &s, int slot, std::string &err);
 	uint64_t frames_done() const { return frames_done_; }
 
 private:

@@ -21,11 +21,6 @@ HipBackend *create_hip_backend(std::string &err);
 int device_count();
 /* "domain:bus:device.function" of HIP device `dev` (bench.py: one rank per physical GPU, proved in the result line) */
 bool device_pci_bus_id(int dev, char *buf, int len);
-/* test probe: the differentiator's division against IEEE division, all divisors (kat_div_kernel) */
-bool kat_div(float a, int variant, unsigned long long *mismatches, uint32_t *first_bad);
-/* test probe: evaluate one line block on the device (kat_line_kernel) */
-bool kat_line(const saudev::LineState &st, uint32_t len, const float *mul, float *out,
-		saudev::LineState *st_out);
 
 } /* namespace sauhip */
 #endif

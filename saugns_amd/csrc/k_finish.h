@@ -321,14 +321,3 @@ __global__ void event_kernel(DevOp *ops, const OpUpdate *recs, uint32_t n, const
 	apply_update(o, u, wc);
 	ops[u.op] = o;
 }
-
-/* Known-answer probe of the shared arithmetic as compiled for the device:
- * one block evaluates a line for `len` samples exactly as ST_LINE does. */
-__global__ void kat_line_kernel(LineState st, uint32_t len, const float *mul, float *out,
-		LineState *st_out) {
-	LineState ls = st;
-	LineBlock lb = line_begin(ls, len, mul != nullptr, mul ? mul[0] : 0.f, lattice_none(), 0);
-	for (uint32_t j = threadIdx.x; j < len; j += blockDim.x)
-		out[j] = line_value(lb, j, mul ? mul[j] : 1.f);
-	if (threadIdx.x == 0) *st_out = ls;
-}

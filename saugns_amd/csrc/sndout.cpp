@@ -12,6 +12,7 @@
 #include "../../include/saugns_amd.h"
 #include "engine.h"
 #include "hip_backend.h"
+#include "capi_internal.h"
 #include <stdio.h>
 #include <string.h>
 #include <string>
@@ -87,7 +88,7 @@ struct SndOut {
 
 thread_local std::string g_file_error;
 
-bool render_file(const sauProgram *prg, uint32_t srate, const char *path, int format,
+bool render_file_over(const sauProgram *prg, uint32_t srate, const char *path, int format,
 		int channels, Backend *backend /* owned */, uint64_t *frames_out, std::string &err) {
 	if (!prg || !path || (channels != 1 && channels != 2) || format < 0 || format > SAU_AMD_SNDFILE_WAV) {
 		err = "bad argument";
@@ -157,7 +158,7 @@ extern "C" bool sauAmd_render_file(const sauProgram *prg, uint32_t srate, const 
 		int format, int channels, uint64_t *frames_out) {
 	std::string err;
 	sauhip::HipBackend *hip = sauhip::create_hip_backend(err);
-	bool ok = hip && render_file(prg, srate, path, format, channels, hip, frames_out, err);
+	bool ok = hip && render_file_over(prg, srate, path, format, channels, hip, frames_out, err);
 	if (!ok) {
 		g_file_error = err;
 		fprintf(stderr, "error [output]: %s\n", err.c_str());
@@ -165,12 +166,8 @@ extern "C" bool sauAmd_render_file(const sauProgram *prg, uint32_t srate, const 
 	return ok;
 }
 
-/* Test hook (not in the public header): the same output stage over a
- * caller-supplied sauengine::Backend (CPU tests of headers, chunking, byte order). */
-extern "C" SAU_AMD_API bool sauAmd_render_file_with_backend(const sauProgram *prg, uint32_t srate,
-		const char *path, int format, int channels, void *backend, uint64_t *frames_out) {
-	std::string err;
-	bool ok = backend && render_file(prg, srate, path, format, channels, (Backend *)backend, frames_out, err);
-	if (!ok) fprintf(stderr, "error [output]: %s\n", err.c_str());
-	return ok;
+/* (tests/hooks: the same output stage over a caller-supplied backend -- CPU tests of headers, chunking, byte order) */
+bool sauamd_internal::render_file(const sauProgram *prg, uint32_t srate, const char *path, int format, int channels,
+		Backend *injected, uint64_t *frames_out, std::string &err) {
+	return injected && render_file_over(prg, srate, path, format, channels, injected, frames_out, err);
 }

@@ -107,8 +107,35 @@ def sa(tables):
     return saugns_amd
 
 
+def hooks_path():
+    """tests/hooks/libsaugns_amd_hooks.so: the product's own object files + the test entry points (injected backends, the
+    read-ahead's rewind count, known-answer probes). SAU_HOOKS_LIB: another build that holds them (tests/test_sanitizers.py)."""
+    import subprocess
+    path = os.environ.get("SAU_HOOKS_LIB")
+    if not path:
+        import saugns_amd
+        saugns_amd.build()  # (the hook library links saugns_amd/csrc/*.o)
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "hooks")])
+        path = os.path.join(ROOT, "tests", "hooks", "libsaugns_amd_hooks.so")
+    return path
+
+
 @pytest.fixture(scope="session")
-def seqexec():
+def hooks(sa):
+    """The hook library, registered with saugns_amd.api (objects made with backend=... live in it)."""
+    L = sa.api.use_hooks(hooks_path())
+    L.sauAmd_kat_line_host.restype = C.c_int
+    L.sauAmd_kat_line_host.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    if hasattr(L, "sauAmd_kat_line_device"):  # (not in the sanitizer build of the host side)
+        L.sauAmd_kat_line_device.restype = C.c_int
+        L.sauAmd_kat_line_device.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.sauAmd_kat_div_device.restype = C.c_longlong
+        L.sauAmd_kat_div_device.argtypes = [C.c_uint32, C.c_int, C.c_void_p]
+    return L
+
+
+@pytest.fixture(scope="session")
+def seqexec(hooks):
     import subprocess
     # SAU_SEQEXEC_LIB: another build that holds the executor (tests/test_sanitizers.py: the ASan + UBSan library, which is
     # also what SAU_AMD_LIB then points the product's loader at)
@@ -120,6 +147,15 @@ def seqexec():
     lib.seq_backend_create.restype = C.c_void_p
     lib.seq_backend_create.argtypes = [C.c_uint32]
     return lib
+
+
+def need_ref(oracle):
+    """GPU tests that compare with the compiled reference (oracle/_ref/libsau_ref.so, built here by oracle/Makefile from
+    /root/reference and carried to the GPU box with the tree): a missing checker is a FAILURE there, not a skip -- nine of
+    the strongest tests would otherwise vanish silently."""
+    if not oracle.have_ref():
+        pytest.fail("oracle/_ref/libsau_ref.so is not here: build it with `make -C oracle ref` where /root/reference exists; "
+                    "it travels to the GPU box with the tree")
 
 
 def load_program(sa, key):

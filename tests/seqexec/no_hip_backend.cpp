@@ -9,6 +9,4 @@ namespace sauhip {
 HipBackend *create_hip_backend(std::string &err) { err = "no HIP device (sanitizer build of the host control plane: there is no device backend in it)"; return nullptr; }
 int device_count() { return 0; }
 bool device_pci_bus_id(int, char *, int) { return false; }
-bool kat_div(float, int, unsigned long long *, uint32_t *) { return false; }
-bool kat_line(const saudev::LineState &, uint32_t, const float *, float *, saudev::LineState *) { return false; }
 } /* namespace sauhip */

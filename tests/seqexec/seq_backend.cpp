@@ -339,6 +339,13 @@ struct SeqBackend : public Backend {
 	}
 	const int16_t *device_pcm(uint32_t) override { return nullptr; }
 	bool sync(std::string &) override { return true; }
+	std::vector<DevOp> snap[4];
+	bool save_state(int slot, std::string &) override { snap[slot & 3] = ops; return true; }
+	bool load_state(int slot, std::string &err) override {
+		if (snap[slot & 3].size() != ops.size()) { err = "no operator state was saved under this slot"; return false; }
+		ops = snap[slot & 3];
+		return true;
+	}
 };
 
 } /* namespace */

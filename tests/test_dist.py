@@ -34,6 +34,7 @@ def test_two_rank_gloo_batch(tmp_path, seqexec):  # (the fixture rebuilds libseq
         from conftest import load_program, GOLDEN
         tabs = np.fromfile(os.path.join(GOLDEN, "piluts_ref.f32"), dtype="<f4").reshape(12, 2048)
         sa.set_piluts(tabs)
+        sa.api.use_hooks(os.path.join(%r, "tests", "hooks", "libsaugns_amd_hooks.so"))
         seq = C.CDLL(os.path.join(%r, "tests", "seqexec", "libseqexec.so"))
         seq.seq_backend_create.restype = C.c_void_p; seq.seq_backend_create.argtypes = [C.c_uint32]
         # as bench.py --workload config4 shards them: seeds of tests/golden/config4_seeds.npz (all 512
@@ -56,7 +57,7 @@ def test_two_rank_gloo_batch(tmp_path, seqexec):  # (the fixture rebuilds libseq
             assert abs(checksum - want) <= 4 * 11025, (checksum, want)
             print("OK", frames)
         dist.destroy_process_group()
-    """ % (ROOT, ROOT, ROOT))
+    """ % (ROOT, ROOT, ROOT, ROOT))
     f = tmp_path / "rank.py"
     f.write_text(script)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
@@ -69,8 +70,7 @@ def test_two_rank_gloo_batch(tmp_path, seqexec):  # (the fixture rebuilds libseq
 
 def _bench(argv, seqexec, launcher=False, env_extra=None, timeout=600):
     """bench.py's N-rank logic on a box without GPUs: the host control plane over the sequential executor, gloo."""
-    env = dict(os.environ, SAU_BENCH_TEST_BACKEND=os.path.join(ROOT, "tests", "seqexec", "libseqexec.so"),
-               SAU_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, SAU_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     env.update(env_extra or {})
@@ -78,8 +78,9 @@ def _bench(argv, seqexec, launcher=False, env_extra=None, timeout=600):
     if launcher:
         cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                 "--master-port", "29541"]
-    return subprocess.run(cmd + [os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, env=env,
-                          timeout=timeout)
+    # (tests/tools/bench_seqexec.py = bench.py with its batches made over the sequential executor)
+    return subprocess.run(cmd + [os.path.join(ROOT, "tests", "tools", "bench_seqexec.py")] + argv, capture_output=True, text=True,
+                          env=env, timeout=timeout)
 
 
 def _line(out):
@@ -178,7 +179,7 @@ def test_bench_under_a_launcher_and_world_mismatch(seqexec):
 def test_bench_launcher_reports_a_failed_rank(seqexec):
     """A rank that cannot run (here: a test backend that does not exist) makes `bench.py --gpus 2` exit non-zero."""
     out = _bench(["--gpus", "2", "--voices", "8", "--frames", "4410", "--steps", "1", "--warmup", "0", "--no-cpu"],
-                 seqexec, env_extra={"SAU_BENCH_TEST_BACKEND": "/nonexistent/libseqexec.so"}, timeout=300)
+                 seqexec, env_extra={"SAU_SEQEXEC_LIB": "/nonexistent/libseqexec.so"}, timeout=300)
     assert out.returncode != 0
 
 
@@ -191,7 +192,7 @@ def test_bench_gpus_2_on_one_gpu_box_with_cpu_rendezvous():
     reductions through gloo), each rendering its shard of BASELINE config 4 at full length on the HIP backend, every
     render's SHA-256 checked against the compiled reference's; then config 3, where both ranks render the same bank."""
     env = dict(os.environ, SAU_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "SAU_BENCH_TEST_BACKEND"):
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
 
     def run(argv):

@@ -31,9 +31,9 @@ def _build(tmp, name, libs):
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "libsau_ref.so")),
-                    reason="compiled reference library not present")
 def test_same_host_two_link_lines(tmp_path, sa):
+    # (a missing checker fails here, it does not skip: VERDICT r04 item 6)
+    assert os.path.exists(os.path.join(REF, "libsau_ref.so")), "oracle/_ref/libsau_ref.so is not here (`make -C oracle ref`)"
     tmp = str(tmp_path)
     rpath = ["-Wl,-rpath," + LIBDIR, "-Wl,-rpath," + REF]
     gpu_exe = _build(tmp, "host_gpu", ["-L" + LIBDIR, "-lsaugns_amd", "-L" + REF, "-lsau_ref", "-lm"] + rpath)

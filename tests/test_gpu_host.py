@@ -17,6 +17,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.path.join(ROOT, "oracle", "_ref")
 CPU, GPU = os.path.join(REF, "saugns_cpu"), os.path.join(REF, "saugns_gpu")
 have_hosts = os.path.exists(CPU) and os.path.exists(GPU)
+from conftest import need_ref  # noqa: E402
+
+
+@pytest.fixture(autouse=True)
+def _hosts_are_here(request):
+    """The two host binaries travel to the GPU box prebuilt; without them these tests FAIL (a missing checker must not look
+    like a pass: VERDICT r04 item 6) -- except the one that needs the reference's script files, which exist in the build
+    container only and which says so itself."""
+    if not have_hosts and "crash_the_reference_parser" not in request.node.name:
+        pytest.fail("oracle/_ref/saugns_cpu / saugns_gpu are not here: `make -C oracle hosts` where /root/reference exists")
 
 # scripts of this repo's own (README.SAU syntax): PM stack, ramps + panning, FM + range AM, feedback with a
 # frequency ramp, R and N operators, several timed steps with later events
@@ -47,7 +57,6 @@ def close(a, b, what):
     assert int(np.abs(a - b).max()) == 0, what
 
 
-@pytest.mark.skipif(not have_hosts, reason="reference hosts not built (oracle/Makefile hosts)")
 def test_gpu_host_binds_the_generator_here(tmp_path):
     """No GPU needed: the unchanged host's generator calls and the reference parser's sauNoise_names
     resolve to libsaugns_amd.so, the binary holds none of the reference generator's code, and
@@ -66,12 +75,10 @@ def test_gpu_host_binds_the_generator_here(tmp_path):
         assert out.returncode == 1 and b"no CPU fallback" in out.stderr
 
 
-@pytest.mark.skipif(not have_hosts, reason="reference hosts not built (oracle/Makefile hosts)")
 def test_cpu_host_equals_the_compiled_reference(tmp_path, oracle, sa):
     """The reference host with the reference generator writes what libsau_ref.so renders (pins the
     host build itself: same sources, same flags)."""
-    if not oracle.have_ref():
-        pytest.skip("compiled reference not present")
+    need_ref(oracle)
     for script in SCRIPTS[:4]:
         path = str(tmp_path / "c.wav")
         out = run(CPU, ["-m", "-d", "-r", "44100", "-o", path, "-e", script])
@@ -83,7 +90,6 @@ def test_cpu_host_equals_the_compiled_reference(tmp_path, oracle, sa):
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(not have_hosts, reason="reference hosts not built (oracle/Makefile hosts)")
 def test_unchanged_reference_host_on_the_gpu(tmp_path):
     """saugns -o x.wav / -o - (AU on stdout) / --stdout (raw) / --mono, every script through both
     binaries: headers byte-identical, samples within 1 LSB."""
@@ -117,7 +123,6 @@ def test_unchanged_reference_host_on_the_gpu(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(not have_hosts, reason="reference hosts not built (oracle/Makefile hosts)")
 def test_two_generators_at_two_rates(tmp_path):
     """saugns.c:585 (split_gen): audio device on, a file asked for, and the device only supports another
     rate -- the host creates a second generator at the device rate and calls the two alternately, each

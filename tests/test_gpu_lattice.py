@@ -72,15 +72,16 @@ def test_lattice_programs_in_one_batch(sa, oracle):
         _same(got, oracle.oracle_render(prg.ptr, 44100, False, chunk=2500), k)
 
 
-def _render_pattern(create, run, destroy, prg, rate, stereo, sizes):
-    """A host that changes the size of its calls from one to the next: sizes in turn, the last one until the script ends."""
+def _render_calls(create, run, destroy, prg, rate, calls):
+    """A host that changes its calls from one to the next: (frames, stereo) in turn, the last one until the script ends.
+    -> the calls' PCM, one after the other."""
     import ctypes as C
     g = create(prg, rate)
     assert g
-    ch = 2 if stereo else 1
     n, out, k = C.c_size_t(), [], 0
     while True:
-        size = sizes[min(k, len(sizes) - 1)]
+        size, stereo = calls[min(k, len(calls) - 1)]
+        ch = 2 if stereo else 1
         k += 1
         buf = np.zeros(size * ch, np.int16)
         more = run(g, buf.ctypes.data, size, stereo, C.byref(n))
@@ -91,20 +92,40 @@ def _render_pattern(create, run, destroy, prg, rate, stereo, sizes):
     return np.concatenate(out)
 
 
+def _render_pattern(create, run, destroy, prg, rate, stereo, sizes):
+    return _render_calls(create, run, destroy, prg, rate, [(s, stereo) for s in sizes])
+
+
+PATTERNS = [[1746, 300, 11289, 5, 1024, 4000], [11289, 11289, 11289, 700, 700, 20000], [1, 2, 3, 50000],
+            [11289] * 9 + [1746] * 30 + [11289]]
+# ... and ones that change the channel layout as well (True: stereo)
+MIXED = [[(11289, False)] * 3 + [(11289, True)] * 4 + [(11289, False)],
+         [(1746, True), (1746, True), (300, False), (300, False), (300, True), (11289, False), (5000, True)],
+         [(4000, False)] * 20 + [(4000, True)] * 20 + [(1000, False)] * 7 + [(25000, True)]]
+
+
 def test_a_host_that_changes_its_call_size(sa, oracle, monkeypatch):
-    """The reference's output can depend on the size of the host's calls (its blocks restart at every call). With
-    SAU_AMD_READAHEAD=0 -- one engine run per call -- the drop-in generator follows any pattern of sizes exactly; with the
-    read-ahead (the default) every frame still arrives, calls of an unchanged size are exact, and a program that does not
-    depend on the lattice is exact whatever the host does."""
+    """The reference's output can depend on the size of the host's calls (its blocks restart at every call), and
+    sauGenerator_run takes the size per call (sau/generator.c:905-913). The drop-in generator follows any pattern of sizes
+    exactly -- with one engine run per call (SAU_AMD_READAHEAD=0) and, since round 5, in its default setting too: a call of
+    another size takes the read-ahead back to the start of the run being handed out and goes on from what the host has
+    consumed in the new lattice (capi.cpp: generator_rewind). Programs whose sound depends on the lattice
+    (tests/lattice_cases.py), against the oracle -- which renders in the reference's own blocks -- and, where the compiled
+    reference is here (it is on the GPU box), against that."""
     import saugns_amd.api as api
     lib, ora = api.lib(), oracle.oracle()
     ora.ora_set_fastmath_forms(ORACLE_FORMS)
-    patterns = [[1746, 300, 11289, 5, 1024, 4000], [11289, 11289, 11289, 700, 700, 20000], [1, 2, 3, 50000]]
-    dep = [expiry_value_goal_program(s) for s in range(4)]
+    ref = oracle.ref() if oracle.have_ref() else None
+    dep = [expiry_value_goal_program(s) for s in range(4)] + [lattice_case(np.random.default_rng(77300 + k)) for k in range(4)]
+    differs = 0
     for stereo in (False, True):
         for k, prg in enumerate(dep):
-            for sizes in patterns:
+            base = None
+            for sizes in PATTERNS:
                 want = _render_pattern(ora.ora_create, ora.ora_run, ora.ora_destroy, prg.ptr, 44100, stereo, sizes)
+                if ref is not None and ORACLE_FORMS == 2:
+                    _same(_render_pattern(ref.sau_create_Generator, ref.sauGenerator_run, ref.sau_destroy_Generator,
+                                          prg.ptr, 44100, stereo, sizes), want, (k, sizes, "oracle vs compiled reference"))
                 monkeypatch.setenv("SAU_AMD_READAHEAD", "0")
                 got = _render_pattern(lib.sau_create_Generator, lib.sauGenerator_run, lib.sau_destroy_Generator,
                                       prg.ptr, 44100, stereo, sizes)
@@ -112,12 +133,36 @@ def test_a_host_that_changes_its_call_size(sa, oracle, monkeypatch):
                 monkeypatch.delenv("SAU_AMD_READAHEAD")
                 got = _render_pattern(lib.sau_create_Generator, lib.sauGenerator_run, lib.sau_destroy_Generator,
                                       prg.ptr, 44100, stereo, sizes)
-                assert len(got) == len(want), (k, sizes)
-    # a program without anything the lattice moves: exact with the read-ahead under every pattern
+                _same(got, want, (k, sizes, "read-ahead (default)"))
+                differs += base is not None and (len(base) != len(want) or bool((base != want).any()))
+                base = want
+    assert differs > 8, differs  # (the patterns really render differently: the test means something)
+    # a program without anything the lattice moves: exact under every pattern as well
     from saugns_amd import voicebank
     prg = voicebank.config3(n=8, seconds=1)
-    for sizes in patterns:
+    for sizes in PATTERNS:
         want = _render_pattern(ora.ora_create, ora.ora_run, ora.ora_destroy, prg.ptr, 44100, False, sizes)
         got = _render_pattern(lib.sau_create_Generator, lib.sauGenerator_run, lib.sau_destroy_Generator,
                               prg.ptr, 44100, False, sizes)
         _same(got, want, (sizes, "read-ahead"))
+
+
+def test_a_host_that_changes_its_channel_layout(sa, oracle):
+    """`stereo` is an argument of every sauGenerator_run call as well (sau/generator.c:905): mono <-> stereo flips in
+    mid-stream, with and without a change of size, with frames buffered for the other layout (until round 5: a failure,
+    silence + false, which a host reads as the end of the script). Against the compiled reference itself."""
+    import saugns_amd.api as api
+    from conftest import need_ref
+    need_ref(oracle)
+    lib, ref, ora = api.lib(), oracle.ref(), oracle.oracle()
+    ora.ora_set_fastmath_forms(ORACLE_FORMS)
+    from saugns_amd import voicebank
+    prgs = [expiry_value_goal_program(s) for s in (1, 3)] + [lattice_case(np.random.default_rng(77400 + k)) for k in range(3)] + \
+           [voicebank.config3(n=6, seconds=2), voicebank.config5(n=5, seconds=2)]
+    for k, prg in enumerate(prgs):
+        for calls in MIXED:
+            want = _render_calls(ref.sau_create_Generator, ref.sauGenerator_run, ref.sau_destroy_Generator, prg.ptr, 44100, calls)
+            if ORACLE_FORMS == 2:
+                _same(_render_calls(ora.ora_create, ora.ora_run, ora.ora_destroy, prg.ptr, 44100, calls), want, (k, "oracle"))
+                got = _render_calls(lib.sau_create_Generator, lib.sauGenerator_run, lib.sau_destroy_Generator, prg.ptr, 44100, calls)
+                _same(got, want, (k, calls[:8], "device vs compiled reference"))

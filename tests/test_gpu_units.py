@@ -99,13 +99,9 @@ def test_many_voices_stereo(sa, oracle):
     check(sa, oracle, voices, stereo=True)
 
 
-def test_line_arithmetic_device_vs_host(sa):
-    """sau_dev_math.h compiled for gfx950 == compiled for the host, bit for bit."""
-    import ctypes as C
-    L = sa.lib()
-    for f in (L.sauAmd_kat_line_device, L.sauAmd_kat_line_host):
-        f.restype = C.c_int
-        f.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+def test_line_arithmetic_device_vs_host(sa, hooks):
+    """sau_dev_math.h compiled for gfx950 == compiled for the host, bit for bit (the probes live in the hook library)."""
+    L = hooks
     rng = np.random.default_rng(7)
     n = 1016
     mul = rng.uniform(50, 5000, n).astype(np.float32)
@@ -157,15 +153,13 @@ def test_operators_out_of_time_across_runs(sa, oracle, chunk):
                chunk, stereo=True)
 
 
-def test_differentiator_division_exhaustive(sa):
+def test_differentiator_division_exhaustive(sa, hooks):
     """diff_scale / (float)dphase (wosc.h:253) is computed as v_rcp_f32 plus one residual
     correction; that is correctly rounded for these operands only, so it is checked against
     IEEE division for every f32 divisor of magnitude 1..2^31 (both signs) and the diff_scale
     of every wave. The probe is shown to discriminate: the uncorrected product fails."""
     import ctypes as C
-    fn = sa.lib().sauAmd_kat_div_device
-    fn.restype = C.c_longlong
-    fn.argtypes = [C.c_uint32, C.c_int, C.POINTER(C.c_uint32)]
+    fn = hooks.sauAmd_kat_div_device
     for wave in range(12):
         first = C.c_uint32()
         assert fn(wave, 0, C.byref(first)) == 0, (wave, hex(first.value))

@@ -19,7 +19,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import ROOT
+from conftest import need_ref, ROOT
 from saugns_amd import voicebank as vb
 from saugns_amd.api import POP_CAMOD, POP_FPMOD, POP_PMOD, POP_RFMOD, POPT_RASEG
 import test_gpu_units as tu
@@ -44,8 +44,7 @@ def _programs():
 
 
 def test_gpu_vs_compiled_reference_on_random_graphs(sa, oracle, tables):
-    if not oracle.have_ref():
-        pytest.skip("oracle/_ref/libsau_ref.so not present (built here from /root/reference; travels to the GPU box)")
+    need_ref(oracle)
     oracle.ref()
     # The reference builds its wave tables with libm's sin() when it starts (sau/wave.c:105-221), and glibc picks
     # its sin() by CPU (with or without FMA): on the GPU box's host four tables differ from the fixture by an ulp
@@ -124,8 +123,7 @@ def test_corpus_equals_the_compiled_reference_bit_for_bit(sa, oracle, tables, in
     reference host's call size, against libsau_ref.so's render of the same images on this box: identical, every sample
     (with the loop tails of `cub` reproduced -- the product's default; the rest of the suite compares with the oracle's
     mode 1 and the committed heads of the reference's renders within 1 LSB)."""
-    if not oracle.have_ref():
-        pytest.skip("oracle/_ref/libsau_ref.so not present")
+    need_ref(oracle)
     oracle.ref()
     ref_tabs = oracle.ref_piluts()
     sa.set_piluts(ref_tabs)
@@ -204,8 +202,7 @@ def test_open_batch_cases(sa, oracle, tables, bseed, subset):
       feedback drove its phase below -2^31 cycles, where the reference build's inlined floorf wraps (sau_dev_math.h:
       floor_i32_ref; rasg.h:251).
     Both must equal libsau_ref.so's render of the program alone, also as part of their whole batch."""
-    if not oracle.have_ref():
-        pytest.skip("oracle/_ref/libsau_ref.so not present")
+    need_ref(oracle)
     with _RefSetup(sa, oracle, tables):
         prgs, rate, stereo, call, chunk = _sweep_batch(bseed)
         idx = list(subset) if subset else list(range(12))
@@ -245,8 +242,7 @@ def _ratio_f2_under_modulated_parent(event_ms):
 def test_ratio_second_frequency_under_a_modulated_parent_with_scaled_pm(sa, oracle, tables):
     """The single-program form of batch 3883's case: every cut of the segment between 80 and 112 ms (two of six cuts showed the
     wrong frame before the fix; holds -- repeated phases -- are frequent in this program, its frequencies are megahertz)."""
-    if not oracle.have_ref():
-        pytest.skip("oracle/_ref/libsau_ref.so not present")
+    need_ref(oracle)
     with _RefSetup(sa, oracle, tables):
         bad = []
         for ms in [0] + list(range(80, 113)):
@@ -281,8 +277,7 @@ def test_runs_of_repeated_phases_at_a_groups_start(sa, oracle, tables):
     later ones kept the main pass's value (a division by the zero phase step). As old as the repair pass; contiguous rows made
     such groups few enough per voice to be repaired rather than redone by the block loop, which had hidden it. The same program
     with the repair pass off (every such group redone) and with narrow rows must equal the reference too."""
-    if not oracle.have_ref():
-        pytest.skip("oracle/_ref/libsau_ref.so not present")
+    need_ref(oracle)
     with _RefSetup(sa, oracle, tables):
         prg, stereo, call, rate = _sweep_program(1501673, True)
         ref = oracle.ref_render(prg.ptr, rate, stereo, chunk=call)

@@ -499,3 +499,76 @@ def test_bank_builder_in_the_c_abi(sa, oracle):
     assert not one(freq__shape=13)              # no such ramp shape
     assert not one(time_ms=0)                   # a carrier without a length
     assert not one(start_ms=0xFFFFFFF0, time_ms=100)  # duration beyond 32 bits
+
+
+def _calls_pattern(rng, n):
+    """(frames, stereo) per call: runs of equal calls broken by changes of size, of layout, or of both"""
+    calls, size, stereo = [], int(rng.integers(1, 4000)), bool(rng.integers(2))
+    while len(calls) < n:
+        for _ in range(int(rng.integers(1, 9)) if size >= 40 else int(rng.integers(1, 60))):
+            calls.append((size, stereo))
+        what = int(rng.integers(3))
+        if what != 1:
+            size = int([rng.integers(1, 40), rng.integers(40, 1200), rng.integers(40, 1200), rng.integers(1200, 4000),
+                        rng.integers(4000, 30000)][int(rng.integers(5))])
+        if what != 0:
+            stereo = not stereo
+    return calls[:n]
+
+
+@pytest.mark.parametrize("readahead", ["", "6000", "60000"])
+def test_dropin_generator_follows_changes_of_call_size_and_layout(sa, oracle, seqexec, readahead, monkeypatch):
+    """sauGenerator_run takes buf_len and stereo per call (sau/generator.c:905-913): a host may change either from one call to
+    the next, and what it gets depends on both -- the block lattice restarts at every call (854-878), mono is (L + R) / 2 before
+    rounding. The drop-in generator renders ahead for calls like the last one; a call of another kind takes the engine back to
+    the start of the run being handed out (Engine::snapshot / restore), renders what was consumed again and goes on in the new
+    size / layout: every call's (more, out_len) and samples equal the reference generator's, with the read-ahead on (VERDICT r04
+    item 2; until round 5 a layout change failed and a size change kept the old lattice for up to two runs). The programs
+    are ones whose sound depends on the lattice (tests/lattice_cases.py)."""
+    from lattice_cases import expiry_value_goal_program, lattice_case
+    if readahead:
+        monkeypatch.setenv("SAU_AMD_READAHEAD", readahead)
+    lib = oracle.oracle()
+    lib.ora_set_fastmath_forms(ORACLE_FORMS)
+    rewinds = 0
+    for seed in range(6):
+        rng = np.random.default_rng(4100 + seed)
+        prg = expiry_value_goal_program(seed) if seed < 3 else lattice_case(rng)
+        calls = _calls_pattern(rng, 4000)
+        o = lib.ora_create(prg.ptr, 44100)
+        g = sa.Generator(prg, 44100, backend=seqexec.seq_backend_create(1016))
+        n = C.c_size_t()
+        for i, (size, stereo) in enumerate(calls):
+            ch = 2 if stereo else 1
+            want = np.zeros(size * ch, np.int16)
+            got = np.full(size * ch, 77, np.int16)
+            more_o = bool(lib.ora_run(o, want.ctypes.data, size, stereo, C.byref(n)))
+            more, out_len = g.run(got, size, stereo)
+            assert (more, out_len) == (more_o, n.value), (seed, i, size, stereo)
+            d = np.nonzero(got != want)[0]
+            assert len(d) == 0, (seed, i, size, stereo, len(d), int(d[0]), got[d[:4]].tolist(), want[d[:4]].tolist())
+            if not more_o:
+                break
+        else:
+            raise AssertionError("the script did not end within the pattern")
+        rewinds += g.rewinds()
+        g.close()
+        lib.ora_destroy(o)
+    assert rewinds > 30, rewinds  # (the read-ahead was on and was taken back, not bypassed)
+
+
+def test_product_library_exports_only_the_abi():
+    """test probes and hooks are not exports of libsaugns_amd.so (they live in tests/hooks). What it
+    exports is include/saugns_amd.h + the reference's four generator symbols (+ the kernels' host stubs, which hipcc emits
+    with default visibility)."""
+    import re
+    import subprocess
+    import saugns_amd
+    out = subprocess.run(["nm", "-D", "--defined-only", saugns_amd.build()], capture_output=True, text=True, check=True).stdout
+    names = [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
+    bad = [x for x in names if re.search(r"kat_|with_backend|_rewinds|seq_backend", x)]
+    assert not bad, bad
+    hdr = open(os.path.join(ROOT, "include", "saugns_amd.h")).read()
+    declared = set(re.findall(r"\b(sauAmd_\w+|sau_create_Generator|sau_destroy_Generator|sauGenerator_run|sauNoise_names)\s*[\(\[]", hdr))
+    exported = {x for x in names if x.startswith(("sauAmd_", "sau_", "sauGenerator_", "sauNoise_"))}
+    assert exported == declared, (sorted(exported - declared), sorted(declared - exported))

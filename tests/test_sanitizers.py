@@ -35,7 +35,7 @@ def san_env():
     subprocess.check_call(["make", "-s", "-C", SEQ, "asan"])
     env = dict(os.environ)
     env.update(LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1",
-               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1", SAU_AMD_LIB=LIB, SAU_SEQEXEC_LIB=LIB)
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1", SAU_AMD_LIB=LIB, SAU_SEQEXEC_LIB=LIB, SAU_HOOKS_LIB=LIB)
     return env
 
 

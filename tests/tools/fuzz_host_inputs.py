@@ -18,6 +18,7 @@ from saugns_amd import api, voicebank as vb
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 4)
 L = sa.lib()
+api.use_hooks(os.environ.get("SAU_HOOKS_LIB") or os.path.join(ROOT, "tests", "hooks", "libsaugns_amd_hooks.so"))
 seqlib = C.CDLL(os.environ.get("SAU_SEQEXEC_LIB") or os.path.join(ROOT, "tests", "seqexec", "libseqexec.so"))
 seqlib.seq_backend_create.restype = C.c_void_p
 seqlib.seq_backend_create.argtypes = [C.c_uint32]

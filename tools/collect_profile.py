@@ -24,7 +24,47 @@ out = {"command": "rocprofv3 --pmc <C> --kernel-trace --output-format csv -- pyt
                "here: mix_kernel reads voices x frames f32 and FETCH_SIZE reports half of it), WRITE_SIZE "
                "exact (fast_kernel writes the same bytes of voice rows)", "kernels": {}}
 import os
-for d, f in (("fetch", "f"), ("write", "w"), ("sq", "s"), ("inst", "i"), ("grbm", "g")):
+COSTS = json.load(open("profiles/r05_valu_costs.json"))
+CLASSES = ("ADD_F64", "MUL_F64", "FMA_F64", "TRANS_F64", "ADD_F32", "MUL_F32", "FMA_F32", "TRANS_F32", "CVT", "INT32", "INT64")
+
+
+def valu_side(v):
+    """the VALU side of the roofline from a kernel's counters. With the class census (SQ_INSTS_VALU_*:
+    tools/pmc_classes.sh / the `cls` passes of tools/profile_round.sh) every class is priced with the issue cost
+    tools/valu_probe.hip measured (profiles/r05_valu_costs.json), what SQ_INSTS_VALU counts beyond the classes -- moves
+    incl. DPP, compares, selects, lane reads -- as OTHER; without it, every instruction at the probe's in-mix average.
+    Against 1024 SIMDs x launch cycles (GRBM_GUI_ACTIVE is summed over the 8 XCDs: MI355X_MICROARCH.md)."""
+    if not ("SQ_INSTS_VALU" in v and v.get("GRBM_GUI_ACTIVE", 0) > 0):
+        return None
+    cycles = v["GRBM_GUI_ACTIVE"] / 8
+    n = v["SQ_INSTS_VALU"]
+    out = {"insts_per_launch": n, "launch_cycles": cycles, "simds": 1024, "simd_cycles_per_launch": 1024 * cycles,
+           "cycles_per_inst_per_simd": 1024 * cycles / n if n else None,
+           "salu_per_valu": (v.get("SQ_INSTS_SALU", 0) / n) if n else None, "costs": "profiles/r05_valu_costs.json"}
+    if all(("SQ_INSTS_VALU_" + c) in v for c in CLASSES):
+        census = {c: v["SQ_INSTS_VALU_" + c] for c in CLASSES}
+        census["OTHER"] = max(0.0, n - sum(census.values()))
+        out["census_frac"] = {c: round(x / n, 4) for c, x in census.items()} if n else None
+        for name in ("pure", "in_mix"):
+            w = sum(x * COSTS[name][c] for c, x in census.items())
+            out["weighted_cycles_" + name] = w
+            out["frac_" + name] = w / (1024 * cycles)
+        # the figure on the bench line: priced with every class's best case, i.e. the least the kernel can be using
+        out["weighted_cycles_per_launch"] = out["weighted_cycles_pure"]
+        out["frac"] = out["frac_pure"]
+        out["formula"] = ("sum over SQ_INSTS_VALU_* classes (+ the rest of SQ_INSTS_VALU as OTHER) of instructions x the class's cost "
+                          "as a stream of its own (a lower bound on what the kernel uses; frac_in_mix: 2-cycle instructions priced as "
+                          "they cost between 4-cycle ones) / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)")
+    else:
+        out["weighted_cycles_per_launch"] = n * COSTS["flat_in_mix"]
+        out["frac"] = n * COSTS["flat_in_mix"] / (1024 * cycles)
+        out["formula"] = "SQ_INSTS_VALU x the probe's hot-path mix average (no class census for this kernel) / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)"
+    if "SQ_ACTIVE_INST_VALU" in v:  # (quad-cycles summed over waves: the share of SIMD time with a vector instruction in execution)
+        out["sq_active_inst_valu_frac"] = 4 * v["SQ_ACTIVE_INST_VALU"] / (1024 * cycles)
+    return out
+
+
+for d, f in (("fetch", "f"), ("write", "w"), ("sq", "s"), ("inst", "i"), ("grbm", "g"), ("cls_a", "a"), ("cls_b", "b")):
     src = f"gpurun_out/pmc_{tag}_{d}/{f}_counter_collection.csv"
     if not os.path.exists(src):
         continue
@@ -43,15 +83,9 @@ for d, f in (("fetch", "f"), ("write", "w"), ("sq", "s"), ("inst", "i"), ("grbm"
 for k, v in out["kernels"].items():
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         v["hbm_bytes_per_launch_corrected"] = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
-    if "SQ_INSTS_VALU" in v and "GRBM_GUI_ACTIVE" in v and v["GRBM_GUI_ACTIVE"] > 0:
-        # the VALU side of the roofline. A wave64 VALU instruction occupies its SIMD's 16 lanes for 4 cycles
-        # (f32 and f64 alike on CDNA4; transcendentals longer: a lower bound); 256 CUs x 4 SIMDs; GRBM_GUI_ACTIVE is
-        # summed over the 8 XCDs (MI355X_MICROARCH.md, DVFS give-back), so launch cycles = GRBM_GUI_ACTIVE / 8
-        cycles = v["GRBM_GUI_ACTIVE"] / 8
-        v["valu"] = {"insts_per_launch": v["SQ_INSTS_VALU"], "launch_cycles": cycles, "simds": 1024,
-                     "busy_frac": 4 * v["SQ_INSTS_VALU"] / (1024 * cycles),
-                     "formula": "4 cycles x SQ_INSTS_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)",
-                     "salu_per_valu": (v.get("SQ_INSTS_SALU", 0) / v["SQ_INSTS_VALU"]) if v["SQ_INSTS_VALU"] else None}
+    vs = valu_side(v)
+    if vs:
+        v["valu"] = vs
 json.dump(out, open(f"profiles/{name}_pmc_summary.json", "w"), indent=1)
 # the other workloads' bench lines and kernel statistics, when the round measured them
 if os.path.exists(f"gpurun_out/bench_{tag}_full.json"):
@@ -68,7 +102,7 @@ for wl in ("c5", "c4"):
 # the profiled command renders twice (the first step, whose SHA-256 is checked, and one timed step)
 for wl, wname in (("c5", "config5"), ("c4", "config4"), ("fmbank", "fm"), ("config2", "config2")):
     ks = {}
-    for d, f in ((wl + "_fetch", "m"), (wl + "_write", "m"), (wl + "_inst", "i")):
+    for d, f in ((wl + "_fetch", "m"), (wl + "_write", "m"), (wl + "_inst", "i"), (wl + "_cls_a", "a"), (wl + "_cls_b", "b"), (wl + "_grbm", "g")):
         src = f"gpurun_out/pmc_{tag}_{d}/{f}_counter_collection.csv"
         if not os.path.exists(src):
             continue
@@ -88,6 +122,9 @@ for wl, wname in (("c5", "config5"), ("c4", "config4"), ("fmbank", "fm"), ("conf
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             v["hbm_bytes_per_launch_corrected"] = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
             total += v["hbm_bytes_per_launch_corrected"] * v["launches"]
+        vs = valu_side(v)
+        if vs:
+            v["valu"] = vs
     json.dump({"command": f"rocprofv3 --pmc <C> --kernel-trace -- python3 bench.py --workload {wname} --steps 1 --warmup 0 --no-cpu",
                "workload": {"name": wname, "renders_profiled": 2},
                "kernel_source_sha": bench["roofline"].get("kernel_source_sha"),
