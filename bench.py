@@ -625,12 +625,19 @@ def pcm_gather(args, R, sa, step, fx, total, frames_each):
     torch = R.torch
     from saugns_amd import shard
     if R.cuda and R.backend == "nccl":
+        if args.c4_run and args.c4_run < frames_each:
+            # (the batch's PCM block in HBM holds the last engine run only: ADVICE r04)
+            raise SystemExit("--gather-pcm takes the PCM where the batch left it in HBM: one engine run per render (no --c4-run below the render's length)")
         n, _, batch = step(False, keep=True)
         local = torch.stack([shard.device_pcm_tensor(batch, i, frames_each) for i in range(n // frames_each)])
     else:
         batch = None
         n, outs = step(True)
         local = torch.from_numpy(np.stack([np.concatenate(o)[:frames_each] for o in outs]))
+    # what every rank holds, render by render, told to rank 0 on the side (objects, not the data path): the gathered block
+    # must hold exactly these, in rank order -- seeds shard_range(total, r, world) of rank r at rows [a_r, b_r)
+    sums = [int(x.to(torch.int64).sum().item()) for x in local]
+    all_sums = [x for part in R.gather(sums) for x in part]
     R.barrier()
     t0 = time.perf_counter()
     everything = shard.gather_renders_to_root(local, 0)
@@ -643,12 +650,17 @@ def pcm_gather(args, R, sa, step, fx, total, frames_each):
     host = everything.cpu().numpy()
     if len(host) != total:
         raise SystemExit(f"rank 0: gathered {len(host)} renders, expected {total}")
+    got_sums = [int(host[k].astype(np.int64).sum()) for k in range(total)]
+    if got_sums != all_sums:
+        bad = [k for k in range(total) if got_sums[k] != all_sums[k]]
+        raise SystemExit(f"rank 0: gathered renders {bad[:8]} are not what their ranks rendered (rank order / content)")
     if not args.c4_frames:
         bad = [k for k in range(total) if sha256(host[k]) != str(fx["sha256"][k])]
         if bad:
             raise SystemExit(f"rank 0: gathered renders {bad[:8]} differ from the reference's SHA-256")
     nbytes = int(host.nbytes)
-    return {"renders": int(len(host)), "bytes": nbytes, "seconds": dt, "GB_per_s": nbytes / dt / 1e9,
+    return {"renders": int(len(host)), "bytes": nbytes, "seconds": dt, "GB_per_s": nbytes / dt / 1e9, "rank_order_checked": True,
+            "distinct_renders": len(set(got_sums)),
             "backend": R.backend, "what": "torch.distributed.gather of int16 PCM to rank 0 (one direct send per rank), after "
             "the timed region; every gathered render's SHA-256 checked on rank 0" + (" (heads only: not hashed)" if args.c4_frames else "")}
 
@@ -686,11 +698,50 @@ def run_config5(args, R, sa, tabs, steps=None, warmup=None):
         step(False)
     R.barrier()
     tm = {"fast_ms": 0.0, "block_ms": 0.0, "mix_ms": 0.0, "aux_ms": 0.0, "segments": 0}
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step(False, tm)
-    R.barrier()
-    dt = R.max(time.perf_counter() - t0)
+    # One step = the script's whole 10 s from generator creation to its last frame (creation 0.05 ms, the first run's host
+    # work -- t = 0 events, operator records, plans -- 0.6 ms before the first kernel, 43 ms of feedback chains with the passes
+    # and the mixer beside them, the last chunk's tail).
+    def make():
+        b = new_batch(sa, [prg])
+        b.set_timing(2)
+        return b
+
+    def timed(pipelined):
+        tm = {"fast_ms": 0.0, "block_ms": 0.0, "mix_ms": 0.0, "aux_ms": 0.0, "segments": 0}
+        R.barrier()
+        t0 = time.perf_counter()
+        cur = make()
+        cur.run(frames, stereo=False, fetch=False)  # (returns when everything is enqueued)
+        last_pcm = None
+        for i in range(steps):
+            nxt = None
+            if pipelined and i + 1 < steps:
+                nxt = make()
+                nxt.order_after(cur)  # its kernels start when this script's have finished; its host work starts now
+                # (the last script's PCM is fetched -- 882 KB -- and checked below: what ran two deep is the reference's render too)
+                r = nxt.run(frames, stereo=False, fetch=i + 2 == steps)
+                last_pcm = r[0] if i + 2 == steps else last_pcm
+            cur.sync()
+            t = cur.timing_ex()
+            for k in tm:
+                tm[k] += t[k]
+            cur.close()
+            if not pipelined and i + 1 < steps:
+                nxt = make()
+                nxt.run(frames, stereo=False, fetch=False)
+            cur = nxt
+        R.barrier()
+        dtx = R.max(time.perf_counter() - t0)
+        if last_pcm is not None and verified and sha256(last_pcm[0]) != verified["sha256"]:
+            raise SystemExit(f"rank {R.rank}: config 5: the last pipelined step's PCM is not the reference's")
+        return dtx, tm
+
+    # `value`: the K scripts strictly one after the other (each created, issued, drained). Beside it, for the record, the
+    # same K with script k + 1 created and issued while script k renders, ordered behind it (sauAmd_Batch_order_after):
+    # it hides the host work of a script's start (0.6 ms of device idle time per step) and measured no faster -- the
+    # recurrence itself runs 2 % slower on a device that never idles (profiles/r05_headline_ab.json)
+    dt_ordered, _ = timed(True) if not args.c5_serial else (None, None)
+    dt, tm = timed(False)
     mine = [frames * steps, int(np.asarray(pcm, dtype=np.int64).sum() & 0x7FFFFFFF)]
     tally = R.sum(mine)
     if tally[0] != frames * steps * R.world or tally[1] != mine[1] * R.world:
@@ -714,6 +765,10 @@ def run_config5(args, R, sa, tabs, steps=None, warmup=None):
                                f"one step = the script's whole 10 s ({frames} frames) from generator creation on",
                    "voices": args.voices5, "operators": n_ops, "frames_per_step": frames,
                    "frames_all_ranks": tally[0], "pcm_checksum_all_ranks": tally[1], "verified": verified,
+                   "steps_are": "K scripts strictly one after the other: each created, issued and drained before the next is created",
+                   "ordered_two_generators": ({"value": tally[0] / dt_ordered, "ms_per_step": dt_ordered / steps * 1e3,
+                                               "is": "script k + 1 created and issued while script k renders, its kernels ordered behind "
+                                                     "script k's (sauAmd_Batch_order_after)"} if dt_ordered else None),
                    "operator_samples_per_s": tally[0] / dt * n_ops},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                      "frac": achieved / 8000.0, "traffic": traffic5, "traffic_source": source5,
@@ -786,6 +841,7 @@ def main():
     ap.add_argument("--c4-frames", type=int, default=0, help="config4 (tests): render only the first frames of each script")
     ap.add_argument("--sustain", type=int, default=1000, help="config3: steps of the sustained run after the timed region "
                     "(reported under `sustained`, never `value`; 0: none)")
+    ap.add_argument("--c5-serial", action="store_true", help="config5: skip the ordered-two-generators measurement beside `value`")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--gather-pcm", action="store_true",
                     help="--workload config4: afterwards send every rank's finished PCM to rank 0 (SURVEY 8e, optional) and check it there")

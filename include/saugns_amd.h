@@ -92,6 +92,16 @@ SAU_AMD_API void sauAmd_Batch_set_timing(sauAmdBatch *b, int level);
 /* The stream the batch launches its kernels on, as a hipStream_t. */
 SAU_AMD_API void *sauAmd_Batch_stream(sauAmdBatch *b);
 
+/* Order b's next run behind what has been issued for `before` so far: the rendering kernels of b's next
+ * sauAmd_Batch_run start on the device only when everything queued for `before` has finished (b's bookkeeping --
+ * operator updates, plan uploads, the per-voice analysis -- may run earlier: it touches nothing of `before`'s).
+ * A host that renders one script after another with two generators alive (saugns.c:583-621 per script) issues
+ * script k + 1 while script k's last kernels drain: the host work of a run's start (events at t = 0, plans: 1.2 ms
+ * for BASELINE config 5's 4096 voices) overlaps the device's tail, and the two scripts' kernels never compete for
+ * the device -- two runs simply issued side by side did, at three times the time per script. Both on the same
+ * device. false (sauAmd_last_error) on a HIP error. */
+SAU_AMD_API bool sauAmd_Batch_order_after(sauAmdBatch *b, sauAmdBatch *before);
+
 /* Use these twelve 2048-entry tables (wave-id order) instead of the built-in
  * ones for generators created afterwards. */
 SAU_AMD_API void sauAmd_set_piluts(const float *tables);

@@ -117,6 +117,8 @@ def _declare(L):
                                       C.POINTER(C.c_uint64), C.c_int]
     L.sauAmd_Batch_timing_ex.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
     L.sauAmd_Batch_set_timing.argtypes = [C.c_void_p, C.c_int]
+    L.sauAmd_Batch_order_after.restype = C.c_bool
+    L.sauAmd_Batch_order_after.argtypes = [C.c_void_p, C.c_void_p]
     L.sauAmd_Batch_stream.restype = C.c_void_p
     L.sauAmd_Batch_stream.argtypes = [C.c_void_p]
     L.sauAmd_set_piluts.argtypes = [C.c_void_p]
@@ -365,6 +367,12 @@ class Batch:
         """The sauGenerator_run call size whose block lattice the batch reproduces (0: every run
         is one call)."""
         self._L.sauAmd_Batch_set_call_len(self._b, frames)
+
+    def order_after(self, before):
+        """This batch's next run renders on the device only when everything issued for `before` has finished
+        (sauAmd_Batch_order_after): scripts one after the other with two generators alive."""
+        if not self._L.sauAmd_Batch_order_after(self._b, before._b):
+            raise RuntimeError(last_error(self._L))
 
     def sync(self):
         if not self._L.sauAmd_Batch_sync(self._b):

@@ -345,6 +345,13 @@ extern "C" void sauAmd_Batch_set_timing(sauAmdBatch *b, int level) {
 	if (b->hip) b->hip->set_timing(level);
 }
 
+extern "C" bool sauAmd_Batch_order_after(sauAmdBatch *b, sauAmdBatch *before) {
+	if (!b || !before || !b->hip || !before->hip) return true; /* (injected backends render synchronously: nothing to order) */
+	std::string err;
+	if (!b->hip->order_after(before->hip, err)) { report("batch", err); return false; }
+	return true;
+}
+
 extern "C" void *sauAmd_Batch_stream(sauAmdBatch *b) {
 	return b->hip ? b->hip->stream_handle() : nullptr;
 }

@@ -34,19 +34,22 @@ void chain_rows_note_device_memory(size_t free_bytes) {
 	size_t zero = 0; /* the first device the process opens decides (one budget per process: segments are cut on the host) */
 	g_chain_rows_free_hint.compare_exchange_strong(zero, free_bytes);
 }
-static std::atomic<bool> g_chain_rows_alloc_failed{false};
-void chain_rows_note_alloc_failure() { g_chain_rows_alloc_failed.store(true); }
+/*  a failed allocation of rows halves the budget from there on -- it does not take it away: the failure may have
+ * been one engine's, on one device of several, with the pool holding idle blocks (which pool_alloc now gives back first) */
+static std::atomic<unsigned> g_chain_rows_alloc_failures{0};
+void chain_rows_note_alloc_failure() { g_chain_rows_alloc_failures.fetch_add(1); }
 size_t chain_rows_budget() {
-	if (g_chain_rows_alloc_failed.load()) return 0; /* (segments with feedback voices: CHAIN_SEG frames from now on) */
 	static const long long env_mb = [] {
 		const char *v = getenv("SAU_AMD_CHAIN_ROWS_MB");
 		return v ? atoll(v) : -1ll;
 	}();
-	if (env_mb >= 0) return (size_t)env_mb << 20;
+	const unsigned fails = g_chain_rows_alloc_failures.load();
+	const unsigned sh = fails > 40 ? 40 : fails; /* (after a few failures: segments with feedback voices are CHAIN_SEG frames) */
+	if (env_mb >= 0) return ((size_t)env_mb << 20) >> sh;
 	const size_t dflt = (size_t)24 << 30; /* of an MI355X's 288 GB */
 	const size_t free_b = g_chain_rows_free_hint.load();
-	if (!free_b) return dflt; /* no device told (the sequential executor of the tests) */
-	return free_b / 8 < dflt ? free_b / 8 : dflt; /* a smaller or fuller device: an eighth of what was free when it was opened */
+	if (!free_b) return dflt >> sh; /* no device told (the sequential executor of the tests) */
+	return (free_b / 8 < dflt ? free_b / 8 : dflt) >> sh; /* a smaller or fuller device: an eighth of what was free when it was opened */
 }
 uint32_t chain_seg_frames(size_t n_chains) {
 	if (!n_chains) return CHAIN_SEG;

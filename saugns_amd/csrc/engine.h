@@ -165,8 +165,8 @@ size_t chain_rows_budget();
 /* ... without that setting: 24 GiB, or an eighth of the memory that was free on the device when the process first opened it
  * (hipMemGetInfo, told here by the backend) where that is less. */
 void chain_rows_note_device_memory(size_t free_bytes);
-/* ... and when an allocation of rows has failed once, the budget is gone for the rest of the process: segments with feedback
- * voices are CHAIN_SEG frames again (the backend renders the segment that did not fit in the block loop). */
+/* ... and every allocation of rows that fails halves the budget for the rest of the process (the backend renders the
+ * segment that did not fit in the block loop); segments with feedback voices are never cut below CHAIN_SEG frames. */
 void chain_rows_note_alloc_failure();
 /* Environment switches. Product settings are read as they are (INTEGRATION.md has the table: SAU_AMD_DEVICE,
  * SAU_AMD_READAHEAD*, SAU_AMD_LOOP_TAILS, SAU_AMD_CHAIN_ROWS_MB, SAU_AMD_POOL_MB, SAU_AMD_PINNED_POOL_MB, SAU_AMD_DEBUG*);

@@ -14,6 +14,8 @@ public:
 	/* 0 off, 1 time-parallel kernel only, 2 every kernel */
 	virtual void set_timing(int level) = 0;
 	virtual void timing_ex(double *out4, uint64_t *segments, bool reset) = 0;
+	/* the next segment's rendering kernels wait for everything issued on `before` so far (sauAmd_Batch_order_after) */
+	virtual bool order_after(HipBackend *before, std::string &err) = 0;
 };
 
 /* NULL (with err) when no HIP device is usable: there is no CPU fallback. */

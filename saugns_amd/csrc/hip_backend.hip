@@ -137,22 +137,23 @@ private:
 class StreamPool {
 public:
 	static StreamPool &get() { static StreamPool *g = new StreamPool; return *g; }
-	hipStream_t take(int dev) {
+	/* `kind` 1: the streams feedback chains run on (created with high priority: see chain_stream_) */
+	hipStream_t take(int dev, int kind = 0) {
 		std::lock_guard<std::mutex> lk(mu_);
-		auto &v = free_[dev & 15];
+		auto &v = free_[kind & 1][dev & 15];
 		if (v.empty()) return nullptr;
 		hipStream_t s = v.back();
 		v.pop_back();
 		return s;
 	}
-	void give(int dev, hipStream_t s) {
+	void give(int dev, hipStream_t s, int kind = 0) {
 		std::lock_guard<std::mutex> lk(mu_);
-		auto &v = free_[dev & 15];
+		auto &v = free_[kind & 1][dev & 15];
 		if (v.size() < 8) v.push_back(s); else (void)hipStreamDestroy(s);
 	}
 private:
 	std::mutex mu_;
-	std::vector<hipStream_t> free_[16];
+	std::vector<hipStream_t> free_[2][16];
 };
 
 /* Launches of the single-pass running-sum build whose voices have waves in more than one workgroup wait for each
@@ -322,9 +323,10 @@ public:
 		use_device();
 		/* the buffers go back to the pool (member destructors): nothing may still be using them */
 		if (stream_) (void)hipStreamSynchronize(stream_);
-		if (chain_stream_) { (void)hipStreamSynchronize(chain_stream_); StreamPool::get().give(dev_, chain_stream_); }
+		if (chain_stream_) { (void)hipStreamSynchronize(chain_stream_); StreamPool::get().give(dev_, chain_stream_, 1); }
 		for (hipEvent_t e : chain_ev_) (void)hipEventDestroy(e);
 		for (int i = 0; i < 4; ++i) if (fetch_ev_[i]) (void)hipEventDestroy(fetch_ev_[i]);
+		if (after_ev_) (void)hipEventDestroy(after_ev_);
 		for (auto &e : events_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
 		if (stream_) StreamPool::get().give(dev_, stream_); /* drained above */
 	}
@@ -381,6 +383,8 @@ public:
 		two_pass_enabled_ = tune_env("SAU_AMD_NO_TWO_PASS") == nullptr; /* ... in two passes where possible */
 		if (const char *lr = tune_env("SAU_AMD_LEAN_ROWS")) lean_rows_ = (uint32_t)atoi(lr);
 		mix_few_enabled_ = tune_env("SAU_AMD_NO_MIX_FEW") == nullptr;
+		early_mix_enabled_ = tune_env("SAU_AMD_NO_EARLY_MIX") == nullptr;
+		short_last_chunk_ = tune_env("SAU_AMD_NO_SHORT_LAST_CHUNK") == nullptr;
 		lean_enabled_ = tune_env("SAU_AMD_NO_LEAN") == nullptr; /* chains' passes in a build without the several-pass sums */
 		dyn_enabled_ = tune_env("SAU_AMD_NO_DYN") == nullptr; /* closed-form launches deal tasks out through a counter */
 		wide_tabs_ = tune_env("SAU_AMD_NO_WIDE_TABS") == nullptr; /* closed-form launches with f64 [c1, c0] table entries in LDS */
@@ -394,6 +398,7 @@ public:
 			fast_rows_ = r >= 8 ? 8 : r >= 6 ? 6 : r >= 5 ? 5 : r >= 4 ? 4 : 2;
 		}
 		if (const char *mm = tune_env("SAU_AMD_MULTI_MIN")) multi_min_ = (uint32_t)atol(mm);
+		if (const char *mt = tune_env("SAU_AMD_MULTI_TEAMS")) multi_teams_ = atoi(mt) == 8 ? 8u : 16u;
 		if (!ops_.ensure(cfg.op_count ? cfg.op_count : 1, err)) return false;
 		HIP_OK(hipMemsetAsync(ops_.p, 0, ops_.cap * sizeof(DevOp), stream_));
 		tables_ = shared_tables(cfg.piluts, cfg.wconst, err);
@@ -489,6 +494,7 @@ public:
 		use_device();
 		if (!seg.n_voices) return true;
 		++acc_launches_; /* segments rendered */
+		early_mixed_blocks_ = 0;
 		const size_t tab_bytes = (size_t)WAVE_LEN * (sizeof(HerpC23) + sizeof(HerpC01));
 		/* (the time-parallel kernels keep their LDS copy of a table in another form: FAST_TAB_BYTES, k_fast_types.h) */
 		const size_t ftab_bytes = FAST_TAB_BYTES;
@@ -507,10 +513,11 @@ public:
 			const size_t need_tab = seg.wave_mask ? tab_bytes : 0;
 			/* longer blocks amortise the per-step bookkeeping: 255 samples per block measured
 			 * 14 % faster than 127 on BASELINE config 5 */
-			if (16 * team_size(1, 4) + need_tab <= lds_limit_) { W = 1; T = 4; V = 16; }
-			else if (16 * team_size(1, 3) + need_tab <= lds_limit_) { W = 1; T = 3; V = 16; }
-			else if (16 * team_size(1, 2) + need_tab <= lds_limit_) { W = 1; T = 2; V = 16; }
-			else if (16 * team_size(1, 1) + need_tab <= lds_limit_) { W = 1; T = 1; V = 16; }
+			const uint32_t mt = multi_teams_; /* single-wave teams per workgroup: 8 (512 threads: 256 VGPRs each, no scratch) or 16 */
+			if (mt * team_size(1, 4) + need_tab <= lds_limit_) { W = 1; T = 4; V = mt; }
+			else if (mt * team_size(1, 3) + need_tab <= lds_limit_) { W = 1; T = 3; V = mt; }
+			else if (mt * team_size(1, 2) + need_tab <= lds_limit_) { W = 1; T = 2; V = mt; }
+			else if (mt * team_size(1, 1) + need_tab <= lds_limit_) { W = 1; T = 1; V = mt; }
 		}
 		/* a voice with very many block buffers: one wave, one frame per lane (256 B per buffer) */
 		if (V == 1 && team_size(W, T) > lds_limit_) { W = 1; T = 1; }
@@ -804,6 +811,7 @@ public:
 			if (ta) (void)hipEventRecord(ta->b, stream_);
 			if (use_fast) {
 				hipLaunchKernelGGL(decode_kernel, dim3(seg.n_voices), dim3(64), 0, stream_, fp);
+				if (!wait_for_predecessor(err)) return false; /* (sauAmd_Batch_order_after: the rendering kernels from here on) */
 				/* build 0: closed-form phases only; 1: every kind of running-sum voice; 2: single-pass voices and closed-form ones */
 				const int main_build = !seq_ok ? 0 : look_split ? 2 : 1;
 				/* (rows per pass 2, 4, 5, 6, 8; the full build never runs at more than 4: its 5- and 6-row slots stand in with 4's) */
@@ -835,7 +843,14 @@ public:
 					const int ri = rows == 8 ? 4 : rows == 6 ? 3 : rows == 5 ? 2 : rows == 4 ? 1 : 0;
 					const size_t a16 = area16 ? area16 : 16 * area_of(rows);
 					void *args[] = {(void *)(prm ? prm : &fp)};
-					if (wide && build == 0 && (rows == 8 || rows == 6 || rows == 10 || rows == 12)) {
+					const bool wide_rows = rows == 8 || rows == 6 || rows == 10 || rows == 12;
+					/* (a row count without an instantiation -- 10 or 12 rows outside the wide form, anything the
+					 * tables above do not hold -- must not fall through to the 2-row kernel beside slots laid out for `rows`) */
+					if (!(wide && build == 0 && wide_rows) && rows != 8 && rows != 6 && rows != 5 && rows != 4 && rows != 2) {
+						err = "internal error: no fast_kernel build with " + std::to_string(rows) + " rows per pass in this form";
+						return false;
+					}
+					if (wide && build == 0 && wide_rows) {
 						const int wi = rows == 12 ? 3 : rows == 10 ? 2 : rows == 8 ? 1 : 0;
 						const size_t lds = ft * (size_t)FAST_TAB_BYTES_WIDE + a16;
 						if (!raise_lds_attr(fk_wide[wi], lds, wconfigured[dev_ & 15][wi], err)) return false;
@@ -937,7 +952,11 @@ public:
 						if (!raise_lds_attr((const void *)chain_kernel, clds, chain_lds_configured_[dev_ & 15], err)) return false;
 						fp.chain_early = 1; fp.range_mode = 0;
 						hipLaunchKernelGGL(chain_kernel, dim3((seg.n_chain_rows + 63) / 64), dim3(192), clds, stream_, fp);
-						hipLaunchKernelGGL(rchain_kernel, dim3((seg.n_chain_rows + 63) / 64), dim3(64), 0, stream_, fp); /* R feedback */
+						{ /* R feedback: a chain wave and a feeder wave per 64 chains (k_chain.h) */
+							static size_t rc_configured[16];
+							if (!raise_lds_attr((const void *)rchain_kernel, RCHAIN_LDS_BYTES, rc_configured[dev_ & 15], err)) return false;
+							hipLaunchKernelGGL(rchain_kernel, dim3((seg.n_chain_rows + 63) / 64), dim3(128), RCHAIN_LDS_BYTES, stream_, fp);
+						}
 						fp.chain_early = 0;
 					}
 					for (uint32_t pass = 1; pass <= fp.sum_levels && (!fp.look || seg.n_chain_rows); ++pass) {
@@ -958,16 +977,36 @@ public:
 						if (n_chunks > 32) n_chunks = 32;
 						while (n_chunks > 1 && seg.len / n_chunks < 4096) --n_chunks;
 						if (!chain_stream_ && n_chunks > 1) {
-							chain_stream_ = StreamPool::get().take(dev_);
-							if (!chain_stream_) HIP_OK(hipStreamCreateWithFlags(&chain_stream_, hipStreamNonBlocking));
+							chain_stream_ = StreamPool::get().take(dev_, 1);
+							if (!chain_stream_) {
+								/* High priority, for the sake of the hardware queue it gets: the runtime maps streams onto a
+								 * handful of queues (four per priority), and a second generator's two streams of ordinary priority
+								 * landed on ONE -- its chains and its passes then ran one after the other, 76 ms for a config-5
+								 * step instead of 45 (profiles/r05_c5_pipelined_trace.txt). Queues of another priority are others:
+								 * a generator's chain stream never shares its main stream's. (The chain wave is also what the
+								 * step's time hangs on.) */
+								int lo = 0, hi = 0;
+								(void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+								HIP_OK(hipStreamCreateWithPriority(&chain_stream_, hipStreamNonBlocking, hi));
+							}
+						}
+						/* chunk boundaries: multiples of the chain kernel's batch. What follows the last chunk's chains is not
+						 * overlapped with anything -- its final pass, finalize_kernel, its share of the mixer (which follows the
+						 * other chunks since round 5) -- so the last chunk is a short one (4096 frames: 0.4 ms of chains, 0.15 ms of
+						 * final pass behind them instead of 0.5-0.7) */
+						uint32_t cb[34];
+						{
+							const uint32_t tail = (!chain_chunks_ && short_last_chunk_ && n_chunks >= 4 && n_chunks < 32 && seg.len > 8 * 4096u) ? 4096u : 0u;
+							const uint32_t body = (seg.len - tail) & ~255u;
+							const uint32_t clen0 = (((tail ? body : seg.len) + n_chunks - 1) / n_chunks + 255) & ~255u;
+							for (uint32_t c = 0; c <= n_chunks; ++c) cb[c] = c * clen0 < (tail ? body : seg.len) ? c * clen0 : (tail ? body : c * clen0);
+							if (tail) { cb[n_chunks] = body; ++n_chunks; cb[n_chunks] = seg.len; }
 						}
 						while (chain_ev_.size() < 2 * (size_t)n_chunks) {
 							hipEvent_t e;
 							HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
 							chain_ev_.push_back(e);
 						}
-						/* chunk boundaries: multiples of the chain kernel's batch */
-						const uint32_t clen = ((seg.len + n_chunks - 1) / n_chunks + 255) & ~255u;
 						/* the time-parallel passes leave the chains' CUs alone while both run */
 						const uint32_t pgrid = n_chunks > 1 && fgrid + cgrid > fk_grid_ ? (fk_grid_ > cgrid + 32 ? fk_grid_ - cgrid : 32) : fgrid;
 						TimedPair *tc = timing_on_ ? new_pair(0) : nullptr; /* counted with the block loop it replaces */
@@ -980,24 +1019,43 @@ public:
 							launch_fast(fp.sum_levels + 1);
 						} else {
 							for (uint32_t c = 0; c < n_chunks; ++c) { /* inputs of chunk c, then its chains on the other stream */
-								fp.range_mode = 1; fp.f_lo = c * clen; fp.f_hi = c + 1 == n_chunks ? 0xffffffffu : (c + 1) * clen;
+								fp.range_mode = 1; fp.f_lo = cb[c]; fp.f_hi = c + 1 == n_chunks ? 0xffffffffu : cb[c + 1];
 								fp.range_last = c + 1 == n_chunks;
 								launch_fast(fp.sum_levels + 2, pgrid);
 								HIP_OK(hipEventRecord(chain_ev_[2 * c], stream_));
 								HIP_OK(hipStreamWaitEvent(chain_stream_, chain_ev_[2 * c], 0));
 								FastParams cp = fp;
-								cp.range_mode = 1; cp.f_lo = c * clen; cp.f_hi = c + 1 == n_chunks ? 0xffffffffu : (c + 1) * clen;
+								cp.range_mode = 1; cp.f_lo = cb[c]; cp.f_hi = c + 1 == n_chunks ? 0xffffffffu : cb[c + 1];
 								if (tc && c == 0) (void)hipEventRecord(tc->a, chain_stream_);
 								hipLaunchKernelGGL(chain_kernel, dim3(cgrid), dim3(192), clds, chain_stream_, cp);
 								if (tc && c + 1 == n_chunks) (void)hipEventRecord(tc->b, chain_stream_);
 								HIP_OK(hipEventRecord(chain_ev_[2 * c + 1], chain_stream_));
 							}
+							/* the mixer follows the final passes chunk by chunk (k_finish.h: premix_kernel): after the pass over the
+							 * row groups that end in chunk c, every frame below the chunk's end less one group's span is written
+							 * (a group has at most 64 x 6 frames in the builds that run here) */
+							const bool early_mix = early_mix_enabled_ && max_write && !(mix_few_enabled_ && max_rows <= 8 && seg.n_streams >= 8);
+							uint32_t mixed_blocks = 0;
+							if (early_mix) hipLaunchKernelGGL(premix_kernel, dim3((seg.n_voices + 63) / 64), dim3(64), 0, stream_, fp);
 							for (uint32_t c = 0; c < n_chunks; ++c) { /* the final pass follows the chains chunk by chunk */
 								HIP_OK(hipStreamWaitEvent(stream_, chain_ev_[2 * c + 1], 0));
-								fp.range_mode = 2; fp.f_lo = c * clen; fp.f_hi = c + 1 == n_chunks ? 0xffffffffu : (c + 1) * clen;
+								fp.range_mode = 2; fp.f_lo = cb[c]; fp.f_hi = c + 1 == n_chunks ? 0xffffffffu : cb[c + 1];
 								fp.range_last = c + 1 == n_chunks;
 								launch_fast(fp.sum_levels + 1, c + 1 == n_chunks ? fgrid : pgrid);
+								if (early_mix && c + 1 < n_chunks && cb[c + 1] > 512) {
+									const uint32_t hi = (cb[c + 1] - 512) / 256;
+									if (hi > mixed_blocks) {
+										MixParams mp = mix_params(seg, S);
+										mp.blk_lo = mixed_blocks; mp.blk_hi = hi;
+										TimedPair *tm = timing_on_ ? new_pair(1) : nullptr;
+										if (tm) (void)hipEventRecord(tm->a, stream_);
+										hipLaunchKernelGGL(mix_kernel, dim3(hi - mixed_blocks, seg.n_streams), dim3(256), 0, stream_, mp);
+										if (tm) (void)hipEventRecord(tm->b, stream_);
+										mixed_blocks = hi;
+									}
+								}
 							}
+							early_mixed_blocks_ = mixed_blocks;
 							fp.range_mode = 0; fp.f_lo = 0; fp.f_hi = 0; fp.range_last = 0;
 						}
 					} else {
@@ -1089,9 +1147,14 @@ public:
 			if (!big_slots_.ensure((size_t)block_grid_ * stride, err)) return false;
 			rp.big_slots = big_slots_.p; rp.big_stride = (uint32_t)stride;
 		}
+		if (!wait_for_predecessor(err)) return false; /* (a segment without the time-parallel path) */
 		TimedPair *tp = timing_on_ ? new_pair(0) : nullptr;
 		if (tp) (void)hipEventRecord(tp->a, stream_);
-		bool ok = V > 1 ? (T == 4 ? launch_render<1, 4, 16>(rp, block_grid_, lds, err)
+		bool ok = V == 8 ? (T == 4 ? launch_render<1, 4, 8>(rp, block_grid_, lds, err)
+		                  : T == 3 ? launch_render<1, 3, 8>(rp, block_grid_, lds, err)
+		                  : T == 2 ? launch_render<1, 2, 8>(rp, block_grid_, lds, err)
+		                           : launch_render<1, 1, 8>(rp, block_grid_, lds, err))
+		        : V > 1 ? (T == 4 ? launch_render<1, 4, 16>(rp, block_grid_, lds, err)
 		                 : T == 3 ? launch_render<1, 3, 16>(rp, block_grid_, lds, err)
 		                 : T == 2 ? launch_render<1, 2, 16>(rp, block_grid_, lds, err)
 		                          : launch_render<1, 1, 16>(rp, block_grid_, lds, err))
@@ -1103,11 +1166,10 @@ public:
 		if (tp) (void)hipEventRecord(tp->b, stream_);
 		if (debug_) debug_dump("after render", seg);
 		if (max_write) {
-			MixParams mp;
-			mp.streams = S.mstreams.p; mp.vout = S.vout.p; mp.pan = S.pan.p; mp.vinfo = S.vinfo.p;
-			mp.row_stride = row_stride_; mp.pcm_offset = seg.pcm_offset;
-			mp.stereo = seg.stereo ? 1 : 0;
-			mp.swap_bytes = seg.swap_bytes ? 1 : 0;
+			MixParams mp = mix_params(seg, S);
+			/* (frames an early launch has mixed are skipped when the device says those results stand: k_finish.h) */
+			mp.early_blocks = early_mixed_blocks_;
+			early_mixed_blocks_ = 0;
 			/* (on the generator's one stream, behind the segment's kernels. Round 3 built the mixer on a stream of its own beside the
 			 * next segment's kernels -- ordinary grid or persistent on a few CUs, everything it reads and writes double-buffered --
 			 * and measured it no faster in any form, profiles/r03_headline_ab.json; that code is gone since round 4.) */
@@ -1123,6 +1185,16 @@ public:
 			if (tm) (void)hipEventRecord(tm->b, ms);
 		}
 		return true;
+	}
+
+	template <typename SetT> MixParams mix_params(const SegmentDesc &seg, const SetT &S) {
+		MixParams mp;
+		mp.streams = S.mstreams.p; mp.vout = S.vout.p; mp.pan = S.pan.p; mp.vinfo = S.vinfo.p;
+		mp.row_stride = row_stride_; mp.pcm_offset = seg.pcm_offset;
+		mp.stereo = seg.stereo ? 1 : 0;
+		mp.swap_bytes = seg.swap_bytes ? 1 : 0;
+		mp.blk_lo = 0; mp.blk_hi = 0; mp.early_blocks = 0; mp.guard = work_count_.p;
+		return mp;
 	}
 
 	bool fetch_pcm(uint32_t stream, int16_t *dst, uint32_t frames, bool stereo, std::string &err) override {
@@ -1209,6 +1281,24 @@ public:
 	}
 
 	void *stream_handle() override { return (void *)stream_; }
+	bool order_after(HipBackend *before, std::string &err) override {
+		HipBackendImpl *o = static_cast<HipBackendImpl *>(before);
+		if (o == this) return true;
+		if (o->dev_ != dev_) { err = "sauAmd_Batch_order_after: the two batches are on different devices"; return false; }
+		use_device();
+		if (!after_ev_) HIP_OK(hipEventCreateWithFlags(&after_ev_, hipEventDisableTiming));
+		/* (everything of `before` ends on its main stream: its chain stream's work is joined there by the final passes) */
+		HIP_OK(hipEventRecord(after_ev_, o->stream_));
+		after_pending_ = true;
+		return true;
+	}
+	/* (render(): ahead of the first kernel that does real work -- after analyze_kernel and decode_kernel) */
+	bool wait_for_predecessor(std::string &err) {
+		if (!after_pending_) return true;
+		after_pending_ = false;
+		HIP_OK(hipStreamWaitEvent(stream_, after_ev_, 0));
+		return true;
+	}
 	void set_timing(int level) override { timing_on_ = level > 0; timing_level_ = level; }
 
 	void timing_ex(double *out4, uint64_t *segments, bool reset) override {
@@ -1352,6 +1442,7 @@ private:
 	int dev_ = 0;
 	std::map<void *, size_t> host_blocks_; /* alloc_host() blocks and their pool sizes */
 	uint32_t multi_min_ = 256;
+	uint32_t multi_teams_ = 16; /* SAU_AMD_MULTI_TEAMS: 8 or 16 single-wave teams per workgroup */
 	uint32_t fast_rows_ = 8;
 	static inline size_t chain_lds_configured_[16] = {}; /* chain_kernel's LDS attribute per device (two launch sites) */
 	bool seq_enabled_ = true, two_pass_enabled_ = true, chain_enabled_ = true, chain_inline_ = false, chain_early_ = true;
@@ -1373,6 +1464,11 @@ private:
 	uint32_t block_grid_ = 1;
 	uint32_t fk_grid_ = FK_GRID;
 	bool dyn_enabled_ = true, lean_enabled_ = true, mix_few_enabled_ = true;
+	bool short_last_chunk_ = true; /* SAU_AMD_NO_SHORT_LAST_CHUNK */
+	bool early_mix_enabled_ = true; /* segments with chains in chunks: the mixer follows the final passes chunk by chunk */
+	hipEvent_t after_ev_ = nullptr; /* order_after() */
+	bool after_pending_ = false;
+	uint32_t early_mixed_blocks_ = 0; /* 256-frame blocks of this segment that early launches have mixed */
 	bool wide_tabs_ = true;
 	uint32_t more_rows_ = 12;
 	uint32_t lean_rows_ = 6;    /* SAU_AMD_LEAN_ROWS: rows per pass of fast_kernel<T, 3> at most (6, 5 or 4) */

@@ -67,7 +67,7 @@ __device__ __forceinline__ bool op_has_fpm(const Step *plan, uint32_t n, uint32_
 
 __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 	const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; /* (the host picks the voices per wave) */
-	if (v == 0) *P.work_count = 0; /* finalize_kernel (a later launch) builds the block loop's work list */
+	if (v == 0) { P.work_count[0] = 0; P.work_count[1] = 0; } /* finalize_kernel (a later launch) builds the block loop's work list; [1]: premix_kernel's verdict */
 	if (v >= P.n_voices) return;
 	const VoiceDesc vd = P.voices[v];
 	const uint32_t *ids = P.op_ids + vd.ops_ofs;

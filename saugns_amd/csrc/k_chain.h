@@ -527,48 +527,168 @@ __global__ void __launch_bounds__(192) chain_kernel(FastParams P) {
 
 /* R-oscillator feedback (rasg.h:242-294: per sample, feedback -> phase offset -> cycle carry -> segment value ->
  * feedback), lanes = chains, for R oscillators fed from their own lines (CL_RASEG: always early chains, whole
- * segment, ahead of every pass). No feeder wave: the counter is the lane's own running sum of its frequency line's
- * increments, the amounts come from its pm_a line; samples go to the chain's first row, where every pass that
- * needs them reads them (FT_CHAIN_EARLY). Nothing here is tuned -- no BASELINE configuration or corpus script has
- * R feedback; what it buys is that such voices no longer take the block loop's one-lane loop. */
-__global__ void __launch_bounds__(64) rchain_kernel(FastParams P) {
+ * segment, ahead of every pass); samples go to the chain's first row, where every pass that needs them reads them
+ * (FT_CHAIN_EARLY). Round 5: what chain_kernel has. A workgroup is two waves over the same 64
+ * chains. The CHAIN wave runs nothing but the recurrence -- amount x feedback, the phase offset, the reference build's
+ * integer floor, the segment's value, the feedback average -- on inputs it finds in LDS, thirty-two frames per lane at a
+ * time, and leaves its samples there. The FEEDER wave does everything that does not depend on the feedback: it evaluates the
+ * frequency line and sums the 64-bit counter (post-increment, rasg.h:184-186: what a frame reads is the counter before its
+ * own increment), splits it into cycle and phase, evaluates the amount line, a batch ahead; and it writes the batch of
+ * samples before to the chain's row, sixteen bytes at a time (until round 5: one lane's 4-byte store per sample, and
+ * both line evaluations, on the dependent chain: 480 ns per frame for a single voice). One barrier per batch. */
+constexpr uint32_t RCHAIN_BATCH = 32;
+constexpr size_t RCHAIN_LDS_BYTES = (size_t)(3 + 1) * 2 * RCHAIN_BATCH * 64 * 4; /* cycle, phase, amount in; samples out: two batches each */
+__global__ void __launch_bounds__(128) rchain_kernel(FastParams P) {
 	if (P.pass_flags[FAST_EARLY_FLAG] == 0) return;
-	const uint32_t c = blockIdx.x * 64 + threadIdx.x;
-	if (c >= P.n_chain_rows || P.chain_desc[c].n == 0) return;
-	const ChainDesc cd = P.chain_desc[c];
-	if (!(cd.lflags & CL_RASEG)) return;
-	DevOp &o = P.ops[cd.gop];
-	const bool rate2x = (o.flags & OPF_RATE2X) != 0;
-	const float rcoeff = rate2x ? cd.coeff * 2 : cd.coeff;
-	const RasParams rp = ras_params(o.ras_func, o.ras_flags, o.ras_level, o.ras_alpha, o.wave);
-	float *row = P.chain_rows + (size_t)2 * c * P.chain_stride;
-	unsigned long long cp = o.cycle_phase;
-	const unsigned long long inc_c = (unsigned long long)rint64(rcoeff * o.rt_fconst);
-	float fb_s = o.fb_s, prev_s = o.prev_s;
-	for (uint32_t t = 0; t < cd.n; ++t) {
-		unsigned long long inc = inc_c;
-		if (!(cd.lflags & CL_FCONST)) {
-			float v = fast_line_value(cd.fl, (int)t);
-			if (cd.lflags & (t < cd.fl.goal_len ? CL_MUL_GOAL : CL_MUL_HOLD)) v *= cd.mulc;
-			inc = (unsigned long long)rint64(rcoeff * v);
-		}
-		uint32_t cyc; float phf;
-		ras_split(cp, cyc, phf); /* rasg.h:184-186, post-increment */
-		cp += inc;
-		const float pma_v = fast_line_value(cd.pl, (int)t);
-		const float pm_a = ras_fb_amount(fb_s, pma_v);
-		float phase = phf + pm_a;
-		const int32_t cycle_adj = floor_i32_ref(phase); /* (a feedback offset of 2^31 cycles and more: the host's conversion and its wrap) */
-		const uint32_t cycle = cyc + (uint32_t)cycle_adj;
-		phase -= (float)cycle_adj;
-		const float sv = ras_sample(rp, cycle, phase, false);
-		row[t] = sv;
-		fb_s = ((fb_s + prev_s) + sv) * 0.5f; /* the reference build's association (see the oracle) */
-		prev_s = sv;
+	extern __shared__ __align__(16) unsigned char rc_lds[];
+	uint32_t *const in_cyc = (uint32_t *)rc_lds;                       /* [2][RCHAIN_BATCH][64] */
+	float *const in_ph = (float *)(in_cyc + 2 * RCHAIN_BATCH * 64);
+	float *const in_am = in_ph + 2 * RCHAIN_BATCH * 64;
+	float *const out_s = in_am + 2 * RCHAIN_BATCH * 64;
+	const int l = threadIdx.x & 63;
+	const bool feeder = uni((uint32_t)threadIdx.x >> 6) != 0;
+	const uint32_t c = blockIdx.x * 64 + (uint32_t)l;
+	ChainDesc cd = P.chain_desc[c < P.n_chain_rows ? c : 0];
+	uint32_t n = 0;
+	if (c < P.n_chain_rows) {
+		if (cd.n && (cd.lflags & CL_RASEG)) n = cd.n;
 	}
-	/* staged: finalize_kernel makes it the operator's state unless the voice's segment is redone */
-	o.st_prev_Is = __longlong_as_double((long long)cp);
-	o.st_prev_s = prev_s;
-	o.st_prev_phase = f_bits(fb_s);
-	o.st_phase = CHAIN_MARK;
+	uint32_t n_max = n; /* the workgroup's longest chain decides the number of batches (both waves alike) */
+#pragma unroll
+	for (int sh = 32; sh >= 1; sh >>= 1) n_max = max(n_max, (uint32_t)__shfl_xor((int)n_max, sh));
+	n_max = uni(n_max);
+	if (n_max == 0) return;
+	const uint32_t nb = (n_max + RCHAIN_BATCH - 1) / RCHAIN_BATCH;
+	DevOp *op = n ? &P.ops[cd.gop] : nullptr;
+	const unsigned long long act = __ballot(n != 0);
+	const int first = act ? __builtin_ctzll(act) : 0;
+	if (feeder) {
+		const bool rate2x = n && (op->flags & OPF_RATE2X) != 0;
+		const float rcoeff = n ? (rate2x ? cd.coeff * 2 : cd.coeff) : 0.f;
+		unsigned long long cp = n ? op->cycle_phase : 0ull;
+		const unsigned long long inc_c = n ? (unsigned long long)rint64(rcoeff * op->rt_fconst) : 0ull;
+		float *row = P.chain_rows + (size_t)2 * c * P.chain_stride;
+		/* the whole of the feeder's work, for line shapes and flags that are the lane's own or -- chains of one kind: a bank of
+		 * like voices, one voice -- the wave's (two copies of the loop: in the second every value's shape dispatch is a scalar
+		 * branch) */
+		auto feed = [&](const FastLine &fl, const FastLine &pl, const uint32_t lflags) {
+			auto fill = [&](uint32_t k) { /* the inputs of batch k */
+				uint32_t *cy = in_cyc + (k & 1) * RCHAIN_BATCH * 64;
+				float *ph = in_ph + (k & 1) * RCHAIN_BATCH * 64, *am = in_am + (k & 1) * RCHAIN_BATCH * 64;
+				const uint32_t t0 = k * RCHAIN_BATCH;
+				if (t0 >= n) return;
+#pragma unroll 4
+				for (uint32_t j = 0; j < RCHAIN_BATCH; ++j) {
+					const uint32_t t = t0 + j;
+					unsigned long long inc = inc_c;
+					if (!(lflags & CL_FCONST)) {
+						float v = fast_line_value(fl, (int)t);
+						if (lflags & (t < fl.goal_len ? CL_MUL_GOAL : CL_MUL_HOLD)) v *= cd.mulc;
+						inc = (unsigned long long)rint64(rcoeff * v);
+					}
+					uint32_t cyc; float phf;
+					ras_split(cp, cyc, phf); /* rasg.h:184-186, post-increment */
+					if (t < n) cp += inc;
+					cy[j * 64 + l] = cyc; ph[j * 64 + l] = phf;
+					am[j * 64 + l] = fast_line_value(pl, (int)t);
+				}
+			};
+			auto drain = [&](uint32_t k) { /* the samples of batch k to the chain's row */
+				const float *os = out_s + (k & 1) * RCHAIN_BATCH * 64;
+				const uint32_t t0 = k * RCHAIN_BATCH;
+				if (t0 >= n) return;
+				if (t0 + RCHAIN_BATCH <= n) {
+#pragma unroll
+					for (uint32_t q = 0; q < RCHAIN_BATCH / 4; ++q) /* (rows are 256-byte aligned: chain_stride is a multiple of 64) */
+						*(float4 *)(row + t0 + 4 * q) = make_float4(os[(4 * q) * 64 + l], os[(4 * q + 1) * 64 + l], os[(4 * q + 2) * 64 + l], os[(4 * q + 3) * 64 + l]);
+				} else {
+					for (uint32_t j = 0; t0 + j < n; ++j) row[t0 + j] = os[j * 64 + l];
+				}
+			};
+			fill(0);
+			__syncthreads();
+			for (uint32_t k = 0; k < nb; ++k) {
+				if (k + 1 < nb) fill(k + 1);
+				if (k >= 1) drain(k - 1);
+				__syncthreads();
+			}
+			drain(nb - 1);
+		};
+		const uint32_t ft0 = (uint32_t)__builtin_amdgcn_readlane((int)cd.fl.sw.type, first), pt0 = (uint32_t)__builtin_amdgcn_readlane((int)cd.pl.sw.type, first);
+		const uint32_t lf0 = (uint32_t)__builtin_amdgcn_readlane((int)cd.lflags, first);
+		if (!__any(n != 0 && (cd.fl.sw.type != ft0 || cd.pl.sw.type != pt0 || cd.lflags != lf0))) {
+			FastLine fl = cd.fl, pl = cd.pl;
+			fl.sw.type = ft0; pl.sw.type = pt0;
+			feed(fl, pl, lf0);
+		} else {
+			feed(cd.fl, cd.pl, cd.lflags);
+		}
+		if (n) { /* staged: finalize_kernel makes it the operator's state unless the voice's segment is redone */
+			op->st_prev_Is = __longlong_as_double((long long)cp);
+			op->st_phase = CHAIN_MARK;
+		}
+		return;
+	}
+	/* the chain wave */
+	RasParams rp;
+	float fb_s = 0.f, prev_s = 0.f;
+	if (n) {
+		rp = ras_params(op->ras_func, op->ras_flags, op->ras_level, op->ras_alpha, op->wave);
+		fb_s = op->fb_s; prev_s = op->prev_s;
+	} else {
+		rp = ras_params(0, 0, 0, 0, 0);
+	}
+	auto chain = [&](const RasParams &rq) {
+		__syncthreads(); /* batch 0's inputs */
+		for (uint32_t k = 0; k < nb; ++k) {
+			const uint32_t *cy = in_cyc + (k & 1) * RCHAIN_BATCH * 64;
+			const float *ph = in_ph + (k & 1) * RCHAIN_BATCH * 64, *am = in_am + (k & 1) * RCHAIN_BATCH * 64;
+			float *os = out_s + (k & 1) * RCHAIN_BATCH * 64;
+			const uint32_t t0 = k * RCHAIN_BATCH;
+			if (t0 < n) {
+				const uint32_t m = min(RCHAIN_BATCH, n - t0);
+				auto step = [&](const uint32_t cyc_in, const float ph_in, const float am_in, const uint32_t j) {
+					const float pm_a = ras_fb_amount(fb_s, am_in);
+					float phase = ph_in + pm_a;
+					const int32_t cycle_adj = floor_i32_ref(phase); /* (a feedback offset of 2^31 cycles and more: the host's conversion and its wrap) */
+					const uint32_t cycle = cyc_in + (uint32_t)cycle_adj;
+					phase -= (float)cycle_adj;
+					const float sv = ras_sample<true>(rq, cycle, phase, false);
+					os[j * 64 + l] = sv;
+					fb_s = ((fb_s + prev_s) + sv) * 0.5f; /* the reference build's association (see the oracle) */
+					prev_s = sv;
+				};
+				if (m == RCHAIN_BATCH) {
+					/* four steps' inputs into registers ahead of the four steps: the LDS reads go out together and off the chain
+					 * (between the steps stand the scalar branches of the function / flag / shape dispatch, which loads do not cross) */
+					for (uint32_t j0 = 0; j0 < RCHAIN_BATCH; j0 += 4) {
+						uint32_t c4[4]; float p4[4], a4[4];
+#pragma unroll
+						for (uint32_t u = 0; u < 4; ++u) { c4[u] = cy[(j0 + u) * 64 + l]; p4[u] = ph[(j0 + u) * 64 + l]; a4[u] = am[(j0 + u) * 64 + l]; }
+#pragma unroll
+						for (uint32_t u = 0; u < 4; ++u) step(c4[u], p4[u], a4[u], j0 + u);
+					}
+				} else {
+					for (uint32_t j = 0; j < m; ++j) step(cy[j * 64 + l], ph[j * 64 + l], am[j * 64 + l], j);
+				}
+			}
+			__syncthreads();
+		}
+	};
+	{ /* (as the feeder's line shapes: function, flags, level and line of a bank of like voices are the wave's, and every
+	   * sample's dispatch on them a scalar branch) */
+		const uint32_t f0 = (uint32_t)__builtin_amdgcn_readlane((int)rp.func, first), g0 = (uint32_t)__builtin_amdgcn_readlane((int)rp.flags, first);
+		const uint32_t v0 = (uint32_t)__builtin_amdgcn_readlane((int)rp.level, first), l0 = (uint32_t)__builtin_amdgcn_readlane((int)rp.line, first);
+		if (!__any(n != 0 && (rp.func != f0 || rp.flags != g0 || rp.level != v0 || rp.line != l0))) {
+			RasParams ru = rp;
+			ru.func = f0; ru.flags = g0; ru.level = v0; ru.line = l0;
+			chain(ru);
+		} else {
+			chain(rp);
+		}
+	}
+	if (n) {
+		op->st_prev_s = prev_s;
+		op->st_prev_phase = f_bits(fb_s);
+	}
 }

@@ -38,10 +38,20 @@ typedef float __attribute__((ext_vector_type(2))) fk_f32x2;
 typedef const fk_f64x2 __attribute__((address_space(3))) *fk_lds_f64x2;
 typedef const fk_f32x2 __attribute__((address_space(3))) *fk_lds_f32x2;
 struct FkHerp { double c3, c2, c1, c0; };
-template <bool WIDE>
+template <bool WIDE, bool TAB0 = false>
 __device__ __forceinline__ FkHerp fk_entry(const uint32_t tab, const uint32_t ph) {
 	FkHerp h;
-	if (WIDE) {
+	if (WIDE && TAB0) {
+		/* the table block at LDS address 0 (a launch's first table: every operator of a one-wave bank): the address is the
+		 * index alone, (ph >> 17) & 0x7ff0 -- two 2-cycle instructions where v_lshrrev + v_lshl_add (a 4-cycle one) stand --
+		 * and the [c1, c0] entry's 32 KiB go into the read's offset field. Round 5, measured and not used: a second copy of
+		 * the Hermite block under a uniform test of the table's address cost fast_kernel<12, 0, false, true> ten spilled VGPRs
+		 * and everything the cheaper address bought (1.784 against 1.757 ms per launch, profiles/r05_headline_ab.json) */
+		const uint32_t a = (ph >> (SLEN_BITS - 4)) & ((WAVE_LEN - 1) << 4);
+		const fk_f64x2 hi = *(fk_lds_f64x2)(uintptr_t)a;
+		const fk_f64x2 lo = *(fk_lds_f64x2)(uintptr_t)(a + FkTab<true>::C01);
+		h.c3 = hi.x; h.c2 = hi.y; h.c1 = lo.x; h.c0 = lo.y;
+	} else if (WIDE) {
 		/* one address (v_lshrrev + v_lshl_add) serves both reads: the [c1, c0] entry sits a constant 32 KiB further on */
 		/* (the empty asm keeps LLVM from rewriting (ph >> 21) << 4 as (ph >> 17) & 0x7ff0, which costs a third instruction) */
 		uint32_t ind = ph >> SLEN_BITS;
@@ -303,12 +313,20 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 								 * row -- rendered wrong samples from the second row group on, with the DPP move folded into the
 								 * subtraction; the per-row compare stays) */
 								bool zero = false, zero_n = false; /* a phase step of zero in row 0 / in a later row */
+								/* (round 5: one v_min_u32 per later row -- a 2-cycle instruction, tools/valu_probe.hip -- and one compare per
+								 * group, where a v_cmp + s_or per row stood: 1.787 -> 1.755 ms per config-3 launch. The unsigned minimum
+								 * of the steps is zero exactly when one of them is. Round 4's v_min3 form rendered wrong samples with the
+								 * DPP move folded into the subtraction that fed it: the empty asm keeps the move a move) */
+								uint32_t dmin = 0xffffffffu;
 #pragma unroll
 								for (int k = 0; k < T; ++k) {
-									const int32_t d = (int32_t)(ph[k] - prev32(ph, k));
-									if (CONTIG && k > 0) zero_n |= (d == 0); else zero |= (d == 0);
+									uint32_t pp = prev32(ph, k);
+									asm("" : "+v"(pp));
+									const int32_t d = (int32_t)(ph[k] - pp);
+									if (CONTIG && k > 0) dmin = min(dmin, (uint32_t)d); else zero |= (d == 0);
 									s[k] = wosc_diff(Is[k], prev64(Is, k), d, f.diff_scale, f.diff_offset);
 								}
+								zero_n = dmin == 0;
 								/* (every lane of a contiguous group's later rows is a defined one) */
 								done = !__any((zero && l >= p_min) || zero_n);
 							}

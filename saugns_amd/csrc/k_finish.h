@@ -111,6 +111,29 @@ __global__ void __launch_bounds__(64) finalize_kernel(FastParams P) {
 	}
 }
 
+/* Segments with feedback chains run in chunks of frames, chains beside passes (hip_backend.hip), and the mixer -- 1.07 ms of
+ * reading 7 GB of voice rows for BASELINE config 5's 10 s -- used to wait for the last of them. It can take a chunk's frames
+ * as soon as the chunk's final pass has written them, provided it knows what finalize_kernel will tell it: this kernel writes
+ * every voice's mixer record ahead of the passes -- the constant pan, the frames the time-parallel path will render -- and
+ * notes in work_count[1] when some voice is not one it can speak for (not on that path, or not to its end: the block loop will
+ * rewrite its row). The early launches then mix frame windows; the launch after finalize_kernel mixes what is left -- the
+ * whole segment, once more, when the note or a voice on the block loop's work list (a bail-out found in a pass) says the
+ * early results do not stand. Sums and order are the mixer's own: the same PCM either way (round 5). */
+__global__ void __launch_bounds__(64) premix_kernel(FastParams P) {
+	const uint32_t v = blockIdx.x * 64 + threadIdx.x;
+	if (v >= P.n_voices) return;
+	const FastInfo fi = P.info[v];
+	const VoiceDesc vd = P.voices[v];
+	if (fi.total == 0 || fi.bail || fi.total < vd.run_len) { atomicOr(&P.work_count[1], 1u); return; }
+	const uint32_t *ids = P.op_ids + vd.ops_ofs;
+	VoiceOut vo;
+	vo.pan_const = P.ops[ids[vd.carr_local]].line[L_PAN].v0; /* (a held line: finalize_kernel's advance leaves v0 alone) */
+	vo.has_pan = vd.pan_dynamic_row != ~0u ? 1u : 0u;
+	vo.valid_len = fi.total;
+	vo.pan_row = vd.pan_dynamic_row;
+	P.vinfo[vd.out_row] = vo;
+}
+
 struct MixStream {
 	uint32_t first_row, n_rows;
 	float amp_scale;
@@ -127,6 +150,10 @@ struct MixParams {
 	uint32_t pcm_offset;
 	uint32_t stereo;
 	uint32_t swap_bytes; /* big-endian PCM for AU files (player/sndfile.c:160-168) */
+	/* frame windows (premix_kernel above): an early launch mixes the 256-frame blocks [blk_lo, blk_hi); the last one skips
+	 * the blocks below early_blocks when guard[0] (voices on the block loop's list) and guard[1] (premix_kernel's note) are 0 */
+	uint32_t blk_lo, blk_hi, early_blocks;
+	const uint32_t *guard;
 };
 
 /* generator.c:749-825: ordered voice sum (ref-build association) and PCM.
@@ -243,8 +270,11 @@ __global__ void __launch_bounds__(256) mix_kernel(MixParams P) {
 	__shared__ uint32_t s_prow[MIX_TILE]; /* pan row, or ~0u */
 	__shared__ uint32_t s_special;        /* tile has a short row or a pan row */
 	const MixStream ms = P.streams[blockIdx.y];
-	if (blockIdx.x * 256 >= ms.write_len) return;
-	mix_body(P, ms, blockIdx.x, s_pan, s_valid, s_prow, s_special);
+	const uint32_t bx = blockIdx.x + P.blk_lo;
+	if (bx * 256 >= ms.write_len || (P.blk_hi && bx >= P.blk_hi)) return;
+	if (P.blk_hi && P.guard[1]) return; /* an early launch, and premix_kernel could not speak for every voice: their records are not there yet */
+	if (P.early_blocks && bx < P.early_blocks && P.guard[0] == 0 && P.guard[1] == 0) return; /* mixed by an early launch, and it stands */
+	mix_body(P, ms, bx, s_pan, s_valid, s_prow, s_special);
 }
 
 /* Streams of a few voices each (a batch of many small scripts: BASELINE config 4 has two voices per render): four

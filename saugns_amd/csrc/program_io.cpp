@@ -131,13 +131,18 @@ extern "C" sauProgram *sauAmd_program_load(const void *image, size_t len) {
 	memcpy(base, image, total);
 	sauProgram *prg = (sauProgram *)(base + 16);
 	bool ok = fix(prg->events, base, total, sizeof(sauProgramEvent), prg->ev_count);
+	uint64_t max_id = 0; /* the highest operator id anything in the image names */
 	for (size_t i = 0; ok && i < prg->ev_count; ++i) {
 		sauProgramEvent *ev = (sauProgramEvent *)&prg->events[i];
 		if (ev->op_list == nullptr) ev->op_count = 0; /* (the list is optional: generator.c never reads it) */
 		ok = ok && fix(ev->op_list, base, total, sizeof(sauProgramOpRef), ev->op_count);
 		ok = ok && fix(ev->op_data, base, total, sizeof(sauProgramOpData), ev->op_data_count);
+		for (size_t k = 0; ok && ev->op_list && k < ev->op_count; ++k)
+			if (ev->op_list[k].id > max_id) max_id = ev->op_list[k].id;
+		if (ok && ev->carr_op_id > max_id && ev->vo_id != SAU_PVO_NO_ID) max_id = ev->carr_op_id;
 		for (size_t k = 0; ok && k < ev->op_data_count; ++k) {
 			sauProgramOpData *od = (sauProgramOpData *)&ev->op_data[k];
+			if (od->id > max_id) max_id = od->id;
 			sauLine **lines[] = {&od->pan, &od->amp, &od->amp2, &od->freq, &od->freq2, &od->pm_a};
 			for (sauLine **l : lines) ok = ok && (*l == nullptr || fix(*l, base, total, sizeof(sauLine), 1));
 			const sauProgramIDArr **arrs[] = {&od->camods, &od->amods, &od->ramods, &od->fmods,
@@ -148,14 +153,18 @@ extern "C" sauProgram *sauAmd_program_load(const void *image, size_t len) {
 				if (ok) {
 					const size_t at = (size_t)((const uint8_t *)(*a) - base);
 					ok = (*a)->count <= (total - at) / sizeof(uint32_t) - 1;
+					for (uint32_t j = 0; ok && j < (*a)->count; ++j)
+						if ((*a)->ids[j] > max_id) max_id = (*a)->ids[j];
 				}
 			}
 		}
 	}
-	/* An image of n bytes does not describe more than n operators (the parser may count ids that no event ever gives data
-	 * for -- devtests/freelist.sau: 4 ids, 2 with data -- so the count is not bounded by the operator data); one that claims
-	 * 2^31 of them would only have the engine allocate for them. (vo_count is 16 bits wide.) */
-	ok = ok && prg->op_count <= total;
+	/* The engine allocates per-operator state for op_count operators: the count is bounded by what the image can name --
+	 * the highest operator id in any operator datum, graph list, modulator list or carrier field, plus the ids the parser
+	 * may have counted without ever using them (devtests/freelist.sau: 4 ids, 2 with data, the others named nowhere; 64 of
+	 * slack) -- so a forged count cannot make a small image cost gigabytes (until round 5: op_count <= bytes).
+	 * (vo_count is 16 bits wide.) */
+	ok = ok && prg->op_count <= max_id + 1 + 64 && prg->op_count <= total / sizeof(sauProgramOpRef);
 	if (!ok) { free(base); return nullptr; }
 	prg->name = "image";
 	return prg;

@@ -178,7 +178,7 @@ SAU_HD float expramp6(float x) {
 
 /* Scalar shape value, sau/line.h:153-266 (ref-build forms for cub smo ncl nhl
  * and, through expramp6, exp log xpe lge). */
-SAU_HD_CALL float shape_val(uint32_t type, float x, float a, float b) {
+SAU_HD float shape_val_inl(uint32_t type, float x, float a, float b) {
 	switch (type) {
 	default:
 	case LN_sah: return a;
@@ -212,6 +212,9 @@ SAU_HD_CALL float shape_val(uint32_t type, float x, float a, float b) {
 	}
 	}
 }
+/* (a real call on the device: inlined into the 1000-line block-loop kernel it exposed a hipcc miscompile, DESIGN.md 5;
+ * rchain_kernel -- a small kernel with the shape known per wave -- takes the inline form, ras_sample<true>) */
+SAU_HD_CALL float shape_val(uint32_t type, float x, float a, float b) { return shape_val_inl(type, x, a, b); }
 
 /* Parameters of one timed sweep, hoisted out of the per-sample evaluation
  * exactly as the reference's fill functions hoist them (sau/line.c:65-281). */
@@ -1038,6 +1041,7 @@ SAU_HD void ras_ends(const RasParams &c, uint32_t cycle, float &a, float &b) {
  * reference build only in how -ffast-math associated the Perlin scaling: the block loop (vector
  * body and scalar tail alike) computes (a * phase) * amp and (b * amp) * (phase - 1), the six
  * per-sample loops keep the source's a * (amp * phase) and b * (amp * (phase - 1)). */
+template <bool INL = false>
 SAU_HD float ras_sample(const RasParams &c, uint32_t cycle, float phase, bool block, bool cub_tail = false) {
 	float a, b;
 	ras_ends(c, cycle, a, b);
@@ -1067,7 +1071,7 @@ SAU_HD float ras_sample(const RasParams &c, uint32_t cycle, float phase, bool bl
 		b *= fabsf(b);
 	}
 	if (cub_tail && c.line == LN_cub) return shape_cub_tail(phase, a, b); /* (the last 1-3 samples of the reference's block: TailCtx) */
-	return shape_val(c.line, phase, a, b);
+	return INL ? shape_val_inl(c.line, phase, a, b) : shape_val(c.line, phase, a, b);
 }
 
 /* Split the 64-bit cycle|phase counter: rasg.h:184-186 */

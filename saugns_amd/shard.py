@@ -29,11 +29,13 @@ class _DevicePCM:
         self.__cuda_array_interface__ = {"shape": (int(frames),), "typestr": "<i2", "data": (int(ptr), False), "version": 2}  # (torch takes no read-only flag; nothing here writes)
 
 
-def device_pcm_tensor(batch, stream, frames):
-    """The PCM of `stream` as the batch left it in HBM -> int16 torch tensor on the current device (no copy; valid
-    until the batch renders again or is closed)."""
+def device_pcm_tensor(batch, stream, frames, channels=1):
+    """The PCM of `stream` as the batch's LAST engine run left it in HBM -> int16 torch tensor [frames * channels] on the
+    current device (no copy; valid until the batch renders again or is closed). The PCM block holds one run: a render made
+    of several runs has only its last one there (the block is cleared at the start of every run) -- callers that want a
+    whole render render it in one run (bench.py --gather-pcm checks that it did)."""
     import torch
-    return torch.as_tensor(_DevicePCM(batch.device_pcm(stream), frames), device="cuda")
+    return torch.as_tensor(_DevicePCM(batch.device_pcm(stream), int(frames) * int(channels)), device="cuda")
 
 
 def gather_renders_to_root(local, dst=0):

@@ -158,6 +158,23 @@ def need_ref(oracle):
                     "it travels to the GPU box with the tree")
 
 
+@contextlib.contextmanager
+def ref_tables(sa, oracle, tables):
+    """Device, oracle and compiled reference on the wave tables that very reference library has built: it makes them with
+    libm's sin() when it starts (sau/wave.c:105-221) and glibc picks its sin() by CPU -- on the GPU box's host four tables
+    differ from the fixture by an ulp here and there. (What a host linked against this backend gets too: the shim adopts the
+    host binary's sauWave_piluts, INTEGRATION.md.)"""
+    oracle.ref()
+    t = oracle.ref_piluts()
+    sa.set_piluts(t)
+    oracle.oracle_use_tables(t)
+    try:
+        yield t
+    finally:
+        sa.set_piluts(tables)
+        oracle.oracle_use_tables(tables)
+
+
 def load_program(sa, key):
     blob = open(os.path.join(GOLDEN, "programs", key + ".saup"), "rb").read()
     return sa.Program.from_image(blob)

@@ -126,6 +126,22 @@ def test_bench_gpus_2_gathers_finished_pcm_to_rank_0(seqexec):
     assert g["renders"] == 4 and g["bytes"] == 4 * 11025 * 2 and g["backend"] == "gloo" and g["seconds"] > 0
 
 
+def test_bench_gpus_8_config4_at_the_north_stars_split(seqexec):
+    """The north star's multi-GPU case with its real geometry, as far as a box without GPUs can run it:
+    eight ranks (gloo), rank r renders seeds shard_range(512, r, 8) = [64 r, 64 r + 64) of BASELINE config 4 -- the heads of the
+    renders, over the sequential executor --, the ranks tally {frames, renders} and, with --gather-pcm, send their finished PCM
+    to rank 0, which must end up holding all 512 renders in rank order (checked against what every rank says it rendered).
+    The day an 8-GPU node exists the only new thing is RCCL itself."""
+    j = _line(_bench(["--gpus", "8", "--workload", "config4", "--renders", "64", "--c4-frames", "2205", "--steps", "1",
+                      "--warmup", "0", "--no-cpu", "--gather-pcm"], seqexec, timeout=1500))
+    assert j["n_gpus"] == 8 and j["scaling"] == "weak"
+    assert j["config"]["renders_all_ranks"] == 512 and j["config"]["frames_all_ranks"] == 512 * 2205
+    assert "shard_range(512, rank, 8)" in j["config"]["workload"]
+    g = j["config"]["pcm_gather"]
+    assert g["renders"] == 512 and g["bytes"] == 512 * 2205 * 2 and g["backend"] == "gloo" and g["rank_order_checked"]
+    assert g["distinct_renders"] > 500  # (seed = k: every render is its own)
+
+
 def test_gather_renders_to_root_keeps_rank_order(tmp_path):
     """shard.gather_renders_to_root with two gloo ranks: rank 0 gets [rank 0's renders, rank 1's], rank 1 nothing."""
     script = f"""

@@ -72,6 +72,18 @@ def test_lattice_programs_in_one_batch(sa, oracle):
         _same(got, oracle.oracle_render(prg.ptr, 44100, False, chunk=2500), k)
 
 
+@pytest.fixture()
+def on_ref_tables(sa, oracle, tables):
+    """Where the compiled reference is here (the GPU box): device and oracle on the wave tables that library built (conftest.py:
+    ref_tables) for the test's duration -> True; else the fixture tables -> False."""
+    from conftest import ref_tables
+    if not oracle.have_ref():
+        yield False
+        return
+    with ref_tables(sa, oracle, tables):
+        yield True
+
+
 def _render_calls(create, run, destroy, prg, rate, calls):
     """A host that changes its calls from one to the next: (frames, stereo) in turn, the last one until the script ends.
     -> the calls' PCM, one after the other."""
@@ -104,7 +116,7 @@ MIXED = [[(11289, False)] * 3 + [(11289, True)] * 4 + [(11289, False)],
          [(4000, False)] * 20 + [(4000, True)] * 20 + [(1000, False)] * 7 + [(25000, True)]]
 
 
-def test_a_host_that_changes_its_call_size(sa, oracle, monkeypatch):
+def test_a_host_that_changes_its_call_size(sa, oracle, on_ref_tables, monkeypatch):
     """The reference's output can depend on the size of the host's calls (its blocks restart at every call), and
     sauGenerator_run takes the size per call (sau/generator.c:905-913). The drop-in generator follows any pattern of sizes
     exactly -- with one engine run per call (SAU_AMD_READAHEAD=0) and, since round 5, in its default setting too: a call of
@@ -115,7 +127,7 @@ def test_a_host_that_changes_its_call_size(sa, oracle, monkeypatch):
     import saugns_amd.api as api
     lib, ora = api.lib(), oracle.oracle()
     ora.ora_set_fastmath_forms(ORACLE_FORMS)
-    ref = oracle.ref() if oracle.have_ref() else None
+    ref = oracle.ref() if on_ref_tables else None
     dep = [expiry_value_goal_program(s) for s in range(4)] + [lattice_case(np.random.default_rng(77300 + k)) for k in range(4)]
     differs = 0
     for stereo in (False, True):
@@ -147,13 +159,14 @@ def test_a_host_that_changes_its_call_size(sa, oracle, monkeypatch):
         _same(got, want, (sizes, "read-ahead"))
 
 
-def test_a_host_that_changes_its_channel_layout(sa, oracle):
+def test_a_host_that_changes_its_channel_layout(sa, oracle, on_ref_tables):
     """`stereo` is an argument of every sauGenerator_run call as well (sau/generator.c:905): mono <-> stereo flips in
     mid-stream, with and without a change of size, with frames buffered for the other layout (until round 5: a failure,
     silence + false, which a host reads as the end of the script). Against the compiled reference itself."""
     import saugns_amd.api as api
     from conftest import need_ref
     need_ref(oracle)
+    assert on_ref_tables
     lib, ref, ora = api.lib(), oracle.ref(), oracle.oracle()
     ora.ora_set_fastmath_forms(ORACLE_FORMS)
     from saugns_amd import voicebank

@@ -1011,6 +1011,50 @@ def test_look_back_wait_is_bounded(sa, oracle, monkeypatch):
         assert b.timing_ex()["block_ms"] > 1.0  # (the block loop did redo them: the hook really withheld the words)
 
 
+def test_batches_ordered_one_behind_the_other(sa, oracle):
+    """sauAmd_Batch_order_after: scripts one after the other with two generators alive -- the next script is created and
+    its run issued while the device still renders the current one, its rendering kernels ordered behind the current
+    script's (bench.py's config-5 steps). Feedback voices (chunks, chains on their second stream, the mixer following the
+    chunks), FM voices (look-back across workgroups) and plain ones; every render equals the oracle's, whatever order the
+    host then collects them in."""
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
+    fm = [vb.Op("sin", freq=vb.Line(120.0 + 9 * k, goal=260.0, shape="exp"), time_ms=1200,
+                mods={POP_FMOD: [vb.Op("sin", freq=4.0 + k % 3, amp=12.0)]}) for k in range(24)]
+    prgs = [vb.config5(n=200, seconds=2), vb.build_program(fm), vb.config3(n=64, seconds=2), vb.config5(n=70, seconds=3)]
+    want = [oracle.oracle_render(p.ptr, RATE, False, chunk=150000) for p in prgs]
+    order = [0, 1, 2, 3, 0, 3, 1]
+    cur = sa.Batch([prgs[order[0]]], RATE)
+    pend = [(cur, order[0], [])]
+    outs = []
+    for nxt_i in order[1:] + [None]:
+        b, i, parts = pend[-1]
+        nb = None
+        if nxt_i is not None:
+            nb = sa.Batch([prgs[nxt_i]], RATE)
+            nb.order_after(b)
+        # the current script to its end, fetched (each run's PCM block holds one run), the next one issued behind it
+        while True:
+            pcm, more, lens = b.run(150000, stereo=False)
+            parts.append(pcm[0, :lens[0]].copy())
+            if not more[0]:
+                break
+        outs.append((i, np.concatenate(parts)))
+        b.close()
+        if nb is not None:
+            pend.append((nb, nxt_i, []))
+    for i, got in outs:
+        assert len(got) == len(want[i]) and (got == want[i]).all(), i
+    # both in flight: the first issued and not fetched, the second ordered behind it and fetched, then the first's next run
+    a, b = sa.Batch([prgs[0]], RATE), sa.Batch([prgs[3]], RATE)
+    a.run(50000, stereo=False, fetch=False)
+    b.order_after(a)
+    pcm, more, lens = b.run(132300, stereo=False)
+    assert lens[0] == 132300 and (pcm[0] == want[3][:132300]).all()
+    pcm, more, lens = a.run(38200, stereo=False)
+    assert lens[0] == 38200 and (pcm[0] == want[0][50000:88200]).all()
+    a.close(); b.close()
+
+
 @pytest.mark.timeout(180)
 def test_two_generators_at_once_with_running_sums(sa, oracle):
     """Two host threads, a generator each, rendering banks of FM voices at the same time: their single-pass

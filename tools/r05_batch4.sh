@@ -1,0 +1,5 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT"
+AB_ARGS="--steps 60" tools/ab_run.sh cur zmin
+python tests/tools/gpu_r_feedback_timing.py 2>&1 | tail -5
+python -m pytest tests/test_gpu_units.py -m gpu -x -q -k "r_oscillator or feedback or chain or ordered" 2>&1 | tail -3
