@@ -117,8 +117,9 @@ def _declare(L):
                                       C.POINTER(C.c_uint64), C.c_int]
     L.sauAmd_Batch_timing_ex.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
     L.sauAmd_Batch_set_timing.argtypes = [C.c_void_p, C.c_int]
-    L.sauAmd_Batch_order_after.restype = C.c_bool
-    L.sauAmd_Batch_order_after.argtypes = [C.c_void_p, C.c_void_p]
+    if hasattr(L, "sauAmd_Batch_order_after"):  # (SAU_AMD_LIB may name an older build: A/B timing against earlier rounds)
+        L.sauAmd_Batch_order_after.restype = C.c_bool
+        L.sauAmd_Batch_order_after.argtypes = [C.c_void_p, C.c_void_p]
     L.sauAmd_Batch_stream.restype = C.c_void_p
     L.sauAmd_Batch_stream.argtypes = [C.c_void_p]
     L.sauAmd_set_piluts.argtypes = [C.c_void_p]

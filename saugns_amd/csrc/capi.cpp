@@ -157,7 +157,8 @@ static bool generator_issue(sauGenerator *o, size_t big, size_t call_len, bool s
 	}
 	bool more = false;
 	size_t len = 0;
-	if (!o->batch.engine->snapshot(o->snap[k], k, err)) return false; /* (where a call of another size or layout goes back to) */
+	if (!sauengine::tune_env("SAU_AMD_NO_SNAPSHOT") && /* (debugging aid: a later change of the calls then fails) */
+	    !o->batch.engine->snapshot(o->snap[k], k, err)) return false; /* (where a call of another size or layout goes back to) */
 	/* PCM stays on the device; the copy queues behind the mixer */
 	if (!o->batch.engine->run(nullptr, frames, stereo, &more, &len, err)) return false;
 	if (len && !be->fetch_pcm_async(0, o->slot[k], (uint32_t)len, stereo, k, err)) return false;

@@ -1034,7 +1034,10 @@ public:
 							/* the mixer follows the final passes chunk by chunk (k_finish.h: premix_kernel): after the pass over the
 							 * row groups that end in chunk c, every frame below the chunk's end less one group's span is written
 							 * (a group has at most 64 x 6 frames in the builds that run here) */
-							const bool early_mix = early_mix_enabled_ && max_write && !(mix_few_enabled_ && max_rows <= 8 && seg.n_streams >= 8);
+							/* (not where a launch BEHIND the chunks still writes voice rows: the closed-form build with the loop tails of
+							 * `cub` R segments, below -- found by round 5's drop-in sweep, 2 programs of 3000; rows that repair_kernel
+							 * touches afterwards make the last launch mix everything again: fast_voice notes it in work_count[1]) */
+							const bool early_mix = early_mix_enabled_ && max_write && !fp.cub_ok && !(mix_few_enabled_ && max_rows <= 8 && seg.n_streams >= 8);
 							uint32_t mixed_blocks = 0;
 							if (early_mix) hipLaunchKernelGGL(premix_kernel, dim3((seg.n_voices + 63) / 64), dim3(64), 0, stream_, fp);
 							for (uint32_t c = 0; c < n_chunks; ++c) { /* the final pass follows the chains chunk by chunk */

@@ -935,6 +935,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 						rep[2 + 2 * at] = cg;
 						rep[3 + 2 * at] = held_rows;
 						atomicOr(&P.pass_flags[FAST_MAX_LEVELS], 1u);
+						atomicOr(&P.work_count[1], 2u); /* (frames the mixer may have taken early -- k_finish.h: premix_kernel -- change in the repair pass) */
 					}
 					noted = true;
 				}

@@ -124,7 +124,9 @@ __global__ void __launch_bounds__(64) premix_kernel(FastParams P) {
 	if (v >= P.n_voices) return;
 	const FastInfo fi = P.info[v];
 	const VoiceDesc vd = P.voices[v];
-	if (fi.total == 0 || fi.bail || fi.total < vd.run_len) { atomicOr(&P.work_count[1], 1u); return; }
+	/* (seq == 1: a voice one wave walks in order -- more than eight running sums, or look-back switched off -- is rendered whole in
+	 * the LAST chunk's launch (fast_voice: range_last), not chunk by chunk: found by round 5's drop-in sweep, 1 program of 3000) */
+	if (fi.total == 0 || fi.bail || fi.total < vd.run_len || fi.seq == 1) { atomicOr(&P.work_count[1], 1u); return; }
 	const uint32_t *ids = P.op_ids + vd.ops_ofs;
 	VoiceOut vo;
 	vo.pan_const = P.ops[ids[vd.carr_local]].line[L_PAN].v0; /* (a held line: finalize_kernel's advance leaves v0 alone) */

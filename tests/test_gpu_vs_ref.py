@@ -296,3 +296,52 @@ def test_runs_of_repeated_phases_at_a_groups_start(sa, oracle, tables):
                         os.environ[k] = v
             d = np.nonzero(got[:len(ref)] != ref[:len(got)])[0]
             assert len(got) == len(ref) and len(d) == 0, (env, len(d), d[:6].tolist())
+
+
+def test_the_mixer_takes_no_chunk_before_its_rows_are_written(sa, oracle, tables):
+    """Round 5's sweep through the drop-in generator: 2 programs of 3000 (3501608, 3502040) wrong from their second read-ahead
+    run on. Since round 5 the mixer follows a feedback segment's final passes chunk by chunk (k_finish.h: premix_kernel) -- and
+    two kinds of voice rows were not written chunk by chunk: a voice one wave walks in order (more than eight running sums) is
+    rendered whole in the LAST chunk's launch, and the closed-form build with the loop tails of `cub` R segments is launched
+    behind the chunks. Such a voice now makes the last launch mix the whole segment (premix_kernel) / switches the early
+    launches off (hip_backend.hip). What it took to see: a segment of several chunks -- the read-ahead's second run, four host
+    calls long -- of which the voices fill only the first frames. The programs as the sweep draws them, through the drop-in
+    generator (the read-ahead ramp on and off, one run per call) and the batch API, and the mixer after the last chunk
+    (SAU_AMD_NO_EARLY_MIX) beside the default; hand-made banks of both kinds as well."""
+    need_ref(oracle)
+    from saugns_amd.api import POP_FMOD, POP_PMOD, POPT_RASEG
+    with _RefSetup(sa, oracle, tables):
+        cases = [_sweep_program(3501608, False), _sweep_program(3502040, False)]
+        # (i) a feedback voice beside a voice with nine running sums (in order: one wave); (ii) ... beside a closed-form voice with
+        # an R oscillator of `cub` segments; short voices in a long run
+        nine = vb.Op("sin", freq=vb.Line(200.0, goal=260.0, shape="lin"), time_ms=160, amp=0.5)
+        cur = nine
+        for k in range(8):
+            m = vb.Op("tri", freq=vb.Line(3.0 + k, goal=5.0 + k, shape="lin"), amp=4.0)
+            cur.mods = {POP_FMOD: [m]}
+            cur = m
+        fbv = vb.Op("sin", freq=vb.Line(150.0, goal=300.0, shape="exp"), time_ms=160, pm_a=0.4, amp=0.5)
+        rcub = vb.Op("sin", freq=220.0, time_ms=160, amp=0.5,
+                     mods={POP_PMOD: [vb.Op(op_type=POPT_RASEG, ras=("cub", 0, 0), seed=77, freq=30.0, amp=0.6)]})
+        cases += [(vb.build_program([fbv, nine]), False, 6800, 44100), (vb.build_program([fbv, rcub]), True, 5600, 44100)]
+        for i, (prg, stereo, call, rate) in enumerate(cases):
+            ref = oracle.ref_render(prg.ptr, rate, stereo, chunk=call)
+            for env in ({}, {"SAU_AMD_NO_EARLY_MIX": "1"}, {"SAU_AMD_READAHEAD_RAMP": "0"}, {"SAU_AMD_READAHEAD": "0"}):
+                old = {k: os.environ.get(k) for k in env}
+                os.environ.update(env)
+                try:
+                    g = sa.Generator(prg, rate)
+                    got = g.render(stereo=stereo, chunk=call)
+                    g.close()
+                finally:
+                    for k, v in old.items():
+                        if v is None:
+                            os.environ.pop(k, None)
+                        else:
+                            os.environ[k] = v
+                d = np.nonzero(got[:len(ref)] != ref[:len(got)])[0]
+                assert len(got) == len(ref) and len(d) == 0, (i, env, len(d), d[:6].tolist())
+            b = sa.Batch([prg], rate)
+            b.set_call_len(call)
+            got = b.render(stereo=stereo, chunk=call * 4)[0]
+            assert len(got) == len(ref) and (got == ref).all(), (i, "batch")

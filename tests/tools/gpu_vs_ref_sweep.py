@@ -24,9 +24,10 @@ count = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 tall = len(sys.argv) > 3 and sys.argv[3] == "tall"  # operator trees up to 256 levels deep, the list kind drawn per level (wide plans)
 extreme = len(sys.argv) > 3 and sys.argv[3] == "extreme"  # the same graphs with parameters pushed to extremes
 corpus = len(sys.argv) > 3 and sys.argv[3] == "corpus"  # the reference's 95 scripts (program images), `count` passes over them
-dropin = corpus or len(sys.argv) > 3 and sys.argv[3] == "dropin"  # through sau_create_Generator / sauGenerator_run (read-ahead runs) instead of the batch API
+varied = len(sys.argv) > 3 and sys.argv[3] == "varied"  # round 5: the host changes the size and the channel layout of its calls as it goes (the drop-in generator's read-ahead is taken back and re-issued: capi.cpp generator_rewind)
+dropin = corpus or varied or len(sys.argv) > 3 and sys.argv[3] == "dropin"  # through sau_create_Generator / sauGenerator_run (read-ahead runs) instead of the batch API
 S = {"programs": 0, "identical": 0, "samples": 0, "samples_differing": 0, "max_abs_diff": 0, "differing": [],
-     "first_seed": first, "loop_tails": True, "api": "drop-in generator" if dropin else "batch", "programs_are": "the 95 corpus scripts" if corpus else "random graphs, extreme parameters" if extreme else "trees up to 256 levels deep" if tall else "random graphs"}
+     "first_seed": first, "loop_tails": True, "api": "drop-in generator, call sizes and channel layouts changing in mid-stream" if varied else "drop-in generator" if dropin else "batch", "programs_are": "the 95 corpus scripts" if corpus else "random graphs, extreme parameters" if extreme else "trees up to 256 levels deep" if tall else "random graphs"}
 t0 = time.time()
 _push = T._push_extremes
 _tall = T._tall_tree
@@ -68,9 +69,41 @@ def cases():
         # time-parallel build and showed at such call sizes only)
         call = int(rng.integers(1, 12)) if seed % 5 == 4 else int(rng.integers(300, 12000))
         yield seed, prg, bool(seed & 2), call, (rate_x or (44100 if seed % 3 else int(rng.choice([8000, 22050, 48000, 96000]))))
+def render_calls(create, run, destroy, prg, rate, calls):
+    import ctypes as C
+    g = create(prg, rate)
+    n, out, k = C.c_size_t(), [], 0
+    while True:
+        size, st = calls[min(k, len(calls) - 1)]
+        k += 1
+        buf = np.zeros(size * (2 if st else 1), np.int16)
+        more = run(g, buf.ctypes.data, size, st, C.byref(n))
+        out.append(buf[: n.value * (2 if st else 1)].copy())
+        if not more:
+            break
+    destroy(g)
+    return np.concatenate(out)
+
+
 for seed, prg, stereo, chunk, rate in cases():
-    ref = po.ref_render(prg.ptr, rate, stereo, chunk=chunk)
-    if dropin:
+    if varied:
+        r4 = np.random.default_rng(555000 + (seed if not isinstance(seed, tuple) else seed[0]))
+        calls, size, st = [], chunk, stereo
+        for _ in range(int(r4.integers(3, 9))):
+            calls += [(size, st)] * int(r4.integers(1, 7))
+            what = int(r4.integers(3))
+            if what != 1:
+                size = int([r4.integers(1, 30), r4.integers(30, 3000), r4.integers(3000, 40000)][int(r4.integers(3))])
+            if what != 0:
+                st = not st
+        L, Rl = sa.lib(), po.ref()
+        ref = render_calls(Rl.sau_create_Generator, Rl.sauGenerator_run, Rl.sau_destroy_Generator, prg.ptr, rate, calls)
+        gpu = render_calls(L.sau_create_Generator, L.sauGenerator_run, L.sau_destroy_Generator, prg.ptr, rate, calls)
+    else:
+        ref = po.ref_render(prg.ptr, rate, stereo, chunk=chunk)
+    if varied:
+        pass
+    elif dropin:
         g = sa.Generator(prg, rate)
         gpu = g.render(stereo=stereo, chunk=chunk)
         g.close()
@@ -92,6 +125,6 @@ for seed, prg, stereo, chunk, rate in cases():
         print("seed", seed, "DIFFERS", S["differing"][-1], flush=True)
 S["seconds"] = round(time.time() - t0, 1)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(S, open(os.path.join(ROOT, "gpurun_out", "gpu_vs_ref_sweep%s.json" % ("_corpus" if corpus else "_tall" if tall else "_extreme" if extreme else "_dropin" if dropin else "")), "w"), indent=1)
+json.dump(S, open(os.path.join(ROOT, "gpurun_out", "gpu_vs_ref_sweep%s.json" % ("_corpus" if corpus else "_tall" if tall else "_extreme" if extreme else "_varied" if varied else "_dropin" if dropin else "")) if not os.environ.get("SWEEP_OUT") else os.environ["SWEEP_OUT"], "w"), indent=1)
 print(json.dumps({k: v for k, v in S.items() if k != "differing"}))
 sys.exit(0 if S["identical"] == S["programs"] else 1)
