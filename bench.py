@@ -778,7 +778,7 @@ def run_config5(args, R, sa, tabs, steps=None, warmup=None):
     # same K with script k + 1 created and issued while script k renders, ordered behind it (sauAmd_Batch_order_after):
     # it hides the host work of a script's start (0.6 ms of device idle time per step) and measured no faster -- the
     # recurrence itself runs 2 % slower on a device that never idles (profiles/r05_headline_ab.json)
-    dt_ordered, _ = timed(True) if not args.c5_serial else (None, None)
+    dt_ordered, _ = timed(True) if args.c5_ordered else (None, None)
     dt, tm = timed(False)
     mine = [frames * steps, int(np.asarray(pcm, dtype=np.int64).sum() & 0x7FFFFFFF)]
     tally = R.sum(mine)
@@ -882,7 +882,8 @@ def main():
     ap.add_argument("--c4-frames", type=int, default=0, help="config4 (tests): render only the first frames of each script")
     ap.add_argument("--sustain", type=int, default=1000, help="config3: steps of the sustained run after the timed region "
                     "(reported under `sustained`, never `value`; 0: none)")
-    ap.add_argument("--c5-serial", action="store_true", help="config5: skip the ordered-two-generators measurement beside `value`")
+    ap.add_argument("--c5-serial", action="store_true", help="(accepted for old command lines: the default)")
+    ap.add_argument("--c5-ordered", action="store_true", help="config5: also measure the steps with script k + 1 issued while script k renders, ordered behind it")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--gather-pcm", action="store_true",
                     help="--workload config4: afterwards send every rank's finished PCM to rank 0 (SURVEY 8e, optional) and check it there")

@@ -151,7 +151,11 @@ bool Engine::handle_event(Stream &st, const EventNode &e, std::vector<OpUpdate> 
 		memset(&u, 0, sizeof u);
 		u.op = gid;
 		u.params = od->params;
-		u.type = od->type;
+		/* (an operator is of the type it was made with: the reference's update_op switches on the datum's type, generator.c:
+		 * 283-343, which for a program whose later data name another type than the first -- no parser emits one; the fuzz of
+		 * program images does -- reinterprets the node's union; here the later datum is applied as one of the operator's own type,
+		 * so that the wave / noise / line id in its record stays one of that type's: found under ASan in round 5) */
+		u.type = m.inited ? m.type : od->type;
 		u.first = !m.inited;
 		u.coeff = (float)(0x1p32 / (double)srate_);
 		if (!m.inited) {
@@ -161,9 +165,9 @@ bool Engine::handle_event(Stream &st, const EventNode &e, std::vector<OpUpdate> 
 			for (int k = 0; k < SAU_POP_NAMED; ++k) m.mods[k] = &g_no_ids;
 			m.wave = SAU_WAVE_N_sin;
 		}
-		const bool is_osc = (od->type == SAU_POPT_N_wave || od->type == SAU_POPT_N_raseg);
+		const bool is_osc = (u.type == SAU_POPT_N_wave || u.type == SAU_POPT_N_raseg);
 		u.mode_main = od->mode.main;
-		if (od->type == SAU_POPT_N_raseg) {
+		if (u.type == SAU_POPT_N_raseg) {
 			u.ras_line = od->mode.ras.line;
 			u.ras_flags = od->mode.ras.flags;
 			u.ras_func = od->mode.ras.func;
@@ -171,9 +175,9 @@ bool Engine::handle_event(Stream &st, const EventNode &e, std::vector<OpUpdate> 
 			u.ras_alpha = od->mode.ras.alpha;
 			if (od->mode.ras.line == SAU_LINE_N_cub) m.ras_cub_seen = true;
 		}
-		if (od->type == SAU_POPT_N_wave && (od->params & SAU_POPP_MODE))
+		if (u.type == SAU_POPT_N_wave && (od->params & SAU_POPP_MODE))
 			m.wave = od->mode.main < SAU_WAVE_NAMED ? od->mode.main : 0;
-		if (od->type == SAU_POPT_N_noise && (od->params & SAU_POPP_MODE))
+		if (u.type == SAU_POPT_N_noise && (od->params & SAU_POPP_MODE))
 			m.wave = od->mode.main;
 		u.phase = od->phase;
 		u.seed = od->seed;

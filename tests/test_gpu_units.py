@@ -1087,17 +1087,20 @@ def test_two_generators_at_once_with_running_sums(sa, oracle):
 
 
 @pytest.mark.gpu
-def test_feedback_voices_render_when_the_chain_rows_cannot_be_allocated(tmp_path):
+@pytest.mark.parametrize("how", ["1", "real"])
+def test_feedback_voices_render_when_the_chain_rows_cannot_be_allocated(tmp_path, how):
     """the chains' rows are the one large allocation that depends on how the engine cut the segment. When the device
     cannot give them (SAU_AMD_CHAIN_ROWS_FAIL makes an engine's first such allocation fail) the segment's feedback voices take
-    the block loop, the process's budget is gone and later segments are cut at 131072 frames -- the render stays exact. In a
-    process of its own: the lowered budget is process-wide."""
+    the block loop, the process's budget is halved and later segments are cut shorter -- the render stays exact. In a
+    process of its own: the lowered budget is process-wide. "real" (ADVICE r04): the allocation is asked of hipMalloc and refused
+    by it (64 TiB) -- the failed call's error stays the thread's last one on this runtime, and the launches behind it check
+    hipGetLastError(): pool_alloc consumes it (and gives the pool's idle blocks back before it gives up)."""
     import subprocess, sys
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = f"""
 import os, sys
 sys.path.insert(0, {ROOT!r}); sys.path.insert(0, os.path.join({ROOT!r}, "tests"))
-os.environ["SAU_AMD_TUNE"] = "1"; os.environ["SAU_AMD_CHAIN_ROWS_FAIL"] = "1"
+os.environ["SAU_AMD_TUNE"] = "1"; os.environ["SAU_AMD_CHAIN_ROWS_FAIL"] = {how!r}
 import numpy as np
 import saugns_amd as sa
 from saugns_amd import voicebank as vb
