@@ -384,6 +384,11 @@ public:
 		if (const char *lr = tune_env("SAU_AMD_LEAN_ROWS")) lean_rows_ = (uint32_t)atoi(lr);
 		mix_few_enabled_ = tune_env("SAU_AMD_NO_MIX_FEW") == nullptr;
 		early_mix_enabled_ = tune_env("SAU_AMD_NO_EARLY_MIX") == nullptr;
+		inmix_enabled_ = tune_env("SAU_AMD_NO_INMIX") == nullptr;
+		xcd_queues_ = tune_env("SAU_AMD_NO_XCD_QUEUES") == nullptr;
+		inmix_report_ = tune_env("SAU_AMD_INMIX_REPORT") != nullptr;
+		if (const char *ia = tune_env("SAU_AMD_INMIX_AT")) inmix_at_ = (uint32_t)atoi(ia) & 15u;
+		if (const char *mv = tune_env("SAU_AMD_INMIX_MIN_VOICES")) inmix_min_voices_ = (uint32_t)atoi(mv);
 		short_last_chunk_ = tune_env("SAU_AMD_NO_SHORT_LAST_CHUNK") == nullptr;
 		lean_enabled_ = tune_env("SAU_AMD_NO_LEAN") == nullptr; /* chains' passes in a build without the several-pass sums */
 		dyn_enabled_ = tune_env("SAU_AMD_NO_DYN") == nullptr; /* closed-form launches deal tasks out through a counter */
@@ -495,6 +500,7 @@ public:
 		if (!seg.n_voices) return true;
 		++acc_launches_; /* segments rendered */
 		early_mixed_blocks_ = 0;
+		inmix_live_ = false;
 		const size_t tab_bytes = (size_t)WAVE_LEN * (sizeof(HerpC23) + sizeof(HerpC01));
 		/* (the time-parallel kernels keep their LDS copy of a table in another form: FAST_TAB_BYTES, k_fast_types.h) */
 		const size_t ftab_bytes = FAST_TAB_BYTES;
@@ -647,6 +653,10 @@ public:
 			fp.row_stride = row_stride_; fp.n_voices = seg.n_voices; fp.n_fast = n_fast;
 			fp.seq_enable = seq_ok ? 1u : 0u; fp.ids_full_ofs = n_steps_total_;
 			fp.scan = nullptr; fp.scan_groups = 0; fp.mode = 0;
+			if (xcd_queues_) { /* the closed-form launch's task queues, one per XCD (k_fast_types.h) */
+				if (!inmix_ctl_.ensure(INMIX_WORDS, err)) return false;
+				fp.inmix = inmix_ctl_.p;
+			}
 			if (seq_ok && two_pass_enabled_) {
 				/* row groups per voice at most: rows hold at least 32 new frames (H <= 32) */
 				fp.scan_groups = seg.len / (32 * FTM) + 2;
@@ -1067,8 +1077,23 @@ public:
 				} else {
 					/* closed-form voices only: tasks of about eight row groups, dealt out by a counter */
 					if (main_build == 0) set_tasks(fp, groups, fgrid);
+					/* tasks dealt out by the counter: one queue per XCD, chunk-major (k_fast_types.h) -- 1.80 -> 1.76 ms per config-3
+					 * launch against the one counter in voice order */
+					if (fp.inmix && main_build == 0 && !fp.dyn_static && fp.dyn_chunks >= 16 && !fp.cub_ok) {
+						fp.inmix_flags = 64u; /* (analyze_kernel has cleared the queues) */
+						/* ... and a bank of voices mixed into one stream: the launch mixes its own rows, chunk by chunk behind the rendering;
+						 * premix_kernel has the last word. Config 3: 2.056 -> 1.995 ms per step (the launch 1.74 -> 1.87 ms, the mixer
+						 * 0.26 -> 0.07 ms) */
+						if (inmix_enabled_ && seg.n_streams == 1 && max_write && seg.n_voices >= inmix_min_voices_ && row_stride_ < (1u << 24)) {
+							fp.inmix_stream = S.mstreams.p;
+							fp.inmix_flags = 64u | 32u | (seg.stereo ? 1u : 0u) | (seg.swap_bytes ? 2u : 0u) | (tune_env("SAU_AMD_INMIX_DRY") ? 4u : 0u) | ((inmix_at_ & 15u) << 8);
+							fp.inmix_pcm_offset = seg.pcm_offset;
+							hipLaunchKernelGGL(premix_kernel, dim3((seg.n_voices + 63) / 64), dim3(64), 0, stream_, fp);
+							inmix_live_ = true;
+						}
+					}
 					launch_fast(0);
-					fp.dyn_chunks = 0;
+					fp.dyn_chunks = 0; fp.inmix_flags = 0;
 				}
 				{ /* closed-form voices with the loop tails of `cub` R segments (FastInfo.cub): the build with that code,
 				   * FAST_CUB_ROWS rows per pass, fixed strides over the same voices as the closed-form launch; returns at
@@ -1173,6 +1198,8 @@ public:
 			/* (frames an early launch has mixed are skipped when the device says those results stand: k_finish.h) */
 			mp.early_blocks = early_mixed_blocks_;
 			early_mixed_blocks_ = 0;
+			mp.inmix = inmix_live_ ? inmix_ctl_.p : nullptr; /* (the closed-form launch has mixed tiles itself: mix_kernel takes what is left) */
+			inmix_live_ = false;
 			/* (on the generator's one stream, behind the segment's kernels. Round 3 built the mixer on a stream of its own beside the
 			 * next segment's kernels -- ordinary grid or persistent on a few CUs, everything it reads and writes double-buffered --
 			 * and measured it no faster in any form, profiles/r03_headline_ab.json; that code is gone since round 4.) */
@@ -1186,6 +1213,22 @@ public:
 				hipLaunchKernelGGL(mix_kernel, dim3((max_write + 255) / 256, seg.n_streams), dim3(256), 0, ms, mp);
 			HIP_OK(hipGetLastError());
 			if (tm) (void)hipEventRecord(tm->b, ms);
+			if (mp.inmix && inmix_report_) { /* (tests: what the launch mixed itself) */
+				std::vector<uint32_t> h(INMIX_WORDS);
+				uint32_t g[2] = {0, 0};
+				(void)hipStreamSynchronize(ms);
+				(void)hipMemcpy(h.data(), mp.inmix, INMIX_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost);
+				(void)hipMemcpy(g, work_count_.p, sizeof g, hipMemcpyDeviceToHost);
+				const uint32_t nch = h[INMIX_NCH] < INMIX_MAX_CHUNKS ? h[INMIX_NCH] : INMIX_MAX_CHUNKS, tpc = h[INMIX_TPC];
+				uint32_t tiles = 0, whole = 0;
+				for (uint32_t k = 0; k < nch; ++k) {
+					uint32_t c = 0;
+					for (uint32_t j = 0; j < tpc && j < INMIX_MAX_TPC; ++j) c += (h[INMIX_CHUNK + INMIX_LINE * k + INMIX_BITS + (j >> 5)] >> (j & 31u)) & 1u;
+					tiles += c; whole += c == tpc ? 1u : 0u;
+				}
+				fprintf(stderr, "[sau-amd] inmix: voices %u frames %u chunks %u x %u frames, tiles %u of %u, chunks mixed whole %u, guard %u %u\n",
+						seg.n_voices, max_write, nch, h[INMIX_CF], tiles, nch * tpc, whole, g[0], g[1]);
+			}
 		}
 		return true;
 	}
@@ -1196,7 +1239,7 @@ public:
 		mp.row_stride = row_stride_; mp.pcm_offset = seg.pcm_offset;
 		mp.stereo = seg.stereo ? 1 : 0;
 		mp.swap_bytes = seg.swap_bytes ? 1 : 0;
-		mp.blk_lo = 0; mp.blk_hi = 0; mp.early_blocks = 0; mp.guard = work_count_.p;
+		mp.blk_lo = 0; mp.blk_hi = 0; mp.early_blocks = 0; mp.guard = work_count_.p; mp.inmix = nullptr;
 		return mp;
 	}
 
@@ -1472,6 +1515,13 @@ private:
 	hipEvent_t after_ev_ = nullptr; /* order_after() */
 	bool after_pending_ = false;
 	uint32_t early_mixed_blocks_ = 0; /* 256-frame blocks of this segment that early launches have mixed */
+	bool xcd_queues_ = true;          /* a closed-form launch's tasks come from one queue per XCD, chunk-major (SAU_AMD_NO_XCD_QUEUES: the one counter, voice-major) */
+	bool inmix_enabled_ = true;       /* a many-voice stream's closed-form launch mixes its own rows (SAU_AMD_NO_INMIX: the mixer alone) */
+	uint32_t inmix_min_voices_ = 64;  /* ... from that many voices on (SAU_AMD_INMIX_MIN_VOICES) */
+	bool inmix_live_ = false;         /* this segment's launch did: mix_kernel looks at the control words */
+	uint32_t inmix_at_ = 12;           /* which of a chunk's tasks mix the chunk before: from this many sixteenths into it (SAU_AMD_INMIX_AT) */
+	bool inmix_report_ = false;       /* SAU_AMD_INMIX_REPORT: a line on stderr per such segment (tests) */
+	DevBuf<uint32_t> inmix_ctl_;
 	bool wide_tabs_ = true;
 	uint32_t more_rows_ = 12;
 	uint32_t lean_rows_ = 6;    /* SAU_AMD_LEAN_ROWS: rows per pass of fast_kernel<T, 3> at most (6, 5 or 4) */

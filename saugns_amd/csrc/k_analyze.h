@@ -67,6 +67,8 @@ __device__ __forceinline__ bool op_has_fpm(const Step *plan, uint32_t n, uint32_
 
 __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 	const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; /* (the host picks the voices per wave) */
+	if (v == 0 && P.inmix) /* the XCDs' task queues of the closed-form launch (k_fast_types.h) */
+		for (uint32_t x = 0; x < 8; ++x) P.inmix[INMIX_QUEUE + INMIX_LINE * x] = 0;
 	if (v == 0) { P.work_count[0] = 0; P.work_count[1] = 0; } /* finalize_kernel (a later launch) builds the block loop's work list; [1]: premix_kernel's verdict */
 	if (v >= P.n_voices) return;
 	const VoiceDesc vd = P.voices[v];

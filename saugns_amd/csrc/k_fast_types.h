@@ -90,6 +90,46 @@ constexpr uint32_t FT_CHAIN_EARLY = 1u << 20; /* ... whose samples are in its ro
 constexpr uint32_t FT_CUBTAIL = 1u << 19;   /* ... an R oscillator with `cub` segments and the reference's loop tails on: FastStep.phase0 =
                                              * frames until it, an ancestor or the voice stops (TailCtx.rem) */
 constexpr uint32_t CHAIN_MARK = 0xC4A10001u; /* DevOp.ras_level of a W operator: chain_kernel staged its state */
+
+struct MixStream {
+	uint32_t first_row, n_rows;
+	float amp_scale;
+	uint32_t write_len;
+	int16_t *pcm; /* stream's PCM row */
+};
+/* The mixer inside the closed-form launch (round 5). A bank of many voices mixed into one stream: the mixer reads every voice
+ * row once more -- 1.8 GB, 0.26 ms at 6.9 TB/s, an eighth of a BASELINE config-3 step -- while the launch that wrote them is
+ * bound by vector issue and leaves HBM idle. Mixed by the launch itself, the reads hide under its arithmetic. Voice order
+ * is the reference's f32 sum order (generator.c:749-825) and cannot be split, so a tile of INMIX_TILE frames is mixed by one
+ * wave over all rows, as mix_kernel does it, once every voice has written those frames:
+ *  - the launch's tasks (voice, run of row groups = chunk) are dealt out chunk-major instead of voice-major, one queue per
+ *    XCD: chunk k belongs to XCD k mod 8, whose waves render it for every voice and mix its tiles. Producer and consumer
+ *    share an L2, so the hand-off needs no L2 write-back (MI355X_MICROARCH.md, inter-workgroup visibility): the storing
+ *    wave waits for its stores (vmcnt) and adds to the chunk's counter; the mixing wave reads the counter, invalidates its
+ *    L1 (agent-scope acquire) and loads;
+ *  - who mixes what is fixed, not claimed: some of a chunk's tasks each mix, when their voice is rendered, a tile of the XCD's
+ *    chunk before (eight chunks back), which the queue has dealt out whole by then and a task's length ago; if its counter
+ *    is not full after all, the tile is left alone. A finished tile sets its bit. (Tiles taken from a shared counter, first version:
+ *    three dependent round trips per task to find one -- the launch's waves stall for them, and four waves per SIMD
+ *    hide nothing: 1.80 -> 1.95 ms per launch for 0.18 ms less mixing.)
+ *  - a wave whose XCD has run out of tasks takes another XCD's (nobody idles at the end); such a task counts for nothing
+ *    and mixes nothing, so a chunk it touched stays incomplete;
+ *  - mix_kernel runs after the launch as before and mixes every frame whose tile has no bit -- each XCD's last chunk at
+ *    least; all of them when premix_kernel or the pass itself says the early results do not stand (k_finish.h).
+ * premix_kernel decides (work_count[1]): every voice on this path to its end, same lead-in (so the chunks' frame ranges
+ * are the same for all), constant pan, no shorter than the stream. Control words (FastParams.inmix): */
+constexpr uint32_t INMIX_TILE = 256;        /* frames per tile: four per lane, 16-byte row loads */
+/* (words that many waves add to or poll lie on 128-byte lines of their own: an agent-scope atomic takes its line for about
+ * 12 ns chip-wide, and with the queues' counters and the constants all on one line the launch took 5.2 ms for 2.05) */
+constexpr uint32_t INMIX_LINE = 32;         /* words per line */
+constexpr uint32_t INMIX_CF = 0;            /* [0]: frames per chunk, [1]: tiles per chunk, [2]: chunks (premix_kernel; read-only in the launch) */
+constexpr uint32_t INMIX_TPC = 1, INMIX_NCH = 2;
+constexpr uint32_t INMIX_QUEUE = 1 * INMIX_LINE; /* + INMIX_LINE x: XCD x's task counter */
+constexpr uint32_t INMIX_CHUNK = 9 * INMIX_LINE; /* + INMIX_LINE k: chunk k's line -- [0] own-XCD tasks that have stored their rows, [8 + j / 32] bit j % 32: tile j is mixed */
+constexpr uint32_t INMIX_DONE = 0, INMIX_BITS = 8;
+constexpr uint32_t INMIX_MAX_TPC = 256;     /* tiles per chunk at most (eight words of bits) */
+constexpr uint32_t INMIX_MAX_CHUNKS = 2039;
+constexpr uint32_t INMIX_WORDS = INMIX_CHUNK + INMIX_LINE * INMIX_MAX_CHUNKS; /* 256 KiB */
 struct FastParams {
 	const VoiceDesc *voices;
 	const Step *steps;
@@ -183,4 +223,10 @@ struct FastParams {
 	int8_t tab_of_wave[12];
 	uint8_t wave_of_tab[12];
 	WaveConst wc[12];
+	/* (at the end: the 12-row closed-form build fits its 128 vector registers exactly, and with these 24 bytes in front of the
+	 * tables above -- every offset behind them moved -- it spilled 88 of them, with not a line of the mixing code compiled in) */
+	uint32_t *inmix;      /* the mixer inside the closed-form launch: INMIX_WORDS control words, or NULL */
+	const MixStream *inmix_stream; /* ... the one stream */
+	uint32_t inmix_flags, inmix_pcm_offset; /* 64: this launch takes its tasks from the XCDs' queues; 32: ... and mixes (premix_kernel has run); 1: stereo PCM,
+	                                         * 2: byte-swapped; 4: timing aid; bits 8-11: which tasks mix (sixteenths into a chunk). MixParams.pcm_offset */
 };

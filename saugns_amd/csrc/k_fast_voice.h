@@ -947,6 +947,186 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 
 }
 
+/* The mixer inside the closed-form launch (k_fast_types.h): tile j of chunk k, four frames per lane, every row of the stream
+ * in voice order -- mix_kernel's sums (k_finish.h: mix_body, the tile whose rows all cover the segment with a constant pan;
+ * generator.c:749-825) and its PCM. Two batches of INMIX_AHEAD 16-byte row loads in flight per lane: what a wave keeps in
+ * flight is its bandwidth, and while it waits the SIMD's other three waves do not make up for it. */
+#ifndef INMIX_AHEAD_N
+#define INMIX_AHEAD_N 8 /* (a power of two, 64 at most) */
+#endif
+constexpr int INMIX_AHEAD = INMIX_AHEAD_N;
+__device__ __forceinline__ uint32_t xcc_id() {
+	uint32_t x;
+	asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+	return x & 7u;
+}
+/* (what the functions below need of FastParams) */
+struct InmixArgs {
+	uint32_t *ctl;
+	const float *vout;
+	const VoiceOut *vinfo;
+	const MixStream *stream;
+	uint32_t row_stride, flags, pcm_offset, nvc;
+};
+typedef float __attribute__((ext_vector_type(4))) inmix_f4;
+typedef uint32_t __attribute__((ext_vector_type(4))) inmix_u4;
+__device__ __forceinline__ void inmix_tile(const InmixArgs &A, const uint32_t k, const uint32_t j, const uint32_t cf, const int l) {
+	const MixStream ms = *A.stream;
+	const uint32_t i0 = k * cf + j * INMIX_TILE + 4u * (uint32_t)l; /* this lane's first frame */
+	const uint32_t end = min((k + 1) * cf, ms.write_len);
+	/* (a row's address: a buffer descriptor at the batch's first row + the row's offset in a scalar register + the lane's offset in
+	 * ONE vector register for all the loads in flight. As plain pointers the compiler made per-lane 64-bit addresses of them, two
+	 * registers per load. The host sees to it that INMIX_AHEAD rows span less than 4 GiB. Lanes past the chunk's end load its
+	 * first frames and store nothing; a lane across the end loads up to three frames of the row beyond it -- row_stride is a
+	 * multiple of 64 frames and no smaller than the stream -- and stores only its own.) */
+	const uint32_t off = (i0 < end ? i0 : k * cf) * 4u;
+	const float *rows = A.vout + (size_t)ms.first_row * A.row_stride;
+	const VoiceOut *vo = A.vinfo + ms.first_row;
+	/* (-DINMIX_DBG_SAME_ROW, -DINMIX_DBG_NOLOAD: timing aids -- every row the first one; no row loads at all. Wrong PCM.) */
+#ifdef INMIX_DBG_SAME_ROW
+	const uint32_t rbytes = 0u;
+#else
+	const uint32_t rbytes = A.row_stride * 4u;
+#endif
+	float L[4] = {0.f, 0.f, 0.f, 0.f}, R[4] = {0.f, 0.f, 0.f, 0.f};
+	auto load = [&](inmix_f4 *sv, float &panv, uint32_t at) {
+#ifdef INMIX_DBG_NOLOAD
+#pragma unroll
+		for (int u = 0; u < INMIX_AHEAD; ++u) { sv[u] = inmix_f4{(float)at, 1.f, 2.f, (float)l}; asm volatile("" : "+v"(sv[u])); }
+		panv = 0.5f;
+		return;
+#endif
+#ifdef INMIX_DBG_SAME_ROW
+		const auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)rows, 0, 0xffffffffu, 0x00020000);
+#else
+		const auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)(rows + (size_t)at * A.row_stride), 0, 0xffffffffu, 0x00020000);
+#endif
+#pragma unroll
+		for (int u = 0; u < INMIX_AHEAD; ++u)
+#ifndef FK_TEMPORAL_ROWS
+			sv[u] = __builtin_bit_cast(inmix_f4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, (int)((uint32_t)u * rbytes), 2 /* nt */));
+#else
+			sv[u] = __builtin_bit_cast(inmix_f4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, (int)((uint32_t)u * rbytes), 0));
+#endif
+		/* (the rows' pans: one load -- lane u fetches row at + u's -- handed round by v_readlane; as loads of their own, one per
+		 * row, the compiler made them vector loads and waited for each before the next) */
+		panv = vo[at + ((uint32_t)l & (uint32_t)(INMIX_AHEAD - 1))].pan_const;
+	};
+	auto add = [&](const inmix_f4 *sv, const float panv) {
+#pragma unroll
+		for (int u = 0; u < INMIX_AHEAD; ++u) {
+			const float pan = bits_f((uint32_t)__builtin_amdgcn_readlane((int)f_bits(panv), u));
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				const float v = sv[u][q] * ms.amp_scale;
+				const float s_r = v * pan;
+				L[q] = (L[q] + v) - s_r;
+				R[q] = (R[q] + v) + s_r;
+			}
+		}
+	};
+	inmix_f4 sa[INMIX_AHEAD], sb[INMIX_AHEAD];
+	float pa = 0.f, pb = 0.f;
+	uint32_t r = 0;
+	if (r + INMIX_AHEAD <= ms.n_rows) load(sa, pa, r);
+	while (r + INMIX_AHEAD <= ms.n_rows) {
+		const bool more_b = r + 2 * INMIX_AHEAD <= ms.n_rows;
+		if (more_b) load(sb, pb, r + INMIX_AHEAD);
+		add(sa, pa);
+		r += INMIX_AHEAD;
+		if (!more_b) break;
+		if (r + 2 * INMIX_AHEAD <= ms.n_rows) load(sa, pa, r + INMIX_AHEAD);
+		add(sb, pb);
+		r += INMIX_AHEAD;
+	}
+	for (; r < ms.n_rows; ++r) {
+		const auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)(rows + (size_t)r * A.row_stride), 0, 0xffffffffu, 0x00020000);
+		const inmix_f4 s1 = __builtin_bit_cast(inmix_f4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
+		const float pan = vo[r].pan_const;
+#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+			const float v = s1[q] * ms.amp_scale;
+			const float s_r = v * pan;
+			L[q] = (L[q] + v) - s_r;
+			R[q] = (R[q] + v) + s_r;
+		}
+	}
+	const bool swap = (A.flags & 2u) != 0;
+#pragma unroll
+	for (int q = 0; q < 4; ++q) {
+		const uint32_t i = i0 + (uint32_t)q;
+		if (i >= end) continue;
+		if (A.flags & 1u) {
+			int16_t *d = ms.pcm + 2 * (size_t)(A.pcm_offset + i);
+			const int16_t l16 = pcm16(L[q]), r16 = pcm16(R[q]);
+			d[0] = swap ? pcm_swap(l16) : l16;
+			d[1] = swap ? pcm_swap(r16) : r16;
+		} else {
+			const int16_t m16 = pcm16((L[q] + R[q]) * 0.5f);
+			ms.pcm[A.pcm_offset + i] = swap ? pcm_swap(m16) : m16;
+		}
+	}
+}
+/* (Inlined into fast_kernel's task loop, where the 12-row build fits its 128 vector registers exactly. Read from the kernel's
+ * argument block behind a barrier the compiler cannot see through: taken from fast_kernel's copy of FastParams, these values
+ * -- and what the tile derives from them, its row offsets -- were computed ahead of the task loop and kept across fast_voice:
+ * 207 spilled scalars where 192 fit into three vector registers, and the fourth cost that build spilled vector registers in
+ * its hot loops; as real calls the functions cost it 88 of them.) */
+__device__ __forceinline__ InmixArgs inmix_args(const uint32_t nvc) {
+	typedef const __attribute__((address_space(4))) FastParams *KArg;
+	KArg Pk = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
+	asm volatile("" : "+s"(Pk));
+	InmixArgs A;
+	A.ctl = Pk->inmix; A.vout = Pk->vout; A.vinfo = Pk->vinfo; A.stream = Pk->inmix_stream;
+	A.row_stride = Pk->row_stride; A.flags = Pk->inmix_flags; A.pcm_offset = Pk->inmix_pcm_offset; A.nvc = nvc;
+	return A;
+}
+__device__ __forceinline__ uint32_t inmix_ctl(const InmixArgs &A, uint32_t i) {
+	return uni(__hip_atomic_load(&A.ctl[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+/* the next task: from the XCD's own queue -- its chunks xcd, xcd + 8, ..., each for every voice -- then from the others'.
+ * -> chunk << 32 | voice index, or ~0: none left */
+__device__ __forceinline__ unsigned long long inmix_next(const InmixArgs &A, const uint32_t nch, int l) {
+	const uint32_t xcd = xcc_id();
+	for (uint32_t s_ = 0; s_ < 8; ++s_) {
+		const uint32_t x = (xcd + s_) & 7u;
+		const uint32_t mine = nch > x ? (nch - x + 7) / 8 : 0u; /* chunks of XCD x */
+		/* (another XCD's queue: a look first, so that waves with nothing left do not keep adding to it) */
+		if (s_ && inmix_ctl(A, INMIX_QUEUE + INMIX_LINE * x) / A.nvc >= mine) continue;
+		uint32_t q = 0;
+		if (l == 0) q = __hip_atomic_fetch_add(&A.ctl[INMIX_QUEUE + INMIX_LINE * x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		q = uni(q);
+		if (q / A.nvc < mine) return ((unsigned long long)(x + 8 * (q / A.nvc)) << 32) | (q % A.nvc);
+	}
+	return ~0ull;
+}
+/* after the task (voice index vi, chunk kc): its rows are counted; some of the chunk's tasks each mix tiles of the XCD's chunk before */
+__device__ __forceinline__ void inmix_after(const InmixArgs &A, const uint32_t kc, const uint32_t vi, int l) {
+	if ((kc & 7u) != xcc_id()) return; /* (a task from another XCD's queue: its rows are not in this L2, and that chunk stays incomplete) */
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this wave's rows of the chunk are in the XCD's L2 */
+	if (l == 0) __hip_atomic_fetch_add(&A.ctl[INMIX_CHUNK + INMIX_LINE * kc + INMIX_DONE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	const uint32_t tpc = A.ctl[INMIX_TPC]; /* (premix_kernel's, from before the launch: a plain load) */
+	/* Which tasks: those of voices part of the way into the chunk -- voice `first`: tile 0, the next: tile 1, ... (banks of fewer
+	 * voices than tiles: every voice-count-th tile). Dealt out when the chunk before has been dealt out whole, they look at its
+	 * counter a task's length later, when its last tasks have finished too; and they are through with their tiles before the
+	 * chunk's last tasks end. (The chunk's LAST voices, first form: in the queue's last chunk those are the launch's last tasks,
+	 * and their tiles went straight onto its end -- 0.1 ms of the 0.18 ms the mixing cost the launch.)
+	 * (A second chance for a tile whose chunk was not whole then, from a task early in the chunk after, sixteen chunks on: tried;
+	 * the launch got slower by more than the tiles were worth.) */
+	const uint32_t first = A.nvc * ((A.flags >> 8) & 15u) / 16u; /* (sixteenths of the chunk: the host's choice) */
+	uint32_t j = vi + A.nvc - first;
+	if (j >= A.nvc) j -= A.nvc;
+	if (kc < 8 || j >= tpc) return;
+	if (inmix_ctl(A, INMIX_CHUNK + INMIX_LINE * (kc - 8) + INMIX_DONE) != A.nvc) return; /* (not all there after all: mix_kernel's) */
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); /* (this CU's L1 may hold older lines of the rows) */
+	const uint32_t cf = A.ctl[INMIX_CF];
+	if (A.flags & 4u) return; /* (SAU_AMD_INMIX_DRY, a timing aid: everything but the tiles) */
+	for (; j < tpc; j += A.nvc) {
+		inmix_tile(A, kc - 8, j, cf, l);
+		if (l == 0) __hip_atomic_fetch_or(&A.ctl[INMIX_CHUNK + INMIX_LINE * (kc - 8) + INMIX_BITS + (j >> 5)], 1u << (j & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+}
+
 /* SCAN: the kernel may meet voices with running-sum phases (it then holds both builds of fast_voice). */
 #ifndef FK_MINB
 #define FK_MINB 1
@@ -1001,9 +1181,18 @@ __global__ void FK_ATTR fast_kernel(FastParams P) {
 		const bool counted = P.dyn_static == 0;
 		const uint32_t stride = gridDim.x * W;
 		uint32_t snext = blockIdx.x * W + (uint32_t)w;
+		/* tasks from the XCDs' queues (k_fast_types.h), and the launch mixes when the host asks for it and premix_kernel has found
+		 * nothing against it */
+		const bool im = !CUB && (P.inmix_flags & 64u) != 0;
+		const bool mixing = im && (P.inmix_flags & 32u) && uni(__hip_atomic_load(&P.work_count[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0;
 		for (;;) {
 			uint32_t t_ = snext;
-			if (counted) { t_ = 0; if (l == 0) t_ = atomicAdd(&P.pass_flags[FAST_DYN_CTR], 1u); }
+			if (counted && !im) { t_ = 0; if (l == 0) t_ = atomicAdd(&P.pass_flags[FAST_DYN_CTR], 1u); }
+			if (!CUB && im) { /* (as a task's number in the one queue's order: voice x chunks + chunk) */
+				const InmixArgs A = inmix_args(NVc);
+				const unsigned long long nx = inmix_next(A, mixing ? A.ctl[INMIX_NCH] : K, l);
+				t_ = nx == ~0ull ? n_tasks : (uint32_t)nx * K + (uint32_t)(nx >> 32);
+			}
 			const uint32_t task = uni(t_);
 			if (task >= n_tasks) break;
 			snext = task + stride;
@@ -1011,6 +1200,10 @@ __global__ void FK_ATTR fast_kernel(FastParams P) {
 			const uint32_t v = P.split_cf ? P.vlists[vi] : vi;
 			const FastInfo fi = P.info[v];
 			fast_voice<T, 0, false, CUB, WIDE>(P, v, fi, slots, carry, tabs, l, 1u, 0u, nullptr, task - vi * K, K);
+			if (!CUB && mixing) {
+				const InmixArgs A = inmix_args(NVc);
+				inmix_after(A, task - vi * K, vi, l);
+			}
 		}
 		return;
 	}

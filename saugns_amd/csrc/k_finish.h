@@ -1,5 +1,5 @@
 /* k_finish.h -- part of hip_backend.hip (included there, inside namespace sauhip; not a header of its own).
- * finalize_kernel, mix_kernel, event_kernel and the line known-answer kernel. */
+ * finalize_kernel, premix_kernel, mix_kernel, mix_few_kernel, event_kernel. */
 /* Apply the closed forms to the operator state, or hand the whole segment
  * to the block loop when a chunk had to bail out. */
 __global__ void __launch_bounds__(64) finalize_kernel(FastParams P) {
@@ -121,9 +121,36 @@ __global__ void __launch_bounds__(64) finalize_kernel(FastParams P) {
  * early results do not stand. Sums and order are the mixer's own: the same PCM either way (round 5). */
 __global__ void __launch_bounds__(64) premix_kernel(FastParams P) {
 	const uint32_t v = blockIdx.x * 64 + threadIdx.x;
+	if (P.inmix_flags & 32u) { /* ahead of a closed-form launch that mixes (k_fast_types.h): its control words */
+		/* the chunks' frame ranges, as fast_voice cuts voice 0's (and, checked below, every voice's) row groups into dyn_chunks runs */
+		const FastInfo f0 = P.info[0];
+		const uint32_t GF = 64u * P.rows - f0.H;
+		const uint32_t ngroups = f0.total && f0.H < 64u * P.rows ? (f0.total + GF - 1) / GF : 0u;
+		const uint32_t K = P.dyn_chunks ? P.dyn_chunks : 1u, per = (ngroups + K - 1) / K;
+		const uint32_t nch = per ? (ngroups + per - 1) / per : 0u;
+		const uint32_t tpc = (per * GF + INMIX_TILE - 1) / INMIX_TILE;
+		const bool fits = nch != 0 && nch <= INMIX_MAX_CHUNKS && tpc <= INMIX_MAX_TPC && (per * GF) % 4u == 0; /* (16-byte row loads: chunks begin on a multiple of four frames) */
+		if (v == 0) {
+			P.inmix[INMIX_CF] = per * GF;
+			P.inmix[INMIX_TPC] = tpc;
+			P.inmix[INMIX_NCH] = fits ? nch : 0u;
+			if (!fits) atomicOr(&P.work_count[1], 4u);
+		}
+		/* the queues' counters; per chunk the count and the tiles' bits */
+		const uint32_t lines = 9 + (fits ? nch : 0u);
+		for (uint32_t i = v; i < lines * 9; i += gridDim.x * 64) {
+			const uint32_t ln = i / 9, wd = i % 9;
+			if (ln) P.inmix[ln * INMIX_LINE + (wd ? INMIX_BITS + wd - 1 : 0u)] = 0;
+		}
+	}
 	if (v >= P.n_voices) return;
 	const FastInfo fi = P.info[v];
 	const VoiceDesc vd = P.voices[v];
+	if (P.inmix_flags & 32u) {
+		const FastInfo f0 = P.info[0];
+		if (fi.H != f0.H || fi.total != f0.total || vd.pan_dynamic_row != ~0u || fi.total < P.inmix_stream->write_len || fi.cub)
+			atomicOr(&P.work_count[1], 4u);
+	}
 	/* (seq == 1: a voice one wave walks in order -- more than eight running sums, or look-back switched off -- is rendered whole in
 	 * the LAST chunk's launch (fast_voice: range_last), not chunk by chunk: found by round 5's drop-in sweep, 1 program of 3000) */
 	if (fi.total == 0 || fi.bail || fi.total < vd.run_len || fi.seq == 1) { atomicOr(&P.work_count[1], 1u); return; }
@@ -135,13 +162,6 @@ __global__ void __launch_bounds__(64) premix_kernel(FastParams P) {
 	vo.pan_row = vd.pan_dynamic_row;
 	P.vinfo[vd.out_row] = vo;
 }
-
-struct MixStream {
-	uint32_t first_row, n_rows;
-	float amp_scale;
-	uint32_t write_len;
-	int16_t *pcm; /* stream's PCM row */
-};
 
 struct MixParams {
 	const MixStream *streams;
@@ -156,6 +176,7 @@ struct MixParams {
 	 * the blocks below early_blocks when guard[0] (voices on the block loop's list) and guard[1] (premix_kernel's note) are 0 */
 	uint32_t blk_lo, blk_hi, early_blocks;
 	const uint32_t *guard;
+	const uint32_t *inmix; /* the closed-form launch has mixed tiles itself (k_fast_types.h): its control words, or NULL */
 };
 
 /* generator.c:749-825: ordered voice sum (ref-build association) and PCM.
@@ -171,10 +192,10 @@ struct MixParams {
 constexpr int MIX_TILE = 256; /* voices whose constants are staged at a time */
 constexpr int MIX_AHEAD = 32; /* loads per batch and thread */
 __device__ __forceinline__ void mix_body(const MixParams &P, const MixStream &ms, const uint32_t bx,
-		float *s_pan, uint32_t *s_valid, uint32_t *s_prow, uint32_t &s_special) {
+		float *s_pan, uint32_t *s_valid, uint32_t *s_prow, uint32_t &s_special, const bool covered = false) {
 	const uint32_t tl = threadIdx.x; /* within the 256 frames of bx */
 	const uint32_t i = bx * 256 + tl;
-	const bool act = i < ms.write_len;
+	const bool act = i < ms.write_len && !covered;
 	float L = 0.f, R = 0.f;
 	for (uint32_t r0 = 0; r0 < ms.n_rows; r0 += MIX_TILE) {
 		const uint32_t nt = min((uint32_t)MIX_TILE, ms.n_rows - r0);
@@ -276,7 +297,16 @@ __global__ void __launch_bounds__(256) mix_kernel(MixParams P) {
 	if (bx * 256 >= ms.write_len || (P.blk_hi && bx >= P.blk_hi)) return;
 	if (P.blk_hi && P.guard[1]) return; /* an early launch, and premix_kernel could not speak for every voice: their records are not there yet */
 	if (P.early_blocks && bx < P.early_blocks && P.guard[0] == 0 && P.guard[1] == 0) return; /* mixed by an early launch, and it stands */
-	mix_body(P, ms, bx, s_pan, s_valid, s_prow, s_special);
+	bool covered = false;
+	if (P.inmix && P.guard[0] == 0 && P.guard[1] == 0) {
+		/* frames the closed-form launch has mixed itself: those of the tiles with their bits set (and it stands) */
+		const uint32_t cf = P.inmix[INMIX_CF], i = bx * 256 + threadIdx.x;
+		const uint32_t k = cf ? i / cf : 0u;
+		const uint32_t j = cf ? (i - k * cf) / INMIX_TILE : 0u;
+		covered = k < P.inmix[INMIX_NCH] && ((P.inmix[INMIX_CHUNK + INMIX_LINE * k + INMIX_BITS + (j >> 5)] >> (j & 31u)) & 1u) != 0;
+		if (__syncthreads_and(covered)) return;
+	}
+	mix_body(P, ms, bx, s_pan, s_valid, s_prow, s_special, covered);
 }
 
 /* Streams of a few voices each (a batch of many small scripts: BASELINE config 4 has two voices per render): four
@@ -345,7 +375,8 @@ __global__ void __launch_bounds__(256) mix_few_kernel(MixParams P) {
 	}
 }
 
-__global__ void event_kernel(DevOp *ops, const OpUpdate *recs, uint32_t n, const WaveConst *wc) {
+/* (launched with 64 threads per workgroup: told so, the kernel keeps a DevOp in registers instead of spilling 84 of them) */
+__global__ void __launch_bounds__(64) event_kernel(DevOp *ops, const OpUpdate *recs, uint32_t n, const WaveConst *wc) {
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	OpUpdate u = recs[i];

@@ -1,0 +1,123 @@
+"""The closed-form launch's task queues, one per XCD, and the mixer inside that launch (saugns_amd/csrc/k_fast_types.h, round 5):
+a bank of many voices mixed into one stream can have its tiles mixed by the launch that renders the rows, chunk by chunk,
+with mix_kernel taking what is left. The sums are the reference's ordered f32 sums either way (generator.c:749-825): every
+PCM here is compared with the oracle's or with the reference's SHA-256, and SAU_AMD_INMIX_REPORT tells how much the launch
+mixed itself -- a test that passed on the plain mixer alone would say nothing."""
+import hashlib
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ORACLE_FORMS
+
+pytestmark = pytest.mark.gpu
+
+LINE = re.compile(r"inmix: voices (\d+) frames (\d+) chunks (\d+) x (\d+) frames, tiles (\d+) of (\d+), chunks mixed whole (\d+), guard (\d+) (\d+)")
+
+
+def _reports(capfd):
+    return [tuple(int(x) for x in m.groups()) for m in LINE.finditer(capfd.readouterr().err)]
+
+
+@pytest.fixture()
+def report(monkeypatch):
+    """The launch reports what it mixed itself."""
+    monkeypatch.setenv("SAU_AMD_INMIX_REPORT", "1")
+
+
+def test_config3_whole_render_in_one_run(sa, index, report, capfd):
+    """BASELINE config 3 as bench.py renders it -- all 441000 frames in one engine run: SHA-256 of the PCM equals the
+    reference's, and most of it was mixed inside the launch."""
+    from saugns_amd import voicebank
+    batch = sa.Batch([voicebank.config3()], 44100)
+    pcm = batch.run(441000, stereo=False)[0][0]
+    batch.close()
+    assert hashlib.sha256(np.ascontiguousarray(pcm[:441000]).tobytes()).hexdigest() == index["configs"]["config3"]["sha256"]
+    reps = _reports(capfd)
+    assert reps, "the launch did not mix at all"
+    voices, frames, nch, cf, tiles, of, whole, g0, g1 = reps[0]
+    assert voices == 1024 and frames == 441000 and g0 == 0 and g1 == 0
+    assert tiles * 2 > of, reps[0]
+
+
+@pytest.mark.parametrize("stereo", [False, True])
+@pytest.mark.parametrize("grid", ["16", "24"])
+def test_banks_against_the_oracle(sa, oracle, report, capfd, monkeypatch, stereo, grid):
+    """Smaller banks, so that the oracle can render them: 96 voices x 4 s with pans of their own, a launch of few workgroups
+    (SAU_AMD_FK_GRID: tasks enough per wave for the counter to deal them out) -- mono and stereo, frames not a multiple of
+    anything."""
+    from saugns_amd import voicebank as vb
+    monkeypatch.setenv("SAU_AMD_FK_GRID", grid)
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
+    voices = vb.config3_voices(96, 4)
+    for i, v in enumerate(voices):
+        v.pan = vb.Line(vb._num(".2f", ((i * 37) % 100) / 100.0))
+    prg = vb.build_program(voices)
+    want = oracle.oracle_render(prg.ptr, 44100, stereo, chunk=176400)
+    batch = sa.Batch([prg], 44100)
+    got = batch.run(176400, stereo=stereo)[0][0]
+    batch.close()
+    n = len(want)
+    assert (np.asarray(got).reshape(-1)[:n] == want).all()
+    reps = _reports(capfd)
+    assert reps and reps[0][4] > 0, reps
+
+
+def test_voices_of_different_depth_leave_it_to_the_mixer(sa, oracle, report, capfd, monkeypatch):
+    """Voices whose lead-in differs (nesting depth 1 and 3) cut their row groups at different frames: premix_kernel says so
+    and the launch mixes nothing; same PCM."""
+    from saugns_amd import voicebank as vb
+    monkeypatch.setenv("SAU_AMD_FK_GRID", "16")
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
+    voices = vb.config3_voices(64, 4) + [vb.Op("sin", freq=vb._num(".4f", 55.0 * (1 + i)), time_ms=4000) for i in range(32)]
+    prg = vb.build_program(voices)
+    want = oracle.oracle_render(prg.ptr, 44100, False, chunk=176400)
+    batch = sa.Batch([prg], 44100)
+    got = batch.run(176400, stereo=False)[0][0]
+    batch.close()
+    assert (np.asarray(got)[:len(want)] == want).all()
+    reps = _reports(capfd)
+    assert reps and reps[0][4] == 0 and reps[0][8] != 0, reps
+
+
+def test_the_same_pcm_whoever_mixes_and_however_tasks_are_dealt(sa, oracle, capfd, monkeypatch):
+    """Tasks from one queue per XCD, chunk-major, with the launch mixing (what ships) == the same with every frame left to
+    mix_kernel (SAU_AMD_NO_INMIX) == the one counter in voice order (SAU_AMD_NO_XCD_QUEUES) == the oracle."""
+    from saugns_amd import voicebank as vb
+    monkeypatch.setenv("SAU_AMD_FK_GRID", "16")
+    monkeypatch.setenv("SAU_AMD_INMIX_REPORT", "1")
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
+    prg = vb.config3(96, 4)
+    want = oracle.oracle_render(prg.ptr, 44100, False, chunk=176400)
+
+    def render():
+        batch = sa.Batch([prg], 44100)
+        pcm = np.array(batch.run(176400, stereo=False)[0][0], copy=True)
+        batch.close()
+        return pcm[:len(want)]
+
+    assert (render() == want).all()
+    assert _reports(capfd)
+    monkeypatch.setenv("SAU_AMD_NO_INMIX", "1")
+    assert (render() == want).all()
+    assert not _reports(capfd)
+    monkeypatch.setenv("SAU_AMD_NO_XCD_QUEUES", "1")
+    assert (render() == want).all()
+
+
+def test_step_after_step_of_config3(sa, monkeypatch):
+    """Six consecutive 441000-frame runs of a 60 s config-3 bank (the control words and the voice rows are reused from run to
+    run): the launch that mixes and the mixer alone give the same PCM, run by run."""
+    from saugns_amd import voicebank
+
+    def runs(n):
+        batch = sa.Batch([voicebank.config3(seconds=10 * n)], 44100)
+        out = [hashlib.sha256(np.ascontiguousarray(batch.run(441000, stereo=False)[0][0]).tobytes()).hexdigest() for _ in range(n)]
+        batch.close()
+        return out
+
+    a = runs(6)
+    monkeypatch.setenv("SAU_AMD_NO_INMIX", "1")
+    b = runs(6)
+    assert a == b and len(set(a)) == 6
