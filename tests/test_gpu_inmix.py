@@ -121,3 +121,41 @@ def test_step_after_step_of_config3(sa, monkeypatch):
     monkeypatch.setenv("SAU_AMD_NO_INMIX", "1")
     b = runs(6)
     assert a == b and len(set(a)) == 6
+
+
+def _bank(vb, rng, n, seconds, depth):
+    """n voices of one nesting depth (so that their row groups are cut at the same frames), frequencies, amplitudes and pans drawn"""
+    voices = []
+    for i in range(n):
+        op = None
+        for d in range(depth - 1):
+            op = vb.Op("sin", freq=vb.Line(float(rng.integers(1, 6)), ratio=True), amp=vb._num(".2f", rng.uniform(0.2, 0.9)),
+                       mods={vb.POP_PMOD: [op]} if op else None)
+        voices.append(vb.Op("sin", freq=vb._num(".3f", rng.uniform(60.0, 900.0)), time_ms=seconds * 1000,
+                            pan=vb.Line(vb._num(".2f", rng.uniform(0.0, 1.0))), mods={vb.POP_PMOD: [op]} if op else None))
+    return vb.build_program(voices)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_drawn_banks_against_the_oracle(sa, oracle, report, capfd, monkeypatch, seed):
+    """Banks drawn at random -- 64 to 200 voices of depth 1 to 4, 3 to 5 s, mono or stereo, a run that ends short of the
+    script or past it, launches of 8 to 32 workgroups -- identical to the oracle's PCM."""
+    from saugns_amd import voicebank as vb
+    rng = np.random.default_rng(9100 + seed)
+    n, seconds, depth = int(rng.integers(64, 201)), int(rng.integers(3, 6)), int(rng.integers(1, 5))
+    stereo, grid = bool(rng.integers(0, 2)), int(rng.integers(8, 33))
+    run = int(seconds * 44100 + rng.integers(-5000, 3000))
+    monkeypatch.setenv("SAU_AMD_FK_GRID", str(grid))
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
+    prg = _bank(vb, rng, n, seconds, depth)
+    want = oracle.oracle_render(prg.ptr, 44100, stereo, chunk=run)
+    batch = sa.Batch([prg], 44100)
+    pcm, more, lens = batch.run(run, stereo=stereo)
+    got = [np.array(pcm[0][: lens[0] * (2 if stereo else 1)], copy=True)]
+    while more[0]:
+        pcm, more, lens = batch.run(run, stereo=stereo)
+        got.append(np.array(pcm[0][: lens[0] * (2 if stereo else 1)], copy=True))
+    batch.close()
+    got = np.concatenate(got)
+    assert len(got) == len(want) and (got == want).all(), (n, seconds, depth, stereo, grid, run)
+    print("mixed inside the launch:", _reports(capfd))  # (short runs of shallow voices have too few tasks for the queues: pytest -s shows which)
