@@ -488,7 +488,8 @@ def run_config3(args, R, sa, tabs):
                      "unit": "SIMD-cycles per launch (vector instructions by class x measured issue cost, against 1024 SIMDs x launch cycles)",
                      "frac": valu_frac, "traffic": traffic, "traffic_source": source,
                      "valu": valu,
-                     "kernel": "fast_kernel<12, 0, false, true> (closed-form build, 12 rows per pass, wide table blocks in LDS)",
+                     "kernel": "fast_kernel<12, 0, false, true> (closed-form build, 12 rows per pass, wide table blocks in LDS; since round 5 tasks from "
+                               "one queue per XCD, and the launch mixes about three quarters of the output frames itself -- DESIGN.md 4.1)",
                      "avg_launch_ms": launch_s * 1e3, "launches": tm["segments"],
                      # SURVEY 8d's convention: every operator's block output priced as one f32 write + one f32 read in HBM. This
                      # kernel keeps those blocks in LDS -- HBM carries the voice rows only (`traffic`, about an eighth) -- so this
