@@ -105,8 +105,10 @@ def profile_step_valu(workload, kernel_prefix):
             pmc = json.load(open(os.path.join(pdir, f)))
             if pmc.get("kernel_source_sha") == kernel_source_hash() and pmc.get("workload", {}).get("name") == workload:
                 for n, v in pmc["kernels"].items():
-                    if kernel_prefix in n and v.get("valu"):
-                        best = dict(v["valu"], kernel=n, source="profiles/" + f)
+                    # (the step's dominant launch: token launches of other builds match the prefix too)
+                    if kernel_prefix in n and v.get("valu") and (best is None or best["file"] != f or
+                                                                  v["valu"].get("weighted_cycles_per_launch", 0) > best.get("weighted_cycles_per_launch", 0)):
+                        best = dict(v["valu"], kernel=n, source="profiles/" + f, file=f)
         except (OSError, KeyError, ValueError, AttributeError):
             pass
     return best
