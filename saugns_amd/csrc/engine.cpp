@@ -197,6 +197,8 @@ bool Engine::handle_event(Stream &st, const EventNode &e, std::vector<OpUpdate> 
 				m.goal_seen = true;
 				if (l == L_FREQ || l == L_FREQ2) m.freq_goal_seen = true;
 			}
+			if (src[l] && (l == L_FREQ || l == L_FREQ2) && (src[l]->flags & (SAU_LINEP_STATE_RATIO | SAU_LINEP_GOAL_RATIO)))
+				m.freq_ratio_seen = true;
 		}
 		u.loop_tails = loop_tails_ ? 1u : 0u;
 		line_copy(m.pan, u.line[L_PAN], loop_tails_);
@@ -309,6 +311,17 @@ bool Engine::rebuild_plans(std::string &err) {
 					vn.plan.n_steps = (uint32_t)vn.plan.steps.size();
 				}
 				vn.plan_valid = true;
+				if (tune_env("SAU_AMD_PLAN_DUMP")) { /* (debugging aid: the voice's plan and its block buffers in the time-parallel numberings) */
+					const VoicePlan &pl = vn.shape >= 0 ? shapes_[vn.shape].plan : vn.plan;
+					fprintf(stderr, "[sau-amd] plan: voice %zu steps %zu n_fast %u n_fast_full %u\n", v, pl.steps.size(), vn.plan.n_fast, vn.plan.n_fast_full);
+					for (size_t i = 0; i < pl.steps.size(); ++i) {
+						const Step &q = pl.steps[i];
+						const FastIds f = i < pl.fast_ids_full.size() ? pl.fast_ids_full[i] : FastIds();
+						fprintf(stderr, "[sau-amd]   %2zu kind %u flags %#x op %u which %u out %u freq %u fmul %u pm %u amp %u | full ids: out %d pm %d amp %d aux %d freq %d fmul %d\n",
+								i, q.kind, q.flags, q.op, q.which, q.out, q.freq, q.fmul, q.pm, q.amp,
+								(int)(int8_t)f.out, (int)(int8_t)f.pm, (int)(int8_t)f.amp, (int)(int8_t)f.aux, (int)(int8_t)f.freq, (int)(int8_t)f.fmul);
+					}
+				}
 			}
 			const VoicePlan &steps_of = vn.shape >= 0 ? shapes_[vn.shape].plan : vn.plan;
 			ref.ops_ofs = (uint32_t)all_op_ids_.size();

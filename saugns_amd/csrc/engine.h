@@ -120,6 +120,7 @@ struct OpMirror { /* host-side knowledge about one operator */
 	bool ras_cub_seen = false;        /* an R operator that was ever given `cub` segments (conservative: SegmentDesc.maybe_cub) */
 	bool goal_seen = false;           /* some event gave one of its lines a sweep */
 	bool freq_goal_seen = false;      /* ... one of its frequency lines */
+	bool freq_ratio_seen = false;     /* some event gave one of its frequency lines a ratio (state or goal) */
 	OpMirror() { pan = LineState{0, 0, 0, 0, 0, 0}; }
 };
 

@@ -499,6 +499,73 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 			}
 		}
 	}
+	/* The host numbers a running-sum voice's block buffers without those of frequency lines it takes to be one value for every
+	 * segment (sau_dev_types.h: fast_slot_compact, the lean form). Should this segment's state say otherwise -- a line kept
+	 * here that has no buffer, a frequency or a ratio's multiplier read from one that does not exist -- the voice is the block
+	 * loop's for this segment: slow, never wrong. (The host's rule is analyze_kernel's without the ramps, which it sees coming
+	 * as events; SAU_AMD_LEAN_IDS_LIE makes it forget them, for the test of this path.) */
+	{
+		bool lost = false;
+		if ((uint32_t)l < vd.plan_len && seq) {
+			const Step st = P.steps[vd.plan_ofs + l];
+			const FastIds cs = P.fast_ids[P.ids_full_ofs + vd.plan_ofs + l];
+			const DevOp &o = P.ops[ids[st.op]];
+			if (keep && st.kind == ST_LINE && st.which == L_FREQ && cs.out == NO_SLOT) lost = true;
+			/* the end of a range without a buffer: one value, folded into the blend that reads it (below) -- or not one value after all */
+			if (keep && st.kind == ST_LINE && (st.which == L_FREQ2 || st.which == L_AMP2) && cs.out == NO_SLOT)
+				keep = false; /* (whether it is one value: its blend's lane, next) */
+			if (keep && st.kind == ST_LERP && st.freq != NO_SLOT && cs.aux == NO_SLOT) {
+				/* its range end: the line step that filled plan buffer st.freq last */
+				bool found = false;
+				for (uint32_t q = (uint32_t)l; q-- > 0;) {
+					const Step sq = P.steps[vd.plan_ofs + q];
+					if (sq.out != st.freq) continue;
+					if (sq.kind == ST_LINE && (sq.which == L_FREQ2 || sq.which == L_AMP2)) {
+						const DevOp &oq = P.ops[ids[sq.op]];
+						const LineState &ls = oq.line[sq.which];
+						float c = ls.v0;
+						bool pc = true;
+						if (sq.fmul != NO_SLOT && (ls.flags & LP_STATE_RATIO)) { /* sau/line.c:72, as the line step would: v0 x the parent's one value */
+							pc = sq.prov != NO_SLOT && P.ops[ids[sq.prov]].rt_fconst_valid != 0;
+							if (pc) c *= P.ops[ids[sq.prov]].rt_fconst;
+							else {
+								/* ... or x the parent's block as it stands when the line step reads it (analyze_kernel: rt_fblk_valid then): one
+								 * value while the parent's line is held, its own multiplier -- if it is a ratio -- one value, and nothing has been
+								 * added into the block yet (a range modulator's rate under a carrier whose own range blend comes later) */
+								for (uint32_t r = q; r-- > 0;) {
+									const Step sr = P.steps[vd.plan_ofs + r];
+									if (sr.out != sq.fmul) continue;
+									if (sr.kind == ST_LINE && sr.which == L_FREQ) {
+										const DevOp &po = P.ops[ids[sr.op]];
+										const LineState &pls = po.line[L_FREQ];
+										pc = !(pls.flags & LP_GOAL) && (sr.fmul == NO_SLOT || !(pls.flags & LP_STATE_RATIO) ||
+										                                (sr.prov != NO_SLOT && P.ops[ids[sr.prov]].rt_fconst_valid != 0));
+										if (pc) c *= po.rt_fconst;
+									}
+									break; /* (anything else that wrote it: not one value) */
+								}
+							}
+						}
+						found = pc && !(ls.flags & LP_GOAL);
+						f.fc = c;
+					}
+					break;
+				}
+				if (!found) lost = true;
+			}
+			if (keep && st.kind == ST_OSC && (o.type == OT_WAVE || o.type == OT_RASEG) && !o.rt_fconst_valid && st.freq != NO_SLOT && cs.freq == NO_SLOT) lost = true;
+			if (keep && (f.ramp & 2) && fa.fmul_off == ~0u && (fa.flags & (FA_MUL_GOAL | FA_MUL_HOLD)) && fa.mulc == 1.f && st.fmul != NO_SLOT && cs.fmul == NO_SLOT) {
+				/* (a multiplier wanted from a block: fine only when the parent's frequency was found to be one value) */
+				bool pc = false;
+				if (st.prov != NO_SLOT) pc = P.ops[ids[st.prov]].rt_fconst_valid != 0;
+				if (!pc) lost = true;
+			}
+		}
+		if (__any(lost)) {
+			if (l == 0) { P.info[v].total = 0; P.info[v].bail = 1; }
+			keep = false;
+		}
+	}
 	/* step lists: one per pass that runs the step (a multi-pass voice), else just list 0 */
 #pragma unroll
 	for (uint32_t li = 0; li < FAST_LISTS; ++li) {

@@ -901,10 +901,12 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 					for (int k = 0; k < T; ++k) slots[f.out_off + k * 64] = f.ac;
 				}
 			} else if (kind == ST_LERP) { /* generator.c:466-467 */
+				/* (round 5: a range end that is one value for the segment has no block -- decode_kernel hands it over as f.fc) */
+				const bool end_const = f.aux_off == ~0u;
 #pragma unroll
 				for (int k = 0; k < T; ++k) {
 					float pv = slots[f.out_off + k * 64];
-					pv += (slots[f.aux_off + k * 64] - pv) * slots[f.pm_off + k * 64];
+					pv += ((end_const ? f.fc : slots[f.aux_off + k * 64]) - pv) * slots[f.pm_off + k * 64];
 					slots[f.out_off + k * 64] = pv;
 				}
 			} else if (kind == ST_VOICE) { /* generator.c:749-788 with pan modulators */

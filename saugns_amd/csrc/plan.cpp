@@ -265,7 +265,8 @@ struct ShapeWalk {
 		const OpMirror &m = ops[op];
 		const bool is_osc = m.type == SAU_POPT_N_wave || m.type == SAU_POPT_N_raseg;
 		uint32_t t = m.type | ((m.line_set & (1u << L_PMA)) ? 0x100u : 0u) |
-			((m.type == SAU_POPT_N_noise && m.wave == SAU_NOISE_N_re) ? 0x200u : 0u);
+			((m.type == SAU_POPT_N_noise && m.wave == SAU_NOISE_N_re) ? 0x200u : 0u) |
+			(m.freq_goal_seen ? 0x400u : 0u) | (m.goal_seen ? 0x800u : 0u) | (m.freq_ratio_seen ? 0x1000u : 0u); /* (which of its lines keep their buffers: fast_slot_compact's lean form) */
 		for (int use = 1; use < SAU_POP_NAMED; ++use) if (count(m.mods[use])) t |= 0x1000u << use;
 		tokens.push_back(t);
 		for (int use = 1; use < SAU_POP_NAMED; ++use) if (count(m.mods[use])) tokens.push_back(count(m.mods[use]));
@@ -380,8 +381,19 @@ bool compile_voice_plan(const std::vector<OpMirror> &ops, uint32_t carrier,
 	if (!out.wide) {
 		out.n_fast = fast_slot_compact(out.steps.data(), (uint32_t)out.steps.size(),
 				out.steps.empty() ? nullptr : out.fast_ids.data(), false);
+		/* (with frequency blocks -- the lean form: lines that are one value for every segment get none, sau_dev_types.h) */
+		uint8_t ramped[256];
+		for (size_t i = 0; i < 256; ++i) {
+			ramped[i] = 7;
+			if (i < out.op_ids.size()) {
+				const OpMirror &m = ops[out.op_ids[i]];
+				ramped[i] = (uint8_t)((m.freq_goal_seen ? 1 : 0) | (m.goal_seen ? 2 : 0) | (m.freq_ratio_seen ? 4 : 0));
+			}
+		}
+		static const bool lean = !tune_env("SAU_AMD_NO_LEAN_IDS");
+		if (tune_env("SAU_AMD_LEAN_IDS_LIE")) for (size_t i = 0; i < 256; ++i) ramped[i] = 0; /* (test: the device finds out, k_decode.h) */
 		out.n_fast_full = fast_slot_compact(out.steps.data(), (uint32_t)out.steps.size(),
-				out.steps.empty() ? nullptr : out.fast_ids_full.data(), true);
+				out.steps.empty() ? nullptr : out.fast_ids_full.data(), true, lean ? ramped : nullptr);
 	}
 	if (out.n_fast == 0xffffffffu || out.n_fast_full == 0xffffffffu) {
 		out.n_fast = out.n_fast_full = 0;

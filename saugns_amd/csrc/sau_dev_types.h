@@ -147,12 +147,23 @@ static_assert(sizeof(Step) == 16, "Step is 4 dwords");
  * steps. */
 struct FastIds { uint8_t out, pm, fpm, amp, aux /* LERP range end */, freq, fmul, sm /* self-modulation amounts */; };
 static_assert(sizeof(FastIds) == 8, "FastIds is 2 dwords");
-SAU_HD uint32_t fast_slot_compact(const Step *plan, uint32_t n, FastIds *ids, bool with_freq) {
+SAU_HD uint32_t fast_slot_compact(const Step *plan, uint32_t n, FastIds *ids, bool with_freq, const uint8_t *ramped = nullptr) {
 	const uint32_t limit = with_freq ? 250u : (uint32_t)FSLOT_BASE;
 	constexpr int NR = 7;
 	uint8_t last[256];
 	uint8_t map[256];
-	for (uint32_t s = 0; s < 256; ++s) { last[s] = 0xff; map[s] = NO_SLOT; }
+	/* `ramped` (with_freq; indexed by voice-local operator: its frequency line has had a ramp at some time): the lean form --
+	 * a frequency line that is one value for every segment gets no buffer, as decode_kernel will not materialise it
+	 * (k_decode.h: keep; analyze_kernel: rt_fconst_valid). One value: never ramped, nothing added into its block
+	 * (SF_FORCE: an FM or range modulator will be), and -- a ratio line multiplies by the parent's block -- the block it
+	 * may multiply by one value too when this step reads it (analyze_kernel: block_owner, rt_fblk_valid). one[s]: plan
+	 * buffer s holds such a frequency at this point of the plan (1: not materialised, 2: a real block nothing has been
+	 * added into yet). The carrier-FM bank needs 2 buffers for 4, BASELINE config 4's second voice 4 for 5: rows per pass
+	 * are what LDS holds of them. Should the device find such a line not to be one value after all, the voice goes to the
+	 * block loop (decode_kernel). */
+	uint8_t one[256];
+	const bool lean = with_freq && ramped != nullptr;
+	for (uint32_t s = 0; s < 256; ++s) { last[s] = 0xff; map[s] = NO_SLOT; one[s] = 0; }
 	auto reads_of = [](const Step &st, uint8_t *rd) {
 		for (int k = 0; k < NR; ++k) rd[k] = NO_SLOT;
 		if (st.kind == ST_OSC) { rd[0] = st.pm; rd[1] = st.fpm; rd[2] = st.amp; if (st.flags & SF_LAYER) rd[3] = st.out; rd[4] = st.freq; rd[5] = st.fmul; rd[6] = st.sm; }
@@ -160,11 +171,59 @@ SAU_HD uint32_t fast_slot_compact(const Step *plan, uint32_t n, FastIds *ids, bo
 		else if (st.kind == ST_VOICE) { rd[0] = st.out; rd[1] = st.pm; }
 		else if (st.kind == ST_LINE) { rd[0] = st.fmul; }
 	};
+	/* (lean: which frequency lines get no buffer, decided in plan order ahead of the liveness pass -- what reads such a line's
+	 * buffer reads nothing) */
+	uint8_t skip[256], strict[256];
+	for (uint32_t i = 0; i < 256; ++i) { skip[i] = 0; strict[i] = 0; }
+	if (lean) {
+		for (uint32_t i = 0; i < n && i < 0xff; ++i) {
+			const Step st = plan[i];
+			const bool writes_blk = (st.kind == ST_OSC && !(st.which & OX_VOICE)) || st.kind == ST_LERP;
+			const uint8_t rf = st.op < 256 ? ramped[st.op] : (uint8_t)7; /* (256 entries; 1: a frequency line has ramped, 2: some line has, 4: a frequency line has been a ratio) */
+			if (st.kind == ST_LINE && st.which == L_FREQ && st.out < limit) {
+				const bool parent_one = st.fmul == NO_SLOT || st.fmul >= limit || !(rf & 4) || one[st.fmul] != 0;
+				const bool own = !(rf & 1);
+				if (own && parent_one && !(st.flags & SF_FORCE)) { one[st.out] = 1; skip[i] = 1; }
+				else one[st.out] = (own && parent_one) ? 2 : 0;
+				/* (... and by the narrower rule decode_kernel can check again when a range end multiplies by this block: its own
+				 * multiplier, if it has one, a line without a buffer) */
+				strict[st.out] = own && (st.fmul == NO_SLOT || st.fmul >= limit || !(rf & 4) || one[st.fmul] == 1);
+			} else if (st.kind == ST_LINE && (st.which == L_FREQ2 || st.which == L_AMP2) && st.out < limit && !(rf & 2) && /* (SF_FORCE on these: "always written" -- for the blend's sake) */
+			           (st.fmul == NO_SLOT || st.fmul >= limit || !(rf & 4) || one[st.fmul] == 1 || (one[st.fmul] == 2 && strict[st.fmul]))) {
+				/* the end of a range (generator.c:466-467) that is one value: folded into the blend that reads it, if nothing
+				 * else does before the buffer is written again (decode_kernel: ST_LERP with the end as a constant) */
+				bool only_blends = false;
+				for (uint32_t j = i + 1; j < n && j < 0xff; ++j) {
+					const Step sj = plan[j];
+					uint8_t rj[NR];
+					reads_of(sj, rj);
+					bool other = false;
+					for (int k = 0; k < NR; ++k) if (rj[k] == st.out && !(sj.kind == ST_LERP && k == 1)) other = true;
+					if (other) { only_blends = false; break; }
+					if (sj.kind == ST_LERP && sj.freq == st.out) only_blends = true;
+					const bool wj = (sj.kind == ST_OSC && !(sj.which & OX_VOICE)) || sj.kind == ST_LERP || sj.kind == ST_LINE || sj.kind == ST_SMLINE;
+					if (wj && sj.out == st.out) break;
+				}
+				if (only_blends) skip[i] = 1;
+				one[st.out] = 0;
+			} else if ((writes_blk || st.kind == ST_LINE || st.kind == ST_SMLINE) && st.out < limit) {
+				one[st.out] = 0; /* something else is written or added into it */
+			}
+		}
+	}
+	/* (a buffer skipped this way is never live: its readers are not counted) */
+	uint8_t dead[256]; /* per plan buffer, as the walk below goes: its current value is a skipped line's */
+	for (uint32_t s = 0; s < 256; ++s) dead[s] = 0;
 	for (uint32_t i = 0; i < n && i < 0xff; ++i) {
 		uint8_t rd[NR];
 		reads_of(plan[i], rd);
-		for (int k = 0; k < NR; ++k) if (rd[k] < limit) last[rd[k]] = (uint8_t)i;
+		if (skip[i]) { dead[plan[i].out] = 1; continue; }
+		const Step st = plan[i];
+		const bool writes_new = ((st.kind == ST_OSC && !(st.which & OX_VOICE) && !(st.flags & SF_LAYER)) || st.kind == ST_LINE || st.kind == ST_SMLINE);
+		for (int k = 0; k < NR; ++k) if (rd[k] < limit && !dead[rd[k]]) last[rd[k]] = (uint8_t)i;
+		if (writes_new && st.out < limit) dead[st.out] = 0;
 	}
+	for (uint32_t s = 0; s < 256; ++s) dead[s] = 0;
 	unsigned long long used = 0;
 	uint32_t count = 0;
 	if (ids) {
@@ -175,8 +234,10 @@ SAU_HD uint32_t fast_slot_compact(const Step *plan, uint32_t n, FastIds *ids, bo
 	for (uint32_t i = 0; i < n && i < 0xff; ++i) {
 		const Step st = plan[i];
 		if (!with_freq && st.kind == ST_LINE && st.which == L_FREQ) continue; /* never materialised */
+		if (skip[i]) { map[st.out] = NO_SLOT; dead[st.out] = 1; continue; } /* (lean: one value, never materialised either) */
 		uint8_t rd[NR];
 		reads_of(st, rd);
+		for (int k = 0; k < NR; ++k) if (rd[k] < limit && dead[rd[k]]) rd[k] = NO_SLOT; /* (reads of a skipped line's buffer) */
 		bool writes = false;
 		if (st.kind == ST_OSC) writes = !(st.which & OX_VOICE);
 		else if (st.kind == ST_LERP || st.kind == ST_LINE || st.kind == ST_SMLINE) writes = true;
@@ -215,6 +276,7 @@ SAU_HD uint32_t fast_slot_compact(const Step *plan, uint32_t n, FastIds *ids, bo
 				if (last[st.out] == 0xff || last[st.out] < i) used &= ~(1ull << c); /* nobody reads it */
 			}
 			got.out = map[st.out];
+			if (writes) dead[st.out] = 0;
 		}
 		if (ids) ids[i] = got;
 	}
