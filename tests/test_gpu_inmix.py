@@ -159,3 +159,27 @@ def test_drawn_banks_against_the_oracle(sa, oracle, report, capfd, monkeypatch, 
     got = np.concatenate(got)
     assert len(got) == len(want) and (got == want).all(), (n, seconds, depth, stereo, grid, run)
     print("mixed inside the launch:", _reports(capfd))  # (short runs of shallow voices have too few tasks for the queues: pytest -s shows which)
+
+
+def test_a_line_the_host_took_for_one_value_sends_the_voice_to_the_block_loop(sa, oracle, monkeypatch):
+    """Round 5's lean buffer numbering (tests/test_plan_buffers.py): the host leaves out the buffers of frequency lines and range
+    ends it knows to be one value. SAU_AMD_LEAN_IDS_LIE makes it forget the sweeps it has seen: decode_kernel then finds a
+    line it must keep without a buffer, and the voice is rendered by the block loop -- same PCM as the oracle's, with the
+    switch and without."""
+    from saugns_amd import voicebank as vb
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
+
+    def voice(i):
+        m3 = vb.Op("sin", freq=vb.Line(3.0, ratio=True), amp=vb._f32(0.4))
+        m2 = vb.Op("sin", freq=vb.Line(2.0, goal=5.0, ratio=True), amp=vb._f32(0.7), mods={vb.POP_PMOD: [m3]})
+        m1 = vb.Op("sin", freq=vb.Line(1.0, ratio=True), amp=20.0 + i, amp2=vb.Line(40.0), mods={vb.POP_PMOD: [m2]})
+        return vb.Op("sin", freq=vb._num(".2f", 110.0 + 3.7 * i), freq2=vb.Line(vb._num(".2f", 220.0 + i), goal=330.0), time_ms=1500,
+                     mods={vb.POP_FMOD: [m1]})
+
+    prg = vb.build_program([voice(i) for i in range(24)])
+    want = oracle.oracle_render(prg.ptr, 44100, False, chunk=11289)
+    for lie in (False, True):
+        if lie:
+            monkeypatch.setenv("SAU_AMD_LEAN_IDS_LIE", "1")
+        got = sa.Batch([prg], 44100).render(stereo=False, chunk=11289)[0]
+        assert len(got) == len(want) and (got == want).all(), lie
