@@ -1081,6 +1081,13 @@ public:
 					 * launch against the one counter in voice order */
 					if (fp.inmix && main_build == 0 && !fp.dyn_static && fp.dyn_chunks >= 16 && !fp.cub_ok) {
 						fp.inmix_flags = 64u; /* (analyze_kernel has cleared the queues) */
+						{ /* the voice count as a divisor (k_fast_voice.h: udiv_magic) */
+							const uint32_t d = seg.n_voices;
+							uint32_t sh = 0;
+							while ((1ull << sh) < d) ++sh;
+							fp.inmix_div_s = sh;
+							fp.inmix_div_m = (uint32_t)(((1ull << (32 + sh)) / d) + 1ull - (1ull << 32));
+						}
 						/* ... and a bank of voices mixed into one stream: the launch mixes its own rows, chunk by chunk behind the rendering;
 						 * premix_kernel has the last word. Config 3: 2.056 -> 1.995 ms per step (the launch 1.74 -> 1.87 ms, the mixer
 						 * 0.26 -> 0.07 ms) */
@@ -1519,7 +1526,7 @@ private:
 	bool inmix_enabled_ = true;       /* a many-voice stream's closed-form launch mixes its own rows (SAU_AMD_NO_INMIX: the mixer alone) */
 	uint32_t inmix_min_voices_ = 64;  /* ... from that many voices on (SAU_AMD_INMIX_MIN_VOICES) */
 	bool inmix_live_ = false;         /* this segment's launch did: mix_kernel looks at the control words */
-	uint32_t inmix_at_ = 12;           /* which of a chunk's tasks mix the chunk before: from this many sixteenths into it (SAU_AMD_INMIX_AT) */
+	uint32_t inmix_at_ = 13;           /* which of a chunk's tasks mix the chunk before: from this many sixteenths into it (SAU_AMD_INMIX_AT) */
 	bool inmix_report_ = false;       /* SAU_AMD_INMIX_REPORT: a line on stderr per such segment (tests) */
 	DevBuf<uint32_t> inmix_ctl_;
 	bool wide_tabs_ = true;

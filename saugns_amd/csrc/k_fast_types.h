@@ -227,6 +227,7 @@ struct FastParams {
 	 * tables above -- every offset behind them moved -- it spilled 88 of them, with not a line of the mixing code compiled in) */
 	uint32_t *inmix;      /* the mixer inside the closed-form launch: INMIX_WORDS control words, or NULL */
 	const MixStream *inmix_stream; /* ... the one stream */
+	uint32_t inmix_div_m, inmix_div_s; /* the voice count as a divisor: q / n_voices = udiv_magic(q, m, s), scalar instructions only (a task's number -> chunk, voice) */
 	uint32_t inmix_flags, inmix_pcm_offset; /* 64: this launch takes its tasks from the XCDs' queues; 32: ... and mixes (premix_kernel has run); 1: stereo PCM,
 	                                         * 2: byte-swapped; 4: timing aid; bits 8-11: which tasks mix (sixteenths into a chunk). MixParams.pcm_offset */
 };

@@ -968,8 +968,16 @@ struct InmixArgs {
 	const float *vout;
 	const VoiceOut *vinfo;
 	const MixStream *stream;
-	uint32_t row_stride, flags, pcm_offset, nvc;
+	uint32_t row_stride, flags, pcm_offset, nvc, div_m, div_s;
 };
+/* q / d for the divisor the host has prepared (m = floor(2^(32 + s) / d) + 1 - 2^32, s = ceil(log2 d); Granlund & Montgomery's
+ * round-up form, exact for every 32-bit q): s_mul_hi_u32 and shifts -- a compiler-made 32-bit division is two dozen vector
+ * instructions, and the task loop had five of them per task */
+__device__ __forceinline__ uint32_t udiv_magic(const uint32_t q, const uint32_t m, const uint32_t s) {
+	if (s == 0) return q;
+	const uint32_t t = __umulhi(q, m);
+	return (t + ((q - t) >> 1)) >> (s - 1);
+}
 typedef float __attribute__((ext_vector_type(4))) inmix_f4;
 typedef uint32_t __attribute__((ext_vector_type(4))) inmix_u4;
 __device__ __forceinline__ void inmix_tile(const InmixArgs &A, const uint32_t k, const uint32_t j, const uint32_t cf, const int l) {
@@ -1081,6 +1089,7 @@ __device__ __forceinline__ InmixArgs inmix_args(const uint32_t nvc) {
 	InmixArgs A;
 	A.ctl = Pk->inmix; A.vout = Pk->vout; A.vinfo = Pk->vinfo; A.stream = Pk->inmix_stream;
 	A.row_stride = Pk->row_stride; A.flags = Pk->inmix_flags; A.pcm_offset = Pk->inmix_pcm_offset; A.nvc = nvc;
+	A.div_m = Pk->inmix_div_m; A.div_s = Pk->inmix_div_s;
 	return A;
 }
 __device__ __forceinline__ uint32_t inmix_ctl(const InmixArgs &A, uint32_t i) {
@@ -1094,11 +1103,14 @@ __device__ __forceinline__ unsigned long long inmix_next(const InmixArgs &A, con
 		const uint32_t x = (xcd + s_) & 7u;
 		const uint32_t mine = nch > x ? (nch - x + 7) / 8 : 0u; /* chunks of XCD x */
 		/* (another XCD's queue: a look first, so that waves with nothing left do not keep adding to it) */
-		if (s_ && inmix_ctl(A, INMIX_QUEUE + INMIX_LINE * x) / A.nvc >= mine) continue;
+		if (s_ && inmix_ctl(A, INMIX_QUEUE + INMIX_LINE * x) >= mine * A.nvc) continue;
 		uint32_t q = 0;
 		if (l == 0) q = __hip_atomic_fetch_add(&A.ctl[INMIX_QUEUE + INMIX_LINE * x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		q = uni(q);
-		if (q / A.nvc < mine) return ((unsigned long long)(x + 8 * (q / A.nvc)) << 32) | (q % A.nvc);
+		if (q < mine * A.nvc) {
+			const uint32_t rank = udiv_magic(q, A.div_m, A.div_s);
+			return ((unsigned long long)(x + 8 * rank) << 32) | (q - rank * A.nvc);
+		}
 	}
 	return ~0ull;
 }
