@@ -183,3 +183,24 @@ def test_a_line_the_host_took_for_one_value_sends_the_voice_to_the_block_loop(sa
             monkeypatch.setenv("SAU_AMD_LEAN_IDS_LIE", "1")
         got = sa.Batch([prg], 44100).render(stereo=False, chunk=11289)[0]
         assert len(got) == len(want) and (got == want).all(), lie
+
+
+@pytest.mark.parametrize("channels", [1, 2])
+def test_files_written_with_the_launch_mixing(sa, oracle, report, capfd, monkeypatch, tmp_path, channels):
+    """sauAmd_render_file over a bank the launch mixes itself: the AU file's big-endian PCM (the tiles swap bytes as mix_kernel
+    does) and the WAV file's, byte for byte the restated writer's over the oracle's PCM."""
+    from saugns_amd import voicebank as vb
+    monkeypatch.setenv("SAU_AMD_FK_GRID", "16")
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
+    voices = vb.config3_voices(96, 8)
+    for i, v in enumerate(voices):
+        v.pan = vb.Line(vb._num(".2f", ((i * 29) % 100) / 100.0))
+    prg = vb.build_program(voices)
+    pcm = oracle.oracle_render(prg.ptr, 44100, channels == 2)
+    for fmt, name in ((sa.api.SNDFILE_AU, "au"), (sa.api.SNDFILE_WAV, "wav")):
+        path = str(tmp_path / f"bank.{name}")
+        n = sa.render_file(prg, 44100, path, fmt, channels)
+        assert n == len(pcm) // channels
+        assert open(path, "rb").read() == oracle.oracle_sndfile_bytes(fmt, channels, 44100, pcm), name
+    reps = _reports(capfd)
+    assert reps and max(r[4] for r in reps) > 0, reps
