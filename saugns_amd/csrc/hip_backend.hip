@@ -860,6 +860,14 @@ public:
 						err = "internal error: no fast_kernel build with " + std::to_string(rows) + " rows per pass in this form";
 						return false;
 					}
+					if (wide && build == 2 && rows == 8) { /* the look-back build with wide table blocks (round 5: where the lean buffer numbering leaves LDS for them) */
+						static size_t lwconfigured[16];
+						const void *lk = (const void *)fast_kernel<8, 2, false, true>;
+						const size_t lds = ft * (size_t)FAST_TAB_BYTES_WIDE + a16 + LOOK_LDS_BYTES;
+						if (!raise_lds_attr(lk, lds, lwconfigured[dev_ & 15], err)) return false;
+						HIP_OK(hipLaunchKernel(lk, dim3(grid), dim3(1024), args, lds, stream_));
+						return true;
+					}
 					if (wide && build == 0 && wide_rows) {
 						const int wi = rows == 12 ? 3 : rows == 10 ? 2 : rows == 8 ? 1 : 0;
 						const size_t lds = ft * (size_t)FAST_TAB_BYTES_WIDE + a16;
@@ -934,9 +942,12 @@ public:
 					if (fp.look) {
 						const unsigned long long waves = (unsigned long long)seg.n_voices * (fp.look_words_real ? (groups < 64 ? groups : 64) : look_wpv_);
 						const uint32_t grid2 = waves > (unsigned long long)fk_grid_ * 16 ? fk_grid_ : (uint32_t)((waves + 15) / 16);
+						/* (wide table blocks for the look-back voices too, where they fit beside the buffers at 8 rows: the carrier-FM bank) */
+						const bool wide_look = wide_tabs_ && !tune_env("SAU_AMD_NO_WIDE_LOOK") && FT == 8 && ft > 0 && ft == n_want &&
+							ft * (size_t)FAST_TAB_BYTES_WIDE + 16 * area + LOOK_LDS_BYTES + 1024 <= lds_limit_;
 						if (look_inside_) { /* (every voice within one workgroup: no waits across workgroups) */
-							if (!launch_build(2, FT, grid2 ? grid2 : 1)) launched = false;
-						} else if (!SpreadLaunchOrder::get().ordered(dev_, stream_, [&]() { return launch_build(2, FT, grid2 ? grid2 : 1); })) {
+							if (!launch_build(2, FT, grid2 ? grid2 : 1, nullptr, 0, wide_look)) launched = false;
+						} else if (!SpreadLaunchOrder::get().ordered(dev_, stream_, [&]() { return launch_build(2, FT, grid2 ? grid2 : 1, nullptr, 0, wide_look); })) {
 							launched = false;
 						}
 						if (fp.cub_ok) { /* look-back voices with the loop tails of `cub` R segments: the build with that code, same lists */

@@ -1152,7 +1152,7 @@ __device__ __forceinline__ void inmix_after(const InmixArgs &A, const uint32_t k
 #endif
 template <int T, int SCAN, bool CUB = false, bool WIDE = false>
 __global__ void FK_ATTR fast_kernel(FastParams P) {
-	static_assert(!WIDE || (SCAN == 0 && !CUB), "only the closed-form builds have a wide-table form");
+	static_assert(!WIDE || ((SCAN == 0 || SCAN == 2) && !CUB), "only the closed-form and the look-back builds have a wide-table form");
 	constexpr int NP = 64 * T;
 	constexpr int W = 16;
 	extern __shared__ __align__(16) unsigned char lds[];
@@ -1238,7 +1238,7 @@ __global__ void FK_ATTR fast_kernel(FastParams P) {
 		for (uint32_t j = g / wpv; j < NVl; j += slots_v) {
 			const uint32_t v = P.vlists[NV + j];
 			const FastInfo fi = P.info[v];
-			fast_voice<T, 2, false, CUB>(P, v, fi, slots, carry, tabs, l, wpv, g % wpv, lring, 0u, 0u, j);
+			fast_voice<T, 2, false, CUB, WIDE>(P, v, fi, slots, carry, tabs, l, wpv, g % wpv, lring, 0u, 0u, j);
 		}
 		return;
 	}
