@@ -99,7 +99,9 @@ struct MixStream {
 };
 /* The mixer inside the closed-form launch (round 5). A bank of many voices mixed into one stream: the mixer reads every voice
  * row once more -- 1.8 GB, 0.26 ms at 6.9 TB/s, an eighth of a BASELINE config-3 step -- while the launch that wrote them is
- * bound by vector issue and leaves HBM idle. Mixed by the launch itself, the reads hide under its arithmetic. Voice order
+ * bound by vector issue and leaves HBM idle. Mixed by the launch itself, the reads hide under its arithmetic -- but the six
+ * flops per voice-sample that the mixer hides under its HBM time are then vector instructions of an issue-bound launch
+ * (+3 %), so the gain is what is left of the mixer's 0.2 ms: 0 to 3 % of a config-3 step by box. Voice order
  * is the reference's f32 sum order (generator.c:749-825) and cannot be split, so a tile of INMIX_TILE frames is mixed by one
  * wave over all rows, as mix_kernel does it, once every voice has written those frames:
  *  - the launch's tasks (voice, run of row groups = chunk) are dealt out chunk-major instead of voice-major, one queue per
