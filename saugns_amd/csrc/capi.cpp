@@ -66,6 +66,7 @@ struct sauGenerator {
 	 * The device is never idle meanwhile -- the next run is always issued before the current one is handed out. */
 	unsigned runs_issued = 0;
 	bool ramp = true;                      /* SAU_AMD_READAHEAD_RAMP=0: every run ahead_frames long */
+	unsigned grow_bits = 2;                /* a run is 2^grow_bits times the one before (SAU_AMD_READAHEAD_GROW) */
 	size_t ahead_call = 0;                 /* the call size the buffered runs were issued for (their block lattice) */
 	Engine::Snapshot snap[SLOTS];          /* the engine before the run in each slot */
 	unsigned rewinds = 0;                  /* times a changed call took the engine back (sauAmd_Generator_rewinds: tests) */
@@ -108,6 +109,7 @@ sauGenerator *sauamd_internal::make_generator(const sauProgram *prg, uint32_t sr
 	if (!make_batch(g->batch, &prg, 1, srate, injected)) { delete g; return nullptr; }
 	if (const char *ra = getenv("SAU_AMD_READAHEAD")) g->ahead_frames = (size_t)atol(ra);
 	if (const char *rr = getenv("SAU_AMD_READAHEAD_RAMP")) g->ramp = atoi(rr) != 0;
+	if (const char *rg = getenv("SAU_AMD_READAHEAD_GROW")) { const int b = atoi(rg); if (b >= 1 && b <= 8) g->grow_bits = (unsigned)b; }
 	if (const char *rd = getenv("SAU_AMD_READAHEAD_DEPTH")) g->depth = atoi(rd) >= 2 ? 2 : 1;
 	return g;
 }
@@ -145,7 +147,7 @@ static bool generator_issue(sauGenerator *o, size_t big, size_t call_len, bool s
 	/* this run: whole host calls, four times as many as the run before, up to `big` (every run has a fixed cost of
 	 * about 0.1 ms: doubling cost the 95 corpus scripts 40 ms of their 410) */
 	size_t frames = big;
-	if (o->ramp && o->runs_issued < 12 && call_len && (call_len << (2 * o->runs_issued)) < big) frames = call_len << (2 * o->runs_issued);
+	if (o->ramp && o->runs_issued * o->grow_bits < 24 && call_len && (call_len << (o->grow_bits * o->runs_issued)) < big) frames = call_len << (o->grow_bits * o->runs_issued);
 	++o->runs_issued;
 	if (o->runs_issued == 1 && !o->batch.engine->reserve(big, stereo, err)) return false; /* (device buffers too) */
 	if (o->slot_cap[k] < big * ch) { /* (sized for the longest run at once: growing later would wait for the stream) */
