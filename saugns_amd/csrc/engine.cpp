@@ -502,8 +502,19 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 			if (end > st.part_gen) st.part_gen = end;
 		}
 	}
+	/* Every frame of the call belongs to some segment, and a segment's mixer writes a stream's frames [0, write_len): what lies
+	 * behind -- the stream's last voice has ended, or nothing of it sounds in this segment -- is cleared here, runs of streams
+	 * with the same share at a time (generator.c:911-914 clears the caller's whole buffer ahead of every call and adds into it;
+	 * round 6: a batch of 64 one-minute renders cleared 339 MB per run that its mixers then wrote frame for frame) */
+	for (size_t s = 0; s < sdescs.size();) {
+		size_t e = s + 1;
+		while (e < sdescs.size() && sdescs[e].write_len == sdescs[s].write_len) ++e;
+		if (sdescs[s].write_len < len &&
+		    !backend_->zero_pcm((uint32_t)s, (uint32_t)(e - s), offset + sdescs[s].write_len, len - sdescs[s].write_len, stereo, err))
+			return false;
+		s = e;
+	}
 	if (descs.empty()) return true;
-	out_dirty_ = true;
 	SegmentDesc seg;
 	seg.len = len; seg.pcm_offset = offset; seg.stereo = stereo; seg.swap_bytes = pcm_swap_;
 	seg.voices = descs.data(); seg.n_voices = (uint32_t)descs.size();
@@ -547,7 +558,6 @@ bool Engine::snapshot(Snapshot &s, int slot, std::string &err) {
 	}
 	s.frames_done = frames_done_;
 	s.call_len = call_len_; s.lat_call = lat_call_; s.call_phase = call_phase_;
-	s.out_dirty = out_dirty_;
 	if (!backend_->save_state(slot, err)) return false;
 	s.valid = true;
 	return true;
@@ -570,7 +580,6 @@ bool Engine::restore(const Snapshot &s, int slot, std::string &err) {
 	plans_dirty_ = true;
 	frames_done_ = s.frames_done;
 	call_len_ = s.call_len; lat_call_ = s.lat_call; call_phase_ = s.call_phase;
-	out_dirty_ = true; /* (whatever the abandoned runs left in the PCM block is cleared before the next one) */
 	return backend_->load_state(slot, err);
 }
 
@@ -585,10 +594,7 @@ bool Engine::run(int16_t *const *host_bufs, size_t buf_len, bool stereo,
 		reserved_frames_ = want;
 		reserved_stereo_ = stereo || reserved_stereo_;
 	}
-	if (out_dirty_) { /* generator.c:911-914 */
-		if (!backend_->clear_pcm(reserved_frames_, reserved_stereo_, err)) return false;
-		out_dirty_ = false;
-	}
+	/* (generator.c:911-914, the buffer cleared ahead of the call: render_segment clears what the mixers leave) */
 	for (Stream &st : streams_) { st.call_gen = 0; st.part_start = 0; st.part_gen = 0; }
 	{
 		const uint32_t want = call_len_ ? call_len_ : (total ? total : 1u);

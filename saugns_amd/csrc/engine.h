@@ -82,8 +82,11 @@ public:
 			const uint32_t *op_ids, size_t n_ids, std::string &err) = 0;
 	/* apply operator updates in order; ops are distinct within one call */
 	virtual bool apply_updates(const OpUpdate *recs, size_t n, std::string &err) = 0;
-	/* zero the PCM rows [0, frames) of every stream */
-	virtual bool clear_pcm(uint32_t frames, bool stereo, std::string &err) = 0;
+	/* zero the frames [first_frame, first_frame + n_frames) of the PCM rows of streams [first_stream, first_stream + n_streams):
+	 * what a run's mixers do not write (generator.c:911-914 clears the whole buffer ahead of every call; here only the frames
+	 * behind a stream's last voice and the segments nothing sounds in are cleared, ordered with the rendering like any device work) */
+	virtual bool zero_pcm(uint32_t first_stream, uint32_t n_streams, uint32_t first_frame, uint32_t n_frames, bool stereo,
+			std::string &err) = 0;
 	virtual bool render(const SegmentDesc &seg, std::string &err) = 0;
 	/* copy stream `s` PCM [0, frames) to host memory (blocks until done) */
 	virtual bool fetch_pcm(uint32_t stream, int16_t *dst, uint32_t frames,
@@ -283,7 +286,6 @@ private:
 	std::vector<uint32_t> all_op_ids_;
 	struct PlanRef { uint32_t plan_ofs, plan_len, ops_ofs, nops; };
 	std::vector<PlanRef> plan_refs_; /* indexed by global voice index */
-	bool out_dirty_ = false;         /* PCM written since last clear */
 	uint64_t frames_done_ = 0;
 	uint32_t call_len_ = 0;          /* set_call_len() */
 	uint32_t lat_call_ = 0;          /* call size of the lattice in force */

@@ -479,10 +479,14 @@ public:
 		return true;
 	}
 
-	bool clear_pcm(uint32_t frames, bool stereo, std::string &err) override {
+	bool zero_pcm(uint32_t first_stream, uint32_t n_streams, uint32_t first_frame, uint32_t n_frames, bool stereo,
+			std::string &err) override {
 		use_device();
-		(void)frames; (void)stereo;
-		if (pcm_.p) HIP_OK(hipMemsetAsync(pcm_.p, 0, pcm_row_ * cfg_.n_streams * sizeof(int16_t), stream_));
+		if (!pcm_.p || !n_streams || !n_frames) return true;
+		const size_t ch = stereo ? 2 : 1;
+		int16_t *at = pcm_.p + pcm_row_ * first_stream + (size_t)first_frame * ch;
+		if (n_streams == 1) HIP_OK(hipMemsetAsync(at, 0, (size_t)n_frames * ch * sizeof(int16_t), stream_));
+		else HIP_OK(hipMemset2DAsync(at, pcm_row_ * sizeof(int16_t), 0, (size_t)n_frames * ch * sizeof(int16_t), n_streams, stream_));
 		return true;
 	}
 
@@ -938,7 +942,8 @@ public:
 					set_tasks(cfp, groups_cf, grid_cf ? grid_cf : 1);
 					if (!launch_build(0, rows_cf, grid_cf ? grid_cf : 1, &cfp, 16 * area_cf(rows_cf), wide_cf)) launched = false;
 					fp.mode = fp.sum_levels + 1; fp.only_multi = 0; fp.look_wpv = look_wpv_; fp.look_groups = groups;
-					fp.look_wpv_flags = (tune_env("SAU_AMD_LOOK_NO_LDS") ? 1u : 0u) | (tune_env("SAU_AMD_LOOK_WITHHOLD") ? 2u : 0u);
+					fp.look_wpv_flags = (tune_env("SAU_AMD_LOOK_NO_LDS") ? 1u : 0u) | (tune_env("SAU_AMD_LOOK_WITHHOLD") ? 2u : 0u) |
+						(tune_env("SAU_AMD_LOOK_NO_SPREAD") ? 4u : 0u);
 					if (fp.look) {
 						const unsigned long long waves = (unsigned long long)seg.n_voices * (fp.look_words_real ? (groups < 64 ? groups : 64) : look_wpv_);
 						const uint32_t grid2 = waves > (unsigned long long)fk_grid_ * 16 ? fk_grid_ : (uint32_t)((waves + 15) / 16);

@@ -88,39 +88,7 @@ __device__ __forceinline__ Step uni(const Step &st) {
 	return c.s;
 }
 
-/* inclusive sum over the 64 lanes with DPP moves (no LDS): four shifts inside
- * each row of 16, then the rows' totals passed on with row_bcast 15 and 31 */
-__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
-#define SAU_DPP_ADD(ctrl, rmask) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xf, false)
-	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
-	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112 /* row_shr:2 */, 0xf, 0xf, true);
-	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114 /* row_shr:4 */, 0xf, 0xf, true);
-	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118 /* row_shr:8 */, 0xf, 0xf, true);
-	SAU_DPP_ADD(0x142 /* row_bcast:15 */, 0xa);
-	SAU_DPP_ADD(0x143 /* row_bcast:31 */, 0xc);
-#undef SAU_DPP_ADD
-	return v;
-}
-
-__device__ __forceinline__ unsigned long long wave_incl_scan64_dpp(unsigned long long v) {
-#define SAU_DPP_ADD64(ctrl, rmask, bc) do { \
-		const uint32_t lo_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, ctrl, rmask, 0xf, bc); \
-		const uint32_t hi_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), ctrl, rmask, 0xf, bc); \
-		v += ((unsigned long long)hi_ << 32) | lo_; } while (0)
-	SAU_DPP_ADD64(0x111, 0xf, true);
-	SAU_DPP_ADD64(0x112, 0xf, true);
-	SAU_DPP_ADD64(0x114, 0xf, true);
-	SAU_DPP_ADD64(0x118, 0xf, true);
-	SAU_DPP_ADD64(0x142, 0xa, false);
-	SAU_DPP_ADD64(0x143, 0xc, false);
-#undef SAU_DPP_ADD64
-	return v;
-}
-__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int lane) {
-	const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane);
-	const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
-	return ((unsigned long long)hi << 32) | lo;
-}
+#include "k_wave_scan.h" /* wave_incl_scan_dpp, wave_incl_scan64_dpp, wave_sum64_dpp, readlane64 */
 
 /* Decoupled look-back over a voice's row groups (FastParams.look). The calling wave owns group cg and its
  * group total `tot`; returns the sum of all earlier groups' totals. Words carry value and status together,
@@ -176,8 +144,10 @@ template <bool LDS> __device__ __forceinline__ uint32_t lookback32(unsigned long
 		const int first_pref = m_pref ? __builtin_ctzll(m_pref) : 64;
 		const int first_none = m_none ? __builtin_ctzll(m_none) : 64;
 		const int upto = first_pref < first_none ? first_pref + 1 : first_none; /* lanes [0, upto) count */
-		const uint32_t part = wave_incl_scan_dpp(l < upto && idx >= 0 ? (uint32_t)e : 0u);
-		excl += (uint32_t)__builtin_amdgcn_readlane((int)part, 63);
+		if (upto) { /* (an empty poll -- nothing new published -- adds nothing: no scan for it) */
+			const uint32_t part = wave_incl_scan_dpp(l < upto && idx >= 0 ? (uint32_t)e : 0u);
+			excl += (uint32_t)__builtin_amdgcn_readlane((int)part, 63);
+		}
 		if (first_pref < first_none) break;
 		p -= upto;
 		if (upto == 0) {
@@ -226,8 +196,7 @@ template <bool LDS> __device__ __forceinline__ unsigned long long lookback64(uns
 		const int first_none = m_none ? __builtin_ctzll(m_none) : 64;
 		const int upto = first_pref < first_none ? first_pref + 1 : first_none;
 		const unsigned long long v = ((unsigned long long)(uint32_t)b << 32) | (uint32_t)a;
-		const unsigned long long part = wave_incl_scan64_dpp(l < upto && idx >= 0 ? v : 0ull);
-		excl += readlane64(part, 63);
+		if (upto) excl += wave_sum64_dpp(l < upto && idx >= 0 ? v : 0ull);
 		if (first_pref < first_none) break;
 		p -= upto;
 		if (upto == 0) {

@@ -1234,11 +1234,21 @@ __global__ void FK_ATTR fast_kernel(FastParams P) {
 			wpv = wpv >= 64 ? 64u : wpv >= 32 ? 32u : wpv >= 16 ? 16u : wpv >= 8 ? 8u : wpv >= 4 ? 4u : wpv >= 2 ? 2u : 1u;
 		}
 		const uint32_t slots_v = total_waves / wpv; /* voices in flight at once */
-		if (g / wpv >= slots_v) return; /* (waves beyond the last whole voice) */
-		for (uint32_t j = g / wpv; j < NVl; j += slots_v) {
+		/* Which wave takes which voice. Voices inside a workgroup (wpv <= 16, rings in LDS): neighbouring waves, so that a SIMD's four
+		 * waves are four voices' (or, at 16 waves per voice, four groups of one). Voices spread over workgroups (wpv 32 or 64, words in
+		 * HBM; BASELINE config 4: 64 voices on 4096 waves): round 5 gave a voice 2 or 4 neighbouring workgroups -- every wave of a CU
+		 * then waits for the same voice's sums at the same time, nothing on the SIMD fills the gap (SQ_ACTIVE_INST_VALU 0.80), and the
+		 * waiting waves' polls were a quarter of the launch's vector instructions (profiles/census/r06_lookback_census.json). Round 6:
+		 * wave g takes voice slot g mod slots_v, group phase g / slots_v -- a workgroup's 16 waves are 16 different voices' -- and a
+		 * wave that waits leaves its SIMD to three others that do not. (Earlier groups of a round still belong to lower workgroups,
+		 * which are dispatched first.) look_wpv_flags & 4: round 5's placement (SAU_AMD_LOOK_NO_SPREAD, A/B) */
+		const bool spread = wpv >= 32 && !(P.look_wpv_flags & 4u);
+		const uint32_t j0 = spread ? g % slots_v : g / wpv, cs = spread ? g / slots_v : g % wpv;
+		if (j0 >= slots_v || cs >= wpv) return; /* (waves beyond the last whole voice) */
+		for (uint32_t j = j0; j < NVl; j += slots_v) {
 			const uint32_t v = P.vlists[NV + j];
 			const FastInfo fi = P.info[v];
-			fast_voice<T, 2, false, CUB, WIDE>(P, v, fi, slots, carry, tabs, l, wpv, g % wpv, lring, 0u, 0u, j);
+			fast_voice<T, 2, false, CUB, WIDE>(P, v, fi, slots, carry, tabs, l, wpv, cs, lring, 0u, 0u, j);
 		}
 		return;
 	}

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include "../../saugns_amd/csrc/sau_dev_ops.h"
 #include <stdint.h>
+#include "../../saugns_amd/csrc/k_wave_scan.h"
 
 using namespace saudev;
 
@@ -76,5 +77,29 @@ bool kat_line(const LineState &st, uint32_t len, const float *mul, float *out, L
 	if (d_mul) (void)hipFree(d_mul);
 	if (d_out) (void)hipFree(d_out);
 	if (d_st) (void)hipFree(d_st);
+	return ok;
+}
+
+/* the 64-bit wave scan and sum (k_wave_scan.h): one wave per 64 values */
+__global__ void kat_scan64_kernel(const unsigned long long *in, unsigned long long *scan, unsigned long long *sum) {
+	const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+	scan[i] = wave_incl_scan64_dpp(in[i]);
+	const unsigned long long t = wave_sum64_dpp(in[i]);
+	if (threadIdx.x == 0) sum[blockIdx.x] = t;
+}
+bool kat_scan64(const unsigned long long *in, unsigned long long *scan, unsigned long long *sum, uint32_t n_waves) {
+	unsigned long long *d_in = nullptr, *d_scan = nullptr, *d_sum = nullptr;
+	const size_t nb = (size_t)n_waves * 64 * sizeof(unsigned long long);
+	bool ok = hipMalloc((void **)&d_in, nb) == hipSuccess && hipMalloc((void **)&d_scan, nb) == hipSuccess &&
+		hipMalloc((void **)&d_sum, n_waves * sizeof(unsigned long long)) == hipSuccess &&
+		hipMemcpy(d_in, in, nb, hipMemcpyHostToDevice) == hipSuccess;
+	if (ok) {
+		hipLaunchKernelGGL(kat_scan64_kernel, dim3(n_waves), dim3(64), 0, 0, d_in, d_scan, d_sum);
+		ok = hipDeviceSynchronize() == hipSuccess && hipMemcpy(scan, d_scan, nb, hipMemcpyDeviceToHost) == hipSuccess &&
+			hipMemcpy(sum, d_sum, n_waves * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess;
+	}
+	if (d_in) (void)hipFree(d_in);
+	if (d_scan) (void)hipFree(d_scan);
+	if (d_sum) (void)hipFree(d_sum);
 	return ok;
 }

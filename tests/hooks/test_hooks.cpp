@@ -5,7 +5,8 @@
  *     the host control plane, the drop-in generator and the output stage over a caller-supplied sauengine::Backend
  *     (tests/seqexec: the sequential plan executor) -- host logic without a GPU
  *   sauAmd_Generator_rewinds: how often a changed call size / channel layout took a generator's read-ahead back
- *   sauAmd_kat_line_device / _host, sauAmd_kat_div_device: the shared arithmetic as compiled for the device and the host */
+ *   sauAmd_kat_line_device / _host, sauAmd_kat_div_device: the shared arithmetic as compiled for the device and the host
+ *   sauAmd_kat_scan64_device: the kernels' 64-bit wave scan and sum (k_wave_scan.h) over caller-supplied values */
 #include "../../saugns_amd/csrc/capi_internal.h"
 #include "../../saugns_amd/csrc/sau_dev_ops.h"
 #include <stdio.h>
@@ -16,6 +17,7 @@
 #ifndef SAU_HOOKS_NO_HIP
 bool kat_div(float a, int variant, unsigned long long *mismatches, uint32_t *first_bad);
 bool kat_line(const saudev::LineState &st, uint32_t len, const float *mul, float *out, saudev::LineState *st_out);
+bool kat_scan64(const unsigned long long *in, unsigned long long *scan, unsigned long long *sum, uint32_t n_waves);
 #endif
 
 HOOK sauGenerator *sauAmd_create_Generator_with_backend(const sauProgram *prg, uint32_t srate, void *backend) {
@@ -59,5 +61,9 @@ HOOK long long sauAmd_kat_div_device(uint32_t wave, int variant, uint32_t *first
 	if (wave >= 12 || !kat_div(sauengine::wave_consts()[wave].diff_scale, variant, &m, &fb)) return -1;
 	if (first_bad) *first_bad = fb;
 	return (long long)m;
+}
+/* in[64 * n_waves] -> scan[64 * n_waves] (inclusive per wave), sum[n_waves]; 0 on a device error */
+HOOK int sauAmd_kat_scan64_device(const unsigned long long *in, unsigned long long *scan, unsigned long long *sum, uint32_t n_waves) {
+	return kat_scan64(in, scan, sum, n_waves) ? 1 : 0;
 }
 #endif

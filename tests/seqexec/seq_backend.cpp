@@ -57,8 +57,9 @@ struct SeqBackend : public Backend {
 		for (size_t i = 0; i < n; ++i) apply_update(ops[r[i].op], r[i], wc);
 		return true;
 	}
-	bool clear_pcm(uint32_t, bool, std::string &) override {
-		for (auto &p : pcm) std::fill(p.begin(), p.end(), 0);
+	bool zero_pcm(uint32_t s0, uint32_t ns, uint32_t first, uint32_t n, bool stereo, std::string &) override {
+		const size_t ch = stereo ? 2 : 1;
+		for (uint32_t s = s0; s < s0 + ns; ++s) std::fill(pcm[s].begin() + (size_t)first * ch, pcm[s].begin() + (size_t)(first + n) * ch, 0);
 		return true;
 	}
 	double herp(uint32_t wave, uint32_t phase) const {

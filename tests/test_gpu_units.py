@@ -166,6 +166,31 @@ def test_differentiator_division_exhaustive(sa, hooks):
         assert fn(wave, 1, C.byref(first)) > 0
 
 
+def test_wave_scan_of_64_bit_values_counts_its_carries(hooks):
+    """k_wave_scan.h: the inclusive 64-bit scan (two 32-bit DPP scans + the wraps of the low words counted from one compare) and the
+    64-bit sum, against numpy's wrapping cumsum -- positive and negative increments (high words 0 and ~0: rasg.h:154-155 with a
+    negative rate), low words that wrap at every lane or never, random 64-bit values."""
+    rng = np.random.default_rng(606)
+    waves = []
+    waves.append(rng.integers(0, 1 << 32, 64, dtype=np.uint64))                       # small positive: hi = 0, wraps now and then
+    waves.append((-rng.integers(1, 1 << 32, 64).astype(np.int64)).astype(np.uint64))  # small negative: hi = ~0
+    waves.append(np.full(64, 0xffffffff, dtype=np.uint64))                            # wraps at every lane but the first
+    waves.append(np.full(64, 0x80000000, dtype=np.uint64))                            # wraps at every second lane
+    waves.append(np.zeros(64, dtype=np.uint64))
+    waves.append(np.full(64, 0xffffffffffffffff, dtype=np.uint64))
+    w = np.zeros(64, dtype=np.uint64); w[17] = 0xffffffff; w[18] = 1; waves.append(w)  # one wrap, exactly to zero
+    for _ in range(57):
+        waves.append(rng.integers(0, 1 << 63, 64, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, 64, dtype=np.uint64))
+    a = np.ascontiguousarray(np.stack(waves))
+    scan = np.zeros_like(a)
+    tot = np.zeros(len(waves), dtype=np.uint64)
+    assert hooks.sauAmd_kat_scan64_device(a.ctypes.data, scan.ctypes.data, tot.ctypes.data, len(waves))
+    with np.errstate(over="ignore"):
+        want = np.cumsum(a, axis=1, dtype=np.uint64)
+    assert (scan == want).all(), np.argwhere(scan != want)[:4]
+    assert (tot == want[:, 63]).all()
+
+
 @pytest.mark.parametrize("chunk", [1500, 20000])
 def test_running_sum_phases_across_runs(sa, oracle, chunk):
     """Ramped and modulated frequencies (phase = running sum of per-frame increments,
