@@ -114,6 +114,16 @@ def profile_step_valu(workload, kernel_prefix):
     return best
 
 
+def sha_checked(rec):
+    """Did this run compare a step's PCM with the compiled reference's SHA-256 (and pass: a mismatch aborts the run)?
+    False when the run had no such comparison (a reduced workload): never a claim that did not run."""
+    cfg = rec.get("config", {})
+    v = cfg.get("first_step_verified") or cfg.get("verified")
+    if isinstance(v, dict):
+        return bool(v.get("sha256"))
+    return isinstance(v, str) and v.startswith("SHA-256 of every one")
+
+
 def hbm_convention(achieved, alg, key="bytes_per_step"):
     """SURVEY 8d's byte model as a nested record: a convention (operator blocks priced as HBM traffic), not a roof the
     time-parallel kernels touch -- they keep those blocks in LDS."""
@@ -391,7 +401,7 @@ def run_bank(args, R, sa, tabs, name, steps=20, warmup=2):
                                peak=v["simd_cycles_per_launch"] if v else None, unit="SIMD-cycles per launch",
                                frac=v["frac"] if v else None, valu=v)
         out["valu_frac"] = v["frac"] if v else None
-    out["first_step_sha_ok"] = True
+    out["first_step_sha_ok"] = bool(verified and verified.get("sha256"))
     if not args.no_cpu and R.world == 1:
         out["cpu_baseline"] = cpu_reference(lambda: spec["make"](30), spec["what"].split(":")[0], spec["voices"], spec["ops"],
                                             tabs, budget_s=5.0)
@@ -512,6 +522,14 @@ def run_config3(args, R, sa, tabs):
         out["cpu_baseline"] = cpu_reference(lambda: voicebank.config3(n=args.voices, seconds=30),
                                             f"config 3 ({args.voices} voices x depth-3 PM)", args.voices, 4,
                                             tabs, all_cores=True)
+        # the same as top-level scalars (the driver's record keeps no nested objects; VERDICT r05 weak 7: the all-cores figure
+        # and its core count were lost with the nested one)
+        cb = out["cpu_baseline"]
+        out["cpu_1core_value"] = cb["value"]
+        ac = cb.get("all_cores") or {}
+        out["cpu_all_cores_value"] = ac.get("value")
+        out["cpu_cores"] = ac.get("cores")
+        out["cpu_kind"] = cb["kind"]
     return out
 
 
@@ -940,7 +958,9 @@ def main():
                 if name in others:
                     out[key + "_value"] = others[name]["value"]
                     out[key + "_ms_per_step"] = others[name]["ms_per_step"]
-                    out[key + "_sha_ok"] = True  # (each of these runs aborts on a mismatch with the compiled reference's SHA-256)
+                    # from the run's own record: a SHA-256 comparison with the compiled reference's that ran and held
+                    # -- config 5 at another voice count and config 4 cut short (--c4-frames) have none, and say so
+                    out[key + "_sha_ok"] = sha_checked(others[name])
             if R.world > 1 and "config4" in others:
                 # the north star's multi-GPU case at the top of an N > 1 line: 64 renders of rainy_thunder.sau per GPU,
                 # seeds shard_range(64 N, rank, N), no data-path collective (the full record stays under other_workloads)

@@ -52,6 +52,12 @@ typedef struct sauAmdBatch sauAmdBatch;
  * Programs are borrowed and must outlive the batch. NULL on failure. */
 SAU_AMD_API sauAmdBatch *sauAmd_create_Batch(const sauProgram *const *prgs, size_t n,
 		uint32_t srate);
+/* The same on HIP device `device` (0 <= device < sauAmd_device_count()) whatever SAU_AMD_DEVICE says: a host that shards
+ * independent renders over the GPUs of a node from one process (contiguous blocks of renders per GPU, no exchange
+ * step) creates one batch per device and runs them side by side -- every batch has its own stream, buffers, pools and budget
+ * for the feedback chains' rows. NULL on failure (sauAmd_last_error), also for a device that does not exist. */
+SAU_AMD_API sauAmdBatch *sauAmd_create_Batch_on(int device, const sauProgram *const *prgs, size_t n,
+		uint32_t srate);
 SAU_AMD_API void sauAmd_destroy_Batch(sauAmdBatch *b);
 
 /* Advance every stream by buf_len frames. bufs may be NULL, or hold one host

@@ -101,6 +101,9 @@ def _declare(L):
                                    C.POINTER(C.c_size_t)]
     L.sauAmd_create_Batch.restype = C.c_void_p
     L.sauAmd_create_Batch.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint32]
+    if hasattr(L, "sauAmd_create_Batch_on"):  # (SAU_AMD_LIB may name an older build)
+        L.sauAmd_create_Batch_on.restype = C.c_void_p
+        L.sauAmd_create_Batch_on.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.c_size_t, C.c_uint32]
     L.sauAmd_destroy_Batch.argtypes = [C.c_void_p]
     L.sauAmd_render_file.restype = C.c_bool
     L.sauAmd_render_file.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_int, C.c_int,
@@ -319,12 +322,15 @@ class Generator:
 class Batch:
     """Many programs rendered in lock step (sauAmd_*Batch*)."""
 
-    def __init__(self, programs, srate, backend=None):
+    def __init__(self, programs, srate, backend=None, device=None):
+        """device: the HIP device of this process to render on (sauAmd_create_Batch_on); None: SAU_AMD_DEVICE's, else device 0"""
         self._prgs = list(programs)
         self.n = len(self._prgs)
         arr = (C.c_void_p * self.n)(*[p.ptr for p in self._prgs])
         self._L = _used(lib() if backend is None else hooks())
-        if backend is None:
+        if backend is None and device is not None:
+            self._b = self._L.sauAmd_create_Batch_on(int(device), arr, self.n, srate)
+        elif backend is None:
             self._b = self._L.sauAmd_create_Batch(arr, self.n, srate)
         else:  # tests only: host control plane on an injected executor, in the hook library
             self._b = self._L.sauAmd_create_Batch_with_backend(arr, self.n, srate, backend)

@@ -9,7 +9,7 @@ LIB = os.path.join(HERE, "libsaugns_amd.so")
 SOURCES = ["capi.cpp", "engine.cpp", "plan.cpp", "tables.cpp", "program_io.cpp", "sndout.cpp", "bank_builder.cpp",
            "hip_backend.hip"]
 HEADERS = ["engine.h", "hip_backend.h", "capi_internal.h", "sau_dev_math.h", "sau_dev_ops.h",
-           "k_common.h", "k_wave_scan.h", "k_block_loop.h", "k_fast_types.h", "k_analyze.h", "k_decode.h", "k_fast_voice.h",
+           "k_common.h", "k_wave_scan.h", "k_block_loop.h", "k_fast_types.h", "k_analyze.h", "k_decode.h", "k_fast_voice.h", "k_fast_group.h",
            "k_chain.h", "k_finish.h",  # parts of hip_backend.hip
            "sau_dev_types.h", "../../include/sau_abi.h", "../../include/saugns_amd.h"]
 # -ffp-contract=off: the arithmetic contract forbids FMA contraction

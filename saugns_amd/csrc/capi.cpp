@@ -78,14 +78,14 @@ extern "C" const char *const sauNoise_names[SAU_NOISE_NAMED + 1] = {
 };
 
 static bool make_batch(sauAmdBatch &b, const sauProgram *const *prgs, size_t n,
-		uint32_t srate, Backend *injected) {
+		uint32_t srate, Backend *injected, int device = -1) {
 	std::string err;
 	b.engine = nullptr;
 	b.hip = nullptr;
 	Backend *be = injected;
 	const auto t0 = std::chrono::steady_clock::now();
 	if (!be) {
-		b.hip = sauhip::create_hip_backend(err);
+		b.hip = sauhip::create_hip_backend(err, device);
 		if (!b.hip) { report("generator", err); return false; }
 		be = b.hip;
 	}
@@ -288,11 +288,18 @@ extern "C" sauAmdBatch *sauAmd_create_Batch(const sauProgram *const *prgs, size_
 	return sauamd_internal::make_batch_over(prgs, n, srate, nullptr);
 }
 
-sauAmdBatch *sauamd_internal::make_batch_over(const sauProgram *const *prgs, size_t n, uint32_t srate, Backend *injected) {
+sauAmdBatch *sauamd_internal::make_batch_over(const sauProgram *const *prgs, size_t n, uint32_t srate, Backend *injected, int device) {
 	if (!prgs || !n) return nullptr;
 	sauAmdBatch *b = new sauAmdBatch();
-	if (!make_batch(*b, prgs, n, srate, injected)) { delete b; return nullptr; }
+	if (!make_batch(*b, prgs, n, srate, injected, device)) { delete b; return nullptr; }
 	return b;
+}
+
+/* include/saugns_amd.h: a batch on HIP device `device` of this process (a C host that spreads independent renders over the
+ * node's GPUs: one batch per device, each with its own stream, buffers and chain-row budget; no device < 0) */
+extern "C" sauAmdBatch *sauAmd_create_Batch_on(int device, const sauProgram *const *prgs, size_t n, uint32_t srate) {
+	if (device < 0) { report("generator", "sauAmd_create_Batch_on: no device " + std::to_string(device)); return nullptr; }
+	return sauamd_internal::make_batch_over(prgs, n, srate, nullptr, device);
 }
 
 extern "C" void sauAmd_destroy_Batch(sauAmdBatch *b) {

@@ -11,7 +11,7 @@
 namespace sauamd_internal {
 /* sau_create_Generator / sauAmd_create_Batch over a caller-supplied backend (owned by the object made; NULL: the HIP one) */
 sauGenerator *make_generator(const sauProgram *prg, uint32_t srate, sauengine::Backend *injected);
-sauAmdBatch *make_batch_over(const sauProgram *const *prgs, size_t n, uint32_t srate, sauengine::Backend *injected);
+sauAmdBatch *make_batch_over(const sauProgram *const *prgs, size_t n, uint32_t srate, sauengine::Backend *injected, int device = -1);
 /* how often a call of another size or channel layout took this generator's read-ahead back (capi.cpp: generator_rewind) */
 unsigned generator_rewinds(const sauGenerator *g);
 /* sauAmd_render_file's body (sndout.cpp) */

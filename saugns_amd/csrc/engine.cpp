@@ -29,31 +29,9 @@ const char *tune_env(const char *name) {
 	return on ? getenv(name) : nullptr;
 }
 
-static std::atomic<size_t> g_chain_rows_free_hint{0};
-void chain_rows_note_device_memory(size_t free_bytes) {
-	size_t zero = 0; /* the first device the process opens decides (one budget per process: segments are cut on the host) */
-	g_chain_rows_free_hint.compare_exchange_strong(zero, free_bytes);
-}
-/*  a failed allocation of rows halves the budget from there on -- it does not take it away: the failure may have
- * been one engine's, on one device of several, with the pool holding idle blocks (which pool_alloc now gives back first) */
-static std::atomic<unsigned> g_chain_rows_alloc_failures{0};
-void chain_rows_note_alloc_failure() { g_chain_rows_alloc_failures.fetch_add(1); }
-size_t chain_rows_budget() {
-	static const long long env_mb = [] {
-		const char *v = getenv("SAU_AMD_CHAIN_ROWS_MB");
-		return v ? atoll(v) : -1ll;
-	}();
-	const unsigned fails = g_chain_rows_alloc_failures.load();
-	const unsigned sh = fails > 40 ? 40 : fails; /* (after a few failures: segments with feedback voices are CHAIN_SEG frames) */
-	if (env_mb >= 0) return ((size_t)env_mb << 20) >> sh;
-	const size_t dflt = (size_t)24 << 30; /* of an MI355X's 288 GB */
-	const size_t free_b = g_chain_rows_free_hint.load();
-	if (!free_b) return dflt >> sh; /* no device told (the sequential executor of the tests) */
-	return (free_b / 8 < dflt ? free_b / 8 : dflt) >> sh; /* a smaller or fuller device: an eighth of what was free when it was opened */
-}
-uint32_t chain_seg_frames(size_t n_chains) {
+uint32_t chain_seg_frames(size_t n_chains, size_t budget) {
 	if (!n_chains) return CHAIN_SEG;
-	const size_t f = chain_rows_budget() / (n_chains * 8);
+	const size_t f = budget / (n_chains * 8);
 	if (f <= CHAIN_SEG) return CHAIN_SEG;
 	return f > (1u << 22) ? (1u << 22) : (uint32_t)f & ~63u;
 }
@@ -669,7 +647,7 @@ bool Engine::run(int16_t *const *host_bufs, size_t buf_len, bool stereo,
 				const uint32_t cut = (first + EXPIRY_GRID - 1) / EXPIRY_GRID * EXPIRY_GRID;
 				if (cut < seg) seg = cut;
 			}
-			if (chains && seg > chain_seg_frames(chains)) seg = chain_seg_frames(chains); /* rows in HBM carry one segment of every recurrence */
+			if (chains && seg > chain_seg_frames(chains, backend_->chain_rows_budget())) seg = chain_seg_frames(chains, backend_->chain_rows_budget()); /* rows in HBM carry one segment of every recurrence */
 		}
 		for (Stream &st : streams_)
 			if (st.event < st.events.size()) st.event_pos += seg;

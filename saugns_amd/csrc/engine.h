@@ -60,6 +60,27 @@ struct SegmentDesc {
 	uint32_t n_look_rows = 0; /* rows the voices' look_base/n_look span (those of them without feedback chains) */
 };
 
+/* Bytes a backend has for the rows of a segment's feedback chains (8 B per chain and frame; the engine cuts segments with
+ * feedback voices accordingly, never below CHAIN_SEG frames). free_bytes: what was free on the backend's device when the
+ * process first opened it (0: not told -- the sequential executor of the tests); alloc_failures: allocations of rows that
+ * failed on this backend. SAU_AMD_CHAIN_ROWS_MB sets the budget; without it: 24 GiB (288 GB of HBM hold BASELINE config 5's
+ * 4096 chains x 441000 frames, 14.4 GB, as one segment -- one fill and one drain of the pass / chain pipeline),
+ * or an eighth of free_bytes where that is less; every failed allocation halves it (the backend renders the segment that did
+ * not fit in the block loop). Per backend since round 6 (Backend::chain_rows_budget): the hint used to be the first device's
+ * of the process and the failures every engine's -- one full GPU of eight cut every other GPU's segments short (ADVICE r04,
+ * VERDICT r05). (inline: the test executor's library has the interface without engine.cpp) */
+inline size_t chain_rows_budget(size_t free_b, unsigned fails) {
+	static const long long env_mb = [] {
+		const char *v = getenv("SAU_AMD_CHAIN_ROWS_MB");
+		return v ? atoll(v) : -1ll;
+	}();
+	const unsigned sh = fails > 40 ? 40 : fails; /* (after a few failures: segments with feedback voices are CHAIN_SEG frames) */
+	if (env_mb >= 0) return ((size_t)env_mb << 20) >> sh;
+	const size_t dflt = (size_t)24 << 30; /* of an MI355X's 288 GB */
+	if (!free_b) return dflt >> sh;
+	return (free_b / 8 < dflt ? free_b / 8 : dflt) >> sh;
+}
+
 struct BackendConfig {
 	uint32_t srate;
 	uint32_t op_count;        /* all streams */
@@ -69,6 +90,7 @@ struct BackendConfig {
 	const float *piluts;      /* 12 x 2048 */
 	const WaveConst *wconst;  /* 12 */
 };
+
 
 class Backend {
 public:
@@ -107,6 +129,9 @@ public:
 	 * with the rendering like any other device work. */
 	virtual bool save_state(int slot, std::string &err) { (void)slot; err = "this backend keeps no state snapshots"; return false; }
 	virtual bool load_state(int slot, std::string &err) { (void)slot; err = "this backend keeps no state snapshots"; return false; }
+	/* bytes this backend has for the feedback chains' rows of one segment (engine.h: chain_rows_budget; the engine cuts segments
+	 * with such voices accordingly) */
+	virtual size_t chain_rows_budget() { return sauengine::chain_rows_budget(0, 0); }
 };
 
 /* ---- plan compiler (plan.cpp) -------------------------------------------- */
@@ -162,22 +187,12 @@ bool voice_plan_shape(const std::vector<OpMirror> &ops, uint32_t carrier, std::v
 /* Segments with feedback voices are at most this long: the recurrences' inputs and outputs pass
  * through per-chain rows in HBM, sized for one segment. */
 constexpr uint32_t CHAIN_SEG = 131072;
-/* ... at least; longer where the rows of the segment's chains (8 B per chain and frame) stay within the budget below:
- * 288 GB of HBM hold BASELINE config 5's 4096 chains x 441000 frames (14.4 GB) as one segment, and a segment is one
- * fill and one drain of the pass / chain pipeline. SAU_AMD_CHAIN_ROWS_MB sets another budget. */
-size_t chain_rows_budget();
-/* ... without that setting: 24 GiB, or an eighth of the memory that was free on the device when the process first opened it
- * (hipMemGetInfo, told here by the backend) where that is less. */
-void chain_rows_note_device_memory(size_t free_bytes);
-/* ... and every allocation of rows that fails halves the budget for the rest of the process (the backend renders the
- * segment that did not fit in the block loop); segments with feedback voices are never cut below CHAIN_SEG frames. */
-void chain_rows_note_alloc_failure();
 /* Environment switches. Product settings are read as they are (INTEGRATION.md has the table: SAU_AMD_DEVICE,
  * SAU_AMD_READAHEAD*, SAU_AMD_LOOP_TAILS, SAU_AMD_CHAIN_ROWS_MB, SAU_AMD_POOL_MB, SAU_AMD_PINNED_POOL_MB, SAU_AMD_DEBUG*);
  * every other SAU_AMD_* name is a tuning or test aid and is looked at only when SAU_AMD_TUNE is set -- a stray variable
  * in a host's environment cannot change how, or on which kernels, a render runs. */
 const char *tune_env(const char *name);
-uint32_t chain_seg_frames(size_t n_chains);
+uint32_t chain_seg_frames(size_t n_chains, size_t budget_bytes);
 
 class Engine {
 public:

@@ -18,8 +18,9 @@ public:
 	virtual bool order_after(HipBackend *before, std::string &err) = 0;
 };
 
-/* NULL (with err) when no HIP device is usable: there is no CPU fallback. */
-HipBackend *create_hip_backend(std::string &err);
+/* NULL (with err) when no HIP device is usable: there is no CPU fallback. device >= 0: that HIP device (sauAmd_create_Batch_on);
+ * -1: the one SAU_AMD_DEVICE names, else device 0. */
+HipBackend *create_hip_backend(std::string &err, int device = -1);
 int device_count();
 /* "domain:bus:device.function" of HIP device `dev` (bench.py: one rank per physical GPU, proved in the result line) */
 bool device_pci_bus_id(int dev, char *buf, int len);

@@ -41,6 +41,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 namespace sauhip {
@@ -314,6 +315,7 @@ bool device_pci_bus_id(int dev, char *buf, int len) {
 
 class HipBackendImpl : public HipBackend {
 public:
+	explicit HipBackendImpl(int device = -1) : want_dev_(device) {}
 	/* every entry point runs on this backend's device, whatever the host thread's current one is
 	 * (another generator on another GPU, torch.cuda.set_device): allocations, the pools (keyed by
 	 * the current device) and launches all follow it */
@@ -335,7 +337,9 @@ public:
 		cfg_ = cfg;
 		int dev = 0;
 		const char *env = getenv("SAU_AMD_DEVICE");
-		if (env) dev = atoi(env);
+		if (want_dev_ >= 0) dev = want_dev_; /* (sauAmd_create_Batch_on: the caller's choice goes before the environment's) */
+		else if (env) dev = atoi(env);
+		if (dev < 0 || dev >= device_count()) { err = "no HIP device " + std::to_string(dev) + " (" + std::to_string(device_count()) + " visible)"; return false; }
 		HIP_OK(hipSetDevice(dev));
 		dev_ = dev;
 		stream_ = StreamPool::get().take(dev);
@@ -343,6 +347,7 @@ public:
 		static std::mutex prop_mu;
 		static size_t dev_lds[16]; /* per device: hipGetDeviceProperties costs a millisecond */
 		static uint32_t dev_cus[16];
+		static size_t dev_free[16]; /* bytes free when the process first opened the device: the chain rows' budget follows it */
 		{
 			std::lock_guard<std::mutex> lk(prop_mu);
 			if (!dev_lds[dev & 15]) {
@@ -352,8 +357,9 @@ public:
 				                                                          : prop.sharedMemPerBlock;
 				dev_cus[dev & 15] = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : FK_GRID;
 				size_t mfree = 0, mtotal = 0; /* the budget of the feedback chains' rows follows what this device has free */
-				if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess) sauengine::chain_rows_note_device_memory(mfree);
+				if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess) dev_free[dev & 15] = mfree;
 			}
+			free_hint_ = dev_free[dev & 15];
 			lds_limit_ = dev_lds[dev & 15];
 			/* the time-parallel kernels' grids are one 1024-thread workgroup per CU at most: waves that wait for other
 			 * workgroups' sums (spread look-back launches) need the whole grid resident, so the grid follows the CUs
@@ -385,6 +391,7 @@ public:
 		mix_few_enabled_ = tune_env("SAU_AMD_NO_MIX_FEW") == nullptr;
 		early_mix_enabled_ = tune_env("SAU_AMD_NO_EARLY_MIX") == nullptr;
 		inmix_enabled_ = tune_env("SAU_AMD_NO_INMIX") == nullptr;
+		tailmix_enabled_ = tune_env("SAU_AMD_TAILMIX") != nullptr;
 		xcd_queues_ = tune_env("SAU_AMD_NO_XCD_QUEUES") == nullptr;
 		inmix_report_ = tune_env("SAU_AMD_INMIX_REPORT") != nullptr;
 		if (const char *ia = tune_env("SAU_AMD_INMIX_AT")) inmix_at_ = (uint32_t)atoi(ia) & 15u;
@@ -728,7 +735,7 @@ public:
 			/* feedback chains: a pair of rows per chain in HBM, one segment long (the engine keeps segments
 			 * with such voices within CHAIN_SEG frames); without them those voices take the block loop */
 			bool chains = chain_enabled_ && use_fast && fp.scan && seg.serial && seg.n_chain_rows &&
-				seg.len <= sauengine::chain_seg_frames(seg.n_chain_rows);
+				seg.len <= sauengine::chain_seg_frames(seg.n_chain_rows, chain_rows_budget());
 			if (chains) {
 				const uint32_t cstride = (seg.len + 63) & ~63u;
 				/* The rows are the one large allocation that depends on how long the engine cut the segment. When the device
@@ -743,7 +750,7 @@ public:
 				const size_t rows_want = (rft && !rows_fail_test) ? (size_t)1 << 44 : (size_t)seg.n_chain_rows * 2 * cstride + 64;
 				if (rows_fail_test || !chain_rows_.ensure(rows_want, rows_err)) {
 					chain_rows_failed_once_ = true;
-					sauengine::chain_rows_note_alloc_failure();
+					++chain_rows_failures_; /* (this backend's budget halves: Backend::chain_rows_budget) */
 					if (debug_) fprintf(stderr, "saugns_amd: %zu bytes of chain rows not available (%s): block loop for this segment\n",
 							((size_t)seg.n_chain_rows * 2 * cstride + 64) * sizeof(float), rows_err.c_str());
 					chains = false;
@@ -864,11 +871,13 @@ public:
 						err = "internal error: no fast_kernel build with " + std::to_string(rows) + " rows per pass in this form";
 						return false;
 					}
-					if (wide && build == 2 && rows == 8) { /* the look-back build with wide table blocks (round 5: where the lean buffer numbering leaves LDS for them) */
-						static size_t lwconfigured[16];
-						const void *lk = (const void *)fast_kernel<8, 2, false, true>;
-						const size_t lds = ft * (size_t)FAST_TAB_BYTES_WIDE + a16 + LOOK_LDS_BYTES;
-						if (!raise_lds_attr(lk, lds, lwconfigured[dev_ & 15], err)) return false;
+					if (build == 2 && rows == 8 && (wide || tail_live_)) { /* the look-back build with wide table blocks (round 5: where the lean buffer numbering leaves LDS for them), and / or the one that mixes few-voice streams (round 6: FastParams.tail_ok) */
+						static size_t lwconfigured[16][3];
+						const int li = wide ? (tail_live_ ? 2 : 0) : 1;
+						const void *lk = wide ? (tail_live_ ? (const void *)fast_kernel<8, 2, false, true, true> : (const void *)fast_kernel<8, 2, false, true>)
+						                      : (const void *)fast_kernel<8, 2, false, false, true>;
+						const size_t lds = ft * (wide ? (size_t)FAST_TAB_BYTES_WIDE : ftab_bytes) + a16 + LOOK_LDS_BYTES;
+						if (!raise_lds_attr(lk, lds, lwconfigured[dev_ & 15][li], err)) return false;
 						HIP_OK(hipLaunchKernel(lk, dim3(grid), dim3(1024), args, lds, stream_));
 						return true;
 					}
@@ -932,6 +941,19 @@ public:
 					}
 				};
 				FastParams cfp; /* the closed-form launch of a split segment (also what repair_kernel runs with) */
+				tail_live_ = false;
+				if (main_build == 2 && fp.look && FT == 8 && tailmix_enabled_ && max_write && !fp.cub_ok && seg.len < (1u << 30) &&
+				    mix_few_enabled_ && max_rows <= 8 && seg.n_streams >= 8 && (seg.pcm_offset & 3u) == 0 && (pcm_row_ & 3u) == 0) {
+					/* many streams of a few voices (a batch of small scripts): where a stream's last row is a look-back voice's and the
+					 * others are closed-form voices', the look-back launch mixes the stream as it stores that row (k_fast_types.h:
+					 * FastParams.tail_ok) and mix_few_kernel has nothing left to do (SAU_AMD_TAILMIX; off by default: see tailmix_enabled_) */
+					if (!tail_ok_.ensure(seg.n_streams, err)) return false;
+					fp.tail_ok = tail_ok_.p; fp.inmix_stream = S.mstreams.p;
+					fp.tail_flags = (seg.stereo ? 1u : 0u) | (seg.swap_bytes ? 2u : 0u);
+					fp.tail_pcm_offset = seg.pcm_offset;
+					hipLaunchKernelGGL(tailmix_kernel, dim3((seg.n_streams + 63) / 64), dim3(64), 0, stream_, fp, seg.n_streams);
+					tail_live_ = true;
+				}
 				if (main_build == 2) {
 					/* two launches over analyze_kernel's lists: the closed-form voices, then the look-back voices */
 					cfp = fp;
@@ -943,7 +965,7 @@ public:
 					if (!launch_build(0, rows_cf, grid_cf ? grid_cf : 1, &cfp, 16 * area_cf(rows_cf), wide_cf)) launched = false;
 					fp.mode = fp.sum_levels + 1; fp.only_multi = 0; fp.look_wpv = look_wpv_; fp.look_groups = groups;
 					fp.look_wpv_flags = (tune_env("SAU_AMD_LOOK_NO_LDS") ? 1u : 0u) | (tune_env("SAU_AMD_LOOK_WITHHOLD") ? 2u : 0u) |
-						(tune_env("SAU_AMD_LOOK_NO_SPREAD") ? 4u : 0u);
+						(tune_env("SAU_AMD_LOOK_SPREAD") ? 4u : 0u);
 					if (fp.look) {
 						const unsigned long long waves = (unsigned long long)seg.n_voices * (fp.look_words_real ? (groups < 64 ? groups : 64) : look_wpv_);
 						const uint32_t grid2 = waves > (unsigned long long)fk_grid_ * 16 ? fk_grid_ : (uint32_t)((waves + 15) / 16);
@@ -1222,6 +1244,8 @@ public:
 			mp.early_blocks = early_mixed_blocks_;
 			early_mixed_blocks_ = 0;
 			mp.inmix = inmix_live_ ? inmix_ctl_.p : nullptr; /* (the closed-form launch has mixed tiles itself: mix_kernel takes what is left) */
+			mp.tail_ok = tail_live_ ? tail_ok_.p : nullptr; /* (the look-back launch has mixed some streams itself: mix_few_kernel leaves them) */
+			tail_live_ = false;
 			inmix_live_ = false;
 			/* (on the generator's one stream, behind the segment's kernels. Round 3 built the mixer on a stream of its own beside the
 			 * next segment's kernels -- ordinary grid or persistent on a few CUs, everything it reads and writes double-buffered --
@@ -1262,7 +1286,7 @@ public:
 		mp.row_stride = row_stride_; mp.pcm_offset = seg.pcm_offset;
 		mp.stereo = seg.stereo ? 1 : 0;
 		mp.swap_bytes = seg.swap_bytes ? 1 : 0;
-		mp.blk_lo = 0; mp.blk_hi = 0; mp.early_blocks = 0; mp.guard = work_count_.p; mp.inmix = nullptr;
+		mp.blk_lo = 0; mp.blk_hi = 0; mp.early_blocks = 0; mp.guard = work_count_.p; mp.inmix = nullptr; mp.tail_ok = nullptr;
 		return mp;
 	}
 
@@ -1349,6 +1373,7 @@ public:
 		if (reset) { acc_ms_[0] = acc_ms_[1] = acc_ms_[2] = acc_ms_[3] = 0; acc_launches_ = 0; }
 	}
 
+	size_t chain_rows_budget() override { return sauengine::chain_rows_budget(free_hint_, chain_rows_failures_); }
 	void *stream_handle() override { return (void *)stream_; }
 	bool order_after(HipBackend *before, std::string &err) override {
 		HipBackendImpl *o = static_cast<HipBackendImpl *>(before);
@@ -1509,6 +1534,7 @@ private:
 	DevBuf<uint32_t> pass_flags_, repair_;
 	hipEvent_t fetch_ev_[4] = {nullptr, nullptr, nullptr, nullptr}; /* per host slot of the drop-in generator's read-ahead */
 	int dev_ = 0;
+	int want_dev_ = -1; /* the device the creator asked for (-1: SAU_AMD_DEVICE, else 0) */
 	std::map<void *, size_t> host_blocks_; /* alloc_host() blocks and their pool sizes */
 	uint32_t multi_min_ = 256;
 	uint32_t multi_teams_ = 16; /* SAU_AMD_MULTI_TEAMS: 8 or 16 single-wave teams per workgroup */
@@ -1528,6 +1554,8 @@ private:
 	std::vector<hipEvent_t> chain_ev_;
 	DevBuf<float> chain_rows_;
 	bool chain_rows_failed_once_ = false;
+	unsigned chain_rows_failures_ = 0; /* allocations of rows that failed on this backend */
+	size_t free_hint_ = 0;             /* bytes free on the device when the process first opened it */
 	DevBuf<ChainDesc> chain_desc_;
 	DevBuf<unsigned char> fplines_;
 	uint32_t block_grid_ = 1;
@@ -1545,6 +1573,12 @@ private:
 	uint32_t inmix_at_ = 13;           /* which of a chunk's tasks mix the chunk before: from this many sixteenths into it (SAU_AMD_INMIX_AT) */
 	bool inmix_report_ = false;       /* SAU_AMD_INMIX_REPORT: a line on stderr per such segment (tests) */
 	DevBuf<uint32_t> inmix_ctl_;
+	DevBuf<uint32_t> tail_ok_;        /* [stream]: the look-back launch mixes this stream itself (k_fast_types.h: FastParams.tail_ok) */
+	bool tailmix_enabled_ = false;    /* SAU_AMD_TAILMIX: the look-back launch mixes few-voice streams itself. Exact (357 GPU tests with it on), and
+	                                   * measured slower: BASELINE config 4 4.19 -> 4.26 ms per step -- the launch is issue-bound and pays 0.32 ms for
+	                                   * the six flops, the clamp and the conversion per frame (and 42 spilled registers), the mixer gives back 0.25
+	                                   * (profiles/r06_ab.txt). Off; kept for the record */
+	bool tail_live_ = false;          /* this segment's look-back launch did: mix_few_kernel looks at tail_ok_ */
 	bool wide_tabs_ = true;
 	uint32_t more_rows_ = 12;
 	uint32_t lean_rows_ = 6;    /* SAU_AMD_LEAN_ROWS: rows per pass of fast_kernel<T, 3> at most (6, 5 or 4) */
@@ -1555,12 +1589,12 @@ private:
 	bool look_inside_ = true;   /* inside one workgroup (LDS rings, no waits across workgroups) */
 };
 
-HipBackend *create_hip_backend(std::string &err) {
+HipBackend *create_hip_backend(std::string &err, int device) {
 	if (device_count() <= 0) {
 		err = "no HIP device available (this backend has no CPU fallback)";
 		return nullptr;
 	}
-	return new HipBackendImpl();
+	return new HipBackendImpl(device);
 }
 
 } /* namespace sauhip */

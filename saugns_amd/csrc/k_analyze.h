@@ -439,7 +439,7 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 	 * closed-form voices have repair_kernel for that case (see FAST_REPAIR_SHIFT). */
 	if (seq || has_chain) ++x_carrier;
 	fi.n_chain = has_chain && !bad ? 1u : 0u;
-	fi.H = maxd + x_carrier; fi.xlead = x_carrier; fi.bail = 0; fi.n_fsteps = 0; fi.n_pass[0] = fi.n_pass[1] = fi.n_pass[2] = fi.n_pass[3] = 0; fi.seq = seq_kind; fi.cub = has_rcub ? 1u : 0u; fi.early = (early && has_chain && !bad) ? 1u : 0u; fi.n_scan = n_scan_out; fi.levels = levels_out; fi.lvl_bits = lvl_bits_out;
+	fi.H = maxd + x_carrier; fi.xlead = x_carrier; fi.bail = 0; fi.n_fsteps = 0; fi.n_pass[0] = fi.n_pass[1] = fi.n_pass[2] = fi.n_pass[3] = 0; fi.seq = seq_kind; fi.cub = has_rcub ? 1u : 0u; fi.early = (early && has_chain && !bad) ? 1u : 0u; fi.n_scan = n_scan_out; fi.levels = levels_out; fi.lvl_bits = lvl_bits_out; fi.tail = 0; fi.tail_stream = 0;
 	fi.total = 0;
 	if ((seq || has_chain) && !P.seq_enable) bad = true;
 	if (!bad && vd.nops <= P.max_ops && vd.plan_len <= P.max_steps && maxd >= 1 && maxd + x_carrier <= P.np / 2)

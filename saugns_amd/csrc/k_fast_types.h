@@ -34,6 +34,10 @@ struct FastInfo {
 	                   * sum passes (FastParams.chain_early), and every pass reads their samples from the rows (FT_CHAIN_EARLY) */
 	uint32_t cub;     /* a closed-form voice with an R oscillator of `cub` segments and the reference's loop tails on: rendered by
 	                   * the closed-form build with the tail code, fast_kernel<4, 0, true>, and by no other launch */
+	uint32_t tail;    /* round 6 (tailmix_kernel, k_finish.h): this voice is the last row of a stream of a few voices whose other rows the
+	                   * launch before has written, and the look-back launch that renders it mixes the stream as it stores: the rows
+	                   * of the stream (this one included), or 0 */
+	uint32_t tail_stream; /* ... and the stream's index (FastParams.inmix_stream[]) */
 };
 
 /* A wave table in the time-parallel kernels' LDS: per table one block -- [c3, c2] x 2048 (f64 pairs), then [c1, c0] x 2048.
@@ -232,4 +236,11 @@ struct FastParams {
 	uint32_t inmix_div_m, inmix_div_s; /* the voice count as a divisor: q / n_voices = udiv_magic(q, m, s), scalar instructions only (a task's number -> chunk, voice) */
 	uint32_t inmix_flags, inmix_pcm_offset; /* 64: this launch takes its tasks from the XCDs' queues; 32: ... and mixes (premix_kernel has run); 1: stereo PCM,
 	                                         * 2: byte-swapped; 4: timing aid; bits 8-11: which tasks mix (sixteenths into a chunk). MixParams.pcm_offset */
+	/* Streams of a few voices each (a batch of small scripts: BASELINE config 4 has a closed-form and a look-back voice per render):
+	 * the look-back launch mixes such a stream while it stores the stream's last row (FastInfo.tail) -- per frame it reads the
+	 * rows before from HBM (written by the closed-form launch that ran first), adds its own sample in the mixer's order and writes
+	 * the PCM; mix_few_kernel then skips the stream unless the guards say a row changed afterwards. tail_ok: one word per stream
+	 * (tailmix_kernel's verdict), or NULL; inmix_stream is then the streams' array; tail_flags: 1 stereo PCM, 2 byte-swapped */
+	uint32_t *tail_ok;
+	uint32_t tail_flags, tail_pcm_offset;
 };

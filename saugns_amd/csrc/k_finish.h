@@ -163,6 +163,37 @@ __global__ void __launch_bounds__(64) premix_kernel(FastParams P) {
 	P.vinfo[vd.out_row] = vo;
 }
 
+/* Streams of a few voices whose last row is a look-back voice's and whose other rows are closed-form voices' (FastParams.tail_ok):
+ * which of them the look-back launch mixes itself. A thread per stream, after analyze_kernel and ahead of both launches: every
+ * row on the time-parallel path to the stream's end with a constant pan, the last one by the look-back build through its
+ * oscillator step, the others by the closed-form launch that runs first. What happens later -- a hold that sends a voice to the
+ * block loop, a repaired group -- shows in the mixer's guards, and mix_few_kernel then mixes the stream again (k_fast_group.h). */
+__global__ void __launch_bounds__(64) tailmix_kernel(FastParams P, uint32_t n_streams) {
+	const uint32_t s = blockIdx.x * 64 + threadIdx.x;
+	if (s >= n_streams) return;
+	const MixStream ms = P.inmix_stream[s];
+	bool ok = ms.n_rows >= 1 && ms.n_rows <= 8 && ms.write_len > 0;
+	const uint32_t last = ms.first_row + ms.n_rows - 1;
+	for (uint32_t r = ms.first_row; ok && r <= last; ++r) {
+		const FastInfo fi = P.info[r];
+		const VoiceDesc vd = P.voices[r];
+		if (fi.total != ms.write_len || fi.total != vd.run_len || fi.cub || fi.bail || vd.pan_dynamic_row != ~0u || vd.out_row != r) ok = false;
+		if (fi.seq != (r == last ? 3u : 0u)) ok = false;
+		if (vd.plan_len == 0 || P.steps[vd.plan_ofs + vd.plan_len - 1].kind == ST_VOICE) ok = false; /* (its carrier's step stores the row) */
+	}
+	P.tail_ok[s] = ok ? 1u : 0u;
+	if (!ok) return;
+	for (uint32_t r = ms.first_row; r <= last; ++r) { /* the rows' mixer records, as finalize_kernel will write them */
+		const VoiceDesc vd = P.voices[r];
+		VoiceOut vo;
+		vo.pan_const = P.ops[(P.op_ids + vd.ops_ofs)[vd.carr_local]].line[L_PAN].v0; /* (a held line: finalize_kernel's advance leaves v0 alone) */
+		vo.has_pan = 0u; vo.valid_len = P.info[r].total; vo.pan_row = ~0u;
+		P.vinfo[r] = vo;
+	}
+	P.info[last].tail = ms.n_rows;
+	P.info[last].tail_stream = s;
+}
+
 struct MixParams {
 	const MixStream *streams;
 	const float *vout;
@@ -177,6 +208,7 @@ struct MixParams {
 	uint32_t blk_lo, blk_hi, early_blocks;
 	const uint32_t *guard;
 	const uint32_t *inmix; /* the closed-form launch has mixed tiles itself (k_fast_types.h): its control words, or NULL */
+	const uint32_t *tail_ok; /* [stream]: the look-back launch has mixed the stream itself (FastParams.tail_ok), or NULL */
 };
 
 /* generator.c:749-825: ordered voice sum (ref-build association) and PCM.
@@ -317,6 +349,9 @@ __global__ void __launch_bounds__(256) mix_few_kernel(MixParams P) {
 	const MixStream ms = P.streams[blockIdx.y];
 	const uint32_t i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
 	if (i0 >= ms.write_len) return;
+	/* mixed by the launch that rendered its last row, and nothing has touched a row since (no voice on the block loop's list, no
+	 * repaired group): done */
+	if (P.tail_ok && P.tail_ok[blockIdx.y] && P.guard[0] == 0 && P.guard[1] == 0) return;
 	float L[4] = {0.f, 0.f, 0.f, 0.f}, R[4] = {0.f, 0.f, 0.f, 0.f};
 	const bool full = i0 + 4 <= ms.write_len;
 	for (uint32_t r = 0; r < ms.n_rows; ++r) {

@@ -148,6 +148,8 @@ def seqexec(hooks):
     lib = C.CDLL(path)
     lib.seq_backend_create.restype = C.c_void_p
     lib.seq_backend_create.argtypes = [C.c_uint32]
+    lib.seq_backend_set_memory.argtypes = [C.c_void_p, C.c_ulonglong, C.c_uint]
+    lib.seq_backend_segments.argtypes = [C.c_void_p, C.c_void_p]
     return lib
 
 

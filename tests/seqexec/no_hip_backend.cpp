@@ -6,7 +6,7 @@
 #include "../../saugns_amd/csrc/hip_backend.h"
 
 namespace sauhip {
-HipBackend *create_hip_backend(std::string &err) { err = "no HIP device (sanitizer build of the host control plane: there is no device backend in it)"; return nullptr; }
+HipBackend *create_hip_backend(std::string &err, int) { err = "no HIP device (sanitizer build of the host control plane: there is no device backend in it)"; return nullptr; }
 int device_count() { return 0; }
 bool device_pci_bus_id(int, char *, int) { return false; }
 } /* namespace sauhip */

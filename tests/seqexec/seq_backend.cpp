@@ -29,6 +29,12 @@ struct SeqBackend : public Backend {
 	WaveConst wc[12];
 	std::vector<std::vector<int16_t>> pcm;
 	uint32_t max_frames = 0;
+	/* a stand-in for a device's memory (tests/test_host.py: two "devices" with budgets of their own): what was free when it was
+	 * opened (0: not told), failed allocations of chain rows, segments rendered and the longest of them */
+	size_t free_hint = 0;
+	unsigned row_failures = 0;
+	uint32_t segments = 0, longest = 0;
+	size_t chain_rows_budget() override { return sauengine::chain_rows_budget(free_hint, row_failures); }
 
 	explicit SeqBackend(uint32_t b) : block(b) {}
 
@@ -46,7 +52,8 @@ struct SeqBackend : public Backend {
 	}
 	bool reserve_frames(uint32_t n, bool, std::string &) override {
 		max_frames = n;
-		for (auto &p : pcm) p.assign((size_t)n * 2, 0);
+		/* (poisoned, not zero: what a run leaves unwritten -- neither mixed nor cleared by Engine::render_segment -- shows) */
+		for (auto &p : pcm) p.assign((size_t)n * 2, (int16_t)0x5a5a);
 		return true;
 	}
 	bool upload_plans(const Step *s, const FastIds *, size_t ns, const uint32_t *ids, size_t ni, std::string &) override {
@@ -303,6 +310,7 @@ struct SeqBackend : public Backend {
 	}
 
 	bool render(const SegmentDesc &seg, std::string &) override {
+		++segments; if (seg.len > longest) longest = seg.len;
 		g_last_counts[0] = seg.n_main; g_last_counts[1] = seg.n_fast; g_last_counts[2] = seg.n_fast_full;
 		g_last_counts[3] = seg.may_scan ? 1u : 0u; g_last_counts[4] = seg.serial ? 1u : 0u;
 		std::vector<std::vector<float>> vout(seg.n_voices), pan(seg.n_voices);
@@ -357,4 +365,12 @@ extern "C" __attribute__((visibility("default"))) void seq_backend_last_counts(u
 
 extern "C" __attribute__((visibility("default"))) void *seq_backend_create(uint32_t block_len) {
 	return new SeqBackend(block_len ? block_len : 1024);
+}
+/* the backend as a device with `free_bytes` free and `failures` failed allocations of chain rows so far */
+extern "C" __attribute__((visibility("default"))) void seq_backend_set_memory(void *be, unsigned long long free_bytes, unsigned failures) {
+	((SeqBackend *)be)->free_hint = (size_t)free_bytes; ((SeqBackend *)be)->row_failures = failures;
+}
+/* out2: segments rendered so far, the longest of them in frames (read before the batch that owns the backend is closed) */
+extern "C" __attribute__((visibility("default"))) void seq_backend_segments(void *be, uint32_t *out2) {
+	out2[0] = ((SeqBackend *)be)->segments; out2[1] = ((SeqBackend *)be)->longest;
 }

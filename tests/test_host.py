@@ -557,6 +557,36 @@ def test_dropin_generator_follows_changes_of_call_size_and_layout(sa, oracle, se
     assert rewinds > 30, rewinds  # (the read-ahead was on and was taken back, not bypassed)
 
 
+def test_every_backend_has_its_own_budget_for_the_chains_rows(sa, oracle, seqexec):
+    """VERDICT r05 item 8 / ADVICE r04: the budget of the feedback chains' rows -- which decides where the engine cuts segments with
+    feedback voices -- belongs to the backend (its device's free memory, its own failed allocations), not to the process: two
+    sequential executors stand in for two devices, one roomy, one nearly full and with two failed allocations behind it. The same
+    4 feedback voices are cut into segments of different lengths, each by its own budget, and a third engine on the roomy
+    "device" afterwards is not affected by the other's failures. Same PCM every time."""
+    import ctypes as C
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
+    from saugns_amd import voicebank as vb
+    prg = vb.config5(n=4, seconds=8)  # 4 chains x 8 s at 48 kHz: 384000 frames
+    want = oracle.oracle_render(prg.ptr, 48000, False)
+
+    def run(free_bytes, failures):
+        be = seqexec.seq_backend_create(1024)
+        seqexec.seq_backend_set_memory(be, free_bytes, failures)
+        b = sa.Batch([prg], 48000, backend=be)
+        got = b.render(stereo=False, chunk=len(want))[0]
+        seg = (C.c_uint32 * 2)()
+        seqexec.seq_backend_segments(be, seg)
+        b.close()
+        assert max_diff(got, want) == 0
+        return seg[0], seg[1]
+
+    roomy = run(64 << 30, 0)          # an eighth of 64 GiB: the whole render is one segment (4 chains x 8 B x 384000 frames)
+    tight = run(256 << 20, 2)         # 256 MiB free, two failures: (32 MiB >> 2) / 32 B = 262144 frames per segment
+    assert roomy[1] >= len(want) and roomy[0] <= 2, roomy
+    assert tight[1] == 262144 and tight[0] >= 2, tight
+    assert run(64 << 30, 0) == roomy  # the tight device's failures are its own
+
+
 def test_product_library_exports_only_the_abi():
     """test probes and hooks are not exports of libsaugns_amd.so (they live in tests/hooks). What it
     exports is include/saugns_amd.h + the reference's four generator symbols (+ the kernels' host stubs, which hipcc emits

@@ -93,7 +93,7 @@ def classify(op):
 def lambda_names():
     """the lambdas of fast_voice by the source lines of their bodies (read off the source: `auto name = [&]`)"""
     names = {}
-    src = open(os.path.join(ROOT, "saugns_amd", "csrc", "k_fast_voice.h")).read().splitlines()
+    src = open(os.path.join(ROOT, "saugns_amd", "csrc", "k_fast_group.h")).read().splitlines()
     cur, depth = None, 0
     for n, ln in enumerate(src, 1):
         m = re.match(r"\s*auto (\w+) = \[&\]", ln)
@@ -124,10 +124,14 @@ def load(name):
     dis = subprocess.run([LLVM + "llvm-objdump", "-d", "--no-show-raw-insn", "--start-address=%#x" % lo,
                           "--stop-address=%#x" % (lo + size), WORK + "/kg.elf"], capture_output=True, text=True).stdout
     ins = []
+    rng = os.environ.get("CENSUS_RANGE")  # "lo:hi", byte offsets within the kernel: one copy of a group body that is there twice
     for ln in dis.splitlines():
         m = re.match(r"\s+(\S+)\s*(.*?)\s*// ([0-9A-F]+):", ln)
         if m:
-            ins.append({"addr": int(m.group(3), 16), "op": m.group(1), "args": m.group(2)})
+            a = int(m.group(3), 16)
+            if rng and not (int(rng.split(":")[0], 0) <= a - lo < int(rng.split(":")[1], 0)):
+                continue
+            ins.append({"addr": a, "op": m.group(1), "args": m.group(2)})
     sym = subprocess.run([LLVM + "llvm-symbolizer", "--obj=" + WORK + "/kg.elf", "--inlines", "--functions=short", "--output-style=JSON"],
                          input="\n".join("%#x" % i["addr"] for i in ins), capture_output=True, text=True).stdout
     for i, ln in zip(ins, sym.splitlines()):
@@ -136,7 +140,7 @@ def load(name):
         i["stack"] = stack
         # the statement of fast_voice this instruction belongs to (the outermost frame in fast_voice), the lines of the lambdas
         # defined in fast_voice on the way down (prev_of, lead32, freq_at ...), and the helper chain below them
-        fvs = [k for k, f in enumerate(stack) if f[0] == "k_fast_voice.h" and f[2] in ("fast_voice", "operator()")]
+        fvs = [k for k, f in enumerate(stack) if f[0] == "k_fast_group.h" and f[2] in ("fast_voice", "operator()")]
         if not fvs:
             i["fv_line"] = None
             i["inner"] = []
@@ -176,7 +180,7 @@ def cmd_lines(name):
 def cmd_census(name, rules_file, out_file):
     """RULES.json: {"workload": ..., "rows": T, "ops_per_voice": n, "groups_per_launch": g (optional, for the check against PMC),
     "measured": {"SQ_INSTS_VALU": per launch (wave-instructions), ...} (optional),
-    "rules": [[first_line, last_line, times_per_group, "why"], ...]}  -- lines of k_fast_voice.h inside fast_voice;
+    "rules": [[first_line, last_line, times_per_group, "why"], ...]}  -- lines of k_fast_group.h (the row group's evaluation in fast_voice);
     a line no rule names executes 0 times (cold: segment edges, hold resolution, other step kinds)."""
     rules = json.load(open(rules_file))
     ins = load(name)
