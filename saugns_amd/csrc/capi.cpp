@@ -67,6 +67,16 @@ struct sauGenerator {
 	unsigned runs_issued = 0;
 	bool ramp = true;                      /* SAU_AMD_READAHEAD_RAMP=0: every run ahead_frames long */
 	unsigned grow_bits = 2;                /* a run is 2^grow_bits times the one before (SAU_AMD_READAHEAD_GROW) */
+	/* Round 6: how long the runs are follows what the script costs. Every run has a fixed cost (about 0.15 ms of launches and
+	 * bookkeeping on the device: BASELINE config 3's 10 s took 3.34 ms in runs of 1, 4, 15, 15, 5 calls and 2.68 ms as one run,
+	 * profiles/r06_ab.txt), so a script is rendered in as few runs as the host's first wait allows: the first run is what an
+	 * estimate of the script's cost per frame puts at FIRST_RUN_NS (whole calls, at least one), the runs after it grow
+	 * 2^grow_bits-fold up to what it puts at LATER_RUN_NS (at least ahead_frames, at most MAX_RUN_FRAMES and what 4 GiB of
+	 * voice rows hold). The estimate is deliberately pessimistic (closed-form voices run four times faster): a script too
+	 * heavy for it starts, as before, with one call. SAU_AMD_READAHEAD=<frames> fixes the later runs' length instead. */
+	double est_ns_frame = 0;               /* estimated device time per frame of this script (make_generator) */
+	size_t run_cap = 0;                    /* frames per run at most (memory), 0: none */
+	bool ahead_set = false;                /* SAU_AMD_READAHEAD given: the later runs are ahead_frames long */
 	size_t ahead_call = 0;                 /* the call size the buffered runs were issued for (their block lattice) */
 	Engine::Snapshot snap[SLOTS];          /* the engine before the run in each slot */
 	unsigned rewinds = 0;                  /* times a changed call took the engine back (sauAmd_Generator_rewinds: tests) */
@@ -107,7 +117,21 @@ sauGenerator *sauamd_internal::make_generator(const sauProgram *prg, uint32_t sr
 	if (!prg) return nullptr;
 	sauGenerator *g = new sauGenerator();
 	if (!make_batch(g->batch, &prg, 1, srate, injected)) { delete g; return nullptr; }
-	if (const char *ra = getenv("SAU_AMD_READAHEAD")) g->ahead_frames = (size_t)atol(ra);
+	if (const char *ra = getenv("SAU_AMD_READAHEAD")) { g->ahead_frames = (size_t)atol(ra); g->ahead_set = true; }
+	{ /* the script's cost per frame, from what its program says: every operator as if it ran all the time, at the rate of
+	   * the slower time-parallel builds; a self-modulated oscillator anywhere makes every frame a step of a recurrence */
+		bool feedback = false;
+		for (size_t e = 0; e < prg->ev_count && !feedback; ++e)
+			for (uint32_t d = 0; d < prg->events[e].op_data_count; ++d) {
+				const sauLine *pm = prg->events[e].op_data[d].pm_a;
+				if (pm && (((pm->flags & SAU_LINEP_STATE) && pm->v0 != 0.f) || ((pm->flags & SAU_LINEP_GOAL) && pm->vt != 0.f))) { feedback = true; break; }
+			}
+		g->est_ns_frame = 1.0 + 0.004 * (double)prg->op_count + (feedback ? 120.0 : 0.0);
+		const size_t vo = prg->vo_count ? prg->vo_count : 1;
+		g->run_cap = ((size_t)1 << 30) / vo; /* (4 GiB of f32 voice rows) */
+		const size_t script = (size_t)((uint64_t)prg->duration_ms * srate / 1000) + 1; /* (no run needs to be longer than the script) */
+		if (script < g->run_cap) g->run_cap = script;
+	}
 	if (const char *rr = getenv("SAU_AMD_READAHEAD_RAMP")) g->ramp = atoi(rr) != 0;
 	if (const char *rg = getenv("SAU_AMD_READAHEAD_GROW")) { const int b = atoi(rg); if (b >= 1 && b <= 8) g->grow_bits = (unsigned)b; }
 	if (const char *rd = getenv("SAU_AMD_READAHEAD_DEPTH")) g->depth = atoi(rd) >= 2 ? 2 : 1;
@@ -147,7 +171,14 @@ static bool generator_issue(sauGenerator *o, size_t big, size_t call_len, bool s
 	/* this run: whole host calls, four times as many as the run before, up to `big` (every run has a fixed cost of
 	 * about 0.1 ms: doubling cost the 95 corpus scripts 40 ms of their 410) */
 	size_t frames = big;
-	if (o->ramp && o->runs_issued * o->grow_bits < 24 && call_len && (call_len << (o->grow_bits * o->runs_issued)) < big) frames = call_len << (o->grow_bits * o->runs_issued);
+	if (o->ramp && call_len) {
+		/* the first run: what the estimate puts at FIRST_RUN_NS, in whole calls (at least one); then 2^grow_bits-fold from run to run */
+		constexpr double FIRST_RUN_NS = 3e6;
+		size_t first = (size_t)(FIRST_RUN_NS / o->est_ns_frame) / call_len * call_len;
+		if (first < call_len) first = call_len;
+		const unsigned sh = o->grow_bits * o->runs_issued;
+		if (sh < 24 && first < (big >> sh)) frames = first << sh;
+	}
 	++o->runs_issued;
 	if (o->runs_issued == 1 && !o->batch.engine->reserve(big, stereo, err)) return false; /* (device buffers too) */
 	if (o->slot_cap[k] < big * ch) { /* (sized for the longest run at once: growing later would wait for the stream) */
@@ -242,7 +273,16 @@ static bool generator_run(sauGenerator *o, int16_t *buf, size_t buf_len, bool st
 		return generator_fail(o, buf, buf_len, stereo, out_len, err);
 	if (o->pos == o->len && !o->queued && (o->ahead_frames == 0 || buf_len >= o->ahead_frames))
 		return generator_run(o, buf, buf_len, stereo, out_len); /* (nothing buffered any more and the call is large: straight into the caller's buffer, above) */
-	const size_t big = buf_len >= o->ahead_frames ? buf_len : o->ahead_frames / buf_len * buf_len;
+	size_t big = buf_len >= o->ahead_frames ? buf_len : o->ahead_frames / buf_len * buf_len;
+	if (!o->ahead_set && o->ramp && o->est_ns_frame > 0) { /* (see sauGenerator::est_ns_frame) */
+		constexpr double LATER_RUN_NS = 20e6;
+		constexpr size_t MAX_RUN_FRAMES = (size_t)1 << 20;
+		size_t want = (size_t)(LATER_RUN_NS / o->est_ns_frame);
+		if (want > MAX_RUN_FRAMES) want = MAX_RUN_FRAMES;
+		if (o->run_cap && want > o->run_cap) want = o->run_cap;
+		want = (want + buf_len - 1) / buf_len * buf_len;
+		if (want > big) big = want;
+	}
 	o->batch.engine->set_call_len(buf_len);
 	size_t filled = 0;
 	bool issued = false;

@@ -393,6 +393,7 @@ public:
 		inmix_enabled_ = tune_env("SAU_AMD_NO_INMIX") == nullptr;
 		tailmix_enabled_ = tune_env("SAU_AMD_TAILMIX") != nullptr;
 		xcd_queues_ = tune_env("SAU_AMD_NO_XCD_QUEUES") == nullptr;
+		inmix_taper_ = tune_env("SAU_AMD_INMIX_TAPER") != nullptr;
 		inmix_report_ = tune_env("SAU_AMD_INMIX_REPORT") != nullptr;
 		if (const char *ia = tune_env("SAU_AMD_INMIX_AT")) inmix_at_ = (uint32_t)atoi(ia) & 15u;
 		if (const char *mv = tune_env("SAU_AMD_INMIX_MIN_VOICES")) inmix_min_voices_ = (uint32_t)atoi(mv);
@@ -1119,6 +1120,18 @@ public:
 					 * launch against the one counter in voice order */
 					if (fp.inmix && main_build == 0 && !fp.dyn_static && fp.dyn_chunks >= 16 && !fp.cub_ok) {
 						fp.inmix_flags = 64u; /* (analyze_kernel has cleared the queues) */
+						/* ... whose last eight chunks are short ones (k_fast_types.h: INMIX_NCH1): a quarter of a task's row groups, where the
+						 * segment has at least four regular chunks per XCD besides */
+						if (inmix_taper_) {
+							const uint32_t S_ = seg.max_steps ? seg.max_steps : 1;
+							uint32_t G = dyn_groups_;
+							if (G * S_ < 48) G = (48 + S_ - 1) / S_;
+							const uint32_t small = G / 4 ? G / 4 : 1;
+							if (groups >= 32 * G + INMIX_NSMALL * small) {
+								fp.dyn_small = small;
+								fp.dyn_chunks = (groups - INMIX_NSMALL * small + G - 1) / G + INMIX_NSMALL;
+							}
+						}
 						{ /* the voice count as a divisor (k_fast_voice.h: udiv_magic) */
 							const uint32_t d = seg.n_voices;
 							uint32_t sh = 0;
@@ -1138,7 +1151,7 @@ public:
 						}
 					}
 					launch_fast(0);
-					fp.dyn_chunks = 0; fp.inmix_flags = 0;
+					fp.dyn_chunks = 0; fp.inmix_flags = 0; fp.dyn_small = 0;
 				}
 				{ /* closed-form voices with the loop tails of `cub` R segments (FastInfo.cub): the build with that code,
 				   * FAST_CUB_ROWS rows per pass, fixed strides over the same voices as the closed-form launch; returns at
@@ -1267,14 +1280,20 @@ public:
 				(void)hipMemcpy(h.data(), mp.inmix, INMIX_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost);
 				(void)hipMemcpy(g, work_count_.p, sizeof g, hipMemcpyDeviceToHost);
 				const uint32_t nch = h[INMIX_NCH] < INMIX_MAX_CHUNKS ? h[INMIX_NCH] : INMIX_MAX_CHUNKS, tpc = h[INMIX_TPC];
-				uint32_t tiles = 0, whole = 0;
+				uint32_t tiles = 0, whole = 0, all = 0;
 				for (uint32_t k = 0; k < nch; ++k) {
+					/* (the chunk's tiles: a regular chunk's, or a short one's at the end -- k_fast_types.h: INMIX_NCH1) */
+					uint32_t lo_f = k * h[INMIX_CF], hi_f = lo_f + h[INMIX_CF];
+					if (k >= h[INMIX_NCH1]) { lo_f = h[INMIX_BASE] + (k - h[INMIX_NCH1]) * h[INMIX_CFS]; hi_f = lo_f + h[INMIX_CFS]; }
+					else if (hi_f > h[INMIX_BASE]) hi_f = h[INMIX_BASE];
+					if (hi_f > max_write) hi_f = max_write;
+					const uint32_t tk = hi_f > lo_f ? (hi_f - lo_f + INMIX_TILE - 1) / INMIX_TILE : 0u;
 					uint32_t c = 0;
-					for (uint32_t j = 0; j < tpc && j < INMIX_MAX_TPC; ++j) c += (h[INMIX_CHUNK + INMIX_LINE * k + INMIX_BITS + (j >> 5)] >> (j & 31u)) & 1u;
-					tiles += c; whole += c == tpc ? 1u : 0u;
+					for (uint32_t j = 0; j < tk && j < tpc && j < INMIX_MAX_TPC; ++j) c += (h[INMIX_CHUNK + INMIX_LINE * k + INMIX_BITS + (j >> 5)] >> (j & 31u)) & 1u;
+					tiles += c; whole += c == tk ? 1u : 0u; all += tk;
 				}
 				fprintf(stderr, "[sau-amd] inmix: voices %u frames %u chunks %u x %u frames, tiles %u of %u, chunks mixed whole %u, guard %u %u\n",
-						seg.n_voices, max_write, nch, h[INMIX_CF], tiles, nch * tpc, whole, g[0], g[1]);
+						seg.n_voices, max_write, nch, h[INMIX_CF], tiles, all, whole, g[0], g[1]);
 			}
 		}
 		return true;
@@ -1570,6 +1589,8 @@ private:
 	bool inmix_enabled_ = true;       /* a many-voice stream's closed-form launch mixes its own rows (SAU_AMD_NO_INMIX: the mixer alone) */
 	uint32_t inmix_min_voices_ = 64;  /* ... from that many voices on (SAU_AMD_INMIX_MIN_VOICES) */
 	bool inmix_live_ = false;         /* this segment's launch did: mix_kernel looks at the control words */
+	bool inmix_taper_ = false;        /* SAU_AMD_INMIX_TAPER: the queues' last eight chunks are short ones, so that less is left to mix_kernel. Measured
+	                                   * slower on config 3 (2.04 -> 2.08 ms per step, the launch 1.91 -> 1.94: profiles/r06_ab.txt): off */
 	uint32_t inmix_at_ = 13;           /* which of a chunk's tasks mix the chunk before: from this many sixteenths into it (SAU_AMD_INMIX_AT) */
 	bool inmix_report_ = false;       /* SAU_AMD_INMIX_REPORT: a line on stderr per such segment (tests) */
 	DevBuf<uint32_t> inmix_ctl_;

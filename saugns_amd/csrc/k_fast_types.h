@@ -95,6 +95,38 @@ constexpr uint32_t FT_CUBTAIL = 1u << 19;   /* ... an R oscillator with `cub` se
                                              * frames until it, an ancestor or the voice stops (TailCtx.rem) */
 constexpr uint32_t CHAIN_MARK = 0xC4A10001u; /* DevOp.ras_level of a W operator: chain_kernel staged its state */
 
+/* Chunk c's run of row groups [lo, hi) of a voice's ngroups: K chunks asked for by the host; small > 0: the last INMIX_NSMALL of
+ * them `small` groups long, the others sharing what is in front (and numbered first). Used alike by fast_voice (a task's groups),
+ * premix_kernel (the chunks' frames) and, through its control words, the tiles and mix_kernel. -> regular chunks there are, the
+ * group the short ones begin at (ngroups: none), groups per regular chunk */
+constexpr uint32_t INMIX_NSMALL = 8; /* short chunks at the end of the closed-form launch's queues: one per XCD (see INMIX_NCH1 below) */
+struct FkChunks { uint32_t nch1, body, per; };
+__device__ __forceinline__ FkChunks fk_chunk_groups(const uint32_t ngroups, const uint32_t K, const uint32_t small, const uint32_t c,
+		uint32_t &lo, uint32_t &hi) {
+	FkChunks q;
+	if (!small || K <= INMIX_NSMALL || ngroups <= 2 * INMIX_NSMALL * small) {
+		q.per = K ? (ngroups + K - 1) / K : ngroups;
+		q.body = ngroups;
+		q.nch1 = q.per ? (ngroups + q.per - 1) / q.per : 0u;
+		lo = c * q.per;
+		if (lo > ngroups) lo = ngroups;
+		hi = lo + q.per < ngroups ? lo + q.per : ngroups;
+		return q;
+	}
+	q.body = ngroups - INMIX_NSMALL * small;
+	q.per = (q.body + (K - INMIX_NSMALL) - 1) / (K - INMIX_NSMALL);
+	q.nch1 = (q.body + q.per - 1) / q.per;
+	if (c < q.nch1) {
+		lo = c * q.per;
+		hi = lo + q.per < q.body ? lo + q.per : q.body;
+	} else {
+		lo = q.body + (c - q.nch1) * small;
+		if (lo > ngroups) lo = ngroups;
+		hi = lo + small < ngroups ? lo + small : ngroups;
+	}
+	return q;
+}
+
 struct MixStream {
 	uint32_t first_row, n_rows;
 	float amp_scale;
@@ -130,6 +162,11 @@ constexpr uint32_t INMIX_TILE = 256;        /* frames per tile: four per lane, 1
 constexpr uint32_t INMIX_LINE = 32;         /* words per line */
 constexpr uint32_t INMIX_CF = 0;            /* [0]: frames per chunk, [1]: tiles per chunk, [2]: chunks (premix_kernel; read-only in the launch) */
 constexpr uint32_t INMIX_TPC = 1, INMIX_NCH = 2;
+/* Round 6: the queues' last chunks are short ones. A chunk's tiles are mixed by the tasks of the XCD's next chunk, so each XCD's
+ * last chunk is left to mix_kernel -- 8 of config 3's 48 chunks, 65 us of a 2 ms step. With the last eight chunks a quarter as
+ * long (FastParams.dyn_small row groups each) it is 8 short ones of 56. [3]: chunks of the regular length (they come first),
+ * [4]: the frame the short ones begin at (~0u: there are none), [5]: frames per short chunk */
+constexpr uint32_t INMIX_NCH1 = 3, INMIX_BASE = 4, INMIX_CFS = 5;
 constexpr uint32_t INMIX_QUEUE = 1 * INMIX_LINE; /* + INMIX_LINE x: XCD x's task counter */
 constexpr uint32_t INMIX_CHUNK = 9 * INMIX_LINE; /* + INMIX_LINE k: chunk k's line -- [0] own-XCD tasks that have stored their rows, [8 + j / 32] bit j % 32: tile j is mixed */
 constexpr uint32_t INMIX_DONE = 0, INMIX_BITS = 8;
@@ -208,6 +245,7 @@ struct FastParams {
 	 * segment's mixer) hold nobody up at the end. 0: static shares (waves stride over voices and groups). */
 	uint32_t dyn_chunks;
 	uint32_t dyn_static; /* 1: the same tasks in fixed strides over the launch's waves, no counter (SAU_AMD_NO_DYN) */
+	uint32_t dyn_small;  /* > 0: the last eight of the dyn_chunks runs are this many row groups long (fk_chunk_groups) */
 	/* Voices with feedback chains whose other oscillators all have closed-form phases (a chain that sums its own
 	 * increments counts as such: BASELINE config 5) take no sum pass, no scan and no saved increments: their
 	 * chain-input and final passes run in a build of their own, fast_kernel<T, 3> -- fast_voice without the code of

@@ -190,9 +190,7 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 		}
 	}
 	if (!REPAIR && SCAN == 0 && dyn_k) { /* this task's run of consecutive groups */
-		const uint32_t per = (ngroups + dyn_k - 1) / dyn_k;
-		it_lo = dyn_c * per;
-		n_iter = min(ngroups, it_lo + per);
+		(void)fk_chunk_groups(ngroups, dyn_k, P.dyn_small, dyn_c, it_lo, n_iter);
 	}
 	/* this voice's launch mixes its stream as it stores the row (FastInfo.tail, k_fast_types.h): rows of the stream, or 0 */
 	const uint32_t tail_n = (TAIL && SCAN == 2 && !REPAIR && !CUB && P.tail_ok) ? uni(fi.tail) : 0u;
@@ -272,16 +270,17 @@ __device__ __forceinline__ uint32_t udiv_magic(const uint32_t q, const uint32_t 
 }
 typedef float __attribute__((ext_vector_type(4))) inmix_f4;
 typedef uint32_t __attribute__((ext_vector_type(4))) inmix_u4;
-__device__ __forceinline__ void inmix_tile(const InmixArgs &A, const uint32_t k, const uint32_t j, const uint32_t cf, const int l) {
+__device__ __forceinline__ void inmix_tile(const InmixArgs &A, const uint32_t cs, const uint32_t ce /* the chunk's first frame, its end */,
+		const uint32_t j, const int l) {
 	const MixStream ms = *A.stream;
-	const uint32_t i0 = k * cf + j * INMIX_TILE + 4u * (uint32_t)l; /* this lane's first frame */
-	const uint32_t end = min((k + 1) * cf, ms.write_len);
+	const uint32_t i0 = cs + j * INMIX_TILE + 4u * (uint32_t)l; /* this lane's first frame */
+	const uint32_t end = min(ce, ms.write_len);
 	/* (a row's address: a buffer descriptor at the batch's first row + the row's offset in a scalar register + the lane's offset in
 	 * ONE vector register for all the loads in flight. As plain pointers the compiler made per-lane 64-bit addresses of them, two
 	 * registers per load. The host sees to it that INMIX_AHEAD rows span less than 4 GiB. Lanes past the chunk's end load its
 	 * first frames and store nothing; a lane across the end loads up to three frames of the row beyond it -- row_stride is a
 	 * multiple of 64 frames and no smaller than the stream -- and stores only its own.) */
-	const uint32_t off = (i0 < end ? i0 : k * cf) * 4u;
+	const uint32_t off = (i0 < end ? i0 : cs) * 4u;
 	const float *rows = A.vout + (size_t)ms.first_row * A.row_stride;
 	const VoiceOut *vo = A.vinfo + ms.first_row;
 	/* (-DINMIX_DBG_SAME_ROW, -DINMIX_DBG_NOLOAD: timing aids -- every row the first one; no row loads at all. Wrong PCM.) */
@@ -411,7 +410,16 @@ __device__ __forceinline__ void inmix_after(const InmixArgs &A, const uint32_t k
 	if ((kc & 7u) != xcc_id()) return; /* (a task from another XCD's queue: its rows are not in this L2, and that chunk stays incomplete) */
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this wave's rows of the chunk are in the XCD's L2 */
 	if (l == 0) __hip_atomic_fetch_add(&A.ctl[INMIX_CHUNK + INMIX_LINE * kc + INMIX_DONE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	const uint32_t tpc = A.ctl[INMIX_TPC]; /* (premix_kernel's, from before the launch: a plain load) */
+	/* the chunk eight back, whose tiles this chunk's tasks mix: its frames (premix_kernel's words, from before the launch: plain
+	 * loads) -- a chunk of the regular length, or one of the short ones at the end */
+	const uint32_t cf = A.ctl[INMIX_CF], nch1 = A.ctl[INMIX_NCH1];
+	uint32_t cs = 0, ce = 0;
+	if (kc >= 8) {
+		const uint32_t kb = kc - 8;
+		if (kb < nch1) { cs = kb * cf; ce = min(cs + cf, A.ctl[INMIX_BASE]); }
+		else { cs = A.ctl[INMIX_BASE] + (kb - nch1) * A.ctl[INMIX_CFS]; ce = cs + A.ctl[INMIX_CFS]; }
+	}
+	const uint32_t tpc = (ce - cs + INMIX_TILE - 1) / INMIX_TILE;
 	/* Which tasks: those of voices part of the way into the chunk -- voice `first`: tile 0, the next: tile 1, ... (banks of fewer
 	 * voices than tiles: every voice-count-th tile). Dealt out when the chunk before has been dealt out whole, they look at its
 	 * counter a task's length later, when its last tasks have finished too; and they are through with their tiles before the
@@ -425,10 +433,9 @@ __device__ __forceinline__ void inmix_after(const InmixArgs &A, const uint32_t k
 	if (kc < 8 || j >= tpc) return;
 	if (inmix_ctl(A, INMIX_CHUNK + INMIX_LINE * (kc - 8) + INMIX_DONE) != A.nvc) return; /* (not all there after all: mix_kernel's) */
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); /* (this CU's L1 may hold older lines of the rows) */
-	const uint32_t cf = A.ctl[INMIX_CF];
 	if (A.flags & 4u) return; /* (SAU_AMD_INMIX_DRY, a timing aid: everything but the tiles) */
 	for (; j < tpc; j += A.nvc) {
-		inmix_tile(A, kc - 8, j, cf, l);
+		inmix_tile(A, cs, ce, j, l);
 		if (l == 0) __hip_atomic_fetch_or(&A.ctl[INMIX_CHUNK + INMIX_LINE * (kc - 8) + INMIX_BITS + (j >> 5)], 1u << (j & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
 }

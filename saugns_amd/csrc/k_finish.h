@@ -126,13 +126,21 @@ __global__ void __launch_bounds__(64) premix_kernel(FastParams P) {
 		const FastInfo f0 = P.info[0];
 		const uint32_t GF = 64u * P.rows - f0.H;
 		const uint32_t ngroups = f0.total && f0.H < 64u * P.rows ? (f0.total + GF - 1) / GF : 0u;
-		const uint32_t K = P.dyn_chunks ? P.dyn_chunks : 1u, per = (ngroups + K - 1) / K;
-		const uint32_t nch = per ? (ngroups + per - 1) / per : 0u;
+		const uint32_t K = P.dyn_chunks ? P.dyn_chunks : 1u;
+		uint32_t lo_, hi_;
+		const FkChunks q = fk_chunk_groups(ngroups, K, P.dyn_small, 0u, lo_, hi_);
+		const uint32_t per = q.per;
+		const bool tapered = q.body < ngroups; /* (then the last INMIX_NSMALL chunks are P.dyn_small groups each) */
+		const uint32_t nch = q.nch1 + (tapered ? INMIX_NSMALL : 0u);
 		const uint32_t tpc = (per * GF + INMIX_TILE - 1) / INMIX_TILE;
-		const bool fits = nch != 0 && nch <= INMIX_MAX_CHUNKS && tpc <= INMIX_MAX_TPC && (per * GF) % 4u == 0; /* (16-byte row loads: chunks begin on a multiple of four frames) */
+		const bool fits = nch != 0 && nch <= INMIX_MAX_CHUNKS && tpc <= INMIX_MAX_TPC && (per * GF) % 4u == 0 && /* (16-byte row loads: chunks begin on a multiple of four frames) */
+			(!tapered || ((q.body * GF) % 4u == 0 && (P.dyn_small * GF) % 4u == 0));
 		if (v == 0) {
 			P.inmix[INMIX_CF] = per * GF;
 			P.inmix[INMIX_TPC] = tpc;
+			P.inmix[INMIX_NCH1] = q.nch1;
+			P.inmix[INMIX_BASE] = tapered ? q.body * GF : ~0u;
+			P.inmix[INMIX_CFS] = tapered ? P.dyn_small * GF : 0u;
 			P.inmix[INMIX_NCH] = fits ? nch : 0u;
 			if (!fits) atomicOr(&P.work_count[1], 4u);
 		}
@@ -333,8 +341,10 @@ __global__ void __launch_bounds__(256) mix_kernel(MixParams P) {
 	if (P.inmix && P.guard[0] == 0 && P.guard[1] == 0) {
 		/* frames the closed-form launch has mixed itself: those of the tiles with their bits set (and it stands) */
 		const uint32_t cf = P.inmix[INMIX_CF], i = bx * 256 + threadIdx.x;
-		const uint32_t k = cf ? i / cf : 0u;
-		const uint32_t j = cf ? (i - k * cf) / INMIX_TILE : 0u;
+		const uint32_t base = P.inmix[INMIX_BASE], cfs = P.inmix[INMIX_CFS]; /* (the short chunks at the end: k_fast_types.h) */
+		uint32_t k = 0, j = 0;
+		if (i < base || !cfs) { k = cf ? i / cf : 0u; j = cf ? (i - k * cf) / INMIX_TILE : 0u; }
+		else { const uint32_t ks = (i - base) / cfs; k = P.inmix[INMIX_NCH1] + ks; j = (i - base - ks * cfs) / INMIX_TILE; }
 		covered = k < P.inmix[INMIX_NCH] && ((P.inmix[INMIX_CHUNK + INMIX_LINE * k + INMIX_BITS + (j >> 5)] >> (j & 31u)) & 1u) != 0;
 		if (__syncthreads_and(covered)) return;
 	}
