@@ -662,7 +662,8 @@ def run_config4(args, R, sa, tabs, steps=None, warmup=None):
     achieved = alg / kern_s / 1e9 if kern_s > 0 else 0.0
     full4 = not args.c4_frames and args.renders == 64 and not args.c4_run
     traffic4, source4 = profile_step_traffic("config4") if full4 else (None, None)
-    v4 = profile_step_valu("config4", ", 2, false, false>") if full4 else None  # the look-back build, whatever its rows per pass
+    # the step's dominant launch: since round 6 duo_kernel (closed-form and look-back voices in one launch); else the look-back build
+    v4 = (profile_step_valu("config4", "duo_kernel") or profile_step_valu("config4", ", 2, false, false")) if full4 else None
     out = {
         "metric": "mono samples/sec, examples/rainy_thunder.sau x 512 renders sharded over GPUs",
         "value": tally[0] / dt, "unit": "mixed mono int16 frames/s summed over renders",
@@ -678,12 +679,12 @@ def run_config4(args, R, sa, tabs, steps=None, warmup=None):
                                 "(tests/golden/config4_seeds.npz)") if not args.c4_frames else
                                f"first {frames_each} frames of seeds 0..3 within 1 LSB of tests/golden/pcm_heads.npz"},
         "roofline": {"bound": "valu", "achieved": (v4 or {}).get("weighted_cycles_per_launch"), "peak": (v4 or {}).get("simd_cycles_per_launch"),
-                     "unit": "SIMD-cycles per launch of the dominant kernel (fast_kernel<8, 2>: the look-back voices)",
+                     "unit": "SIMD-cycles per launch of the dominant kernel (" + ((v4 or {}).get("kernel") or "duo_kernel") + ")",
                      "frac": (v4 or {}).get("frac"), "valu": v4, "algorithmic": hbm_convention(achieved, alg),
                      "traffic": traffic4, "traffic_source": source4,
                      "traffic_is": "HBM bytes of every kernel of one step (64 renders)",
-                     "kernel": "fast_kernel<8, 0> over the closed-form voices + fast_kernel<8, 2> over the look-back voices "
-                               "(two launches per segment, over analyze_kernel's voice lists)",
+                     "kernel": "duo_kernel: the closed-form voices (as fast_kernel<8, 0>) and the look-back voices (as fast_kernel<8, 2>) of "
+                               "analyze_kernel's two lists in one launch, a workgroup's waves split between them by the lists' lengths",
                      "kernel_ms_per_step": kern_s * 1e3, "other_kernels_ms_per_step":
                      {k: tm[k] / steps for k in ("block_ms", "mix_ms", "aux_ms")},
                      "segments_per_step": tm["segments"] / steps,

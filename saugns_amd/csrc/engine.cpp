@@ -385,7 +385,7 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 	uint32_t n_main = 1, n_fpool = 0, max_ops = 1, n_pan = 0, max_steps = 1, n_fast = 1, n_fast_full = 0;
 	uint64_t wave_mask = 0;
 	bool maybe_block = false, serial = false, may_scan = false, maybe_cub = false;
-	uint32_t sum_levels = 0, n_chain_rows = 0, n_inc_rows = 0, n_look_rows = 0;
+	uint32_t sum_levels = 0, n_chain_rows = 0, n_inc_rows = 0, n_look_rows = 0, n_may_scan = 0;
 	for (size_t s = 0; s < streams_.size(); ++s) {
 		Stream &st = streams_[s];
 		SegmentDesc::Stream &sd = sdescs[s];
@@ -465,6 +465,7 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 			if (voice_block && !vn.plan.no_fast) {
 				n_fast_full = std::max(n_fast_full, vn.plan.n_fast_full);
 				may_scan = true;
+				++n_may_scan;
 				descs.back().inc_base = n_inc_rows; descs.back().n_inc = vn.plan.n_osc;
 				n_inc_rows += vn.plan.n_osc;
 				if (vn.plan.n_chain == 0) { /* single-pass running sums: one look-back row per oscillator, eight at most */
@@ -508,6 +509,7 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 	seg.n_chain_rows = n_chain_rows;
 	seg.n_inc_rows = n_inc_rows;
 	seg.n_look_rows = n_look_rows;
+	seg.n_may_scan = n_may_scan;
 	return backend_->render(seg, err);
 }
 

@@ -58,6 +58,7 @@ struct SegmentDesc {
 	uint32_t n_chain_rows = 0;/* row pairs the voices' chain_base/n_chain span */
 	uint32_t n_inc_rows = 0;  /* row pairs the voices' inc_base/n_inc span (voices that may have running-sum phases) */
 	uint32_t n_look_rows = 0; /* rows the voices' look_base/n_look span (those of them without feedback chains) */
+	uint32_t n_may_scan = 0;  /* voices that may have running-sum phases this segment (the device decides: analyze_kernel) */
 };
 
 /* Bytes a backend has for the rows of a segment's feedback chains (8 B per chain and frame; the engine cuts segments with

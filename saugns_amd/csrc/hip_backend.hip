@@ -365,6 +365,10 @@ public:
 			 * workgroups' sums (spread look-back launches) need the whole grid resident, so the grid follows the CUs
 			 * this device really has (a partitioned or CU-masked device has fewer than 256) */
 			fk_grid_ = dev_cus[dev & 15] < FK_GRID ? dev_cus[dev & 15] : FK_GRID;
+			/* the per-XCD task queues and the launch's own mixing take chunk k mod 8 for XCD k mod 8 and hand rows from wave to wave
+			 * through ONE XCD's L2 (k_fast_types.h): only on a device that is the whole MI355X -- 256 CUs = 8 XCDs x 32. A partition
+			 * (CPX: 32 CUs, one XCD) or a masked device keeps the single counter and mix_kernel */
+			eight_xcds_ = dev_cus[dev & 15] == 256;
 			if (const char *fg = tune_env("SAU_AMD_FK_GRID")) { const int n = atoi(fg); if (n >= 1 && n <= (int)FK_GRID) fk_grid_ = (uint32_t)n; }
 		}
 		if (lds_limit_ > 160 * 1024) lds_limit_ = 160 * 1024;
@@ -392,6 +396,7 @@ public:
 		early_mix_enabled_ = tune_env("SAU_AMD_NO_EARLY_MIX") == nullptr;
 		inmix_enabled_ = tune_env("SAU_AMD_NO_INMIX") == nullptr;
 		tailmix_enabled_ = tune_env("SAU_AMD_TAILMIX") != nullptr;
+		duo_enabled_ = tune_env("SAU_AMD_NO_DUO") == nullptr;
 		xcd_queues_ = tune_env("SAU_AMD_NO_XCD_QUEUES") == nullptr;
 		inmix_taper_ = tune_env("SAU_AMD_INMIX_TAPER") != nullptr;
 		inmix_report_ = tune_env("SAU_AMD_INMIX_REPORT") != nullptr;
@@ -428,11 +433,8 @@ public:
 		(void)stereo;
 		{
 			if (!pcm_.ensure(pcm_row_ * cfg_.n_streams, err)) return false;
-			/* on the generator's own stream: a memset on the null stream is not ordered with a non-blocking stream's kernels,
-			 * and it may still be at work (it is asynchronous for device memory) when the first mixer writes -- zeros in the
-			 * PCM from some page on, seen on the second and later generators of a process (pooled blocks come back at once,
-			 * a first hipMalloc takes long enough to hide it) */
-			HIP_OK(hipMemsetAsync(pcm_.p, 0, pcm_.cap * sizeof(int16_t), stream_));
+			/* (not cleared: every frame of a run is written by a mixer or cleared by zero_pcm, and no frame behind a run's
+			 * length is ever handed out -- until round 6 a memset here, 32 us for a config-4 batch's 677 MB) */
 		}
 		set_.vout_rows = 0; /* re-sized on the next render */
 		return true;
@@ -665,7 +667,7 @@ public:
 			fp.row_stride = row_stride_; fp.n_voices = seg.n_voices; fp.n_fast = n_fast;
 			fp.seq_enable = seq_ok ? 1u : 0u; fp.ids_full_ofs = n_steps_total_;
 			fp.scan = nullptr; fp.scan_groups = 0; fp.mode = 0;
-			if (xcd_queues_) { /* the closed-form launch's task queues, one per XCD (k_fast_types.h) */
+			if (xcd_queues_ && eight_xcds_) { /* the closed-form launch's task queues, one per XCD (k_fast_types.h) */
 				if (!inmix_ctl_.ensure(INMIX_WORDS, err)) return false;
 				fp.inmix = inmix_ctl_.p;
 			}
@@ -824,11 +826,14 @@ public:
 			TimedPair *ta = timing_on_ ? new_pair(3) : nullptr;
 			if (ta) (void)hipEventRecord(ta->a, stream_);
 			{
-				/* a thread per voice, a chain of dependent loads each: few voices per wave shorten it a little (their
-				 * loads diverge; measured per launch, 1024 FM voices / config 4 / config 3: 64 per wave 34 us, 16: 30, 4: 28.5) */
-				static const uint32_t lanes = tune_env("SAU_AMD_ANALYZE_LANES") ? (uint32_t)atoi(tune_env("SAU_AMD_ANALYZE_LANES")) : 4u;
-				const uint32_t al = lanes >= 1 && lanes <= 64 ? lanes : 4u;
-				hipLaunchKernelGGL(analyze_kernel, dim3((seg.n_voices + al - 1) / al), dim3(al), 0, stream_, fp);
+				/* a wave per voice: the voice's operator records and plan staged in LDS for lane 0's chain of dependent reads
+				 * (k_analyze.h; round 6 -- a thread per voice on the records in HBM took 25-53 us per segment). Voices with more
+				 * records or steps than 48 KiB hold are analysed on the records in HBM (SAU_AMD_ANALYZE_NO_LDS: all of them) */
+				uint32_t lo = seg.max_ops, ls = seg.max_steps;
+				size_t albytes = (size_t)lo * sizeof(DevOp) + (size_t)ls * sizeof(Step) + (size_t)lo * sizeof(uint32_t);
+				static const bool no_lds = tune_env("SAU_AMD_ANALYZE_NO_LDS") != nullptr;
+				if (albytes > 48 * 1024 || no_lds) { lo = 0; ls = 0; albytes = 0; }
+				hipLaunchKernelGGL(analyze_kernel, dim3(seg.n_voices), dim3(64), albytes, stream_, fp, lo, ls);
 			}
 			if (ta) (void)hipEventRecord(ta->b, stream_);
 			if (use_fast) {
@@ -962,11 +967,34 @@ public:
 					const uint32_t groups_cf = (seg.len + (60 * rows_cf) - 1) / (60 * rows_cf);
 					const unsigned long long want_cf = (unsigned long long)seg.n_voices * (groups_cf < 64 ? groups_cf : 64);
 					const uint32_t grid_cf = (uint32_t)((want_cf + 15) / 16 > fk_grid_ ? fk_grid_ : (want_cf + 15) / 16);
-					set_tasks(cfp, groups_cf, grid_cf ? grid_cf : 1);
-					if (!launch_build(0, rows_cf, grid_cf ? grid_cf : 1, &cfp, 16 * area_cf(rows_cf), wide_cf)) launched = false;
+					/* Both kinds of voice in ONE launch (duo_kernel, k_fast_voice.h; round 6) where both launches would run 8 rows per pass
+					 * on narrow tables and the look-back voices' words in HBM exist (a voice then takes as many waves as there are). How
+					 * many voices are of which kind only analyze_kernel knows: the kernel splits its waves by the lists' lengths */
+					const bool wide_look_ = wide_tabs_ && !tune_env("SAU_AMD_NO_WIDE_LOOK") && FT == 8 && ft > 0 && ft == n_want &&
+						ft * (size_t)FAST_TAB_BYTES_WIDE + 16 * area + LOOK_LDS_BYTES + 1024 <= lds_limit_; /* (the look-back launch would take wide tables: better apart) */
+					const bool duo = duo_enabled_ && fp.look && fp.look_words_real && FT == 8 && rows_cf == 8 && !fp.cub_ok && !tail_live_ &&
+						!wide_look_ && !wide_cf && ft * ftab_bytes + 16 * area + LOOK_LDS_BYTES + 1024 <= lds_limit_;
+					if (getenv("SAU_AMD_DEBUG_DUO"))
+						fprintf(stderr, "[sau-amd] duo %d: enabled %d look %d words_real %u FT %u rows_cf %u cub_ok %u tail %d may_scan %u of %u voices, lds %zu of %zu\n",
+								(int)duo, (int)duo_enabled_, fp.look != nullptr, fp.look_words_real, FT, rows_cf, fp.cub_ok, (int)tail_live_, seg.n_may_scan, seg.n_voices,
+								ft * ftab_bytes + 16 * area + LOOK_LDS_BYTES + 1024, lds_limit_);
+					set_tasks(cfp, groups_cf, duo ? (fk_grid_ + 1) / 2 : grid_cf ? grid_cf : 1); /* (duo: half a workgroup's waves take closed-form tasks) */
+					if (!duo && !launch_build(0, rows_cf, grid_cf ? grid_cf : 1, &cfp, 16 * area_cf(rows_cf), wide_cf)) launched = false;
 					fp.mode = fp.sum_levels + 1; fp.only_multi = 0; fp.look_wpv = look_wpv_; fp.look_groups = groups;
 					fp.look_wpv_flags = (tune_env("SAU_AMD_LOOK_NO_LDS") ? 1u : 0u) | (tune_env("SAU_AMD_LOOK_WITHHOLD") ? 2u : 0u) |
 						(tune_env("SAU_AMD_LOOK_SPREAD") ? 4u : 0u);
+					if (duo && tune_env("SAU_AMD_DUO_LW")) fp.look_wpv_flags |= ((uint32_t)atoi(tune_env("SAU_AMD_DUO_LW")) & 15u) << 8;
+					if (duo) {
+						static size_t duo_configured[16];
+						const size_t dlds = ft * ftab_bytes + 16 * area + LOOK_LDS_BYTES;
+						if (!raise_lds_attr((const void *)duo_kernel, dlds, duo_configured[dev_ & 15], err)) return false;
+						auto go = [&]() -> bool {
+							void *da[] = {(void *)&fp, (void *)&cfp};
+							return hipLaunchKernel((const void *)duo_kernel, dim3(fk_grid_), dim3(1024), da, dlds, stream_) == hipSuccess;
+						};
+						/* (its look-back waves wait for sums across workgroups: in turn with other such launches of the process) */
+						if (!SpreadLaunchOrder::get().ordered(dev_, stream_, go)) launched = false;
+					} else
 					if (fp.look) {
 						const unsigned long long waves = (unsigned long long)seg.n_voices * (fp.look_words_real ? (groups < 64 ? groups : 64) : look_wpv_);
 						const uint32_t grid2 = waves > (unsigned long long)fk_grid_ * 16 ? fk_grid_ : (uint32_t)((waves + 15) / 16);
@@ -1050,6 +1078,12 @@ public:
 							const uint32_t clen0 = (((tail ? body : seg.len) + n_chunks - 1) / n_chunks + 255) & ~255u;
 							for (uint32_t c = 0; c <= n_chunks; ++c) cb[c] = c * clen0 < (tail ? body : seg.len) ? c * clen0 : (tail ? body : c * clen0);
 							if (tail) { cb[n_chunks] = body; ++n_chunks; cb[n_chunks] = seg.len; }
+							/* (with the rounded-up chunk length the last body chunks can come out empty -- seg.len 81930 in 20
+							 * chunks: cb[19] == cb[20] -- and each would still cost a chain launch, two pass launches and two events) */
+							uint32_t m = 0;
+							for (uint32_t c = 0; c < n_chunks; ++c)
+								if (cb[c + 1] > cb[c]) { cb[m] = cb[c]; ++m; cb[m] = cb[c + 1]; }
+							if (m) n_chunks = m;
 						}
 						while (chain_ev_.size() < 2 * (size_t)n_chunks) {
 							hipEvent_t e;
@@ -1585,6 +1619,7 @@ private:
 	hipEvent_t after_ev_ = nullptr; /* order_after() */
 	bool after_pending_ = false;
 	uint32_t early_mixed_blocks_ = 0; /* 256-frame blocks of this segment that early launches have mixed */
+	bool eight_xcds_ = true;          /* the device is a whole MI355X (init) */
 	bool xcd_queues_ = true;          /* a closed-form launch's tasks come from one queue per XCD, chunk-major (SAU_AMD_NO_XCD_QUEUES: the one counter, voice-major) */
 	bool inmix_enabled_ = true;       /* a many-voice stream's closed-form launch mixes its own rows (SAU_AMD_NO_INMIX: the mixer alone) */
 	uint32_t inmix_min_voices_ = 64;  /* ... from that many voices on (SAU_AMD_INMIX_MIN_VOICES) */
@@ -1600,6 +1635,7 @@ private:
 	                                   * the six flops, the clamp and the conversion per frame (and 42 spilled registers), the mixer gives back 0.25
 	                                   * (profiles/r06_ab.txt). Off; kept for the record */
 	bool tail_live_ = false;          /* this segment's look-back launch did: mix_few_kernel looks at tail_ok_ */
+	bool duo_enabled_ = true;         /* closed-form and look-back voices of a segment in one launch where there are plenty of both (SAU_AMD_NO_DUO: two launches) */
 	bool wide_tabs_ = true;
 	uint32_t more_rows_ = 12;
 	uint32_t lean_rows_ = 6;    /* SAU_AMD_LEAN_ROWS: rows per pass of fast_kernel<T, 3> at most (6, 5 or 4) */

@@ -65,22 +65,49 @@ __device__ __forceinline__ bool op_has_fpm(const Step *plan, uint32_t n, uint32_
 	return false;
 }
 
-__global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
-	const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; /* (the host picks the voices per wave) */
-	if (v == 0 && P.inmix) /* the XCDs' task queues of the closed-form launch (k_fast_types.h) */
+/* Round 6: a workgroup (one wave) per voice, the voice's operator records and plan staged in LDS. The analysis is one thread's
+ * chain of dependent reads and read-modify-writes of the 256-byte records -- 25 us for a config-3 segment and 53 us for a config-4
+ * one when every one of them went to HBM (a thread per voice) --; the wave copies them in (64 lanes, 16 bytes
+ * each), lane 0 runs the analysis on the copies, the wave copies them back. lds_ops: operator records the launch's LDS holds per
+ * voice (0, or fewer than this voice has: the analysis runs on the records in HBM as before). */
+__global__ void __launch_bounds__(64) analyze_kernel(FastParams P, uint32_t lds_ops, uint32_t lds_steps) {
+	extern __shared__ __align__(16) unsigned char a_lds[];
+	const uint32_t v = blockIdx.x;
+	const int lane = threadIdx.x;
+	if (v == 0 && lane == 0 && P.inmix) /* the XCDs' task queues of the closed-form launch (k_fast_types.h) */
 		for (uint32_t x = 0; x < 8; ++x) P.inmix[INMIX_QUEUE + INMIX_LINE * x] = 0;
-	if (v == 0) { P.work_count[0] = 0; P.work_count[1] = 0; } /* finalize_kernel (a later launch) builds the block loop's work list; [1]: premix_kernel's verdict */
+	if (v == 0 && lane == 0) { P.work_count[0] = 0; P.work_count[1] = 0; } /* finalize_kernel (a later launch) builds the block loop's work list; [1]: premix_kernel's verdict */
 	if (v >= P.n_voices) return;
 	const VoiceDesc vd = P.voices[v];
-	const uint32_t *ids = P.op_ids + vd.ops_ofs;
+	const uint32_t *gids = P.op_ids + vd.ops_ofs;
+	const bool use_lds = lds_ops != 0 && vd.nops <= lds_ops && vd.plan_len <= lds_steps; /* (uniform over the wave) */
+	DevOp *lops = (DevOp *)a_lds;
+	Step *lplan = (Step *)(a_lds + (size_t)lds_ops * sizeof(DevOp));
+	uint32_t *lids = (uint32_t *)(a_lds + (size_t)lds_ops * sizeof(DevOp) + (size_t)lds_steps * sizeof(Step)); /* 0, 1, 2 ...: the copies' indices */
+	/* per block buffer (256 ids): extra lead-in lanes; bit 0 / 1: depends on a chain's output / on a chain not fed from its own lines;
+	 * the deepest running-sum level it depends on -- bytes in LDS (until round 6: bit planes in registers, thirty instructions a look) */
+	__shared__ uint8_t a_extra[256], a_dep[256], a_level[256];
+	for (uint32_t i = (uint32_t)lane; i < 64; i += 64) { ((uint32_t *)a_extra)[i] = 0; ((uint32_t *)a_dep)[i] = 0; ((uint32_t *)a_level)[i] = 0; }
+	if (use_lds) {
+		static_assert(sizeof(DevOp) % 16 == 0 && sizeof(Step) == 16, "copied 16 bytes at a time");
+		constexpr uint32_t Q = sizeof(DevOp) / 16;
+		for (uint32_t i = (uint32_t)lane; i < vd.nops * Q; i += 64)
+			((uint4 *)lops)[i] = ((const uint4 *)&P.ops[gids[i / Q]])[i % Q];
+		for (uint32_t i = (uint32_t)lane; i < vd.plan_len; i += 64) ((uint4 *)lplan)[i] = ((const uint4 *)(P.steps + vd.plan_ofs))[i];
+		for (uint32_t i = (uint32_t)lane; i < vd.nops; i += 64) lids[i] = i;
+	}
+	__syncthreads();
+	if (lane == 0) {
+	const uint32_t *ids = use_lds ? lids : gids; /* (for the helpers that take an id list and a record array) */
+	DevOp *const OPS = use_lds ? lops : P.ops;
 	bool bad = (vd.flags & VD_NO_FAST) != 0 || !P.enable;
 	bool seq = false, has_red = false, has_rcub = false, has_rchain = false;
 	uint32_t min_time = 0xFFFFFFFFu;
-	const Step *plan = P.steps + vd.plan_ofs;
+	const Step *plan = use_lds ? lplan : P.steps + vd.plan_ofs;
 	/* An operator that has run out of time yields nothing, and neither it nor
 	 * anything nested in it advances (run_block gives its subtree zero
 	 * length, generator.c:686-700): such subtrees are left out below. */
-	for (uint32_t i = 0; i < vd.nops; ++i) P.ops[ids[i]].rt_frozen = 0;
+	for (uint32_t i = 0; i < vd.nops; ++i) OPS[ids[i]].rt_frozen = 0;
 	if (P.chain_desc)
 		for (uint32_t k = 0; k < vd.n_chain; ++k) /* ChainDesc.n (its first word; the type is defined further down) */
 			((uint32_t *)P.chain_desc)[(size_t)(vd.chain_base + k) * CHAIN_DESC_WORDS] = 0;
@@ -90,7 +117,7 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 		uint32_t dep = 0, frozen_at = 0;
 		for (uint32_t si = 0; si < vd.plan_len; ++si) {
 			const Step st = plan[si];
-			DevOp &o = P.ops[ids[st.op]];
+			DevOp &o = OPS[ids[st.op]];
 			if (st.flags & SF_BEGIN) {
 				++dep;
 				if (!frozen_at && !(o.flags & OPF_TIME_INF) && o.time == 0) frozen_at = dep;
@@ -102,9 +129,9 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 			}
 		}
 	}
-	if (P.ops[ids[vd.carr_local]].rt_frozen) bad = true; /* the voice is over (generator.c:839) */
+	if (OPS[ids[vd.carr_local]].rt_frozen) bad = true; /* the voice is over (generator.c:839) */
 	for (uint32_t i = 0; i < vd.nops; ++i) {
-		DevOp &o = P.ops[ids[i]];
+		DevOp &o = OPS[ids[i]];
 		if (o.rt_frozen) continue;
 		/* ramps in progress: amplitude lines are closed-form per frame (sau/line.c
 		 * fills depend on the position only); frequency ramps need a phase scan,
@@ -143,31 +170,16 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 	 * arises where a ratio frequency multiplies by a modulated frequency block written at a
 	 * smaller depth than the reader's (see "modulated block" below) and travels up the
 	 * operator tree with the data. */
-	unsigned long long x0[4] = {0, 0, 0, 0}, x1[4] = {0, 0, 0, 0}, x2[4] = {0, 0, 0, 0};
-	auto extra_of = [&](uint32_t sl) -> uint32_t {
-		if (sl == NO_SLOT) return 0;
-		const uint32_t q = sl >> 6, sh = sl & 63;
-		const unsigned long long a = q == 0 ? x0[0] : q == 1 ? x0[1] : q == 2 ? x0[2] : x0[3];
-		const unsigned long long b = q == 0 ? x1[0] : q == 1 ? x1[1] : q == 2 ? x1[2] : x1[3];
-		const unsigned long long c = q == 0 ? x2[0] : q == 1 ? x2[1] : q == 2 ? x2[2] : x2[3];
-		return (uint32_t)((a >> sh) & 1ull) | ((uint32_t)((b >> sh) & 1ull) << 1) | ((uint32_t)((c >> sh) & 1ull) << 2);
-	};
+	auto extra_of = [&](uint32_t sl) -> uint32_t { return sl == NO_SLOT ? 0u : (uint32_t)a_extra[sl & 255u]; };
 	auto set_extra = [&](uint32_t sl, uint32_t x, bool keep_max) {
 		if (sl == NO_SLOT) return;
 		if (keep_max) { const uint32_t old = extra_of(sl); if (old > x) x = old; }
-		const unsigned long long bit = 1ull << (sl & 63);
-#pragma unroll
-		for (int q = 0; q < 4; ++q)
-			if ((int)(sl >> 6) == q) {
-				x0[q] = (x0[q] & ~bit) | ((x & 1) ? bit : 0ull);
-				x1[q] = (x1[q] & ~bit) | ((x & 2) ? bit : 0ull);
-				x2[q] = (x2[q] & ~bit) | ((x & 4) ? bit : 0ull);
-			}
+		a_extra[sl & 255u] = (uint8_t)(x & 7u);
 	};
 	uint32_t x_carrier = 0;
 	for (uint32_t si = 0; si < vd.plan_len && !bad; ++si) {
 		const Step st = plan[si];
-		DevOp &o = P.ops[ids[st.op]];
+		DevOp &o = OPS[ids[st.op]];
 		if (o.rt_frozen) { /* nesting still counts: depths of live steps stay what they are */
 			if (st.flags & SF_BEGIN) ++depth;
 			if (st.flags & SF_END) --depth;
@@ -196,10 +208,10 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 			 * first FM modulator of a plain carrier sees exactly that, generator.c:448-477) */
 			const uint32_t ow = block_owner(plan, si, st.fmul);
 			if (ow != 0xff) {
-				const DevOp &po = P.ops[ids[ow]];
+				const DevOp &po = OPS[ids[ow]];
 				pconst = po.rt_fblk_valid != 0; pf = po.rt_fconst;
 			} else if (st.prov != NO_SLOT) {
-				const DevOp &po = P.ops[ids[st.prov]];
+				const DevOp &po = OPS[ids[st.prov]];
 				pconst = po.rt_fconst_valid != 0; pf = po.rt_fconst;
 			}
 		}
@@ -217,7 +229,7 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 		if ((st.kind == ST_OSC || st.kind == ST_LERP) && st.out != NO_SLOT && st.out >= FSLOT_BASE) {
 			const uint32_t ow = block_owner(plan, si, st.out);
 			if (ow != 0xff) {
-				DevOp &oo = P.ops[ids[ow]];
+				DevOp &oo = OPS[ids[ow]];
 				oo.rt_fblk_valid = 0;
 				const uint32_t wd = st.kind == ST_OSC ? depth : depth + 1;
 				if (oo.st_phase == 0 || wd < oo.st_phase) oo.st_phase = wd;
@@ -232,14 +244,14 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 				if ((ls.flags & LP_GOAL) && g_ratio != s_ratio) {
 					/* fine when the parent's frequency is one value for the segment: decode_kernel and
 					 * finalize_kernel then apply the rescaling with it */
-					const bool parent_const = st.prov != NO_SLOT && P.ops[ids[st.prov]].rt_fconst_valid != 0;
+					const bool parent_const = st.prov != NO_SLOT && OPS[ids[st.prov]].rt_fconst_valid != 0;
 					if (!parent_const) bad = true;
 				}
 				if ((s_ratio || ((ls.flags & LP_GOAL) && g_ratio)) && !pconst) {
 					seq = true;
 					if (st.fmul >= FSLOT_BASE) {
 						const uint32_t ow = block_owner(plan, si, st.fmul);
-						const uint32_t wd = ow != 0xff ? P.ops[ids[ow]].st_phase : 0u;
+						const uint32_t wd = ow != 0xff ? OPS[ids[ow]].st_phase : 0u;
 						if (wd) {
 							const uint32_t need = depth + (op_has_fpm(plan, vd.plan_len, st.op) ? 1u : 0u);
 							/* the block is exact from lane H - wd + 1 + its own extra; this reader
@@ -317,23 +329,16 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 		/* c0: depends on some chain's output; c1: ... on the output of a chain that is not fed from its own lines.
 		 * Chains of the latter kind run in chunks between the chain-input and final passes, after the sum passes:
 		 * nothing those passes compute may depend on them. The former kind can run before everything else (early). */
-		unsigned long long c0[4] = {0, 0, 0, 0}, c1[4] = {0, 0, 0, 0};
-		auto dep = [&](const unsigned long long *c, uint32_t sl) -> bool {
-			if (sl == NO_SLOT) return false;
-			const uint32_t q = sl >> 6;
-			const unsigned long long a = q == 0 ? c[0] : q == 1 ? c[1] : q == 2 ? c[2] : c[3];
-			return ((a >> (sl & 63)) & 1ull) != 0;
-		};
-		auto set_dep = [&](unsigned long long *c, uint32_t sl, bool v, bool keep) {
+		constexpr uint32_t c0 = 1u, c1 = 2u; /* (bits of a_dep) */
+		auto dep = [&](uint32_t c, uint32_t sl) -> bool { return sl != NO_SLOT && (a_dep[sl & 255u] & c) != 0; };
+		auto set_dep = [&](uint32_t c, uint32_t sl, bool v, bool keep) {
 			if (sl == NO_SLOT) return;
-			const unsigned long long bit = 1ull << (sl & 63);
-#pragma unroll
-			for (int q = 0; q < 4; ++q)
-				if ((int)(sl >> 6) == q) c[q] = v ? (c[q] | bit) : (keep ? c[q] : (c[q] & ~bit));
+			const uint8_t old = a_dep[sl & 255u];
+			a_dep[sl & 255u] = v ? (uint8_t)(old | c) : (keep ? old : (uint8_t)(old & ~c));
 		};
 		for (uint32_t si = 0; si < vd.plan_len && !bad; ++si) {
 			const Step st = plan[si];
-			const DevOp &o = P.ops[ids[st.op]];
+			const DevOp &o = OPS[ids[st.op]];
 			if (o.rt_frozen) continue;
 			if (st.kind == ST_LINE) { set_dep(c0, st.out, dep(c0, st.fmul), false); set_dep(c1, st.out, dep(c1, st.fmul), false); }
 			else if (st.kind == ST_SMLINE) { set_dep(c0, st.out, false, false); set_dep(c1, st.out, false, false); }
@@ -346,7 +351,7 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 				const bool chain = step_may_chain(st) && (o.type == OT_WAVE || o.type == OT_RASEG) &&
 					(st.sm != NO_SLOT || o.line[L_PMA].v0 != 0.f || (o.line[L_PMA].flags & LP_GOAL));
 				uint32_t ls_ = ~0u;
-				const bool inl = chain && step_is_chain_inline(P.chain_early_ok != 0, plan, si, ids, P.ops, &ls_);
+				const bool inl = chain && step_is_chain_inline(P.chain_early_ok != 0, plan, si, ids, OPS, &ls_);
 				/* (a chain that sums its own increments is no running sum of the passes) */
 				const bool fvar = (o.type == OT_WAVE || o.type == OT_RASEG) && !o.rt_fconst_valid && !(chain && inl);
 				if (chain && o.type == OT_RASEG) { /* R feedback: only as an early chain fed from its own lines */
@@ -365,31 +370,18 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 	}
 	uint32_t seq_kind = seq ? 1u : 0u, n_scan_out = 0, levels_out = 0, lvl_bits_out = 0;
 	if (seq && !bad) {
-		unsigned long long t0[4] = {0, 0, 0, 0}, t1[4] = {0, 0, 0, 0};
-		auto level_of = [&](uint32_t sl) -> uint32_t {
-			if (sl == NO_SLOT) return 0;
-			const uint32_t q = sl >> 6;
-			const unsigned long long a = q == 0 ? t0[0] : q == 1 ? t0[1] : q == 2 ? t0[2] : t0[3];
-			const unsigned long long b = q == 0 ? t1[0] : q == 1 ? t1[1] : q == 2 ? t1[2] : t1[3];
-			return (uint32_t)((a >> (sl & 63)) & 1ull) | ((uint32_t)((b >> (sl & 63)) & 1ull) << 1);
-		};
+		auto level_of = [&](uint32_t sl) -> uint32_t { return sl == NO_SLOT ? 0u : (uint32_t)a_level[sl & 255u]; };
 		auto set_level = [&](uint32_t sl, uint32_t lv, bool keep_max) {
 			if (sl == NO_SLOT) return;
 			if (keep_max) { const uint32_t old = level_of(sl); if (old > lv) lv = old; }
-			const unsigned long long bit = 1ull << (sl & 63);
-#pragma unroll
-			for (int q = 0; q < 4; ++q)
-				if ((int)(sl >> 6) == q) {
-					t0[q] = (t0[q] & ~bit) | ((lv & 1) ? bit : 0ull);
-					t1[q] = (t1[q] & ~bit) | ((lv & 2) ? bit : 0ull);
-				}
+			a_level[sl & 255u] = (uint8_t)(lv & 3u);
 		};
 		auto max2 = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
 		bool multi = true;
 		uint32_t n_scan = 0;
 		for (uint32_t si = 0; si < vd.plan_len; ++si) {
 			const Step st = plan[si];
-			DevOp &o = P.ops[ids[st.op]];
+			DevOp &o = OPS[ids[st.op]];
 			if (o.rt_frozen) continue;
 			if (st.kind == ST_LINE) {
 				set_level(st.out, level_of(st.fmul), false);
@@ -455,4 +447,12 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P) {
 		if (seq_kind == 0) P.vlists[atomicAdd(&P.pass_flags[FAST_CF_COUNT], 1u)] = v;
 		else if (seq_kind == 3) P.vlists[P.n_voices + atomicAdd(&P.pass_flags[FAST_LK_COUNT], 1u)] = v;
 	}
+	} /* (lane 0) */
+	if (use_lds) { /* the records back, with what the analysis has noted in them for decode_kernel and the launches */
+		__syncthreads();
+		constexpr uint32_t Q = sizeof(DevOp) / 16;
+		for (uint32_t i = (uint32_t)lane; i < vd.nops * Q; i += 64)
+			((uint4 *)&P.ops[gids[i / Q]])[i % Q] = ((const uint4 *)lops)[i];
+	}
 }
+

@@ -117,7 +117,8 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 		float *slots, unsigned long long *carry, const uint32_t tabs /* LDS address of the launch's table blocks */, const int l,
 		const uint32_t wpv, const uint32_t cstart, unsigned long long *lring = nullptr,
 		const uint32_t dyn_c = 0, const uint32_t dyn_k = 0 /* > 0: chunk dyn_c of dyn_k of the voice's row groups */,
-		const uint32_t vpos = ~0u /* the voice's place among the launch's voices when that is not v (look-back lists) */) {
+		const uint32_t vpos = ~0u /* the voice's place among the launch's voices when that is not v (look-back lists) */,
+		const uint32_t wg_waves = 16u /* waves of a workgroup that render look-back voices (duo_kernel: 8) */) {
 	constexpr int NP = 64 * T;
 	(void)NP;
 	const uint32_t fast_total = uni(fi.total);
@@ -149,8 +150,8 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 	/* the single-pass build: a voice with one wave carries its sums in LDS like an in-order voice; the waves of
 	 * one workgroup look back through rings in LDS; voices spread wider go through HBM */
 	const bool look_own = SCAN == 2 && wpv == 1;
-	const uint32_t w0 = ((vpos != ~0u ? vpos : v) * wpv) & 15u; /* the voice's first wave within its workgroup (fast_kernel: waves v * wpv ...) */
-	const bool look_lds = SCAN == 2 && lring && wpv >= 2 && w0 + wpv <= 16 && !(P.look_wpv_flags & 1u);
+	const uint32_t w0 = ((vpos != ~0u ? vpos : v) * wpv) % wg_waves; /* the voice's first wave within its workgroup (fast_kernel: waves v * wpv ...) */
+	const bool look_lds = SCAN == 2 && lring && wpv >= 2 && w0 + wpv <= wg_waves && !(P.look_wpv_flags & 1u);
 	const uint32_t lk_ring = 4 * wpv;
 	unsigned long long *lk_base = look_lds ? lring + w0 * 4 : nullptr;
 	if (seq && cstart != 0) return;
@@ -409,6 +410,7 @@ __device__ __forceinline__ unsigned long long inmix_next(const InmixArgs &A, con
 __device__ __forceinline__ void inmix_after(const InmixArgs &A, const uint32_t kc, const uint32_t vi, int l) {
 	if ((kc & 7u) != xcc_id()) return; /* (a task from another XCD's queue: its rows are not in this L2, and that chunk stays incomplete) */
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this wave's rows of the chunk are in the XCD's L2 */
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* (a compiler-visible order of the row stores before the count: ADVICE r05; no code another CU could see) */
 	if (l == 0) __hip_atomic_fetch_add(&A.ctl[INMIX_CHUNK + INMIX_LINE * kc + INMIX_DONE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	/* the chunk eight back, whose tiles this chunk's tasks mix: its frames (premix_kernel's words, from before the launch: plain
 	 * loads) -- a chunk of the regular length, or one of the short ones at the end */
@@ -440,6 +442,9 @@ __device__ __forceinline__ void inmix_after(const InmixArgs &A, const uint32_t k
 	}
 }
 
+#ifndef FK_SPLIT_MASK
+#define FK_SPLIT_MASK 9 /* 1: closed form at 8 rows, 2: at 10, 4: at 12, 8: look-back at 8 (0 = none). Round 6, same box: config 4 4.37 -> 4.24 (8) -> 4.19 ms (9), FM bank 3.39 -> 3.13 ms (8); config 3 at 12 rows 1.99 -> 2.01 ms with 4 (175 spilled registers): not there (profiles/r06_ab.txt) */
+#endif
 /* SCAN: the kernel may meet voices with running-sum phases (it then holds both builds of fast_voice). */
 #ifndef FK_MINB
 #define FK_MINB 1
@@ -459,9 +464,6 @@ __global__ void FK_ATTR fast_kernel(FastParams P) {
 	constexpr int W = 16;
 	/* the builds whose groups away from the segment's ends take a copy of their own (fast_voice: SPLIT) -- the ones BASELINE's
 	 * configurations and the FM bank run in; each costs its compile time and code size twice */
-#ifndef FK_SPLIT_MASK
-#define FK_SPLIT_MASK 9 /* 1: closed form at 8 rows, 2: at 10, 4: at 12, 8: look-back at 8 (0 = none). Round 6, same box: config 4 4.37 -> 4.24 (8) -> 4.19 ms (9), FM bank 3.39 -> 3.13 ms (8); config 3 at 12 rows 1.99 -> 2.01 ms with 4 (175 spilled registers): not there (profiles/r06_ab.txt) */
-#endif
 	constexpr bool SPLIT = !CUB && ((SCAN == 0 && T == 8 && (FK_SPLIT_MASK & 1)) || (SCAN == 0 && T == 10 && (FK_SPLIT_MASK & 2)) ||
 	                                (SCAN == 0 && T == 12 && (FK_SPLIT_MASK & 4)) || (SCAN == 2 && T == 8 && (FK_SPLIT_MASK & 8)));
 	extern __shared__ __align__(16) unsigned char lds[];
@@ -582,6 +584,91 @@ __global__ void FK_ATTR fast_kernel(FastParams P) {
 		if (SCAN == 1 && (P.only_multi ? (seq_kind != 1 && seq_kind != 2) : seq_kind == 3)) continue;
 		if (SCAN && seq_kind != 0) fast_voice<T, 1>(P, v, fi, slots, carry, tabs, l, wpv, cstart);
 		else fast_voice<T, 0>(P, v, fi, slots, carry, tabs, l, wpv, cstart);
+	}
+}
+
+/* Round 6: the closed-form voices and the look-back voices of a segment in ONE launch. Apart, the
+ * look-back launch leaves a fifth of its issue slots empty: twice per row group a wave waits for the sums of the groups before
+ * it (words in HBM: a round trip of microseconds), and a workgroup's sixteen waves are one voice's and wait together -- nothing
+ * on the SIMD fills the gap (SQ_ACTIVE_INST_VALU 0.80; BASELINE config 4: 2.05 ms for the look-back voices + 1.35 ms for the
+ * closed-form ones). Here some of a workgroup's waves -- half of them for config 4 -- render look-back voices (as fast_kernel<8, 2>:
+ * waves per voice from how many such voices there are) at a raised priority, and the others take closed-form tasks from the queues
+ * (as fast_kernel<8, 0>): every SIMD holds waves of both kinds, and what the waiting ones leave is the closed-form waves'. One copy of the tables;
+ * every wave's block buffers are sized for the look-back voices', so that when analyze_kernel finds no voice of one kind all
+ * sixteen waves render the other. P: the look-back launch's parameters, Q: the closed-form launch's (both at 8 rows per pass,
+ * narrow tables). */
+__global__ void __launch_bounds__(1024, 1) duo_kernel(FastParams P, FastParams Q) {
+	constexpr int T = 8, NP = 64 * T, W = 16;
+	constexpr bool SPLIT8 = (FK_SPLIT_MASK & 8) != 0, SPLIT1 = (FK_SPLIT_MASK & 1) != 0;
+	extern __shared__ __align__(16) unsigned char lds[];
+	const int tid = threadIdx.x;
+	const int w = (int)uni((uint32_t)tid >> 6);
+	const int l = tid & 63;
+	const uint32_t NVl = P.pass_flags[FAST_LK_COUNT], NVc = Q.pass_flags[FAST_CF_COUNT];
+	if (NVl == 0 && NVc == 0) return;
+	const uint32_t tabs = (uint32_t)(uintptr_t)lds;
+	unsigned char *areas = lds + (size_t)P.n_tabs * FkTab<false>::BYTES;
+	const size_t area_bytes = (size_t)P.n_fast * NP * sizeof(float) + (size_t)P.max_steps * sizeof(unsigned long long); /* (P.n_fast >= Q.n_fast) */
+	float *slots = (float *)(areas + (size_t)w * area_bytes) + l;
+	unsigned long long *lring = (unsigned long long *)(areas + (size_t)W * area_bytes);
+	lring[tid] = 0;
+	fk_stage_tables<false>(P, lds, (uint32_t)tid, 64 * W);
+	__syncthreads();
+	const uint32_t NV = P.n_voices;
+	/* which waves do what: by the lists' lengths (all of one kind when the other has no voice). Waves 0 .. lw - 1: look-back voices.
+	 * (BASELINE config 4, as many voices of one kind as of the other, ms per step by lw: 5: 5.43, 6: 4.71, 7: 4.16, 8: 3.77, 9: 3.77,
+	 * 10: 4.01, 12: 5.07, 14: 8.30 -- apart: 4.03; profiles/r06_ab.txt. Too few look-back waves and each has too many row groups to
+	 * walk one after the other; too few closed-form waves and they cannot issue what the launch leaves them) */
+	uint32_t lw = NVc == 0 ? (uint32_t)W : 0u;
+	if (NVl && NVc) {
+		lw = (uint32_t)((16ull * NVl + (NVl + NVc) / 2) / ((unsigned long long)NVl + NVc));
+		lw = lw < 2 ? 2u : lw > 14 ? 14u : lw;
+		if (P.look_wpv_flags >> 8) lw = (P.look_wpv_flags >> 8) & 15u; /* (SAU_AMD_DUO_LW: a tuning aid) */
+	}
+	if ((uint32_t)w < lw) {
+		if (lw < (uint32_t)W) __builtin_amdgcn_s_setprio(2); /* (the waves whose waits set the launch's length go first) */
+		unsigned long long *carry = (unsigned long long *)(areas + (size_t)w * area_bytes + (size_t)P.n_fast * NP * sizeof(float));
+		const uint32_t g = blockIdx.x * lw + (uint32_t)w, total_waves = gridDim.x * lw;
+		uint32_t wpv = total_waves / NVl; /* (this launch always comes with the words in HBM: a voice may spread over workgroups) */
+		if (wpv > P.look_groups) wpv = P.look_groups;
+		/* (a voice spread over workgroups looks back through the words in HBM and may have any number of waves up to 64 -- the
+		 * lanes of one poll --; one inside a workgroup a power of two: its rings in LDS) */
+		wpv = wpv >= 64 ? 64u : wpv > 16 ? wpv : wpv >= 16 ? 16u : wpv >= 8 ? 8u : wpv >= 4 ? 4u : wpv >= 2 ? 2u : 1u;
+		const uint32_t slots_v = total_waves / wpv;
+		const uint32_t j0 = g / wpv, cs = g % wpv;
+		if (j0 >= slots_v) return;
+		for (uint32_t j = j0; j < NVl; j += slots_v) {
+			const uint32_t v = P.vlists[NV + j];
+			const FastInfo fi = P.info[v];
+			fast_voice<T, 2, false, false, false, SPLIT8, false>(P, v, fi, slots, carry, tabs, l, wpv, cs, lring, 0u, 0u, j, lw);
+		}
+		return;
+	}
+	/* closed-form tasks: fast_kernel<8, 0>'s loop over Q (tasks from the XCDs' queues or the one counter, or in fixed strides) */
+	unsigned long long *carry = (unsigned long long *)(areas + (size_t)w * area_bytes + (size_t)Q.n_fast * NP * sizeof(float));
+	const uint32_t cw = (uint32_t)W - lw; /* closed-form waves per workgroup */
+	const uint32_t K = Q.dyn_chunks ? Q.dyn_chunks : 1u, n_tasks = NVc * K;
+	const bool counted = Q.dyn_static == 0;
+	const uint32_t stride = gridDim.x * cw;
+	uint32_t snext = blockIdx.x * cw + ((uint32_t)w - lw);
+	const bool im = (Q.inmix_flags & 64u) != 0;
+	for (;;) {
+		uint32_t t_ = snext;
+		if (counted && !im) { t_ = 0; if (l == 0) t_ = atomicAdd(&Q.pass_flags[FAST_DYN_CTR], 1u); }
+		if (im) {
+			InmixArgs A;
+			A.ctl = Q.inmix; A.vout = Q.vout; A.vinfo = Q.vinfo; A.stream = Q.inmix_stream; A.row_stride = Q.row_stride;
+			A.flags = Q.inmix_flags; A.pcm_offset = Q.inmix_pcm_offset; A.nvc = NVc; A.div_m = Q.inmix_div_m; A.div_s = Q.inmix_div_s;
+			const unsigned long long nx = inmix_next(A, K, l);
+			t_ = nx == ~0ull ? n_tasks : (uint32_t)nx * K + (uint32_t)(nx >> 32);
+		}
+		const uint32_t task = uni(t_);
+		if (task >= n_tasks) break;
+		snext = task + stride;
+		const uint32_t vi = task / K;
+		const uint32_t v = Q.vlists[vi];
+		const FastInfo fi = Q.info[v];
+		fast_voice<T, 0, false, false, false, SPLIT1>(Q, v, fi, slots, carry, tabs, l, 1u, 0u, nullptr, task - vi * K, K);
 	}
 }
 
