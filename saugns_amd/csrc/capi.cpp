@@ -70,7 +70,7 @@ struct sauGenerator {
 	/* Round 6: how long the runs are follows what the script costs. Every run has a fixed cost (about 0.15 ms of launches and
 	 * bookkeeping on the device: BASELINE config 3's 10 s took 3.34 ms in runs of 1, 4, 15, 15, 5 calls and 2.68 ms as one run,
 	 * profiles/r06_ab.txt), so a script is rendered in as few runs as the host's first wait allows: the first run is what an
-	 * estimate of the script's cost per frame puts at FIRST_RUN_NS (whole calls, at least one), the runs after it grow
+	 * estimate of the script's cost per frame puts at FIRST_RUN_NS = 8 ms (whole calls, at least one), the runs after it grow
 	 * 2^grow_bits-fold up to what it puts at LATER_RUN_NS (at least ahead_frames, at most MAX_RUN_FRAMES and what 4 GiB of
 	 * voice rows hold). The estimate is deliberately pessimistic (closed-form voices run four times faster): a script too
 	 * heavy for it starts, as before, with one call. SAU_AMD_READAHEAD=<frames> fixes the later runs' length instead. */
@@ -173,7 +173,7 @@ static bool generator_issue(sauGenerator *o, size_t big, size_t call_len, bool s
 	size_t frames = big;
 	if (o->ramp && call_len) {
 		/* the first run: what the estimate puts at FIRST_RUN_NS, in whole calls (at least one); then 2^grow_bits-fold from run to run */
-		constexpr double FIRST_RUN_NS = 3e6;
+		constexpr double FIRST_RUN_NS = 8e6; /* (estimated; a closed-form bank renders four times faster: BASELINE config 3's whole 10 s are one run of 2.5 ms) */
 		size_t first = (size_t)(FIRST_RUN_NS / o->est_ns_frame) / call_len * call_len;
 		if (first < call_len) first = call_len;
 		const unsigned sh = o->grow_bits * o->runs_issued;

@@ -152,6 +152,7 @@ bool Engine::handle_event(Stream &st, const EventNode &e, std::vector<OpUpdate> 
 			u.ras_level = od->mode.ras.level;
 			u.ras_alpha = od->mode.ras.alpha;
 			if (od->mode.ras.line == SAU_LINE_N_cub) m.ras_cub_seen = true;
+			m.ras_kind = (uint32_t)od->mode.ras.line | ((uint32_t)od->mode.ras.func << 8) | ((uint32_t)od->mode.ras.flags << 16);
 		}
 		if (u.type == SAU_POPT_N_wave && (od->params & SAU_POPP_MODE))
 			m.wave = od->mode.main < SAU_WAVE_NAMED ? od->mode.main : 0;
@@ -386,6 +387,7 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 	uint64_t wave_mask = 0;
 	bool maybe_block = false, serial = false, may_scan = false, maybe_cub = false;
 	uint32_t sum_levels = 0, n_chain_rows = 0, n_inc_rows = 0, n_look_rows = 0, n_may_scan = 0;
+	bool chain_rows_padded = false;
 	for (size_t s = 0; s < streams_.size(); ++s) {
 		Stream &st = streams_[s];
 		SegmentDesc::Stream &sd = sdescs[s];
@@ -494,6 +496,52 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 		s = e;
 	}
 	if (descs.empty()) return true;
+	/* Feedback chains are dealt to the chain kernels' waves 64 rows at a time (k_chain.h), and a wave whose R chains agree in
+	 * line shape, function and flags takes the copy of the loop with those dispatches scalar -- 340 ns per frame against about
+	 * 1000 where the 64 differ and every kind present is evaluated for all. So the rows of a
+	 * segment with R feedback are numbered kind by kind (voices without an R operator first, in voice order; nothing else
+	 * depends on the numbering: a row belongs to its voice through chain_base). */
+	static const bool no_chain_sort = tune_env("SAU_AMD_NO_CHAIN_SORT") != nullptr; /* (A/B: rows in voice order) */
+	if (n_chain_rows > 64 && !no_chain_sort) {
+		std::vector<std::pair<uint32_t, uint32_t>> order; /* (kind, index into descs) of the voices with chain rows */
+		bool any_r = false;
+		uint32_t vi = 0;
+		for (size_t s = 0; s < streams_.size(); ++s) {
+			const Stream &st = streams_[s];
+			for (; vi < sdescs[s].first_voice + sdescs[s].n_voices; ++vi) {
+				if (!descs[vi].n_chain) continue;
+				uint32_t kind = 0;
+				for (uint32_t k = 0; k < descs[vi].nops; ++k) {
+					const OpMirror &m = st.ops[all_op_ids_[descs[vi].ops_ofs + k] - st.op_base];
+					if (m.type == SAU_POPT_N_raseg) { kind = 1u + m.ras_kind; any_r = true; break; }
+				}
+				order.emplace_back(kind, vi);
+			}
+		}
+		if (any_r) {
+			std::stable_sort(order.begin(), order.end(), [](const std::pair<uint32_t, uint32_t> &a, const std::pair<uint32_t, uint32_t> &b) { return a.first < b.first; });
+			/* ... and every kind begins a wave of its own (a multiple of 64 rows; the rows in between stay unused: ChainDesc.n = 0)
+			 * while that costs no more than four times the rows and they fit half the backend's budget for this segment: the waves run side
+			 * by side, one per CU, so more of them cost nothing, and none then holds two kinds (1024 voices of 24 kinds: 861 ns
+			 * per frame numbered kind by kind, 1056 in voice order, profiles/r06_ab.txt) */
+			uint32_t padded = 0, prev = ~0u;
+			for (const auto &o : order) {
+				if (o.first != prev && o.first != 0 && prev != ~0u) padded = (padded + 63u) & ~63u;
+				prev = o.first;
+				padded += descs[o.second].n_chain;
+			}
+			const bool pad = padded <= 4 * n_chain_rows + 64 && (size_t)padded * 8 * len <= backend_->chain_rows_budget() / 2 &&
+				len <= chain_seg_frames(padded, backend_->chain_rows_budget());
+			uint32_t at = 0;
+			prev = ~0u;
+			for (const auto &o : order) {
+				if (pad && o.first != prev && o.first != 0 && prev != ~0u) at = (at + 63u) & ~63u;
+				prev = o.first;
+				descs[o.second].chain_base = at; at += descs[o.second].n_chain;
+			}
+			if (pad) { n_chain_rows = at; chain_rows_padded = true; }
+		}
+	}
 	SegmentDesc seg;
 	seg.len = len; seg.pcm_offset = offset; seg.stereo = stereo; seg.swap_bytes = pcm_swap_;
 	seg.voices = descs.data(); seg.n_voices = (uint32_t)descs.size();
@@ -510,6 +558,7 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 	seg.n_inc_rows = n_inc_rows;
 	seg.n_look_rows = n_look_rows;
 	seg.n_may_scan = n_may_scan;
+	seg.chain_rows_padded = chain_rows_padded;
 	return backend_->render(seg, err);
 }
 

@@ -59,6 +59,7 @@ struct SegmentDesc {
 	uint32_t n_inc_rows = 0;  /* row pairs the voices' inc_base/n_inc span (voices that may have running-sum phases) */
 	uint32_t n_look_rows = 0; /* rows the voices' look_base/n_look span (those of them without feedback chains) */
 	uint32_t n_may_scan = 0;  /* voices that may have running-sum phases this segment (the device decides: analyze_kernel) */
+	bool chain_rows_padded = false; /* some of the n_chain_rows row pairs belong to no voice (kinds of R feedback chains begin waves of their own) */
 };
 
 /* Bytes a backend has for the rows of a segment's feedback chains (8 B per chain and frame; the engine cuts segments with
@@ -147,6 +148,7 @@ struct OpMirror { /* host-side knowledge about one operator */
 	const sauProgramIDArr *mods[SAU_POP_NAMED] = {}; /* by use type; [0] unused */
 	uint8_t wave = 0;
 	bool ras_cub_seen = false;        /* an R operator that was ever given `cub` segments (conservative: SegmentDesc.maybe_cub) */
+	uint32_t ras_kind = 0;            /* an R operator's line shape | function << 8 | flags << 16 as last given (the order feedback chains are dealt to waves in) */
 	bool goal_seen = false;           /* some event gave one of its lines a sweep */
 	bool freq_goal_seen = false;      /* ... one of its frequency lines */
 	bool freq_ratio_seen = false;     /* some event gave one of its frequency lines a ratio (state or goal) */

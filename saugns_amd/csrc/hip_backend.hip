@@ -397,6 +397,7 @@ public:
 		inmix_enabled_ = tune_env("SAU_AMD_NO_INMIX") == nullptr;
 		tailmix_enabled_ = tune_env("SAU_AMD_TAILMIX") != nullptr;
 		duo_enabled_ = tune_env("SAU_AMD_NO_DUO") == nullptr;
+		mix64_enabled_ = tune_env("SAU_AMD_NO_MIX64") == nullptr;
 		xcd_queues_ = tune_env("SAU_AMD_NO_XCD_QUEUES") == nullptr;
 		inmix_taper_ = tune_env("SAU_AMD_INMIX_TAPER") != nullptr;
 		inmix_report_ = tune_env("SAU_AMD_INMIX_REPORT") != nullptr;
@@ -763,6 +764,9 @@ public:
 				const uint32_t cstride = (seg.len + 63) & ~63u;
 				if (!chain_desc_.ensure(seg.n_chain_rows, err) ||
 				    !fplines_.ensure((size_t)FAST_LISTS * seg.n_voices * fmax_steps * sizeof(FastLine), err)) return false;
+				/* (row pairs that belong to no voice -- the engine begins every kind of R feedback chain on a wave of its own -- must read
+				 * as unused: analyze_kernel clears the descriptors of the voices' pairs only) */
+				if (seg.chain_rows_padded) HIP_OK(hipMemsetAsync(chain_desc_.p, 0, (size_t)seg.n_chain_rows * sizeof(ChainDesc), stream_));
 				fp.chain_rows = chain_rows_.p; fp.chain_stride = cstride; fp.n_chain_rows = seg.n_chain_rows;
 				fp.chain_desc = chain_desc_.p; fp.fplines = (FastLine *)fplines_.p;
 				fp.chain_inline = chain_inline_ ? 1u : 0u;
@@ -984,6 +988,7 @@ public:
 					fp.look_wpv_flags = (tune_env("SAU_AMD_LOOK_NO_LDS") ? 1u : 0u) | (tune_env("SAU_AMD_LOOK_WITHHOLD") ? 2u : 0u) |
 						(tune_env("SAU_AMD_LOOK_SPREAD") ? 4u : 0u);
 					if (duo && tune_env("SAU_AMD_DUO_LW")) fp.look_wpv_flags |= ((uint32_t)atoi(tune_env("SAU_AMD_DUO_LW")) & 15u) << 8;
+					if (duo && tune_env("SAU_AMD_DUO_PRIO")) fp.look_wpv_flags |= ((uint32_t)atoi(tune_env("SAU_AMD_DUO_PRIO")) & 7u) << 12; /* 1: none, 2: 1, 3: 2 (default), 4: 3 */
 					if (duo) {
 						static size_t duo_configured[16];
 						const size_t dlds = ft * ftab_bytes + 16 * area + LOOK_LDS_BYTES;
@@ -1303,6 +1308,8 @@ public:
 			if (mix_few_enabled_ && max_rows <= 8 && seg.n_streams >= 8 && (seg.pcm_offset & 3u) == 0 && (pcm_row_ & 3u) == 0)
 				/* many streams of a few voices each: four frames per thread, no tile staging (k_finish.h) */
 				hipLaunchKernelGGL(mix_few_kernel, dim3((max_write + 1023) / 1024, seg.n_streams), dim3(256), 0, ms, mp);
+			else if (mp.inmix && !mp.early_blocks && mix64_enabled_)
+				hipLaunchKernelGGL(mix_kernel64, dim3((max_write + 63) / 64, seg.n_streams), dim3(64), 0, ms, mp);
 			else
 				hipLaunchKernelGGL(mix_kernel, dim3((max_write + 255) / 256, seg.n_streams), dim3(256), 0, ms, mp);
 			HIP_OK(hipGetLastError());
@@ -1635,6 +1642,7 @@ private:
 	                                   * the six flops, the clamp and the conversion per frame (and 42 spilled registers), the mixer gives back 0.25
 	                                   * (profiles/r06_ab.txt). Off; kept for the record */
 	bool tail_live_ = false;          /* this segment's look-back launch did: mix_few_kernel looks at tail_ok_ */
+	bool mix64_enabled_ = true;       /* behind a launch that has mixed most tiles itself: the mixer in blocks of 64 frames (SAU_AMD_NO_MIX64: 256) */
 	bool duo_enabled_ = true;         /* closed-form and look-back voices of a segment in one launch where there are plenty of both (SAU_AMD_NO_DUO: two launches) */
 	bool wide_tabs_ = true;
 	uint32_t more_rows_ = 12;

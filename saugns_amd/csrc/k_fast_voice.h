@@ -623,10 +623,15 @@ __global__ void __launch_bounds__(1024, 1) duo_kernel(FastParams P, FastParams Q
 	if (NVl && NVc) {
 		lw = (uint32_t)((16ull * NVl + (NVl + NVc) / 2) / ((unsigned long long)NVl + NVc));
 		lw = lw < 2 ? 2u : lw > 14 ? 14u : lw;
-		if (P.look_wpv_flags >> 8) lw = (P.look_wpv_flags >> 8) & 15u; /* (SAU_AMD_DUO_LW: a tuning aid) */
+		if ((P.look_wpv_flags >> 8) & 15u) lw = (P.look_wpv_flags >> 8) & 15u; /* (SAU_AMD_DUO_LW: a tuning aid) */
 	}
 	if ((uint32_t)w < lw) {
-		if (lw < (uint32_t)W) __builtin_amdgcn_s_setprio(2); /* (the waves whose waits set the launch's length go first) */
+		if (lw < (uint32_t)W) { /* (the waves whose waits set the launch's length go first; look_wpv_flags bits 12-14: SAU_AMD_DUO_PRIO, a tuning aid) */
+			const uint32_t pr = (P.look_wpv_flags >> 12) & 7u;
+			if (pr == 0 || pr == 3) __builtin_amdgcn_s_setprio(2);
+			else if (pr == 2) __builtin_amdgcn_s_setprio(1);
+			else if (pr == 4) __builtin_amdgcn_s_setprio(3);
+		}
 		unsigned long long *carry = (unsigned long long *)(areas + (size_t)w * area_bytes + (size_t)P.n_fast * NP * sizeof(float));
 		const uint32_t g = blockIdx.x * lw + (uint32_t)w, total_waves = gridDim.x * lw;
 		uint32_t wpv = total_waves / NVl; /* (this launch always comes with the words in HBM: a voice may spread over workgroups) */

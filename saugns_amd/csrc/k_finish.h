@@ -231,10 +231,11 @@ struct MixParams {
 #endif
 constexpr int MIX_TILE = 256; /* voices whose constants are staged at a time */
 constexpr int MIX_AHEAD = 32; /* loads per batch and thread */
+template <int BLK = 256>
 __device__ __forceinline__ void mix_body(const MixParams &P, const MixStream &ms, const uint32_t bx,
 		float *s_pan, uint32_t *s_valid, uint32_t *s_prow, uint32_t &s_special, const bool covered = false) {
-	const uint32_t tl = threadIdx.x; /* within the 256 frames of bx */
-	const uint32_t i = bx * 256 + tl;
+	const uint32_t tl = threadIdx.x; /* within the BLK frames of bx */
+	const uint32_t i = bx * BLK + tl;
 	const bool act = i < ms.write_len && !covered;
 	float L = 0.f, R = 0.f;
 	for (uint32_t r0 = 0; r0 < ms.n_rows; r0 += MIX_TILE) {
@@ -242,11 +243,11 @@ __device__ __forceinline__ void mix_body(const MixParams &P, const MixStream &ms
 		__syncthreads();
 		if (tl == 0) s_special = 0;
 		__syncthreads();
-		if (tl < nt) {
-			const VoiceOut vo = P.vinfo[ms.first_row + r0 + tl];
-			s_pan[tl] = vo.pan_const;
-			s_valid[tl] = vo.valid_len;
-			s_prow[tl] = vo.has_pan ? vo.pan_row : ~0u;
+		for (uint32_t q = tl; q < nt; q += BLK) {
+			const VoiceOut vo = P.vinfo[ms.first_row + r0 + q];
+			s_pan[q] = vo.pan_const;
+			s_valid[q] = vo.valid_len;
+			s_prow[q] = vo.has_pan ? vo.pan_row : ~0u;
 			if (vo.has_pan || vo.valid_len < ms.write_len) s_special = 1;
 		}
 		__syncthreads();
@@ -327,20 +328,21 @@ __device__ __forceinline__ void mix_body(const MixParams &P, const MixStream &ms
 	}
 }
 
-__global__ void __launch_bounds__(256) mix_kernel(MixParams P) {
+template <int BLK>
+__device__ __forceinline__ void mix_kernel_body(const MixParams &P) {
 	__shared__ float s_pan[MIX_TILE];
 	__shared__ uint32_t s_valid[MIX_TILE];
 	__shared__ uint32_t s_prow[MIX_TILE]; /* pan row, or ~0u */
 	__shared__ uint32_t s_special;        /* tile has a short row or a pan row */
 	const MixStream ms = P.streams[blockIdx.y];
-	const uint32_t bx = blockIdx.x + P.blk_lo;
-	if (bx * 256 >= ms.write_len || (P.blk_hi && bx >= P.blk_hi)) return;
+	const uint32_t bx = blockIdx.x + P.blk_lo; /* (blk_lo, blk_hi, early_blocks: in blocks of 256 frames -- the 256-frame form's only) */
+	if (bx * BLK >= ms.write_len || (P.blk_hi && bx >= P.blk_hi)) return;
 	if (P.blk_hi && P.guard[1]) return; /* an early launch, and premix_kernel could not speak for every voice: their records are not there yet */
 	if (P.early_blocks && bx < P.early_blocks && P.guard[0] == 0 && P.guard[1] == 0) return; /* mixed by an early launch, and it stands */
 	bool covered = false;
 	if (P.inmix && P.guard[0] == 0 && P.guard[1] == 0) {
 		/* frames the closed-form launch has mixed itself: those of the tiles with their bits set (and it stands) */
-		const uint32_t cf = P.inmix[INMIX_CF], i = bx * 256 + threadIdx.x;
+		const uint32_t cf = P.inmix[INMIX_CF], i = bx * BLK + threadIdx.x;
 		const uint32_t base = P.inmix[INMIX_BASE], cfs = P.inmix[INMIX_CFS]; /* (the short chunks at the end: k_fast_types.h) */
 		uint32_t k = 0, j = 0;
 		if (i < base || !cfs) { k = cf ? i / cf : 0u; j = cf ? (i - k * cf) / INMIX_TILE : 0u; }
@@ -348,8 +350,13 @@ __global__ void __launch_bounds__(256) mix_kernel(MixParams P) {
 		covered = k < P.inmix[INMIX_NCH] && ((P.inmix[INMIX_CHUNK + INMIX_LINE * k + INMIX_BITS + (j >> 5)] >> (j & 31u)) & 1u) != 0;
 		if (__syncthreads_and(covered)) return;
 	}
-	mix_body(P, ms, bx, s_pan, s_valid, s_prow, s_special, covered);
+	mix_body<BLK>(P, ms, bx, s_pan, s_valid, s_prow, s_special, covered);
 }
+__global__ void __launch_bounds__(256) mix_kernel(MixParams P) { mix_kernel_body<256>(P); }
+/* ... in blocks of 64 frames, a wave each: what follows a closed-form launch that has mixed most of the tiles itself (round 6). What
+ * is left then is a few hundred tiles in a row -- each XCD's last chunk -- and as workgroups of 256 frames x 1024 rows (1 MB of
+ * loads each) they were one or two per CU, by chance: 87 us for 0.36 GB. A quarter the size they spread evenly */
+__global__ void __launch_bounds__(64) mix_kernel64(MixParams P) { mix_kernel_body<64>(P); }
 
 /* Streams of a few voices each (a batch of many small scripts: BASELINE config 4 has two voices per render): four
  * consecutive frames per thread, 16-byte row loads, per-row records read straight from memory -- mix_kernel's tile

@@ -961,6 +961,25 @@ def test_feedback_chains_that_running_sums_depend_on(sa, oracle, early, monkeypa
             assert len(got) == len(want) and len(d) == 0, (len(vs), chunk, len(d), d[:4])
 
 
+def test_r_feedback_bank_of_many_kinds(sa, oracle):
+    """R oscillators with self-modulation (rasg.h:242-294: rchain_kernel, lanes = voices) in a bank whose neighbours differ in line
+    shape, function and flags -- 24 kinds over 200 voices, interleaved, a few W feedback voices among them: the host numbers the
+    chains' rows kind by kind (engine.cpp, round 6) so that a wave's 64 chains agree and take the scalarised copy of the loop;
+    the PCM is the oracle's whatever the numbering."""
+    from saugns_amd.api import POPT_RASEG
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
+    voices = []
+    for k in range(200):
+        if k % 25 == 7:
+            voices.append(vb.Op("sin", freq=110.0 + k, pm_a=0.4 + 0.002 * k, amp=0.5, time_ms=400))
+        else:
+            voices.append(vb.Op(op_type=POPT_RASEG, ras=(("lin", "cos", "sqe", "xpe")[k % 4], (k // 4) % 6, (0, 5, 17, 31)[(k // 24) % 4]),
+                                seed=900 + 13 * k, freq=vb.Line(90.0 + 7 * (k % 40), goal=240.0 + k % 60, shape="exp") if k % 3 else 150.0 + k % 80,
+                                pm_a=vb.Line(0.1 + 0.01 * (k % 30), goal=0.8, shape="lin") if k % 2 else 0.45, amp=0.5, time_ms=400))
+    check(sa, oracle, voices, chunk=1000000)
+    check(sa, oracle, voices, chunk=7000, stereo=True)
+
+
 @pytest.mark.parametrize("lookback", ["on", "off"])
 def test_running_sums_by_look_back(sa, oracle, lookback, monkeypatch):
     """Running-sum phases in one pass (every wave publishes its row group's sum and looks back

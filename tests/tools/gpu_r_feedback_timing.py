@@ -12,7 +12,7 @@ tabs = np.fromfile(os.path.join(ROOT, "tests/golden/piluts_ref.f32"), dtype="<f4
 sa.set_piluts(tabs)
 po.build(ref=False); po.oracle_use_tables(tabs); po.oracle().ora_set_fastmath_forms(2)
 SEC = 10
-for n in (1, 8, 64, 1024):
+for n in (1, 8, 64, 1024, 4096):
     voices = [vb.Op(op_type=POPT_RASEG, ras=(("lin", "cos", "sqe", "xpe")[k % 4], k % 6, (5 * k) % 32), seed=1234 + 77 * k,
                     freq=vb.Line(90.0 + 11 * (k % 50), goal=300.0 + k % 70, shape="exp") if k % 3 else 140.0 + k % 90,
                     pm_a=vb.Line(0.1 + 0.01 * (k % 40), goal=0.9, shape="lin") if k % 2 else 0.5, amp=0.6, time_ms=SEC * 1000)
