@@ -124,6 +124,28 @@ def sha_checked(rec):
     return isinstance(v, str) and v.startswith("SHA-256 of every one")
 
 
+def profile_chain_issue():
+    """config 5's chain_kernel from the hash-matched PMC summary: vector instructions per chain-wave cycle -- how busy the one
+    wave per 64 chains keeps its SIMD (the recurrence is a dependent chain: most cycles issue nothing)."""
+    pdir = os.path.join(ROOT, "profiles")
+    for f in sorted(os.listdir(pdir), reverse=True):
+        if not f.endswith("_c5_pmc_summary.json"):
+            continue
+        try:
+            pmc = json.load(open(os.path.join(pdir, f)))
+            if pmc.get("kernel_source_sha") != kernel_source_hash():
+                continue
+            k = [v for n, v in pmc["kernels"].items() if n.endswith("::chain_kernel") or "::chain_kernel" in n][0]
+            # SQ_WAVE_CYCLES counts quad-cycles per resident wave (3 waves per workgroup: the chain wave and its two feeders)
+            return {"valu_insts_per_launch": k["SQ_INSTS_VALU"], "wave_quad_cycles_per_launch": k["SQ_WAVE_CYCLES"],
+                    "valu_insts_per_wave_cycle": k["SQ_INSTS_VALU"] / (4.0 * k["SQ_WAVE_CYCLES"]),
+                    "is": "vector instructions issued per cycle of a resident wave of chain_kernel (chain wave + 2 feeder waves per 64 chains); "
+                          "a wave that issued back to back would show about 0.25", "source": "profiles/" + f}
+        except (OSError, KeyError, ValueError, IndexError):
+            pass
+    return None
+
+
 def hbm_convention(achieved, alg, key="bytes_per_step"):
     """SURVEY 8d's byte model as a nested record: a convention (operator blocks priced as HBM traffic), not a roof the
     time-parallel kernels touch -- they keep those blocks in LDS."""
@@ -856,6 +878,13 @@ def run_config5(args, R, sa, tabs, steps=None, warmup=None):
         # of chain_kernel against the bare recurrence on this part (tools/chain_probe2.hip: 96.9 ns with the wide table entries)
         "roofline": {"bound": "latency", "achieved": kern_s * 1e9 / frames, "peak": 96.9, "unit": "ns per sample step of the feedback recurrence (lower is better)",
                      "frac": (96.9 / (kern_s * 1e9 / frames)) if kern_s > 0 else None,
+                     #  `peak` is this kernel's OWN bare loop -- the same 36 dependent instructions without their
+                     # surroundings --, so `frac` says how little the kernel adds to its recurrence, not how far the machine is:
+                     "peak_is": "own bare loop (tools/chain_probe2.hip): the recurrence's dependent instructions alone on this part",
+                     # ... which is mostly idle: one wave per 64 chains runs the recurrence
+                     "waves_resident": (args.voices5 + 63) // 64, "simds": 1024,
+                     "simds_occupied_frac": ((args.voices5 + 63) // 64) / 1024.0,
+                     "chain_wave_issue": profile_chain_issue(),
                      "algorithmic": hbm_convention(achieved, alg), "traffic": traffic5, "traffic_source": source5,
                      "traffic_is": "HBM bytes of every kernel of one step",
                      "kernel": "feedback recurrence + block loop (" + dom + ")",

@@ -28,7 +28,30 @@ COSTS = json.load(open("profiles/r05_valu_costs.json"))
 CLASSES = ("ADD_F64", "MUL_F64", "FMA_F64", "TRANS_F64", "ADD_F32", "MUL_F32", "FMA_F32", "TRANS_F32", "CVT", "INT32", "INT64")
 
 
-def valu_side(v):
+# what SQ_INSTS_VALU counts beyond the arithmetic classes (moves, DPP moves, lane reads / writes, compares,
+# selects) used to be priced as ONE bucket at 3.72 cycles; the ISA census (tools/isa_census.py -> profiles/census/) names its
+# parts per kernel, and the probe (profiles/r05_valu_probe.json) has a price for each: v_mov_b32 2.3, v_mov_b32_dpp 4.4,
+# v_readlane / v_writelane 4.25, v_cmp 4.25, v_cndmask on a scalar mask 4.25.
+OTHER_PRICES = {"move (v_mov_b32/b64)": 2.3, "DPP move (v_mov_b32_dpp)": 4.4, "lane read/write (v_readlane, v_writelane)": 4.25,
+                "compare": 4.25, "select (v_cndmask)": 4.25, "other vector": 4.25}
+CENSUS_OF = {"fast_kernel<12, 0, false, true, false>": "profiles/census/r06_config3_census.json",
+             "fast_kernel<8, 2, false, true, false>": "profiles/census/r06_fmbank_census.json",
+             "fast_kernel<8, 2, false, false, false>": "profiles/census/r06_lookback_census.json",
+             "duo_kernel": "profiles/census/r06_lookback_census.json"}  # (its look-back waves' code; the closed-form waves' is fast_kernel<8, 0>'s)
+
+
+def other_price(kernel):
+    """cycles per instruction of the kernel's non-arithmetic vector instructions, from its census (None: no census)"""
+    for k, f in CENSUS_OF.items():
+        if k in kernel and os.path.exists(f):
+            kinds = json.load(open(f))["valu_by_kind_per_operator_sample"]
+            n = sum(x for q, x in kinds.items() if q in OTHER_PRICES)
+            if n > 0:
+                return sum(x * OTHER_PRICES[q] for q, x in kinds.items() if q in OTHER_PRICES) / n, f
+    return None, None
+
+
+def valu_side(v, kernel=""):
     """the VALU side of the roofline from a kernel's counters. With the class census (SQ_INSTS_VALU_*:
     tools/pmc_classes.sh / the `cls` passes of tools/profile_round.sh) every class is priced with the issue cost
     tools/valu_probe.hip measured (profiles/r05_valu_costs.json), what SQ_INSTS_VALU counts beyond the classes -- moves
@@ -45,8 +68,12 @@ def valu_side(v):
         census = {c: v["SQ_INSTS_VALU_" + c] for c in CLASSES}
         census["OTHER"] = max(0.0, n - sum(census.values()))
         out["census_frac"] = {c: round(x / n, 4) for c, x in census.items()} if n else None
+        op, src = other_price(kernel)
+        if op is not None:
+            out["other_price_cycles"] = round(op, 3)
+            out["other_price_from"] = src
         for name in ("pure", "in_mix"):
-            w = sum(x * COSTS[name][c] for c, x in census.items())
+            w = sum(x * (op if (c == "OTHER" and op is not None) else COSTS[name][c]) for c, x in census.items())
             out["weighted_cycles_" + name] = w
             out["frac_" + name] = w / (1024 * cycles)
         # the figure on the bench line: priced with every class's best case, i.e. the least the kernel can be using
@@ -83,7 +110,7 @@ for d, f in (("fetch", "f"), ("write", "w"), ("sq", "s"), ("inst", "i"), ("grbm"
 for k, v in out["kernels"].items():
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         v["hbm_bytes_per_launch_corrected"] = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
-    vs = valu_side(v)
+    vs = valu_side(v, k)
     if vs:
         v["valu"] = vs
 json.dump(out, open(f"profiles/{name}_pmc_summary.json", "w"), indent=1)
@@ -122,7 +149,7 @@ for wl, wname in (("c5", "config5"), ("c4", "config4"), ("fmbank", "fm"), ("conf
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             v["hbm_bytes_per_launch_corrected"] = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
             total += v["hbm_bytes_per_launch_corrected"] * v["launches"]
-        vs = valu_side(v)
+        vs = valu_side(v, k)
         if vs:
             v["valu"] = vs
     json.dump({"command": f"rocprofv3 --pmc <C> --kernel-trace -- python3 bench.py --workload {wname} --steps 1 --warmup 0 --no-cpu",

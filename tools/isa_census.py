@@ -114,7 +114,7 @@ def kernel_range(name):
     out = subprocess.run(["nm", "-C", "--print-size", "--defined-only", WORK + "/kg.elf"], capture_output=True, text=True).stdout
     for ln in out.splitlines():
         p = ln.split(None, 3)
-        if len(p) == 4 and p[2] in "Tt" and (p[3] in ("void sauhip::" + name + "(sauhip::FastParams)", "sauhip::" + name + "(sauhip::FastParams)") or p[3] == name):
+        if len(p) == 4 and p[2] in "Tt" and (p[3].startswith(("void sauhip::" + name + "(", "sauhip::" + name + "(")) or p[3] == name):
             return int(p[0], 16), int(p[1], 16)
     raise SystemExit("no kernel named %s in the code object" % name)
 
