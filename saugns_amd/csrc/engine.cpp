@@ -677,7 +677,9 @@ bool Engine::run(int16_t *const *host_bufs, size_t buf_len, bool stereo,
 		 * soon after the earliest such frame -- on a grid, so that staggered envelopes cost a
 		 * handful of segments per run, not one each. (The mirrored times are conservative: an
 		 * operator may in fact stop earlier, which costs one superfluous cut.) */
-		constexpr uint32_t EXPIRY_GRID = 8192;
+		/* (SAU_AMD_EXPIRY_GRID=<frames>, a tuning switch: 1 cuts at the frame itself -- no voice then leaves the time-parallel path
+		 * for an operator that runs out, at a segment per such frame; measured over the corpus in DESIGN.md 10) */
+		static const uint32_t EXPIRY_GRID = [] { const char *e = tune_env("SAU_AMD_EXPIRY_GRID"); const long n = e ? atol(e) : 0; return n >= 1 ? (uint32_t)n : 8192u; }();
 		if (seg > EXPIRY_GRID) {
 			uint32_t first = seg;
 			size_t chains = 0;

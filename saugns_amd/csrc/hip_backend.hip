@@ -403,12 +403,15 @@ public:
 		inmix_report_ = tune_env("SAU_AMD_INMIX_REPORT") != nullptr;
 		if (const char *ia = tune_env("SAU_AMD_INMIX_AT")) inmix_at_ = (uint32_t)atoi(ia) & 15u;
 		if (const char *mv = tune_env("SAU_AMD_INMIX_MIN_VOICES")) inmix_min_voices_ = (uint32_t)atoi(mv);
+		if (const char *ms = tune_env("SAU_AMD_INMIX_MIN_STEPS")) inmix_min_steps_ = (uint32_t)atoi(ms);
 		short_last_chunk_ = tune_env("SAU_AMD_NO_SHORT_LAST_CHUNK") == nullptr;
 		lean_enabled_ = tune_env("SAU_AMD_NO_LEAN") == nullptr; /* chains' passes in a build without the several-pass sums */
 		dyn_enabled_ = tune_env("SAU_AMD_NO_DYN") == nullptr; /* closed-form launches deal tasks out through a counter */
 		wide_tabs_ = tune_env("SAU_AMD_NO_WIDE_TABS") == nullptr; /* closed-form launches with f64 [c1, c0] table entries in LDS */
 		if (const char *mr = tune_env("SAU_AMD_MORE_ROWS")) more_rows_ = (uint32_t)atoi(mr); /* 0, 10 or 12 */
 		if (const char *dg = tune_env("SAU_AMD_DYN_GROUPS")) { const int n = atoi(dg); dyn_groups_ = n >= 1 ? (uint32_t)n : 1u; }
+		if (const char *df = tune_env("SAU_AMD_DYN_FLOOR")) { const int n = atoi(df); dyn_floor_ = n >= 1 ? (uint32_t)n : 1u; }
+		if (const char *dt = tune_env("SAU_AMD_DYN_MIN_TASKS")) { const int n = atoi(dt); dyn_min_tasks_ = n >= 1 ? (uint32_t)n : 1u; }
 		/* voices per segment from which feedback voices get sixteen one-wave teams per workgroup
 		 * (0: never; 1: always, also without feedback -- tests) */
 		multi_min_ = 256;
@@ -938,9 +941,9 @@ public:
 					const uint32_t waves = grid * 16;
 					const uint32_t S = seg.max_steps ? seg.max_steps : 1;
 					uint32_t G = dyn_groups_;
-					if (G * S < 48) G = (48 + S - 1) / S;
+					if (G * S < dyn_floor_) G = (dyn_floor_ + S - 1) / S;
 					const uint32_t k_dyn = (n_groups + G - 1) / G;
-					if (dyn_enabled_ && (unsigned long long)seg.n_voices * k_dyn >= 4ull * waves) {
+					if (dyn_enabled_ && (unsigned long long)seg.n_voices * k_dyn >= (unsigned long long)dyn_min_tasks_ * waves) {
 						q.dyn_chunks = k_dyn ? k_dyn : 1;
 						q.dyn_static = 0;
 					} else {
@@ -1164,7 +1167,7 @@ public:
 						if (inmix_taper_) {
 							const uint32_t S_ = seg.max_steps ? seg.max_steps : 1;
 							uint32_t G = dyn_groups_;
-							if (G * S_ < 48) G = (48 + S_ - 1) / S_;
+							if (G * S_ < dyn_floor_) G = (dyn_floor_ + S_ - 1) / S_;
 							const uint32_t small = G / 4 ? G / 4 : 1;
 							if (groups >= 32 * G + INMIX_NSMALL * small) {
 								fp.dyn_small = small;
@@ -1181,7 +1184,8 @@ public:
 						/* ... and a bank of voices mixed into one stream: the launch mixes its own rows, chunk by chunk behind the rendering;
 						 * premix_kernel has the last word. Config 3: 2.056 -> 1.995 ms per step (the launch 1.74 -> 1.87 ms, the mixer
 						 * 0.26 -> 0.07 ms) */
-						if (inmix_enabled_ && seg.n_streams == 1 && max_write && seg.n_voices >= inmix_min_voices_ && row_stride_ < (1u << 24)) {
+						if (inmix_enabled_ && seg.n_streams == 1 && max_write && seg.n_voices >= inmix_min_voices_ && seg.max_steps >= inmix_min_steps_ &&
+						    row_stride_ < (1u << 24)) {
 							fp.inmix_stream = S.mstreams.p;
 							fp.inmix_flags = 64u | 32u | (seg.stereo ? 1u : 0u) | (seg.swap_bytes ? 2u : 0u) | (tune_env("SAU_AMD_INMIX_DRY") ? 4u : 0u) | ((inmix_at_ & 15u) << 8);
 							fp.inmix_pcm_offset = seg.pcm_offset;
@@ -1630,6 +1634,8 @@ private:
 	bool xcd_queues_ = true;          /* a closed-form launch's tasks come from one queue per XCD, chunk-major (SAU_AMD_NO_XCD_QUEUES: the one counter, voice-major) */
 	bool inmix_enabled_ = true;       /* a many-voice stream's closed-form launch mixes its own rows (SAU_AMD_NO_INMIX: the mixer alone) */
 	uint32_t inmix_min_voices_ = 64;  /* ... from that many voices on (SAU_AMD_INMIX_MIN_VOICES) */
+	uint32_t inmix_min_steps_ = 2;    /* ... of two steps or more (SAU_AMD_INMIX_MIN_STEPS): behind one-step voices (config 2) the launch's mixing
+	                                   * costs it more than the mixer saves -- step 0.269-0.272 ms with it, 0.258-0.261 without */
 	bool inmix_live_ = false;         /* this segment's launch did: mix_kernel looks at the control words */
 	bool inmix_taper_ = false;        /* SAU_AMD_INMIX_TAPER: the queues' last eight chunks are short ones, so that less is left to mix_kernel. Measured
 	                                   * slower on config 3 (2.04 -> 2.08 ms per step, the launch 1.91 -> 1.94: profiles/r06_ab.txt): off */
@@ -1648,6 +1654,12 @@ private:
 	uint32_t more_rows_ = 12;
 	uint32_t lean_rows_ = 6;    /* SAU_AMD_LEAN_ROWS: rows per pass of fast_kernel<T, 3> at most (6, 5 or 4) */
 	uint32_t dyn_groups_ = 12;  /* row groups per task of a closed-form launch, at least (SAU_AMD_DYN_GROUPS) */
+	/* ... and steps x row groups per task, at least (SAU_AMD_DYN_FLOOR), and the tasks per wave from which the queues deal them out
+	 * (fewer: a fixed share per wave; SAU_AMD_DYN_MIN_TASKS). Round 6: 48 -> 24 and 4 -> 2, which takes BASELINE config 2 (256 voices of
+	 * one step: 20 tasks a voice were 1.25 a wave, so every wave got a sixteenth of a voice, fixed) to the queues: its launch 0.192 ->
+	 * 0.163-0.166 ms, the step 0.287 -> 0.259 (floors 4-12 the same, 16: 0.272; profiles/r06_ab.txt [17]) */
+	uint32_t dyn_floor_ = 24;
+	uint32_t dyn_min_tasks_ = 2;
 	bool look_words_real_ = false; /* this segment's look-back words in HBM are usable (not the token block) */
 	DevBuf<uint32_t> vlists_;   /* [2][n_voices]: analyze_kernel's lists of closed-form and look-back voices (split launches) */
 	uint32_t look_wpv_ = 1;     /* this segment's single-pass launch: waves per voice, and whether every voice sits */
