@@ -587,6 +587,68 @@ def test_every_backend_has_its_own_budget_for_the_chains_rows(sa, oracle, seqexe
     assert run(64 << 30, 0) == roomy  # the tight device's failures are its own
 
 
+_EXPIRY_CHILD = r"""
+import ctypes as C, json, os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np
+import saugns_amd as sa
+from saugns_amd import voicebank as vb
+from saugns_amd.api import POP_PMOD
+import hashlib
+import conftest
+sa.lib(); sa.set_piluts(np.fromfile(os.path.join(sys.argv[1], "tests", "golden", "piluts_ref.f32"), dtype="<f4").reshape(12, 2048))
+sa.api.use_hooks(conftest.hooks_path())
+lib = C.CDLL(sys.argv[2])
+lib.seq_backend_create.restype = C.c_void_p; lib.seq_backend_create.argtypes = [C.c_uint32]
+lib.seq_backend_segments.argtypes = [C.c_void_p, C.c_void_p]
+short = vb.Op("sin", freq=vb.Line(3.0, ratio=True), amp=1.0, time_ms=700)    # runs out at frame 30870
+shorter = vb.Op("tri", freq=vb.Line(2.0, ratio=True), amp=0.6, time_ms=250)  # ... and at 11025
+prg = vb.build_program([vb.Op("sin", freq=146.832, time_ms=2000, mods={POP_PMOD: [short]}),
+                        vb.Op("sin", freq=220.0, time_ms=2000, mods={POP_PMOD: [shorter]})])
+be = lib.seq_backend_create(1024)
+b = sa.Batch([prg], 44100, backend=be)
+pcm = b.render(stereo=False, chunk=88200)[0]
+seg = (C.c_uint32 * 2)(); lib.seq_backend_segments(be, seg); b.close()
+print("RESULT " + json.dumps({"segments": seg[0], "longest": seg[1], "sha": hashlib.sha256(np.ascontiguousarray(pcm).tobytes()).hexdigest()}))
+"""
+
+
+def test_a_long_segment_ends_soon_after_an_operator_runs_out_of_time(seqexec, oracle):
+    """generator.c:686-700: an operator out of time stands still and yields silence while its voice plays on. The time-parallel
+    path renders a voice up to the first such frame and the block loop takes it from there to the segment's end, so the engine cuts
+    a long segment on a grid of 8192 frames after that frame (engine.cpp); SAU_AMD_EXPIRY_GRID=1 cuts at the frame itself. Two
+    modulators running out at frames 11025 and 30870 of an 88200-frame run: 16384 | 32768 | the rest on the grid, 11025 | 30870 | the
+    rest without it; the same PCM, which is the oracle's."""
+    import json
+    import subprocess
+    import sys
+    import hashlib
+    from saugns_amd import voicebank as vb
+    from saugns_amd.api import POP_PMOD
+    path = os.environ.get("SAU_SEQEXEC_LIB") or os.path.join(ROOT, "tests", "seqexec", "libseqexec.so")
+
+    def run(grid):
+        env = dict(os.environ, SAU_AMD_TUNE="1")
+        env.pop("SAU_AMD_EXPIRY_GRID", None)
+        if grid:
+            env["SAU_AMD_EXPIRY_GRID"] = grid
+        out = subprocess.run([sys.executable, "-c", _EXPIRY_CHILD, ROOT, path], env=env, capture_output=True, text=True, timeout=300)
+        line = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")]
+        assert line, out.stderr[-2000:]
+        return json.loads(line[0][7:])
+
+    on_grid, exact = run(None), run("1")
+    assert on_grid["segments"] == 3 and on_grid["longest"] == 88200 - 32768, on_grid
+    assert exact["segments"] == 3 and exact["longest"] == 88200 - 30870, exact
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
+    short = vb.Op("sin", freq=vb.Line(3.0, ratio=True), amp=1.0, time_ms=700)
+    shorter = vb.Op("tri", freq=vb.Line(2.0, ratio=True), amp=0.6, time_ms=250)
+    prg = vb.build_program([vb.Op("sin", freq=146.832, time_ms=2000, mods={POP_PMOD: [short]}),
+                            vb.Op("sin", freq=220.0, time_ms=2000, mods={POP_PMOD: [shorter]})])
+    want = hashlib.sha256(np.ascontiguousarray(oracle.oracle_render(prg.ptr, 44100, False, chunk=88200)).tobytes()).hexdigest()
+    assert on_grid["sha"] == want and exact["sha"] == want
+
+
 def test_product_library_exports_only_the_abi():
     """test probes and hooks are not exports of libsaugns_amd.so (they live in tests/hooks). What it
     exports is include/saugns_amd.h + the reference's four generator symbols (+ the kernels' host stubs, which hipcc emits
