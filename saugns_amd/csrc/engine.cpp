@@ -386,7 +386,7 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 	uint32_t n_main = 1, n_fpool = 0, max_ops = 1, n_pan = 0, max_steps = 1, n_fast = 1, n_fast_full = 0;
 	uint64_t wave_mask = 0;
 	bool maybe_block = false, serial = false, may_scan = false, maybe_cub = false;
-	uint32_t sum_levels = 0, n_chain_rows = 0, n_inc_rows = 0, n_look_rows = 0, n_may_scan = 0;
+	uint32_t sum_levels = 0, n_chain_rows = 0, n_chain_slots = 0, n_inc_rows = 0, n_look_rows = 0, n_may_scan = 0;
 	bool chain_rows_padded = false;
 	for (size_t s = 0; s < streams_.size(); ++s) {
 		Stream &st = streams_[s];
@@ -434,7 +434,7 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 				(vn.plan.wide ? VD_WIDE : 0);
 			d.lat = lat;
 			d.ev_left = ev_left;
-			d.chain_base = n_chain_rows; d.n_chain = vn.plan.n_chain;
+			d.chain_base = n_chain_rows; d.chain_slot = n_chain_rows; d.n_chain = vn.plan.n_chain;
 			n_chain_rows += vn.plan.n_chain;
 			d.inc_base = 0; d.n_inc = 0; /* (set below for voices that may have running-sum phases) */
 			d.look_base = 0; d.n_look = 0;
@@ -500,9 +500,9 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 	 * line shape, function and flags takes the copy of the loop with those dispatches scalar -- 340 ns per frame against about
 	 * 1000 where the 64 differ and every kind present is evaluated for all. So the rows of a
 	 * segment with R feedback are numbered kind by kind (voices without an R operator first, in voice order; nothing else
-	 * depends on the numbering: a row belongs to its voice through chain_base). */
+	 * depends on the numbering: a row belongs to its voice through chain_base, a lane through chain_slot). */
 	static const bool no_chain_sort = tune_env("SAU_AMD_NO_CHAIN_SORT") != nullptr; /* (A/B: rows in voice order) */
-	if (n_chain_rows > 64 && !no_chain_sort) {
+	if (n_chain_rows > 1 && !no_chain_sort) { /* (until round 6: from 65 rows on; eight voices of eight kinds in one wave took 1086 ns per frame) */
 		std::vector<std::pair<uint32_t, uint32_t>> order; /* (kind, index into descs) of the voices with chain rows */
 		bool any_r = false;
 		uint32_t vi = 0;
@@ -513,33 +513,36 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 				uint32_t kind = 0;
 				for (uint32_t k = 0; k < descs[vi].nops; ++k) {
 					const OpMirror &m = st.ops[all_op_ids_[descs[vi].ops_ofs + k] - st.op_base];
-					if (m.type == SAU_POPT_N_raseg) { kind = 1u + m.ras_kind; any_r = true; break; }
+					/* (... and whether its lines were ever given sweeps: the feeder waves' line evaluations dispatch on the shapes) */
+					if (m.type == SAU_POPT_N_raseg) { kind = 1u + (m.ras_kind | (m.freq_goal_seen ? 1u << 24 : 0u) | (m.goal_seen ? 1u << 25 : 0u)); any_r = true; break; }
 				}
 				order.emplace_back(kind, vi);
 			}
 		}
 		if (any_r) {
 			std::stable_sort(order.begin(), order.end(), [](const std::pair<uint32_t, uint32_t> &a, const std::pair<uint32_t, uint32_t> &b) { return a.first < b.first; });
-			/* ... and every kind begins a wave of its own (a multiple of 64 rows; the rows in between stay unused: ChainDesc.n = 0)
-			 * while that costs no more than four times the rows and they fit half the backend's budget for this segment: the waves run side
-			 * by side, one per CU, so more of them cost nothing, and none then holds two kinds (1024 voices of 24 kinds: 861 ns
-			 * per frame numbered kind by kind, 1056 in voice order, profiles/r06_ab.txt) */
+			/* ... and every kind begins a wave of its own: the LANES are numbered with gaps (a multiple of 64 per kind; the lanes in
+			 * between stay unused: ChainDesc.n = 0), the rows without -- a gap costs a descriptor, no memory -- while the waves, one
+			 * workgroup each, still run side by side (five workgroups a CU by their LDS: 1280; the cap is 1024). None then holds two
+			 * kinds (1024 voices of 24 kinds: 861 ns per frame numbered kind by kind, 1056 in voice order, profiles/r06_ab.txt;
+			 * until the rows and the lanes had numbers of their own the gaps cost rows, and 4096 voices x 10 s of 96 kinds did not
+			 * fit half the budget: 564 ns per frame where the slowest kind alone takes 405) */
 			uint32_t padded = 0, prev = ~0u;
 			for (const auto &o : order) {
 				if (o.first != prev && o.first != 0 && prev != ~0u) padded = (padded + 63u) & ~63u;
 				prev = o.first;
 				padded += descs[o.second].n_chain;
 			}
-			const bool pad = padded <= 4 * n_chain_rows + 64 && (size_t)padded * 8 * len <= backend_->chain_rows_budget() / 2 &&
-				len <= chain_seg_frames(padded, backend_->chain_rows_budget());
-			uint32_t at = 0;
+			const bool pad = padded <= 64u * 1024u || padded <= 2 * n_chain_rows;
+			uint32_t at = 0, slot = 0;
 			prev = ~0u;
 			for (const auto &o : order) {
-				if (pad && o.first != prev && o.first != 0 && prev != ~0u) at = (at + 63u) & ~63u;
+				if (pad && o.first != prev && o.first != 0 && prev != ~0u) slot = (slot + 63u) & ~63u;
 				prev = o.first;
 				descs[o.second].chain_base = at; at += descs[o.second].n_chain;
+				descs[o.second].chain_slot = slot; slot += descs[o.second].n_chain;
 			}
-			if (pad) { n_chain_rows = at; chain_rows_padded = true; }
+			if (pad && slot != at) { n_chain_slots = slot; chain_rows_padded = true; }
 		}
 	}
 	SegmentDesc seg;
@@ -555,6 +558,7 @@ bool Engine::render_segment(uint32_t len, uint32_t offset, bool stereo, std::str
 	seg.may_scan = may_scan;
 	seg.sum_levels = sum_levels;
 	seg.n_chain_rows = n_chain_rows;
+	seg.n_chain_slots = n_chain_slots > n_chain_rows ? n_chain_slots : n_chain_rows;
 	seg.n_inc_rows = n_inc_rows;
 	seg.n_look_rows = n_look_rows;
 	seg.n_may_scan = n_may_scan;

@@ -59,7 +59,8 @@ struct SegmentDesc {
 	uint32_t n_inc_rows = 0;  /* row pairs the voices' inc_base/n_inc span (voices that may have running-sum phases) */
 	uint32_t n_look_rows = 0; /* rows the voices' look_base/n_look span (those of them without feedback chains) */
 	uint32_t n_may_scan = 0;  /* voices that may have running-sum phases this segment (the device decides: analyze_kernel) */
-	bool chain_rows_padded = false; /* some of the n_chain_rows row pairs belong to no voice (kinds of R feedback chains begin waves of their own) */
+	uint32_t n_chain_slots = 0; /* lanes of the chain kernels' waves the voices' chain_slot/n_chain span (>= n_chain_rows) */
+	bool chain_rows_padded = false; /* some of the n_chain_slots lanes belong to no voice (kinds of R feedback chains begin waves of their own) */
 };
 
 /* Bytes a backend has for the rows of a segment's feedback chains (8 B per chain and frame; the engine cuts segments with

@@ -369,6 +369,7 @@ public:
 			 * through ONE XCD's L2 (k_fast_types.h): only on a device that is the whole MI355X -- 256 CUs = 8 XCDs x 32. A partition
 			 * (CPX: 32 CUs, one XCD) or a masked device keeps the single counter and mix_kernel */
 			eight_xcds_ = dev_cus[dev & 15] == 256;
+			cus_ = dev_cus[dev & 15];
 			if (const char *fg = tune_env("SAU_AMD_FK_GRID")) { const int n = atoi(fg); if (n >= 1 && n <= (int)FK_GRID) fk_grid_ = (uint32_t)n; }
 		}
 		if (lds_limit_ > 160 * 1024) lds_limit_ = 160 * 1024;
@@ -410,6 +411,7 @@ public:
 		wide_tabs_ = tune_env("SAU_AMD_NO_WIDE_TABS") == nullptr; /* closed-form launches with f64 [c1, c0] table entries in LDS */
 		if (const char *mr = tune_env("SAU_AMD_MORE_ROWS")) more_rows_ = (uint32_t)atoi(mr); /* 0, 10 or 12 */
 		if (const char *dg = tune_env("SAU_AMD_DYN_GROUPS")) { const int n = atoi(dg); dyn_groups_ = n >= 1 ? (uint32_t)n : 1u; }
+		if (const char *ca = tune_env("SAU_AMD_CHAIN_ALONE")) chain_alone_ = atoi(ca) != 0;
 		if (const char *df = tune_env("SAU_AMD_DYN_FLOOR")) { const int n = atoi(df); dyn_floor_ = n >= 1 ? (uint32_t)n : 1u; }
 		if (const char *dt = tune_env("SAU_AMD_DYN_MIN_TASKS")) { const int n = atoi(dt); dyn_min_tasks_ = n >= 1 ? (uint32_t)n : 1u; }
 		/* voices per segment from which feedback voices get sixteen one-wave teams per workgroup
@@ -765,12 +767,12 @@ public:
 			}
 			if (chains) {
 				const uint32_t cstride = (seg.len + 63) & ~63u;
-				if (!chain_desc_.ensure(seg.n_chain_rows, err) ||
+				if (!chain_desc_.ensure(seg.n_chain_slots, err) ||
 				    !fplines_.ensure((size_t)FAST_LISTS * seg.n_voices * fmax_steps * sizeof(FastLine), err)) return false;
-				/* (row pairs that belong to no voice -- the engine begins every kind of R feedback chain on a wave of its own -- must read
-				 * as unused: analyze_kernel clears the descriptors of the voices' pairs only) */
-				if (seg.chain_rows_padded) HIP_OK(hipMemsetAsync(chain_desc_.p, 0, (size_t)seg.n_chain_rows * sizeof(ChainDesc), stream_));
-				fp.chain_rows = chain_rows_.p; fp.chain_stride = cstride; fp.n_chain_rows = seg.n_chain_rows;
+				/* (lanes that belong to no voice -- the engine begins every kind of R feedback chain on a wave of its own -- must read
+				 * as unused: analyze_kernel clears the descriptors of the voices' lanes only) */
+				if (seg.chain_rows_padded) HIP_OK(hipMemsetAsync(chain_desc_.p, 0, (size_t)seg.n_chain_slots * sizeof(ChainDesc), stream_));
+				fp.chain_rows = chain_rows_.p; fp.chain_stride = cstride; fp.n_chain_rows = seg.n_chain_rows; fp.n_chain_slots = seg.n_chain_slots;
 				fp.chain_desc = chain_desc_.p; fp.fplines = (FastLine *)fplines_.p;
 				fp.chain_inline = chain_inline_ ? 1u : 0u;
 				fp.chain_early_ok = chain_early_ ? 1u : 0u;
@@ -1033,14 +1035,15 @@ public:
 					if (fp.chain_rows && fp.chain_early_ok) {
 						/* chains that sums or other chains' inputs depend on, fed from their own lines: whole segment, before
 						 * anything else (FastInfo.early); returns at once when analyze_kernel found none */
-						const size_t clds = (size_t)fp.n_ctabs * CHAIN_TAB_BYTES + CHAIN_IO_BYTES;
+						const size_t clds = chain_alone_lds((size_t)fp.n_ctabs * CHAIN_TAB_BYTES + CHAIN_IO_BYTES, (seg.n_chain_slots + 63) / 64);
 						if (!raise_lds_attr((const void *)chain_kernel, clds, chain_lds_configured_[dev_ & 15], err)) return false;
 						fp.chain_early = 1; fp.range_mode = 0;
-						hipLaunchKernelGGL(chain_kernel, dim3((seg.n_chain_rows + 63) / 64), dim3(192), clds, stream_, fp);
+						hipLaunchKernelGGL(chain_kernel, dim3((seg.n_chain_slots + 63) / 64), dim3(192), clds, stream_, fp);
 						{ /* R feedback: a chain wave and a feeder wave per 64 chains (k_chain.h) */
 							static size_t rc_configured[16];
-							if (!raise_lds_attr((const void *)rchain_kernel, RCHAIN_LDS_BYTES, rc_configured[dev_ & 15], err)) return false;
-							hipLaunchKernelGGL(rchain_kernel, dim3((seg.n_chain_rows + 63) / 64), dim3(128), RCHAIN_LDS_BYTES, stream_, fp);
+							const size_t rlds_ = chain_alone_lds(RCHAIN_LDS_BYTES, (seg.n_chain_slots + 63) / 64);
+							if (!raise_lds_attr((const void *)rchain_kernel, rlds_, rc_configured[dev_ & 15], err)) return false;
+							hipLaunchKernelGGL(rchain_kernel, dim3((seg.n_chain_slots + 63) / 64), dim3(RCHAIN_THREADS), rlds_, stream_, fp);
 						}
 						fp.chain_early = 0;
 					}
@@ -1053,9 +1056,9 @@ public:
 						 * chunks of the segment: chain_kernel occupies one CU per 64 chains for frames x chain latency,
 						 * so it runs on a stream of its own while, on the other CUs, the chain-input pass prepares the
 						 * chunks after it and the final pass finishes the chunks before it. */
-						const size_t clds = (size_t)fp.n_ctabs * CHAIN_TAB_BYTES + CHAIN_IO_BYTES;
+						const uint32_t cgrid = (seg.n_chain_slots + 63) / 64;
+						const size_t clds = chain_alone_lds((size_t)fp.n_ctabs * CHAIN_TAB_BYTES + CHAIN_IO_BYTES, cgrid);
 						if (!raise_lds_attr((const void *)chain_kernel, clds, chain_lds_configured_[dev_ & 15], err)) return false;
-						const uint32_t cgrid = (seg.n_chain_rows + 63) / 64;
 						/* chunks of about chain_chunk_frames_ frames (what the first chunk's inputs and the last chunk's final
 						 * pass take is not overlapped with the chains), 32 at most */
 						uint32_t n_chunks = chain_chunks_ ? chain_chunks_ : (seg.len + chain_chunk_frames_ - 1) / chain_chunk_frames_;
@@ -1653,6 +1656,18 @@ private:
 	bool wide_tabs_ = true;
 	uint32_t more_rows_ = 12;
 	uint32_t lean_rows_ = 6;    /* SAU_AMD_LEAN_ROWS: rows per pass of fast_kernel<T, 3> at most (6, 5 or 4) */
+	/* A chain kernel's workgroup is three waves on a latency-bound recurrence. SAU_AMD_CHAIN_ALONE=1 (a tuning switch): while a
+	 * launch has no more workgroups than the device has CUs, each asks for more than half a CU's LDS and so gets a CU of its own.
+	 * Measured without effect -- R feedback banks of 8 / 64 / 1024 / 4096 voices 521 571 501 427 ns per frame with it, 486-511
+	 * 574-609 484-501 426 without, config 5 45.96-46.06 against 45.77-46.00 ms: the workgroups do not slow each other; what varies
+	 * from run to run on a nearly idle device (one voice: 324-418 ns) is not the placement. Off. */
+	size_t chain_alone_lds(size_t need, uint32_t grid) const {
+		if (!chain_alone_ || grid > cus_ || need * 2 > lds_limit_) return need;
+		const size_t half = lds_limit_ / 2 + 1024;
+		return need > half ? need : half;
+	}
+	bool chain_alone_ = false;
+	uint32_t cus_ = 256;
 	uint32_t dyn_groups_ = 12;  /* row groups per task of a closed-form launch, at least (SAU_AMD_DYN_GROUPS) */
 	/* ... and steps x row groups per task, at least (SAU_AMD_DYN_FLOOR), and the tasks per wave from which the queues deal them out
 	 * (fewer: a fixed share per wave; SAU_AMD_DYN_MIN_TASKS). Round 6: 48 -> 24 and 4 -> 2, which takes BASELINE config 2 (256 voices of

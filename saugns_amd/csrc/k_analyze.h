@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(64) analyze_kernel(FastParams P, uint32_t lds_
 	for (uint32_t i = 0; i < vd.nops; ++i) OPS[ids[i]].rt_frozen = 0;
 	if (P.chain_desc)
 		for (uint32_t k = 0; k < vd.n_chain; ++k) /* ChainDesc.n (its first word; the type is defined further down) */
-			((uint32_t *)P.chain_desc)[(size_t)(vd.chain_base + k) * CHAIN_DESC_WORDS] = 0;
+			((uint32_t *)P.chain_desc)[(size_t)(vd.chain_slot + k) * CHAIN_DESC_WORDS] = 0;
 	const bool chain_ok = P.chain_rows != nullptr && P.scan != nullptr;
 	bool has_chain = false;
 	{

@@ -170,7 +170,7 @@ __device__ __forceinline__ void chain_feed(const ChainDesc &cd, bool live, int l
 		const uint4 *bp, const float4 *ap, uint32_t *in_base, float *in_amt, const uint32_t half) {
 	if (!live) return;
 	uint32_t a = *acc, a_end = *acc; /* a_end: the accumulator after the segment's last frame, should it fall in this batch */
-	if (cd.mode == CM_INLINE) {
+	if (chain_mode(cd) == CM_INLINE) {
 		/* Frequency and amounts from the operator's own lines (sau/line.c fills are functions of the position). Two feeder
 		 * waves share a batch, half its frames each (`half`): a wave alone on its SIMD pays its instructions' latencies, and
 		 * one wave took 5 us for the 32 frames the chain wave consumes in 3.4 (round 4). What goes to LDS are phase
@@ -299,7 +299,7 @@ __device__ __forceinline__ void chain_feed(const ChainDesc &cd, bool live, int l
 #pragma unroll
 	for (uint32_t q = 0; q < CHAIN_NQ; ++q) {
 		uint4 b = bp[q]; /* (fetched a batch ahead: chain_fetch) */
-		if (cd.mode == CM_INC) { /* phase increments: summed here */
+		if (chain_mode(cd) == CM_INC) { /* phase increments: summed here */
 			const uint32_t i = t + 4 * q;
 			b.x += a; b.y += b.x; b.z += b.y; b.w += b.z;
 			a = b.w;
@@ -343,7 +343,7 @@ __device__ __forceinline__ void chain_st(float4 *p, const float4 v) {
  * never stands waiting for HBM inside the batch period (1.9 us) the chain wave gives it */
 __device__ __forceinline__ void chain_fetch(const ChainDesc &cd, bool live, uint32_t t, const uint4 *brow, const float4 *arow,
 		uint4 *bp, float4 *ap) {
-	if (!live || cd.mode == CM_INLINE) return;
+	if (!live || chain_mode(cd) == CM_INLINE) return;
 #pragma unroll
 	for (uint32_t q = 0; q < CHAIN_NQ; ++q) { bp[q] = chain_ld(&brow[t / 4 + q]); ap[q] = chain_ld(&arow[t / 4 + q]); }
 }
@@ -365,7 +365,7 @@ __global__ void __launch_bounds__(192) chain_kernel(FastParams P) {
 	const uint32_t c = blockIdx.x * 64 + (uint32_t)l;
 	ChainDesc cd;
 	memset(&cd, 0, sizeof cd);
-	if (c < P.n_chain_rows && P.chain_desc[c].n != 0) cd = P.chain_desc[c]; /* (an unused pair has only `n` set) */
+	if (c < P.n_chain_slots && P.chain_desc[c].n != 0) cd = P.chain_desc[c]; /* (an unused lane has only `n` set) */
 	/* this launch's share of the chain: frames [c_lo, n) of the segment, n cut at the chunk's end */
 	const uint32_t c_lo = P.range_mode ? P.f_lo : 0u;
 	uint32_t n = cd.n;
@@ -384,7 +384,7 @@ __global__ void __launch_bounds__(192) chain_kernel(FastParams P) {
 		f64x2 *d01 = (f64x2 *)(lds + (size_t)t * CHAIN_TAB_BYTES + CHAIN_TAB_C01);
 		for (uint32_t i = threadIdx.x; i < WAVE_LEN; i += 192) { f64x2 v; v.x = (double)s01[i].c1; v.y = (double)s01[i].c0; d01[i] = v; }
 	}
-	const uint32_t wave = cd.wave < 12 ? cd.wave : 0;
+	const uint32_t wave = chain_wave_id(cd) < 12 ? chain_wave_id(cd) : 0;
 	const int ti = P.ctab_of_wave[wave];
 	const bool all_lds = __all(n == 0 || ti >= 0) != 0;
 	const uint32_t tab23 = (uint32_t)(uintptr_t)lds + (uint32_t)(ti >= 0 ? ti : 0) * CHAIN_TAB_BYTES;
@@ -394,7 +394,7 @@ __global__ void __launch_bounds__(192) chain_kernel(FastParams P) {
 	const float dscale = P.wc[wave].diff_scale, doff = P.wc[wave].diff_offset;
 	DevOp &o = P.ops[cd.gop];
 	/* row pair of the chain (idle lanes: pair 0, reads only) */
-	float *brow = P.chain_rows + (size_t)2 * (n ? c : 0u) * P.chain_stride;
+	float *brow = P.chain_rows + (size_t)2 * (n ? cd.row : 0u) * P.chain_stride;
 	const uint4 *bp = (const uint4 *)brow;
 	const float4 *ap = (const float4 *)(brow + P.chain_stride);
 	float4 *op = (float4 *)brow;
@@ -418,7 +418,7 @@ __global__ void __launch_bounds__(192) chain_kernel(FastParams P) {
 	if (role == 2) { /* the second feeder wave: lines of inline chains, second half of every batch; the same barriers as the first */
 		uint32_t acc = 0;
 		for (uint32_t k = 0; k <= n_batches; ++k) {
-			if (k < n_batches && c_lo + k * CHAIN_BATCH < n && cd.mode == CM_INLINE)
+			if (k < n_batches && c_lo + k * CHAIN_BATCH < n && chain_mode(cd) == CM_INLINE)
 				chain_feed(cd, true, l, c_lo + k * CHAIN_BATCH, &acc, nullptr, nullptr, in_base(k & 1), in_amt(k & 1), 1u);
 			CHAIN_SYNC();
 		}
@@ -449,7 +449,7 @@ __global__ void __launch_bounds__(192) chain_kernel(FastParams P) {
 #pragma unroll
 			for (uint32_t q = 0; q < CHAIN_NQ; ++q) chain_st(&op[(c_lo + (n_batches - 1) * CHAIN_BATCH) / 4 + q], *(const float4 *)(sq + chain_io_word(q, l)));
 		}
-		if (n && cd.mode == CM_INC) o.st_phase = acc; /* (inline chains: the chain wave's, which sums their increments) */
+		if (n && chain_mode(cd) == CM_INC) o.st_phase = acc; /* (inline chains: the chain wave's, which sums their increments) */
 		CHAIN_PROF_END();
 		return;
 	}
@@ -458,7 +458,7 @@ __global__ void __launch_bounds__(192) chain_kernel(FastParams P) {
 	uint32_t prev_phase = c_lo ? o.st_prev_phase : o.prev_phase;
 	double prev_Is = c_lo ? o.st_prev_Is : o.prev_Is;
 	float prev_s = c_lo ? o.st_prev_s : o.prev_s, fb_s = c_lo ? bits_f(o.ras_alpha) : o.fb_s;
-	const bool inl = cd.mode == CM_INLINE; /* the feeder waves hand this chain phase increments: summed here */
+	const bool inl = chain_mode(cd) == CM_INLINE; /* the feeder waves hand this chain phase increments: summed here */
 	const int inl_kind = __all(n == 0 || !inl) ? 0 : __all(n == 0 || inl) ? 1 : 2; /* (per wave: the usual bank is all of one kind) */
 	/* (a chain of one frequency stages no accumulator -- finalize_kernel advances its phase in closed form -- so a later
 	 * chunk's start is the closed form too) */
@@ -535,10 +535,16 @@ __global__ void __launch_bounds__(192) chain_kernel(FastParams P) {
  * frequency line and sums the 64-bit counter (post-increment, rasg.h:184-186: what a frame reads is the counter before its
  * own increment), splits it into cycle and phase, evaluates the amount line, a batch ahead; and it writes the batch of
  * samples before to the chain's row, sixteen bytes at a time (until round 5: one lane's 4-byte store per sample, and
- * both line evaluations, on the dependent chain: 480 ns per frame for a single voice). One barrier per batch. */
+ * both line evaluations, on the dependent chain: 480 ns per frame for a single voice). One barrier per batch.
+ * Round 6: TWO feeder waves. One wave alone issues a dependent instruction every eight to twelve cycles, and a feeder that evaluates
+ * two swept lines, rounds, splits and drains took longer per batch than the recurrence it feeds -- banks of one kind measured 312-326 ns
+ * per frame with fixed rate, 371-382 with a swept rate, 496-509 with rate and amount swept (tests/tools/gpu_r_feedback_kinds.py), so a
+ * mixed bank ran at its slowest feeder's pace. Now the RATE feeder has the frequency line, the counter and its split, the AMOUNT
+ * feeder the amount line and the drain; each is shorter than the chain wave's batch. */
 constexpr uint32_t RCHAIN_BATCH = 32;
 constexpr size_t RCHAIN_LDS_BYTES = (size_t)(3 + 1) * 2 * RCHAIN_BATCH * 64 * 4; /* cycle, phase, amount in; samples out: two batches each */
-__global__ void __launch_bounds__(128) rchain_kernel(FastParams P) {
+constexpr uint32_t RCHAIN_THREADS = 192; /* the chain wave, the rate feeder, the amount feeder */
+__global__ void __launch_bounds__(RCHAIN_THREADS) rchain_kernel(FastParams P) {
 	if (P.pass_flags[FAST_EARLY_FLAG] == 0) return;
 	extern __shared__ __align__(16) unsigned char rc_lds[];
 	uint32_t *const in_cyc = (uint32_t *)rc_lds;                       /* [2][RCHAIN_BATCH][64] */
@@ -546,11 +552,12 @@ __global__ void __launch_bounds__(128) rchain_kernel(FastParams P) {
 	float *const in_am = in_ph + 2 * RCHAIN_BATCH * 64;
 	float *const out_s = in_am + 2 * RCHAIN_BATCH * 64;
 	const int l = threadIdx.x & 63;
-	const bool feeder = uni((uint32_t)threadIdx.x >> 6) != 0;
+	const uint32_t role = uni((uint32_t)threadIdx.x >> 6); /* 0 the chain wave, 1 the rate feeder, 2 the amount feeder */
+	const bool feeder = role != 0;
 	const uint32_t c = blockIdx.x * 64 + (uint32_t)l;
-	ChainDesc cd = P.chain_desc[c < P.n_chain_rows ? c : 0];
+	ChainDesc cd = P.chain_desc[c < P.n_chain_slots ? c : 0];
 	uint32_t n = 0;
-	if (c < P.n_chain_rows) {
+	if (c < P.n_chain_slots) {
 		if (cd.n && (cd.lflags & CL_RASEG)) n = cd.n;
 	}
 	uint32_t n_max = n; /* the workgroup's longest chain decides the number of batches (both waves alike) */
@@ -567,61 +574,91 @@ __global__ void __launch_bounds__(128) rchain_kernel(FastParams P) {
 		const float rcoeff = n ? (rate2x ? cd.coeff * 2 : cd.coeff) : 0.f;
 		unsigned long long cp = n ? op->cycle_phase : 0ull;
 		const unsigned long long inc_c = n ? (unsigned long long)rint64(rcoeff * op->rt_fconst) : 0ull;
-		float *row = P.chain_rows + (size_t)2 * c * P.chain_stride;
+		float *row = P.chain_rows + (size_t)2 * (n ? cd.row : 0u) * P.chain_stride;
 		/* the whole of the feeder's work, for line shapes and flags that are the lane's own or -- chains of one kind: a bank of
 		 * like voices, one voice -- the wave's (two copies of the loop: in the second every value's shape dispatch is a scalar
 		 * branch) */
-		auto feed = [&](const FastLine &fl, const FastLine &pl, const uint32_t lflags) {
-			auto fill = [&](uint32_t k) { /* the inputs of batch k */
-				uint32_t *cy = in_cyc + (k & 1) * RCHAIN_BATCH * 64;
-				float *ph = in_ph + (k & 1) * RCHAIN_BATCH * 64, *am = in_am + (k & 1) * RCHAIN_BATCH * 64;
-				const uint32_t t0 = k * RCHAIN_BATCH;
-				if (t0 >= n) return;
+		if (role == 1) {
+			/* the rate feeder: frequency line -> increment -> counter (post-increment) -> cycle and phase */
+			auto feed = [&](const FastLine &fl, const uint32_t lflags) {
+				auto fill = [&](uint32_t k) { /* the inputs of batch k */
+					uint32_t *cy = in_cyc + (k & 1) * RCHAIN_BATCH * 64;
+					float *ph = in_ph + (k & 1) * RCHAIN_BATCH * 64;
+					const uint32_t t0 = k * RCHAIN_BATCH;
+					if (t0 >= n) return;
 #pragma unroll 4
-				for (uint32_t j = 0; j < RCHAIN_BATCH; ++j) {
-					const uint32_t t = t0 + j;
-					unsigned long long inc = inc_c;
-					if (!(lflags & CL_FCONST)) {
-						float v = fast_line_value(fl, (int)t);
-						if (lflags & (t < fl.goal_len ? CL_MUL_GOAL : CL_MUL_HOLD)) v *= cd.mulc;
-						inc = (unsigned long long)rint64(rcoeff * v);
+					for (uint32_t j = 0; j < RCHAIN_BATCH; ++j) {
+						const uint32_t t = t0 + j;
+						unsigned long long inc = inc_c;
+						if (!(lflags & CL_FCONST)) {
+							float v = fast_line_value(fl, (int)t);
+							if (lflags & (t < fl.goal_len ? CL_MUL_GOAL : CL_MUL_HOLD)) v *= cd.mulc;
+							inc = (unsigned long long)rint64(rcoeff * v);
+						}
+						uint32_t cyc; float phf;
+						ras_split(cp, cyc, phf); /* rasg.h:184-186, post-increment */
+						if (t < n) cp += inc;
+						cy[j * 64 + l] = cyc; ph[j * 64 + l] = phf;
 					}
-					uint32_t cyc; float phf;
-					ras_split(cp, cyc, phf); /* rasg.h:184-186, post-increment */
-					if (t < n) cp += inc;
-					cy[j * 64 + l] = cyc; ph[j * 64 + l] = phf;
-					am[j * 64 + l] = fast_line_value(pl, (int)t);
-				}
-			};
-			auto drain = [&](uint32_t k) { /* the samples of batch k to the chain's row */
-				const float *os = out_s + (k & 1) * RCHAIN_BATCH * 64;
-				const uint32_t t0 = k * RCHAIN_BATCH;
-				if (t0 >= n) return;
-				if (t0 + RCHAIN_BATCH <= n) {
-#pragma unroll
-					for (uint32_t q = 0; q < RCHAIN_BATCH / 4; ++q) /* (rows are 256-byte aligned: chain_stride is a multiple of 64) */
-						*(float4 *)(row + t0 + 4 * q) = make_float4(os[(4 * q) * 64 + l], os[(4 * q + 1) * 64 + l], os[(4 * q + 2) * 64 + l], os[(4 * q + 3) * 64 + l]);
-				} else {
-					for (uint32_t j = 0; t0 + j < n; ++j) row[t0 + j] = os[j * 64 + l];
-				}
-			};
-			fill(0);
-			__syncthreads();
-			for (uint32_t k = 0; k < nb; ++k) {
-				if (k + 1 < nb) fill(k + 1);
-				if (k >= 1) drain(k - 1);
+				};
+				fill(0);
 				__syncthreads();
+				for (uint32_t k = 0; k < nb; ++k) {
+					if (k + 1 < nb) fill(k + 1);
+					__syncthreads();
+				}
+			};
+			/* line shapes and flags that are the lane's own or -- chains of one kind: a bank of like voices, one voice -- the wave's
+			 * (two copies of the loop: in the second every value's shape dispatch is a scalar branch) */
+			const uint32_t ft0 = (uint32_t)__builtin_amdgcn_readlane((int)cd.fl.sw.type, first);
+			const uint32_t lf0 = (uint32_t)__builtin_amdgcn_readlane((int)cd.lflags, first);
+			if (!__any(n != 0 && (cd.fl.sw.type != ft0 || cd.lflags != lf0))) {
+				FastLine fl = cd.fl;
+				fl.sw.type = ft0;
+				feed(fl, lf0);
+			} else {
+				feed(cd.fl, cd.lflags);
 			}
-			drain(nb - 1);
-		};
-		const uint32_t ft0 = (uint32_t)__builtin_amdgcn_readlane((int)cd.fl.sw.type, first), pt0 = (uint32_t)__builtin_amdgcn_readlane((int)cd.pl.sw.type, first);
-		const uint32_t lf0 = (uint32_t)__builtin_amdgcn_readlane((int)cd.lflags, first);
-		if (!__any(n != 0 && (cd.fl.sw.type != ft0 || cd.pl.sw.type != pt0 || cd.lflags != lf0))) {
-			FastLine fl = cd.fl, pl = cd.pl;
-			fl.sw.type = ft0; pl.sw.type = pt0;
-			feed(fl, pl, lf0);
 		} else {
-			feed(cd.fl, cd.pl, cd.lflags);
+			/* the amount feeder: amount line; the samples of the batch before to the chain's row */
+			auto feed = [&](const FastLine &pl) {
+				auto fill = [&](uint32_t k) {
+					float *am = in_am + (k & 1) * RCHAIN_BATCH * 64;
+					const uint32_t t0 = k * RCHAIN_BATCH;
+					if (t0 >= n) return;
+#pragma unroll 4
+					for (uint32_t j = 0; j < RCHAIN_BATCH; ++j) am[j * 64 + l] = fast_line_value(pl, (int)(t0 + j));
+				};
+				auto drain = [&](uint32_t k) { /* the samples of batch k to the chain's row */
+					const float *os = out_s + (k & 1) * RCHAIN_BATCH * 64;
+					const uint32_t t0 = k * RCHAIN_BATCH;
+					if (t0 >= n) return;
+					if (t0 + RCHAIN_BATCH <= n) {
+#pragma unroll
+						for (uint32_t q = 0; q < RCHAIN_BATCH / 4; ++q) /* (rows are 256-byte aligned: chain_stride is a multiple of 64) */
+							*(float4 *)(row + t0 + 4 * q) = make_float4(os[(4 * q) * 64 + l], os[(4 * q + 1) * 64 + l], os[(4 * q + 2) * 64 + l], os[(4 * q + 3) * 64 + l]);
+					} else {
+						for (uint32_t j = 0; t0 + j < n; ++j) row[t0 + j] = os[j * 64 + l];
+					}
+				};
+				fill(0);
+				__syncthreads();
+				for (uint32_t k = 0; k < nb; ++k) {
+					if (k + 1 < nb) fill(k + 1);
+					if (k >= 1) drain(k - 1);
+					__syncthreads();
+				}
+				drain(nb - 1);
+			};
+			const uint32_t pt0 = (uint32_t)__builtin_amdgcn_readlane((int)cd.pl.sw.type, first);
+			if (!__any(n != 0 && cd.pl.sw.type != pt0)) {
+				FastLine pl = cd.pl;
+				pl.sw.type = pt0;
+				feed(pl);
+			} else {
+				feed(cd.pl);
+			}
+			return;
 		}
 		if (n) { /* staged: finalize_kernel makes it the operator's state unless the voice's segment is redone */
 			op->st_prev_Is = __longlong_as_double((long long)cp);

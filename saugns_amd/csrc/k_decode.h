@@ -39,8 +39,8 @@ enum : uint32_t { CL_FCONST = 1, CL_MUL_GOAL = 2, CL_MUL_HOLD = 4, CL_EARLY = 8 
 struct ChainDesc {
 	uint32_t n;      /* frames to run this segment (0: row pair unused; the other fields are then unset) */
 	uint32_t gop;    /* the operator's state (global index) */
-	uint32_t wave;
-	uint32_t mode;   /* CM_* */
+	uint32_t wave_mode; /* the wave table's id | CM_* << 8 */
+	uint32_t row;    /* its row pair (entries are numbered by lane: VoiceDesc.chain_slot) */
 	float coeff;     /* CM_INLINE: 2^32 / srate */
 	uint32_t inc_const; /* ... the phase increment when the frequency is one value (CL_FCONST) */
 	uint32_t lflags; /* CL_* */
@@ -49,6 +49,8 @@ struct ChainDesc {
 	FastLine pl;     /* ... self-modulation amount line */
 };
 static_assert(sizeof(ChainDesc) == 4 * CHAIN_DESC_WORDS && offsetof(ChainDesc, n) == 0, "ChainDesc is 32 dwords, n first");
+__device__ __forceinline__ uint32_t chain_wave_id(const ChainDesc &c) { return c.wave_mode & 0xffu; }
+__device__ __forceinline__ uint32_t chain_mode(const ChainDesc &c) { return c.wave_mode >> 8; }
 
 /* What only a sequential-scan voice needs of a step (FastStep.ramp bit 1): where
  * per-frame frequencies come from and how a ratio line is multiplied. */
@@ -257,8 +259,8 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 			f.pan = bits_f(row);
 			ChainDesc cd;
 			memset(&cd, 0, sizeof cd);
-			cd.n = P.info[v].total; cd.gop = ids[st.op]; cd.wave = wv;
-			cd.mode = step_is_chain_acc(st, o) ? CM_INC : CM_BASE;
+			cd.n = P.info[v].total; cd.gop = ids[st.op]; cd.row = row;
+			uint32_t cmode = step_is_chain_acc(st, o) ? CM_INC : CM_BASE;
 			if (st.sm == NO_SLOT) { /* the amounts come from the line itself */
 				LineState pls = o.line[L_PMA];
 				const LineBlock lb = line_begin(pls, P.info[v].total, false, 0.f, lattice_none(), 0);
@@ -268,7 +270,7 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 			uint32_t lstep = ~0u;
 			if (step_is_chain_inline(P.chain_inline != 0 || P.info[v].early != 0, plan, (uint32_t)l, ids, P.ops, &lstep)) {
 				chain_inline = true;
-				cd.mode = CM_INLINE;
+				cmode = CM_INLINE;
 				if (P.info[v].early) { cd.lflags |= CL_EARLY; f.type |= FT_CHAIN_EARLY; }
 				if (o.type == OT_RASEG) cd.lflags |= CL_RASEG;
 				cd.coeff = o.coeff;
@@ -290,7 +292,8 @@ __global__ void __launch_bounds__(64) decode_kernel(FastParams P) {
 					cd.mulc = pf;
 				}
 			}
-			P.chain_desc[row] = cd;
+			cd.wave_mode = (wv & 0xffu) | (cmode << 8);
+			P.chain_desc[vd.chain_slot + k] = cd;
 		}
 		if (st.kind == ST_OSC && o.type == OT_WAVE && !zero_fill && !is_chain && st.pm == NO_SLOT && st.fpm == NO_SLOT &&
 		    o.rt_fconst_valid && f.inc == 0 && ((o.flags & OPF_OSC_RESET) || o.prev_phase == o.phase)) {

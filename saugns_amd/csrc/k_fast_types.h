@@ -211,6 +211,7 @@ struct FastParams {
 	 * base phases, then (in place) the samples; self-modulation amounts -- and what chain_kernel needs to run it */
 	float *chain_rows;    /* [n_chain_rows][2][chain_stride], or NULL: such voices go to the block loop */
 	uint32_t chain_stride, n_chain_rows;
+	uint32_t n_chain_slots; /* lanes of the chain kernels (entries of chain_desc): the rows, or more where kinds of R feedback begin waves of their own */
 	ChainDesc *chain_desc;
 	FastLine *fplines;    /* [voice][max_steps]: the self-modulation amount line of a chain step without a block for it */
 	uint32_t n_ctabs;     /* wave tables chain_kernel stages in LDS */

@@ -342,6 +342,8 @@ struct VoiceDesc {
 	uint32_t flags;              /* VD_* */
 	Lattice lat;                 /* where the reference's blocks lie in this segment, for the voice's program */
 	uint32_t chain_base, n_chain;/* row pairs for its self-modulated oscillators (step_may_chain steps, in plan order) */
+	uint32_t chain_slot;         /* ... and their lanes of the chain kernels' waves (ChainDesc entries): the engine begins every kind of R
+	                              * feedback on a wave of its own, so the lanes are numbered with gaps and the rows without */
 	uint32_t inc_base, n_inc;    /* row pairs for saved phase increments of its oscillator steps (in plan order), or n_inc = 0 */
 	uint32_t look_base, n_look;  /* look-back rows for its running-sum oscillators (a voice without feedback chains), or n_look = 0 */
 	uint32_t ev_left;            /* frames from the segment's first frame to its program's next event (~0u: none): a reference
