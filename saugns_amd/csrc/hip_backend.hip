@@ -412,6 +412,7 @@ public:
 		if (const char *mr = tune_env("SAU_AMD_MORE_ROWS")) more_rows_ = (uint32_t)atoi(mr); /* 0, 10 or 12 */
 		if (const char *dg = tune_env("SAU_AMD_DYN_GROUPS")) { const int n = atoi(dg); dyn_groups_ = n >= 1 ? (uint32_t)n : 1u; }
 		if (const char *ca = tune_env("SAU_AMD_CHAIN_ALONE")) chain_alone_ = atoi(ca) != 0;
+		inner_enabled_ = tune_env("SAU_AMD_NO_INNER") == nullptr;
 		if (const char *df = tune_env("SAU_AMD_DYN_FLOOR")) { const int n = atoi(df); dyn_floor_ = n >= 1 ? (uint32_t)n : 1u; }
 		if (const char *dt = tune_env("SAU_AMD_DYN_MIN_TASKS")) { const int n = atoi(dt); dyn_min_tasks_ = n >= 1 ? (uint32_t)n : 1u; }
 		/* voices per segment from which feedback voices get sixteen one-wave teams per workgroup
@@ -1196,7 +1197,23 @@ public:
 							inmix_live_ = true;
 						}
 					}
-					launch_fast(0);
+					if (inner_enabled_ && main_build == 0 && wide_cf && FT == 12 && fp.dyn_chunks >= 3) {
+						/* BASELINE config 3's build in two launches (k_fast_voice.h: INNER): every voice's first and last row group by the plain
+						 * build, a wave per group; then the groups between by the build that holds only the form without in-segment masks */
+						static size_t inner_configured[16];
+						const void *ik = (const void *)fast_kernel<12, 0, false, true, false, true>;
+						const size_t lds = ft * (size_t)FAST_TAB_BYTES_WIDE + 16 * area;
+						FastParams ep = fp;
+						ep.mode = 0; ep.edge_only = 1; ep.dyn_static = 1; ep.dyn_chunks = 2; ep.dyn_small = 0; ep.inmix_flags = 0; /* (two tasks a voice: its first group, its last) */
+						const uint32_t egrid = (2 * seg.n_voices + 15) / 16 < fk_grid_ ? (2 * seg.n_voices + 15) / 16 : fk_grid_;
+						if (!launch_build(0, FT, egrid, &ep, 0, true)) launched = false;
+						fp.mode = 0;
+						void *iargs[] = {(void *)&fp};
+						if (!raise_lds_attr(ik, lds, inner_configured[dev_ & 15], err)) return false;
+						HIP_OK(hipLaunchKernel(ik, dim3(fgrid), dim3(1024), iargs, lds, stream_));
+					} else {
+						launch_fast(0);
+					}
 					fp.dyn_chunks = 0; fp.inmix_flags = 0; fp.dyn_small = 0;
 				}
 				{ /* closed-form voices with the loop tails of `cub` R segments (FastInfo.cub): the build with that code,
@@ -1667,6 +1684,7 @@ private:
 		return need > half ? need : half;
 	}
 	bool chain_alone_ = false;
+	bool inner_enabled_ = true;  /* the 12-row wide closed-form build as two launches, edges and inner groups (SAU_AMD_NO_INNER: one) */
 	uint32_t cus_ = 256;
 	uint32_t dyn_groups_ = 12;  /* row groups per task of a closed-form launch, at least (SAU_AMD_DYN_GROUPS) */
 	/* ... and steps x row groups per task, at least (SAU_AMD_DYN_FLOOR), and the tasks per wave from which the queues deal them out

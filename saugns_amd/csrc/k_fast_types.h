@@ -282,4 +282,6 @@ struct FastParams {
 	 * (tailmix_kernel's verdict), or NULL; inmix_stream is then the streams' array; tail_flags: 1 stereo PCM, 2 byte-swapped */
 	uint32_t *tail_ok;
 	uint32_t tail_flags, tail_pcm_offset;
+	uint32_t edge_only; /* the 12-row wide closed-form build: nonzero = the first and the last row group of every voice only (the launch ahead
+	                     * of fast_kernel<12, 0, false, true, false, true>, which renders the groups between) */
 };

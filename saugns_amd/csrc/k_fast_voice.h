@@ -112,7 +112,7 @@ __device__ __forceinline__ FastStep load_step_uniform(const FastStep *p) {
  * (frequency ramps, FM); the plain build stays as lean as closed-form voices
  * need it (the same code with the running-sum branches compiled in was 27 %
  * slower on them), and a kernel that may meet both kinds holds both copies. */
-template <int T, int SCAN, bool REPAIR = false, bool CUB = false, bool WIDE = false, bool SPLIT = false, bool TAIL = false>
+template <int T, int SCAN, bool REPAIR = false, bool CUB = false, bool WIDE = false, int SPLIT = 0 /* 1: three loops, 2: the groups between only */, bool TAIL = false>
 __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v, const FastInfo &fi,
 		float *slots, unsigned long long *carry, const uint32_t tabs /* LDS address of the launch's table blocks */, const int l,
 		const uint32_t wpv, const uint32_t cstart, unsigned long long *lring = nullptr,
@@ -193,6 +193,14 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 	if (!REPAIR && SCAN == 0 && dyn_k) { /* this task's run of consecutive groups */
 		(void)fk_chunk_groups(ngroups, dyn_k, P.dyn_small, dyn_c, it_lo, n_iter);
 	}
+	if constexpr (!REPAIR && SCAN == 0 && WIDE && T == 12 && SPLIT == 0) {
+		/* the launch ahead of the INNER build's (fast_kernel): two tasks a voice, its first row group and its last */
+		if (P.edge_only) {
+			if (dyn_c && last_group == 0) return;
+			it_lo = dyn_c ? last_group : 0u;
+			n_iter = it_lo + 1;
+		}
+	}
 	/* this voice's launch mixes its stream as it stores the row (FastInfo.tail, k_fast_types.h): rows of the stream, or 0 */
 	const uint32_t tail_n = (TAIL && SCAN == 2 && !REPAIR && !CUB && P.tail_ok) ? uni(fi.tail) : 0u;
 	const uint32_t tail_s = tail_n ? uni(fi.tail_stream) : 0u;
@@ -209,7 +217,15 @@ __device__ __forceinline__ void fast_voice(const FastParams &P, const uint32_t v
 	 * and not one loop with both forms in it, which kept the edge form's hoisted values alive across the other's iterations
 	 * (178 spilled vector registers in the look-back build). */
 #define FKG_ADVANCE() (it += gstride, cgm = cgm + wpv >= lk_ring ? cgm + wpv - lk_ring : cgm + wpv)
-	if constexpr (SPLIT && !REPAIR) {
+	if constexpr (SPLIT == 2 && !REPAIR) {
+		/* (FK_INNER builds, fast_kernel: the groups between only -- the first and the last are another launch's, FastParams.edge_only) */
+		for (uint32_t it = it_lo + cstart; it < n_iter; FKG_ADVANCE()) {
+			if (it == 0 || it == last_group) continue;
+			const uint32_t cg = it, repair_rows = 0;
+			constexpr bool EDGE = false;
+#include "k_fast_group.h"
+		}
+	} else if constexpr (SPLIT == 1 && !REPAIR) {
 		uint32_t it = it_lo + cstart;
 		if (it < n_iter && (it == 0 || it == last_group)) {
 			const uint32_t cg = it, repair_rows = 0;
@@ -456,16 +472,21 @@ __device__ __forceinline__ void inmix_after(const InmixArgs &A, const uint32_t k
 #endif
 /* TAIL: the look-back build that also mixes few-voice streams as it stores their last rows (FastParams.tail_ok) -- a build of its own:
  * with that code in it the look-back build spills 40-odd vector registers (0 without), 3 % of the FM bank's and config 4's launches */
-template <int T, int SCAN, bool CUB = false, bool WIDE = false, bool TAIL = false>
+/* INNER (round 6, the 12-row wide closed-form build -- BASELINE config 3's): only the row groups that touch neither end of the
+ * segment, in the form without in-segment masks (fast_voice: EDGE false), one loop; the first and the last group of every voice are
+ * rendered by a launch of the plain build ahead of this one (FastParams.edge_only). The three-loop form of fast_voice, which holds
+ * both forms in one kernel, spilled 175 vector registers at 12 rows. */
+template <int T, int SCAN, bool CUB = false, bool WIDE = false, bool TAIL = false, bool INNER = false>
 __global__ void FK_ATTR fast_kernel(FastParams P) {
+	static_assert(!INNER || (SCAN == 0 && WIDE && T == 12 && !CUB && !TAIL), "the inner-groups-only form exists for the 12-row wide closed-form build");
 	static_assert(!WIDE || ((SCAN == 0 || SCAN == 2) && !CUB), "only the closed-form and the look-back builds have a wide-table form");
 	static_assert(!TAIL || (SCAN == 2 && !CUB && T == 8), "the stream-mixing form exists for the 8-row look-back build");
 	constexpr int NP = 64 * T;
 	constexpr int W = 16;
 	/* the builds whose groups away from the segment's ends take a copy of their own (fast_voice: SPLIT) -- the ones BASELINE's
 	 * configurations and the FM bank run in; each costs its compile time and code size twice */
-	constexpr bool SPLIT = !CUB && ((SCAN == 0 && T == 8 && (FK_SPLIT_MASK & 1)) || (SCAN == 0 && T == 10 && (FK_SPLIT_MASK & 2)) ||
-	                                (SCAN == 0 && T == 12 && (FK_SPLIT_MASK & 4)) || (SCAN == 2 && T == 8 && (FK_SPLIT_MASK & 8)));
+	constexpr int SPLIT = INNER ? 2 : (!CUB && ((SCAN == 0 && T == 8 && (FK_SPLIT_MASK & 1)) || (SCAN == 0 && T == 10 && (FK_SPLIT_MASK & 2)) ||
+	                                (SCAN == 0 && T == 12 && (FK_SPLIT_MASK & 4)) || (SCAN == 2 && T == 8 && (FK_SPLIT_MASK & 8)))) ? 1 : 0;
 	extern __shared__ __align__(16) unsigned char lds[];
 	const int tid = threadIdx.x;
 	const int w = (int)uni((uint32_t)tid >> 6);
@@ -599,7 +620,7 @@ __global__ void FK_ATTR fast_kernel(FastParams P) {
  * narrow tables). */
 __global__ void __launch_bounds__(1024, 1) duo_kernel(FastParams P, FastParams Q) {
 	constexpr int T = 8, NP = 64 * T, W = 16;
-	constexpr bool SPLIT8 = (FK_SPLIT_MASK & 8) != 0, SPLIT1 = (FK_SPLIT_MASK & 1) != 0;
+	constexpr int SPLIT8 = (FK_SPLIT_MASK & 8) ? 1 : 0, SPLIT1 = (FK_SPLIT_MASK & 1) ? 1 : 0;
 	extern __shared__ __align__(16) unsigned char lds[];
 	const int tid = threadIdx.x;
 	const int w = (int)uni((uint32_t)tid >> 6);
