@@ -66,7 +66,9 @@ def profile_traffic(workload, kernel_prefix):
                 continue
             if pmc.get("workload", {}).get("name") != workload:
                 continue
-            k = [v for n, v in pmc["kernels"].items() if kernel_prefix in n]
+            # (the dominant launch of the prefix: config 3's step has two of fast_kernel<12, ...> since round 6, edge groups and the rest)
+            k = sorted((v for n, v in pmc["kernels"].items() if kernel_prefix in n),
+                       key=lambda v: -v.get("hbm_bytes_per_launch_corrected", 0.0))
             # every kernel of a step is launched once per step (one segment per step): their sum is the step's HBM bytes
             step_bytes = sum(v.get("hbm_bytes_per_launch_corrected", 0.0) for v in pmc["kernels"].values())
             best = (k[0]["hbm_bytes_per_launch_corrected"], "profiles/" + f, k[0].get("valu"), step_bytes)
@@ -337,7 +339,7 @@ class Ranks:
 
 def dropin_rate(sa, args):
     """Config 3's 10 s through sau_create_Generator / sauGenerator_run as the reference host drives them (saugns.c:589-618:
-    11289-frame calls into a host buffer), creation to the last frame, best of five -- host copies and PCIe included. The loop
+    11289-frame calls into a host buffer), creation to the last frame, best of twelve -- host copies and PCIe included. The loop
     is the C host's: the three entry points called through pre-bound ctypes handles (a numpy `.ctypes.data` and a wrapper
     object per call cost 0.3 ms of the 3 ms in rounds 3-5's figure, which a C host does not pay)."""
     import ctypes as C
@@ -350,7 +352,7 @@ def dropin_rate(sa, args):
     bufp, got = C.c_void_p(buf.ctypes.data), C.c_size_t()
     gotp = C.byref(got)
     best = None
-    for _ in range(5):
+    for _ in range(12):
         t0 = time.perf_counter()
         g = create(prg.ptr, 44100)
         if not g:
@@ -373,7 +375,7 @@ def dropin_rate(sa, args):
                                 "and the wait for its PCM); the other calls (copies out of the read-ahead buffers, the waits for the "
                                 "later runs); sau_destroy_Generator"},
             "what": "sau_create_Generator -> sauGenerator_run in 11289-frame calls into host memory -> sau_destroy_Generator, "
-                    "the script's whole 10 s, best of 5"}
+                    "the script's whole 10 s, best of 12"}
 
 
 def run_bank(args, R, sa, tabs, name, steps=20, warmup=2):
@@ -540,8 +542,10 @@ def run_config3(args, R, sa, tabs):
                      "unit": "SIMD-cycles per launch (vector instructions by class x measured issue cost, against 1024 SIMDs x launch cycles)",
                      "frac": valu_frac, "traffic": traffic, "traffic_source": source,
                      "valu": valu,
-                     "kernel": "fast_kernel<12, 0, false, true> (closed-form build, 12 rows per pass, wide table blocks in LDS; since round 5 tasks from "
-                               "one queue per XCD, and the launch mixes about three quarters of the output frames itself -- DESIGN.md 4.1)",
+                     "kernel": "fast_kernel<12, 0, false, true, false, true> (closed-form build, 12 rows per pass, wide table blocks in LDS: the row groups "
+                               "away from the segment's ends, in the form without in-segment masks; tasks from one queue per XCD, and the launch mixes "
+                               "about three quarters of the output frames itself -- DESIGN.md 4.1; avg_launch_ms also holds the 25 us launch of the "
+                               "plain build that renders every voice's first and last group ahead of it)",
                      "avg_launch_ms": launch_s * 1e3, "launches": tm["segments"],
                      # SURVEY 8d's convention: every operator's block output priced as one f32 write + one f32 read in HBM. This
                      # kernel keeps those blocks in LDS -- HBM carries the voice rows only (`traffic`, about an eighth) -- so this
@@ -995,7 +999,7 @@ def main():
                 others[name] = o
         if not test_backend():  # (the CPU plan executor of the rank-logic tests would take minutes over these)
             for name in ("fm", "config2"):
-                o = run_bank(args, R, sa, tabs, name, steps=10, warmup=2)
+                o = run_bank(args, R, sa, tabs, name, steps=40, warmup=5)  # (0.3-3 ms steps: ten of them were a sample of 3 ms)
                 if o is not None:
                     o["roofline"]["kernel_source_sha"] = kernel_source_hash()
                     others[name] = o

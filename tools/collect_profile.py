@@ -34,9 +34,10 @@ CLASSES = ("ADD_F64", "MUL_F64", "FMA_F64", "TRANS_F64", "ADD_F32", "MUL_F32", "
 # v_readlane / v_writelane 4.25, v_cmp 4.25, v_cndmask on a scalar mask 4.25.
 OTHER_PRICES = {"move (v_mov_b32/b64)": 2.3, "DPP move (v_mov_b32_dpp)": 4.4, "lane read/write (v_readlane, v_writelane)": 4.25,
                 "compare": 4.25, "select (v_cndmask)": 4.25, "other vector": 4.25}
-CENSUS_OF = {"fast_kernel<12, 0, false, true, false>": "profiles/census/r06_config3_census.json",
-             "fast_kernel<8, 2, false, true, false>": "profiles/census/r06_fmbank_census.json",
-             "fast_kernel<8, 2, false, false, false>": "profiles/census/r06_lookback_census.json",
+CENSUS_OF = {"fast_kernel<12, 0, false, true, false, true>": "profiles/census/r06_config3_census.json",
+             "fast_kernel<12, 0, false, true, false, false>": "profiles/census/r06_config3_census.json",  # (the launch of the edge groups: the same code with the masks)
+             "fast_kernel<8, 2, false, true, false, false>": "profiles/census/r06_fmbank_census.json",
+             "fast_kernel<8, 2, false, false, false, false>": "profiles/census/r06_lookback_census.json",
              "duo_kernel": "profiles/census/r06_lookback_census.json"}  # (its look-back waves' code; the closed-form waves' is fast_kernel<8, 0>'s)
 
 
@@ -177,6 +178,6 @@ if os.path.exists(src):
                "note": "1024 voices x 4 operators with carrier FM, then 1024 x 2 with a carrier glide; 44100-frame steps; "
                        "averages per launch over both", "kernels": fm},
               open(f"profiles/{name}_fm_pmc_summary.json", "w"), indent=1)
-fk = [v for n, v in out["kernels"].items() if "fast_kernel" in n][0]
+fk = max((v for n, v in out["kernels"].items() if "fast_kernel" in n), key=lambda v: v.get("GRBM_GUI_ACTIVE", 0))  # (the dominant launch)
 rows = bench["config"]["operators"] * frames_per_step / 60  # 64-lane rows incl. lead-in, per launch
 print({a: (round(b / rows, 2) if isinstance(b, float) and b > 1e6 else b) for a, b in fk.items()})
