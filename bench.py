@@ -655,16 +655,57 @@ def run_config4(args, R, sa, tabs, steps=None, warmup=None):
         batch.close()
         return n, outs
 
-    for _ in range(warmup):
-        step(False)
+    # The timed steps are pipelined two deep, as a host that renders batch after batch would drive them: step n + 1's generators
+    # are created and its engine runs issued (host work: 64 programs' conversion, their t = 0 events, plans, uploads -- 0.2-0.3 ms)
+    # while the device renders step n; a step's batch is synchronised with and destroyed once the next one is under way. Until
+    # round 6 every step ended with a synchronisation and the device idled through the next one's set-up. Both sides of the timed
+    # region are synchronised as ever. Two batches live at a time: the warm-up runs two steps at least, so that the pools hold
+    # both sets of buffers before the clock starts.
+    def issue(timing=None):
+        batch = new_batch(sa, prgs)
+        batch.set_call_len(11289)
+        if timing is not None:
+            batch.set_timing(2)
+        alive, n = True, 0
+        while alive:
+            _pcm, more, lens = batch.run(run_len, stereo=False, fetch=False)
+            n += sum(lens)
+            alive = any(more) and not args.c4_frames
+        return batch, n
+
+    def finish(batch, timing=None):
+        batch.sync()
+        if timing is not None:
+            t = batch.timing_ex()
+            for k in timing:
+                timing[k] += t[k]
+        batch.close()
+
+    def pipelined(count, timing=None):
+        frames, pending = 0, None
+        for _ in range(count):
+            batch, n = issue(timing)
+            frames += n
+            if pending is not None:
+                finish(pending, timing)
+            pending = batch
+        if pending is not None:
+            finish(pending, timing)
+        return frames
+
+    warmup_done = max(warmup, 2) if not test_backend() else warmup
+    pipelined(warmup_done)
     R.barrier()
-    tm = {"fast_ms": 0.0, "block_ms": 0.0, "mix_ms": 0.0, "aux_ms": 0.0, "segments": 0}
     t0 = time.perf_counter()
-    frames_mine = 0
-    for _ in range(steps):
-        frames_mine += step(False, tm)[0]
+    frames_mine = pipelined(steps)
     R.barrier()
     dt = R.max(time.perf_counter() - t0)
+    # the kernels' own times (events around every launch) from `steps_timed` steps of their own, one at a time: with two batches in
+    # flight a launch's events also span its wait for the other batch's workgroups
+    tm = {"fast_ms": 0.0, "block_ms": 0.0, "mix_ms": 0.0, "aux_ms": 0.0, "segments": 0}
+    steps_timed = min(steps, 2)
+    for _ in range(steps_timed):
+        pipelined(1, tm)
     # after the timed region: every render against the reference's SHA-256, then the ranks' report
     n, outs = step(True)
     if args.c4_frames:
@@ -684,7 +725,7 @@ def run_config4(args, R, sa, tabs, steps=None, warmup=None):
         return None
     # 7 operators per render (2 voices): 8 B per operator-sample + 2 B per output frame
     alg = (7 * 8 + 2) * frames_each * len(prgs)
-    kern_s = tm["fast_ms"] / 1e3 / steps
+    kern_s = tm["fast_ms"] / 1e3 / max(1, steps_timed)
     achieved = alg / kern_s / 1e9 if kern_s > 0 else 0.0
     full4 = not args.c4_frames and args.renders == 64 and not args.c4_run
     traffic4, source4 = profile_step_traffic("config4") if full4 else (None, None)
@@ -693,12 +734,13 @@ def run_config4(args, R, sa, tabs, steps=None, warmup=None):
     out = {
         "metric": "mono samples/sec, examples/rainy_thunder.sau x 512 renders sharded over GPUs",
         "value": tally[0] / dt, "unit": "mixed mono int16 frames/s summed over renders",
-        "n_gpus": R.world, "steps": steps, "warmup": warmup,
+        "n_gpus": R.world, "steps": steps, "warmup": warmup_done,
         "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32 (u64 cycle counters, u32 phase)", "data": "synthetic",
         "config": {"workload": f"BASELINE config 4: rainy_thunder.sau with seed=k, {len(prgs)} renders per GPU "
                                f"(seeds shard_range({total}, rank, {R.world})), 60 s at 44.1 kHz mono each; one step = "
-                               f"the rank's renders from generator creation to the last frame",
+                               f"the rank's renders from generator creation to the last frame; steps pipelined two deep (the next step's "
+                               f"generators are set up while the device renders this one's)",
                    "renders_all_ranks": tally[3], "frames_all_ranks": tally[0],
                    "pcm_checksum_all_ranks": tally[2],
                    "verified": (f"SHA-256 of every one of the {total} renders equals the compiled reference's "
@@ -712,8 +754,9 @@ def run_config4(args, R, sa, tabs, steps=None, warmup=None):
                      "kernel": "duo_kernel: the closed-form voices (as fast_kernel<8, 0>) and the look-back voices (as fast_kernel<8, 2>) of "
                                "analyze_kernel's two lists in one launch, a workgroup's waves split between them by the lists' lengths",
                      "kernel_ms_per_step": kern_s * 1e3, "other_kernels_ms_per_step":
-                     {k: tm[k] / steps for k in ("block_ms", "mix_ms", "aux_ms")},
-                     "segments_per_step": tm["segments"] / steps,
+                     {k: tm[k] / max(1, steps_timed) for k in ("block_ms", "mix_ms", "aux_ms")},
+                     "segments_per_step": tm["segments"] / max(1, steps_timed),
+                     "kernel_times_from": f"{steps_timed} steps of their own after the timed region, one batch at a time",
                      "note": "64 renders per GPU are 128 voices; one engine run (one segment) per render since r03"},
         "valu_frac": (v4 or {}).get("frac"), "hbm_real_frac": (traffic4 / (dt / steps) / 8e12) if traffic4 else None,
     }
