@@ -63,6 +63,10 @@ SAU_HD int64_t rint64(float x) {
 	/* out of range (and NaN) the reference's host gives the x86 "integer indefinite", 0x8000...0 (cvtss2si), where
 	 * the device's conversion saturates: frequency-scaled PM of thousands of cycles under a frequency of gigahertz
 	 * gets there (found by the sweep with extreme parameters, round 3) */
+	/* (gfx950 has no f32 -> i64 conversion: the compiler's costs eleven vector instructions. Phase increments are almost always
+	 * below 2^31 in magnitude -- a frequency below the sample rate -- and there v_rndne_f32 + v_cvt_i32_f32 + a sign extension do:
+	 * a float of that size rounds to an integer an int32 holds. One wave-uniform test picks the form.) */
+	if (__all(fabsf(x) < 0x1p31f)) return (long long)(int32_t)rintf(x);
 	const long long v = __float2ll_rn(x);
 	return fabsf(x) < 0x1p63f ? v : (long long)0x8000000000000000ull;
 #else
@@ -925,8 +929,11 @@ SAU_HD float ssgauss_dist4(float x) {
 SAU_HD float franssgauss32(uint32_t n) {
 	int32_t s0 = (int32_t)ranfast32(n);
 	int32_t s1 = (int32_t)mcg32((uint32_t)s0);
-	float a = (float)((double)s0 * 0x1p-32);
-	float b = (float)((double)s1 * 0x1p-32);
+	/* (the reference's `float a = s0 * 0x1p-32;` multiplies in double and rounds once: the nearest float to s0 x 2^-32. So is
+	 * (float)s0 x 2^-32 -- the conversion rounds the same 32-bit integer to the same 24 bits, and the power of two moves only the
+	 * exponent, far from the denormals: identical bits, without the two f64 conversions and the f64 scaling, 4 cycles of issue each) */
+	float a = (float)s0 * 0x1p-32f;
+	float b = (float)s1 * 0x1p-32f;
 	float c = ssgauss_dist4(soft_sqrtm2logp1(a));
 	b = c * sinpi_d5f(b);
 	return b;

@@ -131,6 +131,8 @@ def hooks(sa):
         L.sauAmd_kat_line_device.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.sauAmd_kat_div_device.restype = C.c_longlong
         L.sauAmd_kat_div_device.argtypes = [C.c_uint32, C.c_int, C.c_void_p]
+        L.sauAmd_kat_rint64_device.restype = C.c_longlong
+        L.sauAmd_kat_rint64_device.argtypes = [C.c_int, C.c_void_p]
         L.sauAmd_kat_scan64_device.restype = C.c_int
         L.sauAmd_kat_scan64_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
     return L

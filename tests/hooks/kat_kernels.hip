@@ -103,3 +103,47 @@ bool kat_scan64(const unsigned long long *in, unsigned long long *scan, unsigned
 	if (d_sum) (void)hipFree(d_sum);
 	return ok;
 }
+
+/* rint64() (sau_dev_math.h: llrintf with the host's out-of-range answer) for EVERY f32 bit pattern against an independent
+ * formulation -- the value rounded in f64 and taken apart by hand -- in two lane orders: consecutive patterns (a wave's lanes
+ * alike in magnitude: the wave-uniform short form below 2^31, or the long form) and scattered ones (both forms' lanes in one
+ * wave). franssgauss32()'s scaled conversions against the reference's double form, for every 32-bit integer, ride along. */
+__device__ __forceinline__ long long kat_rint64_ref(float x) {
+	if (!(fabsf(x) < 0x1p63f)) return (long long)0x8000000000000000ull; /* (NaN too) */
+	const double d = rint((double)x); /* round-half-even, exact: an f32 has 24 significant bits */
+	const double a = fabs(d);
+	const double hi = floor(a * 0x1p-32);
+	const unsigned long long mag = ((unsigned long long)(uint32_t)hi << 32) | (unsigned long long)(uint32_t)(a - hi * 0x1p32);
+	return d < 0 ? (long long)(0ull - mag) : (long long)mag;
+}
+__global__ void kat_rint64_kernel(int scattered, unsigned long long *mismatches, uint32_t *first_bad) {
+	unsigned long long bad = 0;
+	const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, n = gridDim.x * blockDim.x; /* n divides 2^32 */
+	for (uint32_t k = 0; k < (uint32_t)(0x100000000ull / n); ++k) {
+		uint32_t bits = k * n + tid;
+		if (scattered) bits *= 0x9e3779b1u; /* (odd: a permutation of the patterns; neighbouring lanes far apart) */
+		const float x = bits_f(bits);
+		if (rint64(x) != kat_rint64_ref(x)) { ++bad; atomicMin(first_bad, bits); }
+		const int32_t s0 = (int32_t)bits;
+		if (f_bits((float)s0 * 0x1p-32f) != f_bits((float)((double)s0 * 0x1p-32))) { ++bad; atomicMin(first_bad, bits); }
+	}
+	if (bad) atomicAdd(mismatches, bad);
+}
+bool kat_rint64(int scattered, unsigned long long *mismatches, uint32_t *first_bad) {
+	unsigned long long *d_m = nullptr;
+	uint32_t *d_f = nullptr;
+	bool ok = hipMalloc((void **)&d_m, sizeof *d_m) == hipSuccess && hipMalloc((void **)&d_f, sizeof *d_f) == hipSuccess;
+	if (ok) {
+		const uint32_t none = 0xffffffffu;
+		ok = hipMemset(d_m, 0, sizeof *d_m) == hipSuccess && hipMemcpy(d_f, &none, sizeof none, hipMemcpyHostToDevice) == hipSuccess;
+	}
+	if (ok) {
+		hipLaunchKernelGGL(kat_rint64_kernel, dim3(4096), dim3(256), 0, 0, scattered, d_m, d_f);
+		ok = hipDeviceSynchronize() == hipSuccess &&
+			hipMemcpy(mismatches, d_m, sizeof *d_m, hipMemcpyDeviceToHost) == hipSuccess &&
+			hipMemcpy(first_bad, d_f, sizeof *d_f, hipMemcpyDeviceToHost) == hipSuccess;
+	}
+	if (d_m) (void)hipFree(d_m);
+	if (d_f) (void)hipFree(d_f);
+	return ok;
+}

@@ -18,6 +18,7 @@
 bool kat_div(float a, int variant, unsigned long long *mismatches, uint32_t *first_bad);
 bool kat_line(const saudev::LineState &st, uint32_t len, const float *mul, float *out, saudev::LineState *st_out);
 bool kat_scan64(const unsigned long long *in, unsigned long long *scan, unsigned long long *sum, uint32_t n_waves);
+bool kat_rint64(int scattered, unsigned long long *mismatches, uint32_t *first_bad);
 #endif
 
 HOOK sauGenerator *sauAmd_create_Generator_with_backend(const sauProgram *prg, uint32_t srate, void *backend) {
@@ -63,6 +64,14 @@ HOOK long long sauAmd_kat_div_device(uint32_t wave, int variant, uint32_t *first
 	return (long long)m;
 }
 /* in[64 * n_waves] -> scan[64 * n_waves] (inclusive per wave), sum[n_waves]; 0 on a device error */
+/* rint64() and franssgauss32()'s conversions over every 32-bit pattern (kat_kernels.hip): mismatches, or -1 */
+HOOK long long sauAmd_kat_rint64_device(int scattered, uint32_t *first_bad) {
+	unsigned long long m = 0;
+	uint32_t fb = 0;
+	if (!kat_rint64(scattered, &m, &fb)) return -1;
+	if (first_bad) *first_bad = fb;
+	return (long long)m;
+}
 HOOK int sauAmd_kat_scan64_device(const unsigned long long *in, unsigned long long *scan, unsigned long long *sum, uint32_t n_waves) {
 	return kat_scan64(in, scan, sum, n_waves) ? 1 : 0;
 }

@@ -166,6 +166,18 @@ def test_differentiator_division_exhaustive(sa, hooks):
         assert fn(wave, 1, C.byref(first)) > 0
 
 
+@pytest.mark.parametrize("scattered", [0, 1])
+def test_rint64_and_the_gauss_noise_conversions_on_every_bit_pattern(hooks, scattered):
+    """rint64() (llrintf kept as int64, sau/math.h:63-64: phase increments of R oscillators and swept frequencies) has a short form
+    for waves whose values are all below 2^31 (round 6) beside the compiler's eleven-instruction conversion, and franssgauss32()
+    (noise.h:90-98) scales its integers in f32 where the reference multiplies in double and rounds: both against independent
+    forms on the device, for all 2^32 bit patterns, with a wave's lanes alike in magnitude and with them scattered."""
+    import ctypes as C
+    fb = C.c_uint32(0)
+    bad = hooks.sauAmd_kat_rint64_device(scattered, C.byref(fb))
+    assert bad == 0, (bad, hex(fb.value))
+
+
 def test_wave_scan_of_64_bit_values_counts_its_carries(hooks):
     """k_wave_scan.h: the inclusive 64-bit scan (two 32-bit DPP scans + the wraps of the low words counted from one compare) and the
     64-bit sum, against numpy's wrapping cumsum -- positive and negative increments (high words 0 and ~0: rasg.h:154-155 with a
