@@ -1013,7 +1013,7 @@ def main():
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args.gpus)  # before anything touches the GPU
-    defaults = {"config3": (100, 3), "config4": (5, 1), "config5": (5, 1), "config2": (20, 2), "fm": (20, 2)}[args.workload]
+    defaults = {"config3": (500, 20), "config4": (5, 1), "config5": (5, 1), "config2": (20, 2), "fm": (20, 2)}[args.workload]
     if args.steps is None:
         args.steps = defaults[0]
     if args.warmup is None:
@@ -1036,7 +1036,7 @@ def main():
         for name, fn in (("config5", run_config5), ("config4", run_config4)):
             if name == "config5" and test_backend():
                 continue  # (4096 feedback voices on the CPU plan executor of the rank-logic tests: minutes)
-            o = fn(args, R, sa, tabs, steps=3, warmup=1)
+            o = fn(args, R, sa, tabs, steps=8 if name == "config4" else 3, warmup=1)  # (config 4: 3.5 ms steps, two deep)
             if o is not None:
                 o["roofline"]["kernel_source_sha"] = kernel_source_hash()
                 others[name] = o

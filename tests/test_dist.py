@@ -174,7 +174,7 @@ def test_bench_gpus_2_default_workload_carries_config4_sharded(seqexec):
     j = _line(_bench(["--gpus", "2", "--voices", "8", "--frames", "4410", "--steps", "1", "--warmup", "0", "--no-cpu",
                       "--force-others", "--renders", "2", "--c4-frames", "11025"], seqexec))
     c4 = j["config4_sharded"]
-    assert c4["n_gpus"] == 2 and c4["renders_all_ranks"] == 4 and c4["frames_all_ranks"] == 3 * 4 * 11025
+    assert c4["n_gpus"] == 2 and c4["renders_all_ranks"] == 4 and c4["frames_all_ranks"] == 8 * 4 * 11025  # (eight timed steps of the side workload)
     assert c4["scaling"] == "weak" and c4["value"] > 0
     assert j["other_workloads"]["config4"]["config"]["renders_all_ranks"] == 4
     one = _line(_bench(["--gpus", "1", "--voices", "8", "--frames", "4410", "--steps", "1", "--warmup", "0", "--no-cpu",
