@@ -675,7 +675,7 @@ __global__ void __launch_bounds__(RCHAIN_THREADS) rchain_kernel(FastParams P) {
 	} else {
 		rp = ras_params(0, 0, 0, 0, 0);
 	}
-	auto chain = [&](const RasParams &rq) {
+	auto chain = [&](const RasParams &rq) __attribute__((always_inline)) {
 		__syncthreads(); /* batch 0's inputs */
 		for (uint32_t k = 0; k < nb; ++k) {
 			const uint32_t *cy = in_cyc + (k & 1) * RCHAIN_BATCH * 64;
@@ -718,8 +718,19 @@ __global__ void __launch_bounds__(RCHAIN_THREADS) rchain_kernel(FastParams P) {
 		const uint32_t v0 = (uint32_t)__builtin_amdgcn_readlane((int)rp.level, first), l0 = (uint32_t)__builtin_amdgcn_readlane((int)rp.line, first);
 		if (!__any(n != 0 && (rp.func != f0 || rp.flags != g0 || rp.level != v0 || rp.line != l0))) {
 			RasParams ru = rp;
-			ru.func = f0; ru.flags = g0; ru.level = v0; ru.line = l0;
-			chain(ru);
+			ru.flags = g0; ru.level = v0; ru.line = l0;
+			/* ... and a copy of the loop per function (round 6: the loop is inlined with the function a constant, so that ras_ends'
+			 * dispatch -- four to six taken scalar branches a sample, some twenty cycles each for a wave alone on its SIMD --
+			 * is compiled out; flags and line shape stay scalar branches) */
+			switch (f0) {
+			case RF_URAND: ru.func = RF_URAND; chain(ru); break;
+			case RF_GAUSS: ru.func = RF_GAUSS; chain(ru); break;
+			case RF_BIN: ru.func = RF_BIN; chain(ru); break;
+			case RF_TERN: ru.func = RF_TERN; chain(ru); break;
+			case RF_FIXED: ru.func = RF_FIXED; chain(ru); break;
+			case RF_ADDREC: ru.func = RF_ADDREC; chain(ru); break;
+			default: ru.func = f0; chain(ru); break;
+			}
 		} else {
 			chain(rp);
 		}
