@@ -106,6 +106,32 @@ def test_the_same_pcm_whoever_mixes_and_however_tasks_are_dealt(sa, oracle, capf
     assert (render() == want).all()
 
 
+@pytest.mark.parametrize("stereo", [False, True])
+def test_edge_groups_and_inner_groups_in_launches_of_their_own(sa, oracle, report, capfd, monkeypatch, stereo):
+    """The 12-row closed-form build renders a bank in two launches since round 6 -- every voice's first and last row group by the plain
+    build, the groups between by the build that holds only the form without in-segment masks (k_fast_voice.h: INNER) -- or in one
+    (SAU_AMD_NO_INNER): the same PCM, the oracle's, for voices that end at different frames (their last groups differ), in one run and
+    in runs that cut the voices' groups elsewhere."""
+    from saugns_amd import voicebank as vb
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
+    voices = vb.config3_voices(80, 5)
+    for i, v in enumerate(voices):
+        v.time_ms = 5000 - 37 * (i % 23)  # (different last groups)
+        v.pan = vb.Line(vb._num(".2f", ((i * 29) % 100) / 100.0))
+    prg = vb.build_program(voices)
+    for chunk in (220500, 70001):
+        want = oracle.oracle_render(prg.ptr, 44100, stereo, chunk=chunk)
+        for no_inner in (False, True):
+            if no_inner:
+                monkeypatch.setenv("SAU_AMD_NO_INNER", "1")
+            else:
+                monkeypatch.delenv("SAU_AMD_NO_INNER", raising=False)
+            batch = sa.Batch([prg], 44100)
+            got = batch.render(stereo=stereo, chunk=chunk)[0]
+            batch.close()
+            assert len(got) == len(want) and (np.asarray(got) == want).all(), (chunk, no_inner)
+
+
 def test_step_after_step_of_config3(sa, monkeypatch):
     """Six consecutive 441000-frame runs of a 60 s config-3 bank (the control words and the voice rows are reused from run to
     run): the launch that mixes and the mixer alone give the same PCM, run by run."""
