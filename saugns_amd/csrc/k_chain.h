@@ -542,7 +542,42 @@ __global__ void __launch_bounds__(192) chain_kernel(FastParams P) {
  * mixed bank ran at its slowest feeder's pace. Now the RATE feeder has the frequency line, the counter and its split, the AMOUNT
  * feeder the amount line and the drain; each is shorter than the chain wave's batch. */
 constexpr uint32_t RCHAIN_BATCH = 32;
-constexpr size_t RCHAIN_LDS_BYTES = (size_t)(3 + 1) * 2 * RCHAIN_BATCH * 64 * 4; /* cycle, phase, amount in; samples out: two batches each */
+/* A line's values over a batch of frames for a feeder wave, the shape a constant in the loop: fast_line_value() dispatches on the
+ * shape per value -- three to five taken scalar branches, some twenty cycles each for a wave alone on its SIMD, and one value's
+ * arithmetic a dependent chain -- where a loop per shape issues the batch's independent values back to back. UNI: the shape is the
+ * wave's (chains of one kind); else the lanes' own, value by value as before. */
+template <bool UNI>
+__device__ __forceinline__ void fast_line_batch(const FastLine &fl, const uint32_t t0, float (&v)[RCHAIN_BATCH]) {
+	if (UNI) { /* (the sweeps' lengths are the lanes' own: the whole batch inside every lane's sweep, or the general form below) */
+		auto run = [&](auto TYPE) __attribute__((always_inline)) {
+			Sweep sw = fl.sw;
+			sw.type = decltype(TYPE)::value;
+#pragma unroll
+			for (uint32_t j = 0; j < RCHAIN_BATCH; ++j) v[j] = sweep_value_inl<true>(sw, t0 + j);
+		};
+		if (__all(t0 + RCHAIN_BATCH <= fl.goal_len)) {
+			switch (fl.sw.type) {
+			case LN_cos: run(std::integral_constant<uint32_t, LN_cos>{}); return;
+			case LN_lin: run(std::integral_constant<uint32_t, LN_lin>{}); return;
+			case LN_sah: run(std::integral_constant<uint32_t, LN_sah>{}); return;
+			case LN_xpe: run(std::integral_constant<uint32_t, LN_xpe>{}); return;
+			case LN_lge: run(std::integral_constant<uint32_t, LN_lge>{}); return;
+			case LN_sqe: run(std::integral_constant<uint32_t, LN_sqe>{}); return;
+			case LN_cub: run(std::integral_constant<uint32_t, LN_cub>{}); return;
+			case LN_smo: run(std::integral_constant<uint32_t, LN_smo>{}); return;
+			default: break; /* (the noise shapes, and what else there may be: value by value) */
+			}
+		}
+	}
+	if (__all(t0 >= fl.goal_len)) { /* the line holds */
+#pragma unroll
+		for (uint32_t j = 0; j < RCHAIN_BATCH; ++j) v[j] = fl.hold;
+		return;
+	}
+#pragma unroll 4
+	for (uint32_t j = 0; j < RCHAIN_BATCH; ++j) v[j] = fast_line_value(fl, (int)(t0 + j));
+}
+constexpr size_t RCHAIN_LDS_BYTES = (size_t)(3 + 1 + 2) * 2 * RCHAIN_BATCH * 64 * 4; /* cycle, phase, amount in; samples out; the counter's increments (64 bits): two batches each */
 constexpr uint32_t RCHAIN_THREADS = 192; /* the chain wave, the rate feeder, the amount feeder */
 __global__ void __launch_bounds__(RCHAIN_THREADS) rchain_kernel(FastParams P) {
 	if (P.pass_flags[FAST_EARLY_FLAG] == 0) return;
@@ -551,6 +586,7 @@ __global__ void __launch_bounds__(RCHAIN_THREADS) rchain_kernel(FastParams P) {
 	float *const in_ph = (float *)(in_cyc + 2 * RCHAIN_BATCH * 64);
 	float *const in_am = in_ph + 2 * RCHAIN_BATCH * 64;
 	float *const out_s = in_am + 2 * RCHAIN_BATCH * 64;
+	uint32_t *const in_inc = (uint32_t *)(out_s + 2 * RCHAIN_BATCH * 64); /* [2][RCHAIN_BATCH][2][64]: low words, high words */
 	const int l = threadIdx.x & 63;
 	const uint32_t role = uni((uint32_t)threadIdx.x >> 6); /* 0 the chain wave, 1 the rate feeder, 2 the amount feeder */
 	const bool feeder = role != 0;
@@ -579,32 +615,41 @@ __global__ void __launch_bounds__(RCHAIN_THREADS) rchain_kernel(FastParams P) {
 		 * like voices, one voice -- the wave's (two copies of the loop: in the second every value's shape dispatch is a scalar
 		 * branch) */
 		if (role == 1) {
-			/* the rate feeder: frequency line -> increment -> counter (post-increment) -> cycle and phase */
-			auto feed = [&](const FastLine &fl, const uint32_t lflags) {
-				auto fill = [&](uint32_t k) { /* the inputs of batch k */
-					uint32_t *cy = in_cyc + (k & 1) * RCHAIN_BATCH * 64;
-					float *ph = in_ph + (k & 1) * RCHAIN_BATCH * 64;
+			/* the rate feeder: frequency line -> the counter's increment per frame, TWO batches ahead of the chain wave (round 6, later:
+			 * summing the counter and splitting it went to the amount feeder, which had the time -- with a swept rate this wave's
+			 * 330-340 ns per frame were the workgroup's pace, the recurrence itself 230-250) */
+			auto feed = [&](const FastLine &fl, const uint32_t lflags, auto UNI_) {
+				constexpr bool UNI = decltype(UNI_)::value;
+				auto fill = [&](uint32_t k) { /* the increments of batch k */
+					uint32_t *ic = in_inc + (k & 1) * RCHAIN_BATCH * 128;
 					const uint32_t t0 = k * RCHAIN_BATCH;
 					if (t0 >= n) return;
+					if (UNI && (lflags & CL_FCONST)) { /* (the wave's rates are fixed) */
+#pragma unroll
+						for (uint32_t j = 0; j < RCHAIN_BATCH; ++j) { ic[j * 128 + l] = (uint32_t)inc_c; ic[j * 128 + 64 + l] = (uint32_t)(inc_c >> 32); }
+						return;
+					}
+					float v[RCHAIN_BATCH]; /* (indexed by the loop below: in scratch memory, read back off the recurrence's path; the loops
+					                        * unrolled whole to keep it in registers ran the feeders at 640 ns per frame) */
+					fast_line_batch<UNI>(fl, t0, v);
 #pragma unroll 4
 					for (uint32_t j = 0; j < RCHAIN_BATCH; ++j) {
 						const uint32_t t = t0 + j;
 						unsigned long long inc = inc_c;
 						if (!(lflags & CL_FCONST)) {
-							float v = fast_line_value(fl, (int)t);
-							if (lflags & (t < fl.goal_len ? CL_MUL_GOAL : CL_MUL_HOLD)) v *= cd.mulc;
-							inc = (unsigned long long)rint64(rcoeff * v);
+							float x = v[j];
+							if (lflags & (t < fl.goal_len ? CL_MUL_GOAL : CL_MUL_HOLD)) x *= cd.mulc;
+							inc = (unsigned long long)rint64(rcoeff * x);
 						}
-						uint32_t cyc; float phf;
-						ras_split(cp, cyc, phf); /* rasg.h:184-186, post-increment */
-						if (t < n) cp += inc;
-						cy[j * 64 + l] = cyc; ph[j * 64 + l] = phf;
+						ic[j * 128 + l] = (uint32_t)inc; ic[j * 128 + 64 + l] = (uint32_t)(inc >> 32);
 					}
 				};
 				fill(0);
 				__syncthreads();
+				if (nb > 1) fill(1);
+				__syncthreads();
 				for (uint32_t k = 0; k < nb; ++k) {
-					if (k + 1 < nb) fill(k + 1);
+					if (k + 2 < nb) fill(k + 2);
 					__syncthreads();
 				}
 			};
@@ -615,19 +660,35 @@ __global__ void __launch_bounds__(RCHAIN_THREADS) rchain_kernel(FastParams P) {
 			if (!__any(n != 0 && (cd.fl.sw.type != ft0 || cd.lflags != lf0))) {
 				FastLine fl = cd.fl;
 				fl.sw.type = ft0;
-				feed(fl, lf0);
+				feed(fl, lf0, std::true_type{});
 			} else {
-				feed(cd.fl, cd.lflags);
+				feed(cd.fl, cd.lflags, std::false_type{});
 			}
+			return;
 		} else {
-			/* the amount feeder: amount line; the samples of the batch before to the chain's row */
-			auto feed = [&](const FastLine &pl) {
+			/* the amount feeder: amount line; the counter summed over the rate feeder's increments (post-increment, rasg.h:184-186) and
+			 * split into cycle and phase; the samples of the batch before to the chain's row */
+			auto feed = [&](const FastLine &pl, auto UNI_) {
+				constexpr bool UNI = decltype(UNI_)::value;
 				auto fill = [&](uint32_t k) {
 					float *am = in_am + (k & 1) * RCHAIN_BATCH * 64;
+					uint32_t *cy = in_cyc + (k & 1) * RCHAIN_BATCH * 64;
+					float *ph = in_ph + (k & 1) * RCHAIN_BATCH * 64;
+					const uint32_t *ic = in_inc + (k & 1) * RCHAIN_BATCH * 128;
 					const uint32_t t0 = k * RCHAIN_BATCH;
 					if (t0 >= n) return;
+					float v[RCHAIN_BATCH];
+					fast_line_batch<UNI>(pl, t0, v);
 #pragma unroll 4
-					for (uint32_t j = 0; j < RCHAIN_BATCH; ++j) am[j * 64 + l] = fast_line_value(pl, (int)(t0 + j));
+					for (uint32_t j = 0; j < RCHAIN_BATCH; ++j) {
+						const uint32_t t = t0 + j;
+						const unsigned long long inc = ((unsigned long long)ic[j * 128 + 64 + l] << 32) | ic[j * 128 + l];
+						uint32_t cyc; float phf;
+						ras_split(cp, cyc, phf);
+						if (t < n) cp += inc;
+						cy[j * 64 + l] = cyc; ph[j * 64 + l] = phf;
+						am[j * 64 + l] = v[j];
+					}
 				};
 				auto drain = [&](uint32_t k) { /* the samples of batch k to the chain's row */
 					const float *os = out_s + (k & 1) * RCHAIN_BATCH * 64;
@@ -641,6 +702,7 @@ __global__ void __launch_bounds__(RCHAIN_THREADS) rchain_kernel(FastParams P) {
 						for (uint32_t j = 0; t0 + j < n; ++j) row[t0 + j] = os[j * 64 + l];
 					}
 				};
+				__syncthreads(); /* the increments of batch 0 */
 				fill(0);
 				__syncthreads();
 				for (uint32_t k = 0; k < nb; ++k) {
@@ -654,11 +716,10 @@ __global__ void __launch_bounds__(RCHAIN_THREADS) rchain_kernel(FastParams P) {
 			if (!__any(n != 0 && cd.pl.sw.type != pt0)) {
 				FastLine pl = cd.pl;
 				pl.sw.type = pt0;
-				feed(pl);
+				feed(pl, std::true_type{});
 			} else {
-				feed(cd.pl);
+				feed(cd.pl, std::false_type{});
 			}
-			return;
 		}
 		if (n) { /* staged: finalize_kernel makes it the operator's state unless the voice's segment is redone */
 			op->st_prev_Is = __longlong_as_double((long long)cp);
@@ -676,6 +737,7 @@ __global__ void __launch_bounds__(RCHAIN_THREADS) rchain_kernel(FastParams P) {
 		rp = ras_params(0, 0, 0, 0, 0);
 	}
 	auto chain = [&](const RasParams &rq) __attribute__((always_inline)) {
+		__syncthreads(); /* (the feeders' first hand-over: batch 0's increments) */
 		__syncthreads(); /* batch 0's inputs */
 		for (uint32_t k = 0; k < nb; ++k) {
 			const uint32_t *cy = in_cyc + (k & 1) * RCHAIN_BATCH * 64;
