@@ -1110,6 +1110,29 @@ SAU_HD void ras_split(uint64_t cp, uint32_t &cycle, float &phase) {
 	phase = (float)(int32_t)ph * 0x1p-31f;
 }
 
+/* The per-sample form of ras_sample() (block false, no loop tail) from segment ends the caller already has: the feedback loop's
+ * chain wave keeps a lane's ends while its cycle stands (rchain_kernel, round 6) -- they are a function of the cycle alone
+ * (rasg.h:299-671), and an oscillator of a few hundred Hz stays in one cycle for a hundred samples and more. */
+SAU_HD float ras_sample_ends(const RasParams &c, float a, float b, float phase) {
+	if (c.flags & RO_PERLIN) {
+		a *= c.perlin_amp * phase;
+		b *= c.perlin_amp * (phase - 1.f);
+	}
+	if (c.flags & RO_HALFSHAPE) { /* (maxss a,b / minss b,a: see ras_sample) */
+		float mx = (a > b ? a : b);
+		float mn = (b < a ? b : a);
+		a = mx; b = mn;
+	}
+	if (c.flags & RO_ZIGZAG) {
+		float t = a; a = b; b = t;
+	}
+	if (c.flags & RO_SQUARE) {
+		a *= fabsf(a);
+		b *= fabsf(b);
+	}
+	return shape_val_inl(c.line, phase, a, b);
+}
+
 /* ---- mixing ----------------------------------------------------------------- */
 
 /* generator.c:384-426 */
