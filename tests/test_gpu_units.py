@@ -166,6 +166,26 @@ def test_differentiator_division_exhaustive(sa, hooks):
         assert fn(wave, 1, C.byref(first)) > 0
 
 
+def test_a_batch_on_a_named_device(sa, oracle):
+    """sauAmd_create_Batch_on (include/saugns_amd.h, round 6): a batch on the HIP device the caller names -- the same PCM as the
+    default batch's and the oracle's on device 0, two of them rendering side by side; a device the process does not have, and a
+    negative one, are refused with a message and NULL, as a constructor of the reference's is (generator.c:191-231)."""
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
+    prg = vb.build_program(vb.config3_voices(8, 1) + [vb.Op("sin", freq=220.0, pm_a=0.6, amp=0.4, time_ms=1000)])
+    want = oracle.oracle_render(prg.ptr, RATE, False, chunk=44100)
+    a = sa.Batch([prg], RATE, device=0)
+    b = sa.Batch([prg], RATE, device=0)
+    got_a = a.render(stereo=False, chunk=44100)[0]
+    got_b = b.render(stereo=False, chunk=44100)[0]
+    a.close(); b.close()
+    assert len(got_a) == len(want) and (np.asarray(got_a) == want).all() and (np.asarray(got_b) == want).all()
+    n = sa.lib().sauAmd_device_count()
+    for bad in (n, -1):
+        with pytest.raises(Exception):
+            sa.Batch([prg], RATE, device=bad)
+        assert sa.last_error()
+
+
 @pytest.mark.parametrize("scattered", [0, 1])
 def test_rint64_and_the_gauss_noise_conversions_on_every_bit_pattern(hooks, scattered):
     """rint64() (llrintf kept as int64, sau/math.h:63-64: phase increments of R oscillators and swept frequencies) has a short form
