@@ -142,3 +142,39 @@ def test_only_one_kind_present(sa, oracle, capfd, monkeypatch):
     got = batch.render(stereo=False, chunk=22050)[0]
     batch.close()
     assert len(got) == len(want) and (np.asarray(got) == want).all()
+
+
+def test_two_batches_in_flight(sa, oracle, monkeypatch):
+    """bench.py's config 4 since round 6: the next batch's generators are created and their runs issued while the device still
+    renders this batch's (two batches in flight, each on a stream of its own; their joint launches take turns through the event
+    chain of hip_backend.hip: SpreadLaunchOrder). Two batches of six small scripts, both issued before either is waited for, five
+    times over; the PCM read from the device afterwards is the oracle's."""
+    import ctypes as C
+    oracle.oracle().ora_set_fastmath_forms(ORACLE_FORMS)
+    monkeypatch.setenv("SAU_AMD_MORE_ROWS", "0")
+    monkeypatch.setenv("SAU_AMD_NO_WIDE_TABS", "1")
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    sets = []
+    for half in range(2):
+        prgs = []
+        for k in range(6):
+            ms = 1500 + 200 * k
+            prgs.append(vb.build_program([_pm_voice(3 * k + half, ms), _r_voice(k + 7 * half, ms) if k % 2 else _fm_voice(2 * k + half, ms),
+                                          _pm_voice(3 * k + 3 + half, ms)]))
+        frames = 44100 * 3
+        want = [oracle.oracle_render(p.ptr, 44100, False, chunk=frames) for p in prgs]
+        sets.append((prgs, want, frames))
+    for rep in range(5):
+        live = []
+        for prgs, want, frames in sets:  # both issued, neither waited for
+            b = sa.Batch(prgs, 44100)
+            b.run(frames, stereo=False, fetch=False)
+            live.append((b, want, frames))
+        for b, want, frames in live:
+            b.sync()
+            for i, w in enumerate(want):
+                got = np.zeros(len(w), np.int16)
+                assert hip.hipMemcpy(got.ctypes.data, b.device_pcm(i), got.nbytes, 2) == 0
+                assert (got == w).all(), (rep, i)
+            b.close()
